@@ -1,0 +1,199 @@
+"""oracle/oracle.py -- ctypes face of the CPU checker.  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(the product path, pygsti_amd/, must never do so; tests/test_layout_rules.py greps for it).
+
+Two back ends with one signature:
+  * "port"      -> oracle/liboracle.so       (our C restatement, mapfill_oracle.c)
+  * "reference" -> oracle/_ref/libgst_ref.so (the reference's own C++ reps + ref_driver.cpp)
+
+Plus `analytic_dprobs`: a small numpy forward/backward analytic Jacobian, the independent check
+SURVEY.md section 8(c) asks for; it is validated against MatrixForwardSimulator golden vectors
+(pygsti/forwardsims/matrixforwardsim.py:1059-1140 computes the same sums over an eval tree).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Plan(C.Structure):
+    _fields_ = [("D", C.c_int32), ("n_rows", C.c_int32), ("cache_size", C.c_int32),
+                ("t_dest", C.c_void_p), ("t_start", C.c_void_p), ("t_cache", C.c_void_p), ("t_rho", C.c_void_p),
+                ("row_ptr", C.c_void_p), ("gate_idx", C.c_void_p),
+                ("eff_ptr", C.c_void_p), ("eff_label", C.c_void_p), ("eff_dest", C.c_void_p)]
+
+
+class _Model(C.Structure):
+    _fields_ = [("nG", C.c_int32), ("nR", C.c_int32), ("nEl", C.c_int32),
+                ("gates", C.c_void_p), ("rhos", C.c_void_p), ("effects", C.c_void_p),
+                ("nP", C.c_int32), ("pkind", C.c_void_p), ("pobj", C.c_void_p), ("pelem", C.c_void_p)]
+
+
+def build(ref=True):
+    """Compile liboracle.so (always) and _ref/libgst_ref.so (when /root/reference is present)."""
+    subprocess.check_call(["make", "-s", "-C", HERE])
+    if ref and os.path.isdir("/root/reference/pygsti/evotypes/densitymx"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "_ref"])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Holds one table-format plan + model (the arrays of a golden fixture or of a host layout)."""
+
+    def __init__(self, tbl, model, kind="port"):
+        """tbl: dict with D, cache_size, t_dest, t_start, t_cache, t_rho, row_ptr, gate_idx,
+        eff_ptr, eff_label, eff_dest, nE.  model: dict with gates, rhos, effects, pkind, pobj, pelem."""
+        path = os.path.join(HERE, "liboracle.so") if kind == "port" else os.path.join(HERE, "_ref", "libgst_ref.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle library %s is not built (run oracle.build())" % path)
+        self.kind = kind
+        self.lib = C.CDLL(path)
+        self.prefix = "oracle_" if kind == "port" else "ref_"
+        i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+        i64 = lambda x: np.ascontiguousarray(x, dtype=np.int64)
+        f64 = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+        self.D = int(tbl["D"])
+        self.nE = int(tbl["nE"])
+        self._keep = dict(
+            t_dest=i32(tbl["t_dest"]), t_start=i32(tbl["t_start"]), t_cache=i32(tbl["t_cache"]),
+            t_rho=i32(tbl["t_rho"]), row_ptr=i64(tbl["row_ptr"]), gate_idx=i32(tbl["gate_idx"]),
+            eff_ptr=i64(tbl["eff_ptr"]), eff_label=i32(tbl["eff_label"]), eff_dest=i32(tbl["eff_dest"]),
+            gates=f64(model["gates"]), rhos=f64(model["rhos"]), effects=f64(model["effects"]),
+            pkind=i32(model["pkind"]), pobj=i32(model["pobj"]), pelem=i32(model["pelem"]))
+        k = self._keep
+        if len(k["gate_idx"]) == 0:
+            k["gate_idx"] = np.zeros(1, np.int32)
+        self.plan = _Plan(self.D, len(k["t_dest"]), int(tbl["cache_size"]),
+                          _ptr(k["t_dest"]), _ptr(k["t_start"]), _ptr(k["t_cache"]), _ptr(k["t_rho"]),
+                          _ptr(k["row_ptr"]), _ptr(k["gate_idx"]),
+                          _ptr(k["eff_ptr"]), _ptr(k["eff_label"]), _ptr(k["eff_dest"]))
+        self.nP = len(k["pkind"])
+        self.model = _Model(k["gates"].shape[0], k["rhos"].shape[0], k["effects"].shape[0],
+                            _ptr(k["gates"]), _ptr(k["rhos"]), _ptr(k["effects"]),
+                            self.nP, _ptr(k["pkind"]), _ptr(k["pobj"]), _ptr(k["pelem"]))
+
+    def set_model(self, gates, rhos, effects):
+        k = self._keep
+        k["gates"][...] = gates; k["rhos"][...] = rhos; k["effects"][...] = effects
+
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def probs(self):
+        out = np.empty(self.nE, np.float64)
+        rc = self._fn("fill_probs")(C.byref(self.plan), C.byref(self.model), _ptr(out))
+        assert rc == 0
+        return out
+
+    def dprobs(self, param_idx=None, eps=1e-7, return_probs=False):
+        if param_idx is None:
+            param_idx = np.arange(self.nP)
+        param_idx = np.ascontiguousarray(param_idx, np.int64)
+        n = len(param_idx)
+        out = np.empty((self.nE, n), np.float64)
+        pr = np.empty(self.nE, np.float64)
+        rc = self._fn("fill_dprobs")(C.byref(self.plan), C.byref(self.model), C.c_int64(self.nE),
+                                     _ptr(param_idx), None, C.c_int64(n), C.c_double(eps),
+                                     _ptr(out), C.c_int64(n), _ptr(pr))
+        assert rc == 0
+        return (out, pr) if return_probs else out
+
+    def hprobs(self, param_idx1, param_idx2, eps=1e-5):
+        assert self.kind == "port"
+        p1 = np.ascontiguousarray(param_idx1, np.int64)
+        p2 = np.ascontiguousarray(param_idx2, np.int64)
+        out = np.empty((self.nE, len(p1), len(p2)), np.float64)
+        rc = self.lib.oracle_fill_hprobs(C.byref(self.plan), C.byref(self.model), C.c_int64(self.nE),
+                                         _ptr(p1), None, C.c_int64(len(p1)), _ptr(p2), None, C.c_int64(len(p2)),
+                                         C.c_double(eps), _ptr(out), C.c_int64(len(p1)), C.c_int64(len(p2)))
+        assert rc == 0
+        return out
+
+    def time_passes(self, n_pass):
+        """Run n_pass full probability passes (the cost of n_pass FD columns); returns seconds."""
+        import time
+        out = np.empty(self.nE, np.float64)
+        t0 = time.perf_counter()
+        rc = self._fn("time_passes")(C.byref(self.plan), C.byref(self.model), C.c_int64(self.nE),
+                                     C.c_int(n_pass), _ptr(out))
+        assert rc == 0
+        return time.perf_counter() - t0
+
+
+def from_fixture(fx, kind="port"):
+    """Build an Oracle from a tests/golden/*.npz fixture (np.load result or dict)."""
+    tbl = {k: fx[k] for k in ("D", "cache_size", "t_dest", "t_start", "t_cache", "t_rho", "row_ptr",
+                              "gate_idx", "eff_ptr", "eff_label", "eff_dest", "nE")}
+    mdl = {k: fx[k] for k in ("gates", "rhos", "effects", "pkind", "pobj", "pelem")}
+    return Oracle(tbl, mdl, kind)
+
+
+# ------------------------------------------------------------------------------------------------
+# numpy analytic Jacobian / Hessian (independent check for the analytic device mode)
+# ------------------------------------------------------------------------------------------------
+
+def expand_table_circuits(fx):
+    """Full gate string + rho index of every expanded circuit, rebuilt from the prefix table."""
+    R = len(fx["t_dest"])
+    full = [None] * R
+    rho = np.zeros(R, np.int32)
+    cache = {}
+    rp = fx["row_ptr"]
+    for k in range(R):
+        seg = list(fx["gate_idx"][rp[k]:rp[k + 1]])
+        if fx["t_start"][k] == -1:
+            pre, r = [], int(fx["t_rho"][k])
+        else:
+            pre, r = cache[int(fx["t_start"][k])]
+        s = pre + seg
+        i = int(fx["t_dest"][k])
+        full[i] = s
+        rho[i] = r
+        if fx["t_cache"][k] != -1:
+            cache[int(fx["t_cache"][k])] = (s, r)
+    return full, rho
+
+
+def analytic_dprobs(fx, cols=None):
+    """dp/dtheta by forward states and backward effect vectors (exact derivative, `full` params)."""
+    D = int(fx["D"]); nE = int(fx["nE"]); nP = len(fx["pkind"])
+    gates, rhos, effects = fx["gates"], fx["rhos"], fx["effects"]
+    full, rho = expand_table_circuits(fx)
+    # parameter index of each dense element
+    gmap = -np.ones((gates.shape[0], D * D), np.int64)
+    rmap = -np.ones((rhos.shape[0], D), np.int64)
+    emap = -np.ones((effects.shape[0], D), np.int64)
+    for p in range(nP):
+        k, o, e = int(fx["pkind"][p]), int(fx["pobj"][p]), int(fx["pelem"][p])
+        if k == 0: gmap[o, e] = p
+        elif k == 1: rmap[o, e] = p
+        elif k == 2: emap[o, e] = p
+    J = np.zeros((nE, nP))
+    P = np.zeros(nE)
+    for i, s in enumerate(full):
+        fwd = [rhos[rho[i]]]
+        for g in s:
+            fwd.append(gates[g] @ fwd[-1])
+        for x in range(fx["eff_ptr"][i], fx["eff_ptr"][i + 1]):
+            el, dest = int(fx["eff_label"][x]), int(fx["eff_dest"][x])
+            P[dest] = effects[el] @ fwd[-1]
+            J[dest, emap[el][emap[el] >= 0]] += fwd[-1][emap[el] >= 0]
+            b = effects[el].copy()
+            for pos in range(len(s) - 1, -1, -1):
+                g = s[pos]
+                outer = np.outer(b, fwd[pos]).ravel()
+                m = gmap[g] >= 0
+                np.add.at(J[dest], gmap[g][m], outer[m])
+                b = gates[g].T @ b
+            m = rmap[rho[i]] >= 0
+            J[dest, rmap[rho[i]][m]] += b[m]
+    if cols is not None:
+        J = J[:, cols]
+    return J, P

@@ -1,0 +1,339 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the forward-simulation hot path by IMPORTING the reference.
+
+Runs only in the build container (needs a scratch build of the reference):
+
+    PYTHONPATH=/tmp/pgref OMP_NUM_THREADS=1 python3 tests/golden/make_golden.py
+
+It never travels to the GPU box; only the `.npz` files it writes (inputs + expected outputs,
+pure data) are committed.  Each fixture holds
+
+  inputs : model arrays in the order the reference's layout atom uses them (gates [nG,D,D],
+           rhos [nR,D], effects [nEl,D]), the parameter -> (kind, object, element) map of the
+           `full` parameterisation, the integerised circuit list, the reference's own prefix
+           table (`_MapCOPALayoutAtom.table.contents`) as flat int arrays, the effect CSR
+           (`elbl_indices_by_expcircuit`, `elindices_by_expcircuit`), the layout element order.
+  outputs: probs (Cython map), dprobs_map (Cython FD, eps 1e-7), dprobs_matrix (analytic,
+           MatrixForwardSimulator), hprobs_map / hprobs_matrix for small cases.
+
+Reference entry points exercised: ForwardSimulator.bulk_fill_probs / bulk_fill_dprobs /
+bulk_fill_hprobs (pygsti/forwardsims/forwardsim.py:584,628,701) on MapForwardSimulator
+(mapforwardsim.py:111) and MatrixForwardSimulator (matrixforwardsim.py:578).
+"""
+import os
+import sys
+import hashlib
+import numpy as np
+
+import pygsti
+from pygsti.baseobjs import Label
+from pygsti.forwardsims import MapForwardSimulator, MatrixForwardSimulator
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _label_str(lbl):
+    return str(lbl)
+
+
+def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hprobs=False,
+              hprobs_blk=None, circuit_subset_for_matrix=None, extra=None):
+    """Build a 1-atom Map layout for `circuits`, run the reference, save everything."""
+    assert model.sim.calclib.__name__.endswith('calc_densitymx'), "reference Cython path not built!"
+    model = model.copy()
+    model.sim = MapForwardSimulator(num_atoms=1)
+    nP = model.num_params
+    D = model.dim
+
+    array_types = ('e', 'ep') + (('epp',) if want_hprobs else ())
+    layout = model.sim.create_layout(circuits, array_types=array_types)
+    assert len(layout.atoms) == 1
+    atom = layout.atoms[0]
+    nE = layout.num_elements
+
+    # ---- model arrays in atom order -------------------------------------------------
+    op_labels = list(atom.op_labels)
+    rho_labels = list(atom.rho_labels)
+    eff_labels = list(atom.full_effect_labels)   # a set: capture iteration order
+    gates = np.array([model._circuit_layer_operator(l, 'op').to_dense('minimal') for l in op_labels])
+    rhos = np.array([model._circuit_layer_operator(l, 'prep').to_dense('minimal') for l in rho_labels])
+    effects = np.array([model._circuit_layer_operator(l, 'povm').to_dense('minimal') for l in eff_labels])
+    gates = np.ascontiguousarray(gates.real.reshape(len(op_labels), D, D), dtype=np.float64)
+    rhos = np.ascontiguousarray(rhos.real.reshape(len(rho_labels), D), dtype=np.float64)
+    effects = np.ascontiguousarray(effects.real.reshape(len(eff_labels), D), dtype=np.float64)
+
+    # ---- parameter map (full parameterisation: one param <-> one dense element) ---------
+    # kind: 0 = gate, 1 = rho, 2 = effect
+    pkind = -np.ones(nP, dtype=np.int32)
+    pobj = -np.ones(nP, dtype=np.int32)
+    pelem = -np.ones(nP, dtype=np.int32)
+    for kind, labels, typ in ((0, op_labels, 'op'), (1, rho_labels, 'prep'), (2, eff_labels, 'povm')):
+        for oi, lbl in enumerate(labels):
+            member = model._circuit_layer_operator(lbl, typ)
+            idx = member.gpindices_as_array()
+            assert len(idx) == member.num_params
+            n_el = D * D if kind == 0 else D
+            assert len(idx) == n_el, "fixture generator assumes `full` parameterisation"
+            pkind[idx] = kind
+            pobj[idx] = oi
+            pelem[idx] = np.arange(n_el)
+    paramvec = model.to_vector().copy()
+    # consistency: the parameter value IS the dense element
+    for p in range(nP):
+        if pkind[p] == 0:
+            assert gates[pobj[p]].flat[pelem[p]] == paramvec[p]
+        elif pkind[p] == 1:
+            assert rhos[pobj[p]].flat[pelem[p]] == paramvec[p]
+        elif pkind[p] == 2:
+            assert effects[pobj[p]].flat[pelem[p]] == paramvec[p]
+        else:
+            pass  # parameter of a gate/effect this atom never applies: kind -1, derivative exactly 0
+
+    # ---- reference prefix table as flat ints -----------------------------------------
+    op_lookup = {l: i for i, l in enumerate(op_labels)}
+    rho_lookup = {l: i for i, l in enumerate(rho_labels)}
+    contents = atom.table.contents
+    R = len(contents)
+    t_dest = np.empty(R, np.int32); t_start = np.empty(R, np.int32)
+    t_cache = np.empty(R, np.int32); t_rho = -np.ones(R, np.int32)
+    row_ptr = np.zeros(R + 1, np.int64)
+    gidx = []
+    for k, (iDest, iStart, remainder, iCache) in enumerate(contents):
+        t_dest[k] = iDest
+        t_start[k] = -1 if iStart is None else iStart
+        t_cache[k] = -1 if iCache is None else iCache
+        rem = list(remainder)
+        if iStart is None:
+            t_rho[k] = rho_lookup[rem[0]]
+            rem = rem[1:]
+        gidx.extend(op_lookup[g] for g in rem)
+        row_ptr[k + 1] = len(gidx)
+    gate_idx = np.array(gidx, dtype=np.int32)
+
+    # ---- effect CSR, indexed by expanded-circuit index (== iDest) ---------------------
+    nX = len(atom.elbl_indices_by_expcircuit)
+    assert nX == R
+    eff_ptr = np.zeros(nX + 1, np.int64)
+    eff_label, eff_dest = [], []
+    for i in range(nX):
+        eff_label.extend(atom.elbl_indices_by_expcircuit[i])
+        eff_dest.extend(atom.elindices_by_expcircuit[i])
+        eff_ptr[i + 1] = len(eff_label)
+    eff_label = np.array(eff_label, np.int32)
+    eff_dest = np.array(eff_dest, np.int32)
+    assert atom.element_slice == slice(0, nE)
+
+    # ---- integerised circuit list in the caller's order + the layout's element order -----
+    circ_ptr = np.zeros(len(circuits) + 1, np.int64)
+    cg = []
+    for ci, c in enumerate(circuits):
+        cg.extend(op_lookup[l] for l in c.layertup)  # circuits hold no SPAM labels here
+        circ_ptr[ci + 1] = len(cg)
+    circ_gates = np.array(cg, np.int32)
+    # element k <-> (circuit index, outcome index into eff_labels-less outcome tuple)
+    el_circuit = np.empty(nE, np.int32)
+    el_outcome = np.empty(nE, np.int32)
+    outcome_names = None
+    for ci, c in enumerate(circuits):
+        inds = layout.indices_for_index(ci)
+        outs = layout.outcomes_for_index(ci)
+        inds = np.arange(inds.start, inds.stop, inds.step or 1) if isinstance(inds, slice) else np.asarray(inds)
+        if outcome_names is None:
+            outcome_names = [''.join(o) for o in outs]
+        for k, o in zip(inds, outs):
+            el_circuit[k] = ci
+            el_outcome[k] = outcome_names.index(''.join(o))
+
+    # ---- reference outputs -----------------------------------------------------------
+    probs = np.empty(nE, 'd')
+    model.sim.bulk_fill_probs(probs, layout)
+    out = dict(probs=probs)
+
+    if dprobs_cols is None:
+        dprobs_cols = np.arange(nP)
+    dprobs_cols = np.asarray(dprobs_cols, dtype=np.int64)
+    out['dprobs_cols'] = dprobs_cols
+    ralloc = layout.resource_alloc('param-processing')
+    if len(dprobs_cols) == nP:
+        J = np.empty((nE, nP), 'd')
+        model.sim.bulk_fill_dprobs(J, layout)
+    else:
+        J = np.empty((nE, len(dprobs_cols)), 'd')
+        # column subset through the per-atom seam (distforwardsim.py:148-152)
+        model.sim._bulk_fill_dprobs_atom(J, None, atom, dprobs_cols, ralloc)
+    out['dprobs_map'] = J
+    # the FD loop must restore the model exactly
+    assert np.array_equal(model.to_vector(), paramvec)
+
+    if want_hprobs:
+        b1, b2 = hprobs_blk
+        b1 = np.asarray(b1, np.int64); b2 = np.asarray(b2, np.int64)
+        H = np.empty((nE, len(b1), len(b2)), 'd')
+        model.sim._bulk_fill_hprobs_atom(H, None, None, atom, b1, b2, ralloc)
+        out['hprobs_map'] = H
+        out['hprobs_rows'] = b1
+        out['hprobs_cols'] = b2
+        assert np.allclose(model.to_vector(), paramvec, atol=0, rtol=0)
+
+    if want_matrix:
+        m2 = model.copy()
+        m2.sim = MatrixForwardSimulator(num_atoms=1)
+        sub = circuits if circuit_subset_for_matrix is None else [circuits[i] for i in circuit_subset_for_matrix]
+        lay2 = m2.sim.create_layout(sub, array_types=array_types)
+        # the Matrix layout orders elements differently: map by (circuit, outcome)
+        J2 = np.empty((lay2.num_elements, nP), 'd')
+        p2 = np.empty(lay2.num_elements, 'd')
+        m2.sim.bulk_fill_dprobs(J2, lay2, pr_array_to_fill=p2)
+        if want_hprobs:
+            H2 = np.empty((lay2.num_elements, nP, nP), 'd')
+            m2.sim.bulk_fill_hprobs(H2, lay2)
+        sub_idx = list(range(len(circuits))) if circuit_subset_for_matrix is None else list(circuit_subset_for_matrix)
+        rows_map = []   # element indices (Map layout) in the order we store the matrix results
+        rows_mat = []
+        for si, ci in enumerate(sub_idx):
+            inds_map = layout.indices_for_index(ci)
+            inds_mat = lay2.indices_for_index(si)
+            inds_map = np.arange(nE)[inds_map]
+            inds_mat = np.arange(lay2.num_elements)[inds_mat]
+            outs_map = layout.outcomes_for_index(ci)
+            outs_mat = lay2.outcomes_for_index(si)
+            for k, o in zip(inds_map, outs_map):
+                rows_map.append(k)
+                rows_mat.append(inds_mat[list(outs_mat).index(o)])
+        rows_map = np.array(rows_map, np.int64)
+        rows_mat = np.array(rows_mat, np.int64)
+        out['matrix_rows'] = rows_map                      # Map-layout element index of each stored row
+        out['probs_matrix'] = p2[rows_mat]
+        out['dprobs_matrix'] = J2[rows_mat][:, dprobs_cols]
+        if want_hprobs:
+            out['hprobs_matrix'] = H2[rows_mat][:, b1][:, :, b2]
+
+    meta = dict(
+        D=np.int32(D), nP=np.int32(nP), nE=np.int32(nE), cache_size=np.int32(atom.cache_size),
+        gates=gates, rhos=rhos, effects=effects, paramvec=paramvec,
+        pkind=pkind, pobj=pobj, pelem=pelem,
+        t_dest=t_dest, t_start=t_start, t_cache=t_cache, t_rho=t_rho, row_ptr=row_ptr, gate_idx=gate_idx,
+        eff_ptr=eff_ptr, eff_label=eff_label, eff_dest=eff_dest,
+        circ_ptr=circ_ptr, circ_gates=circ_gates, el_circuit=el_circuit, el_outcome=el_outcome,
+        op_labels=np.array([_label_str(l) for l in op_labels]),
+        rho_labels=np.array([_label_str(l) for l in rho_labels]),
+        eff_labels=np.array([_label_str(l) for l in eff_labels]),
+        outcome_names=np.array(outcome_names),
+        derivative_eps=np.float64(model.sim.derivative_eps), hessian_eps=np.float64(model.sim.hessian_eps),
+    )
+    if extra:
+        meta.update(extra)
+    meta.update(out)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **meta)
+    print("%-28s nC=%6d nE=%7d nP=%5d rows=%6d A=%8d  -> %s (%.1f kB)" % (
+        name, len(circuits), nE, nP, R, len(gate_idx), os.path.basename(path), os.path.getsize(path) / 1024))
+    return meta
+
+
+def circuit_list_hash(circ_ptr, circ_gates):
+    h = hashlib.sha256()
+    h.update(np.asarray(circ_ptr, np.int64).tobytes())
+    h.update(np.asarray(circ_gates, np.int32).tobytes())
+    return h.hexdigest()
+
+
+def main():
+    from pygsti.modelpacks import smq1Q_XYI, smq2Q_XYICNOT
+    which = sys.argv[1:] or ['1q4', '1q4k', '1q128', '2q2', '2qdeep', 'designs']
+
+    if '1q4' in which:   # BASELINE configs[0] / SURVEY C1: smq1Q_XYI L in {1,2,4}
+        m = smq1Q_XYI.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
+        circs = list(smq1Q_XYI.create_gst_experiment_design(4).all_circuits_needing_data)
+        blk = (np.arange(0, 60, 7), np.arange(3, 60, 5))
+        dump_case('smq1Q_XYI_L4_depol', m, circs, want_hprobs=True, hprobs_blk=blk)
+
+    if '1q4k' in which:  # kicked model: generic dense values (FD-vs-analytic stress, run_me_with_mpiexec.py:40)
+        m = smq1Q_XYI.target_model().depolarize(op_noise=0.01, spam_noise=0.01).kick(0.1, seed=1234)
+        circs = list(smq1Q_XYI.create_gst_experiment_design(4).all_circuits_needing_data)
+        dump_case('smq1Q_XYI_L4_kick', m, circs, want_hprobs=False)
+
+    if '1q128' in which:  # BASELINE configs[1] / SURVEY C2
+        m = smq1Q_XYI.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
+        circs = list(smq1Q_XYI.create_gst_experiment_design(128).all_circuits_needing_data)
+        dump_case('smq1Q_XYI_L128_depol', m, circs, want_matrix=True)
+
+    if '2q2' in which:   # 2Q, D=16: every circuit of the L<=2 lite design, a spread of 96 columns
+        m = smq2Q_XYICNOT.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
+        circs = list(smq2Q_XYICNOT.create_gst_experiment_design(2, lite=True).all_circuits_needing_data)
+        rng = np.random.default_rng(7)
+        cols = np.sort(np.concatenate([np.arange(0, 16), np.arange(16, 80, 5),
+                                       rng.choice(np.arange(80, 1616), 67, replace=False)]))
+        sub = list(range(0, len(circs), 9))
+        dump_case('smq2Q_XYICNOT_L2_depol', m, circs, dprobs_cols=cols, want_matrix=True,
+                  circuit_subset_for_matrix=sub)
+
+    if '2qdeep' in which:  # SURVEY C3 slice: whole germ-power families at L<=1024, 64 columns
+        m = smq2Q_XYICNOT.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
+        design = smq2Q_XYICNOT.create_gst_experiment_design(1024, lite=True)
+        allc = list(design.all_circuits_needing_data)
+        germs = smq2Q_XYICNOT.germs(lite=True)
+        prepf = smq2Q_XYICNOT.prep_fiducials(); measf = smq2Q_XYICNOT.meas_fiducials()
+        fam = []
+        for g in (germs[1], germs[5], germs[10]):          # Gxpi2:0, Gcnot, a 5-gate germ
+            for p in (1, 4, 64, 1024):
+                rep = p // len(g)
+                if rep == 0: continue
+                for pf in (prepf[0], prepf[6], prepf[15]):
+                    for mf in (measf[0], measf[3], measf[8]):
+                        fam.append(pf + g * rep + mf)
+        allset = set(allc)
+        fam = [c for c in dict.fromkeys(fam) if c in allset]
+        cols = np.arange(336, 400)
+        dump_case('smq2Q_XYICNOT_L1024_deep', m, fam, dprobs_cols=cols, want_matrix=False)
+
+    if 'designs' in which:
+        # pins for the build's own circuit generator: counts and sha256 of integerised lists, plus
+        # the model data of the two packs (target superoperators, SPAM, fiducials, germs)
+        rec = {}
+        for pack, tag, Ls, lites in ((smq1Q_XYI, '1Q', [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024], (True, False)),
+                                     (smq2Q_XYICNOT, '2Q', [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024], (True, False))):
+            tm = pack.target_model()
+            ops = list(tm.operations.keys())
+            lookup = {l: i for i, l in enumerate(ops)}
+            rec[tag + '_op_labels'] = np.array([str(l) for l in ops])
+            rec[tag + '_gates'] = np.array([tm.operations[l].to_dense() for l in ops])
+            rec[tag + '_rho'] = tm.preps['rho0'].to_dense()
+            rec[tag + '_effects'] = np.array([tm.povms['Mdefault'][k].to_dense() for k in tm.povms['Mdefault'].keys()])
+            rec[tag + '_effect_labels'] = np.array(list(tm.povms['Mdefault'].keys()))
+            dm = tm.depolarize(op_noise=0.01, spam_noise=0.01)
+            rec[tag + '_gates_depol'] = np.array([dm.operations[l].to_dense() for l in ops])
+            rec[tag + '_rho_depol'] = dm.preps['rho0'].to_dense()
+            rec[tag + '_effects_depol'] = np.array([dm.povms['Mdefault'][k].to_dense() for k in dm.povms['Mdefault'].keys()])
+            rec[tag + '_paramvec_depol'] = dm.to_vector()
+
+            def enc(clist):
+                ptr = np.zeros(len(clist) + 1, np.int64); g = []
+                for i, c in enumerate(clist):
+                    g.extend(lookup[l] for l in c.layertup); ptr[i + 1] = len(g)
+                return ptr, np.array(g, np.int32)
+            for nm, lst in (('prep_fiducials', pack.prep_fiducials()), ('meas_fiducials', pack.meas_fiducials()),
+                            ('germs_lite', pack.germs(lite=True)), ('germs_full', pack.germs(lite=False))):
+                p, g = enc(lst)
+                rec['%s_%s_ptr' % (tag, nm)] = p
+                rec['%s_%s_gates' % (tag, nm)] = g
+            for lite in lites:
+                counts, hashes, depth = [], [], []
+                for L in Ls:
+                    if tag == '2Q' and not lite and L not in (1, 2, 1024):
+                        counts.append(-1); hashes.append(''); depth.append(-1); continue
+                    cl = list(pack.create_gst_experiment_design(L, lite=lite).all_circuits_needing_data)
+                    p, g = enc(cl)
+                    counts.append(len(cl)); hashes.append(circuit_list_hash(p, g)); depth.append(len(g))
+                    print(tag, 'lite' if lite else 'full', L, len(cl), len(g), hashes[-1][:12])
+                key = '%s_%s' % (tag, 'lite' if lite else 'full')
+                rec[key + '_L'] = np.array(Ls)
+                rec[key + '_counts'] = np.array(counts)
+                rec[key + '_depth'] = np.array(depth)
+                rec[key + '_sha256'] = np.array(hashes)
+        np.savez_compressed(os.path.join(HERE, 'designs.npz'), **rec)
+        print("designs.npz written")
+
+
+if __name__ == '__main__':
+    main()
