@@ -1,0 +1,180 @@
+/*
+ * gstfwd.h -- C ABI of the MI355X-native dense-matrix forward simulator (libgstfwd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of pyGSTi: circuit-outcome probabilities and their
+ * Jacobian / Hessian blocks for `densitymx` models,
+ *     ForwardSimulator.bulk_fill_probs / bulk_fill_dprobs / bulk_fill_hprobs
+ *     (reference: pygsti/forwardsims/forwardsim.py:584,628,701), reached per layout atom through
+ *     MapForwardSimulator._bulk_fill_{probs,dprobs,hprobs}_atom (pygsti/forwardsims/mapforwardsim.py:372-391).
+ * Today that seam is a Cython cimport of C++ classes (mapforwardsim_calc_densitymx.pyx:15-17); the
+ * functions below are what a ctypes/cffi binding of the same seam would bind.  Plain C, plain
+ * pointers and sizes, no framework types.  Every function returns 0 on success or a negative
+ * GST_E* code; gst_last_error() gives the message (thread-local).  Nothing here aborts the process
+ * and nothing here computes on the CPU: if no gfx950 device/HIP runtime is usable, the fill calls
+ * fail with GST_ENODEVICE.
+ *
+ * Ownership: the caller owns every host array for the duration of the call only; the library owns
+ * the plan handle and all device memory.  Calls on one plan are not re-entrant; different plans may
+ * be used from different threads.  Host-output calls are blocking; `_dev` calls enqueue on the
+ * plan's stream and return (use gst_sync()).
+ */
+#ifndef GSTFWD_H
+#define GSTFWD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GST_OK 0
+#define GST_EINVAL (-1)     /* bad argument / inconsistent plan description */
+#define GST_ENODEVICE (-2)  /* no usable HIP device (the library never falls back to the CPU) */
+#define GST_EHIP (-3)       /* a HIP runtime call failed */
+#define GST_ENOMEM (-4)     /* host or device allocation failed (Python shell raises MemoryError) */
+#define GST_ESTATE (-5)     /* call order violated (e.g. fill before gst_set_model) */
+#define GST_EUNSUPPORTED (-6)
+
+/* parameter kinds of gst_set_param_map (one parameter <-> one dense element: the reference's
+ * `full` parameterisation, modelmembers/operations/fullarbitraryop.py:139-164) */
+#define GST_KIND_NONE (-1)  /* parameter of an object this plan never applies: derivative exactly 0 */
+#define GST_KIND_GATE 0
+#define GST_KIND_RHO 1
+#define GST_KIND_EFFECT 2
+
+/* derivative modes of gst_fill_dprobs */
+#define GST_DERIV_FD 0        /* forward finite differences, bit-for-bit the reference's Map path
+                                 (mapforwardsim_calc_densitymx.pyx:290-383) */
+#define GST_DERIV_ANALYTIC 1  /* exact derivative (what MatrixForwardSimulator computes,
+                                 matrixforwardsim.py:1059-1140), not yet in this round */
+
+typedef struct gst_plan gst_plan;
+
+/*
+ * Plan description in the reference's own per-atom format (what _MapCOPALayoutAtom holds,
+ * pygsti/layouts/maplayout.py:101-134, after the int conversion of convert_maplayout,
+ * mapforwardsim_calc_densitymx.pyx:55-77):
+ *   row k of the prefix table: expanded circuit t_dest[k] = cached state t_start[k] (or, when
+ *   t_start[k] == -1, state preparation t_rho[k]) followed by gate_idx[row_ptr[k]..row_ptr[k+1]);
+ *   the resulting state is kept in cache slot t_cache[k] (-1: not cached).
+ *   expanded circuit i yields elements eff_dest[eff_ptr[i]..eff_ptr[i+1]) (indices into the atom's
+ *   slice of the 'e' array) using effect vectors eff_label[...] (elbl_indices_by_expcircuit /
+ *   elindices_by_expcircuit).
+ * The library re-derives every full circuit from the table, builds its own prefix trie and walk
+ * programs from them (the table's caching choices do not constrain the device schedule) -- results
+ * are identical because each state is still the same left-to-right product.
+ */
+typedef struct {
+    int32_t D;           /* state-vector length d^2 (4 or 16 in this round) */
+    int32_t n_gates;     /* number of distinct layer operators (atom.op_labels) */
+    int32_t n_rhos;      /* atom.rho_labels */
+    int32_t n_effects;   /* atom.full_effect_labels */
+    int32_t n_rows;      /* table rows == expanded circuits */
+    int32_t cache_size;  /* atom.cache_size (only used for validation) */
+    int64_t n_elements;  /* atom.num_elements */
+    const int32_t *t_dest, *t_start, *t_cache, *t_rho;   /* [n_rows] */
+    const int64_t *row_ptr;                              /* [n_rows+1] */
+    const int32_t *gate_idx;                             /* [row_ptr[n_rows]] */
+    const int64_t *eff_ptr;                              /* [n_rows+1] */
+    const int32_t *eff_label, *eff_dest;                 /* [eff_ptr[n_rows]] */
+} gst_table_desc;
+
+/* The same information as raw circuits (no prefix table): circuit i = rho circ_rho[i] followed by
+ * circ_gates[circ_ptr[i]..circ_ptr[i+1]); effect CSR as above, indexed by circuit. */
+typedef struct {
+    int32_t D, n_gates, n_rhos, n_effects;
+    int32_t n_circuits;
+    int64_t n_elements;
+    const int32_t *circ_rho;     /* [n_circuits] */
+    const int64_t *circ_ptr;     /* [n_circuits+1] */
+    const int32_t *circ_gates;
+    const int64_t *eff_ptr;      /* [n_circuits+1] */
+    const int32_t *eff_label, *eff_dest;
+} gst_circuits_desc;
+
+typedef struct {
+    int32_t device;          /* HIP device ordinal; -1 = current device */
+    int32_t target_tasks;    /* 0 = default; how many independent walk programs to aim for */
+    int32_t reserved[6];
+} gst_options;
+
+typedef struct {
+    int64_t n_circuits, n_elements;
+    int64_t sum_depth;         /* gate applications without any prefix sharing */
+    int64_t trie_nodes;        /* distinct prefixes (states) over all circuits */
+    int64_t applies_per_pass;  /* gate applications one pass actually executes (incl. task-prefix recompute) */
+    int64_t n_tasks;
+    int64_t prog_words;
+    int32_t max_slots;         /* deepest save-slot index any walk program uses, plus one */
+    int32_t max_depth;
+    double last_kernel_ms;     /* device time of the dominant kernel of the last fill (HIP events) */
+    double last_total_ms;      /* device time of the whole last fill */
+    int64_t last_launches;
+} gst_stats;
+
+int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *opt, gst_plan **out);
+int gst_plan_create_from_circuits(const gst_circuits_desc *desc, const gst_options *opt, gst_plan **out);
+int gst_plan_destroy(gst_plan *plan);
+
+/* Dense model arrays (what the reference's reps borrow: OpRepDenseSuperop.base, StateRepDense.data,
+ * EffectRepConjugatedState.state_rep.data; evotypes/densitymx/opreps.pyx:75-90), C-contiguous f64:
+ * gates[n_gates][D][D], rhos[n_rhos][D], effects[n_effects][D].  Re-call after every
+ * model.from_vector(); costs one small H2D copy. */
+int gst_set_model(gst_plan *plan, const double *gates, const double *rhos, const double *effects);
+
+/* Parameter p perturbs element `elem[p]` (flat, row-major) of object `obj[p]` of kind `kind[p]`. */
+int gst_set_param_map(gst_plan *plan, int32_t n_params, const int32_t *kind, const int32_t *obj,
+                      const int32_t *elem);
+
+/* probs: out[n_elements] (host). */
+int gst_fill_probs(gst_plan *plan, double *out);
+
+/* dprobs: out[k*ld + dest_idx[c]] = d p_k / d theta_{param_idx[c]} for c < n_param (host, row-major,
+ * leading dimension ld so that a column window of an 'ep' array can be filled in place).
+ * dest_idx == NULL means dest c.  probs_out (may be NULL) receives the probabilities, as
+ * bulk_fill_dprobs(pr_array_to_fill=...) does.  mode/eps: GST_DERIV_FD with the simulator's
+ * derivative_eps (1e-7 in the reference, mapforwardsim.py:166-172). */
+int gst_fill_dprobs(gst_plan *plan, double *out, int64_t ld, const int64_t *param_idx,
+                    const int64_t *dest_idx, int64_t n_param, int mode, double eps, double *probs_out);
+
+/* hprobs block: out[(k*ld1 + dest1[a])*ld2 + dest2[b]] = d2 p_k / d theta_{idx1[a]} d theta_{idx2[b]}
+ * by finite differences of finite differences with step eps, bit-for-bit
+ * MapForwardSimulator._mapfill_hprobs_atom (mapforwardsim.py:394-438). */
+int gst_fill_hprobs(gst_plan *plan, double *out, int64_t ld1, int64_t ld2,
+                    const int64_t *idx1, const int64_t *dest1, int64_t n1,
+                    const int64_t *idx2, const int64_t *dest2, int64_t n2, double eps);
+
+/* Device-resident variants: `d_out` / `d_probs_out` are device pointers on the plan's device
+ * (e.g. a buffer the caller shares with RCCL).  Asynchronous on the plan's stream. */
+int gst_fill_probs_dev(gst_plan *plan, double *d_out);
+int gst_fill_dprobs_dev(gst_plan *plan, double *d_out, int64_t ld, const int64_t *param_idx,
+                        const int64_t *dest_idx, int64_t n_param, int mode, double eps,
+                        double *d_probs_out);
+int gst_sync(gst_plan *plan);
+
+/* Introspection (tests, bench, DESIGN.md numbers). */
+int gst_get_stats(const gst_plan *plan, gst_stats *out);
+/* Copies up to `cap` program words of the concatenated walk programs; returns the total count in
+ * *n_words.  task_off (may be NULL) receives n_tasks+1 offsets when cap_tasks suffices. */
+int gst_get_program(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words,
+                    int64_t *task_off, int64_t cap_tasks);
+
+int gst_device_count(int32_t *n);
+const char *gst_last_error(void);
+const char *gst_version(void);
+
+/* Walk-program encoding (one 32-bit word per instruction, opcode in the top 4 bits) -- public so
+ * that tests can interpret programs independently of the device code. */
+#define GST_OP_END 0u    /* end of task */
+#define GST_OP_RHO 1u    /* v <- rho[arg] */
+#define GST_OP_APPLY 2u  /* v <- G[arg] v */
+#define GST_OP_SAVE 3u   /* slot[arg] <- v */
+#define GST_OP_LOAD 4u   /* v <- slot[arg] */
+#define GST_OP_EMIT 5u   /* elements of expanded circuit arg: p = E . v */
+#define GST_OP(word) ((word) >> 28)
+#define GST_ARG(word) ((word) & 0x0FFFFFFFu)
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSTFWD_H */

@@ -1,0 +1,257 @@
+"""ctypes binding of libgstfwd.so (include/gstfwd.h).  No PyTorch, no numpy-side compute.
+
+The library is the product's only compute path: if it is missing this module raises ImportError-like
+RuntimeError at first use, and if no gfx950 device is usable every fill raises `GstDeviceError`.
+There is deliberately NO CPU fallback (the CPU checker lives in oracle/ and is test-only).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgstfwd.so")
+
+GST_OK = 0
+GST_EINVAL, GST_ENODEVICE, GST_EHIP, GST_ENOMEM, GST_ESTATE, GST_EUNSUPPORTED = -1, -2, -3, -4, -5, -6
+KIND_NONE, KIND_GATE, KIND_RHO, KIND_EFFECT = -1, 0, 1, 2
+DERIV_FD, DERIV_ANALYTIC = 0, 1
+
+OP_END, OP_RHO, OP_APPLY, OP_SAVE, OP_LOAD, OP_EMIT = 0, 1, 2, 3, 4, 5
+
+
+class GstError(RuntimeError):
+    pass
+
+
+class GstDeviceError(GstError):
+    """No usable MI355X / HIP runtime.  The library never computes on the CPU instead."""
+
+
+class TableDesc(C.Structure):
+    _fields_ = [("D", C.c_int32), ("n_gates", C.c_int32), ("n_rhos", C.c_int32), ("n_effects", C.c_int32),
+                ("n_rows", C.c_int32), ("cache_size", C.c_int32), ("n_elements", C.c_int64),
+                ("t_dest", C.c_void_p), ("t_start", C.c_void_p), ("t_cache", C.c_void_p), ("t_rho", C.c_void_p),
+                ("row_ptr", C.c_void_p), ("gate_idx", C.c_void_p),
+                ("eff_ptr", C.c_void_p), ("eff_label", C.c_void_p), ("eff_dest", C.c_void_p)]
+
+
+class CircuitsDesc(C.Structure):
+    _fields_ = [("D", C.c_int32), ("n_gates", C.c_int32), ("n_rhos", C.c_int32), ("n_effects", C.c_int32),
+                ("n_circuits", C.c_int32), ("n_elements", C.c_int64),
+                ("circ_rho", C.c_void_p), ("circ_ptr", C.c_void_p), ("circ_gates", C.c_void_p),
+                ("eff_ptr", C.c_void_p), ("eff_label", C.c_void_p), ("eff_dest", C.c_void_p)]
+
+
+class Options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("target_tasks", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_circuits", C.c_int64), ("n_elements", C.c_int64), ("sum_depth", C.c_int64),
+                ("trie_nodes", C.c_int64), ("applies_per_pass", C.c_int64), ("n_tasks", C.c_int64),
+                ("prog_words", C.c_int64), ("max_slots", C.c_int32), ("max_depth", C.c_int32),
+                ("last_kernel_ms", C.c_double), ("last_total_ms", C.c_double), ("last_launches", C.c_int64)]
+
+
+# every symbol include/gstfwd.h declares (tests check the library exports all of them)
+EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
+           "gst_set_param_map", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_probs_dev",
+           "gst_fill_dprobs_dev", "gst_sync", "gst_get_stats", "gst_get_program", "gst_device_count",
+           "gst_last_error", "gst_version"]
+
+_lib = None
+
+
+def lib():
+    """Load libgstfwd.so (once).  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GstError("libgstfwd.so not found at %s: build it with `make -C pygsti_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.gst_last_error.restype = C.c_char_p
+        L.gst_version.restype = C.c_char_p
+        vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+        L.gst_plan_create_from_table.argtypes = [C.POINTER(TableDesc), C.POINTER(Options), C.POINTER(vp)]
+        L.gst_plan_create_from_circuits.argtypes = [C.POINTER(CircuitsDesc), C.POINTER(Options), C.POINTER(vp)]
+        L.gst_plan_destroy.argtypes = [vp]
+        L.gst_set_model.argtypes = [vp, vp, vp, vp]
+        L.gst_set_param_map.argtypes = [vp, i32, vp, vp, vp]
+        L.gst_fill_probs.argtypes = [vp, vp]
+        L.gst_fill_dprobs.argtypes = [vp, vp, i64, vp, vp, i64, C.c_int, dbl, vp]
+        L.gst_fill_hprobs.argtypes = [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, dbl]
+        L.gst_fill_probs_dev.argtypes = [vp, vp]
+        L.gst_fill_dprobs_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.c_int, dbl, vp]
+        L.gst_sync.argtypes = [vp]
+        L.gst_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.gst_get_program.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64]
+        L.gst_device_count.argtypes = [C.POINTER(i32)]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc == GST_OK:
+        return
+    msg = lib().gst_last_error().decode("utf-8", "replace")
+    if rc == GST_ENOMEM:
+        raise MemoryError(msg)          # the reference raises MemoryError (mapforwardsim.py:374-387)
+    if rc == GST_ENODEVICE:
+        raise GstDeviceError(msg)
+    if rc == GST_EINVAL:
+        raise ValueError(msg)
+    raise GstError("libgstfwd error %d: %s" % (rc, msg))
+
+
+def device_count():
+    n = C.c_int32(0)
+    check(lib().gst_device_count(C.byref(n)))
+    return n.value
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _i32(x):
+    return np.ascontiguousarray(x, dtype=np.int32)
+
+
+def _i64(x):
+    return np.ascontiguousarray(x, dtype=np.int64)
+
+
+def _f64(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+class Plan:
+    """One compiled evaluation plan (== one layout atom) living on one GPU."""
+
+    def __init__(self, handle, D, n_gates, n_rhos, n_effects, n_elements):
+        self._h = handle
+        self.D, self.n_gates, self.n_rhos, self.n_effects = D, n_gates, n_rhos, n_effects
+        self.n_elements = int(n_elements)
+        self.n_params = 0
+
+    # -- construction --------------------------------------------------------------------------
+    @classmethod
+    def from_table(cls, D, n_gates, n_rhos, n_effects, n_elements, cache_size, t_dest, t_start, t_cache, t_rho,
+                   row_ptr, gate_idx, eff_ptr, eff_label, eff_dest, device=-1, target_tasks=0):
+        a = dict(t_dest=_i32(t_dest), t_start=_i32(t_start), t_cache=_i32(t_cache), t_rho=_i32(t_rho),
+                 row_ptr=_i64(row_ptr), gate_idx=_i32(gate_idx) if len(gate_idx) else np.zeros(1, np.int32),
+                 eff_ptr=_i64(eff_ptr), eff_label=_i32(eff_label), eff_dest=_i32(eff_dest))
+        d = TableDesc(int(D), int(n_gates), int(n_rhos), int(n_effects), len(a["t_dest"]), int(cache_size),
+                      int(n_elements), _ptr(a["t_dest"]), _ptr(a["t_start"]), _ptr(a["t_cache"]), _ptr(a["t_rho"]),
+                      _ptr(a["row_ptr"]), _ptr(a["gate_idx"]), _ptr(a["eff_ptr"]), _ptr(a["eff_label"]),
+                      _ptr(a["eff_dest"]))
+        opt = Options(int(device), int(target_tasks))
+        h = C.c_void_p()
+        check(lib().gst_plan_create_from_table(C.byref(d), C.byref(opt), C.byref(h)))
+        return cls(h, int(D), int(n_gates), int(n_rhos), int(n_effects), n_elements)
+
+    @classmethod
+    def from_circuits(cls, D, n_gates, n_rhos, n_effects, n_elements, circ_rho, circ_ptr, circ_gates,
+                      eff_ptr, eff_label, eff_dest, device=-1, target_tasks=0):
+        a = dict(circ_rho=_i32(circ_rho), circ_ptr=_i64(circ_ptr),
+                 circ_gates=_i32(circ_gates) if len(circ_gates) else np.zeros(1, np.int32),
+                 eff_ptr=_i64(eff_ptr), eff_label=_i32(eff_label), eff_dest=_i32(eff_dest))
+        d = CircuitsDesc(int(D), int(n_gates), int(n_rhos), int(n_effects), len(a["circ_rho"]), int(n_elements),
+                         _ptr(a["circ_rho"]), _ptr(a["circ_ptr"]), _ptr(a["circ_gates"]),
+                         _ptr(a["eff_ptr"]), _ptr(a["eff_label"]), _ptr(a["eff_dest"]))
+        opt = Options(int(device), int(target_tasks))
+        h = C.c_void_p()
+        check(lib().gst_plan_create_from_circuits(C.byref(d), C.byref(opt), C.byref(h)))
+        return cls(h, int(D), int(n_gates), int(n_rhos), int(n_effects), n_elements)
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().gst_plan_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- model -------------------------------------------------------------------------------------
+    def set_model(self, gates, rhos, effects):
+        g = _f64(gates).reshape(self.n_gates, self.D, self.D) if self.n_gates else np.zeros((1,), np.float64)
+        r = _f64(rhos).reshape(self.n_rhos, self.D)
+        e = _f64(effects).reshape(self.n_effects, self.D)
+        check(lib().gst_set_model(self._h, _ptr(g), _ptr(r), _ptr(e)))
+
+    def set_param_map(self, kind, obj, elem):
+        k, o, e = _i32(kind), _i32(obj), _i32(elem)
+        assert len(k) == len(o) == len(e)
+        check(lib().gst_set_param_map(self._h, len(k), _ptr(k), _ptr(o), _ptr(e)))
+        self.n_params = len(k)
+
+    # -- fills (host arrays) ---------------------------------------------------------------------------
+    def fill_probs(self, out=None):
+        if out is None:
+            out = np.empty(self.n_elements, np.float64)
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.size == self.n_elements
+        check(lib().gst_fill_probs(self._h, _ptr(out)))
+        return out
+
+    def fill_dprobs(self, out=None, param_idx=None, dest_idx=None, eps=1e-7, probs_out=None, mode=DERIV_FD):
+        if param_idx is None:
+            param_idx = np.arange(self.n_params)
+        pi = _i64(param_idx)
+        di = None if dest_idx is None else _i64(dest_idx)
+        if out is None:
+            ncol = len(pi) if di is None else (int(di.max()) + 1 if len(di) else 0)
+            out = np.empty((self.n_elements, ncol), np.float64)
+        assert out.dtype == np.float64 and out.ndim == 2 and out.shape[0] == self.n_elements
+        assert out.strides[1] == 8 and out.strides[0] % 8 == 0, "rows must be contiguous in the parameter dimension"
+        ld = out.strides[0] // 8 if out.shape[0] > 1 else max(out.shape[1], 1)
+        if probs_out is not None:
+            assert probs_out.dtype == np.float64 and probs_out.flags.c_contiguous and probs_out.size == self.n_elements
+        check(lib().gst_fill_dprobs(self._h, _ptr(out), ld, _ptr(pi), _ptr(di), len(pi), int(mode), float(eps),
+                                    _ptr(probs_out)))
+        return out
+
+    def fill_hprobs(self, out=None, idx1=None, idx2=None, dest1=None, dest2=None, eps=1e-5):
+        i1 = _i64(np.arange(self.n_params) if idx1 is None else idx1)
+        i2 = _i64(np.arange(self.n_params) if idx2 is None else idx2)
+        d1 = None if dest1 is None else _i64(dest1)
+        d2 = None if dest2 is None else _i64(dest2)
+        if out is None:
+            out = np.empty((self.n_elements, len(i1), len(i2)), np.float64)
+        assert out.dtype == np.float64 and out.ndim == 3 and out.flags.c_contiguous
+        check(lib().gst_fill_hprobs(self._h, _ptr(out), out.shape[1], out.shape[2], _ptr(i1), _ptr(d1), len(i1),
+                                    _ptr(i2), _ptr(d2), len(i2), float(eps)))
+        return out
+
+    # -- fills (device pointers) -------------------------------------------------------------------------
+    def fill_probs_dev(self, d_out_ptr):
+        check(lib().gst_fill_probs_dev(self._h, C.c_void_p(int(d_out_ptr))))
+
+    def fill_dprobs_dev(self, d_out_ptr, ld, param_idx, dest_idx=None, eps=1e-7, d_probs_ptr=None, mode=DERIV_FD):
+        pi = _i64(param_idx)
+        di = None if dest_idx is None else _i64(dest_idx)
+        check(lib().gst_fill_dprobs_dev(self._h, C.c_void_p(int(d_out_ptr)), int(ld), _ptr(pi), _ptr(di), len(pi),
+                                        int(mode), float(eps),
+                                        None if d_probs_ptr is None else C.c_void_p(int(d_probs_ptr))))
+
+    def sync(self):
+        check(lib().gst_sync(self._h))
+
+    # -- introspection -----------------------------------------------------------------------------------
+    def stats(self):
+        s = Stats()
+        check(lib().gst_get_stats(self._h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def program(self):
+        n = C.c_int64(0)
+        check(lib().gst_get_program(self._h, None, 0, C.byref(n), None, 0))
+        words = np.empty(max(n.value, 1), np.uint32)
+        nt = self.stats()["n_tasks"]
+        off = np.empty(nt + 1, np.int64)
+        check(lib().gst_get_program(self._h, _ptr(words), n.value, C.byref(n), _ptr(off), nt + 1))
+        return words[:n.value], off

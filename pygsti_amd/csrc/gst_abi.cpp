@@ -1,0 +1,607 @@
+// gst_abi.cpp -- the C ABI of include/gstfwd.h on top of the plan compiler and the HIP kernels.
+//
+// Host-side counterpart of what mapfill_probs_atom / mapfill_dprobs_atom do around the hot loop in
+// the reference (mapforwardsim_calc_densitymx.pyx:149-190, 290-383): marshal the plan once (the
+// reference re-converts it on EVERY call, :170-181), upload the small model arrays per call, launch.
+// There is no CPU compute path in this file: without a usable HIP device every fill fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gstfwd.h"
+#include "gst_kernels.hpp"
+#include "gst_plan.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            const int code_ = (e_ == hipErrorOutOfMemory) ? GST_ENOMEM                          \
+                              : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? GST_ENODEVICE : GST_EHIP; \
+            return fail(code_, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+        }                                                                                       \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count)
+    {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = std::max<size_t>(count, 1);
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct gst_plan {
+    gst::HostPlan hp;
+    int device = -1;
+    bool dev_ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+
+    // device copies of the plan
+    DevBuf<uint32_t> d_prog;
+    DevBuf<int64_t> d_task_off;
+    DevBuf<int32_t> d_eff_ptr, d_eff_label, d_eff_dest;
+    // model
+    std::vector<double> h_gates, h_gates_t, h_rhos, h_effects;
+    bool have_model = false;
+    DevBuf<double> d_gates, d_gates_t, d_rhos, d_effects;
+    // parameter map
+    std::vector<int32_t> pkind, pobj, pelem;
+    bool have_pmap = false;
+    // work buffers
+    DevBuf<double> d_pbase, d_scratch, d_out, d_raw, d_dcol, d_probs_tmp;
+    DevBuf<int32_t> d_lane[7];   // col, kind0, obj0, elem0, kind1, obj1, elem1
+    DevBuf<int32_t> d_wave_row, d_wave_rowidx, d_lane_colidx;
+
+    double last_kernel_ms = 0, last_total_ms = 0;
+    int64_t last_launches = 0;
+
+    ~gst_plan()
+    {
+        if (!dev_ready) return;
+        (void)hipSetDevice(device);
+        d_prog.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
+        d_pbase.release(); d_scratch.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
+        for (auto& b : d_lane) b.release();
+        d_wave_row.release(); d_wave_rowidx.release(); d_lane_colidx.release();
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (evk0) (void)hipEventDestroy(evk0);
+        if (evk1) (void)hipEventDestroy(evk1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
+{
+    std::string err = gst::compile_plan(p->hp, opt ? opt->target_tasks : 0);
+    if (!err.empty()) { delete p; return fail(GST_EINVAL, err); }
+    if (p->hp.D != 4 && p->hp.D != 16) {
+        const int D = p->hp.D;
+        delete p;
+        return fail(GST_EUNSUPPORTED, "state dimension " + std::to_string(D) + " not supported in this round (4 or 16)");
+    }
+    p->device = opt ? opt->device : -1;
+    *out = p;
+    return GST_OK;
+}
+
+// Bring the plan onto the device (lazily, at the first call that needs it).
+int ensure_device(gst_plan* p)
+{
+    if (p->dev_ready) { HIP_TRY(hipSetDevice(p->device)); return GST_OK; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(GST_ENODEVICE, std::string("no HIP device available (") + hipGetErrorString(e) +
+                                       "); libgstfwd has no CPU fallback");
+    if (p->device < 0) { int cur = 0; HIP_TRY(hipGetDevice(&cur)); p->device = cur; }
+    if (p->device >= n) return fail(GST_ENODEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(p->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, p->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GST_ENODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&p->ev0)); HIP_TRY(hipEventCreate(&p->ev1));
+    HIP_TRY(hipEventCreate(&p->evk0)); HIP_TRY(hipEventCreate(&p->evk1));
+    const gst::HostPlan& h = p->hp;
+    HIP_TRY(p->d_prog.ensure(h.prog.size()));
+    HIP_TRY(p->d_task_off.ensure(h.task_off.size()));
+    HIP_TRY(p->d_eff_ptr.ensure(h.eff_ptr.size()));
+    HIP_TRY(p->d_eff_label.ensure(h.eff_label.size()));
+    HIP_TRY(p->d_eff_dest.ensure(h.eff_dest.size()));
+    HIP_TRY(hipMemcpy(p->d_prog.p, h.prog.data(), h.prog.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_task_off.p, h.task_off.data(), h.task_off.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_eff_ptr.p, h.eff_ptr.data(), h.eff_ptr.size() * 4, hipMemcpyHostToDevice));
+    if (!h.eff_label.empty()) {
+        HIP_TRY(hipMemcpy(p->d_eff_label.p, h.eff_label.data(), h.eff_label.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_eff_dest.p, h.eff_dest.data(), h.eff_dest.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(p->d_pbase.ensure(h.n_elements));
+    p->dev_ready = true;
+    return GST_OK;
+}
+
+int upload_model(gst_plan* p)
+{
+    const gst::HostPlan& h = p->hp;
+    HIP_TRY(p->d_gates.ensure(p->h_gates.size()));
+    HIP_TRY(p->d_gates_t.ensure(p->h_gates_t.size()));
+    HIP_TRY(p->d_rhos.ensure(p->h_rhos.size()));
+    HIP_TRY(p->d_effects.ensure(p->h_effects.size()));
+    if (!p->h_gates.empty()) {
+        HIP_TRY(hipMemcpyAsync(p->d_gates.p, p->h_gates.data(), p->h_gates.size() * 8, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_gates_t.p, p->h_gates_t.data(), p->h_gates_t.size() * 8, hipMemcpyHostToDevice, p->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(p->d_rhos.p, p->h_rhos.data(), p->h_rhos.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_effects.p, p->h_effects.data(), p->h_effects.size() * 8, hipMemcpyHostToDevice, p->stream));
+    (void)h;
+    return GST_OK;
+}
+
+void base_args(gst_plan* p, gst::WalkArgs& a)
+{
+    std::memset(&a, 0, sizeof(a));
+    a.prog = p->d_prog.p; a.task_off = p->d_task_off.p;
+    a.eff_ptr = p->d_eff_ptr.p; a.eff_label = p->d_eff_label.p; a.eff_dest = p->d_eff_dest.p;
+    a.gates = p->d_gates.p; a.gates_t = p->d_gates_t.p; a.rhos = p->d_rhos.p; a.effects = p->d_effects.p;
+    a.n_gates = p->hp.n_gates;
+    a.n_pwaves = 1;
+}
+
+// global-memory save slots for `blocks` wavefronts
+int ensure_scratch(gst_plan* p, int S, int64_t blocks, gst::WalkArgs& a)
+{
+    const int nreg = gst::reg_slots(p->hp.D, S);
+    const int extra = std::max(0, p->hp.max_slots - nreg);
+    a.n_scratch_slots = extra;
+    a.scratch = nullptr;
+    if (extra > 0) {
+        const size_t need = (size_t)blocks * extra * p->hp.D * 64;
+        HIP_TRY(p->d_scratch.ensure(need));
+        a.scratch = p->d_scratch.p;
+    }
+    return GST_OK;
+}
+
+// Base probabilities into d_dst (device), S = 0 walk: one wavefront per task.
+int run_probs(gst_plan* p, double* d_dst)
+{
+    gst::WalkArgs a;
+    base_args(p, a);
+    a.mode = gst::EMIT_PROBS;
+    a.out = d_dst;
+    int rc = ensure_scratch(p, 0, p->hp.n_tasks(), a);
+    if (rc) return rc;
+    HIP_TRY(gst::launch_walk(p->hp.D, 0, a, p->hp.n_tasks(), p->stream));
+    p->last_launches++;
+    return GST_OK;
+}
+
+struct LaneLayout {
+    std::vector<int32_t> col, kind[2], obj[2], elem[2];
+    int32_t n_waves = 0;
+};
+
+// Pack the requested parameter columns into wavefronts of 64 lanes.  Lanes of one wavefront should
+// perturb the same gate (the special-row work is paid per gate per wavefront): SPAM parameters are
+// packed together, each gate's parameters start on a wavefront boundary when the gate has >= 32
+// requested parameters.
+void pack_lanes(const gst_plan* p, const int64_t* param_idx, const int64_t* dest_idx, int64_t n, LaneLayout& L)
+{
+    struct Item { int32_t kind, obj, elem, col; };
+    std::vector<Item> spam, none;
+    std::vector<std::vector<Item>> per_gate(p->hp.n_gates);
+    for (int64_t c = 0; c < n; c++) {
+        const int64_t pi = param_idx[c];
+        Item it{p->pkind[pi], p->pobj[pi], p->pelem[pi], (int32_t)(dest_idx ? dest_idx[c] : c)};
+        if (it.kind == GST_KIND_GATE) per_gate[it.obj].push_back(it);
+        else if (it.kind == GST_KIND_NONE) none.push_back(it);
+        else spam.push_back(it);
+    }
+    auto push = [&](const Item& it) {
+        L.col.push_back(it.col); L.kind[0].push_back(it.kind); L.obj[0].push_back(it.obj); L.elem[0].push_back(it.elem);
+    };
+    auto pad = [&]() {
+        while (L.col.size() % 64) { L.col.push_back(-1); L.kind[0].push_back(GST_KIND_NONE); L.obj[0].push_back(0); L.elem[0].push_back(0); }
+    };
+    for (auto& it : spam) push(it);
+    for (auto& it : none) push(it);
+    for (auto& g : per_gate) {
+        if (g.size() >= 32) pad();
+        for (auto& it : g) push(it);
+    }
+    pad();
+    L.n_waves = (int32_t)(L.col.size() / 64);
+}
+
+int upload_i32(DevBuf<int32_t>& b, const std::vector<int32_t>& v, hipStream_t s)
+{
+    HIP_TRY(b.ensure(v.size()));
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice, s));
+    return GST_OK;
+}
+
+int check_params(const gst_plan* p, const int64_t* idx, int64_t n)
+{
+    if (n < 0) return fail(GST_EINVAL, "negative parameter count");
+    if (n > 0 && !idx) return fail(GST_EINVAL, "param_idx is NULL");
+    for (int64_t c = 0; c < n; c++)
+        if (idx[c] < 0 || idx[c] >= (int64_t)p->pkind.size()) return fail(GST_EINVAL, "parameter index out of range");
+    return GST_OK;
+}
+
+// FD Jacobian columns into device memory.  d_raw (optional) receives the perturbed probabilities.
+int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
+                  int64_t n_param, double eps, double* d_probs_out, double* d_raw, int64_t ldraw)
+{
+    // base probabilities (pyx:349)
+    double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
+    int rc = run_probs(p, d_base);
+    if (rc) return rc;
+    if (n_param == 0) return GST_OK;
+    LaneLayout L;
+    pack_lanes(p, param_idx, dest_idx, n_param, L);
+    // the host vectors must outlive the async copies: synchronous small copies instead
+    if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_lane[1], L.kind[0], p->stream))) return rc;
+    if ((rc = upload_i32(p->d_lane[2], L.obj[0], p->stream))) return rc;
+    if ((rc = upload_i32(p->d_lane[3], L.elem[0], p->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    gst::WalkArgs a;
+    base_args(p, a);
+    a.mode = gst::EMIT_FD;
+    a.out = d_out; a.ld = ld; a.eps = eps; a.pbase = d_base;
+    a.raw = d_raw; a.ldraw = ldraw;
+    a.lanes.col = p->d_lane[0].p; a.lanes.kind[0] = p->d_lane[1].p; a.lanes.obj[0] = p->d_lane[2].p; a.lanes.elem[0] = p->d_lane[3].p;
+    a.n_pwaves = L.n_waves;
+    const int64_t blocks = p->hp.n_tasks() * (int64_t)L.n_waves;
+    if ((rc = ensure_scratch(p, 1, blocks, a))) return rc;
+    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    HIP_TRY(gst::launch_walk(p->hp.D, 1, a, p->hp.n_tasks(), p->stream));
+    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    p->last_launches++;
+    return GST_OK;
+}
+
+int begin_call(gst_plan* p)
+{
+    if (!p) return fail(GST_EINVAL, "plan is NULL");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    if (!p->have_model) return fail(GST_ESTATE, "gst_set_model has not been called");
+    p->last_launches = 0;
+    p->last_kernel_ms = 0;
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    return upload_model(p);
+}
+
+int end_call(gst_plan* p, bool sync)
+{
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    if (sync) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_total_ms = ms;
+        if (hipEventElapsedTime(&ms, p->evk0, p->evk1) == hipSuccess) p->last_kernel_ms = ms;
+    }
+    return GST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gst_last_error(void) { return g_err.c_str(); }
+const char* gst_version(void) { return "gstfwd 0.1 (gfx950)"; }
+
+int gst_device_count(int32_t* n)
+{
+    if (!n) return fail(GST_EINVAL, "n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *n = (e == hipSuccess) ? c : 0;
+    return GST_OK;
+}
+
+int gst_plan_create_from_table(const gst_table_desc* d, const gst_options* opt, gst_plan** out)
+{
+    if (!d || !out) return fail(GST_EINVAL, "NULL argument");
+    *out = nullptr;
+    gst_plan* p = new (std::nothrow) gst_plan();
+    if (!p) return fail(GST_ENOMEM, "out of host memory");
+    try {
+        gst::HostPlan& h = p->hp;
+        h.D = d->D; h.n_gates = d->n_gates; h.n_rhos = d->n_rhos; h.n_effects = d->n_effects;
+        h.n_elements = d->n_elements;
+        if (d->n_rows < 0 || !d->t_dest || !d->t_start || !d->t_cache || !d->t_rho || !d->row_ptr || !d->eff_ptr) {
+            delete p; return fail(GST_EINVAL, "table arrays missing");
+        }
+        std::string err = gst::expand_table(h, d->n_rows, d->cache_size, d->t_dest, d->t_start, d->t_cache,
+                                            d->t_rho, d->row_ptr, d->gate_idx);
+        if (!err.empty()) { delete p; return fail(GST_EINVAL, err); }
+        if (d->eff_ptr[d->n_rows] > 0x7fffffffLL) { delete p; return fail(GST_EINVAL, "too many elements"); }
+        h.eff_ptr.resize(d->n_rows + 1);
+        for (int32_t i = 0; i <= d->n_rows; i++) h.eff_ptr[i] = (int32_t)d->eff_ptr[i];
+        h.eff_label.assign(d->eff_label, d->eff_label + d->eff_ptr[d->n_rows]);
+        h.eff_dest.assign(d->eff_dest, d->eff_dest + d->eff_ptr[d->n_rows]);
+        return finish_create(p, opt, out);
+    } catch (const std::bad_alloc&) {
+        delete p; return fail(GST_ENOMEM, "out of host memory while compiling the plan");
+    }
+}
+
+int gst_plan_create_from_circuits(const gst_circuits_desc* d, const gst_options* opt, gst_plan** out)
+{
+    if (!d || !out) return fail(GST_EINVAL, "NULL argument");
+    *out = nullptr;
+    gst_plan* p = new (std::nothrow) gst_plan();
+    if (!p) return fail(GST_ENOMEM, "out of host memory");
+    try {
+        gst::HostPlan& h = p->hp;
+        h.D = d->D; h.n_gates = d->n_gates; h.n_rhos = d->n_rhos; h.n_effects = d->n_effects;
+        h.n_elements = d->n_elements; h.n_circuits = d->n_circuits;
+        if (d->n_circuits < 0 || !d->circ_rho || !d->circ_ptr || !d->eff_ptr) { delete p; return fail(GST_EINVAL, "circuit arrays missing"); }
+        const int64_t nC = d->n_circuits;
+        h.circ_rho.assign(d->circ_rho, d->circ_rho + nC);
+        h.circ_ptr.assign(d->circ_ptr, d->circ_ptr + nC + 1);
+        if (h.circ_ptr[nC] < 0) { delete p; return fail(GST_EINVAL, "bad circ_ptr"); }
+        if (h.circ_ptr[nC] > 0) h.circ_gates.assign(d->circ_gates, d->circ_gates + h.circ_ptr[nC]);
+        if (d->eff_ptr[nC] > 0x7fffffffLL || d->eff_ptr[nC] < 0) { delete p; return fail(GST_EINVAL, "bad eff_ptr"); }
+        h.eff_ptr.resize(nC + 1);
+        for (int64_t i = 0; i <= nC; i++) h.eff_ptr[i] = (int32_t)d->eff_ptr[i];
+        h.eff_label.assign(d->eff_label, d->eff_label + d->eff_ptr[nC]);
+        h.eff_dest.assign(d->eff_dest, d->eff_dest + d->eff_ptr[nC]);
+        return finish_create(p, opt, out);
+    } catch (const std::bad_alloc&) {
+        delete p; return fail(GST_ENOMEM, "out of host memory while compiling the plan");
+    }
+}
+
+int gst_plan_destroy(gst_plan* plan)
+{
+    delete plan;
+    return GST_OK;
+}
+
+int gst_set_model(gst_plan* p, const double* gates, const double* rhos, const double* effects)
+{
+    if (!p || !rhos || !effects || (p->hp.n_gates > 0 && !gates)) return fail(GST_EINVAL, "NULL argument");
+    const int D = p->hp.D;
+    const size_t ng = (size_t)p->hp.n_gates * D * D;
+    p->h_gates.assign(gates, gates + ng);
+    p->h_gates_t.resize(ng);
+    for (int g = 0; g < p->hp.n_gates; g++)
+        for (int i = 0; i < D; i++)
+            for (int j = 0; j < D; j++)
+                p->h_gates_t[((size_t)g * D + j) * D + i] = gates[((size_t)g * D + i) * D + j];
+    p->h_rhos.assign(rhos, rhos + (size_t)p->hp.n_rhos * D);
+    p->h_effects.assign(effects, effects + (size_t)p->hp.n_effects * D);
+    p->have_model = true;
+    return GST_OK;
+}
+
+int gst_set_param_map(gst_plan* p, int32_t n_params, const int32_t* kind, const int32_t* obj, const int32_t* elem)
+{
+    if (!p || n_params < 0 || (n_params > 0 && (!kind || !obj || !elem))) return fail(GST_EINVAL, "bad argument");
+    const int D = p->hp.D;
+    for (int32_t i = 0; i < n_params; i++) {
+        const int k = kind[i];
+        if (k == GST_KIND_NONE) continue;
+        const int nobj = k == GST_KIND_GATE ? p->hp.n_gates : k == GST_KIND_RHO ? p->hp.n_rhos : k == GST_KIND_EFFECT ? p->hp.n_effects : -1;
+        const int nel = k == GST_KIND_GATE ? D * D : D;
+        if (nobj < 0 || obj[i] < 0 || obj[i] >= nobj || elem[i] < 0 || elem[i] >= nel)
+            return fail(GST_EINVAL, "parameter map entry " + std::to_string(i) + " out of range");
+    }
+    p->pkind.assign(kind, kind + n_params);
+    p->pobj.assign(obj, obj + n_params);
+    p->pelem.assign(elem, elem + n_params);
+    p->have_pmap = true;
+    return GST_OK;
+}
+
+int gst_fill_probs_dev(gst_plan* p, double* d_out)
+{
+    int rc = begin_call(p);
+    if (rc) return rc;
+    if (!d_out) return fail(GST_EINVAL, "d_out is NULL");
+    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    if ((rc = run_probs(p, d_out))) return rc;
+    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    return end_call(p, false);
+}
+
+int gst_fill_probs(gst_plan* p, double* out)
+{
+    int rc = begin_call(p);
+    if (rc) return rc;
+    if (!out) return fail(GST_EINVAL, "out is NULL");
+    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    if ((rc = run_probs(p, p->d_pbase.p))) return rc;
+    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    HIP_TRY(hipMemcpyAsync(out, p->d_pbase.p, p->hp.n_elements * 8, hipMemcpyDeviceToHost, p->stream));
+    return end_call(p, true);
+}
+
+int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
+                        int64_t n_param, int mode, double eps, double* d_probs_out)
+{
+    int rc = begin_call(p);
+    if (rc) return rc;
+    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
+    if (mode != GST_DERIV_FD) return fail(GST_EUNSUPPORTED, "only GST_DERIV_FD is implemented in this round");
+    if (!d_out && n_param > 0) return fail(GST_EINVAL, "d_out is NULL");
+    if ((rc = check_params(p, param_idx, n_param))) return rc;
+    if ((rc = run_dprobs_fd(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out, nullptr, 0))) return rc;
+    return end_call(p, false);
+}
+
+int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
+                    int64_t n_param, int mode, double eps, double* probs_out)
+{
+    int rc = begin_call(p);
+    if (rc) return rc;
+    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
+    if (mode != GST_DERIV_FD) return fail(GST_EUNSUPPORTED, "only GST_DERIV_FD is implemented in this round");
+    if (!out && n_param > 0) return fail(GST_EINVAL, "out is NULL");
+    if ((rc = check_params(p, param_idx, n_param))) return rc;
+    const int64_t nE = p->hp.n_elements;
+    // device staging is dense [nE][n_param]; scattered into the caller's (ld, dest_idx) window on the host
+    HIP_TRY(p->d_out.ensure((size_t)nE * std::max<int64_t>(n_param, 1)));
+    if ((rc = run_dprobs_fd(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr, nullptr, 0))) return rc;
+    std::vector<double> stage;
+    const bool direct = (!dest_idx && ld == n_param);
+    double* dst = out;
+    if (!direct) { stage.resize((size_t)nE * n_param); dst = stage.data(); }
+    if (n_param > 0) HIP_TRY(hipMemcpyAsync(dst, p->d_out.p, (size_t)nE * n_param * 8, hipMemcpyDeviceToHost, p->stream));
+    if (probs_out) HIP_TRY(hipMemcpyAsync(probs_out, p->d_pbase.p, nE * 8, hipMemcpyDeviceToHost, p->stream));
+    if ((rc = end_call(p, true))) return rc;
+    if (!direct)
+        for (int64_t k = 0; k < nE; k++)
+            for (int64_t c = 0; c < n_param; c++)
+                out[k * ld + (dest_idx ? dest_idx[c] : c)] = stage[(size_t)k * n_param + c];
+    return GST_OK;
+}
+
+int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
+                    int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2, double eps)
+{
+    int rc = begin_call(p);
+    if (rc) return rc;
+    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
+    if (!out && n1 > 0 && n2 > 0) return fail(GST_EINVAL, "out is NULL");
+    if ((rc = check_params(p, idx1, n1)) || (rc = check_params(p, idx2, n2))) return rc;
+    const int64_t nE = p->hp.n_elements;
+    if (n1 == 0 || n2 == 0) return end_call(p, true);
+    // (1) dprobs over block 2 at theta (mapforwardsim.py:420-421), FD step = eps
+    HIP_TRY(p->d_dcol.ensure((size_t)nE * n2));
+    if ((rc = run_dprobs_fd(p, p->d_dcol.p, n2, idx2, nullptr, n2, eps, nullptr, nullptr, 0))) return rc;
+    // (2) probabilities at theta + eps e_i for every i of block 1 (the `probs` of the inner FD, pyx:349)
+    HIP_TRY(p->d_raw.ensure((size_t)nE * n1));
+    HIP_TRY(p->d_probs_tmp.ensure((size_t)nE * n1));
+    if ((rc = run_dprobs_fd(p, p->d_probs_tmp.p, n1, idx1, nullptr, n1, eps, nullptr, p->d_raw.p, n1))) return rc;
+    // (3) all (i, j) pairs: wavefront = (row i, 64 columns j)
+    LaneLayout L2;
+    pack_lanes(p, idx2, nullptr, n2, L2);   // col = position in block 2
+    const int32_t w2 = L2.n_waves;
+    LaneLayout L;
+    std::vector<int32_t> wave_row, wave_rowidx, lane_colidx;
+    for (int64_t a = 0; a < n1; a++) {
+        const int64_t pi = idx1[a];
+        for (int32_t w = 0; w < w2; w++) {
+            wave_row.push_back((int32_t)(dest1 ? dest1[a] : a));
+            wave_rowidx.push_back((int32_t)a);
+            for (int q = 0; q < 64; q++) {
+                const size_t s = (size_t)w * 64 + q;
+                const int32_t c = L2.col[s];
+                L.col.push_back(c < 0 ? -1 : (int32_t)(dest2 ? dest2[c] : c));
+                lane_colidx.push_back(c < 0 ? 0 : c);
+                L.kind[0].push_back(p->pkind[pi]); L.obj[0].push_back(p->pobj[pi]); L.elem[0].push_back(p->pelem[pi]);
+                L.kind[1].push_back(L2.kind[0][s]); L.obj[1].push_back(L2.obj[0][s]); L.elem[1].push_back(L2.elem[0][s]);
+            }
+        }
+    }
+    L.n_waves = (int32_t)(L.col.size() / 64);
+    if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
+    for (int s = 0; s < 2; s++) {
+        if ((rc = upload_i32(p->d_lane[1 + 3 * s], L.kind[s], p->stream))) return rc;
+        if ((rc = upload_i32(p->d_lane[2 + 3 * s], L.obj[s], p->stream))) return rc;
+        if ((rc = upload_i32(p->d_lane[3 + 3 * s], L.elem[s], p->stream))) return rc;
+    }
+    if ((rc = upload_i32(p->d_wave_row, wave_row, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_wave_rowidx, wave_rowidx, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_lane_colidx, lane_colidx, p->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    // dense device output [nE][n1'][n2'] in the caller's leading dimensions
+    HIP_TRY(p->d_out.ensure((size_t)nE * ld1 * ld2));
+    gst::WalkArgs a;
+    base_args(p, a);
+    a.mode = gst::EMIT_HESS;
+    a.out = p->d_out.p; a.ld = ld1; a.ld2 = ld2; a.eps = eps;
+    a.prow = p->d_raw.p; a.ldrow = n1; a.dcol = p->d_dcol.p; a.lddcol = n2;
+    a.lanes.col = p->d_lane[0].p;
+    for (int s = 0; s < 2; s++) {
+        a.lanes.kind[s] = p->d_lane[1 + 3 * s].p; a.lanes.obj[s] = p->d_lane[2 + 3 * s].p; a.lanes.elem[s] = p->d_lane[3 + 3 * s].p;
+    }
+    a.wave_row = p->d_wave_row.p; a.wave_rowidx = p->d_wave_rowidx.p; a.lane_colidx = p->d_lane_colidx.p;
+    a.n_pwaves = L.n_waves;
+    const int64_t blocks = p->hp.n_tasks() * (int64_t)L.n_waves;
+    if ((rc = ensure_scratch(p, 2, blocks, a))) return rc;
+    // rows/columns of the caller's block that this call does not own must survive: start from the caller's data
+    const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
+    if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    HIP_TRY(gst::launch_walk(p->hp.D, 2, a, p->hp.n_tasks(), p->stream));
+    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    p->last_launches++;
+    HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));
+    return end_call(p, true);
+}
+
+int gst_sync(gst_plan* p)
+{
+    if (!p) return fail(GST_EINVAL, "plan is NULL");
+    if (!p->dev_ready) return GST_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_total_ms = ms;
+    if (hipEventElapsedTime(&ms, p->evk0, p->evk1) == hipSuccess) p->last_kernel_ms = ms;
+    return GST_OK;
+}
+
+int gst_get_stats(const gst_plan* p, gst_stats* s)
+{
+    if (!p || !s) return fail(GST_EINVAL, "NULL argument");
+    const gst::HostPlan& h = p->hp;
+    s->n_circuits = h.n_circuits; s->n_elements = h.n_elements; s->sum_depth = h.sum_depth;
+    s->trie_nodes = h.trie_nodes; s->applies_per_pass = h.applies_per_pass; s->n_tasks = h.n_tasks();
+    s->prog_words = (int64_t)h.prog.size(); s->max_slots = h.max_slots; s->max_depth = h.max_depth;
+    s->last_kernel_ms = p->last_kernel_ms; s->last_total_ms = p->last_total_ms; s->last_launches = p->last_launches;
+    return GST_OK;
+}
+
+int gst_get_program(const gst_plan* p, uint32_t* words, int64_t cap, int64_t* n_words, int64_t* task_off, int64_t cap_tasks)
+{
+    if (!p || !n_words) return fail(GST_EINVAL, "NULL argument");
+    const gst::HostPlan& h = p->hp;
+    *n_words = (int64_t)h.prog.size();
+    if (words && cap > 0) std::memcpy(words, h.prog.data(), sizeof(uint32_t) * std::min<int64_t>(cap, *n_words));
+    if (task_off && cap_tasks >= (int64_t)h.task_off.size())
+        std::memcpy(task_off, h.task_off.data(), sizeof(int64_t) * h.task_off.size());
+    return GST_OK;
+}
+
+}  // extern "C"

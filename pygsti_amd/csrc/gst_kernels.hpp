@@ -1,0 +1,65 @@
+// gst_kernels.hpp -- launch interface between the C ABI (gst_abi.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace gst {
+
+// Per-lane perturbation ("special") tables, one entry per lane slot (n_waves * 64 entries).
+// Lane slot q of wave w = w*64 + q.  kind -1 = no perturbation for that special.
+struct LaneTables {
+    const int32_t* col;     // output column (dest index) of the lane, -1 = idle lane
+    const int32_t* kind[2]; // GST_KIND_* of special s
+    const int32_t* obj[2];
+    const int32_t* elem[2];
+};
+
+enum EmitMode : int32_t {
+    EMIT_PROBS = 0,   // out[dest] = p                                   (lane 0 of the wave writes)
+    EMIT_FD = 1,      // out[dest*ld + col] = (p - pbase[dest]) / eps    (+ optional raw[dest*ldraw + col] = p)
+    EMIT_HESS = 2,    // out[(dest*ld + row)*ld2 + col] = ((p - prow[dest*ldrow + rowidx]) / eps - dcol[dest*lddcol + colidx]) / eps
+};
+
+struct WalkArgs {
+    // plan (device)
+    const uint32_t* prog;
+    const int64_t* task_off;
+    const int32_t* eff_ptr;
+    const int32_t* eff_label;
+    const int32_t* eff_dest;
+    // model (device)
+    const double* gates;     // [nG][D][D] row-major (special-row set-up)
+    const double* gates_t;   // [nG][D][D] transposed: gates_t[g][j][i] = gates[g][i][j] (column sweeps)
+    const double* rhos;
+    const double* effects;
+    int32_t n_gates;
+    // lanes
+    LaneTables lanes;
+    int32_t n_pwaves;        // wavefronts along the parameter dimension (grid.x)
+    // output
+    int32_t mode;
+    double* out;
+    int64_t ld, ld2;
+    double eps;
+    const double* pbase;     // EMIT_FD: base probabilities [nE]
+    double* raw;             // EMIT_FD: optional raw perturbed probabilities [nE][ldraw]
+    int64_t ldraw;
+    const double* prow;      // EMIT_HESS: probs at theta+eps e_i      [nE][ldrow]
+    int64_t ldrow;
+    const double* dcol;      // EMIT_HESS: FD dprobs at theta over block 2 [nE][lddcol]
+    int64_t lddcol;
+    const int32_t* wave_row;     // EMIT_HESS: per wave: dest row (block-1 position) and its index into prow
+    const int32_t* wave_rowidx;
+    const int32_t* lane_colidx;  // EMIT_HESS: per lane slot: index into dcol's columns
+    // save slots beyond the register-resident ones: [wave][slot][D][64]
+    double* scratch;
+    int32_t n_scratch_slots;
+};
+
+// Number of save slots the kernels keep in registers for state dimension D and S specials.
+int reg_slots(int D, int S);
+
+// Launch the walk over all tasks x parameter wavefronts.  S = number of specials per lane (0,1,2).
+hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, hipStream_t stream);
+
+}  // namespace gst

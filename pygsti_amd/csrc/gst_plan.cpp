@@ -1,0 +1,286 @@
+// gst_plan.cpp -- see gst_plan.hpp.  Pure host C++ (no HIP), unit-testable without a GPU through
+// gst_plan_create_* + gst_get_program (tests/test_plan_compiler.py interprets the programs in numpy).
+#include "gst_plan.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "../../include/gstfwd.h"
+
+namespace gst {
+
+std::string expand_table(HostPlan& P, int32_t n_rows, int32_t cache_size, const int32_t* t_dest,
+                         const int32_t* t_start, const int32_t* t_cache, const int32_t* t_rho,
+                         const int64_t* row_ptr, const int32_t* gate_idx)
+{
+    // circuit[t_dest[k]] = cached[t_start[k]] + gates(row k); cached[t_cache[k]] = circuit[t_dest[k]]
+    // (mapforwardsim_calc_densitymx.pyx:228-277).  Rows are in evaluation order.
+    if (n_rows < 0 || cache_size < 0) return "negative n_rows/cache_size";
+    std::vector<int64_t> len(n_rows, -1);
+    std::vector<int32_t> cache_owner(cache_size, -1);   // expanded-circuit index held in each slot
+    P.n_circuits = n_rows;
+    P.circ_rho.assign(n_rows, -1);
+    // first pass: lengths
+    for (int32_t k = 0; k < n_rows; k++) {
+        const int32_t i = t_dest[k];
+        if (i < 0 || i >= n_rows || len[i] != -1) return "t_dest is not a permutation of the rows";
+        if (row_ptr[k + 1] < row_ptr[k]) return "row_ptr not monotone";
+        int64_t base = 0;
+        if (t_start[k] == -1) {
+            if (t_rho[k] < 0 || t_rho[k] >= P.n_rhos) return "t_rho out of range";
+            P.circ_rho[i] = t_rho[k];
+        } else {
+            if (t_start[k] < 0 || t_start[k] >= cache_size || cache_owner[t_start[k]] < 0)
+                return "t_start refers to a cache slot that has not been written yet";
+            const int32_t src = cache_owner[t_start[k]];
+            base = len[src];
+            P.circ_rho[i] = P.circ_rho[src];
+        }
+        len[i] = base + (row_ptr[k + 1] - row_ptr[k]);
+        if (t_cache[k] != -1) {
+            if (t_cache[k] < 0 || t_cache[k] >= cache_size) return "t_cache out of range";
+            cache_owner[t_cache[k]] = i;
+        }
+    }
+    P.circ_ptr.assign(n_rows + 1, 0);
+    for (int32_t i = 0; i < n_rows; i++) P.circ_ptr[i + 1] = P.circ_ptr[i] + len[i];
+    P.circ_gates.resize(P.circ_ptr[n_rows]);
+    std::fill(cache_owner.begin(), cache_owner.end(), -1);
+    for (int32_t k = 0; k < n_rows; k++) {
+        const int32_t i = t_dest[k];
+        int32_t* dst = P.circ_gates.data() + P.circ_ptr[i];
+        int64_t base = 0;
+        if (t_start[k] != -1) {
+            const int32_t src = cache_owner[t_start[k]];
+            base = len[src];
+            std::memcpy(dst, P.circ_gates.data() + P.circ_ptr[src], sizeof(int32_t) * base);
+        }
+        const int64_t n = row_ptr[k + 1] - row_ptr[k];
+        if (n) std::memcpy(dst + base, gate_idx + row_ptr[k], sizeof(int32_t) * n);
+        if (t_cache[k] != -1) cache_owner[t_cache[k]] = i;
+    }
+    return "";
+}
+
+namespace {
+
+struct Node {
+    int32_t sym;          // rho index at depth 1, gate index deeper
+    int32_t first_child = -1, last_child = -1, next_sibling = -1;
+    int32_t n_children = 0;
+    int32_t emit_head = -1;   // index into emit list (linked through emit_next)
+    int32_t need = 0;         // save slots needed below this node
+    int32_t weight = 0;       // nodes in subtree (tie-break)
+};
+
+struct TaskCompiler {
+    const HostPlan& P;
+    std::vector<Node> nodes;
+    std::vector<int32_t> emit_circ, emit_next;
+    std::vector<uint32_t>& prog;
+    int32_t max_slot_used = 0;
+
+    TaskCompiler(const HostPlan& p, std::vector<uint32_t>& out) : P(p), prog(out) {}
+
+    int32_t sym_at(int32_t c, int64_t pos) const   // pos 0 = rho
+    {
+        return pos == 0 ? P.circ_rho[c] : P.circ_gates[P.circ_ptr[c] + pos - 1];
+    }
+
+    // Build the local trie of sorted circuits order[a..b) (lcp[k] = common symbols of k-1 and k).
+    void build(const std::vector<int32_t>& order, const std::vector<int64_t>& lcp, int64_t a, int64_t b)
+    {
+        nodes.clear(); emit_circ.clear(); emit_next.clear();
+        nodes.push_back(Node{-1});                 // virtual root (depth 0)
+        std::vector<int32_t> path{0};              // path[d] = node at depth d
+        for (int64_t k = a; k < b; k++) {
+            const int32_t c = order[k];
+            const int64_t L = 1 + (P.circ_ptr[c + 1] - P.circ_ptr[c]);
+            const int64_t common = (k == a) ? 0 : std::min<int64_t>(lcp[k], L);
+            path.resize(common + 1);
+            for (int64_t d = common; d < L; d++) {
+                Node n{sym_at(c, d)};
+                const int32_t id = (int32_t)nodes.size();
+                Node& par = nodes[path.back()];
+                if (par.last_child >= 0) nodes[par.last_child].next_sibling = id; else par.first_child = id;
+                par.last_child = id;
+                par.n_children++;
+                nodes.push_back(n);
+                path.push_back(id);
+            }
+            const int32_t e = (int32_t)emit_circ.size();
+            emit_circ.push_back(c);
+            emit_next.push_back(-1);
+            // append at tail of the node's emit list (keeps circuit order deterministic)
+            Node& end = nodes[path.back()];
+            if (end.emit_head < 0) end.emit_head = e;
+            else { int32_t t = end.emit_head; while (emit_next[t] >= 0) t = emit_next[t]; emit_next[t] = e; }
+        }
+        // children are created after their parents: reverse index order is a post-order
+        for (int32_t i = (int32_t)nodes.size() - 1; i >= 0; i--) {
+            Node& n = nodes[i];
+            n.weight = 1;
+            int32_t best = -1, second = -1;   // largest and second-largest child need
+            for (int32_t ch = n.first_child; ch >= 0; ch = nodes[ch].next_sibling) {
+                n.weight += nodes[ch].weight;
+                const int32_t nd = nodes[ch].need;
+                if (nd > best) { second = best; best = nd; } else if (nd > second) second = nd;
+            }
+            if (n.n_children <= 1) n.need = std::max(best, 0);
+            else n.need = std::max(best, second + 1);   // max-need child goes last and reuses the slot
+        }
+    }
+
+    void op(int32_t node, int depth)
+    {
+        prog.push_back(((depth == 1 ? GST_OP_RHO : GST_OP_APPLY) << 28) | (uint32_t)nodes[node].sym);
+    }
+
+    // emit the program for the subtree below `node` (whose state is in v), free slots from `base`
+    void walk(int32_t node, int depth, int32_t base)
+    {
+        for (;;) {
+            for (int32_t e = nodes[node].emit_head; e >= 0; e = emit_next[e])
+                prog.push_back((GST_OP_EMIT << 28) | (uint32_t)emit_circ[e]);
+            const Node& n = nodes[node];
+            if (n.n_children == 0) return;
+            if (n.n_children == 1) {             // chain: iterate, do not recurse
+                node = n.first_child; depth++;
+                op(node, depth);
+                continue;
+            }
+            // pick the child that goes last: largest need, then largest subtree
+            int32_t last = -1;
+            for (int32_t ch = n.first_child; ch >= 0; ch = nodes[ch].next_sibling)
+                if (last < 0 || nodes[ch].need > nodes[last].need ||
+                    (nodes[ch].need == nodes[last].need && nodes[ch].weight > nodes[last].weight))
+                    last = ch;
+            const bool root = (depth == 0);      // children of the root start from a rho: nothing to save
+            if (!root) {
+                prog.push_back((GST_OP_SAVE << 28) | (uint32_t)base);
+                max_slot_used = std::max(max_slot_used, base + 1);
+            }
+            bool first = true;
+            for (int32_t ch = n.first_child; ch >= 0; ch = nodes[ch].next_sibling) {
+                if (ch == last) continue;
+                if (!first && !root) prog.push_back((GST_OP_LOAD << 28) | (uint32_t)base);
+                first = false;
+                op(ch, depth + 1);
+                walk(ch, depth + 1, root ? base : base + 1);
+            }
+            if (!root) prog.push_back((GST_OP_LOAD << 28) | (uint32_t)base);
+            node = last; depth++;
+            op(node, depth);                     // continue into the last child with slot `base` free again
+        }
+    }
+};
+
+}  // namespace
+
+std::string compile_plan(HostPlan& P, int32_t target_tasks)
+{
+    const int64_t nC = P.n_circuits;
+    if (P.D <= 0 || P.n_gates < 0 || P.n_rhos <= 0 || P.n_effects <= 0) return "bad dimensions";
+    if ((int64_t)P.circ_rho.size() != nC || (int64_t)P.circ_ptr.size() != nC + 1) return "circuit arrays have wrong size";
+    if ((int64_t)P.eff_ptr.size() != nC + 1) return "effect CSR has wrong size";
+    if (P.n_gates >= (1 << 28) || nC >= (1 << 28)) return "plan too large for the 28-bit program argument";
+    for (int64_t i = 0; i < nC; i++) {
+        if (P.circ_rho[i] < 0 || P.circ_rho[i] >= P.n_rhos) return "circ_rho out of range";
+        if (P.circ_ptr[i + 1] < P.circ_ptr[i]) return "circ_ptr not monotone";
+        if (P.eff_ptr[i + 1] < P.eff_ptr[i]) return "eff_ptr not monotone";
+    }
+    if ((int64_t)P.circ_gates.size() != P.circ_ptr[nC]) return "circ_gates has wrong size";
+    for (int32_t g : P.circ_gates) if (g < 0 || g >= P.n_gates) return "gate index out of range";
+    if ((int64_t)P.eff_label.size() != P.eff_ptr[nC] || P.eff_dest.size() != P.eff_label.size())
+        return "effect arrays have wrong size";
+    std::vector<uint8_t> seen(P.n_elements, 0);
+    for (size_t x = 0; x < P.eff_label.size(); x++) {
+        if (P.eff_label[x] < 0 || P.eff_label[x] >= P.n_effects) return "effect label out of range";
+        const int32_t d = P.eff_dest[x];
+        if (d < 0 || d >= P.n_elements) return "element index out of range";
+        if (seen[d]) return "element index assigned twice";
+        seen[d] = 1;
+    }
+
+    // --- sort circuits lexicographically on (rho, gates...) --------------------------------------
+    std::vector<int32_t> order(nC);
+    std::iota(order.begin(), order.end(), 0);
+    const int32_t* G = P.circ_gates.data();
+    const int64_t* ptr = P.circ_ptr.data();
+    auto less = [&](int32_t a, int32_t b) {
+        if (P.circ_rho[a] != P.circ_rho[b]) return P.circ_rho[a] < P.circ_rho[b];
+        const int64_t la = ptr[a + 1] - ptr[a], lb = ptr[b + 1] - ptr[b];
+        const int32_t *pa = G + ptr[a], *pb = G + ptr[b];
+        const int64_t n = std::min(la, lb);
+        for (int64_t i = 0; i < n; i++) if (pa[i] != pb[i]) return pa[i] < pb[i];
+        if (la != lb) return la < lb;
+        return a < b;
+    };
+    std::sort(order.begin(), order.end(), less);
+    std::vector<int64_t> lcp(nC, 0);   // common symbols (rho counts as one) with the previous circuit
+    P.sum_depth = 0; P.trie_nodes = 0; P.max_depth = 0;
+    for (int64_t k = 0; k < nC; k++) {
+        const int32_t c = order[k];
+        const int64_t L = ptr[c + 1] - ptr[c];
+        P.sum_depth += L;
+        P.max_depth = std::max<int32_t>(P.max_depth, (int32_t)L);
+        if (k > 0) {
+            const int32_t p = order[k - 1];
+            if (P.circ_rho[p] == P.circ_rho[c]) {
+                const int64_t Lp = ptr[p + 1] - ptr[p], n = std::min(L, Lp);
+                int64_t i = 0;
+                while (i < n && G[ptr[p] + i] == G[ptr[c] + i]) i++;
+                lcp[k] = 1 + i;
+            }
+        }
+        P.trie_nodes += (1 + L) - lcp[k];
+    }
+
+    // --- cut the sorted list into tasks ------------------------------------------------------------
+    // A task restarts from rho, so cutting before circuit k re-computes lcp[k]-1 gate applications.
+    // Cut only where that is small against the task being closed (<= 5% of the grain).
+    if (target_tasks <= 0) target_tasks = 2048;
+    const int64_t grain = std::max<int64_t>(32, P.trie_nodes / target_tasks);
+    const int64_t max_restart = std::max<int64_t>(2, grain / 20);
+    std::vector<int64_t> cuts{0};
+    int64_t cur = 0;
+    for (int64_t k = 0; k < nC; k++) {
+        const int32_t c = order[k];
+        const int64_t L = 1 + (ptr[c + 1] - ptr[c]);
+        if (k > 0 && cur >= grain && lcp[k] - 1 <= max_restart) { cuts.push_back(k); cur = 0; }
+        cur += (cur == 0) ? L : L - lcp[k];
+    }
+    cuts.push_back(nC);
+
+    // --- compile each task ----------------------------------------------------------------------------
+    struct Built { std::vector<uint32_t> words; int64_t applies; };
+    std::vector<Built> built;
+    built.reserve(cuts.size());
+    P.max_slots = 0;
+    P.applies_per_pass = 0;
+    for (size_t t = 0; t + 1 < cuts.size(); t++) {
+        if (cuts[t] == cuts[t + 1]) continue;
+        Built b;
+        TaskCompiler tc(P, b.words);
+        tc.build(order, lcp, cuts[t], cuts[t + 1]);
+        tc.walk(0, 0, 0);
+        b.words.push_back(GST_OP_END << 28);
+        b.applies = 0;
+        for (uint32_t w : b.words) b.applies += (GST_OP(w) == GST_OP_APPLY);
+        P.max_slots = std::max(P.max_slots, tc.max_slot_used);
+        P.applies_per_pass += b.applies;
+        built.push_back(std::move(b));
+    }
+    // heaviest first: the device takes tasks in launch order, long ones should not start last
+    std::stable_sort(built.begin(), built.end(), [](const Built& a, const Built& b) { return a.applies > b.applies; });
+    P.prog.clear(); P.task_off.assign(1, 0); P.task_applies.clear();
+    for (auto& b : built) {
+        P.prog.insert(P.prog.end(), b.words.begin(), b.words.end());
+        P.task_off.push_back((int64_t)P.prog.size());
+        P.task_applies.push_back(b.applies);
+    }
+    return "";
+}
+
+}  // namespace gst

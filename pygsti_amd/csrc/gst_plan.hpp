@@ -1,0 +1,50 @@
+// gst_plan.hpp -- host-side plan compiler: circuits -> prefix trie -> walk programs.
+//
+// Replaces, for the device path, what the reference does in PrefixTable (pygsti/layouts/prefixtable.py:26-101,
+// 680-741: sort by length, cache only prefixes that are themselves circuits) and convert_maplayout
+// (pygsti/forwardsims/mapforwardsim_calc_densitymx.pyx:55-77).  Design differs on purpose:
+//   * sharing is over the FULL prefix trie (every distinct prefix is one state), not only over
+//     prefixes that happen to be circuits;
+//   * the trie is cut into independent "tasks" (contiguous runs of lexicographically sorted
+//     circuits); each task is compiled to a linear walk program (RHO/APPLY/SAVE/LOAD/EMIT) that one
+//     wavefront interprets, with save slots assigned statically (no run-time stack pointer).
+// Every state is still rho followed by the circuit's gates applied left to right, so results are
+// bit-identical to the reference's table walk whatever the sharing structure.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace gst {
+
+struct HostPlan {
+    int32_t D = 0, n_gates = 0, n_rhos = 0, n_effects = 0;
+    int64_t n_circuits = 0, n_elements = 0;
+
+    // expanded circuits, CSR
+    std::vector<int32_t> circ_rho;
+    std::vector<int64_t> circ_ptr;
+    std::vector<int32_t> circ_gates;
+    // effect CSR indexed by circuit
+    std::vector<int32_t> eff_ptr;   // int32 offsets on device
+    std::vector<int32_t> eff_label, eff_dest;
+
+    // compiled programs
+    std::vector<uint32_t> prog;
+    std::vector<int64_t> task_off;      // [n_tasks+1]
+    std::vector<int64_t> task_applies;  // gate applications per task (scheduling weight)
+    int32_t max_slots = 0, max_depth = 0;
+    int64_t sum_depth = 0, trie_nodes = 0, applies_per_pass = 0;
+
+    int64_t n_tasks() const { return (int64_t)task_off.size() - 1; }
+};
+
+// Fill circ_* from the reference's prefix-table format.  Returns "" or an error message.
+std::string expand_table(HostPlan& P, int32_t n_rows, int32_t cache_size, const int32_t* t_dest,
+                         const int32_t* t_start, const int32_t* t_cache, const int32_t* t_rho,
+                         const int64_t* row_ptr, const int32_t* gate_idx);
+
+// Validate indices, then build trie/tasks/programs.  target_tasks <= 0 picks a default.
+std::string compile_plan(HostPlan& P, int32_t target_tasks);
+
+}  // namespace gst

@@ -1,0 +1,108 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against (a) the golden vectors
+generated from the reference and (b) the CPU oracle on the same inputs.  Bar: BIT-EXACT for probs,
+FD dprobs and FD-of-FD hprobs (the device computes in the reference's arithmetic order)."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture, assert_bitwise, plan_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = ["smq1Q_XYI_L4_depol", "smq1Q_XYI_L4_kick", "smq1Q_XYI_L128_depol",
+            "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep"]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("target_tasks", [0, 7])
+def test_probs_bitwise_vs_reference(name, target_tasks):
+    fx = load_fixture(name)
+    pl = plan_from_fixture(fx, target_tasks=target_tasks)
+    p = pl.fill_probs()
+    assert_bitwise(p, fx['probs'], "probs " + name)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_dprobs_fd_bitwise_vs_reference(name):
+    fx = load_fixture(name)
+    pl = plan_from_fixture(fx)
+    pr = np.empty(int(fx['nE']))
+    J = pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']), probs_out=pr)
+    assert_bitwise(pr, fx['probs'], "probs (pr_array_to_fill) " + name)
+    assert_bitwise(J, fx['dprobs_map'], "dprobs " + name)
+
+
+def test_dprobs_column_window_and_dest_indices():
+    """dest_param_slice semantics (distforwardsim.py:130-144): fill a column window of a wider 'ep' array."""
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    pl = plan_from_fixture(fx)
+    nE, nP = int(fx['nE']), int(fx['nP'])
+    full = np.full((nE, nP + 5), -7.0)
+    cols = np.arange(10, 30)
+    pl.fill_dprobs(out=full, param_idx=cols, dest_idx=cols + 2, eps=1e-7)
+    assert_bitwise(full[:, 12:32], fx['dprobs_map'][:, 10:30], "window")
+    assert (full[:, :12] == -7.0).all() and (full[:, 32:] == -7.0).all()
+    view = full[:, 3:40]      # non-contiguous rows (leading dimension nP+5)
+    pl.fill_dprobs(out=view, param_idx=np.arange(0, 8), dest_idx=None, eps=1e-7)
+    assert_bitwise(full[:, 3:11], fx['dprobs_map'][:, 0:8], "view")
+
+
+def test_hprobs_fd_bitwise_vs_reference():
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    pl = plan_from_fixture(fx)
+    H = pl.fill_hprobs(idx1=fx['hprobs_rows'], idx2=fx['hprobs_cols'], eps=float(fx['hessian_eps']))
+    assert_bitwise(H, fx['hprobs_map'], "hprobs")
+
+
+def test_hprobs_same_row_and_same_element(oracle_built):
+    """Blocks that overlap (same element, same row) exercise the merged-special-row path."""
+    O = oracle_built
+    fx = load_fixture("smq1Q_XYI_L4_kick")
+    pl = plan_from_fixture(fx)
+    idx = np.array([0, 1, 4, 5, 12, 13, 14, 16, 17, 28, 29, 44, 59])
+    H = pl.fill_hprobs(idx1=idx, idx2=idx, eps=1e-5)
+    Ho = O.from_fixture(fx).hprobs(idx, idx, eps=1e-5)
+    assert_bitwise(H, Ho, "hprobs overlap")
+
+
+def test_2q_hprobs_block_vs_oracle(oracle_built):
+    O = oracle_built
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    pl = plan_from_fixture(fx)
+    i1 = np.array([3, 20, 80, 81, 97, 336, 600, 1615])
+    i2 = np.concatenate([np.arange(0, 20), np.arange(80, 150), np.arange(1500, 1530)])
+    H = pl.fill_hprobs(idx1=i1, idx2=i2, eps=1e-5)
+    Ho = O.from_fixture(fx).hprobs(i1, i2, eps=1e-5)
+    assert_bitwise(H, Ho, "2Q hprobs")
+
+
+def test_random_model_vs_oracle(oracle_built):
+    """Seeded random dense model (no structure, no zeros) on the 2Q L<=2 plan: full Jacobian."""
+    O = oracle_built
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    rng = np.random.default_rng(11)
+    fx = dict(fx)
+    fx['gates'] = fx['gates'] + 0.05 * rng.standard_normal(fx['gates'].shape)
+    fx['rhos'] = fx['rhos'] + 0.05 * rng.standard_normal(fx['rhos'].shape)
+    fx['effects'] = fx['effects'] + 0.05 * rng.standard_normal(fx['effects'].shape)
+    pl = plan_from_fixture(fx)
+    orc = O.from_fixture(fx)
+    assert_bitwise(pl.fill_probs(), orc.probs(), "random probs")
+    cols = np.arange(int(fx['nP']))
+    assert_bitwise(pl.fill_dprobs(param_idx=cols), orc.dprobs(cols), "random dprobs")
+
+
+def test_kind_none_columns_are_exact_zero():
+    fx = load_fixture("smq2Q_XYICNOT_L1024_deep")   # the idle gate and Gypi2:0 never occur in this atom
+    pl = plan_from_fixture(fx)
+    none_cols = np.flatnonzero(fx['pkind'] == -1)[:70]
+    assert len(none_cols) == 70
+    J = pl.fill_dprobs(param_idx=none_cols)
+    assert (J == 0).all() and not np.signbit(J).any()
+
+
+def test_stats_report_device_time():
+    fx = load_fixture("smq1Q_XYI_L128_depol")
+    pl = plan_from_fixture(fx)
+    pl.fill_dprobs()
+    st = pl.stats()
+    assert st['last_kernel_ms'] > 0 and st['last_total_ms'] >= st['last_kernel_ms']
