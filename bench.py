@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- the BASELINE.json metric on MI355X.
+
+Metric : dprobs Jacobian-elements/s (+ circuit-outcome probs/s as a secondary figure), 2Q GST L<=1024.
+Workload: smq2Q_XYICNOT target model .depolarize(0.01, 0.01), `create_gst_experiment_design(1024, lite=False)`
+          = 136,275 circuits, nE = 545,100 elements, nP = 1,616 parameters, D = 16 (BASELINE configs[2], the
+          "~10^5 circuits" case).  One "step" = one bulk_fill_dprobs over the whole design (base
+          probabilities + all 1,616 finite-difference columns, derivative_eps = 1e-7) exactly as the reference's
+          MapForwardSimulator computes it (mapforwardsim_calc_densitymx.pyx:290-383) -- bit-identical results --
+          with the Jacobian left resident in HBM (7.05 GB).  The model arrays are re-uploaded every step, as an
+          optimizer iteration does after model.from_vector().
+Multi-GPU: circuits are dealt to `--gpus` atoms (one per rank, contiguous element slices), strong scaling,
+          no data-path collective (the reference's bulk_fill_dprobs leaves rows distributed, too).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (walk_kernel<16,1,*>, fp64 VALU bound);
+`cpu_baseline` times the CPU oracle on a bounded sample on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (FMA = 2 flop); separate mul+add can reach half of it
+HBM_PEAK_GBS = 8000.0
+
+
+def build_workload(design, max_len, world, rank, device, target_tasks):
+    from pygsti_amd import modelpacks
+    from pygsti_amd.layout import HipCOPALayout
+    pack = modelpacks.smq2Q_XYICNOT
+    model = pack.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
+    circuits = pack.create_gst_circuits(max_len, lite=(design == "lite"))
+    layout = HipCOPALayout(circuits, model, num_atoms=world, devices=[device], rank=rank, size=world,
+                           target_tasks=target_tasks)
+    return pack, model, circuits, layout
+
+
+def cpu_baseline(pack, model, max_len):
+    """Time the CPU checker on a bounded sample: the `lite` sub-design (15 of the 88 germs; every one of its
+    circuits is in the full design), walking the reference-format prefix table for a fixed number of passes
+    (one pass = one finite-difference column)."""
+    from oracle import oracle as O, prefix_table as PT
+    circuits = pack.create_gst_circuits(max_len, lite=True)
+    lookup = {l: i for i, l in enumerate(model.operations.keys())}
+    ptr = np.zeros(len(circuits) + 1, np.int64)
+    ptr[1:] = np.cumsum([len(c) for c in circuits])
+    gates = np.fromiter((lookup[g] for c in circuits for g in c), np.int32, count=int(ptr[-1]))
+    nO = len(model.effect_labels)
+    tbl = PT.build_table(ptr, gates, nO)
+    tbl["D"] = model.dim
+    G = np.array([model.operations[l] for l in model.operations])
+    R = np.array([next(iter(model.preps.values()))])
+    E = np.array([model.effect_vector(l) for l in model.effect_labels])
+    nP = model.num_params
+    mdl = dict(gates=G, rhos=R, effects=E, pkind=-np.ones(nP, np.int32), pobj=np.zeros(nP, np.int32),
+               pelem=np.zeros(nP, np.int32))
+    kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgst_ref.so")) else "port"
+    orc = O.Oracle(tbl, mdl, kind)
+    t1 = orc.time_passes(4)                      # calibrate
+    n_pass = int(max(8, min(400, 12.0 / max(t1 / 4, 1e-6))))
+    t = orc.time_passes(n_pass)
+    nE = tbl["nE"]
+    return {"value": nE * n_pass / t, "unit": "Jacobian-elements/s", "cores": 1, "kind": kind,
+            "sample": "%d FD columns (probability passes) over the lite sub-design (%d of the workload's circuits, "
+                      "nE=%d, %d gate applications per pass on the reference prefix table), %.1f s"
+                      % (n_pass, len(circuits), nE, len(tbl["gate_idx"]), t),
+            "probs_per_s": nE * n_pass / t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--design", default="full", choices=["full", "lite"])
+    ap.add_argument("--max-len", type=int, default=1024)
+    ap.add_argument("--target-tasks", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier_sync(plan):
+        plan.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    pack, model, circuits, layout = build_workload(args.design, args.max_len, world, rank, local_rank, args.target_tasks)
+    atom = layout.atoms[0]
+    plan = atom.plan()
+    gates, rhos, effects = layout.model_arrays(model)
+    plan.set_model(gates, rhos, effects)
+    plan.set_param_map(*layout.param_map(model))
+    nP = model.num_params
+    nE_local = atom.num_elements
+    nE_total = layout.global_num_elements
+    d_out = plan.device_malloc(nE_local * nP * 8)
+    d_probs = plan.device_malloc(nE_local * 8)
+    pidx = np.arange(nP, dtype=np.int64)
+
+    def step():
+        plan.set_model(gates, rhos, effects)          # from_vector -> new dense arrays -> H2D
+        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(plan)
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        step()
+        if world == 1:
+            plan.sync()                                # N=1: per-step HIP-event read-out (stream stays ordered)
+            kernel_ms.append(plan.stats()["last_kernel_ms"])
+    barrier_sync(plan)
+    dt = time.perf_counter() - t0
+    if not kernel_ms:
+        kernel_ms = [plan.stats()["last_kernel_ms"]]
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # secondary: probabilities only
+    for _ in range(2):
+        plan.fill_probs_dev(d_probs)
+    barrier_sync(plan)
+    tp0 = time.perf_counter()
+    n_pr = max(3, args.steps)
+    for _ in range(n_pr):
+        plan.set_model(gates, rhos, effects)
+        plan.fill_probs_dev(d_probs)
+    barrier_sync(plan)
+    dtp = time.perf_counter() - tp0
+
+    st = plan.stats()
+    if rank == 0:
+        D = model.dim
+        k_ms = float(np.mean(kernel_ms))
+        # algorithmic flops of one FD Jacobian on the schedule actually executed by this rank:
+        # (nP perturbed passes) x (2 D^2 per gate application + 2 D per element)
+        flops = nP * (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local)
+        jac_bytes = 8.0 * nE_local * nP
+        out = {
+            "metric": "dprobs Jacobian-elements/sec, 2Q GST L<=1024 (bulk_fill_dprobs, FD eps=1e-7, bit-identical to the reference Map path)",
+            "value": nE_total * nP * args.steps / dt,
+            "unit": "Jacobian-elements/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "smq2Q_XYICNOT GST L<=%d %s germs: %d circuits, nE=%d, nP=%d, D=%d; "
+                                   "target model depolarized 0.01/0.01" % (args.max_len, args.design, len(circuits),
+                                                                           nE_total, nP, D),
+                       "derivative": "forward finite differences, eps=1e-7 (reference MapForwardSimulator semantics)",
+                       "parallelism": "atoms%d" % world},
+            "probs_per_s": nE_total * n_pr / dtp,
+            "probs_ms": 1e3 * dtp / n_pr,
+            "roofline": {"bound": "valu_f64", "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
+                         "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / (k_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
+                         "note": "separate v_mul_f64+v_add_f64 (no FMA, required for bitwise parity) caps this kernel at 0.5 of the FMA peak",
+                         "kernel_ms": k_ms, "flops_per_launch": flops,
+                         "hbm_write_GBps": jac_bytes / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
+                         "traffic": None},
+            "plan": {k: st[k] for k in ("n_circuits", "n_elements", "sum_depth", "trie_nodes", "applies_per_pass",
+                                        "n_tasks", "prog_words", "max_slots")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pack, model, args.max_len)
+        print(json.dumps(out))
+    plan.device_free(d_out)
+    plan.device_free(d_probs)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,6 +152,12 @@ int gst_fill_dprobs_dev(gst_plan *plan, double *d_out, int64_t ld, const int64_t
                         double *d_probs_out);
 int gst_sync(gst_plan *plan);
 
+/* Plain device-buffer helpers on the plan's device, so that callers without any GPU framework can
+ * keep results resident (bench.py, tests).  Buffers from any other allocator work equally. */
+int gst_device_malloc(gst_plan *plan, int64_t nbytes, void **d_ptr);
+int gst_device_free(gst_plan *plan, void *d_ptr);
+int gst_memcpy_d2h(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
+
 /* Introspection (tests, bench, DESIGN.md numbers). */
 int gst_get_stats(const gst_plan *plan, gst_stats *out);
 /* Copies up to `cap` program words of the concatenated walk programs; returns the total count in

@@ -57,7 +57,7 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_sync", "gst_get_stats", "gst_get_program", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_device_count",
            "gst_last_error", "gst_version"]
 
 _lib = None
@@ -85,6 +85,9 @@ def lib():
         L.gst_fill_probs_dev.argtypes = [vp, vp]
         L.gst_fill_dprobs_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.c_int, dbl, vp]
         L.gst_sync.argtypes = [vp]
+        L.gst_device_malloc.argtypes = [vp, i64, C.POINTER(vp)]
+        L.gst_device_free.argtypes = [vp, vp]
+        L.gst_memcpy_d2h.argtypes = [vp, vp, vp, i64]
         L.gst_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.gst_get_program.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64]
         L.gst_device_count.argtypes = [C.POINTER(i32)]
@@ -240,6 +243,19 @@ class Plan:
 
     def sync(self):
         check(lib().gst_sync(self._h))
+
+    def device_malloc(self, nbytes):
+        p = C.c_void_p()
+        check(lib().gst_device_malloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def device_free(self, d_ptr):
+        check(lib().gst_device_free(self._h, C.c_void_p(int(d_ptr))))
+
+    def memcpy_d2h(self, out, d_ptr, offset_bytes=0):
+        assert out.flags.c_contiguous
+        check(lib().gst_memcpy_d2h(self._h, _ptr(out), C.c_void_p(int(d_ptr) + int(offset_bytes)), out.nbytes))
+        return out
 
     # -- introspection -----------------------------------------------------------------------------------
     def stats(self):

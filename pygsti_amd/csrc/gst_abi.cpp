@@ -570,6 +570,34 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     return end_call(p, true);
 }
 
+int gst_device_malloc(gst_plan* p, int64_t nbytes, void** d_ptr)
+{
+    if (!p || !d_ptr || nbytes < 0) return fail(GST_EINVAL, "bad argument");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(d_ptr, (size_t)std::max<int64_t>(nbytes, 1)));
+    return GST_OK;
+}
+
+int gst_device_free(gst_plan* p, void* d_ptr)
+{
+    if (!p) return fail(GST_EINVAL, "plan is NULL");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    HIP_TRY(hipFree(d_ptr));
+    return GST_OK;
+}
+
+int gst_memcpy_d2h(gst_plan* p, void* dst, const void* d_src, int64_t nbytes)
+{
+    if (!p || !dst || !d_src || nbytes < 0) return fail(GST_EINVAL, "bad argument");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost));
+    return GST_OK;
+}
+
 int gst_sync(gst_plan* p)
 {
     if (!p) return fail(GST_EINVAL, "plan is NULL");

@@ -1,0 +1,270 @@
+"""HipMapForwardSimulator: the reference's ForwardSimulator surface on top of libgstfwd.
+
+Same method names, argument meaning and array conventions as the reference so that the callers of
+the hot path read the same (pygsti/forwardsims/forwardsim.py:584-609 bulk_fill_probs, :628-662
+bulk_fill_dprobs, :701-753 bulk_fill_hprobs, :787-878 iter_hprobs_by_rectangle, :415-582 bulk_probs /
+bulk_dprobs / bulk_hprobs; distforwardsim.py:92-340 the per-atom loops and parameter blocking;
+mapforwardsim.py:166-172 the constructor, :372-391 the three `_bulk_fill_*_atom` seams).
+
+Derivatives are forward finite differences with `derivative_eps` (1e-7) and FD-of-FD with
+`hessian_eps` (1e-5), exactly as MapForwardSimulator computes them -- the device evaluates all
+perturbed models concurrently and reproduces the reference's numbers bit for bit.
+
+There is no CPU path: every fill goes through the C ABI and raises `GstDeviceError` without a GPU.
+"""
+import numpy as np
+
+from . import _lib
+from .layout import HipCOPALayout
+
+
+def _slice_len(s, n):
+    if s is None:
+        return n
+    if isinstance(s, slice):
+        return len(range(*s.indices(n)))
+    return len(s)
+
+
+def _to_index_array(s, n):
+    if s is None:
+        return np.arange(n, dtype=np.int64)
+    if isinstance(s, slice):
+        return np.arange(*s.indices(n), dtype=np.int64)
+    return np.asarray(s, dtype=np.int64)
+
+
+def _slice_up_range(n, num_slices):
+    """mpitools.slice_up_range: `num_slices` nearly equal contiguous slices of range(n)."""
+    base, rem = divmod(n, num_slices)
+    out, start = [], 0
+    for i in range(num_slices):
+        ln = base + (1 if i < rem else 0)
+        out.append(slice(start, start + ln))
+        start += ln
+    return out
+
+
+class HipMapForwardSimulator:
+    """Drop-in counterpart of MapForwardSimulator for dense `densitymx` models on MI355X."""
+
+    def __init__(self, model=None, max_cache_size=None, num_atoms=None, processor_grid=None, param_blk_sizes=None,
+                 derivative_eps=1e-7, hessian_eps=1e-5, devices=None, target_tasks=0):
+        self._model = None
+        self._max_cache_size = max_cache_size   # accepted for signature parity; the device plan needs no state cache
+        self._num_atoms = num_atoms
+        self._processor_grid = processor_grid
+        self._pblk_sizes = param_blk_sizes
+        self.derivative_eps = derivative_eps
+        self.hessian_eps = hessian_eps
+        self.devices = devices
+        self.target_tasks = target_tasks
+        if model is not None:
+            self.model = model
+
+    # -- model attachment (forwardsim.py:134-150) ---------------------------------------------------------
+    @property
+    def model(self):
+        return self._model
+
+    @model.setter
+    def model(self, val):
+        self._model = val
+
+    def copy(self, keep_model_attached=False):
+        s = HipMapForwardSimulator(None, self._max_cache_size, self._num_atoms, self._processor_grid,
+                                   self._pblk_sizes, self.derivative_eps, self.hessian_eps, self.devices,
+                                   self.target_tasks)
+        if keep_model_attached:
+            s._model = self._model
+        return s
+
+    def _to_nice_serialization(self):
+        return {"module": type(self).__module__, "class": type(self).__name__,
+                "max_cache_size": self._max_cache_size, "derivative_epsilon": self.derivative_eps,
+                "hessian_epsilon": self.hessian_eps}
+
+    @classmethod
+    def _from_nice_serialization(cls, state):
+        return cls(None, state.get("max_cache_size"), derivative_eps=state.get("derivative_epsilon", 1e-7),
+                   hessian_eps=state.get("hessian_epsilon", 1e-5))
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_model"] = None          # the parent model re-attaches itself (forwardsim.py:121-132)
+        return st
+
+    # -- layout ---------------------------------------------------------------------------------------------
+    def create_layout(self, circuits, dataset=None, resource_alloc=None, array_types=("E",),
+                      derivative_dimensions=None, verbosity=0, layout_creation_circuit_cache=None):
+        """Build the element index and one device plan per atom (mapforwardsim.py:206-335).  `dataset` must be
+        None (all outcomes are laid out, copalayout.py:161-164)."""
+        if dataset is not None:
+            raise NotImplementedError("dataset-restricted layouts are not part of the device path yet")
+        rank = getattr(resource_alloc, "comm_rank", 0) if resource_alloc is not None else 0
+        size = getattr(resource_alloc, "comm_size", 1) if resource_alloc is not None else 1
+        natoms = self._num_atoms if self._num_atoms is not None else max(size, len(self.devices or [0]))
+        blk = tuple(self._pblk_sizes) if self._pblk_sizes else (None, None)
+        if len(blk) == 1:
+            blk = (blk[0], None)
+        return HipCOPALayout(circuits, self.model, natoms, self.devices, rank, size, self.target_tasks, blk)
+
+    # -- per-atom seams (mapforwardsim.py:372-391) ---------------------------------------------------------------
+    def _prepare_atom(self, layout_atom):
+        plan = layout_atom.plan()
+        L = layout_atom.layout
+        plan.set_model(*L.model_arrays(self.model))
+        if plan.n_params != self.model.num_params:
+            plan.set_param_map(*L.param_map(self.model))
+        return plan
+
+    def _bulk_fill_probs_atom(self, array_to_fill, layout_atom, resource_alloc=None):
+        plan = self._prepare_atom(layout_atom)
+        if array_to_fill.flags.c_contiguous:
+            plan.fill_probs(array_to_fill)
+        else:
+            array_to_fill[:] = plan.fill_probs()
+
+    def _bulk_fill_dprobs_atom(self, array_to_fill, dest_param_slice, layout_atom, param_slice, resource_alloc=None,
+                               pr_array_to_fill=None):
+        plan = self._prepare_atom(layout_atom)
+        nP = self.model.num_params
+        pidx = _to_index_array(param_slice, nP)
+        didx = None if dest_param_slice is None else _to_index_array(dest_param_slice, array_to_fill.shape[1])
+        plan.fill_dprobs(array_to_fill, pidx, didx, self.derivative_eps, pr_array_to_fill)
+
+    def _bulk_fill_hprobs_atom(self, array_to_fill, dest_param_slice1, dest_param_slice2, layout_atom,
+                               param_slice1, param_slice2, resource_alloc=None):
+        plan = self._prepare_atom(layout_atom)
+        nP = self.model.num_params
+        i1, i2 = _to_index_array(param_slice1, nP), _to_index_array(param_slice2, nP)
+        d1 = None if dest_param_slice1 is None else _to_index_array(dest_param_slice1, array_to_fill.shape[1])
+        d2 = None if dest_param_slice2 is None else _to_index_array(dest_param_slice2, array_to_fill.shape[2])
+        if array_to_fill.flags.c_contiguous:
+            plan.fill_hprobs(array_to_fill, i1, i2, d1, d2, self.hessian_eps)
+        else:
+            tmp = np.ascontiguousarray(array_to_fill)
+            plan.fill_hprobs(tmp, i1, i2, d1, d2, self.hessian_eps)
+            array_to_fill[...] = tmp
+
+    # -- bulk fills (forwardsim.py:584-753, distforwardsim.py:92-234) ------------------------------------------------
+    def bulk_fill_probs(self, array_to_fill, layout):
+        for atom in layout.atoms:
+            self._bulk_fill_probs_atom(array_to_fill[atom.element_slice], atom)
+
+    def bulk_fill_dprobs(self, array_to_fill, layout, pr_array_to_fill=None):
+        blk = layout.param_dimension_blk_sizes[0]
+        gps = layout.global_param_slice
+        Np = _slice_len(gps, self.model.num_params)
+        for atom in layout.atoms:
+            es = atom.element_slice
+            pr = None if pr_array_to_fill is None else pr_array_to_fill[es]
+            if blk is None:
+                self._bulk_fill_dprobs_atom(array_to_fill[es, :], None, atom, gps, None, pr)
+            else:
+                nblk = int(np.ceil(Np / blk))
+                for k, block in enumerate(_slice_up_range(Np, nblk)):
+                    shifted = slice(block.start + gps.start, block.stop + gps.start)
+                    self._bulk_fill_dprobs_atom(array_to_fill[es, :], block, atom, shifted, None, pr if k == 0 else None)
+                if Np == 0 and pr is not None:
+                    self._bulk_fill_probs_atom(pr, atom)
+
+    def bulk_fill_hprobs(self, array_to_fill, layout, pr_array_to_fill=None, deriv1_array_to_fill=None,
+                         deriv2_array_to_fill=None):
+        b1, b2 = layout.param_dimension_blk_sizes[0], layout.param_dimension_blk_sizes[1]
+        gps1, gps2 = layout.global_param_slice, layout.global_param2_slice
+        nP = self.model.num_params
+        Np1, Np2 = _slice_len(gps1, nP), _slice_len(gps2, nP)
+        for atom in layout.atoms:
+            es = atom.element_slice
+            if pr_array_to_fill is not None:
+                self._bulk_fill_probs_atom(pr_array_to_fill[es], atom)
+            if deriv1_array_to_fill is not None:
+                self._bulk_fill_dprobs_atom(deriv1_array_to_fill[es, :], None, atom, gps1)
+            if deriv2_array_to_fill is not None:
+                if deriv1_array_to_fill is not None and gps1 == gps2:
+                    deriv2_array_to_fill[es, :] = deriv1_array_to_fill[es, :]
+                else:
+                    self._bulk_fill_dprobs_atom(deriv2_array_to_fill[es, :], None, atom, gps2)
+            if b1 is None and b2 is None:
+                self._bulk_fill_hprobs_atom(array_to_fill[es, :, :], None, None, atom, gps1, gps2)
+            else:
+                assert b1 is not None and b2 is not None, "Both (or neither) of the Hessian block sizes must be specified!"
+                for blk1 in _slice_up_range(Np1, int(np.ceil(Np1 / b1))):
+                    g1 = slice(blk1.start + gps1.start, blk1.stop + gps1.start)
+                    for blk2 in _slice_up_range(Np2, int(np.ceil(Np2 / b2))):
+                        g2 = slice(blk2.start + gps2.start, blk2.stop + gps2.start)
+                        self._bulk_fill_hprobs_atom(array_to_fill[es, :, :], blk1, blk2, atom, g1, g2)
+
+    def iter_hprobs_by_rectangle(self, layout, wrt_slices_list, return_dprobs_12=False):
+        """Yield (wrtSlice1, wrtSlice2, hprobs[, dprobs12]) per rectangle (forwardsim.py:787-878,
+        distforwardsim.py:263-302); the full Hessian is never materialised."""
+        nE, nP = layout.num_elements, self.model.num_params
+        for s1, s2 in wrt_slices_list:
+            n1, n2 = _slice_len(s1, nP), _slice_len(s2, nP)
+            h = np.zeros((nE, n1, n2))
+            d1 = np.zeros((nE, n1)) if return_dprobs_12 else None
+            d2 = np.zeros((nE, n2)) if return_dprobs_12 else None
+            for atom in layout.atoms:
+                es = atom.element_slice
+                if return_dprobs_12:
+                    self._bulk_fill_dprobs_atom(d1[es, :], None, atom, s1)
+                    if s1 == s2:
+                        d2[es, :] = d1[es, :]
+                    else:
+                        self._bulk_fill_dprobs_atom(d2[es, :], None, atom, s2)
+                self._bulk_fill_hprobs_atom(h[es, :, :], None, None, atom, s1, s2)
+            if return_dprobs_12:
+                yield s1, s2, h, d1[:, :, None] * d2[:, None, :]
+            else:
+                yield s1, s2, h
+
+    def _iter_atom_hprobs_by_rectangle(self, atom, wrt_slices_list, return_dprobs_12, resource_alloc=None):
+        nE, nP = atom.num_elements, self.model.num_params
+        for s1, s2 in wrt_slices_list:
+            n1, n2 = _slice_len(s1, nP), _slice_len(s2, nP)
+            h = np.zeros((nE, n1, n2))
+            if return_dprobs_12:
+                d1 = np.zeros((nE, n1)); d2 = np.zeros((nE, n2))
+                self._bulk_fill_dprobs_atom(d1, None, atom, s1)
+                if s1 == s2: d2[:, :] = d1
+                else: self._bulk_fill_dprobs_atom(d2, None, atom, s2)
+            self._bulk_fill_hprobs_atom(h, None, None, atom, s1, s2)
+            if return_dprobs_12:
+                yield s1, s2, h, d1[:, :, None] * d2[:, None, :]
+            else:
+                yield s1, s2, h
+
+    # -- convenience (forwardsim.py:171-277, 415-582) -------------------------------------------------------------------
+    def bulk_probs(self, circuits, clip_to=None, resource_alloc=None, smartc=None):
+        layout = self.create_layout(circuits, array_types=("e",))
+        vp = np.empty(layout.num_elements)
+        self.bulk_fill_probs(vp, layout)
+        if clip_to is not None:
+            vp = np.clip(vp, clip_to[0], clip_to[1])
+        return {c: {o: vp[k] for k, o in zip(range(*inds.indices(len(vp))), outs)}
+                for inds, c, outs in layout.iter_unique_circuits()}
+
+    def probs(self, circuit, outcomes=None, time=None, resource_alloc=None):
+        return self.bulk_probs([circuit])[tuple(circuit)]
+
+    def bulk_dprobs(self, circuits, resource_alloc=None, smartc=None):
+        layout = self.create_layout(circuits, array_types=("ep",))
+        vdp = np.empty((layout.num_elements, self.model.num_params))
+        self.bulk_fill_dprobs(vdp, layout)
+        return {c: {o: vdp[k] for k, o in zip(range(*inds.indices(len(vdp))), outs)}
+                for inds, c, outs in layout.iter_unique_circuits()}
+
+    def dprobs(self, circuit, resource_alloc=None):
+        return self.bulk_dprobs([circuit])[tuple(circuit)]
+
+    def bulk_hprobs(self, circuits, resource_alloc=None, smartc=None):
+        layout = self.create_layout(circuits, array_types=("epp",))
+        nP = self.model.num_params
+        vhp = np.empty((layout.num_elements, nP, nP))
+        self.bulk_fill_hprobs(vhp, layout)
+        return {c: {o: vhp[k] for k, o in zip(range(*inds.indices(len(vhp))), outs)}
+                for inds, c, outs in layout.iter_unique_circuits()}
+
+    def hprobs(self, circuit, resource_alloc=None):
+        return self.bulk_hprobs([circuit])[tuple(circuit)]

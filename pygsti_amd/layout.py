@@ -1,0 +1,218 @@
+"""COPA layout for the device path: element index + per-atom evaluation plans.
+
+Host-side mirror of the surface of pyGSTi's `CircuitOutcomeProbabilityArrayLayout` /
+`DistributableCOPALayout` / `MapCOPALayout` that the objective functions and the simulator touch
+(layouts/copalayout.py:27-801, distlayout.py:110-1405, maplayout.py:171-328):
+`num_elements`, `num_circuits`, `atoms` (each with a contiguous `element_slice`),
+`indices_for_index`, `outcomes_for_index`, `indices_and_outcomes_for_index`, `iter_unique_circuits`,
+`allocate_local_array` for the 'e' / 'ep' / 'epp' families, `global_layout`, `host_element_slice`,
+`global_param_slice`, `global_param2_slice`, `param_dimension_blk_sizes`, `resource_alloc`.
+
+Element order follows the reference's 1-atom Map layout: element k <-> (circuit k // nOutcomes,
+outcome k % nOutcomes) with circuits in the caller's order (tests/golden fixtures pin this).  With
+`num_atoms` > 1 circuits are dealt to atoms as contiguous runs of the prefix-sorted circuit list
+(cut where few gate applications are shared), every atom owning one contiguous element slice --
+as in the reference, the element order then differs from the caller's circuit order and
+`indices_for_index` is the map.  Atoms are the unit of multi-GPU sharding (distlayout.py:326-332).
+"""
+import numpy as np
+
+from . import _lib
+from .model import KIND_GATE, KIND_RHO, KIND_EFFECT
+
+
+class _ResourceAlloc:
+    """Stand-in for pygsti.baseobjs.ResourceAllocation on the serial/one-process-per-GPU path."""
+
+    def __init__(self, rank=0, size=1):
+        self.comm = None
+        self.comm_rank, self.comm_size = rank, size
+        self.is_host_leader = True
+        self.mem_limit = None
+
+    def host_comm_barrier(self):
+        pass
+
+    def check_can_allocate_memory(self, nbytes):
+        pass
+
+
+class HipLayoutAtom:
+    """One atom: a set of circuits, its contiguous slice of the element dimension, one device plan."""
+
+    def __init__(self, layout, circuit_indices, element_slice, device):
+        self.layout = layout
+        self.circuit_indices = np.asarray(circuit_indices, dtype=np.int64)
+        self.element_slice = element_slice
+        self.num_elements = element_slice.stop - element_slice.start
+        self.device = device
+        self._plan = None
+
+    @property
+    def cache_size(self):
+        return 0   # the device schedule keeps no per-circuit state cache (save slots live in registers)
+
+    def plan(self):
+        """Compile (once) and return the device plan of this atom."""
+        if self._plan is None:
+            L = self.layout
+            nO = L.num_outcomes
+            n = len(self.circuit_indices)
+            lens = L._circ_len[self.circuit_indices]
+            ptr = np.zeros(n + 1, np.int64)
+            np.cumsum(lens, out=ptr[1:])
+            gates = np.empty(int(ptr[-1]), np.int32)
+            for k, ci in enumerate(self.circuit_indices):
+                gates[ptr[k]:ptr[k + 1]] = L._circ_gates[L._circ_ptr[ci]:L._circ_ptr[ci + 1]]
+            eff_ptr = np.arange(n + 1, dtype=np.int64) * nO
+            eff_label = np.tile(np.arange(nO, dtype=np.int32), n)
+            eff_dest = np.arange(n * nO, dtype=np.int32)
+            self._plan = _lib.Plan.from_circuits(L.dim, L.num_gates, 1, nO, n * nO, np.zeros(n, np.int32), ptr,
+                                                 gates, eff_ptr, eff_label, eff_dest, device=self.device,
+                                                 target_tasks=L.target_tasks)
+        return self._plan
+
+
+class HipCOPALayout:
+    def __init__(self, circuits, model, num_atoms=1, devices=None, rank=0, size=1, target_tasks=0,
+                 param_dimension_blk_sizes=(None, None)):
+        self.circuits = [tuple(c) for c in circuits]
+        self.num_circuits = len(self.circuits)
+        self.model_gate_labels = list(model.operations.keys())
+        self.num_gates = len(self.model_gate_labels)
+        self.dim = model.dim
+        self.effect_labels = model.effect_labels
+        self._outcomes = [tuple([lbl.split("_", 1)[1]]) for lbl in self.effect_labels]
+        self.num_outcomes = len(self._outcomes)
+        self.target_tasks = target_tasks
+        self._num_params = model.num_params
+        lookup = {l: i for i, l in enumerate(self.model_gate_labels)}
+        self._circ_len = np.fromiter((len(c) for c in self.circuits), dtype=np.int64, count=self.num_circuits)
+        self._circ_ptr = np.zeros(self.num_circuits + 1, np.int64)
+        np.cumsum(self._circ_len, out=self._circ_ptr[1:])
+        self._circ_gates = np.fromiter((lookup[g] for c in self.circuits for g in c), dtype=np.int32,
+                                       count=int(self._circ_ptr[-1]))
+        self._rank, self._size = rank, size
+
+        # ---- deal circuits to atoms ------------------------------------------------------------------
+        num_atoms = max(1, int(num_atoms or 1))
+        groups = self._partition(num_atoms)
+        self.global_num_elements = self.num_circuits * self.num_outcomes
+        self._circuit_offset = np.empty(self.num_circuits, np.int64)   # first element of each circuit
+        atoms, off = [], 0
+        devices = list(devices) if devices else [-1]
+        for a, idx in enumerate(groups):
+            n_el = len(idx) * self.num_outcomes
+            self._circuit_offset[idx] = off + np.arange(len(idx)) * self.num_outcomes
+            atoms.append(HipLayoutAtom(self, idx, slice(off, off + n_el), devices[a % len(devices)]))
+            off += n_el
+        self.all_atoms = atoms
+        # one process per GPU: this rank owns atoms rank, rank+size, ... (all of them when size == 1)
+        self.atoms = [at for a, at in enumerate(atoms) if a % size == rank]
+        self.num_elements = self.global_num_elements   # arrays are allocated full-size; see allocate_local_array
+        self.host_element_slice = slice(0, self.global_num_elements)
+        self.global_param_slice = slice(0, self._num_params)
+        self.global_param2_slice = slice(0, self._num_params)
+        self.host_param_slice = self.global_param_slice
+        self.host_param2_slice = self.global_param2_slice
+        self.param_dimension_blk_sizes = tuple(param_dimension_blk_sizes)
+        self.global_num_params = self._num_params
+        self.host_num_elements = self.global_num_elements
+        self.max_atom_elements = max(at.num_elements for at in atoms)
+
+    # ---- partition ------------------------------------------------------------------------------------
+    def _partition(self, num_atoms):
+        if num_atoms == 1:
+            return [np.arange(self.num_circuits)]
+        order = sorted(range(self.num_circuits), key=lambda i: self.circuits[i])
+        lcp = np.zeros(self.num_circuits, np.int64)
+        cost = np.zeros(self.num_circuits, np.int64)
+        for k, ci in enumerate(order):
+            c = self.circuits[ci]
+            if k:
+                p = self.circuits[order[k - 1]]
+                n = min(len(p), len(c)); j = 0
+                while j < n and p[j] == c[j]: j += 1
+                lcp[k] = j
+            cost[k] = len(c) - lcp[k] + 1
+        cum = np.cumsum(cost)
+        total = int(cum[-1])
+        cuts = [0]
+        for a in range(1, num_atoms):
+            target = total * a // num_atoms
+            k0 = int(np.searchsorted(cum, target))
+            lo, hi = max(cuts[-1] + 1, k0 - 200), min(self.num_circuits - 1, k0 + 200)
+            if lo > hi:
+                k = min(max(cuts[-1] + 1, k0), self.num_circuits - 1)
+            else:
+                k = lo + int(np.argmin(lcp[lo:hi + 1]))   # cheapest restart near the balanced cut
+            cuts.append(k)
+        cuts.append(self.num_circuits)
+        order = np.asarray(order, np.int64)
+        return [np.sort(order[cuts[a]:cuts[a + 1]]) for a in range(num_atoms) if cuts[a + 1] > cuts[a]]
+
+    # ---- element index (copalayout.py:683-763) ----------------------------------------------------------------
+    def __len__(self):
+        return self.num_elements
+
+    @property
+    def global_layout(self):
+        return self
+
+    def indices_for_index(self, index):
+        o = int(self._circuit_offset[index])
+        return slice(o, o + self.num_outcomes)
+
+    def outcomes_for_index(self, index):
+        return tuple(self._outcomes)
+
+    def indices_and_outcomes_for_index(self, index):
+        return self.indices_for_index(index), self.outcomes_for_index(index)
+
+    def indices(self, circuit):
+        return self.indices_for_index(self.circuits.index(tuple(circuit)))
+
+    def outcomes(self, circuit):
+        return tuple(self._outcomes)
+
+    def iter_unique_circuits(self):
+        for i, c in enumerate(self.circuits):
+            yield self.indices_for_index(i), c, self.outcomes_for_index(i)
+
+    # ---- arrays (copalayout.py:284-361) ----------------------------------------------------------------------------
+    def allocate_local_array(self, array_type, dtype="d", zero_out=False, memory_tracker=None, extra_elements=0):
+        nE, nP = self.num_elements + extra_elements, self._num_params
+        shape = {"e": (nE,), "ep": (nE, nP), "ep2": (nE, nP), "epp": (nE, nP, nP), "p": (nP,), "jtj": (nP, nP),
+                 "jtf": (nP,), "c": (self.num_circuits,), "cp": (self.num_circuits, nP)}[array_type]
+        return np.zeros(shape, dtype) if zero_out else np.empty(shape, dtype)
+
+    def free_local_array(self, local_array):
+        pass
+
+    def gather_local_array(self, array_type, array_portion, extra_elements=0, all_gather=False, return_shared=False):
+        return array_portion
+
+    def resource_alloc(self, sub_alloc_name=None, empty_if_missing=True):
+        return _ResourceAlloc(self._rank, self._size)
+
+    # ---- model arrays in plan order -------------------------------------------------------------------------------
+    def model_arrays(self, model):
+        gates = np.array([model.operations[l] for l in self.model_gate_labels], dtype=np.float64)
+        rhos = np.array([next(iter(model.preps.values()))], dtype=np.float64)
+        effects = np.array([model.effect_vector(l) for l in self.effect_labels], dtype=np.float64)
+        return gates, rhos, effects
+
+    def param_map(self, model):
+        """(kind, obj, elem) of every model parameter, object indices in plan order."""
+        nP = model.num_params
+        kind = -np.ones(nP, np.int32); obj = np.zeros(nP, np.int32); elem = np.zeros(nP, np.int32)
+        rho_label = next(iter(model.preps.keys()))
+        s = model.gpindices(KIND_RHO, rho_label)
+        kind[s] = KIND_RHO; obj[s] = 0; elem[s] = np.arange(s.stop - s.start)
+        for i, l in enumerate(self.effect_labels):
+            s = model.gpindices(KIND_EFFECT, l)
+            kind[s] = KIND_EFFECT; obj[s] = i; elem[s] = np.arange(s.stop - s.start)
+        for i, l in enumerate(self.model_gate_labels):
+            s = model.gpindices(KIND_GATE, l)
+            kind[s] = KIND_GATE; obj[s] = i; elem[s] = np.arange(s.stop - s.start)
+        return kind, obj, elem
