@@ -30,14 +30,14 @@ F64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (FMA = 2 flop); separate
 HBM_PEAK_GBS = 8000.0
 
 
-def build_workload(design, max_len, world, rank, device, target_tasks):
+def build_workload(design, max_len, world, rank, device, target_tasks, max_slots=0):
     from pygsti_amd import modelpacks
     from pygsti_amd.layout import HipCOPALayout
     pack = modelpacks.smq2Q_XYICNOT
     model = pack.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
     circuits = pack.create_gst_circuits(max_len, lite=(design == "lite"))
     layout = HipCOPALayout(circuits, model, num_atoms=world, devices=[device], rank=rank, size=world,
-                           target_tasks=target_tasks)
+                           target_tasks=target_tasks, max_slots=max_slots)
     return pack, model, circuits, layout
 
 
@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--design", default="full", choices=["full", "lite"])
     ap.add_argument("--max-len", type=int, default=1024)
     ap.add_argument("--target-tasks", type=int, default=0)
+    ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -104,7 +105,8 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    pack, model, circuits, layout = build_workload(args.design, args.max_len, world, rank, local_rank, args.target_tasks)
+    pack, model, circuits, layout = build_workload(args.design, args.max_len, world, rank, local_rank, args.target_tasks,
+                                                    args.max_slots)
     atom = layout.atoms[0]
     plan = atom.plan()
     gates, rhos, effects = layout.model_arrays(model)

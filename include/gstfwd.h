@@ -95,7 +95,8 @@ typedef struct {
 typedef struct {
     int32_t device;          /* HIP device ordinal; -1 = current device */
     int32_t target_tasks;    /* 0 = default; how many independent walk programs to aim for */
-    int32_t reserved[6];
+    int32_t max_slots;       /* 0 = default; save slots (LDS-resident states) a walk program may use */
+    int32_t reserved[5];
 } gst_options;
 
 typedef struct {

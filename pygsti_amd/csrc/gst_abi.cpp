@@ -75,7 +75,7 @@ struct gst_plan {
     std::vector<int32_t> pkind, pobj, pelem;
     bool have_pmap = false;
     // work buffers
-    DevBuf<double> d_pbase, d_scratch, d_out, d_raw, d_dcol, d_probs_tmp;
+    DevBuf<double> d_pbase, d_out, d_raw, d_dcol, d_probs_tmp;
     DevBuf<int32_t> d_lane[7];   // col, kind0, obj0, elem0, kind1, obj1, elem1
     DevBuf<int32_t> d_wave_row, d_wave_rowidx, d_lane_colidx;
 
@@ -88,7 +88,7 @@ struct gst_plan {
         (void)hipSetDevice(device);
         d_prog.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
-        d_pbase.release(); d_scratch.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
+        d_pbase.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
         d_wave_row.release(); d_wave_rowidx.release(); d_lane_colidx.release();
         if (ev0) (void)hipEventDestroy(ev0);
@@ -103,7 +103,10 @@ namespace {
 
 int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
 {
-    std::string err = gst::compile_plan(p->hp, opt ? opt->target_tasks : 0);
+    // default slot budget: what fits in LDS at 4 wavefronts per SIMD (16 per CU): one 8 KB slot at D=16
+    int32_t max_slots = opt ? opt->max_slots : 0;
+    if (max_slots <= 0) max_slots = (p->hp.D >= 16) ? 1 : 4;
+    std::string err = gst::compile_plan(p->hp, opt ? opt->target_tasks : 0, max_slots);
     if (!err.empty()) { delete p; return fail(GST_EINVAL, err); }
     if (p->hp.D != 4 && p->hp.D != 16) {
         const int D = p->hp.D;
@@ -179,21 +182,6 @@ void base_args(gst_plan* p, gst::WalkArgs& a)
     a.n_pwaves = 1;
 }
 
-// global-memory save slots for `blocks` wavefronts
-int ensure_scratch(gst_plan* p, int S, int64_t blocks, gst::WalkArgs& a)
-{
-    const int nreg = gst::reg_slots(p->hp.D, S);
-    const int extra = std::max(0, p->hp.max_slots - nreg);
-    a.n_scratch_slots = extra;
-    a.scratch = nullptr;
-    if (extra > 0) {
-        const size_t need = (size_t)blocks * extra * p->hp.D * 64;
-        HIP_TRY(p->d_scratch.ensure(need));
-        a.scratch = p->d_scratch.p;
-    }
-    return GST_OK;
-}
-
 // Base probabilities into d_dst (device), S = 0 walk: one wavefront per task.
 int run_probs(gst_plan* p, double* d_dst)
 {
@@ -201,9 +189,7 @@ int run_probs(gst_plan* p, double* d_dst)
     base_args(p, a);
     a.mode = gst::EMIT_PROBS;
     a.out = d_dst;
-    int rc = ensure_scratch(p, 0, p->hp.n_tasks(), a);
-    if (rc) return rc;
-    HIP_TRY(gst::launch_walk(p->hp.D, 0, a, p->hp.n_tasks(), p->stream));
+    HIP_TRY(gst::launch_walk(p->hp.D, 0, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     p->last_launches++;
     return GST_OK;
 }
@@ -285,10 +271,8 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     a.raw = d_raw; a.ldraw = ldraw;
     a.lanes.col = p->d_lane[0].p; a.lanes.kind[0] = p->d_lane[1].p; a.lanes.obj[0] = p->d_lane[2].p; a.lanes.elem[0] = p->d_lane[3].p;
     a.n_pwaves = L.n_waves;
-    const int64_t blocks = p->hp.n_tasks() * (int64_t)L.n_waves;
-    if ((rc = ensure_scratch(p, 1, blocks, a))) return rc;
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
-    HIP_TRY(gst::launch_walk(p->hp.D, 1, a, p->hp.n_tasks(), p->stream));
+    HIP_TRY(gst::launch_walk(p->hp.D, 1, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     p->last_launches++;
     return GST_OK;
@@ -557,13 +541,11 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     }
     a.wave_row = p->d_wave_row.p; a.wave_rowidx = p->d_wave_rowidx.p; a.lane_colidx = p->d_lane_colidx.p;
     a.n_pwaves = L.n_waves;
-    const int64_t blocks = p->hp.n_tasks() * (int64_t)L.n_waves;
-    if ((rc = ensure_scratch(p, 2, blocks, a))) return rc;
     // rows/columns of the caller's block that this call does not own must survive: start from the caller's data
     const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
     if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
-    HIP_TRY(gst::launch_walk(p->hp.D, 2, a, p->hp.n_tasks(), p->stream));
+    HIP_TRY(gst::launch_walk(p->hp.D, 2, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     p->last_launches++;
     HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));

@@ -1,6 +1,6 @@
 // gst_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the dense-matrix forward simulator.
 //
-// One kernel family, `walk_kernel<D,S,NREG>`: ONE WAVEFRONT interprets ONE walk program (a task: a
+// One kernel family, `walk_kernel<D,S,WPS>` (WPS = wavefronts per SIMD the register budget is cut for): ONE WAVEFRONT interprets ONE walk program (a task: a
 // sub-trie of circuit prefixes, see gst_plan.hpp) and its 64 LANES are 64 different perturbed models
 // (64 columns of the Jacobian / of one Hessian row).  The program is wave-uniform, so
 //   * control flow never diverges,
@@ -58,13 +58,32 @@ __device__ __forceinline__ void matvec_t(cdouble_p __restrict__ Mt, const double
     for (int i = 0; i < D; i++) o[i] = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; s++) r[s] = 0.0;
+    // Software pipeline over columns: the scalar loads of column j+1 are issued before column j's
+    // 2*D VALU instructions, so their latency hides under arithmetic (the scheduling barriers keep
+    // hipcc from sinking the loads back next to their uses, where every s_load would be waited for
+    // immediately).
+    double cur[D], nxt[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) cur[i] = Mt[i];
 #pragma unroll
     for (int j = 0; j < D; j++) {
+        // column j has landed; SMEM returns out of order, so lgkmcnt(0) is the only usable wait and it
+        // must sit BEFORE the next column's loads are issued (0xC07F = lgkmcnt(0), vmcnt/expcnt untouched)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < D) {
+#pragma unroll
+            for (int i = 0; i < D; i++) nxt[i] = Mt[(j + 1) * D + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         const double vj = v[j];
 #pragma unroll
-        for (int i = 0; i < D; i++) o[i] = o[i] + Mt[j * D + i] * vj;
+        for (int i = 0; i < D; i++) o[i] = o[i] + cur[i] * vj;
 #pragma unroll
         for (int s = 0; s < NS; s++) r[s] = r[s] + sp[s][j] * vj;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < D; i++) cur[i] = nxt[i];
     }
 }
 
@@ -86,9 +105,14 @@ __device__ __forceinline__ double dot_r(const double (&r)[D], const double (&v)[
     return acc;
 }
 
-template <int D, int S, int NREG>
-__global__ __launch_bounds__(64, 2) void walk_kernel(const WalkArgs a)
+template <int D, int S, int WPS>
+__global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
 {
+    // Save slots (states kept while the children of a branching trie node are walked) live in LDS:
+    // slot s, component j, lane l at lds[(s*D + j)*64 + l] -- lane-consecutive 8-byte words, conflict
+    // free.  The plan compiler caps the number of slots (gst_options.max_slots) so that 4 wavefronts
+    // per SIMD fit in the CU's 160 KB.
+    extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int64_t bid = blockIdx.x;
     const int32_t pw = (int32_t)(bid % a.n_pwaves);
@@ -166,15 +190,8 @@ __global__ __launch_bounds__(64, 2) void walk_kernel(const WalkArgs a)
     double sp0[1][D];   // placeholder operand of the no-special mat-vec (never read)
 #pragma unroll
     for (int j = 0; j < D; j++) sp0[0][j] = 0.0;
-    double R[NREG > 0 ? NREG : 1][D];
 #pragma unroll
     for (int j = 0; j < D; j++) v[j] = 0.0;
-#pragma unroll
-    for (int r = 0; r < (NREG > 0 ? NREG : 1); r++)
-#pragma unroll
-        for (int j = 0; j < D; j++) R[r][j] = 0.0;
-
-    double* scratch = a.scratch + ((bid * (int64_t)a.n_scratch_slots) * D) * 64 + lane;
 
     int64_t pc = as_const(a.task_off)[task];
     uint32_t wnext = prog[pc];
@@ -239,33 +256,13 @@ __global__ __launch_bounds__(64, 2) void walk_kernel(const WalkArgs a)
                 }
             }
         } else if (op == GST_OP_SAVE) {
-            bool done = false;
+            double* sl = lds + (int64_t)arg * D * 64 + lane;
 #pragma unroll
-            for (int r = 0; r < NREG; r++)
-                if (arg == (uint32_t)r) {
-#pragma unroll
-                    for (int j = 0; j < D; j++) R[r][j] = v[j];
-                    done = true;
-                }
-            if (!done) {
-                double* sl = scratch + ((int64_t)(arg - NREG) * D) * 64;
-#pragma unroll
-                for (int j = 0; j < D; j++) sl[j * 64] = v[j];
-            }
+            for (int j = 0; j < D; j++) sl[j * 64] = v[j];
         } else if (op == GST_OP_LOAD) {
-            bool done = false;
+            const double* sl = lds + (int64_t)arg * D * 64 + lane;
 #pragma unroll
-            for (int r = 0; r < NREG; r++)
-                if (arg == (uint32_t)r) {
-#pragma unroll
-                    for (int j = 0; j < D; j++) v[j] = R[r][j];
-                    done = true;
-                }
-            if (!done) {
-                const double* sl = scratch + ((int64_t)(arg - NREG) * D) * 64;
-#pragma unroll
-                for (int j = 0; j < D; j++) v[j] = sl[j * 64];
-            }
+            for (int j = 0; j < D; j++) v[j] = sl[j * 64];
         } else {  // GST_OP_RHO
             cdouble_p r0 = rhos + (int64_t)arg * D;
 #pragma unroll
@@ -282,33 +279,28 @@ __global__ __launch_bounds__(64, 2) void walk_kernel(const WalkArgs a)
     }
 }
 
-// register-resident save slots per configuration (VGPR budget: 2 waves/SIMD = 256 VGPRs at D=16)
-int reg_slots(int D, int S)
-{
-    if (D <= 4) return 8;
-    return S == 0 ? 4 : (S == 1 ? 3 : 2);
-}
-
-template <int D, int S, int NREG>
-static hipError_t launch_one(const WalkArgs& a, int64_t n_tasks, hipStream_t stream)
+template <int D, int S, int WPS>
+static hipError_t launch_one(const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
 {
     const int64_t blocks = n_tasks * (int64_t)a.n_pwaves;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((walk_kernel<D, S, NREG>), dim3((unsigned)blocks), dim3(64), 0, stream, a);
+    const size_t lds_bytes = (size_t)n_slots * D * 64 * sizeof(double);
+    if (lds_bytes > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((walk_kernel<D, S, WPS>), dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, hipStream_t stream)
+hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
 {
     if (D == 4) {
-        if (S == 0) return launch_one<4, 0, 8>(a, n_tasks, stream);
-        if (S == 1) return launch_one<4, 1, 8>(a, n_tasks, stream);
-        if (S == 2) return launch_one<4, 2, 8>(a, n_tasks, stream);
+        if (S == 0) return launch_one<4, 0, 4>(a, n_tasks, n_slots, stream);
+        if (S == 1) return launch_one<4, 1, 4>(a, n_tasks, n_slots, stream);
+        if (S == 2) return launch_one<4, 2, 4>(a, n_tasks, n_slots, stream);
     } else if (D == 16) {
-        if (S == 0) return launch_one<16, 0, 4>(a, n_tasks, stream);
-        if (S == 1) return launch_one<16, 1, 3>(a, n_tasks, stream);
-        if (S == 2) return launch_one<16, 2, 2>(a, n_tasks, stream);
+        if (S == 0) return launch_one<16, 0, 4>(a, n_tasks, n_slots, stream);
+        if (S == 1) return launch_one<16, 1, 4>(a, n_tasks, n_slots, stream);
+        if (S == 2) return launch_one<16, 2, 3>(a, n_tasks, n_slots, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -51,15 +51,10 @@ struct WalkArgs {
     const int32_t* wave_row;     // EMIT_HESS: per wave: dest row (block-1 position) and its index into prow
     const int32_t* wave_rowidx;
     const int32_t* lane_colidx;  // EMIT_HESS: per lane slot: index into dcol's columns
-    // save slots beyond the register-resident ones: [wave][slot][D][64]
-    double* scratch;
-    int32_t n_scratch_slots;
 };
 
-// Number of save slots the kernels keep in registers for state dimension D and S specials.
-int reg_slots(int D, int S);
-
-// Launch the walk over all tasks x parameter wavefronts.  S = number of specials per lane (0,1,2).
-hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, hipStream_t stream);
+// Launch the walk over all tasks x parameter wavefronts.  S = number of specials per lane (0,1,2);
+// n_slots = save slots the programs use (LDS: n_slots * D * 512 bytes per wavefront).
+hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 
 }  // namespace gst

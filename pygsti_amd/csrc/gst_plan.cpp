@@ -72,6 +72,8 @@ struct Node {
     int32_t emit_head = -1;   // index into emit list (linked through emit_next)
     int32_t need = 0;         // save slots needed below this node
     int32_t weight = 0;       // nodes in subtree (tie-break)
+    int64_t bsum = 0;         // T: sum over branching nodes M of this subtree of (children(M) - 1)
+    int64_t bdist = 0;        // U: the same sum weighted by the distance from this node to M
 };
 
 struct TaskCompiler {
@@ -121,9 +123,13 @@ struct TaskCompiler {
         for (int32_t i = (int32_t)nodes.size() - 1; i >= 0; i--) {
             Node& n = nodes[i];
             n.weight = 1;
+            n.bsum = n.n_children > 1 ? n.n_children - 1 : 0;
+            n.bdist = 0;
             int32_t best = -1, second = -1;   // largest and second-largest child need
             for (int32_t ch = n.first_child; ch >= 0; ch = nodes[ch].next_sibling) {
                 n.weight += nodes[ch].weight;
+                n.bsum += nodes[ch].bsum;
+                n.bdist += nodes[ch].bdist + nodes[ch].bsum;
                 const int32_t nd = nodes[ch].need;
                 if (nd > best) { second = best; best = nd; } else if (nd > second) second = nd;
             }
@@ -137,7 +143,14 @@ struct TaskCompiler {
         prog.push_back(((depth == 1 ? GST_OP_RHO : GST_OP_APPLY) << 28) | (uint32_t)nodes[node].sym);
     }
 
-    // emit the program for the subtree below `node` (whose state is in v), free slots from `base`
+    int32_t slot_limit = 1 << 20;       // save slots the device offers (gst_options.max_slots)
+    std::vector<uint32_t> replay;       // program words that re-create the CURRENT node's state from its anchor
+                                        // (a LOAD of a live slot, or a RHO) -- used where no slot is free
+
+    // Emit the program for the subtree below `node` (whose state is in v); slots >= `base` are free.
+    // A branching node keeps its state in slot `base` while its children are walked; when the slot
+    // budget is exhausted the state is instead re-derived for each child by replaying the (short)
+    // path from the nearest saved ancestor -- same gates in the same order, so bit-identical.
     void walk(int32_t node, int depth, int32_t base)
     {
         for (;;) {
@@ -148,37 +161,73 @@ struct TaskCompiler {
             if (n.n_children == 1) {             // chain: iterate, do not recurse
                 node = n.first_child; depth++;
                 op(node, depth);
+                if (depth == 1) replay.clear();
+                replay.push_back(prog.back());
                 continue;
             }
-            // pick the child that goes last: largest need, then largest subtree
+            // pick the child that goes last (it inherits slot `base`): the heaviest subtree, because with a
+            // bounded slot budget everything walked BEFORE it has one slot less and may have to replay
             int32_t last = -1;
             for (int32_t ch = n.first_child; ch >= 0; ch = nodes[ch].next_sibling)
-                if (last < 0 || nodes[ch].need > nodes[last].need ||
-                    (nodes[ch].need == nodes[last].need && nodes[ch].weight > nodes[last].weight))
+                if (last < 0 || nodes[ch].weight > nodes[last].weight ||
+                    (nodes[ch].weight == nodes[last].weight && nodes[ch].need > nodes[last].need))
                     last = ch;
-            const bool root = (depth == 0);      // children of the root start from a rho: nothing to save
-            if (!root) {
+            const std::vector<uint32_t> here = replay;       // re-creates THIS node's state
+            if (depth == 0) {                    // children of the root start from a rho: nothing to keep
+                for (int32_t ch = n.first_child; ch >= 0; ch = nodes[ch].next_sibling) {
+                    if (ch == last) continue;
+                    op(ch, 1);
+                    replay.assign(1, prog.back());
+                    walk(ch, 1, base);
+                }
+                node = last; depth = 1;
+                op(node, depth);
+                replay.assign(1, prog.back());
+                continue;
+            }
+            bool have_slot = base < slot_limit;
+            if (have_slot && base == slot_limit - 1) {
+                // About to take the LAST free slot.  Holding it here denies it to everything walked before
+                // the last child: each branching node M in those subtrees then replays dist(this, M) gates per
+                // extra child.  If re-deriving THIS node's state per child is cheaper than that, replay here
+                // and leave the slot to the descendants (typical: a shallow fork above several long chains).
+                const int64_t replay_cost = (int64_t)(n.n_children - 1) * (int64_t)here.size();
+                int64_t deny_cost = 0;
+                for (int32_t ch = n.first_child; ch >= 0; ch = nodes[ch].next_sibling)
+                    if (ch != last) deny_cost += nodes[ch].bdist + nodes[ch].bsum;
+                if (replay_cost < deny_cost) have_slot = false;
+            }
+            if (have_slot) {
                 prog.push_back((GST_OP_SAVE << 28) | (uint32_t)base);
                 max_slot_used = std::max(max_slot_used, base + 1);
             }
             bool first = true;
             for (int32_t ch = n.first_child; ch >= 0; ch = nodes[ch].next_sibling) {
                 if (ch == last) continue;
-                if (!first && !root) prog.push_back((GST_OP_LOAD << 28) | (uint32_t)base);
+                if (!first) {
+                    if (have_slot) prog.push_back((GST_OP_LOAD << 28) | (uint32_t)base);
+                    else prog.insert(prog.end(), here.begin(), here.end());
+                }
                 first = false;
                 op(ch, depth + 1);
-                walk(ch, depth + 1, root ? base : base + 1);
+                if (have_slot) replay.assign(1, (GST_OP_LOAD << 28) | (uint32_t)base);
+                else replay = here;
+                replay.push_back(prog.back());
+                walk(ch, depth + 1, have_slot ? base + 1 : base);
             }
-            if (!root) prog.push_back((GST_OP_LOAD << 28) | (uint32_t)base);
+            if (have_slot) prog.push_back((GST_OP_LOAD << 28) | (uint32_t)base);
+            else prog.insert(prog.end(), here.begin(), here.end());
             node = last; depth++;
-            op(node, depth);                     // continue into the last child with slot `base` free again
+            op(node, depth);                     // continue into the last child; slot `base` is free again,
+            replay = here;                       // so its anchor is this node's own anchor
+            replay.push_back(prog.back());
         }
     }
 };
 
 }  // namespace
 
-std::string compile_plan(HostPlan& P, int32_t target_tasks)
+std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
 {
     const int64_t nC = P.n_circuits;
     if (P.D <= 0 || P.n_gates < 0 || P.n_rhos <= 0 || P.n_effects <= 0) return "bad dimensions";
@@ -263,6 +312,7 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks)
         if (cuts[t] == cuts[t + 1]) continue;
         Built b;
         TaskCompiler tc(P, b.words);
+        if (max_slots > 0) tc.slot_limit = max_slots;
         tc.build(order, lcp, cuts[t], cuts[t + 1]);
         tc.walk(0, 0, 0);
         b.words.push_back(GST_OP_END << 28);

@@ -44,7 +44,8 @@ std::string expand_table(HostPlan& P, int32_t n_rows, int32_t cache_size, const 
                          const int32_t* t_start, const int32_t* t_cache, const int32_t* t_rho,
                          const int64_t* row_ptr, const int32_t* gate_idx);
 
-// Validate indices, then build trie/tasks/programs.  target_tasks <= 0 picks a default.
-std::string compile_plan(HostPlan& P, int32_t target_tasks);
+// Validate indices, then build trie/tasks/programs.  target_tasks <= 0 picks a default; max_slots > 0
+// caps the number of save slots a program may use (states beyond it are re-derived by replay).
+std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots);
 
 }  // namespace gst

@@ -69,13 +69,13 @@ class HipLayoutAtom:
             eff_dest = np.arange(n * nO, dtype=np.int32)
             self._plan = _lib.Plan.from_circuits(L.dim, L.num_gates, 1, nO, n * nO, np.zeros(n, np.int32), ptr,
                                                  gates, eff_ptr, eff_label, eff_dest, device=self.device,
-                                                 target_tasks=L.target_tasks)
+                                                 target_tasks=L.target_tasks, max_slots=L.max_slots)
         return self._plan
 
 
 class HipCOPALayout:
     def __init__(self, circuits, model, num_atoms=1, devices=None, rank=0, size=1, target_tasks=0,
-                 param_dimension_blk_sizes=(None, None)):
+                 param_dimension_blk_sizes=(None, None), max_slots=0):
         self.circuits = [tuple(c) for c in circuits]
         self.num_circuits = len(self.circuits)
         self.model_gate_labels = list(model.operations.keys())
@@ -85,6 +85,7 @@ class HipCOPALayout:
         self._outcomes = [tuple([lbl.split("_", 1)[1]]) for lbl in self.effect_labels]
         self.num_outcomes = len(self._outcomes)
         self.target_tasks = target_tasks
+        self.max_slots = max_slots
         self._num_params = model.num_params
         lookup = {l: i for i, l in enumerate(self.model_gate_labels)}
         self._circ_len = np.fromiter((len(c) for c in self.circuits), dtype=np.int64, count=self.num_circuits)
