@@ -1,0 +1,162 @@
+"""Drop-in for the real pyGSTi (when it is importable): a MapForwardSimulator subclass whose three
+per-atom seams run on the MI355X through libgstfwd.
+
+    from pygsti_amd.pygsti_adapter import HipMapForwardSimulator
+    results = pygsti.protocols.GateSetTomography(...).run(data, simulator=HipMapForwardSimulator())
+
+Only the seams `DistributableForwardSimulator` subclasses are meant to override are replaced
+(pygsti/forwardsims/distforwardsim.py:105-108,148-152,236-241; Map implementations at
+mapforwardsim.py:372-391); layout creation (`MapCOPALayout`, which reads `sim.calclib`,
+layouts/maplayout.py:79,283), parameter blocking, the MPI grid, serialization and everything above
+stay pyGSTi's own.  The precedent for this plug-in style is the reference's own test
+test/unit/protocols/test_gst.py:224-302.
+
+The per-atom device plan is built once from the atom's prefix table (`atom.table.contents`,
+`elbl_indices_by_expcircuit`, `elindices_by_expcircuit`; layouts/maplayout.py:101-134) and cached on
+the atom; each call only re-uploads the dense model arrays (the reference re-marshals the whole
+layout on every call, mapforwardsim_calc_densitymx.pyx:170-181).
+
+Scope: dense `densitymx` models whose members are fully parameterised (one parameter per dense
+element: FullArbitraryOp / FullState / FullPOVMEffect).  Anything else raises NotImplementedError --
+there is no silent fallback to the CPU path.
+"""
+import numpy as np
+
+from . import _lib
+
+try:   # pyGSTi is optional: this module is importable (and useless) without it
+    from pygsti.forwardsims.mapforwardsim import MapForwardSimulator as _MapForwardSimulator
+    from pygsti.tools import slicetools as _slct
+    HAVE_PYGSTI = True
+except Exception:   # pragma: no cover - exercised only where pyGSTi is absent
+    _MapForwardSimulator = object
+    _slct = None
+    HAVE_PYGSTI = False
+
+
+def atom_arrays(model, atom):
+    """Dense model arrays in the atom's own index order (op_labels sorted, full_effect_labels a set whose
+    iteration order defines effect indices -- captured once)."""
+    D = model.dim
+    op_labels, rho_labels = list(atom.op_labels), list(atom.rho_labels)
+    eff_labels = getattr(atom, "_hip_eff_labels", None)
+    if eff_labels is None:
+        eff_labels = atom._hip_eff_labels = list(atom.full_effect_labels)
+
+    def dense(lbl, typ, shape):
+        return np.ascontiguousarray(np.real(model._circuit_layer_operator(lbl, typ).to_dense("minimal")),
+                                    dtype=np.float64).reshape(shape)
+    gates = np.array([dense(l, "op", (D, D)) for l in op_labels]).reshape(len(op_labels), D, D)
+    rhos = np.array([dense(l, "prep", (D,)) for l in rho_labels]).reshape(len(rho_labels), D)
+    effects = np.array([dense(l, "povm", (D,)) for l in eff_labels]).reshape(len(eff_labels), D)
+    return gates, rhos, effects
+
+
+def atom_param_map(model, atom):
+    """Parameter -> (kind, object, element) for `full` members; loud failure otherwise."""
+    D, nP = model.dim, model.num_params
+    kind = -np.ones(nP, np.int32); obj = np.zeros(nP, np.int32); elem = np.zeros(nP, np.int32)
+    eff_labels = atom._hip_eff_labels
+    for k, labels, typ in ((_lib.KIND_GATE, list(atom.op_labels), "op"), (_lib.KIND_RHO, list(atom.rho_labels), "prep"),
+                           (_lib.KIND_EFFECT, eff_labels, "povm")):
+        n_el = D * D if k == _lib.KIND_GATE else D
+        for oi, lbl in enumerate(labels):
+            member = model._circuit_layer_operator(lbl, typ)
+            idx = member.gpindices_as_array()
+            if len(idx) == 0:
+                continue        # static member: no parameters
+            dw = None
+            if len(idx) != n_el or not np.array_equal((dw := np.asarray(member.deriv_wrt_params())).reshape(n_el, -1),
+                                                       np.eye(n_el)):
+                raise NotImplementedError(
+                    "member %s is not fully parameterised (deriv_wrt_params is not the identity); the device path "
+                    "supports one-parameter-per-dense-element members only in this round" % str(lbl))
+            kind[idx] = k; obj[idx] = oi; elem[idx] = np.arange(n_el)
+    return kind, obj, elem
+
+
+def atom_plan(model, atom, device=-1, target_tasks=0):
+    """The libgstfwd plan of a `_MapCOPALayoutAtom`, built from its prefix table and cached on the atom."""
+    plan = getattr(atom, "_hip_plan", None)
+    if plan is not None:
+        return plan
+    op_lookup = {l: i for i, l in enumerate(atom.op_labels)}
+    rho_lookup = {l: i for i, l in enumerate(atom.rho_labels)}
+    contents = atom.table.contents
+    R = len(contents)
+    t_dest = np.empty(R, np.int32); t_start = np.empty(R, np.int32); t_cache = np.empty(R, np.int32)
+    t_rho = -np.ones(R, np.int32); row_ptr = np.zeros(R + 1, np.int64); gidx = []
+    for k, (iDest, iStart, remainder, iCache) in enumerate(contents):   # convert_maplayout, pyx:55-77
+        t_dest[k] = iDest
+        t_start[k] = -1 if iStart is None else iStart
+        t_cache[k] = -1 if iCache is None else iCache
+        rem = list(remainder)
+        if iStart is None:
+            t_rho[k] = rho_lookup[rem[0]]; rem = rem[1:]
+        gidx.extend(op_lookup[g] for g in rem)
+        row_ptr[k + 1] = len(gidx)
+    eff_ptr = np.zeros(R + 1, np.int64); el, ed = [], []
+    for i in range(R):
+        el.extend(atom.elbl_indices_by_expcircuit[i]); ed.extend(atom.elindices_by_expcircuit[i])
+        eff_ptr[i + 1] = len(el)
+    atom._hip_eff_labels = list(atom.full_effect_labels)
+    plan = _lib.Plan.from_table(model.dim, len(atom.op_labels), len(atom.rho_labels), len(atom._hip_eff_labels),
+                                atom.num_elements, atom.cache_size, t_dest, t_start, t_cache, t_rho, row_ptr,
+                                np.array(gidx, np.int32), eff_ptr, np.array(el, np.int32), np.array(ed, np.int32),
+                                device=device, target_tasks=target_tasks)
+    atom._hip_plan = plan
+    return plan
+
+
+class HipMapForwardSimulator(_MapForwardSimulator):
+    """MapForwardSimulator whose atom fills run on the GPU (bit-identical results)."""
+
+    def __init__(self, model=None, max_cache_size=None, num_atoms=None, processor_grid=None, param_blk_sizes=None,
+                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1):
+        if not HAVE_PYGSTI:
+            raise ImportError("pygsti is not importable; use pygsti_amd.forwardsim.HipMapForwardSimulator instead")
+        super().__init__(model, max_cache_size, num_atoms, processor_grid, param_blk_sizes, derivative_eps, hessian_eps)
+        self._hip_device = device
+
+    def copy(self, keep_model_attached=True):
+        out = HipMapForwardSimulator(self.model if keep_model_attached else None, self._max_cache_size, self._num_atoms,
+                                     self._processor_grid, self._pblk_sizes, self.derivative_eps, self.hessian_eps,
+                                     self._hip_device)
+        return out
+
+    def _prepare(self, layout_atom):
+        plan = atom_plan(self.model, layout_atom, self._hip_device)
+        plan.set_model(*atom_arrays(self.model, layout_atom))
+        if plan.n_params != self.model.num_params or getattr(layout_atom, "_hip_pmap_model", None) is not self.model:
+            plan.set_param_map(*atom_param_map(self.model, layout_atom))
+            layout_atom._hip_pmap_model = self.model
+        return plan
+
+    def _bulk_fill_probs_atom(self, array_to_fill, layout_atom, resource_alloc):
+        plan = self._prepare(layout_atom)
+        if array_to_fill.flags.c_contiguous:
+            plan.fill_probs(array_to_fill)
+        else:
+            array_to_fill[:] = plan.fill_probs()
+
+    def _bulk_fill_dprobs_atom(self, array_to_fill, dest_param_slice, layout_atom, param_slice, resource_alloc):
+        plan = self._prepare(layout_atom)
+        nP = self.model.num_params
+        pidx = np.arange(nP) if param_slice is None else _slct.to_array(param_slice)
+        didx = None if dest_param_slice is None else _slct.to_array(dest_param_slice)
+        plan.fill_dprobs(array_to_fill, pidx, didx, self.derivative_eps)
+
+    def _bulk_fill_hprobs_atom(self, array_to_fill, dest_param_slice1, dest_param_slice2, layout_atom,
+                               param_slice1, param_slice2, resource_alloc):
+        plan = self._prepare(layout_atom)
+        nP = self.model.num_params
+        i1 = np.arange(nP) if param_slice1 is None else _slct.to_array(param_slice1)
+        i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)
+        d1 = None if dest_param_slice1 is None else _slct.to_array(dest_param_slice1)
+        d2 = None if dest_param_slice2 is None else _slct.to_array(dest_param_slice2)
+        if array_to_fill.flags.c_contiguous:
+            plan.fill_hprobs(array_to_fill, i1, i2, d1, d2, self.hessian_eps)
+        else:
+            tmp = np.ascontiguousarray(array_to_fill)
+            plan.fill_hprobs(tmp, i1, i2, d1, d2, self.hessian_eps)
+            array_to_fill[...] = tmp
