@@ -178,6 +178,9 @@ const char *gst_version(void);
 #define GST_OP_SAVE 3u   /* slot[arg] <- v */
 #define GST_OP_LOAD 4u   /* v <- slot[arg] */
 #define GST_OP_EMIT 5u   /* elements of expanded circuit arg: p = E . v */
+#define GST_OP_NODE 6u   /* marker after every RHO/APPLY: the state just produced has global id arg (the base
+                            pass stores it in the base-state cache; derivative passes use it to skip work
+                            that is bit-identical to the base pass) */
 #define GST_OP(word) ((word) >> 28)
 #define GST_ARG(word) ((word) & 0x0FFFFFFFu)
 

@@ -17,7 +17,7 @@ GST_EINVAL, GST_ENODEVICE, GST_EHIP, GST_ENOMEM, GST_ESTATE, GST_EUNSUPPORTED = 
 KIND_NONE, KIND_GATE, KIND_RHO, KIND_EFFECT = -1, 0, 1, 2
 DERIV_FD, DERIV_ANALYTIC = 0, 1
 
-OP_END, OP_RHO, OP_APPLY, OP_SAVE, OP_LOAD, OP_EMIT = 0, 1, 2, 3, 4, 5
+OP_END, OP_RHO, OP_APPLY, OP_SAVE, OP_LOAD, OP_EMIT, OP_NODE = 0, 1, 2, 3, 4, 5, 6
 
 
 class GstError(RuntimeError):

@@ -75,6 +75,7 @@ struct gst_plan {
     std::vector<int32_t> pkind, pobj, pelem;
     bool have_pmap = false;
     // work buffers
+    DevBuf<double> d_base_cache;   // [n_state_ids][D] states of the last base pass
     DevBuf<double> d_pbase, d_out, d_raw, d_dcol, d_probs_tmp;
     DevBuf<int32_t> d_lane[7];   // col, kind0, obj0, elem0, kind1, obj1, elem1
     DevBuf<int32_t> d_wave_row, d_wave_rowidx, d_lane_colidx;
@@ -88,7 +89,7 @@ struct gst_plan {
         (void)hipSetDevice(device);
         d_prog.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
-        d_pbase.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
+        d_pbase.release(); d_base_cache.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
         d_wave_row.release(); d_wave_rowidx.release(); d_lane_colidx.release();
         if (ev0) (void)hipEventDestroy(ev0);
@@ -182,13 +183,18 @@ void base_args(gst_plan* p, gst::WalkArgs& a)
     a.n_pwaves = 1;
 }
 
-// Base probabilities into d_dst (device), S = 0 walk: one wavefront per task.
-int run_probs(gst_plan* p, double* d_dst)
+// Base probabilities into d_dst (device), S = 0 walk: one wavefront per task.  With `fill_cache` the
+// pass also stores every state it produces (the derivative passes start from them).
+int run_probs(gst_plan* p, double* d_dst, bool fill_cache)
 {
     gst::WalkArgs a;
     base_args(p, a);
     a.mode = gst::EMIT_PROBS;
     a.out = d_dst;
+    if (fill_cache) {
+        HIP_TRY(p->d_base_cache.ensure((size_t)p->hp.n_state_ids * p->hp.D));
+        a.base_cache_w = p->d_base_cache.p;
+    }
     HIP_TRY(gst::launch_walk(p->hp.D, 0, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     p->last_launches++;
     return GST_OK;
@@ -253,7 +259,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
 {
     // base probabilities (pyx:349)
     double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
-    int rc = run_probs(p, d_base);
+    int rc = run_probs(p, d_base, n_param > 0);
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
     LaneLayout L;
@@ -269,6 +275,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     a.mode = gst::EMIT_FD;
     a.out = d_out; a.ld = ld; a.eps = eps; a.pbase = d_base;
     a.raw = d_raw; a.ldraw = ldraw;
+    a.base_cache = p->d_base_cache.p;
     a.lanes.col = p->d_lane[0].p; a.lanes.kind[0] = p->d_lane[1].p; a.lanes.obj[0] = p->d_lane[2].p; a.lanes.elem[0] = p->d_lane[3].p;
     a.n_pwaves = L.n_waves;
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
@@ -422,7 +429,7 @@ int gst_fill_probs_dev(gst_plan* p, double* d_out)
     if (rc) return rc;
     if (!d_out) return fail(GST_EINVAL, "d_out is NULL");
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
-    if ((rc = run_probs(p, d_out))) return rc;
+    if ((rc = run_probs(p, d_out, false))) return rc;
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     return end_call(p, false);
 }
@@ -433,7 +440,7 @@ int gst_fill_probs(gst_plan* p, double* out)
     if (rc) return rc;
     if (!out) return fail(GST_EINVAL, "out is NULL");
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
-    if ((rc = run_probs(p, p->d_pbase.p))) return rc;
+    if ((rc = run_probs(p, p->d_pbase.p, false))) return rc;
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     HIP_TRY(hipMemcpyAsync(out, p->d_pbase.p, p->hp.n_elements * 8, hipMemcpyDeviceToHost, p->stream));
     return end_call(p, true);
@@ -535,6 +542,7 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     a.mode = gst::EMIT_HESS;
     a.out = p->d_out.p; a.ld = ld1; a.ld2 = ld2; a.eps = eps;
     a.prow = p->d_raw.p; a.ldrow = n1; a.dcol = p->d_dcol.p; a.lddcol = n2;
+    a.pbase = p->d_pbase.p; a.base_cache = p->d_base_cache.p;
     a.lanes.col = p->d_lane[0].p;
     for (int s = 0; s < 2; s++) {
         a.lanes.kind[s] = p->d_lane[1 + 3 * s].p; a.lanes.obj[s] = p->d_lane[2 + 3 * s].p; a.lanes.elem[s] = p->d_lane[3 + 3 * s].p;

@@ -45,11 +45,33 @@ struct State {
     double x[D];
 };
 
+// Pin a set of accumulators at this point of the program: an empty volatile asm that "modifies" them.
+// IR-level passes may otherwise move the (side-effect free) multiplies/adds of a column across the
+// scheduling barriers, which empties the software pipeline below.
+template <int D>
+__device__ __forceinline__ void pin(double (&o)[D])
+{
+    if constexpr (D == 16) {
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]),
+                          "+v"(o[8]), "+v"(o[9]), "+v"(o[10]), "+v"(o[11]), "+v"(o[12]), "+v"(o[13]), "+v"(o[14]), "+v"(o[15]));
+    } else {
+#pragma unroll
+        for (int i = 0; i < D; i++) asm volatile("" : "+v"(o[i]));
+    }
+}
+
 // o = M v with M given TRANSPOSED (Mt[j*D+i] = M[i][j]): column sweep, o += M[:,j]*v[j].
 // Every o[i] still accumulates its products in ascending j from +0.0 with separate mul/add (the
 // reference's order, opcreps.cpp:45-51), but the D accumulators are independent, so the VALU never
 // waits on a dependent add, and one contiguous scalar load brings a whole column.
 // `NS` lane-private special rows ride along as extra accumulators: r[s] = sp[s] . v.
+//
+// Software pipeline over columns: column j+1's scalar loads (2 x s_load_dwordx16 at D=16) are issued
+// BEFORE column j's 2*D VALU instructions, so their latency hides under arithmetic.  SMEM returns out
+// of order, so the only usable wait is lgkmcnt(0) and it must come before the next loads are issued.
+// The order is enforced three ways: the wait and the pins are side-effecting (kept in program order),
+// each column's load address passes through a volatile asm (the loads cannot be hoisted above it), and
+// a scheduling barrier keeps the arithmetic behind the loads.
 template <int D, int NS>
 __device__ __forceinline__ void matvec_t(cdouble_p __restrict__ Mt, const double (&v)[D], double (&o)[D],
                                          const double (&sp)[NS > 0 ? NS : 1][D], double (&r)[NS > 0 ? NS : 1])
@@ -58,22 +80,21 @@ __device__ __forceinline__ void matvec_t(cdouble_p __restrict__ Mt, const double
     for (int i = 0; i < D; i++) o[i] = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; s++) r[s] = 0.0;
-    // Software pipeline over columns: the scalar loads of column j+1 are issued before column j's
-    // 2*D VALU instructions, so their latency hides under arithmetic (the scheduling barriers keep
-    // hipcc from sinking the loads back next to their uses, where every s_load would be waited for
-    // immediately).
     double cur[D], nxt[D];
+    {
+        cdouble_p p = Mt;
+        asm volatile("" : "+s"(p));
 #pragma unroll
-    for (int i = 0; i < D; i++) cur[i] = Mt[i];
+        for (int i = 0; i < D; i++) cur[i] = p[i];
+    }
 #pragma unroll
     for (int j = 0; j < D; j++) {
-        // column j has landed; SMEM returns out of order, so lgkmcnt(0) is the only usable wait and it
-        // must sit BEFORE the next column's loads are issued (0xC07F = lgkmcnt(0), vmcnt/expcnt untouched)
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): column j has landed (vmcnt/expcnt untouched)
         if (j + 1 < D) {
+            cdouble_p p = Mt + (j + 1) * D;
+            asm volatile("" : "+s"(p));
 #pragma unroll
-            for (int i = 0; i < D; i++) nxt[i] = Mt[(j + 1) * D + i];
+            for (int i = 0; i < D; i++) nxt[i] = p[i];
         }
         __builtin_amdgcn_sched_barrier(0);
         const double vj = v[j];
@@ -81,7 +102,7 @@ __device__ __forceinline__ void matvec_t(cdouble_p __restrict__ Mt, const double
         for (int i = 0; i < D; i++) o[i] = o[i] + cur[i] * vj;
 #pragma unroll
         for (int s = 0; s < NS; s++) r[s] = r[s] + sp[s][j] * vj;
-        __builtin_amdgcn_sched_barrier(0);
+        pin<D>(o);
 #pragma unroll
         for (int i = 0; i < D; i++) cur[i] = nxt[i];
     }
@@ -120,12 +141,15 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
     const int64_t q = (int64_t)pw * 64 + lane;
 
     cdouble_p gates_t = as_const(a.gates_t);
-    cdouble_p rhos = as_const(a.rhos);
-    cdouble_p effects = as_const(a.effects);
-    cu32_p prog = as_const(a.prog);
-    ci32_p eff_ptr = as_const(a.eff_ptr);
-    ci32_p eff_label = as_const(a.eff_label);
-    ci32_p eff_dest = as_const(a.eff_dest);
+    // Cold kernel arguments (everything EMIT / RHO / NODE need) are NOT kept live in SGPRs across the
+    // interpreter loop: `cold()` re-reads them from the kernarg segment where they are used.  The hot loop
+    // is SGPR-bound (two 32-SGPR coefficient buffers); every argument that stays live gets spilled into
+    // VGPR lanes and comes back through v_readlane in the middle of the arithmetic.
+    auto cold = [&]() -> const GST_CONST WalkArgs* {
+        const GST_CONST WalkArgs* p = (const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));      // opaque: keeps LICM from hoisting the loads out of the loop
+        return p;
+    };
 
     // ---- per-lane specials ---------------------------------------------------------------------
     constexpr int S1 = S > 0 ? S : 1;
@@ -193,43 +217,148 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
 #pragma unroll
     for (int j = 0; j < D; j++) v[j] = 0.0;
 
-    int64_t pc = as_const(a.task_off)[task];
-    uint32_t wnext = prog[pc];
-    for (;;) {
-        const uint32_t w = wnext;
-        const uint32_t op = GST_OP(w);
-        const uint32_t arg = GST_ARG(w);
-        if (op == GST_OP_END) break;
-        pc++;
-        wnext = prog[pc];   // prefetch the next instruction word (scalar load) under this one's work
+    // ---- clean/dirty tracking (derivative passes) ---------------------------------------------------------
+    // A state whose path contains no gate that any lane of this wavefront perturbs (and that did not start
+    // from a perturbed rho) is BIT-IDENTICAL to the base pass's state.  Such "clean" states are not computed:
+    // the wavefront only follows the NODE markers; when a perturbed gate is finally applied the state is
+    // fetched from the base-state cache written by the S=0 pass.  Clean EMITs write exact zeros
+    // ((p - p)/eps == +0.0), unless effect parameters are perturbed, in which case the dot runs on the
+    // cached state.  All of this is wave-uniform scalar bookkeeping.
+    constexpr int MAXSLOT = 4;    // the launcher refuses plans with more slots
+    uint64_t wave_gates = 0;
+    bool wave_rho = false, wave_eff = false;
+#pragma unroll
+    for (int s = 0; s < S; s++) { wave_gates |= gate_mask[s]; wave_rho = wave_rho || rho_any[s]; wave_eff = wave_eff || eff_any[s]; }
+    bool dirty = (S == 0);
+    int32_t cur_id = 0;
+    int32_t slot_tag[MAXSLOT];          // >= 0: the slot "holds" clean state id; -1: real data in LDS
+#pragma unroll
+    for (int i = 0; i < MAXSLOT; i++) slot_tag[i] = -1;
+    cdouble_p cache_c = as_const(a.base_cache);
 
+    // Instruction fetch: the program is read 64 words at a time with ONE coalesced vector load (lane l holds
+    // word base+l) and the current word is picked with v_readlane; the next window is already in flight.
+    const int64_t pc0 = as_const(a.task_off)[task];
+    const int64_t pc_end = as_const(a.task_off)[task + 1];
+    const uint32_t* gprog = a.prog + pc0;
+    const int32_t n_words = (int32_t)(pc_end - pc0);
+    int32_t wbase = 0;                  // first word of the current window (relative to pc0)
+    uint32_t win_cur = (lane < n_words) ? gprog[lane] : 0u;
+    uint32_t win_nxt = (64 + lane < n_words) ? gprog[64 + lane] : 0u;
+    int32_t pc = 0;
+    uint32_t op, arg;
+#define GST_FETCH()                                                                                   \
+    do {                                                                                              \
+        if (pc - wbase == 64) {                                                                       \
+            wbase += 64;                                                                              \
+            win_cur = win_nxt;                                                                        \
+            win_nxt = (wbase + 64 + lane < n_words) ? gprog[wbase + 64 + lane] : 0u;                  \
+        }                                                                                             \
+        const uint32_t w_ = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, (int)(pc - wbase));     \
+        op = GST_OP(w_); arg = GST_ARG(w_); pc++;                                                     \
+    } while (0)
+#define GST_HIT(g, out)                                                                               \
+    do {                                                                                              \
+        out = false;                                                                                  \
+        _Pragma("unroll") for (int s_ = 0; s_ < S; s_++)                                              \
+            out = out || (((g) < 64) ? ((gate_mask[s_] >> (g)) & 1ull) : (gate_mask[s_] != 0));       \
+    } while (0)
+
+    GST_FETCH();
+    for (;;) {
+        if (op == GST_OP_END) break;
         if (op == GST_OP_APPLY) {
-            double o[D];
-            cdouble_p Mt = gates_t + (int64_t)arg * D * D;
-            bool hit = false;
-#pragma unroll
-            for (int s = 0; s < S; s++)
-                hit = hit || ((arg < 64) ? ((gate_mask[s] >> arg) & 1ull) : (gate_mask[s] != 0));
-            if (S > 0 && hit) {      // wave-uniform: some lane's parameter lives in this gate
-                double r[S1];
-                matvec_t<D, S>(Mt, v, o, sp, r);
-#pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const bool mine = (kind[s] == GST_KIND_GATE) && (obj[s] == (int)arg);
-#pragma unroll
-                    for (int i = 0; i < D; i++) o[i] = (mine && row[s] == i) ? r[s] : o[i];
+            // Runs of (APPLY, NODE) pairs -- the chains of the trie -- are handled in two tight inner loops so
+            // that the state vector stays in place (one loop-carried definition) instead of being shuffled
+            // through the big dispatch loop's join blocks.
+            if (S > 0 && !dirty) {
+                bool hit;
+                GST_HIT(arg, hit);
+                while (!hit) {                           // clean run: nothing to compute, follow the markers
+                    GST_FETCH();                         // NODE
+                    cur_id = (int32_t)arg;
+                    GST_FETCH();
+                    if (op != GST_OP_APPLY) break;
+                    GST_HIT(arg, hit);
                 }
-            } else {
-                double r[1];
-                matvec_t<D, 0>(Mt, v, o, sp0, r);
-            }
+                if (op != GST_OP_APPLY || !hit) continue;
+                cdouble_p b = cache_c + (int64_t)cur_id * D;      // first perturbed gate on this path: start from the cache
 #pragma unroll
-            for (int j = 0; j < D; j++) v[j] = o[j];
+                for (int j = 0; j < D; j++) v[j] = b[j];
+                dirty = true;
+            }
+            do {
+                bool hit;
+                GST_HIT(arg, hit);
+                double o[D];
+                cdouble_p Mt = gates_t + (int64_t)arg * D * D;
+                if (S > 0 && hit) {      // wave-uniform: some lane's parameter lives in this gate
+                    double r[S1];
+                    matvec_t<D, S>(Mt, v, o, sp, r);
+#pragma unroll
+                    for (int s = 0; s < S; s++) {
+                        const bool mine = (kind[s] == GST_KIND_GATE) && (obj[s] == (int)arg);
+#pragma unroll
+                        for (int i = 0; i < D; i++) o[i] = (mine && row[s] == i) ? r[s] : o[i];
+                    }
+                } else {
+                    double r[1];
+                    matvec_t<D, 0>(Mt, v, o, sp0, r);
+                }
+#pragma unroll
+                for (int j = 0; j < D; j++) v[j] = o[j];
+                GST_FETCH();                             // the NODE marker of the state just produced
+                cur_id = (int32_t)arg;
+                if (S == 0 && cold()->base_cache_w) {
+                    // all lanes hold the same state: lane j stores component j (one 8*D-byte line per state)
+                    double x = v[0];
+#pragma unroll
+                    for (int j = 1; j < D; j++) x = (lane == j) ? v[j] : x;
+                    if (lane < D) cold()->base_cache_w[(int64_t)arg * D + lane] = x;
+                }
+                GST_FETCH();
+            } while (op == GST_OP_APPLY);
+            continue;
+        }
+        if (op == GST_OP_NODE) {                         // marker after a RHO
+            cur_id = (int32_t)arg;
+            if (S == 0 && cold()->base_cache_w) {
+                double x = v[0];
+#pragma unroll
+                for (int j = 1; j < D; j++) x = (lane == j) ? v[j] : x;
+                if (lane < D) cold()->base_cache_w[(int64_t)arg * D + lane] = x;
+            }
         } else if (op == GST_OP_EMIT) {
+            const GST_CONST WalkArgs* c = cold();
+            ci32_p eff_ptr = as_const(c->eff_ptr);
+            ci32_p eff_label = as_const(c->eff_label);
+            ci32_p eff_dest = as_const(c->eff_dest);
+            cdouble_p effects = as_const(c->effects);
             const int32_t x0 = eff_ptr[arg], x1 = eff_ptr[arg + 1];
+            const bool zero = (S > 0) && !dirty && !wave_eff;
+            if (S > 0 && !dirty && wave_eff) {           // effect parameters: real dots on the (clean) cached state
+                cdouble_p b = cache_c + (int64_t)cur_id * D;
+#pragma unroll
+                for (int j = 0; j < D; j++) v[j] = b[j];
+            }
             for (int32_t x = x0; x < x1; x++) {
                 const int32_t e = eff_label[x];
                 const int64_t dest = eff_dest[x];
+                if (zero) {                              // (p - p)/eps: exact zeros, no arithmetic
+                    if (col >= 0) {
+                        if (c->mode == EMIT_FD) {
+                            c->out[dest * c->ld + col] = 0.0;
+                            if (c->raw) c->raw[dest * c->ldraw + col] = as_const(c->pbase)[dest];
+                        } else {
+                            const double p0 = as_const(c->pbase)[dest];
+                            const double pr = as_const(c->prow)[dest * c->ldrow + hrowidx];
+                            const double d2 = (p0 - pr) / c->eps;
+                            const double d1 = c->dcol[dest * c->lddcol + hcolidx];
+                            c->out[(dest * c->ld + hrow) * c->ld2 + col] = (d2 - d1) / c->eps;
+                        }
+                    }
+                    continue;
+                }
                 double p = dot_c<D>(effects + (int64_t)e * D, v);
 #pragma unroll
                 for (int s = 0; s < S; s++) {
@@ -238,45 +367,68 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
                         p = (kind[s] == GST_KIND_EFFECT && obj[s] == e) ? r : p;
                     }
                 }
-                if (a.mode == EMIT_PROBS) {
-                    if (col >= 0) a.out[dest] = p;
-                } else if (a.mode == EMIT_FD) {
+                if (c->mode == EMIT_PROBS) {
+                    if (col >= 0) c->out[dest] = p;
+                } else if (c->mode == EMIT_FD) {
                     if (col >= 0) {
-                        const double pb = as_const(a.pbase)[dest];
-                        a.out[dest * a.ld + col] = (p - pb) / a.eps;
-                        if (a.raw) a.raw[dest * a.ldraw + col] = p;
+                        const double pb = as_const(c->pbase)[dest];
+                        c->out[dest * c->ld + col] = (p - pb) / c->eps;
+                        if (c->raw) c->raw[dest * c->ldraw + col] = p;
                     }
                 } else {
                     if (col >= 0) {
-                        const double pr = as_const(a.prow)[dest * a.ldrow + hrowidx];
-                        const double d2 = (p - pr) / a.eps;                       // dprobs2 (mapforwardsim.py:431)
-                        const double d1 = a.dcol[dest * a.lddcol + hcolidx];      // dprobs
-                        a.out[(dest * a.ld + hrow) * a.ld2 + col] = (d2 - d1) / a.eps;
+                        const double pr = as_const(c->prow)[dest * c->ldrow + hrowidx];
+                        const double d2 = (p - pr) / c->eps;                       // dprobs2 (mapforwardsim.py:431)
+                        const double d1 = c->dcol[dest * c->lddcol + hcolidx];      // dprobs
+                        c->out[(dest * c->ld + hrow) * c->ld2 + col] = (d2 - d1) / c->eps;
                     }
                 }
             }
         } else if (op == GST_OP_SAVE) {
-            double* sl = lds + (int64_t)arg * D * 64 + lane;
+            if (S > 0 && !dirty) {
 #pragma unroll
-            for (int j = 0; j < D; j++) sl[j * 64] = v[j];
+                for (int i = 0; i < MAXSLOT; i++) if (arg == (uint32_t)i) slot_tag[i] = cur_id;
+            } else {
+#pragma unroll
+                for (int i = 0; i < MAXSLOT; i++) if (arg == (uint32_t)i) slot_tag[i] = -1;
+                double* sl = lds + (int64_t)arg * D * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < D; j++) sl[j * 64] = v[j];
+            }
         } else if (op == GST_OP_LOAD) {
-            const double* sl = lds + (int64_t)arg * D * 64 + lane;
+            int32_t tag = -1;
 #pragma unroll
-            for (int j = 0; j < D; j++) v[j] = sl[j * 64];
+            for (int i = 0; i < MAXSLOT; i++) if (arg == (uint32_t)i) tag = slot_tag[i];
+            if (S > 0 && tag >= 0) {
+                dirty = false; cur_id = tag;
+            } else {
+                const double* sl = lds + (int64_t)arg * D * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < D; j++) v[j] = sl[j * 64];
+                dirty = true;
+            }
         } else {  // GST_OP_RHO
-            cdouble_p r0 = rhos + (int64_t)arg * D;
+            if (S > 0 && !wave_rho) {
+                dirty = false;                           // unperturbed preparation: clean
+            } else {
+                cdouble_p r0 = as_const(cold()->rhos) + (int64_t)arg * D;
 #pragma unroll
-            for (int j = 0; j < D; j++) v[j] = r0[j];
+                for (int j = 0; j < D; j++) v[j] = r0[j];
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                if (rho_any[s]) {
-                    const bool mine = (kind[s] == GST_KIND_RHO) && (obj[s] == (int)arg);
+                for (int s = 0; s < S; s++) {
+                    if (rho_any[s]) {
+                        const bool mine = (kind[s] == GST_KIND_RHO) && (obj[s] == (int)arg);
 #pragma unroll
-                    for (int j = 0; j < D; j++) v[j] = mine ? sp[s][j] : v[j];
+                        for (int j = 0; j < D; j++) v[j] = mine ? sp[s][j] : v[j];
+                    }
                 }
+                dirty = true;
             }
         }
+        GST_FETCH();
     }
+#undef GST_FETCH
+#undef GST_HIT
 }
 
 template <int D, int S, int WPS>

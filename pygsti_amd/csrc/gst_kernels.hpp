@@ -33,6 +33,8 @@ struct WalkArgs {
     const double* rhos;
     const double* effects;
     int32_t n_gates;
+    const double* base_cache;   // [n_state_ids][D] states of the base pass (read by S>0 passes)
+    double* base_cache_w;       // same buffer, written by the S=0 pass at every NODE marker (may be NULL)
     // lanes
     LaneTables lanes;
     int32_t n_pwaves;        // wavefronts along the parameter dimension (grid.x)

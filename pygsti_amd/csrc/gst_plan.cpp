@@ -138,10 +138,16 @@ struct TaskCompiler {
         }
     }
 
+    int64_t node_base = 0;              // global id of this task's local node 0 (base-state cache index)
+
+    // the op that creates `node`'s state, followed by its NODE marker (global state id)
     void op(int32_t node, int depth)
     {
         prog.push_back(((depth == 1 ? GST_OP_RHO : GST_OP_APPLY) << 28) | (uint32_t)nodes[node].sym);
+        prog.push_back((GST_OP_NODE << 28) | (uint32_t)(node_base + node));
     }
+    void replay_add_last_op() { replay.push_back(prog[prog.size() - 2]); replay.push_back(prog.back()); }
+    void replay_set_last_op() { replay.clear(); replay_add_last_op(); }
 
     int32_t slot_limit = 1 << 20;       // save slots the device offers (gst_options.max_slots)
     std::vector<uint32_t> replay;       // program words that re-create the CURRENT node's state from its anchor
@@ -162,7 +168,7 @@ struct TaskCompiler {
                 node = n.first_child; depth++;
                 op(node, depth);
                 if (depth == 1) replay.clear();
-                replay.push_back(prog.back());
+                replay_add_last_op();
                 continue;
             }
             // pick the child that goes last (it inherits slot `base`): the heaviest subtree, because with a
@@ -177,12 +183,12 @@ struct TaskCompiler {
                 for (int32_t ch = n.first_child; ch >= 0; ch = nodes[ch].next_sibling) {
                     if (ch == last) continue;
                     op(ch, 1);
-                    replay.assign(1, prog.back());
+                    replay_set_last_op();
                     walk(ch, 1, base);
                 }
                 node = last; depth = 1;
                 op(node, depth);
-                replay.assign(1, prog.back());
+                replay_set_last_op();
                 continue;
             }
             bool have_slot = base < slot_limit;
@@ -191,7 +197,7 @@ struct TaskCompiler {
                 // the last child: each branching node M in those subtrees then replays dist(this, M) gates per
                 // extra child.  If re-deriving THIS node's state per child is cheaper than that, replay here
                 // and leave the slot to the descendants (typical: a shallow fork above several long chains).
-                const int64_t replay_cost = (int64_t)(n.n_children - 1) * (int64_t)here.size();
+                const int64_t replay_cost = (int64_t)(n.n_children - 1) * (int64_t)(here.size() / 2 + 1);
                 int64_t deny_cost = 0;
                 for (int32_t ch = n.first_child; ch >= 0; ch = nodes[ch].next_sibling)
                     if (ch != last) deny_cost += nodes[ch].bdist + nodes[ch].bsum;
@@ -212,7 +218,7 @@ struct TaskCompiler {
                 op(ch, depth + 1);
                 if (have_slot) replay.assign(1, (GST_OP_LOAD << 28) | (uint32_t)base);
                 else replay = here;
-                replay.push_back(prog.back());
+                replay_add_last_op();
                 walk(ch, depth + 1, have_slot ? base + 1 : base);
             }
             if (have_slot) prog.push_back((GST_OP_LOAD << 28) | (uint32_t)base);
@@ -220,7 +226,7 @@ struct TaskCompiler {
             node = last; depth++;
             op(node, depth);                     // continue into the last child; slot `base` is free again,
             replay = here;                       // so its anchor is this node's own anchor
-            replay.push_back(prog.back());
+            replay_add_last_op();
         }
     }
 };
@@ -308,12 +314,15 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
     built.reserve(cuts.size());
     P.max_slots = 0;
     P.applies_per_pass = 0;
+    P.n_state_ids = 0;
     for (size_t t = 0; t + 1 < cuts.size(); t++) {
         if (cuts[t] == cuts[t + 1]) continue;
         Built b;
         TaskCompiler tc(P, b.words);
         if (max_slots > 0) tc.slot_limit = max_slots;
+        tc.node_base = P.n_state_ids;
         tc.build(order, lcp, cuts[t], cuts[t + 1]);
+        P.n_state_ids += (int64_t)tc.nodes.size();
         tc.walk(0, 0, 0);
         b.words.push_back(GST_OP_END << 28);
         b.applies = 0;

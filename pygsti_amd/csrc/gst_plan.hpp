@@ -35,6 +35,7 @@ struct HostPlan {
     std::vector<int64_t> task_applies;  // gate applications per task (scheduling weight)
     int32_t max_slots = 0, max_depth = 0;
     int64_t sum_depth = 0, trie_nodes = 0, applies_per_pass = 0;
+    int64_t n_state_ids = 0;   // NODE marker ids: one per task-trie node (size of the base-state cache)
 
     int64_t n_tasks() const { return (int64_t)task_off.size() - 1; }
 };

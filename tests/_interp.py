@@ -6,7 +6,7 @@ result must equal the oracle bit for bit.
 """
 import numpy as np
 
-OP_END, OP_RHO, OP_APPLY, OP_SAVE, OP_LOAD, OP_EMIT = 0, 1, 2, 3, 4, 5
+OP_END, OP_RHO, OP_APPLY, OP_SAVE, OP_LOAD, OP_EMIT, OP_NODE = 0, 1, 2, 3, 4, 5, 6
 
 
 def matvec(M, v):
@@ -48,6 +48,11 @@ def run_programs(words, task_off, gates, rhos, effects, eff_ptr, eff_label, eff_
                 for x in range(eff_ptr[arg], eff_ptr[arg + 1]):
                     out[eff_dest[x]] = dot(effects[eff_label[x]], v)
                     written[eff_dest[x]] += 1
+            elif op == OP_NODE:
+                node_states = stats.setdefault('node_states', {})
+                if arg in node_states:      # a replayed state must be bit-identical to its first computation
+                    assert np.array_equal(node_states[arg].view(np.uint64), v.view(np.uint64))
+                node_states[arg] = v.copy()
             else:
                 raise AssertionError("bad opcode %d" % op)
         assert pc == task_off[t + 1]
