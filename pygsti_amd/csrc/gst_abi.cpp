@@ -106,14 +106,17 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
 {
     // default slot budget: what fits in LDS at 4 wavefronts per SIMD (16 per CU): one 8 KB slot at D=16
     int32_t max_slots = opt ? opt->max_slots : 0;
-    if (max_slots <= 0) max_slots = (p->hp.D >= 16) ? 1 : 4;
-    std::string err = gst::compile_plan(p->hp, opt ? opt->target_tasks : 0, max_slots);
-    if (!err.empty()) { delete p; return fail(GST_EINVAL, err); }
-    if (p->hp.D != 4 && p->hp.D != 16) {
+    if (p->hp.D != 4 && p->hp.D != 16 && p->hp.D != 64) {
         const int D = p->hp.D;
         delete p;
-        return fail(GST_EUNSUPPORTED, "state dimension " + std::to_string(D) + " not supported in this round (4 or 16)");
+        return fail(GST_EUNSUPPORTED, "state dimension " + std::to_string(D) + " not supported (4, 16 or 64)");
     }
+    // D = 64 runs on the row-per-lane kernel only (a slot is 512 bytes): generous budget.
+    // D <= 16: the lane-per-model kernel keeps slots in LDS at 8*D*64 bytes each and tracks at most 4.
+    if (max_slots <= 0) max_slots = (p->hp.D == 64) ? 8 : (p->hp.D == 16) ? 1 : 4;
+    max_slots = std::min(max_slots, p->hp.D == 64 ? 32 : 4);
+    std::string err = gst::compile_plan(p->hp, opt ? opt->target_tasks : 0, max_slots);
+    if (!err.empty()) { delete p; return fail(GST_EINVAL, err); }
     p->device = opt ? opt->device : -1;
     *out = p;
     return GST_OK;
@@ -195,7 +198,8 @@ int run_probs(gst_plan* p, double* d_dst, bool fill_cache)
         HIP_TRY(p->d_base_cache.ensure((size_t)p->hp.n_state_ids * p->hp.D));
         a.base_cache_w = p->d_base_cache.p;
     }
-    HIP_TRY(gst::launch_walk(p->hp.D, 0, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
+    a.rows_S = 0;
+    HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     p->last_launches++;
     return GST_OK;
 }
@@ -237,6 +241,17 @@ void pack_lanes(const gst_plan* p, const int64_t* param_idx, const int64_t* dest
     L.n_waves = (int32_t)(L.col.size() / 64);
 }
 
+// Row-per-lane kernel: one wavefront per requested column.
+void pack_waves(const gst_plan* p, const int64_t* param_idx, const int64_t* dest_idx, int64_t n, LaneLayout& L)
+{
+    for (int64_t c = 0; c < n; c++) {
+        const int64_t pi = param_idx[c];
+        L.col.push_back((int32_t)(dest_idx ? dest_idx[c] : c));
+        L.kind[0].push_back(p->pkind[pi]); L.obj[0].push_back(p->pobj[pi]); L.elem[0].push_back(p->pelem[pi]);
+    }
+    L.n_waves = (int32_t)n;
+}
+
 int upload_i32(DevBuf<int32_t>& b, const std::vector<int32_t>& v, hipStream_t s)
 {
     HIP_TRY(b.ensure(v.size()));
@@ -262,8 +277,10 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     int rc = run_probs(p, d_base, n_param > 0);
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
+    const bool rows = (p->hp.D == 64);
     LaneLayout L;
-    pack_lanes(p, param_idx, dest_idx, n_param, L);
+    if (rows) pack_waves(p, param_idx, dest_idx, n_param, L);     // one perturbed model per wavefront
+    else pack_lanes(p, param_idx, dest_idx, n_param, L);
     // the host vectors must outlive the async copies: synchronous small copies instead
     if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
     if ((rc = upload_i32(p->d_lane[1], L.kind[0], p->stream))) return rc;
@@ -279,7 +296,11 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     a.lanes.col = p->d_lane[0].p; a.lanes.kind[0] = p->d_lane[1].p; a.lanes.obj[0] = p->d_lane[2].p; a.lanes.elem[0] = p->d_lane[3].p;
     a.n_pwaves = L.n_waves;
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
-    HIP_TRY(gst::launch_walk(p->hp.D, 1, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
+    if (rows) {
+        a.rows_S = 1;
+        HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
+    } else
+        HIP_TRY(gst::launch_walk(p->hp.D, 1, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     p->last_launches++;
     return GST_OK;
@@ -504,12 +525,26 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     HIP_TRY(p->d_probs_tmp.ensure((size_t)nE * n1));
     if ((rc = run_dprobs_fd(p, p->d_probs_tmp.p, n1, idx1, nullptr, n1, eps, nullptr, p->d_raw.p, n1))) return rc;
     // (3) all (i, j) pairs: wavefront = (row i, 64 columns j)
+    const bool rows = (p->hp.D == 64);
     LaneLayout L2;
-    pack_lanes(p, idx2, nullptr, n2, L2);   // col = position in block 2
+    if (rows) pack_waves(p, idx2, nullptr, n2, L2);
+    else pack_lanes(p, idx2, nullptr, n2, L2);   // col = position in block 2
     const int32_t w2 = L2.n_waves;
     LaneLayout L;
     std::vector<int32_t> wave_row, wave_rowidx, lane_colidx;
-    for (int64_t a = 0; a < n1; a++) {
+    for (int64_t a = 0; rows && a < n1; a++) {       // one wavefront per (i, j) pair
+        const int64_t pi = idx1[a];
+        for (int32_t w = 0; w < w2; w++) {
+            wave_row.push_back((int32_t)(dest1 ? dest1[a] : a));
+            wave_rowidx.push_back((int32_t)a);
+            const int32_t c = L2.col[w];
+            L.col.push_back((int32_t)(dest2 ? dest2[c] : c));
+            lane_colidx.push_back(c);
+            L.kind[0].push_back(p->pkind[pi]); L.obj[0].push_back(p->pobj[pi]); L.elem[0].push_back(p->pelem[pi]);
+            L.kind[1].push_back(L2.kind[0][w]); L.obj[1].push_back(L2.obj[0][w]); L.elem[1].push_back(L2.elem[0][w]);
+        }
+    }
+    for (int64_t a = 0; !rows && a < n1; a++) {
         const int64_t pi = idx1[a];
         for (int32_t w = 0; w < w2; w++) {
             wave_row.push_back((int32_t)(dest1 ? dest1[a] : a));
@@ -524,7 +559,7 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
             }
         }
     }
-    L.n_waves = (int32_t)(L.col.size() / 64);
+    L.n_waves = rows ? (int32_t)L.col.size() : (int32_t)(L.col.size() / 64);
     if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
     for (int s = 0; s < 2; s++) {
         if ((rc = upload_i32(p->d_lane[1 + 3 * s], L.kind[s], p->stream))) return rc;
@@ -553,7 +588,11 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
     if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
-    HIP_TRY(gst::launch_walk(p->hp.D, 2, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
+    if (rows) {
+        a.rows_S = 2;
+        HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
+    } else
+        HIP_TRY(gst::launch_walk(p->hp.D, 2, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     p->last_launches++;
     HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));

@@ -438,7 +438,7 @@ static hipError_t launch_one(const WalkArgs& a, int64_t n_tasks, int n_slots, hi
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds_bytes = (size_t)n_slots * D * 64 * sizeof(double);
-    if (lds_bytes > 64 * 1024) return hipErrorInvalidValue;
+    if (lds_bytes > 64 * 1024 || n_slots > 4) return hipErrorInvalidValue;   // MAXSLOT tags in the kernel
     (void)hipGetLastError();   // drop any stale sticky error (e.g. an event query) so that we report OUR launch
     hipLaunchKernelGGL((walk_kernel<D, S, WPS>), dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a);
     return hipGetLastError();

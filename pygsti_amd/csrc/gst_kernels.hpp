@@ -38,6 +38,8 @@ struct WalkArgs {
     // lanes
     LaneTables lanes;
     int32_t n_pwaves;        // wavefronts along the parameter dimension (grid.x)
+    int32_t rows_S;          // walk_rows_kernel only: number of perturbations per wavefront (0, 1, 2); its
+                             // `lanes` tables then hold ONE entry per wavefront instead of one per lane
     // output
     int32_t mode;
     double* out;
@@ -58,5 +60,8 @@ struct WalkArgs {
 // Launch the walk over all tasks x parameter wavefronts.  S = number of specials per lane (0,1,2);
 // n_slots = save slots the programs use (LDS: n_slots * D * 512 bytes per wavefront).
 hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
+
+// Row-per-lane variant (gst_kernels_rows.hip): one model per wavefront; D = 4, 16 or 64; S = a.rows_S.
+hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 
 }  // namespace gst

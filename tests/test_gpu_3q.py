@@ -1,0 +1,64 @@
+"""D = 64 (three qubits, BASELINE configs[4] shape: 10 dense 64x64 superoperators, 8 outcomes, 41,536
+parameters): the row-per-lane kernel against the CPU oracle, bit for bit, on seeded random circuits."""
+import numpy as np
+import pytest
+
+from conftest import assert_bitwise
+from pygsti_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(n_circ=60, max_len=256, seed=0):
+    rng = np.random.default_rng(seed)
+    D, nG, nEl = 64, 10, 8
+    gates = np.eye(D)[None] + 0.04 * rng.standard_normal((nG, D, D))
+    rhos = np.zeros((1, D)); rhos[0, 0] = 1.0 / np.sqrt(8); rhos[0] += 0.01 * rng.standard_normal(D)
+    effects = 0.1 * rng.standard_normal((nEl, D)); effects[:, 0] += 1.0 / np.sqrt(8)
+    lens = rng.integers(0, max_len + 1, n_circ)
+    lens[:3] = [0, 1, max_len]
+    circs = [rng.integers(0, nG, L) for L in lens]
+    # some shared prefixes so that the trie / save slots are exercised
+    for k in range(3, n_circ, 4):
+        circs[k] = np.concatenate([circs[k - 1][:len(circs[k - 1]) // 2], circs[k][:8]])
+    ptr = np.zeros(n_circ + 1, np.int64); ptr[1:] = np.cumsum([len(c) for c in circs])
+    g = np.concatenate(circs).astype(np.int32)
+    nE = n_circ * nEl
+    eff_ptr = np.arange(n_circ + 1, dtype=np.int64) * nEl
+    eff_label = np.tile(np.arange(nEl, dtype=np.int32), n_circ)
+    eff_dest = np.arange(nE, dtype=np.int32)
+    nP = D + nEl * D + nG * D * D
+    kind = np.concatenate([np.full(D, 1), np.full(nEl * D, 2), np.full(nG * D * D, 0)]).astype(np.int32)
+    obj = np.concatenate([np.zeros(D), np.repeat(np.arange(nEl), D), np.repeat(np.arange(nG), D * D)]).astype(np.int32)
+    elem = np.concatenate([np.arange(D), np.tile(np.arange(D), nEl), np.tile(np.arange(D * D), nG)]).astype(np.int32)
+    assert nP == 41536
+    pl = _lib.Plan.from_circuits(D, nG, 1, nEl, nE, np.zeros(n_circ, np.int32), ptr, g, eff_ptr, eff_label, eff_dest)
+    pl.set_model(gates, rhos, effects)
+    pl.set_param_map(kind, obj, elem)
+    tbl = dict(D=D, nE=nE, cache_size=0, t_dest=np.arange(n_circ), t_start=-np.ones(n_circ), t_cache=-np.ones(n_circ),
+               t_rho=np.zeros(n_circ), row_ptr=ptr, gate_idx=g, eff_ptr=eff_ptr, eff_label=eff_label, eff_dest=eff_dest)
+    mdl = dict(gates=gates, rhos=rhos, effects=effects, pkind=kind, pobj=obj, pelem=elem)
+    return pl, tbl, mdl, nP
+
+
+def test_3q_probs_dprobs_hprobs_vs_oracle(oracle_built):
+    pl, tbl, mdl, nP = _make()
+    orc = oracle_built.Oracle(tbl, mdl)
+    assert_bitwise(pl.fill_probs(), orc.probs(), "3Q probs")
+    rng = np.random.default_rng(5)
+    cols = np.sort(np.concatenate([[0, 63, 64, 575, 576, 577, 576 + 4095, 576 + 4096, nP - 1],
+                                   rng.choice(nP, 40, replace=False)]))
+    pr = np.empty(tbl["nE"])
+    J = pl.fill_dprobs(param_idx=cols, eps=1e-7, probs_out=pr)
+    Jo, po = orc.dprobs(cols, eps=1e-7, return_probs=True)
+    assert_bitwise(pr, po, "3Q pr")
+    assert_bitwise(J, Jo, "3Q dprobs")
+    i1 = np.array([0, 70, 576, 600, 576 + 64, 9000]); i2 = np.array([0, 1, 70, 576, 577, 576 + 64 + 1, 30000])
+    H = pl.fill_hprobs(idx1=i1, idx2=i2, eps=1e-5)
+    assert_bitwise(H, orc.hprobs(i1, i2, eps=1e-5), "3Q hprobs")
+
+
+def test_3q_plan_stats():
+    pl, tbl, mdl, nP = _make(n_circ=40, max_len=64, seed=3)
+    st = pl.stats()
+    assert st["max_slots"] <= 8 and st["applies_per_pass"] <= st["sum_depth"]
