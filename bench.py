@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--target-tasks", type=int, default=0)
     ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deriv", default="fd", choices=["fd", "analytic"],
+                    help="fd: finite differences, bit-identical to the reference Map path (headline); "
+                         "analytic: exact derivatives (MatrixForwardSimulator semantics)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,9 +122,12 @@ def main():
     d_probs = plan.device_malloc(nE_local * 8)
     pidx = np.arange(nP, dtype=np.int64)
 
+    from pygsti_amd import _lib
+    mode = _lib.DERIV_ANALYTIC if args.deriv == "analytic" else _lib.DERIV_FD
+
     def step():
         plan.set_model(gates, rhos, effects)          # from_vector -> new dense arrays -> H2D
-        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs)
+        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)
 
     for _ in range(args.warmup):
         step()
@@ -163,8 +169,17 @@ def main():
         # (nP perturbed passes) x (2 D^2 per gate application + 2 D per element)
         flops = nP * (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local)
         jac_bytes = 8.0 * nE_local * nP
+        if args.deriv == "analytic":
+            roof = {"bound": "hbm", "kernel": "analytic_dprobs_kernel<16,6>", "achieved": jac_bytes / (k_ms * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "algorithmic bytes = the Jacobian write 8*nE*nP; the kernel also re-reads forward states (L2/MALL)",
+                    "kernel_ms": k_ms, "bytes_per_launch": jac_bytes, "traffic": None}
+        else:
+            roof = None
         out = {
-            "metric": "dprobs Jacobian-elements/sec, 2Q GST L<=1024 (bulk_fill_dprobs, FD eps=1e-7, bit-identical to the reference Map path)",
+            "metric": "dprobs Jacobian-elements/sec, 2Q GST L<=1024 (bulk_fill_dprobs, %s)" % (
+                "FD eps=1e-7, bit-identical to the reference Map path" if args.deriv == "fd" else
+                "analytic derivatives, MatrixForwardSimulator semantics, <=1e-8"),
             "value": nE_total * nP * args.steps / dt,
             "unit": "Jacobian-elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -174,11 +189,12 @@ def main():
             "config": {"workload": "smq2Q_XYICNOT GST L<=%d %s germs: %d circuits, nE=%d, nP=%d, D=%d; "
                                    "target model depolarized 0.01/0.01" % (args.max_len, args.design, len(circuits),
                                                                            nE_total, nP, D),
-                       "derivative": "forward finite differences, eps=1e-7 (reference MapForwardSimulator semantics)",
+                       "derivative": ("forward finite differences, eps=1e-7 (reference MapForwardSimulator semantics)"
+                                      if args.deriv == "fd" else "analytic (reference MatrixForwardSimulator semantics)"),
                        "parallelism": "atoms%d" % world},
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,
-            "roofline": {"bound": "valu_f64", "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
+            "roofline": roof or {"bound": "valu_f64", "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
                          "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (k_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
                          "note": "separate v_mul_f64+v_add_f64 (no FMA, required for bitwise parity) caps this kernel at 0.5 of the FMA peak",

@@ -46,7 +46,8 @@ extern "C" {
 #define GST_DERIV_FD 0        /* forward finite differences, bit-for-bit the reference's Map path
                                  (mapforwardsim_calc_densitymx.pyx:290-383) */
 #define GST_DERIV_ANALYTIC 1  /* exact derivative (what MatrixForwardSimulator computes,
-                                 matrixforwardsim.py:1059-1140), not yet in this round */
+                                 matrixforwardsim.py:1059-1140): forward states x backward effect vectors;
+                                 `eps` is ignored.  D = 4 and 16. */
 
 typedef struct gst_plan gst_plan;
 
@@ -165,6 +166,11 @@ int gst_get_stats(const gst_plan *plan, gst_stats *out);
  * *n_words.  task_off (may be NULL) receives n_tasks+1 offsets when cap_tasks suffices. */
 int gst_get_program(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words,
                     int64_t *task_off, int64_t cap_tasks);
+
+/* The state-id graph behind the NODE markers: parent state id (-1 for a state preparation) and gate / rho index of
+ * every state, and the id of each expanded circuit's final state (what the analytic mode walks backwards). */
+int gst_get_state_graph(const gst_plan *plan, int32_t *node_parent, int32_t *node_sym, int64_t cap_nodes,
+                        int32_t *circ_leaf, int64_t cap_circuits, int64_t *n_nodes);
 
 int gst_device_count(int32_t *n);
 const char *gst_last_error(void);

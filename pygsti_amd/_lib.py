@@ -58,7 +58,7 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
            "gst_last_error", "gst_version"]
 
 _lib = None
@@ -91,6 +91,7 @@ def lib():
         L.gst_memcpy_d2h.argtypes = [vp, vp, vp, i64]
         L.gst_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.gst_get_program.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64]
+        L.gst_get_state_graph.argtypes = [vp, vp, vp, i64, vp, i64, C.POINTER(i64)]
         L.gst_device_count.argtypes = [C.POINTER(i32)]
         _lib = L
     return _lib
@@ -263,6 +264,15 @@ class Plan:
         s = Stats()
         check(lib().gst_get_stats(self._h, C.byref(s)))
         return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def state_graph(self):
+        n = C.c_int64(0)
+        check(lib().gst_get_state_graph(self._h, None, None, 0, None, 0, C.byref(n)))
+        nc = self.stats()["n_circuits"]
+        par = np.empty(max(n.value, 1), np.int32); sym = np.empty(max(n.value, 1), np.int32)
+        leaf = np.empty(max(nc, 1), np.int32)
+        check(lib().gst_get_state_graph(self._h, _ptr(par), _ptr(sym), n.value, _ptr(leaf), nc, C.byref(n)))
+        return par[:n.value], sym[:n.value], leaf[:nc]
 
     def program(self):
         n = C.c_int64(0)

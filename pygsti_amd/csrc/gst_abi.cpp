@@ -79,6 +79,8 @@ struct gst_plan {
     DevBuf<double> d_pbase, d_out, d_raw, d_dcol, d_probs_tmp;
     DevBuf<int32_t> d_lane[7];   // col, kind0, obj0, elem0, kind1, obj1, elem1
     DevBuf<int32_t> d_wave_row, d_wave_rowidx, d_lane_colidx;
+    DevBuf<int32_t> d_node_parent, d_node_sym, d_node_run, d_circ_leaf, d_gate_col0, d_cm_gate, d_cm_rho, d_cm_eff;
+    bool graph_uploaded = false;
 
     double last_kernel_ms = 0, last_total_ms = 0;
     int64_t last_launches = 0;
@@ -92,6 +94,8 @@ struct gst_plan {
         d_pbase.release(); d_base_cache.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
         d_wave_row.release(); d_wave_rowidx.release(); d_lane_colidx.release();
+        d_node_parent.release(); d_node_sym.release(); d_node_run.release(); d_circ_leaf.release(); d_gate_col0.release();
+        d_cm_gate.release(); d_cm_rho.release(); d_cm_eff.release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (evk0) (void)hipEventDestroy(evk0);
@@ -306,6 +310,72 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     return GST_OK;
 }
 
+// Exact Jacobian columns (GST_DERIV_ANALYTIC) into device memory.
+int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
+                        int64_t n_param, double* d_probs_out)
+{
+    const gst::HostPlan& h = p->hp;
+    if (h.D != 4 && h.D != 16) return fail(GST_EUNSUPPORTED, "the analytic mode supports D = 4 and D = 16 in this round");
+    double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
+    int rc = run_probs(p, d_base, n_param > 0);        // probabilities + every forward state
+    if (rc) return rc;
+    if (n_param == 0) return GST_OK;
+    const int D = h.D, DD = D * D;
+    std::vector<int32_t> cm_gate((size_t)std::max(h.n_gates, 1) * DD, -1), cm_rho((size_t)h.n_rhos * D, -1),
+        cm_eff((size_t)h.n_effects * D, -1), col0(std::max(h.n_gates, 1), -2);
+    std::vector<int64_t> none_cols;
+    for (int64_t c = 0; c < n_param; c++) {
+        const int64_t pi = param_idx[c];
+        const int32_t col = (int32_t)(dest_idx ? dest_idx[c] : c);
+        switch (p->pkind[pi]) {
+        case GST_KIND_GATE: cm_gate[(size_t)p->pobj[pi] * DD + p->pelem[pi]] = col; break;
+        case GST_KIND_RHO: cm_rho[(size_t)p->pobj[pi] * D + p->pelem[pi]] = col; break;
+        case GST_KIND_EFFECT: cm_eff[(size_t)p->pobj[pi] * D + p->pelem[pi]] = col; break;
+        default: none_cols.push_back(col);
+        }
+    }
+    for (int g = 0; g < h.n_gates; g++) {
+        const int32_t* m = cm_gate.data() + (size_t)g * DD;
+        bool any = false, contiguous = m[0] >= 0;
+        for (int k = 0; k < DD; k++) { any = any || m[k] >= 0; contiguous = contiguous && m[k] == m[0] + k; }
+        col0[g] = contiguous ? m[0] : (any ? -1 : -2);
+    }
+    if (!p->graph_uploaded) {
+        if ((rc = upload_i32(p->d_node_parent, h.node_parent, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_node_sym, h.node_sym, p->stream))) return rc;
+        {   // run[id] = 1 + run[id-1] while parent(id) == id-1 is a gate state reached by a consecutive id
+            std::vector<int32_t> run(h.n_state_ids, 0);
+            for (int64_t i = 1; i < h.n_state_ids; i++)
+                if (h.node_parent[i] == i - 1) run[i] = 1 + ((h.node_parent[i - 1] >= 0 && h.node_parent[i - 1] == i - 2) ? run[i - 1] : 0);
+            if ((rc = upload_i32(p->d_node_run, run, p->stream))) return rc;
+            HIP_TRY(hipStreamSynchronize(p->stream));
+        }
+        if ((rc = upload_i32(p->d_circ_leaf, h.circ_leaf, p->stream))) return rc;
+        p->graph_uploaded = true;
+    }
+    if ((rc = upload_i32(p->d_gate_col0, col0, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_cm_gate, cm_gate, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_cm_rho, cm_rho, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_cm_eff, cm_eff, p->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));          // host vectors above go out of scope
+    for (int64_t col : none_cols)                      // parameters of objects this atom never applies: exact zeros
+        HIP_TRY(hipMemset2DAsync(d_out + col, (size_t)ld * 8, 0, 8, (size_t)h.n_elements, p->stream));
+    gst::AnaArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_circuits = h.n_circuits;
+    a.circ_leaf = p->d_circ_leaf.p; a.node_parent = p->d_node_parent.p; a.node_sym = p->d_node_sym.p; a.node_run = p->d_node_run.p;
+    a.eff_ptr = p->d_eff_ptr.p; a.eff_label = p->d_eff_label.p; a.eff_dest = p->d_eff_dest.p;
+    a.gates_t = p->d_gates_t.p; a.effects = p->d_effects.p; a.base_cache = p->d_base_cache.p;
+    a.n_gates = h.n_gates; a.n_rhos = h.n_rhos; a.n_effects = h.n_effects;
+    a.gate_col0 = p->d_gate_col0.p; a.colmap_gate = p->d_cm_gate.p; a.colmap_rho = p->d_cm_rho.p; a.colmap_eff = p->d_cm_eff.p;
+    a.out = d_out; a.ld = ld;
+    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    HIP_TRY(gst::launch_analytic(D, a, p->stream));
+    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    p->last_launches++;
+    return GST_OK;
+}
+
 int begin_call(gst_plan* p)
 {
     if (!p) return fail(GST_EINVAL, "plan is NULL");
@@ -473,10 +543,12 @@ int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     int rc = begin_call(p);
     if (rc) return rc;
     if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
-    if (mode != GST_DERIV_FD) return fail(GST_EUNSUPPORTED, "only GST_DERIV_FD is implemented in this round");
+    if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!d_out && n_param > 0) return fail(GST_EINVAL, "d_out is NULL");
     if ((rc = check_params(p, param_idx, n_param))) return rc;
-    if ((rc = run_dprobs_fd(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out, nullptr, 0))) return rc;
+    if (mode == GST_DERIV_ANALYTIC) rc = run_dprobs_analytic(p, d_out, ld, param_idx, dest_idx, n_param, d_probs_out);
+    else rc = run_dprobs_fd(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out, nullptr, 0);
+    if (rc) return rc;
     return end_call(p, false);
 }
 
@@ -486,13 +558,15 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     int rc = begin_call(p);
     if (rc) return rc;
     if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
-    if (mode != GST_DERIV_FD) return fail(GST_EUNSUPPORTED, "only GST_DERIV_FD is implemented in this round");
+    if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!out && n_param > 0) return fail(GST_EINVAL, "out is NULL");
     if ((rc = check_params(p, param_idx, n_param))) return rc;
     const int64_t nE = p->hp.n_elements;
     // device staging is dense [nE][n_param]; scattered into the caller's (ld, dest_idx) window on the host
     HIP_TRY(p->d_out.ensure((size_t)nE * std::max<int64_t>(n_param, 1)));
-    if ((rc = run_dprobs_fd(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr, nullptr, 0))) return rc;
+    if (mode == GST_DERIV_ANALYTIC) rc = run_dprobs_analytic(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
+    else rc = run_dprobs_fd(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr, nullptr, 0);
+    if (rc) return rc;
     std::vector<double> stage;
     const bool direct = (!dest_idx && ld == n_param);
     double* dst = out;
@@ -647,6 +721,20 @@ int gst_get_stats(const gst_plan* p, gst_stats* s)
     s->trie_nodes = h.trie_nodes; s->applies_per_pass = h.applies_per_pass; s->n_tasks = h.n_tasks();
     s->prog_words = (int64_t)h.prog.size(); s->max_slots = h.max_slots; s->max_depth = h.max_depth;
     s->last_kernel_ms = p->last_kernel_ms; s->last_total_ms = p->last_total_ms; s->last_launches = p->last_launches;
+    return GST_OK;
+}
+
+int gst_get_state_graph(const gst_plan* p, int32_t* node_parent, int32_t* node_sym, int64_t cap_nodes,
+                        int32_t* circ_leaf, int64_t cap_circuits, int64_t* n_nodes)
+{
+    if (!p || !n_nodes) return fail(GST_EINVAL, "NULL argument");
+    const gst::HostPlan& h = p->hp;
+    *n_nodes = h.n_state_ids;
+    if (node_parent && node_sym && cap_nodes >= h.n_state_ids) {
+        std::memcpy(node_parent, h.node_parent.data(), sizeof(int32_t) * h.n_state_ids);
+        std::memcpy(node_sym, h.node_sym.data(), sizeof(int32_t) * h.n_state_ids);
+    }
+    if (circ_leaf && cap_circuits >= h.n_circuits) std::memcpy(circ_leaf, h.circ_leaf.data(), sizeof(int32_t) * h.n_circuits);
     return GST_OK;
 }
 

@@ -61,6 +61,29 @@ struct WalkArgs {
 // n_slots = save slots the programs use (LDS: n_slots * D * 512 bytes per wavefront).
 hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 
+// Analytic Jacobian (gst_kernels_analytic.hip): one wavefront per circuit walks the state-id graph backwards.
+struct AnaArgs {
+    int64_t n_circuits;
+    const int32_t* circ_leaf;     // [n_circuits] state id of the circuit's final state
+    const int32_t* node_parent;   // [n_state_ids] (-1: a rho state)
+    const int32_t* node_sym;      // [n_state_ids] gate index (rho index for rho states)
+    const int32_t* node_run;      // [n_state_ids] number of upward steps whose parent is id-1 (0: rho state or a jump)
+    const int32_t* eff_ptr;
+    const int32_t* eff_label;
+    const int32_t* eff_dest;
+    const double* gates_t;        // [nG][D][D] transposed
+    const double* effects;
+    const double* base_cache;     // forward states of the base pass
+    int32_t n_gates, n_rhos, n_effects;
+    const int32_t* gate_col0;     // [nG]: >=0 first of D*D consecutive dest columns; -1 use colmap_gate; -2 none requested
+    const int32_t* colmap_gate;   // [nG*D*D] dest column or -1
+    const int32_t* colmap_rho;    // [nR*D]
+    const int32_t* colmap_eff;    // [nEl*D]
+    double* out;
+    int64_t ld;
+};
+hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
+
 // Row-per-lane variant (gst_kernels_rows.hip): one model per wavefront; D = 4, 16 or 64; S = a.rows_S.
 hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 

@@ -67,6 +67,7 @@ namespace {
 
 struct Node {
     int32_t sym;          // rho index at depth 1, gate index deeper
+    int32_t parent = -1;  // local index of the parent node
     int32_t first_child = -1, last_child = -1, next_sibling = -1;
     int32_t n_children = 0;
     int32_t emit_head = -1;   // index into emit list (linked through emit_next)
@@ -80,6 +81,7 @@ struct TaskCompiler {
     const HostPlan& P;
     std::vector<Node> nodes;
     std::vector<int32_t> emit_circ, emit_next;
+    std::vector<std::pair<int32_t, int32_t>> leaf_of_circuit;   // (circuit, local node of its final state)
     std::vector<uint32_t>& prog;
     int32_t max_slot_used = 0;
 
@@ -93,7 +95,7 @@ struct TaskCompiler {
     // Build the local trie of sorted circuits order[a..b) (lcp[k] = common symbols of k-1 and k).
     void build(const std::vector<int32_t>& order, const std::vector<int64_t>& lcp, int64_t a, int64_t b)
     {
-        nodes.clear(); emit_circ.clear(); emit_next.clear();
+        nodes.clear(); emit_circ.clear(); emit_next.clear(); leaf_of_circuit.clear();
         nodes.push_back(Node{-1});                 // virtual root (depth 0)
         std::vector<int32_t> path{0};              // path[d] = node at depth d
         for (int64_t k = a; k < b; k++) {
@@ -103,6 +105,7 @@ struct TaskCompiler {
             path.resize(common + 1);
             for (int64_t d = common; d < L; d++) {
                 Node n{sym_at(c, d)};
+                n.parent = path.back();
                 const int32_t id = (int32_t)nodes.size();
                 Node& par = nodes[path.back()];
                 if (par.last_child >= 0) nodes[par.last_child].next_sibling = id; else par.first_child = id;
@@ -111,6 +114,7 @@ struct TaskCompiler {
                 nodes.push_back(n);
                 path.push_back(id);
             }
+            leaf_of_circuit.push_back({c, path.back()});
             const int32_t e = (int32_t)emit_circ.size();
             emit_circ.push_back(c);
             emit_next.push_back(-1);
@@ -315,6 +319,8 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
     P.max_slots = 0;
     P.applies_per_pass = 0;
     P.n_state_ids = 0;
+    P.node_parent.clear(); P.node_sym.clear();
+    P.circ_leaf.assign(nC, -1);
     for (size_t t = 0; t + 1 < cuts.size(); t++) {
         if (cuts[t] == cuts[t + 1]) continue;
         Built b;
@@ -323,6 +329,15 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
         tc.node_base = P.n_state_ids;
         tc.build(order, lcp, cuts[t], cuts[t + 1]);
         P.n_state_ids += (int64_t)tc.nodes.size();
+        // state-id graph for the analytic (backward) sweeps: parent id and symbol of every state
+        P.node_parent.resize(P.n_state_ids, -1);
+        P.node_sym.resize(P.n_state_ids, 0);
+        for (size_t i = 1; i < tc.nodes.size(); i++) {
+            const int32_t par = tc.nodes[i].parent;
+            P.node_parent[tc.node_base + i] = par <= 0 ? -1 : (int32_t)(tc.node_base + par);   // -1: a rho state
+            P.node_sym[tc.node_base + i] = tc.nodes[i].sym;
+        }
+        for (auto& lc : tc.leaf_of_circuit) P.circ_leaf[lc.first] = (int32_t)(tc.node_base + lc.second);
         tc.walk(0, 0, 0);
         b.words.push_back(GST_OP_END << 28);
         b.applies = 0;

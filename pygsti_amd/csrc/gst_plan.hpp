@@ -36,6 +36,8 @@ struct HostPlan {
     int32_t max_slots = 0, max_depth = 0;
     int64_t sum_depth = 0, trie_nodes = 0, applies_per_pass = 0;
     int64_t n_state_ids = 0;   // NODE marker ids: one per task-trie node (size of the base-state cache)
+    std::vector<int32_t> node_parent, node_sym;   // [n_state_ids]: parent state id (-1: a rho state) and gate/rho index
+    std::vector<int32_t> circ_leaf;               // [n_circuits]: state id of each circuit's final state
 
     int64_t n_tasks() const { return (int64_t)task_off.size() - 1; }
 };

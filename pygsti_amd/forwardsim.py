@@ -49,7 +49,7 @@ class HipMapForwardSimulator:
     """Drop-in counterpart of MapForwardSimulator for dense `densitymx` models on MI355X."""
 
     def __init__(self, model=None, max_cache_size=None, num_atoms=None, processor_grid=None, param_blk_sizes=None,
-                 derivative_eps=1e-7, hessian_eps=1e-5, devices=None, target_tasks=0):
+                 derivative_eps=1e-7, hessian_eps=1e-5, devices=None, target_tasks=0, derivative_mode="fd"):
         self._model = None
         self._max_cache_size = max_cache_size   # accepted for signature parity; the device plan needs no state cache
         self._num_atoms = num_atoms
@@ -59,6 +59,10 @@ class HipMapForwardSimulator:
         self.hessian_eps = hessian_eps
         self.devices = devices
         self.target_tasks = target_tasks
+        # "fd": forward finite differences, bit-identical to MapForwardSimulator (the default simulator);
+        # "analytic": exact first derivatives, what MatrixForwardSimulator computes (matrixforwardsim.py:1059-1140)
+        assert derivative_mode in ("fd", "analytic")
+        self.derivative_mode = derivative_mode
         if model is not None:
             self.model = model
 
@@ -74,7 +78,7 @@ class HipMapForwardSimulator:
     def copy(self, keep_model_attached=False):
         s = HipMapForwardSimulator(None, self._max_cache_size, self._num_atoms, self._processor_grid,
                                    self._pblk_sizes, self.derivative_eps, self.hessian_eps, self.devices,
-                                   self.target_tasks)
+                                   self.target_tasks, self.derivative_mode)
         if keep_model_attached:
             s._model = self._model
         return s
@@ -131,7 +135,8 @@ class HipMapForwardSimulator:
         nP = self.model.num_params
         pidx = _to_index_array(param_slice, nP)
         didx = None if dest_param_slice is None else _to_index_array(dest_param_slice, array_to_fill.shape[1])
-        plan.fill_dprobs(array_to_fill, pidx, didx, self.derivative_eps, pr_array_to_fill)
+        mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
+        plan.fill_dprobs(array_to_fill, pidx, didx, self.derivative_eps, pr_array_to_fill, mode)
 
     def _bulk_fill_hprobs_atom(self, array_to_fill, dest_param_slice1, dest_param_slice2, layout_atom,
                                param_slice1, param_slice2, resource_alloc=None):

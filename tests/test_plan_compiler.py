@@ -83,6 +83,6 @@ def test_bad_descriptions_are_rejected_not_crashed():
     bad = dict(fx); bad['t_start'] = fx['t_start'].copy(); bad['t_start'][0] = 5     # cache slot not yet written
     with pytest.raises(ValueError):
         make(bad)
-    bad = dict(fx); bad['D'] = 64
+    bad = dict(fx); bad['D'] = 32
     with pytest.raises(_lib.GstError):
         make(bad)
