@@ -86,3 +86,26 @@ def test_bad_descriptions_are_rejected_not_crashed():
     bad = dict(fx); bad['D'] = 32
     with pytest.raises(_lib.GstError):
         make(bad)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_state_graph_reproduces_every_circuit(name):
+    """The state-id graph the analytic mode walks backwards: from each circuit's final state id the parent chain
+    spells the circuit's gates in reverse and ends in its state preparation; every NODE marker id of the programs
+    is covered, and replayed states carry the same id (checked bitwise inside the interpreter)."""
+    from oracle import oracle as O
+    fx = load_fixture(name)
+    pl = make(fx, max_slots=1)
+    par, sym, leaf = pl.state_graph()
+    full, rho = O.expand_table_circuits(fx)
+    for c in range(len(full)):
+        i = leaf[c]; s = []
+        while par[i] >= 0:
+            s.append(int(sym[i])); i = par[i]
+        assert s[::-1] == [int(g) for g in full[c]] and sym[i] == rho[c]
+    words, off = pl.program()
+    ids = (words[(words >> 28) == 6] & 0x0FFFFFFF)
+    assert ids.max() < len(par)
+    out, written, st = run_programs(words, off, fx['gates'], fx['rhos'], fx['effects'], fx['eff_ptr'],
+                                    fx['eff_label'], fx['eff_dest'], int(fx['nE']))
+    assert set(leaf.tolist()) <= set(st['node_states'].keys())
