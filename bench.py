@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--target-tasks", type=int, default=0)
     ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="N>1: also all-gather the probability row blocks (RCCL)")
     ap.add_argument("--deriv", default="fd", choices=["fd", "analytic"],
                     help="fd: finite differences, bit-identical to the reference Map path (headline); "
                          "analytic: exact derivatives (MatrixForwardSimulator semantics)")
@@ -95,11 +96,19 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     dist = None
+    backend = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = max(torch.cuda.device_count(), 1)
+        device = local_rank % ndev                  # (ranks share a GPU only in the 1-GPU plumbing test)
+        torch.cuda.set_device(device)
+        backend = os.environ.get("GST_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+        local_rank = device
 
     def barrier_sync(plan):
         plan.sync()
@@ -145,7 +154,7 @@ def main():
         kernel_ms = [plan.stats()["last_kernel_ms"]]
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -160,6 +169,25 @@ def main():
         plan.fill_probs_dev(d_probs)
     barrier_sync(plan)
     dtp = time.perf_counter() - tp0
+
+    gather_ms = None
+    if dist is not None and args.gather:
+        # the reference's `gather_local_array` equivalent: row blocks of the probabilities travel to every rank
+        # (RCCL all-gather over xGMI under nccl); the Jacobian stays distributed, as bulk_fill_dprobs leaves it
+        import torch
+        from pygsti_amd import dist as gdist
+        dev = "cuda" if backend == "nccl" else "cpu"
+        loc = torch.zeros(nE_total, dtype=torch.float64, device=dev)
+        host = np.empty(nE_local)
+        plan.memcpy_d2h(host, d_probs)
+        loc[atom.element_slice.start:atom.element_slice.stop] = torch.from_numpy(host).to(dev)
+        barrier_sync(plan)
+        tg = time.perf_counter()
+        full = gdist.gather_elements(loc, layout)
+        barrier_sync(plan)
+        gather_ms = 1e3 * (time.perf_counter() - tg)
+        s = float(full.sum().item())
+        assert abs(s - len(circuits)) < 1e-6 * len(circuits), "gathered probabilities must sum to 1 per circuit"
 
     st = plan.stats()
     if rank == 0:
@@ -192,6 +220,7 @@ def main():
                        "derivative": ("forward finite differences, eps=1e-7 (reference MapForwardSimulator semantics)"
                                       if args.deriv == "fd" else "analytic (reference MatrixForwardSimulator semantics)"),
                        "parallelism": "atoms%d" % world},
+            "gather_probs_ms": gather_ms,
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,
             "roofline": roof or {"bound": "valu_f64", "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
