@@ -70,11 +70,11 @@ struct BackStep<D, D> {
 constexpr int ANA_PAD = 2;   // LDS row padding (doubles): row stride D+2 keeps the wide reads conflict-free
 constexpr int ANA_P = 4;     // steps per chunk; the next chunk's F / gate symbols are in flight during the current one
 
-template <int D, int NG>
-__global__ __launch_bounds__(256, 2) void analytic_dprobs_kernel(const AnaArgs a)
+template <int D, int NG, int WPS>
+__global__ __launch_bounds__(256, WPS) void analytic_dprobs_kernel(const AnaArgs a)
 {
     static_assert(D == 16 || D == 4, "one DPP row (D = 16) or quad (D = 4) per outcome");
-    extern __shared__ double lds[];          // gates_t, padded: lds[(g*D + b)*(D+PAD) + a] = G[a][b]
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // gates_t, padded: lds[(g*D + b)*(D+PAD) + a] = G[a][b]
     constexpr int RS = D + ANA_PAD;
     constexpr int P = ANA_P;
     const int tid = threadIdx.x;
@@ -144,10 +144,12 @@ __global__ __launch_bounds__(256, 2) void analytic_dprobs_kernel(const AnaArgs a
                         for (int u = 0; u < P; u++) {
                             if (t0 + u < run) {
                                 const int32_t sym = __builtin_amdgcn_readlane(symc, u);
-                                const double* colp = lds + (sym * D + bi) * RS;      // column b of G: G[.][b]
+                                // column b of G, G[.][b]: 16-byte reads at a 144-byte lane stride are bank-conflict free
+                                typedef double d2_t __attribute__((ext_vector_type(2)));
+                                const d2_t* colp = (const d2_t*)__builtin_assume_aligned(lds + (sym * D + bi) * RS, 16);
                                 double col[D];
 #pragma unroll
-                                for (int j = 0; j < D; j++) col[j] = colp[j];
+                                for (int j = 0; j < D; j += 2) { const d2_t t = colp[j / 2]; col[j] = t.x; col[j + 1] = t.y; }
                                 double Bn = 0.0;
                                 const int gl = sym - g0;
                                 bool done = false;
@@ -201,10 +203,10 @@ hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream)
     const size_t lds_bytes = (size_t)a.n_gates * D * (D + ANA_PAD) * sizeof(double);
     if (lds_bytes > 64 * 1024) return hipErrorInvalidValue;
     int64_t blocks = (a.n_circuits + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;       // persistent: every wavefront strides over the circuits
+    if (blocks > 256 * 16) blocks = 256 * 16;     // persistent: every wavefront strides over the circuits
     (void)hipGetLastError();
-    if (D == 16) hipLaunchKernelGGL((analytic_dprobs_kernel<16, 6>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
-    else hipLaunchKernelGGL((analytic_dprobs_kernel<4, 8>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
+    if (D == 16) hipLaunchKernelGGL((analytic_dprobs_kernel<16, 6, 2>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((analytic_dprobs_kernel<4, 8, 4>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
