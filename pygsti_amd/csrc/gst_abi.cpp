@@ -81,6 +81,25 @@ struct gst_plan {
     DevBuf<int32_t> d_wave_row, d_wave_rowidx, d_lane_colidx;
     DevBuf<int32_t> d_node_parent, d_node_sym, d_node_run, d_circ_leaf, d_gate_col0, d_cm_gate, d_cm_rho, d_cm_eff;
     bool graph_uploaded = false;
+    // the lane tables / column maps on the device describe this request (skip re-packing when it repeats)
+    std::vector<int64_t> cached_pidx, cached_didx;
+    int cached_kind = 0;        // 0 none, 1 FD lane tables, 2 analytic column maps
+    bool cached_has_didx = false;
+    int32_t cached_n_waves = 0;
+    std::vector<int64_t> cached_none_cols;
+
+    bool request_cached(int kind, const int64_t* pidx, const int64_t* didx, int64_t n) const
+    {
+        if (cached_kind != kind || (int64_t)cached_pidx.size() != n || cached_has_didx != (didx != nullptr)) return false;
+        if (n && std::memcmp(cached_pidx.data(), pidx, sizeof(int64_t) * n)) return false;
+        if (didx && n && std::memcmp(cached_didx.data(), didx, sizeof(int64_t) * n)) return false;
+        return true;
+    }
+    void remember_request(int kind, const int64_t* pidx, const int64_t* didx, int64_t n)
+    {
+        cached_kind = kind; cached_pidx.assign(pidx, pidx + n); cached_has_didx = didx != nullptr;
+        if (didx) cached_didx.assign(didx, didx + n); else cached_didx.clear();
+    }
 
     double last_kernel_ms = 0, last_total_ms = 0;
     int64_t last_launches = 0;
@@ -282,15 +301,20 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
     const bool rows = (p->hp.D == 64);
-    LaneLayout L;
-    if (rows) pack_waves(p, param_idx, dest_idx, n_param, L);     // one perturbed model per wavefront
-    else pack_lanes(p, param_idx, dest_idx, n_param, L);
-    // the host vectors must outlive the async copies: synchronous small copies instead
-    if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
-    if ((rc = upload_i32(p->d_lane[1], L.kind[0], p->stream))) return rc;
-    if ((rc = upload_i32(p->d_lane[2], L.obj[0], p->stream))) return rc;
-    if ((rc = upload_i32(p->d_lane[3], L.elem[0], p->stream))) return rc;
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (!p->request_cached(1, param_idx, dest_idx, n_param)) {
+        // (an optimizer asks for the same columns every iteration: pack and upload the lane tables once)
+        LaneLayout L;
+        if (rows) pack_waves(p, param_idx, dest_idx, n_param, L);     // one perturbed model per wavefront
+        else pack_lanes(p, param_idx, dest_idx, n_param, L);
+        p->cached_kind = 0;
+        if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_lane[1], L.kind[0], p->stream))) return rc;
+        if ((rc = upload_i32(p->d_lane[2], L.obj[0], p->stream))) return rc;
+        if ((rc = upload_i32(p->d_lane[3], L.elem[0], p->stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(p->stream));       // the host vectors go out of scope
+        p->remember_request(1, param_idx, dest_idx, n_param);
+        p->cached_n_waves = L.n_waves;
+    }
     gst::WalkArgs a;
     base_args(p, a);
     a.mode = gst::EMIT_FD;
@@ -298,7 +322,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     a.raw = d_raw; a.ldraw = ldraw;
     a.base_cache = p->d_base_cache.p;
     a.lanes.col = p->d_lane[0].p; a.lanes.kind[0] = p->d_lane[1].p; a.lanes.obj[0] = p->d_lane[2].p; a.lanes.elem[0] = p->d_lane[3].p;
-    a.n_pwaves = L.n_waves;
+    a.n_pwaves = p->cached_n_waves;
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
     if (rows) {
         a.rows_S = 1;
@@ -320,44 +344,51 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     int rc = run_probs(p, d_base, n_param > 0);        // probabilities + every forward state
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
-    const int D = h.D, DD = D * D;
-    std::vector<int32_t> cm_gate((size_t)std::max(h.n_gates, 1) * DD, -1), cm_rho((size_t)h.n_rhos * D, -1),
-        cm_eff((size_t)h.n_effects * D, -1), col0(std::max(h.n_gates, 1), -2);
-    std::vector<int64_t> none_cols;
-    for (int64_t c = 0; c < n_param; c++) {
-        const int64_t pi = param_idx[c];
-        const int32_t col = (int32_t)(dest_idx ? dest_idx[c] : c);
-        switch (p->pkind[pi]) {
-        case GST_KIND_GATE: cm_gate[(size_t)p->pobj[pi] * DD + p->pelem[pi]] = col; break;
-        case GST_KIND_RHO: cm_rho[(size_t)p->pobj[pi] * D + p->pelem[pi]] = col; break;
-        case GST_KIND_EFFECT: cm_eff[(size_t)p->pobj[pi] * D + p->pelem[pi]] = col; break;
-        default: none_cols.push_back(col);
+    if (!p->request_cached(2, param_idx, dest_idx, n_param)) {
+        const int D = h.D, DD = D * D;
+        std::vector<int32_t> cm_gate((size_t)std::max(h.n_gates, 1) * DD, -1), cm_rho((size_t)h.n_rhos * D, -1),
+            cm_eff((size_t)h.n_effects * D, -1), col0(std::max(h.n_gates, 1), -2);
+        std::vector<int64_t> none_cols;
+        for (int64_t c = 0; c < n_param; c++) {
+            const int64_t pi = param_idx[c];
+            const int32_t col = (int32_t)(dest_idx ? dest_idx[c] : c);
+            switch (p->pkind[pi]) {
+            case GST_KIND_GATE: cm_gate[(size_t)p->pobj[pi] * DD + p->pelem[pi]] = col; break;
+            case GST_KIND_RHO: cm_rho[(size_t)p->pobj[pi] * D + p->pelem[pi]] = col; break;
+            case GST_KIND_EFFECT: cm_eff[(size_t)p->pobj[pi] * D + p->pelem[pi]] = col; break;
+            default: none_cols.push_back(col);
+            }
         }
-    }
-    for (int g = 0; g < h.n_gates; g++) {
-        const int32_t* m = cm_gate.data() + (size_t)g * DD;
-        bool any = false, contiguous = m[0] >= 0;
-        for (int k = 0; k < DD; k++) { any = any || m[k] >= 0; contiguous = contiguous && m[k] == m[0] + k; }
-        col0[g] = contiguous ? m[0] : (any ? -1 : -2);
-    }
-    if (!p->graph_uploaded) {
-        if ((rc = upload_i32(p->d_node_parent, h.node_parent, p->stream))) return rc;
-        if ((rc = upload_i32(p->d_node_sym, h.node_sym, p->stream))) return rc;
-        {   // run[id] = 1 + run[id-1] while parent(id) == id-1 is a gate state reached by a consecutive id
-            std::vector<int32_t> run(h.n_state_ids, 0);
-            for (int64_t i = 1; i < h.n_state_ids; i++)
-                if (h.node_parent[i] == i - 1) run[i] = 1 + ((h.node_parent[i - 1] >= 0 && h.node_parent[i - 1] == i - 2) ? run[i - 1] : 0);
-            if ((rc = upload_i32(p->d_node_run, run, p->stream))) return rc;
-            HIP_TRY(hipStreamSynchronize(p->stream));
+        for (int g = 0; g < h.n_gates; g++) {
+            const int32_t* m = cm_gate.data() + (size_t)g * DD;
+            bool any = false, contiguous = m[0] >= 0;
+            for (int k = 0; k < DD; k++) { any = any || m[k] >= 0; contiguous = contiguous && m[k] == m[0] + k; }
+            col0[g] = contiguous ? m[0] : (any ? -1 : -2);
         }
-        if ((rc = upload_i32(p->d_circ_leaf, h.circ_leaf, p->stream))) return rc;
-        p->graph_uploaded = true;
+        if (!p->graph_uploaded) {
+            if ((rc = upload_i32(p->d_node_parent, h.node_parent, p->stream))) return rc;
+            if ((rc = upload_i32(p->d_node_sym, h.node_sym, p->stream))) return rc;
+            {   // run[id] = 1 + run[id-1] while parent(id) == id-1 is a gate state reached by a consecutive id
+                std::vector<int32_t> run(h.n_state_ids, 0);
+                for (int64_t i = 1; i < h.n_state_ids; i++)
+                    if (h.node_parent[i] == i - 1) run[i] = 1 + ((h.node_parent[i - 1] >= 0 && h.node_parent[i - 1] == i - 2) ? run[i - 1] : 0);
+                if ((rc = upload_i32(p->d_node_run, run, p->stream))) return rc;
+                HIP_TRY(hipStreamSynchronize(p->stream));
+            }
+            if ((rc = upload_i32(p->d_circ_leaf, h.circ_leaf, p->stream))) return rc;
+            p->graph_uploaded = true;
+        }
+        p->cached_kind = 0;
+        if ((rc = upload_i32(p->d_gate_col0, col0, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_cm_gate, cm_gate, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_cm_rho, cm_rho, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_cm_eff, cm_eff, p->stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(p->stream));          // host vectors above go out of scope
+        p->remember_request(2, param_idx, dest_idx, n_param);
+        p->cached_none_cols = none_cols;
     }
-    if ((rc = upload_i32(p->d_gate_col0, col0, p->stream))) return rc;
-    if ((rc = upload_i32(p->d_cm_gate, cm_gate, p->stream))) return rc;
-    if ((rc = upload_i32(p->d_cm_rho, cm_rho, p->stream))) return rc;
-    if ((rc = upload_i32(p->d_cm_eff, cm_eff, p->stream))) return rc;
-    HIP_TRY(hipStreamSynchronize(p->stream));          // host vectors above go out of scope
+    const int D = h.D;
+    const std::vector<int64_t>& none_cols = p->cached_none_cols;
     for (int64_t col : none_cols)                      // parameters of objects this atom never applies: exact zeros
         HIP_TRY(hipMemset2DAsync(d_out + col, (size_t)ld * 8, 0, 8, (size_t)h.n_elements, p->stream));
     gst::AnaArgs a;
@@ -511,6 +542,7 @@ int gst_set_param_map(gst_plan* p, int32_t n_params, const int32_t* kind, const 
     p->pobj.assign(obj, obj + n_params);
     p->pelem.assign(elem, elem + n_params);
     p->have_pmap = true;
+    p->cached_kind = 0;      // device lane tables / column maps describe the old map
     return GST_OK;
 }
 
@@ -634,6 +666,7 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
         }
     }
     L.n_waves = rows ? (int32_t)L.col.size() : (int32_t)(L.col.size() / 64);
+    p->cached_kind = 0;      // the shared lane tables are about to hold the (i, j) pairs
     if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
     for (int s = 0; s < 2; s++) {
         if ((rc = upload_i32(p->d_lane[1 + 3 * s], L.kind[s], p->stream))) return rc;

@@ -102,34 +102,54 @@ __global__ __launch_bounds__(64) void walk_rows_kernel(const WalkArgs a, const i
     for (;;) {
         if (op == GST_OP_END) break;
         if (op == GST_OP_APPLY) {
-            const bool hit = (S > 0) && ((arg < 64) ? ((wave_gates >> arg) & 1ull) : (wave_gates != 0));
+            bool hit = (S > 0) && ((arg < 64) ? ((wave_gates >> arg) & 1ull) : (wave_gates != 0));
             if (S > 0 && !dirty) {
                 if (!hit) { ROWS_FETCH(); continue; }                 // base state: nothing to compute
                 v = a.base_cache[(int64_t)cur_id * D + li];           // first perturbed gate: start from the cache
                 dirty = true;
             }
-            // row `lane` of the gate: c[j] = G[lane][j] = gates_t[g][j][lane]  (coalesced across lanes)
-            double c[D];
-            if (LDSG) {
-                const double* Gt = ldsG + (int)arg * D * D + li;
+            // Chains of (APPLY, NODE) pairs run in this tight loop; the coefficients of the NEXT mat-vec (row
+            // `lane` of its gate: c[j] = G[lane][j] = gates_t[g][j][lane], coalesced across lanes) are requested
+            // before the current one is computed, so their LDS / L2 latency hides under the arithmetic.
+            double c[D], cn[D];
+#define ROWS_LOADC(dst, g_)                                                                           \
+            do {                                                                                      \
+                if (LDSG) {                                                                           \
+                    const double* Gt_ = ldsG + (int)(g_) * D * D + li;                                \
+                    _Pragma("unroll") for (int j = 0; j < D; j++) dst[j] = Gt_[j * D];                \
+                } else {                                                                              \
+                    const double* Gt_ = a.gates_t + (int64_t)(g_) * D * D + li;                       \
+                    _Pragma("unroll") for (int j = 0; j < D; j++) dst[j] = Gt_[j * D];                \
+                }                                                                                     \
+            } while (0)
+            ROWS_LOADC(c, arg);
+            for (;;) {
+                const uint32_t g = arg;
+                ROWS_FETCH();                                          // the NODE marker of the state being produced
+                const int32_t node_id = (int32_t)arg;
+                ROWS_FETCH();                                          // what follows
+                const bool more = (op == GST_OP_APPLY);
+                if (more) ROWS_LOADC(cn, arg);
+                if (hit) {
+                    for (int s = 0; s < S; s++) {
+                        const bool mine = kind[s] == GST_KIND_GATE && obj[s] == (int)g && lane == row[s];
 #pragma unroll
-                for (int j = 0; j < D; j++) c[j] = Gt[j * D];
-            } else {
-                const double* Gt = a.gates_t + (int64_t)arg * D * D + li;
-#pragma unroll
-                for (int j = 0; j < D; j++) c[j] = Gt[j * D];
-            }
-            if (hit) {
-                for (int s = 0; s < S; s++) {
-                    const bool mine = kind[s] == GST_KIND_GATE && obj[s] == (int)arg && lane == row[s];
-#pragma unroll
-                    for (int j = 0; j < D; j++) c[j] = (mine && j == cb[s]) ? c[j] + a.eps : c[j];   // theta + eps
+                        for (int j = 0; j < D; j++) c[j] = (mine && j == cb[s]) ? c[j] + a.eps : c[j];   // theta + eps
+                    }
                 }
-            }
-            double acc = 0.0;
+                double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < D; j++) acc = acc + c[j] * readlane_f64(v, j);
-            v = acc;
+                for (int j = 0; j < D; j++) acc = acc + c[j] * readlane_f64(v, j);
+                v = acc;
+                cur_id = node_id;
+                if (S == 0 && a.base_cache_w && act) a.base_cache_w[(int64_t)node_id * D + lane] = v;
+                if (!more) break;
+#pragma unroll
+                for (int j = 0; j < D; j++) c[j] = cn[j];
+                hit = (S > 0) && ((arg < 64) ? ((wave_gates >> arg) & 1ull) : (wave_gates != 0));
+            }
+#undef ROWS_LOADC
+            continue;                                                  // `op` already holds the next instruction
         } else if (op == GST_OP_NODE) {
             cur_id = (int32_t)arg;
             if (S == 0 && a.base_cache_w && act) a.base_cache_w[(int64_t)arg * D + lane] = v;
