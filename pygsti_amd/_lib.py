@@ -212,8 +212,11 @@ class Plan:
             ncol = len(pi) if di is None else (int(di.max()) + 1 if len(di) else 0)
             out = np.empty((self.n_elements, ncol), np.float64)
         assert out.dtype == np.float64 and out.ndim == 2 and out.shape[0] == self.n_elements
-        assert out.strides[1] == 8 and out.strides[0] % 8 == 0, "rows must be contiguous in the parameter dimension"
-        ld = out.strides[0] // 8 if out.shape[0] > 1 else max(out.shape[1], 1)
+        if out.shape[1] == 0 or out.shape[0] == 0:
+            ld = max(out.shape[1], 1)
+        else:
+            assert out.strides[1] == 8 and out.strides[0] % 8 == 0, "rows must be contiguous in the parameter dimension"
+            ld = out.strides[0] // 8 if out.shape[0] > 1 else max(out.shape[1], 1)
         if probs_out is not None:
             assert probs_out.dtype == np.float64 and probs_out.flags.c_contiguous and probs_out.size == self.n_elements
         check(lib().gst_fill_dprobs(self._h, _ptr(out), ld, _ptr(pi), _ptr(di), len(pi), int(mode), float(eps),
