@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--target-tasks", type=int, default=0)
     ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--jtj", action="store_true", help="also time J^T J and J^T f on the resident Jacobian (row f1)")
     ap.add_argument("--gather", action="store_true", help="N>1: also all-gather the probability row blocks (RCCL)")
     ap.add_argument("--deriv", default="fd", choices=["fd", "analytic"],
                     help="fd: finite differences, bit-identical to the reference Map path (headline); "
@@ -170,6 +171,28 @@ def main():
     barrier_sync(plan)
     dtp = time.perf_counter() - tp0
 
+    jtj_info = None
+    if args.jtj:
+        d_jtj = plan.device_malloc(nP * nP * 8); d_jtf = plan.device_malloc(nP * 8); d_f = plan.device_malloc(nE_local * 8)
+        plan.memcpy_h2d(d_f, np.random.default_rng(0).standard_normal(nE_local))
+        plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj); plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_f, d_jtf)   # warm-up
+        barrier_sync(plan)
+        tj = time.perf_counter()
+        for _ in range(3):
+            plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj)
+        barrier_sync(plan)
+        t_jtj = (time.perf_counter() - tj) / 3
+        tj = time.perf_counter()
+        for _ in range(3):
+            plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_f, d_jtf)
+        barrier_sync(plan)
+        t_jtf = (time.perf_counter() - tj) / 3
+        jtj_info = {"jtj_ms": 1e3 * t_jtj, "jtj_TFLOPs": 2.0 * nE_local * nP * nP / 2 / t_jtj / 1e12,
+                    "jtf_ms": 1e3 * t_jtf, "jtf_GBps": 8.0 * nE_local * nP / t_jtf / 1e9,
+                    "note": "hand-written split-K MFMA fp64 SYRK / streaming GEMV on the device-resident Jacobian of this rank (flops counted for the triangle: nE*nP^2)"}
+        for d in (d_jtj, d_jtf, d_f):
+            plan.device_free(d)
+
     gather_ms = None
     if dist is not None and args.gather:
         # the reference's `gather_local_array` equivalent: row blocks of the probabilities travel to every rank
@@ -237,6 +260,7 @@ def main():
                                       if args.deriv == "fd" else "analytic (reference MatrixForwardSimulator semantics)"),
                        "parallelism": "atoms%d" % world},
             "gather_probs_ms": gather_ms,
+            "normal_equations": jtj_info,
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,
             "roofline": roof or {"bound": "valu_f64", "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,

@@ -154,6 +154,21 @@ int gst_fill_dprobs_dev(gst_plan *plan, double *d_out, int64_t ld, const int64_t
                         double *d_probs_out);
 int gst_sync(gst_plan *plan);
 
+/* Normal equations of the least-squares fit on the device ("next" row f1 of SURVEY 8(f); the reference does this
+ * on the host after the Jacobian has been scaled by the objective's dterms: layout.fill_jtj / fill_jtf,
+ * pygsti/layouts/distlayout.py:1220-1359, copalayout.py:549-598, consumed by optimize/simplerlm.py:677-678).
+ * d_J is a device-resident row-major [n_rows][ld] Jacobian block (n_cols <= ld columns used), e.g. what
+ * gst_fill_dprobs_dev left in HBM -- so the 7 GB Jacobian never crosses PCIe, only n_cols^2 + n_cols numbers do.
+ *   d_row_scale (may be NULL): per-row factor w_k applied on the fly, J_s = diag(w) J  (the objective's dlsvec scaling)
+ *   gst_fill_jtj_dev: d_jtj[n_cols][n_cols] = J_s^T J_s   (full symmetric matrix; split-K MFMA fp64 kernel)
+ *   gst_fill_jtf_dev: d_jtf[n_cols] = J_s^T f,  f = d_f[n_rows]
+ * With several ranks each computes the partial sums of its own rows; the caller all-reduces (RCCL) n_cols^2 doubles. */
+int gst_fill_jtj_dev(gst_plan *plan, double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
+                     const double *d_row_scale, double *d_jtj);
+int gst_fill_jtf_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
+                     const double *d_f, double *d_jtf);
+int gst_memcpy_h2d(gst_plan *plan, void *d_dst, const void *src, int64_t nbytes);
+
 /* Plain device-buffer helpers on the plan's device, so that callers without any GPU framework can
  * keep results resident (bench.py, tests).  Buffers from any other allocator work equally. */
 int gst_device_malloc(gst_plan *plan, int64_t nbytes, void **d_ptr);

@@ -58,7 +58,7 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
            "gst_last_error", "gst_version"]
 
 _lib = None
@@ -85,6 +85,9 @@ def lib():
         L.gst_fill_hprobs.argtypes = [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, dbl]
         L.gst_fill_probs_dev.argtypes = [vp, vp]
         L.gst_fill_dprobs_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.c_int, dbl, vp]
+        L.gst_fill_jtj_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+        L.gst_fill_jtf_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+        L.gst_memcpy_h2d.argtypes = [vp, vp, vp, i64]
         L.gst_sync.argtypes = [vp]
         L.gst_device_malloc.argtypes = [vp, i64, C.POINTER(vp)]
         L.gst_device_free.argtypes = [vp, vp]
@@ -248,6 +251,18 @@ class Plan:
 
     def sync(self):
         check(lib().gst_sync(self._h))
+
+    def fill_jtj_dev(self, d_J, n_rows, n_cols, ld, d_jtj, d_row_scale=None):
+        check(lib().gst_fill_jtj_dev(self._h, C.c_void_p(int(d_J)), int(n_rows), int(n_cols), int(ld),
+                                     None if d_row_scale is None else C.c_void_p(int(d_row_scale)), C.c_void_p(int(d_jtj))))
+
+    def fill_jtf_dev(self, d_J, n_rows, n_cols, ld, d_f, d_jtf):
+        check(lib().gst_fill_jtf_dev(self._h, C.c_void_p(int(d_J)), int(n_rows), int(n_cols), int(ld),
+                                     C.c_void_p(int(d_f)), C.c_void_p(int(d_jtf))))
+
+    def memcpy_h2d(self, d_ptr, arr, offset_bytes=0):
+        arr = np.ascontiguousarray(arr)
+        check(lib().gst_memcpy_h2d(self._h, C.c_void_p(int(d_ptr) + int(offset_bytes)), _ptr(arr), arr.nbytes))
 
     def device_malloc(self, nbytes):
         p = C.c_void_p()

@@ -75,6 +75,7 @@ struct gst_plan {
     std::vector<int32_t> pkind, pobj, pelem;
     bool have_pmap = false;
     // work buffers
+    DevBuf<double> d_jtj_part, d_jtf_part;   // split-K partial sums of the normal equations
     DevBuf<double> d_base_cache;   // [n_state_ids][D] states of the last base pass
     DevBuf<double> d_pbase, d_out, d_raw, d_dcol, d_probs_tmp;
     DevBuf<int32_t> d_lane[7];   // col, kind0, obj0, elem0, kind1, obj1, elem1
@@ -110,7 +111,7 @@ struct gst_plan {
         (void)hipSetDevice(device);
         d_prog.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
-        d_pbase.release(); d_base_cache.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
+        d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
         d_wave_row.release(); d_wave_rowidx.release(); d_lane_colidx.release();
         d_node_parent.release(); d_node_sym.release(); d_node_run.release(); d_circ_leaf.release(); d_gate_col0.release();
@@ -704,6 +705,48 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     p->last_launches++;
     HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));
     return end_call(p, true);
+}
+
+int gst_fill_jtj_dev(gst_plan* p, double* d_J, int64_t n_rows, int64_t n_cols, int64_t ld, const double* d_row_scale,
+                     double* d_jtj)
+{
+    if (!p || !d_J || !d_jtj || n_rows < 0 || n_cols < 0 || ld < n_cols || n_cols > 0x7fffffff) return fail(GST_EINVAL, "bad argument");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    if (d_row_scale && n_rows > 0 && n_cols > 0) HIP_TRY(gst::launch_scale_rows(d_J, n_rows, n_cols, ld, d_row_scale, p->stream));
+    if (n_cols > 0) {
+        const int n_slabs = gst::jtj_num_slabs(n_rows, (int)n_cols);
+        HIP_TRY(p->d_jtj_part.ensure((size_t)n_slabs * n_cols * n_cols));
+        HIP_TRY(hipEventRecord(p->evk0, p->stream));
+        HIP_TRY(gst::launch_jtj(d_J, n_rows, (int)n_cols, ld, p->d_jtj_part.p, n_slabs, d_jtj, p->stream));
+        HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    }
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    return GST_OK;
+}
+
+int gst_fill_jtf_dev(gst_plan* p, const double* d_J, int64_t n_rows, int64_t n_cols, int64_t ld, const double* d_f,
+                     double* d_jtf)
+{
+    if (!p || !d_J || !d_f || !d_jtf || n_rows < 0 || n_cols < 0 || ld < n_cols || n_cols > 0x7fffffff) return fail(GST_EINVAL, "bad argument");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    if (n_cols == 0) return GST_OK;
+    const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n_rows + 255) / 256));
+    HIP_TRY(p->d_jtf_part.ensure((size_t)n_slabs * n_cols));
+    HIP_TRY(gst::launch_jtf(d_J, d_f, n_rows, (int)n_cols, ld, p->d_jtf_part.p, n_slabs, d_jtf, p->stream));
+    return GST_OK;
+}
+
+int gst_memcpy_h2d(gst_plan* p, void* d_dst, const void* src, int64_t nbytes)
+{
+    if (!p || !d_dst || !src || nbytes < 0) return fail(GST_EINVAL, "bad argument");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, src, (size_t)nbytes, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return GST_OK;
 }
 
 int gst_device_malloc(gst_plan* p, int64_t nbytes, void** d_ptr)

@@ -431,6 +431,36 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
 #undef GST_HIT
 }
 
+// ---- small helpers for the normal equations (gst_fill_jtj_dev) ------------------------------------------------
+__global__ void scale_rows_kernel(double* J, int64_t n_rows, int64_t n_cols, int64_t ld, const double* w)
+{
+    const int64_t total = n_rows * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n_cols, c = i - r * n_cols;
+        J[r * ld + c] *= w[r];
+    }
+}
+__global__ void symmetrize_kernel(double* C, int64_t n)   // copy the computed triangle onto the other one
+{
+    const int64_t total = n * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n, c = i - r * n;
+        if (c > r) C[c * n + r] = C[r * n + c];   // dsyrk(lower, column-major) filled the row-major UPPER triangle
+    }
+}
+hipError_t launch_scale_rows(double* J, int64_t n_rows, int64_t n_cols, int64_t ld, const double* w, hipStream_t s)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(2048), dim3(256), 0, s, J, n_rows, n_cols, ld, w);
+    return hipGetLastError();
+}
+hipError_t launch_symmetrize(double* C, int64_t n, hipStream_t s)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(1024), dim3(256), 0, s, C, n);
+    return hipGetLastError();
+}
+
 template <int D, int S, int WPS>
 static hipError_t launch_one(const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
 {

@@ -84,6 +84,14 @@ struct AnaArgs {
 };
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
 
+hipError_t launch_scale_rows(double* J, int64_t n_rows, int64_t n_cols, int64_t ld, const double* w, hipStream_t s);
+hipError_t launch_symmetrize(double* C, int64_t n, hipStream_t s);
+// Normal equations (gst_kernels_normal.hip): split-K MFMA fp64 J^T J and streaming J^T f
+int jtj_num_slabs(int64_t n_rows, int n_cols);
+hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs, double* C, hipStream_t s);
+hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs,
+                      double* y, hipStream_t s);
+
 // Row-per-lane variant (gst_kernels_rows.hip): one model per wavefront; D = 4, 16 or 64; S = a.rows_S.
 hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 

@@ -1,0 +1,176 @@
+// gst_kernels_normal.hip -- normal equations of the least-squares fit on the device-resident Jacobian:
+//   JtJ[c1][c2] = sum_k J[k][c1] * J[k][c2]      (n_cols x n_cols, symmetric)      -- MFMA fp64
+//   Jtf[c]      = sum_k J[k][c]  * f[k]                                              -- streaming
+// This is kernel K10 / "next" row f1 of SURVEY.md (layout.fill_jtj / fill_jtf, pygsti/layouts/distlayout.py:1220-1359),
+// the place where a dense contraction DOES warrant the matrix cores: J is tall and skinny (545,100 x 1,616 for the
+// 2Q L<=1024 design), so J^T J is a 1.4 TFLOP fp64 SYRK whose K dimension is the long one -- the shape vendor GEMMs
+// handle badly (rocBLAS dsyrk: 299 ms = 4.8 TFLOP/s on this box).
+//
+// Tiling (gfx950, wave64, v_mfma_f64_16x16x4_f64):
+//   * The A operand of the MFMA wants lane l to hold A[i = l&15][k = l>>4], the B operand B[k = l>>4][j = l&15].
+//     With A[i][k] = J[k][i0+i] and B[k][j] = J[k][j0+j] BOTH are plain 4-row x 16-column patches of the row-major
+//     Jacobian, 128 contiguous bytes per row: no transposition, no LDS -- operands go HBM/L2 -> VGPR directly.
+//   * One wavefront owns a 64 x 64 block of JtJ (4 x 4 MFMA tiles, 64 fp64 accumulators per lane); a 256-thread
+//     workgroup owns a 128 x 128 tile over ONE SLAB of rows (split-K: the row dimension is cut into slabs so that
+//     tiles x slabs >> 256 CUs); per 4 rows a wavefront loads 4 + 4 patches and issues 16 MFMAs.
+//   * Only tiles on or above the diagonal are computed; partial tiles of every slab go to a scratch buffer and a
+//     second kernel sums the slabs in a fixed order (deterministic, no atomics) and mirrors the triangle.
+#include "gst_kernels.hpp"
+
+namespace gst {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int JTJ_TILE = 128;     // workgroup tile of JtJ
+constexpr int JTJ_WT = 64;        // wavefront tile
+
+__global__ __launch_bounds__(256, 2) void jtj_mfma_kernel(const double* __restrict__ J, int64_t n_rows, int n_cols,
+                                                          int64_t ld, int64_t slab_rows, int n_tiles,
+                                                          double* __restrict__ part /* [n_slabs][n_cols][n_cols] */)
+{
+    // blockIdx.x -> (tile pair index p, slab s); pairs enumerate ti <= tj
+    const int n_pairs = n_tiles * (n_tiles + 1) / 2;
+    const int p = blockIdx.x % n_pairs;
+    const int64_t s = blockIdx.x / n_pairs;
+    int ti = 0, rem = p;
+    while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ti++; }
+    const int tj = ti + rem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = ti * JTJ_TILE + (wave >> 1) * JTJ_WT;      // first JtJ row of this wavefront
+    const int j0 = tj * JTJ_TILE + (wave & 1) * JTJ_WT;       // first JtJ column
+    const int lk = lane >> 4, lc = lane & 15;
+
+    d4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    const int64_t k_begin = s * slab_rows;
+    const int64_t k_end = (k_begin + slab_rows < n_rows) ? k_begin + slab_rows : n_rows;
+    // column guards (the last tile is partial); out-of-range operands are zero
+    bool ca[4], cb[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { ca[t] = i0 + 16 * t + lc < n_cols; cb[t] = j0 + 16 * t + lc < n_cols; }
+
+    auto load = [&](int64_t k, double (&a)[4], double (&b)[4]) {
+        const int64_t r = k + lk;
+        const bool rv = r < k_end;
+        const double* row = J + (rv ? r : 0) * ld;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            a[t] = (rv && ca[t]) ? row[i0 + 16 * t + lc] : 0.0;
+            b[t] = (rv && cb[t]) ? row[j0 + 16 * t + lc] : 0.0;
+        }
+    };
+    double a0[4], b0[4], a1[4], b1[4];
+    load(k_begin, a0, b0);
+    for (int64_t k = k_begin; k < k_end; k += 8) {           // two 4-row steps per iteration, operands double-buffered
+        load(k + 4, a1, b1);
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+#pragma unroll
+            for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], b0[y], acc[x][y], 0, 0, 0);
+        load(k + 8, a0, b0);
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+#pragma unroll
+            for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], b1[y], acc[x][y], 0, 0, 0);
+    }
+    // D layout of v_mfma_f64_16x16x4_f64: lane l, register r -> row (l>>4) + 4r, column l&15
+    double* out = part + (int64_t)s * n_cols * n_cols;
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = i0 + 16 * x + lk + 4 * r, col = j0 + 16 * y + lc;
+                if (row < n_cols && col < n_cols) out[(int64_t)row * n_cols + col] = acc[x][y][r];
+            }
+}
+
+// JtJ[r][c] = sum over slabs of part[s][min][max] (the computed triangle, in units of whole tiles), mirrored
+__global__ void jtj_reduce_kernel(const double* __restrict__ part, int n_slabs, int n_cols, double* __restrict__ C)
+{
+    const int64_t total = (int64_t)n_cols * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / n_cols), c = (int)(i - (int64_t)r * n_cols);
+        // tiles with ti <= tj were computed in full, so an entry is available as (r, c) when tile(r) <= tile(c)
+        const bool direct = (r / JTJ_TILE) <= (c / JTJ_TILE);
+        const int64_t src = direct ? (int64_t)r * n_cols + c : (int64_t)c * n_cols + r;
+        double sum = 0.0;
+        for (int s = 0; s < n_slabs; s++) sum += part[(int64_t)s * total + src];
+        C[i] = sum;
+    }
+}
+
+// Jtf partials: block = 256 consecutive columns x one slab of rows (coalesced 2 KB per row)
+__global__ void jtf_kernel(const double* __restrict__ J, const double* __restrict__ f, int64_t n_rows, int n_cols,
+                           int64_t ld, int64_t slab_rows, double* __restrict__ part /* [n_slabs][n_cols] */)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int64_t s = blockIdx.y;
+    const int64_t k0 = s * slab_rows, k1 = (k0 + slab_rows < n_rows) ? k0 + slab_rows : n_rows;
+    if (c >= n_cols) return;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int64_t k = k0;
+    for (; k + 3 < k1; k += 4) {
+        acc0 = __builtin_fma(J[k * ld + c], f[k], acc0);
+        acc1 = __builtin_fma(J[(k + 1) * ld + c], f[k + 1], acc1);
+        acc2 = __builtin_fma(J[(k + 2) * ld + c], f[k + 2], acc2);
+        acc3 = __builtin_fma(J[(k + 3) * ld + c], f[k + 3], acc3);
+    }
+    for (; k < k1; k++) acc0 = __builtin_fma(J[k * ld + c], f[k], acc0);
+    part[s * n_cols + c] = (acc0 + acc1) + (acc2 + acc3);
+}
+__global__ void jtf_reduce_kernel(const double* __restrict__ part, int n_slabs, int n_cols, double* __restrict__ y)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    double sum = 0.0;
+    for (int s = 0; s < n_slabs; s++) sum += part[(int64_t)s * n_cols + c];
+    y[c] = sum;
+}
+
+int jtj_num_slabs(int64_t n_rows, int n_cols)
+{
+    const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
+    const int n_pairs = n_tiles * (n_tiles + 1) / 2;
+    int slabs = (int)((4096 + n_pairs - 1) / n_pairs);         // aim for ~4096 workgroups (8 per CU-slot pair)
+    const int64_t max_by_rows = (n_rows + 63) / 64;              // at least 64 rows per slab
+    if (slabs > max_by_rows) slabs = (int)(max_by_rows > 0 ? max_by_rows : 1);
+    if (slabs > 64) slabs = 64;
+    return slabs < 1 ? 1 : slabs;
+}
+
+hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs, double* C,
+                      hipStream_t s)
+{
+    const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
+    const int n_pairs = n_tiles * (n_tiles + 1) / 2;
+    int64_t slab_rows = (n_rows + n_slabs - 1) / n_slabs;
+    slab_rows = (slab_rows + 7) / 8 * 8;                         // the k loop advances 8 rows per iteration
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(jtj_mfma_kernel, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), 0, s, J, n_rows, n_cols, ld,
+                       slab_rows, n_tiles, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(jtj_reduce_kernel, dim3(2048), dim3(256), 0, s, part, n_slabs, n_cols, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs,
+                      double* y, hipStream_t s)
+{
+    const int64_t slab_rows = (n_rows + n_slabs - 1) / n_slabs;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(jtf_kernel, dim3((unsigned)((n_cols + 255) / 256), (unsigned)n_slabs), dim3(256), 0, s, J, f, n_rows,
+                       n_cols, ld, slab_rows, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(jtf_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, s, part, n_slabs, n_cols, y);
+    return hipGetLastError();
+}
+
+}  // namespace gst

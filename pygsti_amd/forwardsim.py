@@ -240,6 +240,42 @@ class HipMapForwardSimulator:
             else:
                 yield s1, s2, h
 
+    # -- normal equations on the device ("next" row f1: layout.fill_jtj / fill_jtf, distlayout.py:1220-1359) ----------
+    def bulk_fill_jtj_jtf(self, jtj, jtf, layout, row_scale=None, f=None, pr_array_to_fill=None):
+        """J^T J and J^T f of the (optionally row-scaled) Jacobian without moving the Jacobian off the GPU:
+        the Jacobian of each atom is filled in HBM, scaled by `row_scale[k]` (the objective's dlsvec factor),
+        contracted there, and only num_params^2 + num_params numbers come back.  jtj: (nP, nP), jtf: (nP,) host
+        arrays (summed over this process's atoms; ranks all-reduce them as fill_jtj does)."""
+        nP = self.model.num_params
+        jtj[...] = 0.0
+        if jtf is not None:
+            jtf[...] = 0.0
+        mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
+        pidx = np.arange(nP, dtype=np.int64)
+        for atom in layout.atoms:
+            plan = self._prepare_atom(atom)
+            nE = atom.num_elements
+            es = atom.element_slice
+            d_J = plan.device_malloc(nE * nP * 8); d_pr = plan.device_malloc(nE * 8)
+            d_jtj = plan.device_malloc(nP * nP * 8); d_jtf = plan.device_malloc(nP * 8)
+            d_w = d_f = None
+            try:
+                plan.fill_dprobs_dev(d_J, nP, pidx, None, self.derivative_eps, d_pr, mode)
+                if row_scale is not None:
+                    d_w = plan.device_malloc(nE * 8); plan.memcpy_h2d(d_w, np.asarray(row_scale, np.float64)[es])
+                plan.fill_jtj_dev(d_J, nE, nP, nP, d_jtj, d_w)
+                part = np.empty((nP, nP)); plan.memcpy_d2h(part, d_jtj); jtj += part
+                if jtf is not None:
+                    d_f = plan.device_malloc(nE * 8); plan.memcpy_h2d(d_f, np.asarray(f, np.float64)[es])
+                    plan.fill_jtf_dev(d_J, nE, nP, nP, d_f, d_jtf)
+                    pv = np.empty(nP); plan.memcpy_d2h(pv, d_jtf); jtf += pv
+                if pr_array_to_fill is not None:
+                    plan.memcpy_d2h(pr_array_to_fill[es], d_pr)
+            finally:
+                for d in (d_J, d_pr, d_jtj, d_jtf, d_w, d_f):
+                    if d is not None:
+                        plan.device_free(d)
+
     # -- convenience (forwardsim.py:171-277, 415-582) -------------------------------------------------------------------
     def bulk_probs(self, circuits, clip_to=None, resource_alloc=None, smartc=None):
         layout = self.create_layout(circuits, array_types=("e",))
