@@ -190,6 +190,18 @@ def main():
         jtj_info = {"jtj_ms": 1e3 * t_jtj, "jtj_TFLOPs": 2.0 * nE_local * nP * nP / 2 / t_jtj / 1e12,
                     "jtf_ms": 1e3 * t_jtf, "jtf_GBps": 8.0 * nE_local * nP / t_jtf / 1e9,
                     "note": "hand-written split-K MFMA fp64 SYRK / streaming GEMV on the device-resident Jacobian of this rank (flops counted for the triangle: nE*nP^2)"}
+        if dist is not None:
+            # the path's one real exchange step: every rank holds the partial J^T J of its rows; the optimizer needs
+            # the sum -> one all-reduce of nP^2 doubles (RCCL over xGMI under nccl), cf. distlayout.py:1259,1355
+            import torch
+            host = np.empty((nP, nP)); plan.memcpy_d2h(host, d_jtj)
+            tj = torch.from_numpy(host).to("cuda" if backend == "nccl" else "cpu")
+            barrier_sync(plan)
+            ta = time.perf_counter()
+            dist.all_reduce(tj)
+            barrier_sync(plan)
+            jtj_info["allreduce_ms"] = 1e3 * (time.perf_counter() - ta)
+            jtj_info["allreduce_MB"] = nP * nP * 8 / 1e6
         for d in (d_jtj, d_jtf, d_f):
             plan.device_free(d)
 
