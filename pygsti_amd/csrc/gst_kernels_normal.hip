@@ -29,9 +29,13 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_kernel(const double* __restri
                                                           double* __restrict__ part /* [n_slabs][n_cols][n_cols] */)
 {
     // blockIdx.x -> (tile pair index p, slab s); pairs enumerate ti <= tj
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  All tile
+    // pairs of one slab of rows are given to ONE XCD, so the ~64 workgroups resident there sweep the same rows
+    // at the same pace and share them through that XCD's 4 MB L2 instead of each pulling them from HBM.
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
-    const int p = blockIdx.x % n_pairs;
-    const int64_t s = blockIdx.x / n_pairs;
+    const int xcd = blockIdx.x % 8, q = blockIdx.x / 8;
+    const int p = q % n_pairs;
+    const int64_t s = (int64_t)(q / n_pairs) * 8 + xcd;
     int ti = 0, rem = p;
     while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ti++; }
     const int tj = ti + rem;
@@ -137,11 +141,12 @@ int jtj_num_slabs(int64_t n_rows, int n_cols)
 {
     const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
-    int slabs = (int)((4096 + n_pairs - 1) / n_pairs);         // aim for ~4096 workgroups (8 per CU-slot pair)
+    int slabs = (int)((4096 + n_pairs - 1) / n_pairs);         // aim for ~4096 workgroups
     const int64_t max_by_rows = (n_rows + 63) / 64;              // at least 64 rows per slab
     if (slabs > max_by_rows) slabs = (int)(max_by_rows > 0 ? max_by_rows : 1);
     if (slabs > 64) slabs = 64;
-    return slabs < 1 ? 1 : slabs;
+    slabs = (slabs + 7) / 8 * 8;                                 // one group of slabs per XCD (empty slabs are harmless)
+    return slabs;
 }
 
 hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs, double* C,
