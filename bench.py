@@ -9,8 +9,12 @@ Workload: smq2Q_XYICNOT target model .depolarize(0.01, 0.01), `create_gst_experi
           MapForwardSimulator computes it (mapforwardsim_calc_densitymx.pyx:290-383) -- bit-identical results --
           with the Jacobian left resident in HBM (7.05 GB).  The model arrays are re-uploaded every step, as an
           optimizer iteration does after model.from_vector().
-Multi-GPU: circuits are dealt to `--gpus` atoms (one per rank, contiguous element slices), strong scaling,
-          no data-path collective (the reference's bulk_fill_dprobs leaves rows distributed, too).
+Multi-GPU: the path shards by layout atoms (contiguous runs of circuits), one atom per rank, no data-path
+          collective (the reference's bulk_fill_dprobs leaves rows distributed, too).  `--scaling strong` (default,
+          the mode BASELINE.json's north_star names): the ONE design is dealt to N atoms, total work fixed.
+          `--scaling weak`: every rank's atom is one full design's worth of circuits (the global layout is N
+          designs, as in a bootstrap / multi-dataset GST run where each replica carries its own model estimate --
+          rank r's model is depolarized by 0.01 + 0.001 r), per-GPU work fixed.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (walk_kernel<16,1,*>, fp64 VALU bound);
 `cpu_baseline` times the CPU oracle on a bounded sample on this box's host cores (rank 0, N=1 only).
@@ -30,14 +34,20 @@ F64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (FMA = 2 flop); separate
 HBM_PEAK_GBS = 8000.0
 
 
-def build_workload(design, max_len, world, rank, device, target_tasks, max_slots=0):
+def build_workload(design, max_len, world, rank, device, target_tasks, max_slots=0, scaling="strong"):
     from pygsti_amd import modelpacks
     from pygsti_amd.layout import HipCOPALayout
     pack = modelpacks.smq2Q_XYICNOT
-    model = pack.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
     circuits = pack.create_gst_circuits(max_len, lite=(design == "lite"))
-    layout = HipCOPALayout(circuits, model, num_atoms=world, devices=[device], rank=rank, size=world,
-                           target_tasks=target_tasks, max_slots=max_slots)
+    if scaling == "weak":
+        # rank r owns atom r of an N-design layout: a full design's worth of circuits and its own model estimate
+        model = pack.target_model().depolarize(op_noise=0.01 + 0.001 * rank, spam_noise=0.01)
+        layout = HipCOPALayout(circuits, model, num_atoms=1, devices=[device], rank=0, size=1,
+                               target_tasks=target_tasks, max_slots=max_slots)
+    else:
+        model = pack.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
+        layout = HipCOPALayout(circuits, model, num_atoms=world, devices=[device], rank=rank, size=world,
+                               target_tasks=target_tasks, max_slots=max_slots)
     return pack, model, circuits, layout
 
 
@@ -85,6 +95,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--jtj", action="store_true", help="also time J^T J and J^T f on the resident Jacobian (row f1)")
     ap.add_argument("--gather", action="store_true", help="N>1: also all-gather the probability row blocks (RCCL)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N>1: weak = one full design per rank (N designs in all); strong = one design dealt to N atoms")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="development aid (N=1 only): time rank 0's atom of an N-atom strong-scaling layout on this one "
+                         "GPU; the printed value counts only that atom's elements")
     ap.add_argument("--deriv", default="fd", choices=["fd", "analytic"],
                     help="fd: finite differences, bit-identical to the reference Map path (headline); "
                          "analytic: exact derivatives (MatrixForwardSimulator semantics)")
@@ -118,8 +133,9 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    pack, model, circuits, layout = build_workload(args.design, args.max_len, world, rank, local_rank, args.target_tasks,
-                                                    args.max_slots)
+    lay_world, lay_rank = (args.emulate_ranks, 0) if (world == 1 and args.emulate_ranks > 1) else (world, rank)
+    pack, model, circuits, layout = build_workload(args.design, args.max_len, lay_world, lay_rank, local_rank,
+                                                    args.target_tasks, args.max_slots, args.scaling)
     atom = layout.atoms[0]
     plan = atom.plan()
     gates, rhos, effects = layout.model_arrays(model)
@@ -127,7 +143,10 @@ def main():
     plan.set_param_map(*layout.param_map(model))
     nP = model.num_params
     nE_local = atom.num_elements
-    nE_total = layout.global_num_elements
+    nE_total = layout.global_num_elements * (world if args.scaling == "weak" else 1)
+    if lay_world != world:
+        nE_total = nE_local                       # --emulate-ranks: one atom's share only
+    n_circ_total = len(circuits) * (world if args.scaling == "weak" else 1)
     d_out = plan.device_malloc(nE_local * nP * 8)
     d_probs = plan.device_malloc(nE_local * 8)
     pidx = np.arange(nP, dtype=np.int64)
@@ -206,7 +225,7 @@ def main():
             plan.device_free(d)
 
     gather_ms = None
-    if dist is not None and args.gather:
+    if dist is not None and args.gather and args.scaling == "strong":
         # the reference's `gather_local_array` equivalent: row blocks of the probabilities travel to every rank
         # (RCCL all-gather over xGMI under nccl); the Jacobian stays distributed, as bulk_fill_dprobs leaves it
         import torch
@@ -263,14 +282,17 @@ def main():
             "unit": "Jacobian-elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "smq2Q_XYICNOT GST L<=%d %s germs: %d circuits, nE=%d, nP=%d, D=%d; "
-                                   "target model depolarized 0.01/0.01" % (args.max_len, args.design, len(circuits),
-                                                                           nE_total, nP, D),
+                                   "target model depolarized 0.01/0.01%s" % (
+                                       args.max_len, args.design, len(circuits), layout.global_num_elements, nP, D,
+                                       "" if world == 1 else (" -- x%d designs, one per rank (%d circuits in all)" % (world, n_circ_total)
+                                                              if args.scaling == "weak" else " -- dealt to %d atoms" % world)),
                        "derivative": ("forward finite differences, eps=1e-7 (reference MapForwardSimulator semantics)"
                                       if args.deriv == "fd" else "analytic (reference MatrixForwardSimulator semantics)"),
-                       "parallelism": "atoms%d" % world},
+                       "parallelism": "atoms%d" % world if lay_world == world else
+                                      "rank 0 of atoms%d emulated on one GPU" % lay_world},
             "gather_probs_ms": gather_ms,
             "normal_equations": jtj_info,
             "probs_per_s": nE_total * n_pr / dtp,

@@ -79,6 +79,9 @@ struct gst_plan {
     DevBuf<double> d_base_cache;   // [n_state_ids][D] states of the last base pass
     DevBuf<double> d_pbase, d_out, d_raw, d_dcol, d_probs_tmp;
     DevBuf<int32_t> d_lane[7];   // col, kind0, obj0, elem0, kind1, obj1, elem1
+    DevBuf<uint32_t> d_block_order;     // FD launch order of the cached request (expensive (task, wavefront) pairs first)
+    bool have_block_order = false;
+    std::vector<int32_t> task_cost;     // gst::task_gate_costs, computed at the first FD request
     DevBuf<int32_t> d_wave_row, d_wave_rowidx, d_lane_colidx;
     DevBuf<int32_t> d_node_parent, d_node_sym, d_node_run, d_circ_leaf, d_gate_col0, d_cm_gate, d_cm_rho, d_cm_eff;
     bool graph_uploaded = false;
@@ -109,7 +112,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
-        d_prog.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_prog.release(); d_block_order.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
@@ -206,7 +209,7 @@ void base_args(gst_plan* p, gst::WalkArgs& a)
     a.prog = p->d_prog.p; a.task_off = p->d_task_off.p;
     a.eff_ptr = p->d_eff_ptr.p; a.eff_label = p->d_eff_label.p; a.eff_dest = p->d_eff_dest.p;
     a.gates = p->d_gates.p; a.gates_t = p->d_gates_t.p; a.rhos = p->d_rhos.p; a.effects = p->d_effects.p;
-    a.n_gates = p->hp.n_gates;
+    a.n_gates = p->hp.n_gates; a.n_effects = p->hp.n_effects;
     a.n_pwaves = 1;
 }
 
@@ -312,6 +315,44 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         if ((rc = upload_i32(p->d_lane[1], L.kind[0], p->stream))) return rc;
         if ((rc = upload_i32(p->d_lane[2], L.obj[0], p->stream))) return rc;
         if ((rc = upload_i32(p->d_lane[3], L.elem[0], p->stream))) return rc;
+        // Launch order: longest (task, wavefront) pairs first.  A wavefront's work in a task is set by the objects
+        // its lanes perturb (a gate the task never applies costs almost nothing, a gate of the germ costs the whole
+        // chain), so with only a few pairs per SIMD -- a 1/8 atom of the 2Q design has 4.4 -- the order decides how
+        // long the last SIMD runs.
+        p->have_block_order = false;
+        const int nG = p->hp.n_gates;
+        const int64_t nT = p->hp.n_tasks();
+        if (p->task_cost.empty()) gst::task_gate_costs(p->hp, p->task_cost);
+        if (!p->task_cost.empty() && nT * L.n_waves < 0x7fffffffLL && nT * L.n_waves > 1) {
+            const int stride = nG + 2;
+            std::vector<uint64_t> wave_gates(L.n_waves, 0);
+            std::vector<uint8_t> wave_rho(L.n_waves, 0);
+            for (size_t q = 0; q < L.col.size(); q++) {
+                if (L.col[q] < 0) continue;
+                const size_t w = rows ? q : q / 64;
+                if (L.kind[0][q] == GST_KIND_GATE) wave_gates[w] |= 1ull << L.obj[0][q];
+                else if (L.kind[0][q] == GST_KIND_RHO) wave_rho[w] = 1;
+            }
+            std::vector<std::pair<int32_t, uint32_t>> items;       // (-cost, task * n_waves + pw)
+            items.reserve((size_t)nT * L.n_waves);
+            for (int64_t t = 0; t < nT; t++) {
+                const int32_t* c = p->task_cost.data() + (size_t)t * stride;
+                for (int32_t w = 0; w < L.n_waves; w++) {
+                    int32_t best = c[nG + 1] / 4;
+                    if (wave_rho[w]) best += c[nG];
+                    else
+                        for (uint64_t m = wave_gates[w]; m; m &= m - 1) best = std::max(best, c[nG + 1] / 4 + c[__builtin_ctzll(m)]);
+                    items.emplace_back(-best, (uint32_t)(t * L.n_waves + w));
+                }
+            }
+            std::stable_sort(items.begin(), items.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+            std::vector<uint32_t> order(items.size());
+            for (size_t i = 0; i < items.size(); i++) order[i] = items[i].second;
+            HIP_TRY(p->d_block_order.ensure(order.size()));
+            HIP_TRY(hipMemcpyAsync(p->d_block_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            p->have_block_order = true;
+        }
         HIP_TRY(hipStreamSynchronize(p->stream));       // the host vectors go out of scope
         p->remember_request(1, param_idx, dest_idx, n_param);
         p->cached_n_waves = L.n_waves;
@@ -324,6 +365,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     a.base_cache = p->d_base_cache.p;
     a.lanes.col = p->d_lane[0].p; a.lanes.kind[0] = p->d_lane[1].p; a.lanes.obj[0] = p->d_lane[2].p; a.lanes.elem[0] = p->d_lane[3].p;
     a.n_pwaves = p->cached_n_waves;
+    a.block_order = p->have_block_order ? p->d_block_order.p : nullptr;
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
     if (rows) {
         a.rows_S = 1;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
     // per SIMD fit in the CU's 160 KB.
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    const int64_t bid = blockIdx.x;
+    const int64_t bid = a.block_order ? (int64_t)a.block_order[blockIdx.x] : (int64_t)blockIdx.x;
     const int32_t pw = (int32_t)(bid % a.n_pwaves);
     const int64_t task = bid / a.n_pwaves;
     const int64_t q = (int64_t)pw * 64 + lane;

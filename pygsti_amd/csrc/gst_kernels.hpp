@@ -32,11 +32,12 @@ struct WalkArgs {
     const double* gates_t;   // [nG][D][D] transposed: gates_t[g][j][i] = gates[g][i][j] (column sweeps)
     const double* rhos;
     const double* effects;
-    int32_t n_gates;
+    int32_t n_gates, n_effects;
     const double* base_cache;   // [n_state_ids][D] states of the base pass (read by S>0 passes)
     double* base_cache_w;       // same buffer, written by the S=0 pass at every NODE marker (may be NULL)
     // lanes
     LaneTables lanes;
+    const uint32_t* block_order;   // optional: blockIdx.x -> task * n_pwaves + pw, expensive pairs first (NULL: identity)
     int32_t n_pwaves;        // wavefronts along the parameter dimension (grid.x)
     int32_t rows_S;          // walk_rows_kernel only: number of perturbations per wavefront (0, 1, 2); its
                              // `lanes` tables then hold ONE entry per wavefront instead of one per lane

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void walk_rows_kernel(const WalkArgs a, const i
     const int lane = threadIdx.x;
     const int li = lane < D ? lane : 0;      // idle lanes (D < 64) shadow row 0 and never store
     const bool act = lane < D;
-    const int64_t bid = blockIdx.x;
+    const int64_t bid = a.block_order ? (int64_t)a.block_order[blockIdx.x] : (int64_t)blockIdx.x;
     const int32_t pw = (int32_t)(bid % a.n_pwaves);
     const int64_t task = bid / a.n_pwaves;
     const int S = a.rows_S;
@@ -210,6 +210,201 @@ __global__ __launch_bounds__(64) void walk_rows_kernel(const WalkArgs a, const i
 #undef ROWS_FETCH
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// walk_base_kernel<D> (D = 4, 16): the S = 0 pass -- probabilities and the base-state cache -- on its own.
+// This pass is a pure latency chain (one wavefront per task, ~1,150 dependent mat-vecs at 2Q L<=1024), so the kernel
+// is organised around the length of one chain step (tools/ub_chain.hip measures the pieces):
+//   * every D-lane group of the wavefront carries the SAME state (lane l holds component l % D; identical
+//     arithmetic, so identical bits): v_j reaches all lanes with ONE v_mov_b64_dpp row_newbcast (D = 16) instead of
+//     two v_readlane + an SGPR hazard;
+//   * gates (transposed), effects AND the task's walk program live in LDS (the program in a 2,048-word window that is
+//     refilled half by half); a chain step reads its two program words one step ahead, and the coefficients of the
+//     NEXT mat-vec stream into the registers the current one has just consumed -- the only vector-memory operation of
+//     a step is the 128-byte store of the produced state into the base-state cache, which nothing ever waits for;
+//   * EMITs only park (state, circuit) in an LDS ring; up to 64 parked circuits are evaluated at once, ONE LANE PER
+//     CIRCUIT (each lane walks its circuit's effects and runs the D-term dot product by itself, ascending index from
+//     0.0 like effectcreps.cpp:39-45), so the element-table lookups of 64 circuits overlap instead of costing two
+//     dependent L2 round trips per circuit.
+// Arithmetic contract as everywhere: acc = 0.0; acc = acc + G[i][j] * v[j], ascending j, separate multiply and add.
+template <int D, int J>
+__device__ __forceinline__ double grp_bcast(double x)
+{
+    if constexpr (D == 16) {
+        return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + J, 0xf, 0xf, true);           // row_newbcast:J
+    } else {
+        constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);                          // quad_perm [J,J,J,J]
+        const long long b = __double_as_longlong(x);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), ctrl, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), ctrl, 0xf, 0xf, true);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+}
+// One mat-vec of the chain, phase by phase so that a lone wavefront never issues an instruction that depends on
+// the one just before it except in the final (inherently serial) sum: D broadcasts of v, D products, the D
+// coefficient reads of the NEXT gate into the registers the products just freed, then the ordered sum.
+template <int D, int J>
+__device__ __forceinline__ void bcast_all(double (&bv)[D], const double v)
+{
+    bv[J] = grp_bcast<D, J>(v);
+    if constexpr (J + 1 < D) bcast_all<D, J + 1>(bv, v);
+}
+template <int D>
+__device__ __forceinline__ double matvec_stream(double (&c)[D], const double v, const double* Gn)
+{
+    double bv[D];
+    bcast_all<D, 0>(bv, v);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < D; j++) bv[j] = c[j] * bv[j];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < D; j++) c[j] = Gn[j * D];
+    __builtin_amdgcn_sched_barrier(0);
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; j++) acc = acc + bv[j];
+    __builtin_amdgcn_sched_barrier(0);
+    return acc;
+}
+
+constexpr int BASE_PW = 1024;                // program window (words) in LDS
+constexpr int BASE_ER = 64;                  // emit ring: one lane per parked circuit at evaluation time
+
+// global -> LDS copy by one wavefront, 8 loads in flight per lane (a load-wait-store loop costs one L2 round trip per
+// 64 elements, which at 12 KB of gates + 4 KB of program is tens of microseconds of pure latency per task)
+template <typename T, typename F>
+__device__ __forceinline__ void stage_lds(T* dst, const int total, const int lane, F&& src)
+{
+    for (int base = 0; base < total; base += 64 * 8) {
+        T t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = base + u * 64 + lane;
+            t[u] = (k < total) ? src(k) : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = base + u * 64 + lane;
+            if (k < total) dst[k] = t[u];
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a, const int n_slots)
+{
+    static_assert(D == 4 || D == 16, "group broadcasts are DPP quad / row operations");
+    constexpr int W = BASE_PW, ER = BASE_ER;
+    constexpr int ES = D + 1;                // padded state stride of the emit ring (bank spread for lane-per-circuit reads)
+    extern __shared__ double lds[];          // save slots | effects | gates_t | emit ring | ring circuits | program window
+    const int lane = threadIdx.x;
+    const int li = lane % D, grp = lane / D;
+    const int64_t task = blockIdx.x;
+    double* ldsE = lds + (n_slots > 0 ? n_slots : 1) * D;
+    double* ldsG = ldsE + a.n_effects * D;
+    double* ering = ldsG + a.n_gates * D * D;
+    int32_t* ering_circ = (int32_t*)(ering + ER * ES);
+    uint32_t* ldsP = (uint32_t*)(ering_circ + ER);
+
+    const int64_t pc0 = as_const(a.task_off)[task];
+    const int32_t n_words = (int32_t)(as_const(a.task_off)[task + 1] - pc0);
+    const uint32_t* gprog = a.prog + pc0;
+    stage_lds(ldsP, W, lane, [&](int k) { return (k < n_words) ? gprog[k] : 0u; });
+    stage_lds(ldsG, a.n_gates * D * D, lane, [&](int k) { return a.gates_t[k]; });
+    stage_lds(ldsE, a.n_effects * D, lane, [&](int k) { return a.effects[k]; });
+    __builtin_amdgcn_s_waitcnt(0);           // single-wavefront block: drain, no barrier needed
+    __builtin_amdgcn_wave_barrier();
+
+    double* const cache = a.base_cache_w;
+    int32_t lo = 0;                          // words [lo, lo + W) are resident, word i at ldsP[i % W]
+    int32_t pc = 0;                          // index of the current word
+    int n_er = 0;                            // parked EMITs (wave-uniform)
+
+#define BASE_WORD(i_) ldsP[(i_) & (W - 1)]
+#define BASE_REFILL()                                                                                 \
+    do {                                                                                              \
+        if (pc - lo >= W / 2 + 8) {          /* the half behind pc is dead: bring in the next W/2 words */ \
+            uint32_t* const half_ = ldsP + (lo & (W - 1));   /* lo is a multiple of W/2 */             \
+            const int32_t g0_ = lo + W;                                                               \
+            stage_lds(half_, W / 2, lane, [&](int k_) { return (g0_ + k_ < n_words) ? gprog[g0_ + k_] : 0u; }); \
+            lo += W / 2;                                                                              \
+        }                                                                                             \
+    } while (0)
+#define BASE_STORE_STATE(id_)                                                                         \
+    do {                                                                                              \
+        if (cache && grp == 0) cache[(int64_t)(id_) * D + lane] = v;                                  \
+    } while (0)
+#define BASE_FLUSH_EMITS()                                                                            \
+    do {                                                                                              \
+        if (lane < n_er) {                                                                            \
+            const int32_t circ_ = ering_circ[lane];                                                   \
+            const int32_t x0_ = a.eff_ptr[circ_], x1_ = a.eff_ptr[circ_ + 1];                         \
+            const double* st_ = ering + lane * ES;                                                    \
+            for (int32_t x_ = x0_; x_ < x1_; x_++) {                                                  \
+                const double* E_ = ldsE + a.eff_label[x_] * D;                                        \
+                const int64_t dest_ = a.eff_dest[x_];                                                 \
+                double p_ = 0.0;                                                                      \
+                _Pragma("unroll") for (int i = 0; i < D; i++) p_ = p_ + E_[i] * st_[i];               \
+                a.out[dest_] = p_;                                                                    \
+            }                                                                                         \
+        }                                                                                             \
+        n_er = 0;                                                                                     \
+    } while (0)
+
+    double v = 0.0;
+    uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)BASE_WORD(0));
+    for (;;) {
+        const uint32_t op = GST_OP(w), arg = GST_ARG(w);
+        if (op == GST_OP_END) break;
+        if (op == GST_OP_APPLY) {
+            double c[D];
+            {
+                const double* G0 = ldsG + (int)arg * D * D + li;
+#pragma unroll
+                for (int j = 0; j < D; j++) c[j] = G0[j * D];
+            }
+            uint32_t g = arg;
+            uint32_t p0 = BASE_WORD(pc + 1), p1 = BASE_WORD(pc + 2);   // this step's NODE marker and what follows
+            for (;;) {
+                const int32_t node_id = (int32_t)GST_ARG((uint32_t)__builtin_amdgcn_readfirstlane((int)p0));
+                const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)p1);
+                const bool more = (GST_OP(x) == GST_OP_APPLY);
+                pc += 2;                                                // at `x`
+                p0 = BASE_WORD(pc + 1); p1 = BASE_WORD(pc + 2);         // the next step's pair, one step ahead
+                const double* Gn = ldsG + (int)(more ? GST_ARG(x) : g) * D * D + li;
+                v = matvec_stream<D>(c, v, Gn);
+                BASE_STORE_STATE(node_id);
+                w = x;
+                if (!more) break;
+                g = GST_ARG(x);
+                BASE_REFILL();
+            }
+            continue;                                                  // `w` holds the next instruction, at pc
+        } else if (op == GST_OP_NODE) {
+            BASE_STORE_STATE(arg);
+        } else if (op == GST_OP_EMIT) {
+            if (grp == 0) ering[n_er * ES + lane] = v;
+            if (lane == 0) ering_circ[n_er] = (int32_t)arg;
+            if (++n_er == ER) BASE_FLUSH_EMITS();
+        } else if (op == GST_OP_SAVE) {
+            if (grp == 0) lds[arg * D + lane] = v;
+        } else if (op == GST_OP_LOAD) {
+            v = lds[arg * D + li];
+        } else {  // GST_OP_RHO
+            v = a.rhos[(int64_t)arg * D + li];
+        }
+        pc++;
+        BASE_REFILL();
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)BASE_WORD(pc));
+    }
+    BASE_FLUSH_EMITS();
+#undef BASE_FLUSH_EMITS
+#undef BASE_STORE_STATE
+#undef BASE_REFILL
+#undef BASE_WORD
+}
+
 template <int D>
 static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
 {
@@ -220,6 +415,18 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
     const size_t gate_bytes = (size_t)a.n_gates * D * D * sizeof(double);
     const bool ldsg = (D <= 16) && gate_bytes > 0 && gate_bytes <= 48 * 1024;
     (void)hipGetLastError();
+    if constexpr (D <= 16) {
+        if (ldsg && a.rows_S == 0 && a.n_pwaves == 1 && a.mode == EMIT_PROBS) {
+            // + effects, emit ring (states, circuits), program window
+            const size_t extra = ((size_t)a.n_effects * D + BASE_ER * (D + 1)) * sizeof(double) +
+                                 (BASE_ER + BASE_PW) * sizeof(int32_t);
+            if (lds_bytes + extra + gate_bytes <= 60 * 1024) {
+                hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)blocks), dim3(64), lds_bytes + extra + gate_bytes,
+                                   stream, a, n_slots);
+                return hipGetLastError();
+            }
+        }
+    }
     if (ldsg)
         hipLaunchKernelGGL((walk_rows_kernel<D, true>), dim3((unsigned)blocks), dim3(64), lds_bytes + gate_bytes, stream, a, n_slots);
     else

@@ -298,16 +298,17 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
 
     // --- cut the sorted list into tasks ------------------------------------------------------------
     // A task restarts from rho, so cutting before circuit k re-computes lcp[k]-1 gate applications.
-    // Cut only where that is small against the task being closed (<= 5% of the grain).
+    // Cut only where that is small against the task being closed (<= 5% of its size; the task keeps growing
+    // past the grain until such a place comes, so a small atom of deep germ-power families is still cut between
+    // families instead of collapsing into a few huge tasks).
     if (target_tasks <= 0) target_tasks = 2048;
     const int64_t grain = std::max<int64_t>(32, P.trie_nodes / target_tasks);
-    const int64_t max_restart = std::max<int64_t>(2, grain / 20);
     std::vector<int64_t> cuts{0};
     int64_t cur = 0;
     for (int64_t k = 0; k < nC; k++) {
         const int32_t c = order[k];
         const int64_t L = 1 + (ptr[c + 1] - ptr[c]);
-        if (k > 0 && cur >= grain && lcp[k] - 1 <= max_restart) { cuts.push_back(k); cur = 0; }
+        if (k > 0 && cur >= grain && lcp[k] - 1 <= std::max<int64_t>(2, cur / 20)) { cuts.push_back(k); cur = 0; }
         cur += (cur == 0) ? L : L - lcp[k];
     }
     cuts.push_back(nC);
@@ -355,6 +356,32 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
         P.task_applies.push_back(b.applies);
     }
     return "";
+}
+
+void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost)
+{
+    cost.clear();
+    const int nG = P.n_gates;
+    if (nG > 64) return;
+    const int64_t nT = P.n_tasks();
+    const int stride = nG + 2;
+    cost.assign((size_t)nT * stride, 0);
+    std::vector<uint64_t> slot(64, 0);
+    for (int64_t t = 0; t < nT; t++) {
+        int32_t* c = cost.data() + (size_t)t * stride;
+        uint64_t dirty = 0;                       // bit g: the walk perturbing gate g holds a perturbed state here
+        for (int64_t k = P.task_off[t]; k < P.task_off[t + 1]; k++) {
+            const uint32_t w = P.prog[k], op = GST_OP(w), arg = GST_ARG(w);
+            if (op == GST_OP_APPLY) {
+                dirty |= 1ull << arg;
+                for (uint64_t m = dirty; m; m &= m - 1) c[__builtin_ctzll(m)]++;
+                c[nG]++;
+            } else if (op == GST_OP_SAVE) { if (arg < 64) slot[arg] = dirty; }
+            else if (op == GST_OP_LOAD) { if (arg < 64) dirty = slot[arg]; }
+            else if (op == GST_OP_RHO) dirty = 0;
+            else if (op == GST_OP_EMIT) c[nG + 1]++;
+        }
+    }
 }
 
 }  // namespace gst

@@ -51,4 +51,11 @@ std::string expand_table(HostPlan& P, int32_t n_rows, int32_t cache_size, const 
 // caps the number of save slots a program may use (states beyond it are re-derived by replay).
 std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots);
 
+// Work estimate of a derivative pass per (task, perturbed object): cost[t * (n_gates + 2) + g] = gate applications the
+// walk of task t executes when only gate g is perturbed (states before g's first use are taken from the base-state
+// cache, saved clean states come back clean); column n_gates = a perturbed rho (every application); column
+// n_gates + 1 = the task's EMIT count (what an effect-only wavefront still does).  Used to launch expensive
+// (task, wavefront) pairs first.  Empty result when n_gates > 64.
+void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost);
+
 }  // namespace gst
