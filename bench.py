@@ -192,23 +192,44 @@ def main():
 
     jtj_info = None
     if args.jtj:
-        d_jtj = plan.device_malloc(nP * nP * 8); d_jtf = plan.device_malloc(nP * 8); d_f = plan.device_malloc(nE_local * 8)
-        plan.memcpy_h2d(d_f, np.random.default_rng(0).standard_normal(nE_local))
-        plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj); plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_f, d_jtf)   # warm-up
+        # One Levenberg-Marquardt iteration's worth of data reduction on the resident Jacobian (row f1):
+        # probabilities -> lsvec and dlsvec row scale (Poisson-picture dlogl, synthetic counts N=1000 drawn around the
+        # model's own probabilities) -> J_s^T J_s (split-K MFMA fp64) and J_s^T lsvec (streaming).
+        d_jtj = plan.device_malloc(nP * nP * 8); d_jtf = plan.device_malloc(nP * 8)
+        d_ls = plan.device_malloc(nE_local * 8); d_w = plan.device_malloc(nE_local * 8)
+        d_c = plan.device_malloc(nE_local * 8); d_N = plan.device_malloc(nE_local * 8)
+        pb = plan.memcpy_d2h(np.empty(nE_local), d_probs)
+        rngc = np.random.default_rng(1234 + rank)
+        plan.memcpy_h2d(d_c, rngc.binomial(1000, np.clip(pb, 0.0, 1.0)).astype(np.float64))
+        plan.memcpy_h2d(d_N, np.full(nE_local, 1000.0))
+        obj = plan.objective_rows_dev("logl", d_probs, d_c, d_N, nE_local, d_ls, d_w)                                # warm-up
+        plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj); plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_ls, d_jtf)
         barrier_sync(plan)
         tj = time.perf_counter()
+        for _ in range(10):
+            plan.objective_rows_dev("logl", d_probs, d_c, d_N, nE_local, d_ls, d_w, want_sum=False)
+        barrier_sync(plan)
+        t_obj = (time.perf_counter() - tj) / 10
+        tj = time.perf_counter()
         for _ in range(3):
-            plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj)
+            plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj)      # (row scaling in place is a separate 2-pass stream; timed below)
         barrier_sync(plan)
         t_jtj = (time.perf_counter() - tj) / 3
         tj = time.perf_counter()
         for _ in range(3):
-            plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_f, d_jtf)
+            plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_ls, d_jtf)
         barrier_sync(plan)
         t_jtf = (time.perf_counter() - tj) / 3
-        jtj_info = {"jtj_ms": 1e3 * t_jtj, "jtj_TFLOPs": 2.0 * nE_local * nP * nP / 2 / t_jtj / 1e12,
+        tj = time.perf_counter()
+        plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj, d_w)     # once, with the row scale (J is scaled in place)
+        barrier_sync(plan)
+        t_jtj_scaled = time.perf_counter() - tj
+        jtj_info = {"objective": "Poisson-picture dlogl, min_prob_clip=radius=1e-4", "objective_value": obj,
+                    "objective_rows_ms": 1e3 * t_obj,
+                    "jtj_ms": 1e3 * t_jtj, "jtj_TFLOPs": 2.0 * nE_local * nP * nP / 2 / t_jtj / 1e12,
+                    "jtj_with_row_scale_ms": 1e3 * t_jtj_scaled,
                     "jtf_ms": 1e3 * t_jtf, "jtf_GBps": 8.0 * nE_local * nP / t_jtf / 1e9,
-                    "note": "hand-written split-K MFMA fp64 SYRK / streaming GEMV on the device-resident Jacobian of this rank (flops counted for the triangle: nE*nP^2)"}
+                    "note": "element-wise objective kernel + hand-written split-K MFMA fp64 SYRK / streaming GEMV on the device-resident Jacobian of this rank (flops counted for the triangle: nE*nP^2)"}
         if dist is not None:
             # the path's one real exchange step: every rank holds the partial J^T J of its rows; the optimizer needs
             # the sum -> one all-reduce of nP^2 doubles (RCCL over xGMI under nccl), cf. distlayout.py:1259,1355
@@ -221,7 +242,7 @@ def main():
             barrier_sync(plan)
             jtj_info["allreduce_ms"] = 1e3 * (time.perf_counter() - ta)
             jtj_info["allreduce_MB"] = nP * nP * 8 / 1e6
-        for d in (d_jtj, d_jtf, d_f):
+        for d in (d_jtj, d_jtf, d_ls, d_w, d_c, d_N):
             plan.device_free(d)
 
     gather_ms = None

@@ -169,6 +169,29 @@ int gst_fill_jtf_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t 
                      const double *d_f, double *d_jtf);
 int gst_memcpy_h2d(gst_plan *plan, void *d_dst, const void *src, int64_t nbytes);
 
+/* Element-wise objective maps on device-resident probabilities (row f1): what the reference evaluates with numpy
+ * between bulk_fill_dprobs and fill_jtj -- RawChi2Function / RawPoissonPicDeltaLogLFunction .terms/.lsvec/.dterms
+ * (pygsti/objectivefns/objectivefns.py:1814-1885, 2040-2084, 2944-3160, 3185-3195) combined as
+ * TimeIndependentMDCObjectiveFunction.lsvec / .dlsvec do (:4573-4593, 4633-4665):
+ *   d_lsvec[k]    = sqrt(terms_k) (chi^2: (p-f) sqrt(N/max(p, min_prob_clip)), signed)
+ *   d_rowscale[k] = (|lsvec_k| < 1e-100 ? 0 : 0.5 / lsvec_k) * dterms_k      (the factor of row k of dprobs in dlsvec)
+ *   d_terms[k]    = terms_k (may be NULL);  *sum_terms = sum_k terms_k (may be NULL; blocks until done)
+ * d_probs is clipped in place to [prob_clip_lo, prob_clip_hi] first when prob_clip_lo < prob_clip_hi (_clip_probs
+ * :4766-4774).  d_counts / d_totals are the data set's counts and total counts per element (device, f64).
+ * Feed d_rowscale to gst_fill_jtj_dev and d_lsvec to gst_fill_jtf_dev. */
+#define GST_OBJ_CHI2 0
+#define GST_OBJ_POISSON_DLOGL 1
+typedef struct gst_objective_desc {
+    int32_t kind;            /* GST_OBJ_* */
+    int32_t reserved;
+    double min_prob_clip;    /* chi^2: min_prob_clip_for_weighting; dlogl: min_prob_clip ('minp' regularisation) */
+    double radius;           /* dlogl: zero-frequency radius ("harsh" regularisation) */
+    double prob_clip_lo, prob_clip_hi;
+} gst_objective_desc;
+int gst_objective_rows_dev(gst_plan *plan, const gst_objective_desc *desc, double *d_probs, const double *d_counts,
+                           const double *d_totals, int64_t n, double *d_lsvec, double *d_rowscale, double *d_terms,
+                           double *sum_terms);
+
 /* Plain device-buffer helpers on the plan's device, so that callers without any GPU framework can
  * keep results resident (bench.py, tests).  Buffers from any other allocator work equally. */
 int gst_device_malloc(gst_plan *plan, int64_t nbytes, void **d_ptr);

@@ -16,6 +16,7 @@ GST_OK = 0
 GST_EINVAL, GST_ENODEVICE, GST_EHIP, GST_ENOMEM, GST_ESTATE, GST_EUNSUPPORTED = -1, -2, -3, -4, -5, -6
 KIND_NONE, KIND_GATE, KIND_RHO, KIND_EFFECT = -1, 0, 1, 2
 DERIV_FD, DERIV_ANALYTIC = 0, 1
+OBJ_CHI2, OBJ_POISSON_DLOGL = 0, 1
 
 OP_END, OP_RHO, OP_APPLY, OP_SAVE, OP_LOAD, OP_EMIT, OP_NODE = 0, 1, 2, 3, 4, 5, 6
 
@@ -48,6 +49,11 @@ class Options(C.Structure):
                 ("reserved", C.c_int32 * 5)]
 
 
+class ObjectiveDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("min_prob_clip", C.c_double), ("radius", C.c_double),
+                ("prob_clip_lo", C.c_double), ("prob_clip_hi", C.c_double)]
+
+
 class Stats(C.Structure):
     _fields_ = [("n_circuits", C.c_int64), ("n_elements", C.c_int64), ("sum_depth", C.c_int64),
                 ("trie_nodes", C.c_int64), ("applies_per_pass", C.c_int64), ("n_tasks", C.c_int64),
@@ -58,7 +64,7 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
            "gst_last_error", "gst_version"]
 
 _lib = None
@@ -87,6 +93,7 @@ def lib():
         L.gst_fill_dprobs_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.c_int, dbl, vp]
         L.gst_fill_jtj_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
         L.gst_fill_jtf_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+        L.gst_objective_rows_dev.argtypes = [vp, C.POINTER(ObjectiveDesc), vp, vp, vp, i64, vp, vp, vp, C.POINTER(C.c_double)]
         L.gst_memcpy_h2d.argtypes = [vp, vp, vp, i64]
         L.gst_sync.argtypes = [vp]
         L.gst_device_malloc.argtypes = [vp, i64, C.POINTER(vp)]
@@ -259,6 +266,21 @@ class Plan:
     def fill_jtf_dev(self, d_J, n_rows, n_cols, ld, d_f, d_jtf):
         check(lib().gst_fill_jtf_dev(self._h, C.c_void_p(int(d_J)), int(n_rows), int(n_cols), int(ld),
                                      C.c_void_p(int(d_f)), C.c_void_p(int(d_jtf))))
+
+    def objective_rows_dev(self, kind, d_probs, d_counts, d_totals, n, d_lsvec, d_rowscale, d_terms=None,
+                           min_prob_clip=1e-4, radius=1e-4, prob_clip_interval=None, want_sum=True):
+        """Element-wise objective maps on device probabilities (gst_objective_rows_dev).  kind: 'chi2' | 'logl'.
+        Returns sum(terms) when want_sum (blocks), else None."""
+        k = {"chi2": OBJ_CHI2, "logl": OBJ_POISSON_DLOGL}[kind] if isinstance(kind, str) else int(kind)
+        lo, hi = (0.0, 0.0) if prob_clip_interval is None else (float(prob_clip_interval[0]), float(prob_clip_interval[1]))
+        d = ObjectiveDesc(k, 0, float(min_prob_clip), float(radius), lo, hi)
+        s = C.c_double(0.0)
+        check(lib().gst_objective_rows_dev(self._h, C.byref(d), C.c_void_p(int(d_probs)), C.c_void_p(int(d_counts)),
+                                           C.c_void_p(int(d_totals)), int(n), C.c_void_p(int(d_lsvec)),
+                                           C.c_void_p(int(d_rowscale)),
+                                           None if d_terms is None else C.c_void_p(int(d_terms)),
+                                           C.byref(s) if want_sum else None))
+        return s.value if want_sum else None
 
     def memcpy_h2d(self, d_ptr, arr, offset_bytes=0):
         arr = np.ascontiguousarray(arr)

@@ -79,6 +79,7 @@ struct gst_plan {
     DevBuf<double> d_base_cache;   // [n_state_ids][D] states of the last base pass
     DevBuf<double> d_pbase, d_out, d_raw, d_dcol, d_probs_tmp;
     DevBuf<int32_t> d_lane[7];   // col, kind0, obj0, elem0, kind1, obj1, elem1
+    DevBuf<double> d_obj_part;          // per-block partial sums of the objective terms
     DevBuf<uint32_t> d_block_order;     // FD launch order of the cached request (expensive (task, wavefront) pairs first)
     bool have_block_order = false;
     std::vector<int32_t> task_cost;     // gst::task_gate_costs, computed at the first FD request
@@ -112,7 +113,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
-        d_prog.release(); d_block_order.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
@@ -778,6 +779,33 @@ int gst_fill_jtf_dev(gst_plan* p, const double* d_J, int64_t n_rows, int64_t n_c
     const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n_rows + 255) / 256));
     HIP_TRY(p->d_jtf_part.ensure((size_t)n_slabs * n_cols));
     HIP_TRY(gst::launch_jtf(d_J, d_f, n_rows, (int)n_cols, ld, p->d_jtf_part.p, n_slabs, d_jtf, p->stream));
+    return GST_OK;
+}
+
+int gst_objective_rows_dev(gst_plan* p, const gst_objective_desc* d, double* d_probs, const double* d_counts,
+                           const double* d_totals, int64_t n, double* d_lsvec, double* d_rowscale, double* d_terms,
+                           double* sum_terms)
+{
+    if (!p || !d || !d_probs || !d_counts || !d_totals || !d_lsvec || !d_rowscale || n < 0) return fail(GST_EINVAL, "bad argument");
+    if (d->kind != GST_OBJ_CHI2 && d->kind != GST_OBJ_POISSON_DLOGL) return fail(GST_EINVAL, "unknown objective kind");
+    if (!(d->min_prob_clip > 0.0) || (d->kind == GST_OBJ_POISSON_DLOGL && !(d->radius > 0.0)))
+        return fail(GST_EINVAL, "min_prob_clip and radius must be positive");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    if (sum_terms) *sum_terms = 0.0;
+    if (n == 0) return GST_OK;
+    const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + 255) / 256));
+    HIP_TRY(p->d_obj_part.ensure((size_t)n_blocks));
+    HIP_TRY(gst::launch_objective_rows(d->kind, d_probs, d_counts, d_totals, n, d->min_prob_clip, d->radius, d->prob_clip_lo,
+                                       d->prob_clip_hi, d_lsvec, d_rowscale, d_terms, p->d_obj_part.p, n_blocks, p->stream));
+    if (sum_terms) {
+        std::vector<double> part((size_t)n_blocks);
+        HIP_TRY(hipMemcpyAsync(part.data(), p->d_obj_part.p, part.size() * 8, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        double s = 0.0;
+        for (double x : part) s += x;
+        *sum_terms = s;
+    }
     return GST_OK;
 }
 

@@ -93,6 +93,11 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
 hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs,
                       double* y, hipStream_t s);
 
+// Element-wise objective maps; `part` receives n_blocks partial sums of the terms.
+hipError_t launch_objective_rows(int kind, double* probs, const double* counts, const double* totals, int64_t n, double min_p,
+                                 double radius, double clip_lo, double clip_hi, double* lsvec, double* rowscale,
+                                 double* terms_out, double* part, int n_blocks, hipStream_t s);
+
 // Row-per-lane variant (gst_kernels_rows.hip): one model per wavefront; D = 4, 16 or 64; S = a.rows_S.
 hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 

@@ -137,6 +137,79 @@ __global__ void jtf_reduce_kernel(const double* __restrict__ part, int n_slabs, 
     y[c] = sum;
 }
 
+// Element-wise objective maps (row f1): probabilities -> least-squares vector and the row scale of its Jacobian.
+//   kind 0  chi^2            RawChi2Function.lsvec/dlsvec, _weights/_dweights      objectivefns.py:1814-1885, 2040-2084
+//   kind 1  Poisson dlogl    RawPoissonPicDeltaLogLFunction ('minp', harsh radius) objectivefns.py:2944-3160, 3185-3195
+//   rowscale = (|lsvec| < 1e-100 ? 0 : 0.5 / lsvec) * dterms      TimeIndependentMDCObjectiveFunction.dlsvec :4633-4665
+// Same operation order as the numpy expressions (no contraction), so chi^2 is bit-identical and dlogl differs only by
+// the last bit of log().  Per-block partial sums of `terms` go to `part` (summed on the host in block order).
+__global__ void objective_rows_kernel(int kind, double* __restrict__ probs, const double* __restrict__ counts,
+                                      const double* __restrict__ totals, int64_t n, double min_p, double radius,
+                                      double clip_lo, double clip_hi, double* __restrict__ lsvec,
+                                      double* __restrict__ rowscale, double* __restrict__ terms_out,
+                                      double* __restrict__ part)
+{
+    __shared__ double red[256];
+    double local = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        double p = probs[k];
+        if (clip_lo < clip_hi) {                                   // _clip_probs, objectivefns.py:4766-4774
+            p = p < clip_lo ? clip_lo : (p > clip_hi ? clip_hi : p);
+            probs[k] = p;
+        }
+        const double c = counts[k], N = totals[k];
+        const double f = c / N;
+        double terms, ls, dterms;
+        if (kind == 0) {
+            const double cp = p > min_p ? p : min_p;
+            const double w = sqrt(N / cp);
+            ls = (p - f) * w;
+            const double dw = (p < min_p) ? 0.0 : -0.5 * w / cp;
+            const double dls = w + (p - f) * dw;
+            terms = ls * ls;
+            dterms = 2 * ls * dls;
+        } else {
+            const double fnz = (c == 0) ? 1.0 : f;
+            const double pos = (p < min_p) ? min_p : p;
+            const double c0 = N - c / min_p;
+            const double c1 = 0.5 * c / (min_p * min_p);
+            double t = c * (log(fnz) - 1.0) - c * log(pos) + N * pos;
+            t = t > 0.0 ? t : 0.0;
+            const double dpm = p - min_p;
+            if (p < min_p) t = t + c0 * dpm + c1 * (dpm * dpm);
+            const double a = radius;
+            const double zf = N * (p >= a ? p : (-1.0 / (3 * a * a)) * (p * p * p) + (p * p) / a + a / 3.0);
+            terms = (c == 0) ? zf : t;
+            ls = sqrt(terms);
+            const double d = (p < min_p) ? c0 + 2 * c1 * dpm : N - c / pos;
+            const double dzf = N * (p >= a ? 1.0 : (-1.0 / (a * a)) * (p * p) + 2 * p / a);
+            dterms = (c == 0) ? dzf : d;
+        }
+        const double p5 = (fabs(ls) < 1e-100) ? 0.0 : 0.5 / ls;
+        lsvec[k] = ls;
+        rowscale[k] = p5 * dterms;
+        if (terms_out) terms_out[k] = terms;
+        local += terms;
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+hipError_t launch_objective_rows(int kind, double* probs, const double* counts, const double* totals, int64_t n, double min_p,
+                                 double radius, double clip_lo, double clip_hi, double* lsvec, double* rowscale,
+                                 double* terms_out, double* part, int n_blocks, hipStream_t s)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(objective_rows_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, kind, probs, counts, totals, n, min_p,
+                       radius, clip_lo, clip_hi, lsvec, rowscale, terms_out, part);
+    return hipGetLastError();
+}
+
 int jtj_num_slabs(int64_t n_rows, int n_cols)
 {
     const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;

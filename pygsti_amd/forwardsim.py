@@ -276,6 +276,47 @@ class HipMapForwardSimulator:
                     if d is not None:
                         plan.device_free(d)
 
+    def bulk_fill_lsq_step(self, jtj, jtf, layout, counts, total_counts, objective="logl", min_prob_clip=1e-4,
+                           radius=1e-4, prob_clip_interval=None, lsvec_to_fill=None, pr_array_to_fill=None):
+        """Everything a Levenberg-Marquardt iteration needs from the data, without leaving the GPU: probabilities and
+        Jacobian (bulk_fill_dprobs), the objective's element-wise maps (lsvec and the dlsvec row scale of
+        TimeIndependentMDCObjectiveFunction, pygsti/objectivefns/objectivefns.py:4573-4665, for `objective` = 'chi2'
+        or 'logl'), then J_s^T J_s and J_s^T lsvec (optimize/simplerlm.py:677-678).  `counts` / `total_counts` are
+        per-element host arrays in layout order.  Returns the objective value sum(terms) of this process's atoms;
+        jtj (nP, nP) and jtf (nP,) are summed over them (ranks all-reduce, as layout.fill_jtj does)."""
+        nP = self.model.num_params
+        jtj[...] = 0.0
+        jtf[...] = 0.0
+        mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
+        pidx = np.arange(nP, dtype=np.int64)
+        counts = np.asarray(counts, np.float64)
+        total_counts = np.asarray(total_counts, np.float64)
+        total = 0.0
+        for atom in layout.atoms:
+            plan = self._prepare_atom(atom)
+            nE = atom.num_elements
+            es = atom.element_slice
+            bufs = [plan.device_malloc(max(nb, 8)) for nb in (nE * nP * 8, nE * 8, nE * 8, nE * 8, nE * 8, nE * 8,
+                                                               nP * nP * 8, nP * 8)]
+            d_J, d_pr, d_c, d_N, d_ls, d_w, d_jtj, d_jtf = bufs
+            try:
+                plan.memcpy_h2d(d_c, counts[es]); plan.memcpy_h2d(d_N, total_counts[es])
+                plan.fill_dprobs_dev(d_J, nP, pidx, None, self.derivative_eps, d_pr, mode)
+                total += plan.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius,
+                                                 prob_clip_interval)
+                plan.fill_jtj_dev(d_J, nE, nP, nP, d_jtj, d_w)          # scales the rows of J in place first
+                plan.fill_jtf_dev(d_J, nE, nP, nP, d_ls, d_jtf)
+                part = np.empty((nP, nP)); plan.memcpy_d2h(part, d_jtj); jtj += part
+                pv = np.empty(nP); plan.memcpy_d2h(pv, d_jtf); jtf += pv
+                if lsvec_to_fill is not None:
+                    plan.memcpy_d2h(lsvec_to_fill[es], d_ls)
+                if pr_array_to_fill is not None:
+                    plan.memcpy_d2h(pr_array_to_fill[es], d_pr)
+            finally:
+                for d in bufs:
+                    plan.device_free(d)
+        return total
+
     # -- convenience (forwardsim.py:171-277, 415-582) -------------------------------------------------------------------
     def bulk_probs(self, circuits, clip_to=None, resource_alloc=None, smartc=None):
         layout = self.create_layout(circuits, array_types=("e",))

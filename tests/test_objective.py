@@ -1,0 +1,116 @@
+"""Row f1: element-wise objective maps (chi^2 and Poisson-picture dlogl).  CPU: the numpy restatement against the
+vectors generated from the reference's RawChi2Function / RawPoissonPicDeltaLogLFunction.  GPU: the HIP kernel through
+the C ABI against the same vectors, and the fused probabilities -> lsvec -> J^T J / J^T f step against a numpy
+composition of the separately tested pieces."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_fixture, plan_from_fixture
+from oracle import objective_oracle as OO
+
+VEC = os.path.join(GOLDEN, "objective_vectors.npz")
+NAMES = {OO.CHI2: "chi2", OO.DLOGL: "logl"}
+
+
+def _rel(x, ref):
+    err = np.abs(x - ref) / np.maximum(np.abs(ref), 1e-300)
+    err[x == ref] = 0.0
+    return float(err.max())
+
+
+@pytest.mark.parametrize("kind", [OO.CHI2, OO.DLOGL])
+def test_objective_oracle_matches_reference_vectors(kind):
+    g = np.load(VEC)
+    t, ls, dt, rs = OO.objective_rows(kind, g["probs"], g["counts"], g["total_counts"], float(g["min_prob_clip"]), float(g["radius"]))
+    n = NAMES[kind]
+    if kind == OO.CHI2:            # sqrt and division only: bit-identical
+        for got, key in ((t, "terms"), (ls, "lsvec"), (dt, "dterms"), (rs, "rowscale")):
+            assert np.array_equal(got, g["%s_%s" % (n, key)]), key
+    else:                          # the reference cubes with pow(): last-bit differences
+        for got, key in ((t, "terms"), (ls, "lsvec"), (dt, "dterms"), (rs, "rowscale")):
+            assert _rel(got, g["%s_%s" % (n, key)]) < 1e-15, key
+    # every branch is present in the vectors
+    p, c = g["probs"], g["counts"]
+    assert (c == 0).any() and (p < 1e-4).any() and ((c == 0) & (p < 1e-4)).any() and (ls == 0).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [OO.CHI2, OO.DLOGL])
+def test_gpu_objective_rows_match_reference_vectors(kind):
+    g = np.load(VEC)
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    plan = plan_from_fixture(fx)            # any plan: the call only needs the plan's device and stream
+    n = len(g["probs"])
+    bufs = [plan.device_malloc(n * 8) for _ in range(6)]
+    d_p, d_c, d_N, d_ls, d_w, d_t = bufs
+    try:
+        plan.memcpy_h2d(d_p, g["probs"]); plan.memcpy_h2d(d_c, g["counts"]); plan.memcpy_h2d(d_N, g["total_counts"])
+        total = plan.objective_rows_dev(NAMES[kind], d_p, d_c, d_N, n, d_ls, d_w, d_t, float(g["min_prob_clip"]), float(g["radius"]))
+        ls = plan.memcpy_d2h(np.empty(n), d_ls); w = plan.memcpy_d2h(np.empty(n), d_w); t = plan.memcpy_d2h(np.empty(n), d_t)
+    finally:
+        for b in bufs:
+            plan.device_free(b)
+    nm = NAMES[kind]
+    if kind == OO.CHI2:
+        assert np.array_equal(ls, g[nm + "_lsvec"]) and np.array_equal(t, g[nm + "_terms"])
+        assert np.array_equal(w, g[nm + "_rowscale"])
+    else:
+        # log() on the device is within an ulp of libm's; terms near 0 are differences of O(c) quantities, so the
+        # tolerance is absolute at the scale of the summands (c * log)
+        scale = np.maximum(np.maximum(g["counts"] * 10.0, np.abs(g[nm + "_terms"])), 1.0)
+        assert np.max(np.abs(t - g[nm + "_terms"]) / scale) < 4e-15
+        # lsvec = sqrt(terms): a perturbation dt of terms moves lsvec (and 1/lsvec in the row scale) by dt / (2 terms)
+        # relative -- the conditioning of the reference's own expression near p = f
+        ref_ls = g[nm + "_lsvec"]
+        ok = ref_ls > 1e-6
+        allowed = 4e-15 * scale[ok] / (2 * ref_ls[ok] ** 2) + 4e-15
+        assert np.all(np.abs(ls[ok] - ref_ls[ok]) <= allowed * ref_ls[ok])
+        ref_w = g[nm + "_rowscale"]
+        assert np.all(np.abs(w[ok] - ref_w[ok]) <= allowed * np.abs(ref_w[ok]) + 1e-300)
+    assert abs(total - g[nm + "_terms"].sum()) <= 1e-12 * abs(g[nm + "_terms"].sum())
+    # clip interval: probabilities are clipped in place first (objectivefns.py:4766-4774)
+    d_p2 = plan.device_malloc(n * 8); d_a = plan.device_malloc(n * 8); d_b = plan.device_malloc(n * 8)
+    d_c = plan.device_malloc(n * 8); d_N = plan.device_malloc(n * 8)
+    try:
+        plan.memcpy_h2d(d_p2, g["probs"]); plan.memcpy_h2d(d_c, g["counts"]); plan.memcpy_h2d(d_N, g["total_counts"])
+        plan.objective_rows_dev("chi2", d_p2, d_c, d_N, n, d_a, d_b, None, 1e-4, 1e-4, prob_clip_interval=(1e-3, 0.9))
+        pc = plan.memcpy_d2h(np.empty(n), d_p2); ls = plan.memcpy_d2h(np.empty(n), d_a)
+    finally:
+        for b in (d_p2, d_a, d_b, d_c, d_N):
+            plan.device_free(b)
+    assert np.array_equal(pc, np.clip(g["probs"], 1e-3, 0.9))
+    assert np.array_equal(ls, OO.objective_rows(OO.CHI2, pc, g["counts"], g["total_counts"])[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("objective", ["chi2", "logl"])
+def test_gpu_fused_lsq_step(objective):
+    """probabilities -> lsvec / row scale -> J_s^T J_s, J_s^T lsvec on the device == numpy on the host pieces."""
+    from pygsti_amd import modelpacks
+    from pygsti_amd.forwardsim import HipMapForwardSimulator
+    pack = modelpacks.smq1Q_XYI
+    model = pack.target_model().depolarize(op_noise=0.02, spam_noise=0.01)
+    circuits = pack.create_gst_circuits(16)
+    sim = HipMapForwardSimulator(model)
+    layout = sim.create_layout(circuits, array_types=("ep",))
+    nE, nP = layout.num_elements, model.num_params
+    probs = np.empty(nE); J = np.empty((nE, nP))
+    sim.bulk_fill_dprobs(J, layout, pr_array_to_fill=probs)
+    rng = np.random.default_rng(5)
+    N = np.full(nE, 1000.0)
+    truth = pack.target_model().depolarize(op_noise=0.05, spam_noise=0.02)
+    pt = np.empty(nE); HipMapForwardSimulator(truth).bulk_fill_probs(pt, layout)
+    counts = rng.binomial(1000, np.clip(pt, 0, 1)).astype(np.float64)
+    kind = OO.CHI2 if objective == "chi2" else OO.DLOGL
+    terms, ls, _, w = OO.objective_rows(kind, probs, counts, N)
+    Js = J * w[:, None]
+    jtj = np.empty((nP, nP)); jtf = np.empty(nP); ls_dev = np.empty(nE)
+    total = sim.bulk_fill_lsq_step(jtj, jtf, layout, counts, N, objective=objective, lsvec_to_fill=ls_dev)
+    assert np.allclose(ls_dev, ls, rtol=1e-10, atol=1e-12)
+    assert abs(total - terms.sum()) <= 1e-10 * terms.sum()
+    ref_jtj, ref_jtf = Js.T @ Js, Js.T @ ls
+    assert np.allclose(jtj, ref_jtj, rtol=1e-10, atol=1e-10 * np.abs(ref_jtj).max())
+    assert np.allclose(jtf, ref_jtf, rtol=1e-10, atol=1e-10 * np.abs(ref_jtf).max())
+    assert np.array_equal(jtj, jtj.T)
