@@ -97,7 +97,9 @@ typedef struct {
     int32_t device;          /* HIP device ordinal; -1 = current device */
     int32_t target_tasks;    /* 0 = default; how many independent walk programs to aim for */
     int32_t max_slots;       /* 0 = default; save slots (LDS-resident states) a walk program may use */
-    int32_t reserved[5];
+    int32_t fd_split;        /* 0 = auto; 1, 2 or 4 wavefronts share one (task, 64 columns) pair of the FD Jacobian
+                                (rows of every mat-vec split over them; same results, finer scheduling granularity) */
+    int32_t reserved[4];
 } gst_options;
 
 typedef struct {

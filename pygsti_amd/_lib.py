@@ -46,7 +46,7 @@ class CircuitsDesc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("target_tasks", C.c_int32), ("max_slots", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("fd_split", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class ObjectiveDesc(C.Structure):

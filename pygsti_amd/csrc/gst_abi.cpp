@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -79,6 +80,8 @@ struct gst_plan {
     DevBuf<double> d_base_cache;   // [n_state_ids][D] states of the last base pass
     DevBuf<double> d_pbase, d_out, d_raw, d_dcol, d_probs_tmp;
     DevBuf<int32_t> d_lane[7];   // col, kind0, obj0, elem0, kind1, obj1, elem1
+    int fd_split = 0;                   // gst_options.fd_split: 0 auto, 1 / 2 / 4 wavefronts per (task, 64 columns) pair
+    int n_cus = 256;
     DevBuf<double> d_obj_part;          // per-block partial sums of the objective terms
     DevBuf<uint32_t> d_block_order;     // FD launch order of the cached request (expensive (task, wavefront) pairs first)
     bool have_block_order = false;
@@ -146,6 +149,9 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     std::string err = gst::compile_plan(p->hp, opt ? opt->target_tasks : 0, max_slots);
     if (!err.empty()) { delete p; return fail(GST_EINVAL, err); }
     p->device = opt ? opt->device : -1;
+    p->fd_split = opt ? opt->fd_split : 0;
+    if (const char* e = std::getenv("GST_FD_SPLIT")) p->fd_split = std::atoi(e);     // development override
+    if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
     return GST_OK;
 }
@@ -164,6 +170,7 @@ int ensure_device(gst_plan* p)
     HIP_TRY(hipSetDevice(p->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, p->device));
+    p->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(GST_ENODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -334,16 +341,21 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
                 if (L.kind[0][q] == GST_KIND_GATE) wave_gates[w] |= 1ull << L.obj[0][q];
                 else if (L.kind[0][q] == GST_KIND_RHO) wave_rho[w] = 1;
             }
-            std::vector<std::pair<int32_t, uint32_t>> items;       // (-cost, task * n_waves + pw)
-            items.reserve((size_t)nT * L.n_waves);
+            // D = 64: the launch unit is a group of `grp` consecutive wavefronts (models) of one task
+            const int32_t grp = rows ? gst::rows_group(p->hp.D, p->hp.max_slots) : 1;
+            const int32_t n_units = (L.n_waves + grp - 1) / grp;
+            std::vector<std::pair<int32_t, uint32_t>> items;       // (-cost, task * n_units + unit)
+            items.reserve((size_t)nT * n_units);
             for (int64_t t = 0; t < nT; t++) {
                 const int32_t* c = p->task_cost.data() + (size_t)t * stride;
-                for (int32_t w = 0; w < L.n_waves; w++) {
+                for (int32_t u = 0; u < n_units; u++) {
                     int32_t best = c[nG + 1] / 4;
-                    if (wave_rho[w]) best += c[nG];
-                    else
-                        for (uint64_t m = wave_gates[w]; m; m &= m - 1) best = std::max(best, c[nG + 1] / 4 + c[__builtin_ctzll(m)]);
-                    items.emplace_back(-best, (uint32_t)(t * L.n_waves + w));
+                    for (int32_t w = u * grp; w < std::min<int32_t>((u + 1) * grp, L.n_waves); w++) {
+                        if (wave_rho[w]) best = std::max(best, c[nG + 1] / 4 + c[nG]);
+                        else
+                            for (uint64_t m = wave_gates[w]; m; m &= m - 1) best = std::max(best, c[nG + 1] / 4 + c[__builtin_ctzll(m)]);
+                    }
+                    items.emplace_back(-best, (uint32_t)(t * n_units + u));
                 }
             }
             std::stable_sort(items.begin(), items.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
@@ -371,8 +383,13 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     if (rows) {
         a.rows_S = 1;
         HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
-    } else
-        HIP_TRY(gst::launch_walk(p->hp.D, 1, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
+    } else {
+        // gst_options.fd_split > 1 splits every (task, 64 columns) pair's rows over 2 or 4 wavefronts (walk_kernel's
+        // NW).  Bit-identical, but measured on MI355X it costs 1.35-1.45x the SIMD time per pair (one barrier per gate
+        // application) and that cancels the balance it buys on a 1/8 atom (4.63 vs 4.70 ms), so "auto" is 1.
+        const int split = (p->fd_split == 2 || p->fd_split == 4) && p->hp.D == 16 ? p->fd_split : 1;
+        HIP_TRY(gst::launch_walk(p->hp.D, 1, a, p->hp.n_tasks(), p->hp.max_slots, p->stream, split));
+    }
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     p->last_launches++;
     return GST_OK;

@@ -72,39 +72,59 @@ __device__ __forceinline__ void pin(double (&o)[D])
 // The order is enforced three ways: the wait and the pins are side-effecting (kept in program order),
 // each column's load address passes through a volatile asm (the loads cannot be hoisted above it), and
 // a scheduling barrier keeps the arithmetic behind the loads.
-template <int D, int NS>
-__device__ __forceinline__ void matvec_t(cdouble_p __restrict__ Mt, const double (&v)[D], double (&o)[D],
-                                         const double (&sp)[NS > 0 ? NS : 1][D], double (&r)[NS > 0 ? NS : 1])
+template <int N>
+__device__ __forceinline__ void pin_n(double (&o)[N])
 {
 #pragma unroll
-    for (int i = 0; i < D; i++) o[i] = 0.0;
+    for (int i = 0; i < N; i++) asm volatile("" : "+v"(o[i]));
+}
+
+// RPW < D: the wavefront computes only rows [i0, i0 + RPW) (the state's rows are split over the D/RPW wavefronts of
+// a workgroup, see walk_kernel's NW).  A pipeline stage then covers CPS = D/RPW columns, i.e. the same D
+// coefficients (2*D VALU instructions) per scalar-load round trip as the full-row sweep.
+template <int D, int NS, int RPW = D>
+__device__ __forceinline__ void matvec_t(cdouble_p __restrict__ Mt, const int i0, const double (&v)[D], double (&o)[RPW],
+                                         const double (&sp)[NS > 0 ? NS : 1][D], double (&r)[NS > 0 ? NS : 1])
+{
+    constexpr int CPS = D / RPW;
+#pragma unroll
+    for (int i = 0; i < RPW; i++) o[i] = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; s++) r[s] = 0.0;
-    double cur[D], nxt[D];
-    {
-        cdouble_p p = Mt;
+    double cur[CPS][RPW], nxt[CPS][RPW];
+#pragma unroll
+    for (int c = 0; c < CPS; c++) {
+        cdouble_p p = Mt + c * D + i0;
         asm volatile("" : "+s"(p));
 #pragma unroll
-        for (int i = 0; i < D; i++) cur[i] = p[i];
+        for (int i = 0; i < RPW; i++) cur[c][i] = p[i];
     }
 #pragma unroll
-    for (int j = 0; j < D; j++) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): column j has landed (vmcnt/expcnt untouched)
-        if (j + 1 < D) {
-            cdouble_p p = Mt + (j + 1) * D;
-            asm volatile("" : "+s"(p));
+    for (int j0 = 0; j0 < D; j0 += CPS) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this stage has landed (vmcnt/expcnt untouched)
+        if (j0 + CPS < D) {
 #pragma unroll
-            for (int i = 0; i < D; i++) nxt[i] = p[i];
+            for (int c = 0; c < CPS; c++) {
+                cdouble_p p = Mt + (j0 + CPS + c) * D + i0;
+                asm volatile("" : "+s"(p));
+#pragma unroll
+                for (int i = 0; i < RPW; i++) nxt[c][i] = p[i];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        const double vj = v[j];
 #pragma unroll
-        for (int i = 0; i < D; i++) o[i] = o[i] + cur[i] * vj;
+        for (int c = 0; c < CPS; c++) {
+            const double vj = v[j0 + c];
 #pragma unroll
-        for (int s = 0; s < NS; s++) r[s] = r[s] + sp[s][j] * vj;
-        pin<D>(o);
+            for (int i = 0; i < RPW; i++) o[i] = o[i] + cur[c][i] * vj;
 #pragma unroll
-        for (int i = 0; i < D; i++) cur[i] = nxt[i];
+            for (int s = 0; s < NS; s++) r[s] = r[s] + sp[s][j0 + c] * vj;
+        }
+        if constexpr (RPW == D) pin<D>(o); else pin_n<RPW>(o);
+#pragma unroll
+        for (int c = 0; c < CPS; c++)
+#pragma unroll
+            for (int i = 0; i < RPW; i++) cur[c][i] = nxt[c][i];
     }
 }
 
@@ -126,15 +146,25 @@ __device__ __forceinline__ double dot_r(const double (&r)[D], const double (&v)[
     return acc;
 }
 
-template <int D, int S, int WPS>
-__global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
+// NW > 1 (derivative passes of small atoms): a WORKGROUP of NW wavefronts walks one (task, 64 columns) pair, wavefront
+// w computing rows [w*D/NW, (w+1)*D/NW) of every mat-vec; the rows are exchanged through LDS (one barrier per gate
+// application).  Same arithmetic per row, so same bits; the pair's critical path gets ~NW/1.1 times shorter and the
+// launch has NW times more, smaller pieces -- what a 1/8 atom (4.4 pairs per SIMD) needs to balance.
+constexpr int XPAD = 2;      // exchange-buffer lane stride D + 2 doubles: 16-byte accesses stay bank-conflict free
+
+template <int D, int S, int WPS, int NW = 1>
+__global__ __launch_bounds__(64 * NW, WPS) void walk_kernel(const WalkArgs a)
 {
+    static_assert(NW == 1 || (S == 1 && D % NW == 0), "row splitting is implemented for the single-perturbation passes");
+    constexpr int RPW = D / NW;
     // Save slots (states kept while the children of a branching trie node are walked) live in LDS:
     // slot s, component j, lane l at lds[(s*D + j)*64 + l] -- lane-consecutive 8-byte words, conflict
     // free.  The plan compiler caps the number of slots (gst_options.max_slots) so that 4 wavefronts
     // per SIMD fit in the CU's 160 KB.
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = (NW > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int i0 = wv * RPW;                 // first state row this wavefront computes
     const int64_t bid = a.block_order ? (int64_t)a.block_order[blockIdx.x] : (int64_t)blockIdx.x;
     const int32_t pw = (int32_t)(bid % a.n_pwaves);
     const int64_t task = bid / a.n_pwaves;
@@ -157,9 +187,10 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
     double sp[S1][D];
     int32_t col = (S == 0) ? (lane == 0 ? 0 : -1) : a.lanes.col[q];
     uint64_t gate_mask[S1];
+    uint64_t own_mask[S1];            // NW > 1: gates for which a lane's perturbed row is one of THIS wavefront's rows
     bool eff_any[S1], rho_any[S1];
 #pragma unroll
-    for (int s = 0; s < S1; s++) { kind[s] = GST_KIND_NONE; obj[s] = 0; row[s] = -1; gate_mask[s] = 0; eff_any[s] = false; rho_any[s] = false; }
+    for (int s = 0; s < S1; s++) { kind[s] = GST_KIND_NONE; obj[s] = 0; row[s] = -1; gate_mask[s] = 0; own_mask[s] = 0; eff_any[s] = false; rho_any[s] = false; }
     if (S > 0) {
         int el[S1];
 #pragma unroll
@@ -191,11 +222,15 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
         }
 #pragma unroll
         for (int s = 0; s < S; s++) {
+            const bool own_row = (NW == 1) || (row[s] >= i0 && row[s] < i0 + RPW);
             if (a.n_gates <= 64) {
-                for (int g = 0; g < a.n_gates; g++)
+                for (int g = 0; g < a.n_gates; g++) {
                     if (__ballot(kind[s] == GST_KIND_GATE && obj[s] == g)) gate_mask[s] |= (1ull << g);
+                    if (__ballot(kind[s] == GST_KIND_GATE && obj[s] == g && own_row)) own_mask[s] |= (1ull << g);
+                }
             } else {
                 gate_mask[s] = __ballot(kind[s] == GST_KIND_GATE) ? ~0ull : 0ull;
+                own_mask[s] = __ballot(kind[s] == GST_KIND_GATE && own_row) ? ~0ull : 0ull;
             }
             eff_any[s] = __ballot(kind[s] == GST_KIND_EFFECT) != 0;
             rho_any[s] = __ballot(kind[s] == GST_KIND_RHO) != 0;
@@ -209,6 +244,11 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
         hrowidx = a.wave_rowidx[pw];
         hcolidx = a.lane_colidx[q];
     }
+
+    // LDS: [exchange buffers: 2 x 64 lanes x (D + XPAD), NW > 1 only] [save slots]
+    constexpr int XB = (NW > 1) ? 2 * 64 * (D + XPAD) : 0;
+    double* const slots = lds + XB;
+    int xsel = 0;
 
     double v[D];
     double sp0[1][D];   // placeholder operand of the no-special mat-vec (never read)
@@ -263,6 +303,12 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
         _Pragma("unroll") for (int s_ = 0; s_ < S; s_++)                                              \
             out = out || (((g) < 64) ? ((gate_mask[s_] >> (g)) & 1ull) : (gate_mask[s_] != 0));       \
     } while (0)
+#define GST_HIT_OWN(g, out)                                                                           \
+    do {                                                                                              \
+        out = false;                                                                                  \
+        _Pragma("unroll") for (int s_ = 0; s_ < S; s_++)                                              \
+            out = out || (((g) < 64) ? ((own_mask[s_] >> (g)) & 1ull) : (own_mask[s_] != 0));         \
+    } while (0)
 
     GST_FETCH();
     for (;;) {
@@ -289,24 +335,38 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
             }
             do {
                 bool hit;
-                GST_HIT(arg, hit);
-                double o[D];
+                if constexpr (NW > 1) GST_HIT_OWN(arg, hit); else GST_HIT(arg, hit);
+                double o[RPW];
                 cdouble_p Mt = gates_t + (int64_t)arg * D * D;
-                if (S > 0 && hit) {      // wave-uniform: some lane's parameter lives in this gate
+                if (S > 0 && hit) {      // wave-uniform: some lane's parameter lives in this gate (in one of our rows)
                     double r[S1];
-                    matvec_t<D, S>(Mt, v, o, sp, r);
+                    matvec_t<D, S, RPW>(Mt, i0, v, o, sp, r);
 #pragma unroll
                     for (int s = 0; s < S; s++) {
                         const bool mine = (kind[s] == GST_KIND_GATE) && (obj[s] == (int)arg);
 #pragma unroll
-                        for (int i = 0; i < D; i++) o[i] = (mine && row[s] == i) ? r[s] : o[i];
+                        for (int i = 0; i < RPW; i++) o[i] = (mine && row[s] == i0 + i) ? r[s] : o[i];
                     }
                 } else {
                     double r[1];
-                    matvec_t<D, 0>(Mt, v, o, sp0, r);
+                    matvec_t<D, 0, RPW>(Mt, i0, v, o, sp0, r);
                 }
+                if constexpr (NW == 1) {
 #pragma unroll
-                for (int j = 0; j < D; j++) v[j] = o[j];
+                    for (int j = 0; j < D; j++) v[j] = o[j];
+                } else {
+                    // row exchange: every wavefront publishes its RPW rows, then reads the whole state back
+                    typedef double d2_t __attribute__((ext_vector_type(2)));
+                    double* xb = lds + (xsel * 64 + lane) * (D + XPAD);
+                    d2_t* xw = (d2_t*)__builtin_assume_aligned(xb + i0, 16);
+#pragma unroll
+                    for (int i = 0; i < RPW; i += 2) xw[i / 2] = (d2_t){o[i], o[i + 1]};
+                    __syncthreads();
+                    const d2_t* xr = (const d2_t*)__builtin_assume_aligned(xb, 16);
+#pragma unroll
+                    for (int j = 0; j < D; j += 2) { const d2_t t = xr[j / 2]; v[j] = t.x; v[j + 1] = t.y; }
+                    xsel ^= 1;
+                }
                 GST_FETCH();                             // the NODE marker of the state just produced
                 cur_id = (int32_t)arg;
                 if (S == 0 && cold()->base_cache_w) {
@@ -342,6 +402,7 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
                 for (int j = 0; j < D; j++) v[j] = b[j];
             }
             for (int32_t x = x0; x < x1; x++) {
+                if (NW > 1 && ((x - x0) % NW) != wv) continue;       // the workgroup's wavefronts share out the outcomes
                 const int32_t e = eff_label[x];
                 const int64_t dest = eff_dest[x];
                 if (zero) {                              // (p - p)/eps: exact zeros, no arithmetic
@@ -391,7 +452,7 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
             } else {
 #pragma unroll
                 for (int i = 0; i < MAXSLOT; i++) if (arg == (uint32_t)i) slot_tag[i] = -1;
-                double* sl = lds + (int64_t)arg * D * 64 + lane;
+                double* sl = slots + (int64_t)arg * D * 64 + lane;   // (NW > 1: every wavefront writes the same values)
 #pragma unroll
                 for (int j = 0; j < D; j++) sl[j * 64] = v[j];
             }
@@ -402,7 +463,7 @@ __global__ __launch_bounds__(64, WPS) void walk_kernel(const WalkArgs a)
             if (S > 0 && tag >= 0) {
                 dirty = false; cur_id = tag;
             } else {
-                const double* sl = lds + (int64_t)arg * D * 64 + lane;
+                const double* sl = slots + (int64_t)arg * D * 64 + lane;
 #pragma unroll
                 for (int j = 0; j < D; j++) v[j] = sl[j * 64];
                 dirty = true;
@@ -461,21 +522,23 @@ hipError_t launch_symmetrize(double* C, int64_t n, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int D, int S, int WPS>
+template <int D, int S, int WPS, int NW = 1>
 static hipError_t launch_one(const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
 {
     const int64_t blocks = n_tasks * (int64_t)a.n_pwaves;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const size_t lds_bytes = (size_t)n_slots * D * 64 * sizeof(double);
+    const size_t lds_bytes = ((size_t)n_slots * D * 64 + (NW > 1 ? 2 * 64 * (D + XPAD) : 0)) * sizeof(double);
     if (lds_bytes > 64 * 1024 || n_slots > 4) return hipErrorInvalidValue;   // MAXSLOT tags in the kernel
     (void)hipGetLastError();   // drop any stale sticky error (e.g. an event query) so that we report OUR launch
-    hipLaunchKernelGGL((walk_kernel<D, S, WPS>), dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a);
+    hipLaunchKernelGGL((walk_kernel<D, S, WPS, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
+hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream, int split)
 {
+    if (D == 16 && S == 1 && split == 4) return launch_one<16, 1, 4, 4>(a, n_tasks, n_slots, stream);
+    if (D == 16 && S == 1 && split == 2) return launch_one<16, 1, 4, 2>(a, n_tasks, n_slots, stream);
     if (D == 4) {
         if (S == 0) return launch_one<4, 0, 4>(a, n_tasks, n_slots, stream);
         if (S == 1) return launch_one<4, 1, 4>(a, n_tasks, n_slots, stream);

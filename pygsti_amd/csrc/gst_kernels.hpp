@@ -60,7 +60,7 @@ struct WalkArgs {
 
 // Launch the walk over all tasks x parameter wavefronts.  S = number of specials per lane (0,1,2);
 // n_slots = save slots the programs use (LDS: n_slots * D * 512 bytes per wavefront).
-hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
+hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream, int split = 1);
 
 // Analytic Jacobian (gst_kernels_analytic.hip): one wavefront per circuit walks the state-id graph backwards.
 struct AnaArgs {
@@ -97,6 +97,10 @@ hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_co
 hipError_t launch_objective_rows(int kind, double* probs, const double* counts, const double* totals, int64_t n, double min_p,
                                  double radius, double clip_lo, double clip_hi, double* lsvec, double* rowscale,
                                  double* terms_out, double* part, int n_blocks, hipStream_t s);
+
+// D = 64 derivative passes run NWB = rows_group(D, n_slots) models per workgroup (walk_rows_shared_kernel); a block_order
+// for launch_walk_rows then indexes (task, group of NWB parameter wavefronts) pairs.  1 when not applicable.
+int rows_group(int D, int n_slots);
 
 // Row-per-lane variant (gst_kernels_rows.hip): one model per wavefront; D = 4, 16 or 64; S = a.rows_S.
 hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);

@@ -212,6 +212,193 @@ __global__ __launch_bounds__(64) void walk_rows_kernel(const WalkArgs a, const i
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// walk_rows_shared_kernel<D, NWB>: the derivative passes at D = 64 (S = 1 finite differences, S = 2 Hessian blocks).
+// With one model per wavefront every wavefront used to pull its own copy of each gate (32 KB) through L2 for every
+// gate application: 18 TB/s of L2 traffic and 4.6 TFLOP/s of arithmetic on the 3-qubit configuration.  Here NWB
+// wavefronts -- NWB perturbed models, consecutive parameter columns of ONE task -- form a workgroup that walks the
+// task in lockstep: a gate application stages the transposed gate ONCE in LDS (the next gate's tile is already in
+// flight in registers during the current mat-vec) and every wavefront streams its coefficients from there.
+// Lockstep needs workgroup-uniform control flow, so the clean/dirty bookkeeping runs on the UNION of the wavefronts'
+// perturbed objects: a wavefront may compute a state it could have taken from the base cache, with the unperturbed
+// coefficients and the same operation order -- the same bits.  Arithmetic contract unchanged.
+template <int D, int NWB>
+__global__ __launch_bounds__(64 * NWB) void walk_rows_shared_kernel(const WalkArgs a, const int n_slots)
+{
+    extern __shared__ double lds[];          // gate tile [D][D] (transposed) | save slots [NWB][n_slots][D] | NWB*3 masks
+    constexpr int NT = 64 * NWB;
+    constexpr int TPT = D * D / NT;          // tile elements per thread
+    static_assert(D == 64 && (D * D) % NT == 0, "row-per-lane kernel for three qubits");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t bid = a.block_order ? (int64_t)a.block_order[blockIdx.x] : (int64_t)blockIdx.x;
+    const int32_t n_pblocks = (a.n_pwaves + NWB - 1) / NWB;
+    const int32_t pb = (int32_t)(bid % n_pblocks);
+    const int64_t task = bid / n_pblocks;
+    const bool live = pb * NWB + wv < a.n_pwaves;            // spare wavefronts of the last group shadow its last model
+    const int32_t pw = live ? pb * NWB + wv : a.n_pwaves - 1;
+    const int S = a.rows_S;
+    double* const ldsG = lds;
+    double* const slots = lds + D * D + (size_t)wv * (n_slots > 0 ? n_slots : 1) * D;
+    uint64_t* const msk = (uint64_t*)(lds + D * D + (size_t)NWB * (n_slots > 0 ? n_slots : 1) * D);
+
+    int kind[2] = {GST_KIND_NONE, GST_KIND_NONE}, obj[2] = {0, 0}, row[2] = {-1, -1}, cb[2] = {-1, -1};
+    uint64_t wave_gates = 0;
+    bool wave_rho = false, wave_eff = false;
+    const int32_t col = as_const(a.lanes.col)[pw];
+    for (int s = 0; s < S; s++) {
+        kind[s] = as_const(a.lanes.kind[s])[pw];
+        obj[s] = as_const(a.lanes.obj[s])[pw];
+        const int el = as_const(a.lanes.elem[s])[pw];
+        if (kind[s] == GST_KIND_GATE) { row[s] = el / D; cb[s] = el % D; wave_gates |= (obj[s] < 64) ? (1ull << obj[s]) : ~0ull; }
+        else if (kind[s] == GST_KIND_RHO) { row[s] = el; wave_rho = true; }
+        else if (kind[s] == GST_KIND_EFFECT) { row[s] = el; wave_eff = true; }
+    }
+    int64_t hrow = 0, hrowidx = 0, hcolidx = 0;
+    if (S == 2) { hrow = as_const(a.wave_row)[pw]; hrowidx = as_const(a.wave_rowidx)[pw]; hcolidx = as_const(a.lane_colidx)[pw]; }
+    // workgroup-wide union of the perturbed objects
+    if (lane == 0) { msk[wv] = wave_gates; msk[NWB + wv] = wave_rho ? 1 : 0; msk[2 * NWB + wv] = wave_eff ? 1 : 0; }
+    __syncthreads();
+    uint64_t blk_gates = 0, blk_rho_m = 0, blk_eff_m = 0;
+    for (int w = 0; w < NWB; w++) { blk_gates |= msk[w]; blk_rho_m |= msk[NWB + w]; blk_eff_m |= msk[2 * NWB + w]; }
+    blk_gates = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(blk_gates >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)blk_gates);
+    const bool blk_rho = __builtin_amdgcn_readfirstlane((int)blk_rho_m) != 0;
+    const bool blk_eff = __builtin_amdgcn_readfirstlane((int)blk_eff_m) != 0;
+
+    double v = 0.0;
+    bool dirty = false;
+    int32_t cur_id = 0;
+    int32_t tags = -1;                       // lane s: clean-state id "held" by save slot s (-1: real data in LDS)
+
+    const int64_t pc0 = as_const(a.task_off)[task];
+    const int32_t n_words = (int32_t)(as_const(a.task_off)[task + 1] - pc0);
+    const uint32_t* gprog = a.prog + pc0;
+    int32_t wbase = 0, pc = 0;
+    uint32_t win_cur = (lane < n_words) ? gprog[lane] : 0u;
+    uint32_t win_nxt = (64 + lane < n_words) ? gprog[64 + lane] : 0u;
+    uint32_t op, arg;
+#define SH_FETCH()                                                                                    \
+    do {                                                                                              \
+        if (pc - wbase == 64) {                                                                       \
+            wbase += 64;                                                                              \
+            win_cur = win_nxt;                                                                        \
+            win_nxt = (wbase + 64 + lane < n_words) ? gprog[wbase + 64 + lane] : 0u;                  \
+        }                                                                                             \
+        const uint32_t w_ = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, (int)(pc - wbase));     \
+        op = GST_OP(w_); arg = GST_ARG(w_); pc++;                                                     \
+    } while (0)
+#define SH_BLKHIT(g_) (((g_) < 64) ? ((blk_gates >> (g_)) & 1ull) != 0 : (blk_gates != 0))
+
+    SH_FETCH();
+    for (;;) {
+        if (op == GST_OP_END) break;
+        if (op == GST_OP_APPLY) {
+            if (!dirty) {
+                if (!SH_BLKHIT(arg)) { SH_FETCH(); continue; }             // base state: nothing to compute
+                v = a.base_cache[(int64_t)cur_id * D + lane];              // first perturbed gate: start from the cache
+                dirty = true;
+            }
+            double pre[TPT];
+            {
+                const double* Gt_ = a.gates_t + (int64_t)arg * D * D + tid;
+#pragma unroll
+                for (int k = 0; k < TPT; k++) pre[k] = Gt_[k * NT];
+            }
+            for (;;) {
+                const uint32_t g = arg;
+                __syncthreads();                                           // nobody reads the previous tile any more
+#pragma unroll
+                for (int k = 0; k < TPT; k++) ldsG[tid + k * NT] = pre[k];
+                __syncthreads();
+                SH_FETCH();                                                // the NODE marker of the state being produced
+                const int32_t node_id = (int32_t)arg;
+                SH_FETCH();                                                // what follows
+                const bool more = (op == GST_OP_APPLY);
+                if (more) {                                                // next tile: in flight during this mat-vec
+                    const double* Gt_ = a.gates_t + (int64_t)arg * D * D + tid;
+#pragma unroll
+                    for (int k = 0; k < TPT; k++) pre[k] = Gt_[k * NT];
+                }
+                bool m0 = false, m1 = false;
+                if (S > 0) m0 = kind[0] == GST_KIND_GATE && obj[0] == (int)g && lane == row[0];
+                if (S > 1) m1 = kind[1] == GST_KIND_GATE && obj[1] == (int)g && lane == row[1];
+                const bool any_mine = __builtin_amdgcn_readfirstlane((int)(__ballot(m0 || m1) != 0)) != 0;
+                double acc = 0.0;
+                if (any_mine) {
+#pragma unroll 16
+                    for (int j = 0; j < D; j++) {
+                        double c = ldsG[j * D + lane];
+                        c = (m0 && j == cb[0]) ? c + a.eps : c;            // theta + eps
+                        c = (m1 && j == cb[1]) ? c + a.eps : c;
+                        acc = acc + c * readlane_f64(v, j);
+                    }
+                } else {
+#pragma unroll 16
+                    for (int j = 0; j < D; j++) acc = acc + ldsG[j * D + lane] * readlane_f64(v, j);
+                }
+                v = acc;
+                cur_id = node_id;
+                if (!more) break;
+            }
+            continue;                                                      // `op` already holds the next instruction
+        } else if (op == GST_OP_NODE) {
+            cur_id = (int32_t)arg;
+        } else if (op == GST_OP_EMIT) {
+            const int32_t x0 = as_const(a.eff_ptr)[arg], x1 = as_const(a.eff_ptr)[arg + 1];
+            const bool zero = !dirty && !blk_eff;
+            if (!dirty && blk_eff) v = a.base_cache[(int64_t)cur_id * D + lane];
+            for (int32_t x = x0; x < x1; x++) {
+                const int32_t e = as_const(a.eff_label)[x];
+                const int64_t dest = as_const(a.eff_dest)[x];
+                double p = 0.0;
+                if (!zero) {
+                    double ei = a.effects[(int64_t)e * D + lane];
+                    for (int s = 0; s < S; s++)
+                        if (kind[s] == GST_KIND_EFFECT && obj[s] == e && lane == row[s]) ei = ei + a.eps;
+                    const double prod = ei * v;
+#pragma unroll 16
+                    for (int i = 0; i < D; i++) p = p + readlane_f64(prod, i);
+                }
+                if (lane == 0 && live) {
+                    if (a.mode == EMIT_FD) {
+                        const double pbv = a.pbase[dest];
+                        a.out[dest * a.ld + col] = zero ? 0.0 : (p - pbv) / a.eps;
+                        if (a.raw) a.raw[dest * a.ldraw + col] = zero ? pbv : p;
+                    } else {
+                        if (zero) p = a.pbase[dest];
+                        const double d2 = (p - a.prow[dest * a.ldrow + hrowidx]) / a.eps;
+                        const double d1 = a.dcol[dest * a.lddcol + hcolidx];
+                        a.out[(dest * a.ld + hrow) * a.ld2 + col] = (d2 - d1) / a.eps;
+                    }
+                }
+            }
+        } else if (op == GST_OP_SAVE) {
+            if (!dirty) {
+                tags = (lane == (int)arg) ? cur_id : tags;
+            } else {
+                tags = (lane == (int)arg) ? -1 : tags;
+                slots[arg * D + lane] = v;
+            }
+        } else if (op == GST_OP_LOAD) {
+            const int32_t tag = __builtin_amdgcn_readlane(tags, (int)arg);
+            if (tag >= 0) { dirty = false; cur_id = tag; }
+            else { v = slots[arg * D + lane]; dirty = true; }
+        } else {  // GST_OP_RHO
+            if (!blk_rho) {
+                dirty = false;
+            } else {
+                v = a.rhos[(int64_t)arg * D + lane];
+                for (int s = 0; s < S; s++)
+                    if (kind[s] == GST_KIND_RHO && obj[s] == (int)arg && lane == row[s]) v = v + a.eps;
+                dirty = true;
+            }
+        }
+        SH_FETCH();
+    }
+#undef SH_FETCH
+#undef SH_BLKHIT
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // walk_base_kernel<D> (D = 4, 16): the S = 0 pass -- probabilities and the base-state cache -- on its own.
 // This pass is a pure latency chain (one wavefront per task, ~1,150 dependent mat-vecs at 2Q L<=1024), so the kernel
 // is organised around the length of one chain step (tools/ub_chain.hip measures the pieces):
@@ -268,6 +455,14 @@ __device__ __forceinline__ double matvec_stream(double (&c)[D], const double v, 
     return acc;
 }
 
+constexpr int ROWS_SHARED_NWB = 4;           // wavefronts (models) per workgroup of walk_rows_shared_kernel
+int rows_group(int D, int n_slots)
+{
+    if (D != 64) return 1;
+    const size_t bytes = ((size_t)D * D + (size_t)ROWS_SHARED_NWB * (n_slots > 0 ? n_slots : 1) * D) * sizeof(double) +
+                         3 * ROWS_SHARED_NWB * sizeof(uint64_t);
+    return bytes <= 64 * 1024 ? ROWS_SHARED_NWB : 1;
+}
 constexpr int BASE_PW = 1024;                // program window (words) in LDS
 constexpr int BASE_ER = 64;                  // emit ring: one lane per parked circuit at evaluation time
 
@@ -415,6 +610,15 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
     const size_t gate_bytes = (size_t)a.n_gates * D * D * sizeof(double);
     const bool ldsg = (D <= 16) && gate_bytes > 0 && gate_bytes <= 48 * 1024;
     (void)hipGetLastError();
+    if constexpr (D == 64) {
+        constexpr int NWB = ROWS_SHARED_NWB;
+        const size_t sh_bytes = ((size_t)D * D + (size_t)NWB * (n_slots > 0 ? n_slots : 1) * D) * sizeof(double) + 3 * NWB * sizeof(uint64_t);
+        if (a.rows_S > 0 && a.mode != EMIT_PROBS && rows_group(D, n_slots) > 1) {
+            const int64_t groups = n_tasks * (int64_t)((a.n_pwaves + NWB - 1) / NWB);
+            hipLaunchKernelGGL((walk_rows_shared_kernel<D, NWB>), dim3((unsigned)groups), dim3(64 * NWB), sh_bytes, stream, a, n_slots);
+            return hipGetLastError();
+        }
+    }
     if constexpr (D <= 16) {
         if (ldsg && a.rows_S == 0 && a.n_pwaves == 1 && a.mode == EMIT_PROBS) {
             // + effects, emit ring (states, circuits), program window
@@ -433,6 +637,7 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
         hipLaunchKernelGGL((walk_rows_kernel<D, false>), dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a, n_slots);
     return hipGetLastError();
 }
+
 
 hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
 {

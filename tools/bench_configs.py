@@ -1,0 +1,80 @@
+"""Measure the BASELINE.json configurations other than the bench line (configs[1] 1Q L<=128, configs[4] 3-qubit D=64)
+on one MI355X: probabilities, FD Jacobian, analytic Jacobian (where implemented), one Hessian block.  One JSON line
+per configuration on stdout; the committed copy is profiles/r01_configs.json.   python tools/bench_configs.py"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pygsti_amd import _lib, modelpacks
+from pygsti_amd.layout import HipCOPALayout
+
+
+def timed(fn, plan, reps):
+    fn(); plan.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    plan.sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def one_q():
+    pack = modelpacks.smq1Q_XYI
+    model = pack.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
+    circuits = pack.create_gst_circuits(128)
+    layout = HipCOPALayout(circuits, model, num_atoms=1, devices=[0], rank=0, size=1)
+    plan = layout.atoms[0].plan()
+    plan.set_model(*layout.model_arrays(model)); plan.set_param_map(*layout.param_map(model))
+    nE, nP = layout.num_elements, model.num_params
+    d_J = plan.device_malloc(nE * nP * 8); d_p = plan.device_malloc(nE * 8)
+    pidx = np.arange(nP, dtype=np.int64)
+    t_p = timed(lambda: plan.fill_probs_dev(d_p), plan, 200)
+    t_fd = timed(lambda: plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_FD), plan, 200)
+    t_an = timed(lambda: plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_ANALYTIC), plan, 200)
+    st = plan.stats()
+    return {"config": "smq1Q_XYI L<=128 (BASELINE configs[1]): %d circuits, nE=%d, nP=%d, D=4" % (len(circuits), nE, nP),
+            "probs_us": 1e6 * t_p, "probs_per_s": nE / t_p,
+            "dprobs_fd_us": 1e6 * t_fd, "dprobs_fd_el_per_s": nE * nP / t_fd,
+            "dprobs_analytic_us": 1e6 * t_an, "dprobs_analytic_el_per_s": nE * nP / t_an,
+            "note": "latency-bound: %d tasks, %d gate applications per pass; times include the launch (~10 us each kernel)" % (st["n_tasks"], st["applies_per_pass"])}
+
+
+def three_q(n_circ=400, max_len=256, n_cols=4096):
+    rng = np.random.default_rng(0)
+    D, nG, nEl = 64, 10, 8
+    gates = np.eye(D)[None] + 0.04 * rng.standard_normal((nG, D, D))
+    rhos = np.zeros((1, D)); rhos[0, 0] = 1.0 / np.sqrt(8)
+    effects = 0.1 * rng.standard_normal((nEl, D)); effects[:, 0] += 1.0 / np.sqrt(8)
+    circs = [rng.integers(0, nG, L) for L in rng.integers(1, max_len + 1, n_circ)]
+    ptr = np.zeros(n_circ + 1, np.int64); ptr[1:] = np.cumsum([len(c) for c in circs])
+    g = np.concatenate(circs).astype(np.int32)
+    nE = n_circ * nEl
+    nP = D + nEl * D + nG * D * D
+    kind = np.concatenate([np.full(D, 1), np.full(nEl * D, 2), np.full(nG * D * D, 0)]).astype(np.int32)
+    obj = np.concatenate([np.zeros(D), np.repeat(np.arange(nEl), D), np.repeat(np.arange(nG), D * D)]).astype(np.int32)
+    elem = np.concatenate([np.arange(D), np.tile(np.arange(D), nEl), np.tile(np.arange(D * D), nG)]).astype(np.int32)
+    plan = _lib.Plan.from_circuits(D, nG, 1, nEl, nE, np.zeros(n_circ, np.int32), ptr, g, np.arange(n_circ + 1, dtype=np.int64) * nEl,
+                                   np.tile(np.arange(nEl, dtype=np.int32), n_circ), np.arange(nE, dtype=np.int32))
+    plan.set_model(gates, rhos, effects); plan.set_param_map(kind, obj, elem)
+    d_p = plan.device_malloc(nE * 8)
+    t_p = timed(lambda: plan.fill_probs_dev(d_p), plan, 20)
+    cols = np.arange(576, 576 + n_cols, dtype=np.int64)          # one whole gate's parameters (64 x 64)
+    d_J = plan.device_malloc(nE * n_cols * 8)
+    t_fd = timed(lambda: plan.fill_dprobs_dev(d_J, n_cols, cols, None, 1e-7, d_p, _lib.DERIV_FD), plan, 2)
+    st = plan.stats()
+    i1 = np.arange(576, 576 + 16, dtype=np.int64); i2 = np.arange(576, 576 + 256, dtype=np.int64)
+    t0 = time.perf_counter(); H = plan.fill_hprobs(idx1=i1, idx2=i2, eps=1e-5); t_h = time.perf_counter() - t0
+    flops = n_cols * 2.0 * D * D * st["applies_per_pass"]
+    return {"config": "3-qubit explicit dense model (BASELINE configs[4] shape): D=64, 10 gates, 8 outcomes, nP=%d; %d seeded random circuits, "
+                      "lengths 1..%d, nE=%d" % (nP, n_circ, max_len, nE),
+            "probs_ms": 1e3 * t_p, "probs_per_s": nE / t_p,
+            "dprobs_fd_cols": int(n_cols), "dprobs_fd_ms": 1e3 * t_fd, "dprobs_fd_el_per_s": nE * n_cols / t_fd,
+            "dprobs_fd_kernel_ms": st["last_kernel_ms"], "dprobs_fd_TFLOPs_algorithmic": flops / t_fd / 1e12,
+            "hprobs_block": "16 x 256", "hprobs_ms_incl_d2h": 1e3 * t_h, "hprobs_el_per_s": nE * 16 * 256 / t_h,
+            "applies_per_pass": st["applies_per_pass"], "n_tasks": st["n_tasks"],
+            "note": "bit-exact FD on the row-per-lane kernel (one perturbed model per wavefront, v_readlane broadcasts); no MFMA: "
+                    "separate multiply/add is required for parity with the reference Map path"}
+
+
+if __name__ == "__main__":
+    print(json.dumps(one_q()))
+    print(json.dumps(three_q()))
