@@ -142,9 +142,10 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
         delete p;
         return fail(GST_EUNSUPPORTED, "state dimension " + std::to_string(D) + " not supported (4, 16 or 64)");
     }
-    // D = 64 runs on the row-per-lane kernel only (a slot is 512 bytes): generous budget.
-    // D <= 16: the lane-per-model kernel keeps slots in LDS at 8*D*64 bytes each and tracks at most 4.
-    if (max_slots <= 0) max_slots = (p->hp.D == 64) ? 8 : (p->hp.D == 16) ? 1 : 4;
+    // D = 64: the register-blocked derivative kernel keeps save slots in registers and tracks 2 (plans that ask for
+    // more run on the LDS-slot kernels).  D <= 16: the lane-per-model kernel keeps slots in LDS at 8*D*64 bytes each
+    // and tracks at most 4.
+    if (max_slots <= 0) max_slots = (p->hp.D == 64) ? 2 : (p->hp.D == 16) ? 1 : 4;
     max_slots = std::min(max_slots, p->hp.D == 64 ? 32 : 4);
     std::string err = gst::compile_plan(p->hp, opt ? opt->target_tasks : 0, max_slots);
     if (!err.empty()) { delete p; return fail(GST_EINVAL, err); }

@@ -399,6 +399,322 @@ __global__ __launch_bounds__(64 * NWB) void walk_rows_shared_kernel(const WalkAr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// walk_quad64_kernel<K, NWB>: the derivative passes at D = 64, register-blocked.  A wavefront carries 4*K perturbed
+// models: DPP row m (16 lanes) of "set" k is model 4k + m, and lane i of that row holds the four state components
+// i, 16+i, 32+i, 48+i of it (v[k][0..3]) and computes the same four rows of every mat-vec.  Then
+//   * v_j reaches the 16 lanes of its model with ONE v_mov_b64_dpp row_newbcast (no v_readlane pairs, no SGPR hazard);
+//   * a coefficient G[16c+i][j] read from the LDS tile (one 32-byte read per lane and column: the tile is stored
+//     [j][i][c]) serves all 4*K models of the wavefront, and the tile itself (32 KB, staged once per gate application,
+//     next one prefetched in registers) serves the NWB wavefronts of the workgroup: 9 VALU instructions per 4 rows x 4
+//     models and column instead of 16 x (2 v_readlane + mul + add);
+//   * a model's ONE perturbed row (the reference's `full` parameterisation: one element of one dense object) is redone
+//     on its own after the sweep, with the perturbed coefficient in place, in the same ascending-j order (this is the
+//     "special row" of gst_kernels.hip), only for applications of the perturbed gate;
+//   * save slots live in registers (4 components per lane and model); at most QUAD_MAXSLOT of them.
+// Lockstep across the workgroup (the tile barriers) runs on the union of the perturbed objects, as in
+// walk_rows_shared_kernel.  Arithmetic contract unchanged: acc = 0.0; acc = acc + G[r][j] * v[j], ascending j.
+constexpr int QUAD_MAXSLOT = 2;
+constexpr int QUAD_K = 4;
+constexpr int QUAD_NWB = 4;
+
+template <int J>
+__device__ __forceinline__ double bcast16(double x)      // element J of every 16-lane row to the whole row
+{
+    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + J, 0xf, 0xf, true);
+}
+
+template <int K, int J>
+struct QuadOps {
+    // column J of the sweep: 4 rows x 4*K models
+    static __device__ __forceinline__ void sweep(const double* __restrict__ tile_lane, const double (&v)[K][4], double (&acc)[K][4])
+    {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t* tp = (const d2_t*)__builtin_assume_aligned(tile_lane + J * 64, 16);
+        const d2_t c01 = tp[0], c23 = tp[1];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const double b = bcast16<J & 15>(v[k][J >> 4]);
+            acc[k][0] = acc[k][0] + c01.x * b;
+            acc[k][1] = acc[k][1] + c01.y * b;
+            acc[k][2] = acc[k][2] + c23.x * b;
+            acc[k][3] = acc[k][3] + c23.y * b;
+        }
+        if constexpr (J + 1 < 64) QuadOps<K, J + 1>::sweep(tile_lane, v, acc);
+    }
+    // one row redone with up to two perturbed coefficients: r = sum_j (G[row][j] (+eps at j == cb0) (+eps at j == cb1)) v_j
+    static __device__ __forceinline__ double special(const double* __restrict__ row_ptr, const double (&vk)[4], int cb0, int cb1,
+                                                     double eps, double r)
+    {
+        double c = row_ptr[J * 64];
+        c = (J == cb0) ? c + eps : c;
+        c = (J == cb1) ? c + eps : c;
+        r = r + c * bcast16<J & 15>(vk[J >> 4]);
+        if constexpr (J + 1 < 64) return QuadOps<K, J + 1>::special(row_ptr, vk, cb0, cb1, eps, r);
+        else return r;
+    }
+    // ordered sum of the 64 products of an effect dot (component 16q + i in prod[q] of lane i)
+    static __device__ __forceinline__ double dot(const double (&prod)[4], double p)
+    {
+        p = p + bcast16<J & 15>(prod[J >> 4]);
+        if constexpr (J + 1 < 64) return QuadOps<K, J + 1>::dot(prod, p);
+        else return p;
+    }
+};
+
+template <int K, int NWB>
+__global__ __launch_bounds__(64 * NWB, 2) void walk_quad64_kernel(const WalkArgs a)
+{
+    constexpr int D = 64, NT = 64 * NWB, TPT = D * D / NT, MPW = 4 * K, MPB = MPW * NWB;
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // tile [j][i][c] = G[16c+i][j] | 3*NWB masks
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lm = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t bid = a.block_order ? (int64_t)a.block_order[blockIdx.x] : (int64_t)blockIdx.x;
+    const int32_t n_models = a.n_pwaves;                       // the lane tables hold one entry per model
+    const int32_t n_pblocks = (n_models + MPB - 1) / MPB;
+    const int32_t pb = (int32_t)(bid % n_pblocks);
+    const int64_t task = bid / n_pblocks;
+    const int S = a.rows_S;
+    double* const tile = lds;
+    const double* const tile_lane = tile + li * 4;
+    uint64_t* const msk = (uint64_t*)(lds + D * D);
+
+    // ---- per lane: the model of each set, its perturbation(s) -----------------------------------------------------
+    bool live[K];
+    int32_t col[K];
+    int kind[K][2], obj[K][2], prow[K][2], pcb[K][2];
+    int64_t hrow[K], hrowidx[K], hcolidx[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int32_t M_ = (pb * NWB + wv) * MPW + k * 4 + lm;
+        live[k] = M_ < n_models;
+        const int32_t M = live[k] ? M_ : n_models - 1;         // spare models shadow the last one, never store
+        col[k] = a.lanes.col[M];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            kind[k][s] = GST_KIND_NONE; obj[k][s] = 0; prow[k][s] = -1; pcb[k][s] = -1;
+            if (s < S) {
+                kind[k][s] = a.lanes.kind[s][M];
+                obj[k][s] = a.lanes.obj[s][M];
+                const int el = a.lanes.elem[s][M];
+                if (kind[k][s] == GST_KIND_GATE) { prow[k][s] = el / D; pcb[k][s] = el % D; }
+                else if (kind[k][s] == GST_KIND_RHO || kind[k][s] == GST_KIND_EFFECT) prow[k][s] = el;
+            }
+        }
+        hrow[k] = hrowidx[k] = hcolidx[k] = 0;
+        if (S == 2) { hrow[k] = a.wave_row[M]; hrowidx[k] = a.wave_rowidx[M]; hcolidx[k] = a.lane_colidx[M]; }
+    }
+    uint64_t wave_gates = 0;
+    bool wave_rho = false, wave_eff = false;
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (a.n_gates <= 64) {
+                for (int g = 0; g < a.n_gates; g++)
+                    if (__ballot(kind[k][s] == GST_KIND_GATE && obj[k][s] == g)) wave_gates |= (1ull << g);
+            } else if (__ballot(kind[k][s] == GST_KIND_GATE)) wave_gates = ~0ull;
+            wave_rho = wave_rho || __ballot(kind[k][s] == GST_KIND_RHO) != 0;
+            wave_eff = wave_eff || __ballot(kind[k][s] == GST_KIND_EFFECT) != 0;
+        }
+    if (lane == 0) { msk[wv] = wave_gates; msk[NWB + wv] = wave_rho ? 1 : 0; msk[2 * NWB + wv] = wave_eff ? 1 : 0; }
+    __syncthreads();
+    uint64_t blk_gates = 0, blk_rho_m = 0, blk_eff_m = 0;
+    for (int w = 0; w < NWB; w++) { blk_gates |= msk[w]; blk_rho_m |= msk[NWB + w]; blk_eff_m |= msk[2 * NWB + w]; }
+    blk_gates = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(blk_gates >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)blk_gates);
+    const bool blk_rho = __builtin_amdgcn_readfirstlane((int)blk_rho_m) != 0;
+    const bool blk_eff = __builtin_amdgcn_readfirstlane((int)blk_eff_m) != 0;
+
+    double v[K][4];
+    double sv[QUAD_MAXSLOT][K][4];
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) { v[k][q] = 0.0; sv[0][k][q] = 0.0; sv[1][k][q] = 0.0; }
+    int32_t slot_tag[QUAD_MAXSLOT] = {-1, -1};
+    bool dirty = false;
+    int32_t cur_id = 0;
+
+    const int64_t pc0 = as_const(a.task_off)[task];
+    const int32_t n_words = (int32_t)(as_const(a.task_off)[task + 1] - pc0);
+    const uint32_t* gprog = a.prog + pc0;
+    int32_t wbase = 0, pc = 0;
+    uint32_t win_cur = (lane < n_words) ? gprog[lane] : 0u;
+    uint32_t win_nxt = (64 + lane < n_words) ? gprog[64 + lane] : 0u;
+    uint32_t op, arg;
+#define Q_FETCH()                                                                                     \
+    do {                                                                                              \
+        if (pc - wbase == 64) {                                                                       \
+            wbase += 64;                                                                              \
+            win_cur = win_nxt;                                                                        \
+            win_nxt = (wbase + 64 + lane < n_words) ? gprog[wbase + 64 + lane] : 0u;                  \
+        }                                                                                             \
+        const uint32_t w_ = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, (int)(pc - wbase));     \
+        op = GST_OP(w_); arg = GST_ARG(w_); pc++;                                                     \
+    } while (0)
+#define Q_BLKHIT(g_) (((g_) < 64) ? ((blk_gates >> (g_)) & 1ull) != 0 : (blk_gates != 0))
+#define Q_FROM_CACHE()                                                                                \
+    do {                                                                                              \
+        const double* b_ = a.base_cache + (int64_t)cur_id * D + li;                                   \
+        const double b0_ = b_[0], b1_ = b_[16], b2_ = b_[32], b3_ = b_[48];                           \
+        _Pragma("unroll") for (int k = 0; k < K; k++) { v[k][0] = b0_; v[k][1] = b1_; v[k][2] = b2_; v[k][3] = b3_; } \
+    } while (0)
+    // tile element e (row-major in gates_t: e = j*64 + r, value G[r][j]) goes to [j][r & 15][r >> 4]
+#define Q_TILE_POS(e_) (((e_) & ~63) | ((((e_) & 15)) << 2) | (((e_) >> 4) & 3))
+
+    Q_FETCH();
+    for (;;) {
+        if (op == GST_OP_END) break;
+        if (op == GST_OP_APPLY) {
+            if (!dirty) {
+                if (!Q_BLKHIT(arg)) { Q_FETCH(); continue; }               // base state: nothing to compute
+                Q_FROM_CACHE();                                            // first perturbed gate: start from the cache
+                dirty = true;
+            }
+            double pre[TPT];
+            {
+                const double* Gt_ = a.gates_t + (int64_t)arg * D * D + tid;
+#pragma unroll
+                for (int t = 0; t < TPT; t++) pre[t] = Gt_[t * NT];
+            }
+            for (;;) {
+                const uint32_t g = arg;
+                __syncthreads();                                           // nobody reads the previous tile any more
+#pragma unroll
+                for (int t = 0; t < TPT; t++) { const int e = tid + t * NT; tile[Q_TILE_POS(e)] = pre[t]; }
+                __syncthreads();
+                Q_FETCH();                                                 // the NODE marker of the state being produced
+                const int32_t node_id = (int32_t)arg;
+                Q_FETCH();                                                 // what follows
+                const bool more = (op == GST_OP_APPLY);
+                if (more) {                                                // next tile: in flight during this mat-vec
+                    const double* Gt_ = a.gates_t + (int64_t)arg * D * D + tid;
+#pragma unroll
+                    for (int t = 0; t < TPT; t++) pre[t] = Gt_[t * NT];
+                }
+                double acc[K][4];
+#pragma unroll
+                for (int k = 0; k < K; k++) { acc[k][0] = 0.0; acc[k][1] = 0.0; acc[k][2] = 0.0; acc[k][3] = 0.0; }
+                QuadOps<K, 0>::sweep(tile_lane, v, acc);
+                // special rows: the perturbed row of every model whose perturbed gate this is
+                const bool wave_hit = (g < 64) ? ((wave_gates >> g) & 1ull) != 0 : (wave_gates != 0);
+                if (wave_hit) {
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        for (int s = 0; s < S; s++) {
+                            const bool tgt = kind[k][s] == GST_KIND_GATE && obj[k][s] == (int)g;
+                            if (!__builtin_amdgcn_readfirstlane((int)(__ballot(tgt) != 0))) continue;
+                            const int r_ = tgt ? prow[k][s] : 0;           // every lane of the model's row group helps
+                            // all perturbations of this model that sit in the same row of this gate, in order
+                            const int cb0 = (kind[k][0] == GST_KIND_GATE && obj[k][0] == (int)g && prow[k][0] == r_) ? pcb[k][0] : -1;
+                            const int cb1 = (S > 1 && kind[k][1] == GST_KIND_GATE && obj[k][1] == (int)g && prow[k][1] == r_) ? pcb[k][1] : -1;
+                            const double* row_ptr = tile + (r_ & 15) * 4 + (r_ >> 4);      // + j*64: G[r_][j]
+                            const double r = QuadOps<K, 0>::special(row_ptr, v[k], cb0, cb1, a.eps, 0.0);
+                            const bool put = tgt && li == (r_ & 15);
+#pragma unroll
+                            for (int c = 0; c < 4; c++) acc[k][c] = (put && c == (r_ >> 4)) ? r : acc[k][c];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < K; k++) { v[k][0] = acc[k][0]; v[k][1] = acc[k][1]; v[k][2] = acc[k][2]; v[k][3] = acc[k][3]; }
+                cur_id = node_id;
+                if (!more) break;
+            }
+            continue;                                                      // `op` already holds the next instruction
+        } else if (op == GST_OP_NODE) {
+            cur_id = (int32_t)arg;
+        } else if (op == GST_OP_EMIT) {
+            const int32_t x0 = as_const(a.eff_ptr)[arg], x1 = as_const(a.eff_ptr)[arg + 1];
+            const bool zero = !dirty && !blk_eff;
+            if (!dirty && blk_eff) Q_FROM_CACHE();
+            for (int32_t x = x0; x < x1; x++) {
+                const int32_t e = as_const(a.eff_label)[x];
+                const int64_t dest = as_const(a.eff_dest)[x];
+                double Ev[4];
+                if (!zero) {
+                    const double* E_ = a.effects + (int64_t)e * D + li;
+                    Ev[0] = E_[0]; Ev[1] = E_[16]; Ev[2] = E_[32]; Ev[3] = E_[48];
+                }
+                const double pbv = a.pbase[dest];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    double p = 0.0;
+                    if (!zero) {
+                        double prod[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            double ei = Ev[q];
+                            for (int s = 0; s < S; s++)
+                                if (kind[k][s] == GST_KIND_EFFECT && obj[k][s] == e && prow[k][s] == 16 * q + li) ei = ei + a.eps;
+                            prod[q] = ei * v[k][q];
+                        }
+                        p = QuadOps<K, 0>::dot(prod, 0.0);
+                    }
+                    if (li == 0 && live[k]) {
+                        if (a.mode == EMIT_FD) {
+                            a.out[dest * a.ld + col[k]] = zero ? 0.0 : (p - pbv) / a.eps;
+                            if (a.raw) a.raw[dest * a.ldraw + col[k]] = zero ? pbv : p;
+                        } else {
+                            if (zero) p = pbv;
+                            const double d2 = (p - a.prow[dest * a.ldrow + hrowidx[k]]) / a.eps;
+                            const double d1 = a.dcol[dest * a.lddcol + hcolidx[k]];
+                            a.out[(dest * a.ld + hrow[k]) * a.ld2 + col[k]] = (d2 - d1) / a.eps;
+                        }
+                    }
+                }
+            }
+        } else if (op == GST_OP_SAVE) {
+#pragma unroll
+            for (int i = 0; i < QUAD_MAXSLOT; i++) {
+                if (arg == (uint32_t)i) {
+                    if (!dirty) slot_tag[i] = cur_id;
+                    else {
+                        slot_tag[i] = -1;
+#pragma unroll
+                        for (int k = 0; k < K; k++) { sv[i][k][0] = v[k][0]; sv[i][k][1] = v[k][1]; sv[i][k][2] = v[k][2]; sv[i][k][3] = v[k][3]; }
+                    }
+                }
+            }
+        } else if (op == GST_OP_LOAD) {
+#pragma unroll
+            for (int i = 0; i < QUAD_MAXSLOT; i++) {
+                if (arg == (uint32_t)i) {
+                    if (slot_tag[i] >= 0) { dirty = false; cur_id = slot_tag[i]; }
+                    else {
+#pragma unroll
+                        for (int k = 0; k < K; k++) { v[k][0] = sv[i][k][0]; v[k][1] = sv[i][k][1]; v[k][2] = sv[i][k][2]; v[k][3] = sv[i][k][3]; }
+                        dirty = true;
+                    }
+                }
+            }
+        } else {  // GST_OP_RHO
+            if (!blk_rho) {
+                dirty = false;
+            } else {
+                const double* r_ = a.rhos + (int64_t)arg * D + li;
+                const double r0 = r_[0], r1 = r_[16], r2 = r_[32], r3 = r_[48];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    v[k][0] = r0; v[k][1] = r1; v[k][2] = r2; v[k][3] = r3;
+                    for (int s = 0; s < S; s++) {
+                        if (kind[k][s] == GST_KIND_RHO && obj[k][s] == (int)arg && (prow[k][s] & 15) == li) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) v[k][q] = ((prow[k][s] >> 4) == q) ? v[k][q] + a.eps : v[k][q];
+                        }
+                    }
+                }
+                dirty = true;
+            }
+        }
+        Q_FETCH();
+    }
+#undef Q_TILE_POS
+#undef Q_FROM_CACHE
+#undef Q_BLKHIT
+#undef Q_FETCH
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // walk_base_kernel<D> (D = 4, 16): the S = 0 pass -- probabilities and the base-state cache -- on its own.
 // This pass is a pure latency chain (one wavefront per task, ~1,150 dependent mat-vecs at 2Q L<=1024), so the kernel
 // is organised around the length of one chain step (tools/ub_chain.hip measures the pieces):
@@ -459,6 +775,7 @@ constexpr int ROWS_SHARED_NWB = 4;           // wavefronts (models) per workgrou
 int rows_group(int D, int n_slots)
 {
     if (D != 64) return 1;
+    if (n_slots <= QUAD_MAXSLOT) return 4 * QUAD_K * QUAD_NWB;          // walk_quad64_kernel: models per workgroup
     const size_t bytes = ((size_t)D * D + (size_t)ROWS_SHARED_NWB * (n_slots > 0 ? n_slots : 1) * D) * sizeof(double) +
                          3 * ROWS_SHARED_NWB * sizeof(uint64_t);
     return bytes <= 64 * 1024 ? ROWS_SHARED_NWB : 1;
@@ -613,6 +930,12 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
     if constexpr (D == 64) {
         constexpr int NWB = ROWS_SHARED_NWB;
         const size_t sh_bytes = ((size_t)D * D + (size_t)NWB * (n_slots > 0 ? n_slots : 1) * D) * sizeof(double) + 3 * NWB * sizeof(uint64_t);
+        if (a.rows_S > 0 && a.mode != EMIT_PROBS && n_slots <= QUAD_MAXSLOT) {
+            const size_t q_bytes = (size_t)D * D * sizeof(double) + 3 * QUAD_NWB * sizeof(uint64_t);
+            const int64_t groups = n_tasks * (int64_t)((a.n_pwaves + 4 * QUAD_K * QUAD_NWB - 1) / (4 * QUAD_K * QUAD_NWB));
+            hipLaunchKernelGGL((walk_quad64_kernel<QUAD_K, QUAD_NWB>), dim3((unsigned)groups), dim3(64 * QUAD_NWB), q_bytes, stream, a);
+            return hipGetLastError();
+        }
         if (a.rows_S > 0 && a.mode != EMIT_PROBS && rows_group(D, n_slots) > 1) {
             const int64_t groups = n_tasks * (int64_t)((a.n_pwaves + NWB - 1) / NWB);
             hipLaunchKernelGGL((walk_rows_shared_kernel<D, NWB>), dim3((unsigned)groups), dim3(64 * NWB), sh_bytes, stream, a, n_slots);
