@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="N>1: also all-gather the probability row blocks (RCCL)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1: weak = one full design per rank (N designs in all); strong = one design dealt to N atoms")
+    ap.add_argument("--no-analytic", action="store_true", help="skip the secondary analytic-derivative timing")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="development aid (N=1 only): time rank 0's atom of an N-atom strong-scaling layout on this one "
                          "GPU; the printed value counts only that atom's elements")
@@ -190,6 +191,30 @@ def main():
     barrier_sync(plan)
     dtp = time.perf_counter() - tp0
 
+    # secondary: the same Jacobian by analytic derivatives (MatrixForwardSimulator semantics, <= 1e-8 vs that simulator)
+    ana_info = None
+    if args.deriv == "fd" and not args.no_analytic:
+        for _ in range(2):
+            plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
+        barrier_sync(plan)
+        ta0 = time.perf_counter()
+        n_an = max(3, args.steps)
+        for _ in range(n_an):
+            plan.set_model(gates, rhos, effects)
+            plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
+        barrier_sync(plan)
+        dta = time.perf_counter() - ta0
+        if dist is not None:
+            import torch
+            tt = torch.tensor([dta], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dta = float(tt.item())
+        ana_info = {"value": nE_total * nP * n_an / dta, "unit": "Jacobian-elements/s", "ms_per_step": 1e3 * dta / n_an,
+                    "kernel_ms": plan.stats()["last_kernel_ms"],
+                    "note": "analytic derivatives (reference MatrixForwardSimulator semantics); secondary figure, not `value`"}
+        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the FD Jacobian resident for --jtj
+        barrier_sync(plan)
+
     jtj_info = None
     if args.jtj:
         # One Levenberg-Marquardt iteration's worth of data reduction on the resident Jacobian (row f1):
@@ -268,7 +293,7 @@ def main():
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
         (profiles/r01_hbm_counters.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; KB -> bytes, and
         FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md).  None when no profile matches."""
-        if world != 1 or args.design != "full" or args.max_len != 1024:
+        if world != 1 or lay_world != 1 or args.design != "full" or args.max_len != 1024:
             return None
         try:
             with open(os.path.join(ROOT, "profiles", "r01_hbm_counters.json")) as f:
@@ -316,12 +341,13 @@ def main():
                                       "rank 0 of atoms%d emulated on one GPU" % lay_world},
             "gather_probs_ms": gather_ms,
             "normal_equations": jtj_info,
+            "analytic_dprobs": ana_info,
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,
             "roofline": roof or {"bound": "valu_f64", "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
                          "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (k_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
-                         "note": "separate v_mul_f64+v_add_f64 (no FMA, required for bitwise parity) caps this kernel at 0.5 of the FMA peak",
+                         "note": "flops = the reference schedule's nP*(2*D^2*A + 2*D*nE); the kernel executes ~0.56 of them (the rest is provably bit-identical to the base pass) as separate v_mul_f64+v_add_f64 (no FMA: bitwise parity), whose own ceiling is 0.5 of the FMA peak; VALU issue utilisation 93% (profiles/r01_bench_pmc_sq_current.json)",
                          "kernel_ms": k_ms, "flops_per_launch": flops,
                          "hbm_write_GBps": jac_bytes / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
                          "traffic": measured_traffic("walk_kernel<16, 1")},
