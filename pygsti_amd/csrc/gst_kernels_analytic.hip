@@ -35,11 +35,15 @@ __device__ __forceinline__ const GST_CONST T* as_const(const T* p) { return (con
 template <int D, int SRC>
 __device__ __forceinline__ double row_bcast(double x)
 {
-    constexpr int ctrl = (D == 16) ? (0x150 + SRC) : (SRC | (SRC << 2) | (SRC << 4) | (SRC << 6));
-    const long long b = __double_as_longlong(x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), ctrl, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), ctrl, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    if constexpr (D == 16) {
+        return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + SRC, 0xf, 0xf, true);     // one v_mov_b64_dpp row_newbcast
+    } else {
+        constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+        const long long b = __double_as_longlong(x);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), ctrl, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), ctrl, 0xf, 0xf, true);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
 }
 
 // One backward step for the D-lane group of an outcome.  Lane b holds B[b] and F_{k-1}[b]:

@@ -9,7 +9,7 @@ from pygsti_amd import _lib
 pytestmark = pytest.mark.gpu
 
 
-def _make(n_circ=60, max_len=256, seed=0):
+def _make(n_circ=60, max_len=256, seed=0, max_slots=0):
     rng = np.random.default_rng(seed)
     D, nG, nEl = 64, 10, 8
     gates = np.eye(D)[None] + 0.04 * rng.standard_normal((nG, D, D))
@@ -21,6 +21,10 @@ def _make(n_circ=60, max_len=256, seed=0):
     # some shared prefixes so that the trie / save slots are exercised
     for k in range(3, n_circ, 4):
         circs[k] = np.concatenate([circs[k - 1][:len(circs[k - 1]) // 2], circs[k][:8]])
+    # a balanced binary tree of prefixes, 4 levels deep: walking it needs a save slot per level
+    seg = [[np.concatenate([[2 * lvl + b], rng.integers(0, nG, 3)]) for b in (0, 1)] for lvl in range(4)]
+    for leaf in range(16):
+        circs[4 + leaf] = np.concatenate([seg[lvl][(leaf >> lvl) & 1] for lvl in range(4)])
     ptr = np.zeros(n_circ + 1, np.int64); ptr[1:] = np.cumsum([len(c) for c in circs])
     g = np.concatenate(circs).astype(np.int32)
     nE = n_circ * nEl
@@ -32,7 +36,8 @@ def _make(n_circ=60, max_len=256, seed=0):
     obj = np.concatenate([np.zeros(D), np.repeat(np.arange(nEl), D), np.repeat(np.arange(nG), D * D)]).astype(np.int32)
     elem = np.concatenate([np.arange(D), np.tile(np.arange(D), nEl), np.tile(np.arange(D * D), nG)]).astype(np.int32)
     assert nP == 41536
-    pl = _lib.Plan.from_circuits(D, nG, 1, nEl, nE, np.zeros(n_circ, np.int32), ptr, g, eff_ptr, eff_label, eff_dest)
+    pl = _lib.Plan.from_circuits(D, nG, 1, nEl, nE, np.zeros(n_circ, np.int32), ptr, g, eff_ptr, eff_label, eff_dest,
+                                 max_slots=max_slots)
     pl.set_model(gates, rhos, effects)
     pl.set_param_map(kind, obj, elem)
     tbl = dict(D=D, nE=nE, cache_size=0, t_dest=np.arange(n_circ), t_start=-np.ones(n_circ), t_cache=-np.ones(n_circ),
@@ -41,8 +46,13 @@ def _make(n_circ=60, max_len=256, seed=0):
     return pl, tbl, mdl, nP
 
 
-def test_3q_probs_dprobs_hprobs_vs_oracle(oracle_built):
-    pl, tbl, mdl, nP = _make()
+@pytest.mark.parametrize("max_slots", [0, 8])
+def test_3q_probs_dprobs_hprobs_vs_oracle(oracle_built, max_slots):
+    """max_slots=0 (default, <= 2 slots): the register-blocked walk_quad64_kernel; max_slots=8: plans that use more
+    save slots run on walk_rows_shared_kernel (LDS slots).  Both bit-identical to the oracle."""
+    pl, tbl, mdl, nP = _make(max_slots=max_slots)
+    if max_slots == 8:
+        assert pl.stats()["max_slots"] > 2, "the fixture must exercise the LDS-slot kernel"
     orc = oracle_built.Oracle(tbl, mdl)
     assert_bitwise(pl.fill_probs(), orc.probs(), "3Q probs")
     rng = np.random.default_rng(5)

@@ -31,6 +31,16 @@ def test_dprobs_fd_bitwise_vs_reference(name):
     assert_bitwise(J, fx['dprobs_map'], "dprobs " + name)
 
 
+@pytest.mark.parametrize("fd_split", [2, 4])
+def test_dprobs_fd_row_split_variants_bitwise(fd_split):
+    """gst_options.fd_split: the rows of every mat-vec split over 2 / 4 wavefronts with an LDS exchange -- same bits."""
+    for name in ("smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep"):
+        fx = load_fixture(name)
+        pl = plan_from_fixture(fx, fd_split=fd_split)
+        J = pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']))
+        assert_bitwise(J, fx['dprobs_map'], "dprobs fd_split=%d %s" % (fd_split, name))
+
+
 def test_dprobs_column_window_and_dest_indices():
     """dest_param_slice semantics (distforwardsim.py:130-144): fill a column window of a wider 'ep' array."""
     fx = load_fixture("smq1Q_XYI_L4_depol")
