@@ -314,10 +314,11 @@ def main():
         flops = nP * (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local)
         jac_bytes = 8.0 * nE_local * nP
         if args.deriv == "analytic":
-            roof = {"bound": "hbm", "kernel": "analytic_dprobs_kernel<16,6>", "achieved": jac_bytes / (k_ms * 1e-3) / 1e9,
+            roof = {"bound": "hbm", "kernel": "analytic_mfma_kernel (+ the backward chain pass that feeds it)",
+                    "achieved": jac_bytes / (k_ms * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "note": "algorithmic bytes = the Jacobian write 8*nE*nP; the kernel also re-reads forward states (L2/MALL)",
-                    "kernel_ms": k_ms, "bytes_per_launch": jac_bytes, "traffic": measured_traffic("analytic_dprobs_kernel")}
+                    "note": "algorithmic bytes = the Jacobian write 8*nE*nP; the kernel gathers forward and backward state vectors (20 GB of L2 traffic, of which the PMC `traffic` figure is what reaches HBM)",
+                    "kernel_ms": k_ms, "bytes_per_launch": jac_bytes, "traffic": measured_traffic("analytic_mfma_kernel")}
         else:
             roof = None
         out = {

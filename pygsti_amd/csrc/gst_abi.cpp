@@ -80,6 +80,15 @@ struct gst_plan {
     DevBuf<double> d_base_cache;   // [n_state_ids][D] states of the last base pass
     DevBuf<double> d_pbase, d_out, d_raw, d_dcol, d_probs_tmp;
     DevBuf<int32_t> d_lane[7];   // col, kind0, obj0, elem0, kind1, obj1, elem1
+    // analytic mode, MFMA path (D = 16): plan of the reversed circuits, backward-state cache, pair tables
+    gst::HostPlan rev;
+    bool rev_ready = false;
+    DevBuf<uint32_t> d_rprog;
+    DevBuf<int64_t> d_rtask_off, d_pos_ptr;
+    DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order;
+    DevBuf<double> d_rev_cache;
+    DevBuf<uint32_t> d_work_counter, d_range_begin;
+    bool ana_mfma = true;               // D = 16 analytic mode on the MFMA path (GST_ANALYTIC_MFMA=0: the VALU kernel)
     int fd_split = 0;                   // gst_options.fd_split: 0 auto, 1 / 2 / 4 wavefronts per (task, 64 columns) pair
     int n_cus = 256;
     DevBuf<double> d_obj_part;          // per-block partial sums of the objective terms
@@ -116,7 +125,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
-        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
@@ -152,6 +161,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     p->device = opt ? opt->device : -1;
     p->fd_split = opt ? opt->fd_split : 0;
     if (const char* e = std::getenv("GST_FD_SPLIT")) p->fd_split = std::atoi(e);     // development override
+    if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
     return GST_OK;
@@ -396,6 +406,63 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     return GST_OK;
 }
 
+// Analytic mode, D = 16: reversed plan + pair tables, built and uploaded once per plan.
+int ensure_reverse(gst_plan* p)
+{
+    if (p->rev_ready) return GST_OK;
+    const gst::HostPlan& h = p->hp;
+    std::string err = gst::build_reverse_plan(h, p->rev, 0, h.D == 16 ? 1 : 4);
+    if (!err.empty()) return fail(GST_EINVAL, "reversed plan: " + err);
+    if (p->rev.max_slots > 4) return fail(GST_EUNSUPPORTED, "reversed plan needs too many save slots");
+    std::vector<int32_t> pf, pr;
+    std::vector<int64_t> pos_ptr;
+    gst::build_pair_tables(h, p->rev, pf, pr, pos_ptr);
+    HIP_TRY(p->d_rprog.ensure(p->rev.prog.size() + 64));
+    HIP_TRY(hipMemsetAsync(p->d_rprog.p, 0, (p->rev.prog.size() + 64) * 4, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_rprog.p, p->rev.prog.data(), p->rev.prog.size() * 4, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p->d_rtask_off.ensure(p->rev.task_off.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_rtask_off.p, p->rev.task_off.data(), p->rev.task_off.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p->d_pos_ptr.ensure(pos_ptr.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_pos_ptr.p, pos_ptr.data(), pos_ptr.size() * 8, hipMemcpyHostToDevice, p->stream));
+    int rc;
+    std::vector<int32_t> zeros((size_t)h.n_circuits + 1, 0);
+    if ((rc = upload_i32(p->d_reff_ptr, zeros, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_rev_leaf, p->rev.circ_leaf, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_pair_f, pf, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_pair_r, pr, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_circ_rho, h.circ_rho, p->stream))) return rc;
+    std::vector<int32_t> order((size_t)h.n_circuits);
+    for (int64_t c = 0; c < h.n_circuits; c++) order[(size_t)c] = (int32_t)c;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->rev.circ_leaf[x] < p->rev.circ_leaf[y]; });
+    if ((rc = upload_i32(p->d_circ_order, order, p->stream))) return rc;
+    // 8 contiguous ranges of the ordered list with equal numbers of gate applications (+ a constant per circuit)
+    std::vector<uint32_t> range_begin(9, 0);
+    {
+        double total = 0;
+        for (int64_t c = 0; c < h.n_circuits; c++) total += (double)(h.circ_ptr[c + 1] - h.circ_ptr[c]) + 24.0;
+        double acc = 0;
+        int r = 1;
+        for (int64_t k = 0; k < h.n_circuits && r < 8; k++) {
+            const int32_t c = order[(size_t)k];
+            acc += (double)(h.circ_ptr[c + 1] - h.circ_ptr[c]) + 24.0;
+            while (r < 8 && acc >= total * r / 8.0) range_begin[r++] = (uint32_t)(k + 1);
+        }
+        for (; r < 8; r++) range_begin[r] = (uint32_t)h.n_circuits;
+        range_begin[8] = (uint32_t)h.n_circuits;
+    }
+    HIP_TRY(p->d_range_begin.ensure(9));
+    HIP_TRY(hipMemcpyAsync(p->d_range_begin.p, range_begin.data(), 9 * 4, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(p->d_work_counter.ensure(8));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    // (the host copies of the reversed programs are not needed any more)
+    p->rev.prog.clear(); p->rev.prog.shrink_to_fit();
+    p->rev.node_parent.clear(); p->rev.node_parent.shrink_to_fit();
+    p->rev.node_sym.clear(); p->rev.node_sym.shrink_to_fit();
+    p->rev_ready = true;
+    return GST_OK;
+}
+
 // Exact Jacobian columns (GST_DERIV_ANALYTIC) into device memory.
 int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
                         int64_t n_param, double* d_probs_out)
@@ -462,6 +529,35 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     a.n_gates = h.n_gates; a.n_rhos = h.n_rhos; a.n_effects = h.n_effects;
     a.gate_col0 = p->d_gate_col0.p; a.colmap_gate = p->d_cm_gate.p; a.colmap_rho = p->d_cm_rho.p; a.colmap_eff = p->d_cm_eff.p;
     a.out = d_out; a.ld = ld;
+    if (D == 16 && p->ana_mfma) {
+        if ((rc = ensure_reverse(p))) return rc;
+        // backward states: the chain kernel over the reversed plan, transposed gates (= the row-major array), one lane
+        // group per effect (64/D effects per pass)
+        gst::WalkArgs w;
+        std::memset(&w, 0, sizeof(w));
+        w.prog = p->d_rprog.p; w.task_off = p->d_rtask_off.p;
+        w.eff_ptr = p->d_reff_ptr.p; w.eff_label = p->d_reff_ptr.p; w.eff_dest = p->d_reff_ptr.p;
+        w.gates = p->d_gates_t.p; w.gates_t = p->d_gates.p;          // (G^T)^T = G: the roles of the two layouts swap
+        w.rhos = p->d_effects.p; w.effects = p->d_effects.p;
+        w.n_gates = h.n_gates; w.n_effects = 0;
+        w.n_pwaves = 1; w.rows_S = 0; w.mode = gst::EMIT_PROBS; w.out = p->d_pbase.p;
+        HIP_TRY(p->d_rev_cache.ensure((size_t)p->rev.n_state_ids * h.n_effects * D));
+        w.base_cache_w = p->d_rev_cache.p;
+        w.multi_start = h.n_effects;
+        HIP_TRY(hipEventRecord(p->evk0, p->stream));
+        for (int e0 = 0; e0 < h.n_effects; e0 += 64 / D) {
+            w.start0 = e0;
+            HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream));
+            p->last_launches++;
+        }
+        a.rev_cache = p->d_rev_cache.p; a.rev_leaf = p->d_rev_leaf.p; a.pair_f = p->d_pair_f.p; a.pair_r = p->d_pair_r.p;
+        a.pos_ptr = p->d_pos_ptr.p; a.circ_rho = p->d_circ_rho.p; a.circ_order = p->d_circ_order.p; a.work_counter = p->d_work_counter.p; a.range_begin = p->d_range_begin.p;
+        HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
+        HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+        HIP_TRY(hipEventRecord(p->evk1, p->stream));
+        p->last_launches++;
+        return GST_OK;
+    }
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
     HIP_TRY(gst::launch_analytic(D, a, p->stream));
     HIP_TRY(hipEventRecord(p->evk1, p->stream));

@@ -37,6 +37,8 @@ struct WalkArgs {
     double* base_cache_w;       // same buffer, written by the S=0 pass at every NODE marker (may be NULL)
     // lanes
     LaneTables lanes;
+    int32_t multi_start, start0;   // walk_base_kernel only: > 0 = walk from `multi_start` start vectors (rhos[]), lane group q
+                                   // from rhos[start0 + q], states stored at base_cache_w[id][start0 + q][D]
     const uint32_t* block_order;   // optional: blockIdx.x -> task * n_pwaves + pw, expensive pairs first (NULL: identity)
     int32_t n_pwaves;        // wavefronts along the parameter dimension (grid.x)
     int32_t rows_S;          // walk_rows_kernel only: number of perturbations per wavefront (0, 1, 2); its
@@ -82,8 +84,19 @@ struct AnaArgs {
     const int32_t* colmap_eff;    // [nEl*D]
     double* out;
     int64_t ld;
+    // MFMA path (D = 16): backward states of the reversed plan, pair tables, dynamic work counter
+    const double* rev_cache;      // [n_rev_states][n_effects][D]
+    const int32_t* rev_leaf;      // [n_circuits] state id of B_0 in the reversed plan
+    const int32_t* pair_f;        // state id of F_{k-1}
+    const int32_t* pair_r;        // state id of B_k
+    const int64_t* pos_ptr;       // [n_circuits * n_gates + 1]
+    const int32_t* circ_rho;      // [n_circuits]
+    const int32_t* circ_order;    // [n_circuits] circuits sorted by their reversed string (= by rev_leaf)
+    const uint32_t* range_begin;  // [9] the suffix-ordered list cut into 8 ranges of equal work (one per XCD)
+    uint32_t* work_counter;       // [8] one per range, zeroed before the launch
 };
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
+hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream);   // D = 16
 
 hipError_t launch_scale_rows(double* J, int64_t n_rows, int64_t n_cols, int64_t ld, const double* w, hipStream_t s);
 hipError_t launch_symmetrize(double* C, int64_t n, hipStream_t s);

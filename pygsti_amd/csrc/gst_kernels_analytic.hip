@@ -200,6 +200,139 @@ __global__ __launch_bounds__(256, WPS) void analytic_dprobs_kernel(const AnaArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// analytic_mfma_kernel (D = 16): exact Jacobian rows from BOTH state caches on the matrix cores.
+//   dp/dG_g[a][b] = sum over the applications k of gate g in the circuit of  B_k[a] * F_{k-1}[b]
+// with F the forward states (base pass over the prefix trie) and B_k = (G_n ... G_{k+1})^T E the backward states
+// (the same chain kernel run over the SUFFIX trie of the reversed circuits with the transposed gates, one lane group
+// per effect).  Nothing is propagated here: for a circuit, an outcome and a gate the 16 x 16 block is a
+// [16 x n_k] x [n_k x 16] product over that gate's applications, i.e. n_k / 4 v_mfma_f64_16x16x4_f64 whose operands
+// are 128-byte state vectors gathered by the host-built pair tables (pair_f / pair_r, grouped by circuit and gate):
+// the A operand wants lane l to hold B_{k(l>>4)}[l&15], the B operand F_{k(l>>4)-1}[l&15] -- both are straight
+// coalesced reads of cache lines, no LDS, no transposition.  One F gather feeds the blocks of 4 outcomes.
+// A wavefront takes circuits from a shared counter (depths range from 1 to 1030) and writes whole 16-column row
+// segments of the Jacobian (D-matrix layout: lane l, register r -> row (l>>4) + 4r, column l&15).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int ANA_MFMA_M = 4;      // chunks of 4 gate applications per block of loads
+
+__global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
+{
+    constexpr int D = 16, NX = 4;
+    const int lane = threadIdx.x & 63;
+    const int kk = lane >> 4, i = lane & 15;
+    const int nE = a.n_effects, nG = a.n_gates;
+    // Work distribution: the suffix-ordered circuit list is cut into 8 contiguous ranges of equal work, one per XCD
+    // (workgroup b runs on XCD b % 8 -- observed dispatch rule, used for locality only): neighbours in that order share
+    // their backward chains and, over a longer stretch, the forward chains of their germ, so both stay in that XCD's
+    // 4 MB L2 instead of being pulled from HBM by all eight.  A wavefront that finds its range empty helps the next.
+    const int xcd = blockIdx.x & 7;
+    for (int probe = 0; probe < 8;) {
+        const int rg = (xcd + probe) & 7;
+        const uint32_t r_begin = as_const(a.range_begin)[rg], r_end = as_const(a.range_begin)[rg + 1];
+        uint32_t cu = 0;
+        if (lane == 0) cu = atomicAdd(a.work_counter + rg, 1u);
+        const int64_t ci = (int64_t)r_begin + (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
+        if (ci >= (int64_t)r_end) { probe++; continue; }
+        const int64_t c = as_const(a.circ_order)[ci];
+        const int32_t x0 = as_const(a.eff_ptr)[c], x1 = as_const(a.eff_ptr)[c + 1];
+        const int32_t fleaf = as_const(a.circ_leaf)[c], rleaf = as_const(a.rev_leaf)[c], rsym = as_const(a.circ_rho)[c];
+        for (int32_t xb = x0; xb < x1; xb += NX) {
+            const int nx = (x1 - xb < NX) ? (x1 - xb) : NX;
+            // lane group kk looks after outcome xb + kk for the SPAM columns; the gate blocks need all NX labels uniform
+            const bool on = kk < nx;
+            const int32_t e_l = a.eff_label[on ? xb + kk : x0];
+            const int64_t dest_l = a.eff_dest[on ? xb + kk : x0];
+            int32_t e_u[NX];
+            int64_t dest_u[NX];
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                e_u[x] = __builtin_amdgcn_readlane(e_l, 16 * x);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(dest_l & 0xffffffffLL), 16 * x);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(dest_l >> 32), 16 * x);
+                dest_u[x] = (int64_t)(((uint64_t)hi << 32) | lo);
+            }
+            if (on) {
+                // dp/dE[a] = F_n[a] for the outcome's own effect, exact zeros for the others; dp/drho[b] = B_0[b]
+                const double FL = a.base_cache[(int64_t)fleaf * D + i];
+                for (int e2 = 0; e2 < nE; e2++) {
+                    const int32_t ce = a.colmap_eff[e2 * D + i];
+                    if (ce >= 0) a.out[dest_l * a.ld + ce] = (e2 == e_l) ? FL : 0.0;
+                }
+                const double B0 = a.rev_cache[((int64_t)rleaf * nE + e_l) * D + i];
+                for (int r2 = 0; r2 < a.n_rhos; r2++) {
+                    const int32_t cr = a.colmap_rho[r2 * D + i];
+                    if (cr >= 0) a.out[dest_l * a.ld + cr] = (r2 == rsym) ? B0 : 0.0;
+                }
+            }
+            for (int g = 0; g < nG; g++) {
+                const int32_t c0 = as_const(a.gate_col0)[g];
+                if (c0 == -2) continue;                                // no parameter of this gate was requested
+                const int64_t p0 = as_const(a.pos_ptr)[c * nG + g], p1 = as_const(a.pos_ptr)[c * nG + g + 1];
+                d4_t acc[NX];
+#pragma unroll
+                for (int x = 0; x < NX; x++) acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0};
+                if (p1 > p0) {
+                    // Blocks of M chunks (4*M applications): all pair indices of the block are requested first, then all
+                    // state vectors, then the 4*M MFMAs -- two memory round trips per block instead of per chunk.  Lanes
+                    // past the end re-read the last pair (always a valid address) and multiply by a zeroed F.
+                    constexpr int M = ANA_MFMA_M;
+                    const int64_t last = p1 - 1;
+                    const double* const fb = a.base_cache + i;
+                    const double* const rbase = a.rev_cache + i;
+                    for (int64_t q = p0; q < p1; q += 4 * M) {
+                        int32_t fi[M], ri[M];
+                        bool ok[M];
+#pragma unroll
+                        for (int m = 0; m < M; m++) {
+                            const int64_t pi = q + 4 * m + kk;
+                            ok[m] = pi <= last;
+                            const int64_t pc = ok[m] ? pi : last;
+                            fi[m] = a.pair_f[pc]; ri[m] = a.pair_r[pc];
+                        }
+                        double Fv[M], Bv[M][NX];
+#pragma unroll
+                        for (int m = 0; m < M; m++) {
+                            Fv[m] = fb[(int64_t)fi[m] * D];
+#pragma unroll
+                            for (int x = 0; x < NX; x++) Bv[m][x] = rbase[((int64_t)ri[m] * nE + e_u[x]) * D];
+                        }
+#pragma unroll
+                        for (int m = 0; m < M; m++) {
+                            const double Fz = ok[m] ? Fv[m] : 0.0;
+#pragma unroll
+                            for (int x = 0; x < NX; x++) acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fz, acc[x], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < NX; x++) {
+                    if (x >= nx) break;
+                    if (c0 >= 0) {           // D*D consecutive columns: entry (row, col) at c0 + row*D + col
+                        double* o = a.out + dest_u[x] * a.ld + c0 + kk * D + i;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) o[4 * r * D] = acc[x][r];
+                    } else {                 // arbitrary subset / order: per-element column map
+                        const int32_t* cm = a.colmap_gate + (int64_t)g * D * D + kk * D + i;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) { const int32_t cc = cm[4 * r * D]; if (cc >= 0) a.out[dest_u[x] * a.ld + cc] = acc[x][r]; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream)
+{
+    if (a.n_circuits <= 0) return hipSuccess;
+    int64_t blocks = (a.n_circuits + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;       // persistent wavefronts pulling circuits from a.work_counter[0..7]
+    blocks = (blocks + 7) / 8 * 8;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(analytic_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream)
 {
     if (D != 16 && D != 4) return hipErrorInvalidValue;

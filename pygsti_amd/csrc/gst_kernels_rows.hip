@@ -813,7 +813,7 @@ __global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a, const i
     const int lane = threadIdx.x;
     const int li = lane % D, grp = lane / D;
     const int64_t task = blockIdx.x;
-    double* ldsE = lds + (n_slots > 0 ? n_slots : 1) * D;
+    double* ldsE = lds + (n_slots > 0 ? n_slots : 1) * 64;      // (a save slot holds one state per lane group)
     double* ldsG = ldsE + a.n_effects * D;
     double* ering = ldsG + a.n_gates * D * D;
     int32_t* ering_circ = (int32_t*)(ering + ER * ES);
@@ -828,7 +828,18 @@ __global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a, const i
     __builtin_amdgcn_s_waitcnt(0);           // single-wavefront block: drain, no barrier needed
     __builtin_amdgcn_wave_barrier();
 
+    // State-cache addressing.  Normal pass: every lane group holds the same state, group 0 stores it at
+    // cache[id][D].  Multi-start pass (a.multi_start = number of start vectors, used for the backward states of the
+    // analytic mode): lane group q walks from start vector a.start0 + q (RHO loads rhos[a.start0 + q] whatever its
+    // argument) and stores at cache[id][a.start0 + q][D] -- the walk program, the gates and their order are the same,
+    // so one pass propagates 64/D start vectors.
     double* const cache = a.base_cache_w;
+    const bool multi = a.multi_start > 0;
+    const int my_start = a.start0 + grp;
+    const bool store_on = multi ? (my_start < a.multi_start) : (grp == 0);
+    const int64_t node_stride = multi ? (int64_t)a.multi_start * D : (int64_t)D;
+    const int lane_off = multi ? (store_on ? my_start * D + li : 0) : lane;
+    double* const slot_lane = lds + grp * D + li;            // save slot s of this lane group: + s * 64
     int32_t lo = 0;                          // words [lo, lo + W) are resident, word i at ldsP[i % W]
     int32_t pc = 0;                          // index of the current word
     int n_er = 0;                            // parked EMITs (wave-uniform)
@@ -845,7 +856,7 @@ __global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a, const i
     } while (0)
 #define BASE_STORE_STATE(id_)                                                                         \
     do {                                                                                              \
-        if (cache && grp == 0) cache[(int64_t)(id_) * D + lane] = v;                                  \
+        if (cache && store_on) cache[(int64_t)(id_) * node_stride + lane_off] = v;                    \
     } while (0)
 #define BASE_FLUSH_EMITS()                                                                            \
     do {                                                                                              \
@@ -900,11 +911,11 @@ __global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a, const i
             if (lane == 0) ering_circ[n_er] = (int32_t)arg;
             if (++n_er == ER) BASE_FLUSH_EMITS();
         } else if (op == GST_OP_SAVE) {
-            if (grp == 0) lds[arg * D + lane] = v;
+            slot_lane[arg * 64] = v;
         } else if (op == GST_OP_LOAD) {
-            v = lds[arg * D + li];
+            v = slot_lane[arg * 64];
         } else {  // GST_OP_RHO
-            v = a.rhos[(int64_t)arg * D + li];
+            v = multi ? (store_on ? a.rhos[(int64_t)my_start * D + li] : 0.0) : a.rhos[(int64_t)arg * D + li];
         }
         pc++;
         BASE_REFILL();
@@ -947,12 +958,14 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
             // + effects, emit ring (states, circuits), program window
             const size_t extra = ((size_t)a.n_effects * D + BASE_ER * (D + 1)) * sizeof(double) +
                                  (BASE_ER + BASE_PW) * sizeof(int32_t);
-            if (lds_bytes + extra + gate_bytes <= 60 * 1024) {
-                hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)blocks), dim3(64), lds_bytes + extra + gate_bytes,
+            const size_t slot_bytes = (size_t)(n_slots > 0 ? n_slots : 1) * 64 * sizeof(double);   // one state per lane group
+            if (slot_bytes + extra + gate_bytes <= 60 * 1024) {
+                hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)blocks), dim3(64), slot_bytes + extra + gate_bytes,
                                    stream, a, n_slots);
                 return hipGetLastError();
             }
         }
+        if (a.multi_start > 0) return hipErrorInvalidValue;        // only the chain kernel implements multi-start walks
     }
     if (ldsg)
         hipLaunchKernelGGL((walk_rows_kernel<D, true>), dim3((unsigned)blocks), dim3(64), lds_bytes + gate_bytes, stream, a, n_slots);

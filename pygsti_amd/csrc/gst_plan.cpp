@@ -384,4 +384,53 @@ void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost)
     }
 }
 
+std::string build_reverse_plan(const HostPlan& P, HostPlan& R, int32_t target_tasks, int32_t max_slots)
+{
+    R = HostPlan();
+    R.D = P.D; R.n_gates = P.n_gates; R.n_rhos = 1; R.n_effects = 1;     // (one nominal effect; no circuit emits)
+    R.n_circuits = P.n_circuits; R.n_elements = 0;
+    R.circ_rho.assign((size_t)P.n_circuits, 0);
+    R.circ_ptr = P.circ_ptr;
+    R.circ_gates.resize(P.circ_gates.size());
+    for (int64_t c = 0; c < P.n_circuits; c++) {
+        const int64_t a = P.circ_ptr[c], b = P.circ_ptr[c + 1];
+        for (int64_t k = a; k < b; k++) R.circ_gates[k] = P.circ_gates[a + (b - 1 - k)];
+    }
+    R.eff_ptr.assign((size_t)P.n_circuits + 1, 0);
+    return compile_plan(R, target_tasks, max_slots);
+}
+
+void build_pair_tables(const HostPlan& P, const HostPlan& R, std::vector<int32_t>& pf, std::vector<int32_t>& pr,
+                       std::vector<int64_t>& pos_ptr)
+{
+    const int nG = P.n_gates;
+    const int64_t nC = P.n_circuits;
+    const int64_t total = P.circ_ptr[nC];
+    pf.assign((size_t)total, 0);
+    pr.assign((size_t)total, 0);
+    pos_ptr.assign((size_t)nC * nG + 1, 0);
+    // counts per (circuit, gate) -> offsets
+    for (int64_t c = 0; c < nC; c++)
+        for (int64_t k = P.circ_ptr[c]; k < P.circ_ptr[c + 1]; k++) pos_ptr[(size_t)c * nG + P.circ_gates[k] + 1]++;
+    for (size_t i = 1; i < pos_ptr.size(); i++) pos_ptr[i] += pos_ptr[i - 1];
+    std::vector<int32_t> f, r;
+    std::vector<int64_t> cursor(nG);
+    for (int64_t c = 0; c < nC; c++) {
+        const int64_t a = P.circ_ptr[c];
+        const int64_t n = P.circ_ptr[c + 1] - a;
+        f.resize((size_t)n + 1); r.resize((size_t)n + 1);
+        int32_t id = P.circ_leaf[c];
+        for (int64_t k = n; k >= 0; k--) { f[(size_t)k] = id; if (k > 0) id = P.node_parent[id]; }      // f[k] = state of F_k
+        id = R.circ_leaf[c];
+        for (int64_t d = n; d >= 0; d--) { r[(size_t)d] = id; if (d > 0) id = R.node_parent[id]; }      // r[d] = state of B_{n-d}
+        for (int g = 0; g < nG; g++) cursor[g] = pos_ptr[(size_t)c * nG + g];
+        for (int64_t k = 1; k <= n; k++) {
+            const int g = P.circ_gates[a + k - 1];
+            const int64_t at = cursor[g]++;
+            pf[(size_t)at] = f[(size_t)k - 1];
+            pr[(size_t)at] = r[(size_t)(n - k)];
+        }
+    }
+}
+
 }  // namespace gst

@@ -58,4 +58,16 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots);
 // (task, wavefront) pairs first.  Empty result when n_gates > 64.
 void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost);
 
+// Analytic derivatives (gst_kernels_analytic.hip, MFMA path): the plan of the REVERSED circuits (one dummy start, the
+// gates of every circuit in reverse order, no effects).  Walking it with the transposed gates from every effect
+// vector gives the backward states B_k = (G_n ... G_{k+1})^T E shared over common SUFFIXES, exactly as the forward
+// walk shares prefixes.  Returns "" or an error message.
+std::string build_reverse_plan(const HostPlan& P, HostPlan& R, int32_t target_tasks, int32_t max_slots);
+
+// For every circuit c = g_1 ... g_n and every gate g: the gate applications k with g_k = g, as pairs
+// (state id of F_{k-1} in P, state id of B_k in R), ascending k.  pos_ptr[c * n_gates + g] .. [c * n_gates + g + 1]
+// delimit the pairs of (c, g) in pf / pr.  rev_leaf_state[c] = state id in R of B_0 (the whole reversed circuit).
+void build_pair_tables(const HostPlan& P, const HostPlan& R, std::vector<int32_t>& pf, std::vector<int32_t>& pr,
+                       std::vector<int64_t>& pos_ptr);
+
 }  // namespace gst
