@@ -529,8 +529,12 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     a.n_gates = h.n_gates; a.n_rhos = h.n_rhos; a.n_effects = h.n_effects;
     a.gate_col0 = p->d_gate_col0.p; a.colmap_gate = p->d_cm_gate.p; a.colmap_rho = p->d_cm_rho.p; a.colmap_eff = p->d_cm_eff.p;
     a.out = d_out; a.ld = ld;
-    if (D == 16 && p->ana_mfma) {
+    // (the MFMA kernel addresses both state caches with 32-bit byte offsets)
+    const bool caches_small = (double)h.n_state_ids * D * 8 < 4.0e9;
+    if (D == 16 && p->ana_mfma && caches_small) {
         if ((rc = ensure_reverse(p))) return rc;
+        if ((double)p->rev.n_state_ids * h.n_effects * D * 8 >= 4.0e9)
+            return fail(GST_EUNSUPPORTED, "backward-state cache exceeds 4 GB: set GST_ANALYTIC_MFMA=0 for this plan");
         // backward states: the chain kernel over the reversed plan, transposed gates (= the row-major array), one lane
         // group per effect (64/D effects per pass)
         gst::WalkArgs w;

@@ -277,8 +277,14 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                     // past the end re-read the last pair (always a valid address) and multiply by a zeroed F.
                     constexpr int M = ANA_MFMA_M;
                     const int64_t last = p1 - 1;
-                    const double* const fb = a.base_cache + i;
-                    const double* const rbase = a.rev_cache + i;
+                    // uniform 64-bit bases + 32-bit per-lane byte offsets (both caches are < 4 GB, checked on the host):
+                    // one offset register serves the F load / the NX backward loads of a gathered application
+                    const char* const fb = (const char*)a.base_cache;
+                    const char* rbx[NX];
+#pragma unroll
+                    for (int x = 0; x < NX; x++) rbx[x] = (const char*)a.rev_cache + (uint32_t)e_u[x] * (D * 8);
+                    const uint32_t lane_b = (uint32_t)i * 8u;
+                    const uint32_t rstride = (uint32_t)nE * (D * 8);
                     for (int64_t q = p0; q < p1; q += 4 * M) {
                         int32_t fi[M], ri[M];
                         bool ok[M];
@@ -292,9 +298,11 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                         double Fv[M], Bv[M][NX];
 #pragma unroll
                         for (int m = 0; m < M; m++) {
-                            Fv[m] = fb[(int64_t)fi[m] * D];
+                            const uint32_t fo = (uint32_t)fi[m] * (D * 8) + lane_b;
+                            const uint32_t ro = (uint32_t)ri[m] * rstride + lane_b;
+                            Fv[m] = *(const double*)(fb + fo);
 #pragma unroll
-                            for (int x = 0; x < NX; x++) Bv[m][x] = rbase[((int64_t)ri[m] * nE + e_u[x]) * D];
+                            for (int x = 0; x < NX; x++) Bv[m][x] = *(const double*)(rbx[x] + ro);
                         }
 #pragma unroll
                         for (int m = 0; m < M; m++) {
