@@ -411,9 +411,9 @@ int ensure_reverse(gst_plan* p)
 {
     if (p->rev_ready) return GST_OK;
     const gst::HostPlan& h = p->hp;
-    std::string err = gst::build_reverse_plan(h, p->rev, 0, h.D == 16 ? 1 : 4);
+    std::string err = gst::build_reverse_plan(h, p->rev, 0, h.D == 16 ? 1 : (h.D == 64 ? 8 : 4));
     if (!err.empty()) return fail(GST_EINVAL, "reversed plan: " + err);
-    if (p->rev.max_slots > 4) return fail(GST_EUNSUPPORTED, "reversed plan needs too many save slots");
+    if (p->rev.max_slots > (h.D == 64 ? 32 : 4)) return fail(GST_EUNSUPPORTED, "reversed plan needs too many save slots");
     std::vector<int32_t> pf, pr;
     std::vector<int64_t> pos_ptr;
     gst::build_pair_tables(h, p->rev, pf, pr, pos_ptr);
@@ -468,7 +468,8 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
                         int64_t n_param, double* d_probs_out)
 {
     const gst::HostPlan& h = p->hp;
-    if (h.D != 4 && h.D != 16) return fail(GST_EUNSUPPORTED, "the analytic mode supports D = 4 and D = 16 in this round");
+    if (h.D != 4 && h.D != 16 && h.D != 64) return fail(GST_EUNSUPPORTED, "the analytic mode supports D = 4, 16 and 64");
+    if (h.D == 64 && !p->ana_mfma) return fail(GST_EUNSUPPORTED, "D = 64 analytic derivatives exist on the MFMA path only");
     double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
     int rc = run_probs(p, d_base, n_param > 0);        // probabilities + every forward state
     if (rc) return rc;
@@ -531,7 +532,8 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     a.out = d_out; a.ld = ld;
     // (the MFMA kernel addresses both state caches with 32-bit byte offsets)
     const bool caches_small = (double)h.n_state_ids * D * 8 < 4.0e9;
-    if (D == 16 && p->ana_mfma && caches_small) {
+    if (D == 64 && !caches_small) return fail(GST_EUNSUPPORTED, "forward-state cache exceeds 4 GB");
+    if ((D == 16 || D == 64) && p->ana_mfma && caches_small) {
         if ((rc = ensure_reverse(p))) return rc;
         if ((double)p->rev.n_state_ids * h.n_effects * D * 8 >= 4.0e9)
             return fail(GST_EUNSUPPORTED, "backward-state cache exceeds 4 GB: set GST_ANALYTIC_MFMA=0 for this plan");
@@ -549,15 +551,22 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         w.base_cache_w = p->d_rev_cache.p;
         w.multi_start = h.n_effects;
         HIP_TRY(hipEventRecord(p->evk0, p->stream));
-        for (int e0 = 0; e0 < h.n_effects; e0 += 64 / D) {
-            w.start0 = e0;
+        if (D == 64) {                                         // one wavefront per (task, effect), a single launch
+            w.start0 = 0; w.n_pwaves = h.n_effects;
             HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream));
             p->last_launches++;
+        } else {
+            for (int e0 = 0; e0 < h.n_effects; e0 += 64 / D) {  // four effects (lane groups) per pass of the chain kernel
+                w.start0 = e0;
+                HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream));
+                p->last_launches++;
+            }
         }
         a.rev_cache = p->d_rev_cache.p; a.rev_leaf = p->d_rev_leaf.p; a.pair_f = p->d_pair_f.p; a.pair_r = p->d_pair_r.p;
         a.pos_ptr = p->d_pos_ptr.p; a.circ_rho = p->d_circ_rho.p; a.circ_order = p->d_circ_order.p; a.work_counter = p->d_work_counter.p; a.range_begin = p->d_range_begin.p;
         HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
-        HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+        if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
+        else HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
         HIP_TRY(hipEventRecord(p->evk1, p->stream));
         p->last_launches++;
         return GST_OK;

@@ -97,6 +97,7 @@ struct AnaArgs {
 };
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
 hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream);   // D = 16
+hipError_t launch_analytic_mfma64(const AnaArgs& a, hipStream_t stream); // D = 64 (uses work_counter[0] only)
 
 hipError_t launch_scale_rows(double* J, int64_t n_rows, int64_t n_cols, int64_t ld, const double* w, hipStream_t s);
 hipError_t launch_symmetrize(double* C, int64_t n, hipStream_t s);

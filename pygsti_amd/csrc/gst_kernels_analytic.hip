@@ -330,6 +330,111 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// analytic_mfma64_kernel (D = 64, three qubits): the same contraction with 64 x 64 blocks.  One wavefront owns one
+// circuit outcome: for every gate it holds the 4 x 4 grid of 16 x 16 MFMA tiles of that gate's block (64 fp64
+// accumulators per lane) and, per 4 applications of the gate, gathers 4 + 4 operand registers (the four 16-row
+// slices of B_k and of F_{k-1}) for 16 v_mfma_f64_16x16x4_f64 -- two MFMAs per gathered register.
+__global__ __launch_bounds__(256, 2) void analytic_mfma64_kernel(const AnaArgs a)
+{
+    constexpr int D = 64;
+    const int lane = threadIdx.x & 63;
+    const int kk = lane >> 4, i = lane & 15;
+    const int nE = a.n_effects, nG = a.n_gates;
+    for (;;) {
+        uint32_t cu = 0;
+        if (lane == 0) cu = atomicAdd(a.work_counter, 1u);
+        const int64_t item = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)cu);     // (ordered circuit, outcome slot)
+        if (item >= a.n_circuits * (int64_t)nE) break;
+        const int64_t c = as_const(a.circ_order)[item / nE];
+        const int32_t x0 = as_const(a.eff_ptr)[c], x1 = as_const(a.eff_ptr)[c + 1];
+        const int32_t x = x0 + (int32_t)(item % nE);
+        if (x >= x1) continue;                                         // (a circuit with fewer outcomes than effects)
+        const int32_t e = as_const(a.eff_label)[x];
+        const int64_t dest = as_const(a.eff_dest)[x];
+        const int32_t fleaf = as_const(a.circ_leaf)[c], rleaf = as_const(a.rev_leaf)[c], rsym = as_const(a.circ_rho)[c];
+        double* const orow = a.out + dest * a.ld;
+        // SPAM columns: dp/dE[a] = F_n[a] (own effect; zeros for the others), dp/drho[b] = B_0[b]
+        {
+            const double FL = a.base_cache[(int64_t)fleaf * D + lane];
+            for (int e2 = 0; e2 < nE; e2++) {
+                const int32_t ce = a.colmap_eff[e2 * D + lane];
+                if (ce >= 0) orow[ce] = (e2 == e) ? FL : 0.0;
+            }
+            const double B0 = a.rev_cache[((int64_t)rleaf * nE + e) * D + lane];
+            for (int r2 = 0; r2 < a.n_rhos; r2++) {
+                const int32_t cr = a.colmap_rho[r2 * D + lane];
+                if (cr >= 0) orow[cr] = (r2 == rsym) ? B0 : 0.0;
+            }
+        }
+        const char* const fb = (const char*)a.base_cache;
+        const char* const rb = (const char*)a.rev_cache + (uint32_t)e * (D * 8);
+        const uint32_t lane_b = (uint32_t)i * 8u;
+        const uint32_t rstride = (uint32_t)nE * (D * 8);
+        for (int g = 0; g < nG; g++) {
+            const int32_t c0 = as_const(a.gate_col0)[g];
+            if (c0 == -2) continue;
+            const int64_t p0 = as_const(a.pos_ptr)[c * nG + g], p1 = as_const(a.pos_ptr)[c * nG + g + 1];
+            d4_t acc[4][4];
+#pragma unroll
+            for (int tr = 0; tr < 4; tr++)
+#pragma unroll
+                for (int tc = 0; tc < 4; tc++) acc[tr][tc] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            const int64_t last = p1 - 1;
+            for (int64_t q = p0; q < p1; q += 4) {
+                const int64_t pi = q + kk;
+                const bool ok = pi <= last;
+                const int64_t pc = ok ? pi : last;
+                const uint32_t fo = (uint32_t)a.pair_f[pc] * (D * 8) + lane_b;
+                const uint32_t ro = (uint32_t)a.pair_r[pc] * rstride + lane_b;
+                double Fv[4], Bv[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    Fv[t] = *(const double*)(fb + fo + t * 128);
+                    Bv[t] = *(const double*)(rb + ro + t * 128);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) Fv[t] = ok ? Fv[t] : 0.0;
+#pragma unroll
+                for (int tr = 0; tr < 4; tr++)
+#pragma unroll
+                    for (int tc = 0; tc < 4; tc++)
+                        acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[tr], Fv[tc], acc[tr][tc], 0, 0, 0);
+            }
+            // tile (tr, tc), lane l, register r -> block entry (16 tr + (l>>4) + 4r, 16 tc + (l&15))
+            if (c0 >= 0) {
+#pragma unroll
+                for (int tr = 0; tr < 4; tr++)
+#pragma unroll
+                    for (int tc = 0; tc < 4; tc++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) orow[c0 + (16 * tr + kk + 4 * r) * D + 16 * tc + i] = acc[tr][tc][r];
+            } else {
+                const int32_t* cm = a.colmap_gate + (int64_t)g * D * D;
+#pragma unroll
+                for (int tr = 0; tr < 4; tr++)
+#pragma unroll
+                    for (int tc = 0; tc < 4; tc++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int32_t cc = cm[(16 * tr + kk + 4 * r) * D + 16 * tc + i];
+                            if (cc >= 0) orow[cc] = acc[tr][tc][r];
+                        }
+            }
+        }
+    }
+}
+
+hipError_t launch_analytic_mfma64(const AnaArgs& a, hipStream_t stream)
+{
+    if (a.n_circuits <= 0) return hipSuccess;
+    int64_t blocks = (a.n_circuits * (int64_t)a.n_effects + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4;       // persistent wavefronts pulling (circuit, outcome) items
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(analytic_mfma64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream)
 {
     if (a.n_circuits <= 0) return hipSuccess;

@@ -79,6 +79,12 @@ __global__ __launch_bounds__(64) void walk_rows_kernel(const WalkArgs a, const i
     bool dirty = (S == 0);
     int32_t cur_id = 0;
     int32_t tags = -1;                       // lane s: clean-state id "held" by save slot s (-1: real data in LDS)
+    // S = 0 with a.multi_start > 0 (backward states of the analytic mode): wavefront pw of a task walks from
+    // rhos[a.start0 + pw] whatever RHO's argument and stores its states at base_cache_w[id][a.start0 + pw][D]
+    const bool multi = (S == 0) && a.multi_start > 0;
+    const int32_t my_start = a.start0 + pw;
+    const int64_t cstride = multi ? (int64_t)a.multi_start * D : (int64_t)D;
+    const int64_t coff = multi ? (int64_t)my_start * D : 0;
 
     const int64_t pc0 = as_const(a.task_off)[task];
     const int32_t n_words = (int32_t)(as_const(a.task_off)[task + 1] - pc0);
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(64) void walk_rows_kernel(const WalkArgs a, const i
                 for (int j = 0; j < D; j++) acc = acc + c[j] * readlane_f64(v, j);
                 v = acc;
                 cur_id = node_id;
-                if (S == 0 && a.base_cache_w && act) a.base_cache_w[(int64_t)node_id * D + lane] = v;
+                if (S == 0 && a.base_cache_w && act) a.base_cache_w[(int64_t)node_id * cstride + coff + lane] = v;
                 if (!more) break;
 #pragma unroll
                 for (int j = 0; j < D; j++) c[j] = cn[j];
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(64) void walk_rows_kernel(const WalkArgs a, const i
             continue;                                                  // `op` already holds the next instruction
         } else if (op == GST_OP_NODE) {
             cur_id = (int32_t)arg;
-            if (S == 0 && a.base_cache_w && act) a.base_cache_w[(int64_t)arg * D + lane] = v;
+            if (S == 0 && a.base_cache_w && act) a.base_cache_w[(int64_t)arg * cstride + coff + lane] = v;
         } else if (op == GST_OP_EMIT) {
             const int32_t x0 = as_const(a.eff_ptr)[arg], x1 = as_const(a.eff_ptr)[arg + 1];
             const bool zero = (S > 0) && !dirty && !wave_eff;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(64) void walk_rows_kernel(const WalkArgs a, const i
             if (S > 0 && !wave_rho) {
                 dirty = false;
             } else {
-                v = a.rhos[(int64_t)arg * D + li];
+                v = a.rhos[(int64_t)(multi ? (uint32_t)my_start : arg) * D + li];
                 for (int s = 0; s < S; s++)
                     if (kind[s] == GST_KIND_RHO && obj[s] == (int)arg && lane == row[s]) v = v + a.eps;
                 dirty = true;
@@ -965,7 +971,7 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
                 return hipGetLastError();
             }
         }
-        if (a.multi_start > 0) return hipErrorInvalidValue;        // only the chain kernel implements multi-start walks
+        if (a.multi_start > 0) return hipErrorInvalidValue;        // D <= 16: only the chain kernel implements multi-start walks
     }
     if (ldsg)
         hipLaunchKernelGGL((walk_rows_kernel<D, true>), dim3((unsigned)blocks), dim3(64), lds_bytes + gate_bytes, stream, a, n_slots);

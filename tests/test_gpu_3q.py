@@ -72,3 +72,22 @@ def test_3q_plan_stats():
     pl, tbl, mdl, nP = _make(n_circ=40, max_len=64, seed=3)
     st = pl.stats()
     assert st["max_slots"] <= 8 and st["applies_per_pass"] <= st["sum_depth"]
+
+
+def test_3q_analytic_dprobs_vs_numpy_oracle(oracle_built):
+    """GST_DERIV_ANALYTIC at D = 64: backward states over the suffix trie + 64x64 MFMA blocks, against the numpy
+    forward/backward Jacobian (the restatement pinned to MatrixForwardSimulator vectors at D = 4 and 16)."""
+    pl, tbl, mdl, nP = _make(n_circ=40, max_len=96, seed=7)
+    fx = dict(tbl); fx.update(mdl)
+    rng = np.random.default_rng(11)
+    cols = np.sort(np.concatenate([np.arange(0, 64), np.arange(64, 64 + 512), np.arange(576, 576 + 4096),
+                                   576 + 4096 * 3 + rng.choice(4096, 300, replace=False), [nP - 1]]))
+    pr = np.empty(tbl["nE"])
+    J = pl.fill_dprobs(param_idx=cols, probs_out=pr, mode=_lib.DERIV_ANALYTIC)
+    Jo, po = oracle_built.analytic_dprobs(fx, cols)
+    scale = max(1.0, np.abs(Jo).max())
+    assert np.abs(J - Jo).max() < 1e-8 * scale
+    assert np.abs(pr - po).max() < 1e-10
+    # the finite-difference Jacobian is close but not equal (truncation error of the FD step)
+    Jfd = pl.fill_dprobs(param_idx=cols[:200], eps=1e-7)
+    assert np.abs(Jfd - J[:, :200]).max() < 1e-4 * scale

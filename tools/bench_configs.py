@@ -61,6 +61,12 @@ def three_q(n_circ=400, max_len=256, n_cols=4096):
     d_J = plan.device_malloc(nE * n_cols * 8)
     t_fd = timed(lambda: plan.fill_dprobs_dev(d_J, n_cols, cols, None, 1e-7, d_p, _lib.DERIV_FD), plan, 2)
     st = plan.stats()
+    t_an = timed(lambda: plan.fill_dprobs_dev(d_J, n_cols, cols, None, 1e-7, d_p, _lib.DERIV_ANALYTIC), plan, 5)
+    plan.device_free(d_J)
+    allc = np.arange(nP, dtype=np.int64)
+    d_Jf = plan.device_malloc(nE * nP * 8)
+    t_anf = timed(lambda: plan.fill_dprobs_dev(d_Jf, nP, allc, None, 1e-7, d_p, _lib.DERIV_ANALYTIC), plan, 3)
+    plan.device_free(d_Jf)
     i1 = np.arange(576, 576 + 16, dtype=np.int64); i2 = np.arange(576, 576 + 256, dtype=np.int64)
     t0 = time.perf_counter(); H = plan.fill_hprobs(idx1=i1, idx2=i2, eps=1e-5); t_h = time.perf_counter() - t0
     flops = n_cols * 2.0 * D * D * st["applies_per_pass"]
@@ -69,10 +75,13 @@ def three_q(n_circ=400, max_len=256, n_cols=4096):
             "probs_ms": 1e3 * t_p, "probs_per_s": nE / t_p,
             "dprobs_fd_cols": int(n_cols), "dprobs_fd_ms": 1e3 * t_fd, "dprobs_fd_el_per_s": nE * n_cols / t_fd,
             "dprobs_fd_kernel_ms": st["last_kernel_ms"], "dprobs_fd_TFLOPs_algorithmic": flops / t_fd / 1e12,
+            "dprobs_analytic_same_block_ms": 1e3 * t_an, "dprobs_analytic_same_block_el_per_s": nE * n_cols / t_an,
+            "dprobs_analytic_full_ms": 1e3 * t_anf, "dprobs_analytic_full_el_per_s": nE * nP / t_anf,
+            "dprobs_analytic_full_GBps": 8.0 * nE * nP / t_anf / 1e9,
             "hprobs_block": "16 x 256", "hprobs_ms_incl_d2h": 1e3 * t_h, "hprobs_el_per_s": nE * 16 * 256 / t_h,
             "applies_per_pass": st["applies_per_pass"], "n_tasks": st["n_tasks"],
-            "note": "bit-exact FD on the row-per-lane kernel (one perturbed model per wavefront, v_readlane broadcasts); no MFMA: "
-                    "separate multiply/add is required for parity with the reference Map path"}
+            "note": "FD: bit-exact, register-blocked kernel (16 models per wavefront), no MFMA -- separate multiply/add is what parity "
+                    "with the reference Map path requires; analytic: backward states over the suffix trie + 64x64 MFMA fp64 blocks"}
 
 
 if __name__ == "__main__":
