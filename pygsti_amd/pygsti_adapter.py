@@ -109,19 +109,24 @@ def atom_plan(model, atom, device=-1, target_tasks=0):
 
 
 class HipMapForwardSimulator(_MapForwardSimulator):
-    """MapForwardSimulator whose atom fills run on the GPU (bit-identical results)."""
+    """MapForwardSimulator whose atom fills run on the GPU.  `derivative_mode="fd"` (default): bit-identical to the
+    Map simulator's finite differences; `"analytic"`: exact first derivatives (what MatrixForwardSimulator returns,
+    to <= 1e-8), several times faster; Hessians are FD-of-FD in both modes."""
 
     def __init__(self, model=None, max_cache_size=None, num_atoms=None, processor_grid=None, param_blk_sizes=None,
-                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1):
+                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1, derivative_mode="fd"):
         if not HAVE_PYGSTI:
             raise ImportError("pygsti is not importable; use pygsti_amd.forwardsim.HipMapForwardSimulator instead")
+        if derivative_mode not in ("fd", "analytic"):
+            raise ValueError("derivative_mode must be 'fd' or 'analytic'")
         super().__init__(model, max_cache_size, num_atoms, processor_grid, param_blk_sizes, derivative_eps, hessian_eps)
         self._hip_device = device
+        self.derivative_mode = derivative_mode
 
     def copy(self, keep_model_attached=True):
         out = HipMapForwardSimulator(self.model if keep_model_attached else None, self._max_cache_size, self._num_atoms,
                                      self._processor_grid, self._pblk_sizes, self.derivative_eps, self.hessian_eps,
-                                     self._hip_device)
+                                     self._hip_device, self.derivative_mode)
         return out
 
     def _prepare(self, layout_atom):
@@ -144,7 +149,8 @@ class HipMapForwardSimulator(_MapForwardSimulator):
         nP = self.model.num_params
         pidx = np.arange(nP) if param_slice is None else _slct.to_array(param_slice)
         didx = None if dest_param_slice is None else _slct.to_array(dest_param_slice)
-        plan.fill_dprobs(array_to_fill, pidx, didx, self.derivative_eps)
+        mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
+        plan.fill_dprobs(array_to_fill, pidx, didx, self.derivative_eps, mode=mode)
 
     def _bulk_fill_hprobs_atom(self, array_to_fill, dest_param_slice1, dest_param_slice2, layout_atom,
                                param_slice1, param_slice2, resource_alloc):
