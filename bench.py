@@ -345,7 +345,9 @@ def main():
             "analytic_dprobs": ana_info,
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,
-            "roofline": roof or {"bound": "valu_f64", "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
+            "roofline": roof or {"bound": "valu_f64",
+                         "bound_note": "compute-bound on the fp64 VECTOR ALU (no matrix instruction can reproduce the reference's un-fused, ordered sums); its 78.6 TFLOP/s FMA peak equals MI355X's dense fp64 MFMA peak, so `frac` reads the same against either",
+                         "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
                          "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (k_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
                          "note": "flops = the reference schedule's nP*(2*D^2*A + 2*D*nE); the kernel executes ~0.56 of them (the rest is provably bit-identical to the base pass) as separate v_mul_f64+v_add_f64 (no FMA: bitwise parity), whose own ceiling is 0.5 of the FMA peak; VALU issue utilisation 93% (profiles/r01_bench_pmc_sq_current.json)",

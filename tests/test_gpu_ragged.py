@@ -71,6 +71,11 @@ def test_ragged_inputs_vs_oracle(oracle_built, D, seed, max_slots, target_tasks)
     Jfd = orc.dprobs(cols, eps=1e-7)
     assert np.abs(Ja - Jfd).max() < 1e-4 * max(1.0, np.abs(Jfd).max())
     assert (Ja[:, mdl["pkind"][cols] == -1] == 0).all()
+    # ... and against the exact numpy forward/backward Jacobian (six effects: two backward passes at D = 16; several
+    # preparations; circuits without outcomes; duplicates)
+    fx = dict(tbl); fx.update(mdl)
+    Jo, _ = oracle_built.analytic_dprobs(fx, cols)
+    assert np.abs(Ja - Jo).max() < 1e-8 * max(1.0, np.abs(Jo).max())
 
 
 def test_degenerate_requests():
