@@ -302,13 +302,20 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
     // past the grain until such a place comes, so a small atom of deep germ-power families is still cut between
     // families instead of collapsing into a few huge tasks).
     if (target_tasks <= 0) target_tasks = 2048;
-    const int64_t grain = std::max<int64_t>(32, P.trie_nodes / target_tasks);
+    int64_t grain = std::max<int64_t>(32, P.trie_nodes / target_tasks);
+    // Small plans (a 1Q design is ~4,000 states for 1,024 SIMDs) are pure latency: the time of a pass is the longest
+    // task's dependent chain, not the work.  There a cut is allowed wherever a quarter of the deepest circuit's worth
+    // of new states has accumulated, whatever it re-computes -- many short walks instead of a few long ones.
+    int64_t deepest = 0;
+    for (int64_t k = 0; k < nC; k++) deepest = std::max<int64_t>(deepest, 1 + (ptr[k + 1] - ptr[k]));
+    const bool small = P.trie_nodes <= 65536;
+    if (small) grain = std::max<int64_t>(16, deepest / 4);
     std::vector<int64_t> cuts{0};
     int64_t cur = 0;
     for (int64_t k = 0; k < nC; k++) {
         const int32_t c = order[k];
         const int64_t L = 1 + (ptr[c + 1] - ptr[c]);
-        if (k > 0 && cur >= grain && lcp[k] - 1 <= std::max<int64_t>(2, cur / 20)) { cuts.push_back(k); cur = 0; }
+        if (k > 0 && cur >= grain && (small || lcp[k] - 1 <= std::max<int64_t>(2, cur / 20))) { cuts.push_back(k); cur = 0; }
         cur += (cur == 0) ? L : L - lcp[k];
     }
     cuts.push_back(nC);
