@@ -770,17 +770,26 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     if (mode == GST_DERIV_ANALYTIC) rc = run_dprobs_analytic(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
     else rc = run_dprobs_fd(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr, nullptr, 0);
     if (rc) return rc;
+    // D2H into the caller's (ld, dest_idx) window.  A contiguous destination window -- the `dest_param_slice` of the
+    // reference's seam (mapforwardsim.py:379-383) -- is one strided 2-D copy; only a scattered dest_idx needs staging.
+    bool window = true;
+    for (int64_t c = 1; dest_idx && c < n_param; c++) window = window && dest_idx[c] == dest_idx[0] + c;
+    const int64_t d0 = (dest_idx && n_param > 0) ? dest_idx[0] : 0;
     std::vector<double> stage;
-    const bool direct = (!dest_idx && ld == n_param);
-    double* dst = out;
-    if (!direct) { stage.resize((size_t)nE * n_param); dst = stage.data(); }
-    if (n_param > 0) HIP_TRY(hipMemcpyAsync(dst, p->d_out.p, (size_t)nE * n_param * 8, hipMemcpyDeviceToHost, p->stream));
+    if (n_param > 0) {
+        if (window) {
+            HIP_TRY(hipMemcpy2DAsync(out + d0, (size_t)ld * 8, p->d_out.p, (size_t)n_param * 8, (size_t)n_param * 8, (size_t)nE,
+                                     hipMemcpyDeviceToHost, p->stream));
+        } else {
+            stage.resize((size_t)nE * n_param);
+            HIP_TRY(hipMemcpyAsync(stage.data(), p->d_out.p, (size_t)nE * n_param * 8, hipMemcpyDeviceToHost, p->stream));
+        }
+    }
     if (probs_out) HIP_TRY(hipMemcpyAsync(probs_out, p->d_pbase.p, nE * 8, hipMemcpyDeviceToHost, p->stream));
     if ((rc = end_call(p, true))) return rc;
-    if (!direct)
+    if (n_param > 0 && !window)
         for (int64_t k = 0; k < nE; k++)
-            for (int64_t c = 0; c < n_param; c++)
-                out[k * ld + (dest_idx ? dest_idx[c] : c)] = stage[(size_t)k * n_param + c];
+            for (int64_t c = 0; c < n_param; c++) out[k * ld + dest_idx[c]] = stage[(size_t)k * n_param + c];
     return GST_OK;
 }
 
