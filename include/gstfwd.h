@@ -130,6 +130,19 @@ int gst_set_model(gst_plan *plan, const double *gates, const double *rhos, const
 int gst_set_param_map(gst_plan *plan, int32_t n_params, const int32_t *kind, const int32_t *obj,
                       const int32_t *elem);
 
+/* General parameterisations (TP, CPTP, ... -- anything whose members answer deriv_wrt_params) in GST_DERIV_ANALYTIC:
+ * what MatrixForwardSimulator assembles from `_doperation` = member.deriv_wrt_params()
+ * (pygsti/forwardsims/matrixforwardsim.py:126-190; modelmembers/.../deriv_wrt_params).  Object o = (kind[o], obj[o])
+ * depends on n_cols[o] model parameters, listed in param_idx (concatenated over objects, = the member's gpindices), and
+ * deriv holds d(dense element)/d(parameter), row-major [n_elem][n_cols[o]] per object (n_elem = D*D for gates, D for
+ * rhos and effects), concatenated.  While set, gst_fill_dprobs(_dev)(GST_DERIV_ANALYTIC) returns
+ *     d p / d parameter = sum over objects of (d p / d element) . deriv
+ * for parameters 0 .. n_params-1 (the (kind,obj,elem) map of gst_set_param_map is not used in that mode; a parameter
+ * may appear in several objects, e.g. a TP POVM's complement effect).  Re-call after gst_set_model whenever the
+ * derivatives depend on the parameter values (non-linear parameterisations).  n_objs = 0 clears. */
+int gst_set_derivs(gst_plan *plan, int32_t n_params, int32_t n_objs, const int32_t *kind, const int32_t *obj,
+                   const int32_t *n_cols, const int64_t *param_idx, const double *deriv);
+
 /* probs: out[n_elements] (host). */
 int gst_fill_probs(gst_plan *plan, double *out);
 

@@ -197,3 +197,46 @@ def analytic_dprobs(fx, cols=None):
     if cols is not None:
         J = J[:, cols]
     return J, P
+
+
+def element_param_map(fx):
+    """(kind, obj, elem) of the `full` element layout [rhos | effects | gates] -- the columns of the element Jacobian
+    that the chain rule of general parameterisations starts from."""
+    D = int(fx["D"]); nG, nR, nEl = len(fx["gates"]), len(fx["rhos"]), len(fx["effects"])
+    kind = np.concatenate([np.full(nR * D, 1), np.full(nEl * D, 2), np.full(nG * D * D, 0)]).astype(np.int32)
+    obj = np.concatenate([np.repeat(np.arange(nR), D), np.repeat(np.arange(nEl), D), np.repeat(np.arange(nG), D * D)]).astype(np.int32)
+    elem = np.concatenate([np.tile(np.arange(D), nR), np.tile(np.arange(D), nEl), np.tile(np.arange(D * D), nG)]).astype(np.int32)
+    return kind, obj, elem
+
+
+def derivs_from_fixture(fx):
+    """[(kind, obj, param_idx[n], deriv[n_elem, n])] from the flat dv_* arrays of a general-parameterisation fixture."""
+    out, p0, d0 = [], 0, 0
+    D = int(fx["D"])
+    for k, o, n in zip(fx["dv_kind"], fx["dv_obj"], fx["dv_ncols"]):
+        ne = D * D if k == 0 else D
+        out.append((int(k), int(o), np.asarray(fx["dv_param_idx"][p0:p0 + n], np.int64),
+                    np.asarray(fx["dv_deriv"][d0:d0 + ne * n], np.float64).reshape(ne, n)))
+        p0 += n; d0 += ne * n
+    return out
+
+
+def analytic_dprobs_general(fx, cols=None):
+    """Jacobian w.r.t. model parameters of a general (TP, CPTP, ...) parameterisation: element Jacobian x the members'
+    deriv_wrt_params -- what MatrixForwardSimulator._dprobs_from_rho_e assembles from `_doperation`
+    (pygsti/forwardsims/matrixforwardsim.py:126-190, 1100-1180)."""
+    D = int(fx["D"]); nG, nR, nEl = len(fx["gates"]), len(fx["rhos"]), len(fx["effects"])
+    fe = dict(fx)
+    fe["pkind"], fe["pobj"], fe["pelem"] = element_param_map(fx)
+    Je, P = analytic_dprobs(fe)
+    nP = int(fx["nP"])
+    J = np.zeros((Je.shape[0], nP))
+    base = {1: 0, 2: nR * D, 0: nR * D + nEl * D}
+    for k, o, pidx, dm in derivs_from_fixture(fx):
+        ne = D * D if k == 0 else D
+        a = base[k] + o * ne
+        np.add.at(J, (slice(None), pidx), Je[:, a:a + ne] @ dm)
+    if cols is not None:
+        J = J[:, cols]
+    return J, P
+

@@ -63,7 +63,7 @@ class Stats(C.Structure):
 
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
-           "gst_set_param_map", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_probs_dev",
+           "gst_set_param_map", "gst_set_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_probs_dev",
            "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
            "gst_last_error", "gst_version"]
 
@@ -93,6 +93,7 @@ def lib():
         L.gst_fill_dprobs_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.c_int, dbl, vp]
         L.gst_fill_jtj_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
         L.gst_fill_jtf_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+        L.gst_set_derivs.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
         L.gst_objective_rows_dev.argtypes = [vp, C.POINTER(ObjectiveDesc), vp, vp, vp, i64, vp, vp, vp, C.POINTER(C.c_double)]
         L.gst_memcpy_h2d.argtypes = [vp, vp, vp, i64]
         L.gst_sync.argtypes = [vp]
@@ -204,6 +205,23 @@ class Plan:
         assert len(k) == len(o) == len(e)
         check(lib().gst_set_param_map(self._h, len(k), _ptr(k), _ptr(o), _ptr(e)))
         self.n_params = len(k)
+
+    def set_derivs(self, n_params, objs):
+        """General parameterisations for the analytic mode: objs = [(kind, obj, param_idx[n], deriv[n_elem, n]), ...]
+        (gst_set_derivs); an empty list clears."""
+        objs = list(objs)
+        if not objs:
+            check(lib().gst_set_derivs(self._h, int(n_params), 0, None, None, None, None, None))
+            return
+        kind = _i32([o[0] for o in objs]); obj = _i32([o[1] for o in objs])
+        ncols = _i32([len(o[2]) for o in objs])
+        pidx = _i64(np.concatenate([np.asarray(o[2], np.int64).ravel() for o in objs]))
+        ne = [self.D * self.D if o[0] == KIND_GATE else self.D for o in objs]
+        for o, n in zip(objs, ne):
+            assert np.asarray(o[3]).shape == (n, len(o[2])), "deriv must be [n_elem, n_params_of_object]"
+        der = _f64(np.concatenate([np.ascontiguousarray(o[3], np.float64).ravel() for o in objs]))
+        check(lib().gst_set_derivs(self._h, int(n_params), len(objs), _ptr(kind), _ptr(obj), _ptr(ncols), _ptr(pidx), _ptr(der)))
+        self.n_params = int(n_params)
 
     # -- fills (host arrays) ---------------------------------------------------------------------------
     def fill_probs(self, out=None):

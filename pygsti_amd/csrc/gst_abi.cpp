@@ -88,6 +88,13 @@ struct gst_plan {
     DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order;
     DevBuf<double> d_rev_cache;
     DevBuf<uint32_t> d_work_counter, d_range_begin;
+    // general parameterisations (gst_set_derivs)
+    bool derivs_set = false;
+    int32_t dv_n_params = 0;
+    std::vector<int32_t> dv_kind, dv_obj, dv_ncols;
+    std::vector<int64_t> dv_param_idx, dv_off_cols, dv_off_deriv;
+    DevBuf<double> d_dv_deriv, d_jelem;
+    DevBuf<int32_t> d_dv_colmap;
     bool ana_mfma = true;               // D = 16 analytic mode on the MFMA path (GST_ANALYTIC_MFMA=0: the VALU kernel)
     int fd_split = 0;                   // gst_options.fd_split: 0 auto, 1 / 2 / 4 wavefronts per (task, 64 columns) pair
     int n_cus = 256;
@@ -125,7 +132,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
-        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_jelem.release(); d_dv_colmap.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
@@ -717,6 +724,99 @@ int gst_set_param_map(gst_plan* p, int32_t n_params, const int32_t* kind, const 
     return GST_OK;
 }
 
+int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t* kind, const int32_t* obj,
+                   const int32_t* n_cols, const int64_t* param_idx, const double* deriv)
+{
+    if (!p || n_params < 0 || n_objs < 0) return fail(GST_EINVAL, "bad argument");
+    p->cached_kind = 0;
+    if (n_objs == 0) { p->derivs_set = false; return GST_OK; }
+    if (!kind || !obj || !n_cols || !param_idx || !deriv) return fail(GST_EINVAL, "bad argument");
+    const int D = p->hp.D;
+    std::vector<int64_t> off_c((size_t)n_objs + 1, 0), off_d((size_t)n_objs + 1, 0);
+    for (int32_t o = 0; o < n_objs; o++) {
+        const int k = kind[o];
+        const int nobj = k == GST_KIND_GATE ? p->hp.n_gates : k == GST_KIND_RHO ? p->hp.n_rhos : k == GST_KIND_EFFECT ? p->hp.n_effects : -1;
+        if (nobj < 0 || obj[o] < 0 || obj[o] >= nobj || n_cols[o] < 0) return fail(GST_EINVAL, "derivative object " + std::to_string(o) + " out of range");
+        off_c[o + 1] = off_c[o] + n_cols[o];
+        off_d[o + 1] = off_d[o] + (int64_t)(k == GST_KIND_GATE ? D * D : D) * n_cols[o];
+    }
+    for (int64_t c = 0; c < off_c[n_objs]; c++)
+        if (param_idx[c] < 0 || param_idx[c] >= n_params) return fail(GST_EINVAL, "derivative parameter index out of range");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    p->dv_kind.assign(kind, kind + n_objs); p->dv_obj.assign(obj, obj + n_objs); p->dv_ncols.assign(n_cols, n_cols + n_objs);
+    p->dv_param_idx.assign(param_idx, param_idx + off_c[n_objs]);
+    p->dv_off_cols = off_c; p->dv_off_deriv = off_d;
+    p->dv_n_params = n_params;
+    HIP_TRY(p->d_dv_deriv.ensure((size_t)std::max<int64_t>(off_d[n_objs], 1)));
+    if (off_d[n_objs] > 0) {
+        HIP_TRY(hipMemcpyAsync(p->d_dv_deriv.p, deriv, (size_t)off_d[n_objs] * 8, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    p->derivs_set = true;
+    return GST_OK;
+}
+
+// GST_DERIV_ANALYTIC with gst_set_derivs: element Jacobian (the `full` layout [rhos | effects | gates]) into scratch,
+// then one MFMA chain-rule product per object, accumulated into the requested parameter columns.
+int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
+                       int64_t n_param, double* d_probs_out)
+{
+    const gst::HostPlan& h = p->hp;
+    const int D = h.D;
+    const int64_t nE = h.n_elements;
+    const int64_t n_el = (int64_t)h.n_rhos * D + (int64_t)h.n_effects * D + (int64_t)h.n_gates * D * D;
+    for (int64_t c = 0; c < n_param; c++)
+        if (param_idx[c] < 0 || param_idx[c] >= p->dv_n_params) return fail(GST_EINVAL, "parameter index out of range");
+    std::vector<int32_t> dest_of((size_t)p->dv_n_params, -1);
+    for (int64_t c = 0; c < n_param; c++) {
+        if (dest_of[(size_t)param_idx[c]] >= 0) return fail(GST_EINVAL, "a parameter is requested twice (not supported with gst_set_derivs)");
+        dest_of[(size_t)param_idx[c]] = (int32_t)(dest_idx ? dest_idx[c] : c);
+    }
+    // element Jacobian through the ordinary analytic path with the identity element map
+    std::vector<int32_t> ek((size_t)n_el), eo((size_t)n_el), ee((size_t)n_el);
+    {
+        int64_t q = 0;
+        for (int r = 0; r < h.n_rhos; r++) for (int j = 0; j < D; j++, q++) { ek[q] = GST_KIND_RHO; eo[q] = r; ee[q] = j; }
+        for (int e = 0; e < h.n_effects; e++) for (int j = 0; j < D; j++, q++) { ek[q] = GST_KIND_EFFECT; eo[q] = e; ee[q] = j; }
+        for (int g = 0; g < h.n_gates; g++) for (int j = 0; j < D * D; j++, q++) { ek[q] = GST_KIND_GATE; eo[q] = g; ee[q] = j; }
+    }
+    std::vector<int64_t> all((size_t)n_el);
+    for (int64_t q = 0; q < n_el; q++) all[(size_t)q] = q;
+    HIP_TRY(p->d_jelem.ensure((size_t)std::max<int64_t>(nE * n_el, 1)));
+    p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
+    p->cached_kind = 0;
+    int rc = run_dprobs_analytic(p, p->d_jelem.p, n_el, all.data(), nullptr, n_el, d_probs_out);
+    p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
+    p->cached_kind = 0;
+    if (rc) return rc;
+    if (n_param == 0) return GST_OK;
+    // zero the requested columns, then accumulate object by object
+    bool window = true;
+    for (int64_t c = 1; dest_idx && c < n_param; c++) window = window && dest_idx[c] == dest_idx[0] + c;
+    if (window) {
+        const int64_t d0 = dest_idx ? dest_idx[0] : 0;
+        HIP_TRY(hipMemset2DAsync(d_out + d0, (size_t)ld * 8, 0, (size_t)n_param * 8, (size_t)nE, p->stream));
+    } else {
+        for (int64_t c = 0; c < n_param; c++) HIP_TRY(hipMemset2DAsync(d_out + dest_idx[c], (size_t)ld * 8, 0, 8, (size_t)nE, p->stream));
+    }
+    const int64_t base_rho = 0, base_eff = (int64_t)h.n_rhos * D, base_gate = base_eff + (int64_t)h.n_effects * D;
+    HIP_TRY(p->d_dv_colmap.ensure((size_t)std::max<int64_t>(p->dv_off_cols.back(), 1)));
+    std::vector<int32_t> colmap((size_t)p->dv_off_cols.back());
+    for (size_t c = 0; c < colmap.size(); c++) colmap[c] = dest_of[(size_t)p->dv_param_idx[c]];
+    if (!colmap.empty()) HIP_TRY(hipMemcpyAsync(p->d_dv_colmap.p, colmap.data(), colmap.size() * 4, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));          // `colmap` goes out of scope
+    for (size_t o = 0; o < p->dv_kind.size(); o++) {
+        const int k = p->dv_kind[o];
+        const int K = k == GST_KIND_GATE ? D * D : D;
+        const int64_t a0 = (k == GST_KIND_GATE ? base_gate : k == GST_KIND_RHO ? base_rho : base_eff) + (int64_t)p->dv_obj[o] * K;
+        HIP_TRY(gst::launch_chain_rule_gemm(p->d_jelem.p, n_el, a0, K, p->d_dv_deriv.p + p->dv_off_deriv[o], p->dv_ncols[o],
+                                            p->d_dv_colmap.p + p->dv_off_cols[o], d_out, ld, nE, p->stream));
+        p->last_launches++;
+    }
+    return GST_OK;
+}
+
 int gst_fill_probs_dev(gst_plan* p, double* d_out)
 {
     int rc = begin_call(p);
@@ -745,9 +845,15 @@ int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
 {
     int rc = begin_call(p);
     if (rc) return rc;
-    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!d_out && n_param > 0) return fail(GST_EINVAL, "d_out is NULL");
+    if (p->derivs_set) {
+        if (mode != GST_DERIV_ANALYTIC) return fail(GST_EUNSUPPORTED, "general parameterisations (gst_set_derivs) exist in GST_DERIV_ANALYTIC only");
+        if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
+        if ((rc = run_dprobs_general(p, d_out, ld, param_idx, dest_idx, n_param, d_probs_out))) return rc;
+        return end_call(p, false);
+    }
+    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
     if ((rc = check_params(p, param_idx, n_param))) return rc;
     if (mode == GST_DERIV_ANALYTIC) rc = run_dprobs_analytic(p, d_out, ld, param_idx, dest_idx, n_param, d_probs_out);
     else rc = run_dprobs_fd(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out, nullptr, 0);
@@ -760,14 +866,18 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
 {
     int rc = begin_call(p);
     if (rc) return rc;
-    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!out && n_param > 0) return fail(GST_EINVAL, "out is NULL");
-    if ((rc = check_params(p, param_idx, n_param))) return rc;
+    if (p->derivs_set && mode != GST_DERIV_ANALYTIC)
+        return fail(GST_EUNSUPPORTED, "general parameterisations (gst_set_derivs) exist in GST_DERIV_ANALYTIC only");
+    if (!p->derivs_set && !p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
+    if (!p->derivs_set && (rc = check_params(p, param_idx, n_param))) return rc;
+    if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
     const int64_t nE = p->hp.n_elements;
     // device staging is dense [nE][n_param]; scattered into the caller's (ld, dest_idx) window on the host
     HIP_TRY(p->d_out.ensure((size_t)nE * std::max<int64_t>(n_param, 1)));
-    if (mode == GST_DERIV_ANALYTIC) rc = run_dprobs_analytic(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
+    if (p->derivs_set) rc = run_dprobs_general(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
+    else if (mode == GST_DERIV_ANALYTIC) rc = run_dprobs_analytic(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
     else rc = run_dprobs_fd(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr, nullptr, 0);
     if (rc) return rc;
     // D2H into the caller's (ld, dest_idx) window.  A contiguous destination window -- the `dest_param_slice` of the

@@ -107,6 +107,10 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
 hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs,
                       double* y, hipStream_t s);
 
+// C[:, colmap[j]] += A[:, a_col0 : a_col0 + K] . B[:, j]  (B row-major [K][n]; colmap[j] < 0: skip) -- MFMA fp64
+hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, int K, const double* B, int n, const int32_t* colmap,
+                                  double* C, int64_t ldC, int64_t n_rows, hipStream_t s);
+
 // Element-wise objective maps; `part` receives n_blocks partial sums of the terms.
 hipError_t launch_objective_rows(int kind, double* probs, const double* counts, const double* totals, int64_t n, double min_p,
                                  double radius, double clip_lo, double clip_hi, double* lsvec, double* rowscale,

@@ -210,6 +210,61 @@ hipError_t launch_objective_rows(int kind, double* probs, const double* counts, 
     return hipGetLastError();
 }
 
+// Chain rule of general parameterisations (gst_set_derivs): C[:, colmap[j]] += A[:, a_col0 : a_col0 + K] . B[:, j]
+// with A the element Jacobian (row-major, ldA), B = d(element)/d(parameter) of one object (row-major [K][n]).  One
+// wavefront = 16 rows x 64 columns, v_mfma_f64_16x16x4_f64; operands straight from memory in the MFMA layouts.
+__global__ __launch_bounds__(256) void chain_rule_gemm_kernel(const double* __restrict__ A, int64_t ldA, int64_t a_col0, int K,
+                                                              const double* __restrict__ B, int n,
+                                                              const int32_t* __restrict__ colmap, double* __restrict__ C,
+                                                              int64_t ldC, int64_t n_rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tiles_n = (n + 63) / 64;
+    const int64_t r0 = (wave / tiles_n) * 16;
+    const int c0 = (int)(wave % tiles_n) * 64;
+    if (r0 >= n_rows) return;
+    const int i = lane & 15, kk = lane >> 4;
+    d4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    const bool row_ok = r0 + i < n_rows;
+    const double* arow = A + (row_ok ? r0 + i : 0) * ldA + a_col0;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + kk;
+        const double a = (row_ok && k < K) ? arow[k] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int col = c0 + 16 * t + i;
+            const double b = (k < K && col < n) ? B[(int64_t)k * n + col] : 0.0;
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int col = c0 + 16 * t + i;
+        const int32_t cc = col < n ? colmap[col] : -1;
+        if (cc < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t row = r0 + kk + 4 * r;
+            if (row < n_rows) C[row * ldC + cc] += acc[t][r];
+        }
+    }
+}
+
+hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, int K, const double* B, int n, const int32_t* colmap,
+                                  double* C, int64_t ldC, int64_t n_rows, hipStream_t s)
+{
+    if (n <= 0 || n_rows <= 0 || K <= 0) return hipSuccess;
+    const int64_t waves = ((n_rows + 15) / 16) * ((n + 63) / 64);
+    const int64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(chain_rule_gemm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, A, ldA, a_col0, K, B, n, colmap, C, ldC, n_rows);
+    return hipGetLastError();
+}
+
 int jtj_num_slabs(int64_t n_rows, int n_cols)
 {
     const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;

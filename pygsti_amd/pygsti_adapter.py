@@ -16,9 +16,11 @@ The per-atom device plan is built once from the atom's prefix table (`atom.table
 the atom; each call only re-uploads the dense model arrays (the reference re-marshals the whole
 layout on every call, mapforwardsim_calc_densitymx.pyx:170-181).
 
-Scope: dense `densitymx` models whose members are fully parameterised (one parameter per dense
-element: FullArbitraryOp / FullState / FullPOVMEffect).  Anything else raises NotImplementedError --
-there is no silent fallback to the CPU path.
+Scope: `densitymx` models whose members can be densified.  Fully parameterised members (one parameter
+per dense element: FullArbitraryOp / FullState / FullPOVMEffect) run in both derivative modes and for
+Hessians; any other parameterisation (full TP, CPTPLND, ...) runs probabilities and, with
+`derivative_mode="analytic"`, Jacobians through the members' `deriv_wrt_params()` (gst_set_derivs).
+What is not covered raises NotImplementedError -- there is no silent fallback to the CPU path.
 """
 import numpy as np
 
@@ -75,6 +77,25 @@ def atom_param_map(model, atom):
     return kind, obj, elem
 
 
+def atom_derivs(model, atom):
+    """[(kind, object, gpindices, deriv_wrt_params [n_elem, n])] of every member the atom uses -- the input of
+    gst_set_derivs for parameterisations that are not one-parameter-per-element (TP, CPTP, ...), exactly what
+    MatrixForwardSimulator._doperation consumes (matrixforwardsim.py:126-190)."""
+    D = model.dim
+    out = []
+    for k, labels, typ in ((_lib.KIND_GATE, list(atom.op_labels), "op"), (_lib.KIND_RHO, list(atom.rho_labels), "prep"),
+                           (_lib.KIND_EFFECT, atom._hip_eff_labels, "povm")):
+        n_el = D * D if k == _lib.KIND_GATE else D
+        for oi, lbl in enumerate(labels):
+            member = model._circuit_layer_operator(lbl, typ)
+            idx = member.gpindices_as_array()
+            if len(idx) == 0:
+                continue
+            dm = np.ascontiguousarray(np.real(member.deriv_wrt_params()), dtype=np.float64).reshape(n_el, len(idx))
+            out.append((k, oi, np.asarray(idx, np.int64), dm))
+    return out
+
+
 def atom_plan(model, atom, device=-1, target_tasks=0):
     """The libgstfwd plan of a `_MapCOPALayoutAtom`, built from its prefix table and cached on the atom."""
     plan = getattr(atom, "_hip_plan", None)
@@ -129,12 +150,30 @@ class HipMapForwardSimulator(_MapForwardSimulator):
                                      self._hip_device, self.derivative_mode)
         return out
 
-    def _prepare(self, layout_atom):
+    def _prepare(self, layout_atom, derivatives=False):
         plan = atom_plan(self.model, layout_atom, self._hip_device)
         plan.set_model(*atom_arrays(self.model, layout_atom))
-        if plan.n_params != self.model.num_params or getattr(layout_atom, "_hip_pmap_model", None) is not self.model:
-            plan.set_param_map(*atom_param_map(self.model, layout_atom))
+        if not derivatives:
+            return plan
+        if getattr(layout_atom, "_hip_pmap_model", None) is not self.model:
+            try:
+                layout_atom._hip_pmap = atom_param_map(self.model, layout_atom)     # one parameter per dense element
+            except NotImplementedError:
+                layout_atom._hip_pmap = None                                        # TP, CPTP, ...: chain rule
             layout_atom._hip_pmap_model = self.model
+        if layout_atom._hip_pmap is not None:
+            if plan.n_params != self.model.num_params or getattr(plan, "_hip_mode", None) != "elements":
+                plan.set_derivs(self.model.num_params, [])
+                plan.set_param_map(*layout_atom._hip_pmap)
+                plan._hip_mode = "elements"
+        else:
+            if self.derivative_mode != "analytic":
+                raise NotImplementedError(
+                    "this model is not fully parameterised: finite differences over its parameters are not on the device; "
+                    "use HipMapForwardSimulator(derivative_mode='analytic') (exact derivatives through deriv_wrt_params)")
+            # (re-sent every call: the derivatives of a non-linear parameterisation move with the parameters)
+            plan.set_derivs(self.model.num_params, atom_derivs(self.model, layout_atom))
+            plan._hip_mode = "derivs"
         return plan
 
     def _bulk_fill_probs_atom(self, array_to_fill, layout_atom, resource_alloc):
@@ -145,7 +184,7 @@ class HipMapForwardSimulator(_MapForwardSimulator):
             array_to_fill[:] = plan.fill_probs()
 
     def _bulk_fill_dprobs_atom(self, array_to_fill, dest_param_slice, layout_atom, param_slice, resource_alloc):
-        plan = self._prepare(layout_atom)
+        plan = self._prepare(layout_atom, derivatives=True)
         nP = self.model.num_params
         pidx = np.arange(nP) if param_slice is None else _slct.to_array(param_slice)
         didx = None if dest_param_slice is None else _slct.to_array(dest_param_slice)
@@ -154,7 +193,9 @@ class HipMapForwardSimulator(_MapForwardSimulator):
 
     def _bulk_fill_hprobs_atom(self, array_to_fill, dest_param_slice1, dest_param_slice2, layout_atom,
                                param_slice1, param_slice2, resource_alloc):
-        plan = self._prepare(layout_atom)
+        plan = self._prepare(layout_atom, derivatives=True)
+        if getattr(plan, "_hip_mode", None) != "elements":
+            raise NotImplementedError("Hessians on the device need a fully parameterised model in this round")
         nP = self.model.num_params
         i1 = np.arange(nP) if param_slice1 is None else _slct.to_array(param_slice1)
         i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)

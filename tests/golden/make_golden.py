@@ -37,7 +37,7 @@ def _label_str(lbl):
 
 
 def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hprobs=False,
-              hprobs_blk=None, circuit_subset_for_matrix=None, extra=None):
+              hprobs_blk=None, circuit_subset_for_matrix=None, extra=None, general_params=False):
     """Build a 1-atom Map layout for `circuits`, run the reference, save everything."""
     assert model.sim.calclib.__name__.endswith('calc_densitymx'), "reference Cython path not built!"
     model = model.copy()
@@ -73,6 +73,8 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
             idx = member.gpindices_as_array()
             assert len(idx) == member.num_params
             n_el = D * D if kind == 0 else D
+            if general_params:
+                continue      # TP / CPTP ...: parameters are not dense elements; see the `dv_*` arrays below
             assert len(idx) == n_el, "fixture generator assumes `full` parameterisation"
             pkind[idx] = kind
             pobj[idx] = oi
@@ -88,6 +90,21 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
             assert effects[pobj[p]].flat[pelem[p]] == paramvec[p]
         else:
             pass  # parameter of a gate/effect this atom never applies: kind -1, derivative exactly 0
+
+    # ---- general parameterisations: d(dense element)/d(parameter) of every object, as the reference's members
+    # return it (modelmember.deriv_wrt_params(), consumed by matrixforwardsim.py:_doperation / _dprobs_from_rho_e)
+    dv = {}
+    if general_params:
+        k_l, o_l, n_l, pi_l, d_l = [], [], [], [], []
+        for kind, labels, typ in ((0, op_labels, 'op'), (1, rho_labels, 'prep'), (2, eff_labels, 'povm')):
+            for oi, lbl in enumerate(labels):
+                member = model._circuit_layer_operator(lbl, typ)
+                dm = np.ascontiguousarray(np.real(member.deriv_wrt_params()), dtype=np.float64)
+                idx = member.gpindices_as_array()
+                assert dm.shape == ((D * D if kind == 0 else D), len(idx))
+                k_l.append(kind); o_l.append(oi); n_l.append(len(idx)); pi_l.append(idx); d_l.append(dm.ravel())
+        dv = dict(dv_kind=np.array(k_l, np.int32), dv_obj=np.array(o_l, np.int32), dv_ncols=np.array(n_l, np.int32),
+                  dv_param_idx=np.concatenate(pi_l).astype(np.int64), dv_deriv=np.concatenate(d_l))
 
     # ---- reference prefix table as flat ints -----------------------------------------
     op_lookup = {l: i for i, l in enumerate(op_labels)}
@@ -223,6 +240,7 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
     )
     if extra:
         meta.update(extra)
+    meta.update(dv)
     meta.update(out)
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **meta)
@@ -240,7 +258,7 @@ def circuit_list_hash(circ_ptr, circ_gates):
 
 def main():
     from pygsti.modelpacks import smq1Q_XYI, smq2Q_XYICNOT
-    which = sys.argv[1:] or ['1q4', '1q4k', '1q128', '2q2', '2qdeep', 'designs']
+    which = sys.argv[1:] or ['1q4', '1q4k', '1q128', '2q2', '2qdeep', 'designs', 'tp']
 
     if '1q4' in which:   # BASELINE configs[0] / SURVEY C1: smq1Q_XYI L in {1,2,4}
         m = smq1Q_XYI.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
@@ -257,6 +275,19 @@ def main():
         m = smq1Q_XYI.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
         circs = list(smq1Q_XYI.create_gst_experiment_design(128).all_circuits_needing_data)
         dump_case('smq1Q_XYI_L128_depol', m, circs, want_matrix=True)
+
+    if 'tp' in which:    # general parameterisations (analytic mode + gst_set_derivs): TP and CPTP-constrained models
+        circs = list(smq1Q_XYI.create_gst_experiment_design(4).all_circuits_needing_data)
+        m = smq1Q_XYI.target_model("full TP").depolarize(op_noise=0.01, spam_noise=0.01)
+        dump_case('smq1Q_XYI_L4_TP', m, circs, general_params=True)
+        m = smq1Q_XYI.target_model("CPTPLND")
+        m.from_vector(m.to_vector() + 0.01 * np.random.default_rng(3).standard_normal(m.num_params))
+        dump_case('smq1Q_XYI_L4_CPTPLND', m, circs, general_params=True)
+        m = smq2Q_XYICNOT.target_model("full TP").depolarize(op_noise=0.01, spam_noise=0.01)
+        circs2 = list(smq2Q_XYICNOT.create_gst_experiment_design(1, lite=True).all_circuits_needing_data)
+        cols = np.sort(np.random.default_rng(5).choice(m.num_params, 120, replace=False))
+        dump_case('smq2Q_XYICNOT_L1_TP', m, circs2, dprobs_cols=cols, circuit_subset_for_matrix=list(range(0, len(circs2), 7)),
+                  general_params=True)
 
     if '2q2' in which:   # 2Q, D=16: every circuit of the L<=2 lite design, a spread of 96 columns
         m = smq2Q_XYICNOT.target_model().depolarize(op_noise=0.01, spam_noise=0.01)

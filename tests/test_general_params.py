@@ -1,0 +1,61 @@
+"""General parameterisations (TP, CPTP-constrained) in the analytic mode: d p / d parameter = (d p / d element) x the
+members' deriv_wrt_params, as MatrixForwardSimulator computes it.  Golden vectors: MatrixForwardSimulator.bulk_fill_dprobs
+on `full TP` / `CPTPLND` models, with the members' deriv_wrt_params() and gpindices captured next to them
+(tests/golden/make_golden.py, case 'tp')."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture, plan_from_fixture
+from oracle import oracle as O
+
+CASES = ["smq1Q_XYI_L4_TP", "smq1Q_XYI_L4_CPTPLND", "smq2Q_XYICNOT_L1_TP"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_chain_rule_matches_matrix_simulator(name):
+    fx = load_fixture(name)
+    J, P = O.analytic_dprobs_general(fx, fx["dprobs_cols"])
+    rows = fx["matrix_rows"]
+    assert np.abs(J[rows] - fx["dprobs_matrix"]).max() < 1e-12
+    assert np.abs(P[rows] - fx["probs_matrix"]).max() < 1e-13
+    # the fixtures are genuinely not `full`: parameters shared between objects (a POVM's effects), and for TP fewer
+    # parameters than dense elements
+    D = int(fx["D"])
+    n_el = (len(fx["rhos"]) + len(fx["effects"])) * D + len(fx["gates"]) * D * D
+    assert int(fx["nP"]) <= n_el and (not name.endswith("_TP") or int(fx["nP"]) < n_el)
+    pidx = fx["dv_param_idx"]
+    assert len(np.unique(pidx)) < len(pidx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_general_parameterisation_dprobs(name):
+    from pygsti_amd import _lib
+    fx = load_fixture(name)
+    pl = plan_from_fixture(fx)
+    nP = int(fx["nP"])
+    pl.set_derivs(nP, O.derivs_from_fixture(fx))
+    cols = fx["dprobs_cols"]
+    pr = np.empty(int(fx["nE"]))
+    J = pl.fill_dprobs(param_idx=cols, probs_out=pr, mode=_lib.DERIV_ANALYTIC)
+    rows = fx["matrix_rows"]
+    assert np.abs(J[rows] - fx["dprobs_matrix"]).max() < 1e-8          # the north-star bar; observed ~1e-14
+    if name.endswith("_TP"):      # dense members: the probabilities are the reference Map path's, bit for bit
+        assert np.abs(pr - fx["probs"]).max() == 0.0
+    else:                         # CPTPLND members act through composed (non-dense) reps in the reference; here their
+        assert np.abs(pr - fx["probs"]).max() < 1e-10   # dense superoperators are used
+    Jo, _ = O.analytic_dprobs_general(fx, cols)
+    assert np.abs(J - Jo).max() < 1e-11
+    # a column window with a destination offset, through the device-resident entry point
+    nE = int(fx["nE"])
+    sub = cols[3:3 + min(17, len(cols) - 3)]
+    out = np.full((nE, len(sub) + 6), -7.0)
+    pl.fill_dprobs(out=out, param_idx=sub, dest_idx=np.arange(len(sub)) + 4, mode=_lib.DERIV_ANALYTIC)
+    assert np.array_equal(out[:, 4:4 + len(sub)], J[:, 3:3 + len(sub)])
+    assert (out[:, :4] == -7.0).all() and (out[:, 4 + len(sub):] == -7.0).all()
+    # finite differences are refused loudly in this mode; clearing the derivatives restores the element map
+    with pytest.raises(Exception):
+        pl.fill_dprobs(param_idx=cols[:2], mode=_lib.DERIV_FD)
+    pl.set_derivs(nP, [])
+    J0 = pl.fill_dprobs(param_idx=np.arange(min(nP, 5)), mode=_lib.DERIV_FD)     # kind -1 everywhere: exact zeros
+    assert (J0 == 0).all()

@@ -50,10 +50,43 @@ def test_adapter_plan_matches_pygsti():
             model.sim.bulk_fill_probs(np.empty(layout.num_elements), layout)
 
 
-def test_adapter_rejects_non_full_parameterisations():
+def test_adapter_non_full_parameterisations():
+    """No element map for TP / CPTP members (loud), but their deriv_wrt_params feed gst_set_derivs: the arrays the
+    adapter extracts are the ones the committed fixture was generated with."""
     from pygsti.modelpacks import smq1Q_XYI
     model = smq1Q_XYI.target_model("CPTPLND")
-    model.sim = A.HipMapForwardSimulator()
+    model.sim = A.HipMapForwardSimulator(derivative_mode="analytic")
     layout = model.sim.create_layout(list(smq1Q_XYI.create_gst_experiment_design(1).all_circuits_needing_data))
+    atom = layout.atoms[0]
+    A.atom_plan(model, atom); A.atom_arrays(model, atom)
     with pytest.raises(NotImplementedError):
-        A.atom_plan(model, layout.atoms[0]); A.atom_arrays(model, layout.atoms[0]); A.atom_param_map(model, layout.atoms[0])
+        A.atom_param_map(model, atom)
+    objs = A.atom_derivs(model, atom)
+    D = model.dim
+    assert len(objs) == len(atom.op_labels) + len(atom.rho_labels) + len(atom._hip_eff_labels)
+    for k, oi, idx, dm in objs:
+        assert dm.shape == ((D * D if k == 0 else D), len(idx)) and idx.max() < model.num_params
+    # same extraction as the fixture generator's (tests/golden/make_golden.py 'tp'), on the TP model of the fixture
+    from conftest import load_fixture
+    from oracle import oracle as O
+    fx = load_fixture("smq1Q_XYI_L4_TP")
+    mtp = smq1Q_XYI.target_model("full TP").depolarize(op_noise=0.01, spam_noise=0.01)
+    mtp.sim = A.HipMapForwardSimulator(derivative_mode="analytic", num_atoms=1)
+    lay = mtp.sim.create_layout(list(smq1Q_XYI.create_gst_experiment_design(4).all_circuits_needing_data))
+    A.atom_plan(mtp, lay.atoms[0]); A.atom_arrays(mtp, lay.atoms[0])
+    atom_tp = lay.atoms[0]
+    mine = A.atom_derivs(mtp, atom_tp)
+    ref = O.derivs_from_fixture(fx)
+    assert len(mine) == len(ref)
+    # (effect indices follow the iteration order of a set, which differs between processes: match by label)
+    names_mine = {0: [str(l) for l in atom_tp.op_labels], 1: [str(l) for l in atom_tp.rho_labels], 2: [str(l) for l in atom_tp._hip_eff_labels]}
+    names_ref = {0: list(fx["op_labels"]), 1: list(fx["rho_labels"]), 2: list(fx["eff_labels"])}
+    by_label = {(k, names_ref[k][o]): (i, d) for k, o, i, d in ref}
+    for k, o, i, d in mine:
+        i2, d2 = by_label[(k, names_mine[k][o])]
+        assert np.array_equal(i, i2) and np.array_equal(d, d2)
+    if _lib.device_count() == 0:      # FD over a non-full model is refused before any device work
+        mtp.sim = A.HipMapForwardSimulator(derivative_mode="fd", num_atoms=1)
+        lay = mtp.sim.create_layout(list(smq1Q_XYI.create_gst_experiment_design(1).all_circuits_needing_data), array_types=("ep",))
+        with pytest.raises((NotImplementedError, _lib.GstDeviceError)):
+            mtp.sim.bulk_fill_dprobs(np.empty((lay.num_elements, mtp.num_params)), lay)
