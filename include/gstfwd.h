@@ -207,6 +207,20 @@ int gst_objective_rows_dev(gst_plan *plan, const gst_objective_desc *desc, doubl
                            const double *d_totals, int64_t n, double *d_lsvec, double *d_rowscale, double *d_terms,
                            double *sum_terms);
 
+/* One (n1 x n2) block of the objective's Hessian without moving the hprobs block off the device: what
+ * TimeIndependentMDCObjectiveFunction._construct_hessian does per rectangle (objectivefns.py:1640-1690) with
+ * _iter_atom_hprobs_by_rectangle (forwardsims/distforwardsim.py:304-340) and _hessian_from_block (:4914-4968):
+ *   out[i][j] = sum over this plan's elements e of
+ *                 hterms_e * dprobs[e][idx1[i]] * dprobs[e][idx2[j]]  +  dterms_e * hprobs[e][idx1[i]][idx2[j]]
+ * with the FD-of-FD hprobs and FD dprobs of gst_fill_hprobs / gst_fill_dprobs (step eps for both, as the reference's
+ * Map path), dterms / hterms the raw objective's first and second derivatives in the probabilities (chi^2 or Poisson
+ * dlogl, on the clipped probabilities when the interval is given).  d_counts / d_totals: device, per element.
+ * out: host, row-major [n1][n2]; atoms / ranks add their blocks.  The (nE x n1 x n2) hprobs block lives in device
+ * memory only for the duration of the call -- size the rectangles to fit. */
+int gst_objective_hessian_block(gst_plan *plan, const gst_objective_desc *desc, const double *d_counts,
+                                const double *d_totals, const int64_t *idx1, int64_t n1, const int64_t *idx2,
+                                int64_t n2, double eps, double *out);
+
 /* Plain device-buffer helpers on the plan's device, so that callers without any GPU framework can
  * keep results resident (bench.py, tests).  Buffers from any other allocator work equally. */
 int gst_device_malloc(gst_plan *plan, int64_t nbytes, void **d_ptr);

@@ -53,3 +53,34 @@ def objective_rows(kind, probs, counts, total_counts, min_prob_clip=1e-4, radius
         p5 = np.where(np.abs(ls) < 1e-100, 0.0, 0.5 / ls)
         rowscale = p5 * dterms
     return terms, ls, dterms, rowscale
+
+
+def objective_coeffs(kind, probs, counts, total_counts, min_prob_clip=1e-4, radius=1e-4):
+    """-> (dterms, hterms): first and second derivative of every term in its probability -- the coefficients of
+    _hessian_from_block (objectivefns.py:4914-4968).  chi2: base-class dterms / hterms over lsvec, dlsvec, hlsvec
+    (:631-669, 755-794, 1886-1921, 2086-2108); dlogl: RawPoissonPicDeltaLogLFunction.dterms / .hterms (:3098-3183)."""
+    p = np.asarray(probs, np.float64)
+    c = np.asarray(counts, np.float64)
+    N = np.asarray(total_counts, np.float64)
+    f = c / N
+    with np.errstate(all="ignore"):
+        if kind == CHI2:
+            cp = np.maximum(p, min_prob_clip)
+            w = np.sqrt(N / cp)
+            clipped = p < min_prob_clip
+            dw = np.where(clipped, 0.0, -0.5 * w / cp)
+            hw = np.where(clipped, 0.0, 0.75 * w / cp**2)
+            ls = (p - f) * w
+            dls = w + (p - f) * dw
+            hls = 2 * dw + (p - f) * hw
+            return 2 * ls * dls, 2 * (dls**2 + ls * hls)
+        if kind == DLOGL:
+            _, _, dterms, _ = objective_rows(kind, p, c, N, min_prob_clip, radius)
+            pos = np.where(p < min_prob_clip, min_prob_clip, p)
+            c1 = 0.5 * c / (min_prob_clip * min_prob_clip)
+            h = np.where(p < min_prob_clip, 2 * c1, c / pos**2)
+            a = radius
+            hzf = np.where(p >= a, 0.0, N * ((-2.0 / a**2) * p + 2.0 / a))
+            return dterms, np.where(c == 0, hzf, h)
+    raise ValueError("unknown objective kind")
+

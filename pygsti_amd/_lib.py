@@ -64,7 +64,7 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
            "gst_last_error", "gst_version"]
 
 _lib = None
@@ -95,6 +95,7 @@ def lib():
         L.gst_fill_jtf_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
         L.gst_set_derivs.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
         L.gst_objective_rows_dev.argtypes = [vp, C.POINTER(ObjectiveDesc), vp, vp, vp, i64, vp, vp, vp, C.POINTER(C.c_double)]
+        L.gst_objective_hessian_block.argtypes = [vp, C.POINTER(ObjectiveDesc), vp, vp, vp, i64, vp, i64, C.c_double, vp]
         L.gst_memcpy_h2d.argtypes = [vp, vp, vp, i64]
         L.gst_sync.argtypes = [vp]
         L.gst_device_malloc.argtypes = [vp, i64, C.POINTER(vp)]
@@ -299,6 +300,19 @@ class Plan:
                                            None if d_terms is None else C.c_void_p(int(d_terms)),
                                            C.byref(s) if want_sum else None))
         return s.value if want_sum else None
+
+    def objective_hessian_block(self, kind, d_counts, d_totals, idx1, idx2, eps=1e-5, min_prob_clip=1e-4, radius=1e-4,
+                                prob_clip_interval=None):
+        """(len(idx1), len(idx2)) block of the objective's Hessian, contracted over this plan's elements on the device
+        (gst_objective_hessian_block).  kind: 'chi2' | 'logl'."""
+        k = {"chi2": OBJ_CHI2, "logl": OBJ_POISSON_DLOGL}[kind] if isinstance(kind, str) else int(kind)
+        lo, hi = (0.0, 0.0) if prob_clip_interval is None else (float(prob_clip_interval[0]), float(prob_clip_interval[1]))
+        d = ObjectiveDesc(k, 0, float(min_prob_clip), float(radius), lo, hi)
+        i1, i2 = _i64(idx1), _i64(idx2)
+        out = np.zeros((len(i1), len(i2)), np.float64)
+        check(lib().gst_objective_hessian_block(self._h, C.byref(d), C.c_void_p(int(d_counts)), C.c_void_p(int(d_totals)),
+                                                _ptr(i1), len(i1), _ptr(i2), len(i2), float(eps), _ptr(out)))
+        return out
 
     def memcpy_h2d(self, d_ptr, arr, offset_bytes=0):
         arr = np.ascontiguousarray(arr)

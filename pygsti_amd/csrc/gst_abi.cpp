@@ -94,6 +94,7 @@ struct gst_plan {
     std::vector<int32_t> dv_kind, dv_obj, dv_ncols;
     std::vector<int64_t> dv_param_idx, dv_off_cols, dv_off_deriv;
     DevBuf<double> d_dv_deriv, d_jelem;
+    DevBuf<double> d_obj_dt, d_obj_ht, d_obj_pc, d_obj_tmp, d_hess_part, d_hess_out;   // objective Hessian blocks
     DevBuf<int32_t> d_dv_colmap;
     bool ana_mfma = true;               // D = 16 analytic mode on the MFMA path (GST_ANALYTIC_MFMA=0: the VALU kernel)
     int fd_split = 0;                   // gst_options.fd_split: 0 auto, 1 / 2 / 4 wavefronts per (task, 64 columns) pair
@@ -132,7 +133,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
-        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_jelem.release(); d_dv_colmap.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_jelem.release(); d_dv_colmap.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
@@ -903,16 +904,13 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     return GST_OK;
 }
 
-int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
-                    int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2, double eps)
+// FD-of-FD Hessian block into the device buffer d_H [nE][ld1][ld2] (mapforwardsim.py:394-438).  Leaves behind, on the
+// device: probabilities (d_pbase), FD dprobs over block 2 (d_dcol, [nE][n2]) and over block 1 (d_probs_tmp, [nE][n1]).
+static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
+                          int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2, double eps)
 {
-    int rc = begin_call(p);
-    if (rc) return rc;
-    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
-    if (!out && n1 > 0 && n2 > 0) return fail(GST_EINVAL, "out is NULL");
-    if ((rc = check_params(p, idx1, n1)) || (rc = check_params(p, idx2, n2))) return rc;
+    int rc;
     const int64_t nE = p->hp.n_elements;
-    if (n1 == 0 || n2 == 0) return end_call(p, true);
     // (1) dprobs over block 2 at theta (mapforwardsim.py:420-421), FD step = eps
     HIP_TRY(p->d_dcol.ensure((size_t)nE * n2));
     if ((rc = run_dprobs_fd(p, p->d_dcol.p, n2, idx2, nullptr, n2, eps, nullptr, nullptr, 0))) return rc;
@@ -967,12 +965,10 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     if ((rc = upload_i32(p->d_wave_rowidx, wave_rowidx, p->stream))) return rc;
     if ((rc = upload_i32(p->d_lane_colidx, lane_colidx, p->stream))) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
-    // dense device output [nE][n1'][n2'] in the caller's leading dimensions
-    HIP_TRY(p->d_out.ensure((size_t)nE * ld1 * ld2));
     gst::WalkArgs a;
     base_args(p, a);
     a.mode = gst::EMIT_HESS;
-    a.out = p->d_out.p; a.ld = ld1; a.ld2 = ld2; a.eps = eps;
+    a.out = d_H; a.ld = ld1; a.ld2 = ld2; a.eps = eps;
     a.prow = p->d_raw.p; a.ldrow = n1; a.dcol = p->d_dcol.p; a.lddcol = n2;
     a.pbase = p->d_pbase.p; a.base_cache = p->d_base_cache.p;
     a.lanes.col = p->d_lane[0].p;
@@ -981,9 +977,6 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     }
     a.wave_row = p->d_wave_row.p; a.wave_rowidx = p->d_wave_rowidx.p; a.lane_colidx = p->d_lane_colidx.p;
     a.n_pwaves = L.n_waves;
-    // rows/columns of the caller's block that this call does not own must survive: start from the caller's data
-    const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
-    if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
     if (rows) {
         a.rows_S = 2;
@@ -992,7 +985,70 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
         HIP_TRY(gst::launch_walk(p->hp.D, 2, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     p->last_launches++;
+    return GST_OK;
+}
+
+int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
+                    int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2, double eps)
+{
+    int rc = begin_call(p);
+    if (rc) return rc;
+    if (p->derivs_set) return fail(GST_EUNSUPPORTED, "Hessians need the one-parameter-per-element map (gst_set_derivs is set)");
+    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
+    if (!out && n1 > 0 && n2 > 0) return fail(GST_EINVAL, "out is NULL");
+    if ((rc = check_params(p, idx1, n1)) || (rc = check_params(p, idx2, n2))) return rc;
+    const int64_t nE = p->hp.n_elements;
+    if (n1 == 0 || n2 == 0) return end_call(p, true);
+    // dense device output [nE][n1'][n2'] in the caller's leading dimensions
+    HIP_TRY(p->d_out.ensure((size_t)nE * ld1 * ld2));
+    // rows/columns of the caller's block that this call does not own must survive: start from the caller's data
+    const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
+    if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
+    if ((rc = run_hprobs_dev(p, p->d_out.p, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2, eps))) return rc;
     HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));
+    return end_call(p, true);
+}
+
+int gst_objective_hessian_block(gst_plan* p, const gst_objective_desc* d, const double* d_counts, const double* d_totals,
+                                const int64_t* idx1, int64_t n1, const int64_t* idx2, int64_t n2, double eps, double* out)
+{
+    int rc = begin_call(p);
+    if (rc) return rc;
+    if (!d || !d_counts || !d_totals) return fail(GST_EINVAL, "bad argument");
+    if (d->kind != GST_OBJ_CHI2 && d->kind != GST_OBJ_POISSON_DLOGL) return fail(GST_EINVAL, "unknown objective kind");
+    if (!(d->min_prob_clip > 0.0) || (d->kind == GST_OBJ_POISSON_DLOGL && !(d->radius > 0.0)))
+        return fail(GST_EINVAL, "min_prob_clip and radius must be positive");
+    if (p->derivs_set) return fail(GST_EUNSUPPORTED, "Hessians need the one-parameter-per-element map (gst_set_derivs is set)");
+    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
+    if (!out && n1 > 0 && n2 > 0) return fail(GST_EINVAL, "out is NULL");
+    if ((rc = check_params(p, idx1, n1)) || (rc = check_params(p, idx2, n2))) return rc;
+    if (n1 > 0x7fffffff || n2 > 0x7fffffff) return fail(GST_EINVAL, "block too large");
+    const int64_t nE = p->hp.n_elements;
+    if (n1 == 0 || n2 == 0) return end_call(p, true);
+    HIP_TRY(p->d_out.ensure((size_t)nE * n1 * n2));
+    if ((rc = run_hprobs_dev(p, p->d_out.p, n1, n2, idx1, nullptr, n1, idx2, nullptr, n2, eps))) return rc;
+    // objective coefficients on the (optionally clipped) probabilities, then the contraction over elements
+    HIP_TRY(p->d_obj_dt.ensure((size_t)nE)); HIP_TRY(p->d_obj_ht.ensure((size_t)nE));
+    double* d_probs = p->d_pbase.p;
+    if (d->prob_clip_lo < d->prob_clip_hi) {
+        // _clip_probs (objectivefns.py:4766-4774) through the element-wise objective kernel, on a copy
+        HIP_TRY(p->d_obj_pc.ensure((size_t)nE)); HIP_TRY(p->d_obj_tmp.ensure((size_t)2 * nE));
+        HIP_TRY(hipMemcpyAsync(p->d_obj_pc.p, p->d_pbase.p, (size_t)nE * 8, hipMemcpyDeviceToDevice, p->stream));
+        const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (nE + 255) / 256));
+        HIP_TRY(p->d_obj_part.ensure((size_t)nb));
+        HIP_TRY(gst::launch_objective_rows(d->kind, p->d_obj_pc.p, d_counts, d_totals, nE, d->min_prob_clip, d->radius, d->prob_clip_lo,
+                                           d->prob_clip_hi, p->d_obj_tmp.p, p->d_obj_tmp.p + nE, nullptr, p->d_obj_part.p, nb, p->stream));
+        d_probs = p->d_obj_pc.p;
+    }
+    HIP_TRY(gst::launch_objective_coeffs(d->kind, d_probs, d_counts, d_totals, nE, d->min_prob_clip, d->radius, p->d_obj_dt.p,
+                                         p->d_obj_ht.p, p->stream));
+    const int n_slabs = gst::hessian_block_slabs(nE, (int)n1, (int)n2);
+    HIP_TRY(p->d_hess_part.ensure((size_t)n_slabs * n1 * n2));
+    HIP_TRY(p->d_hess_out.ensure((size_t)n1 * n2));
+    HIP_TRY(gst::launch_hessian_block(p->d_out.p, p->d_probs_tmp.p, p->d_dcol.p, p->d_obj_dt.p, p->d_obj_ht.p, nE, (int)n1, (int)n2,
+                                      p->d_hess_part.p, n_slabs, p->d_hess_out.p, p->stream));
+    p->last_launches += 2;
+    HIP_TRY(hipMemcpyAsync(out, p->d_hess_out.p, (size_t)n1 * n2 * 8, hipMemcpyDeviceToHost, p->stream));
     return end_call(p, true);
 }
 

@@ -111,6 +111,13 @@ hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_co
 hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, int K, const double* B, int n, const int32_t* colmap,
                                   double* C, int64_t ldC, int64_t n_rows, hipStream_t s);
 
+// Objective Hessian block from device-resident hprobs / dprobs blocks and the objective's dterms / hterms.
+hipError_t launch_objective_coeffs(int kind, const double* probs, const double* counts, const double* totals, int64_t n, double min_p,
+                                   double radius, double* dterms, double* hterms, hipStream_t s);
+int hessian_block_slabs(int64_t nE, int n1, int n2);
+hipError_t launch_hessian_block(const double* H, const double* d1, const double* d2, const double* dco, const double* hco, int64_t nE,
+                                int n1, int n2, double* part, int n_slabs, double* out, hipStream_t s);
+
 // Element-wise objective maps; `part` receives n_blocks partial sums of the terms.
 hipError_t launch_objective_rows(int kind, double* probs, const double* counts, const double* totals, int64_t n, double min_p,
                                  double radius, double clip_lo, double clip_hi, double* lsvec, double* rowscale,

@@ -17,6 +17,8 @@
 //     second kernel sums the slabs in a fixed order (deterministic, no atomics) and mirrors the triangle.
 #include "gst_kernels.hpp"
 
+#include <algorithm>
+
 namespace gst {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -207,6 +209,118 @@ hipError_t launch_objective_rows(int kind, double* probs, const double* counts, 
     (void)hipGetLastError();
     hipLaunchKernelGGL(objective_rows_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, kind, probs, counts, totals, n, min_p,
                        radius, clip_lo, clip_hi, lsvec, rowscale, terms_out, part);
+    return hipGetLastError();
+}
+
+// Second-derivative coefficients of the objective (the reference's raw_objfn.dterms / .hterms, objectivefns.py:631-669,
+// 755-794 with RawChi2Function.hlsvec :1886-1921 and _hweights :2086-2108; RawPoissonPicDeltaLogLFunction.dterms
+// :3098-3150 and .hterms :3152-3183) for the Hessian of the objective, element by element.
+__global__ void objective_coeffs_kernel(int kind, const double* __restrict__ probs, const double* __restrict__ counts,
+                                        const double* __restrict__ totals, int64_t n, double min_p, double radius,
+                                        double* __restrict__ dterms_out, double* __restrict__ hterms_out)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const double p = probs[k], c = counts[k], N = totals[k];
+        const double f = c / N;
+        double dterms, hterms;
+        if (kind == 0) {
+            const double cp = p > min_p ? p : min_p;
+            const double w = sqrt(N / cp);
+            const bool clipped = p < min_p;
+            const double dw = clipped ? 0.0 : -0.5 * w / cp;
+            const double hw = clipped ? 0.0 : 0.75 * w / (cp * cp);
+            const double ls = (p - f) * w;
+            const double dls = w + (p - f) * dw;
+            const double hls = 2 * dw + (p - f) * hw;
+            dterms = 2 * ls * dls;
+            hterms = 2 * (dls * dls + ls * hls);
+        } else {
+            const double pos = (p < min_p) ? min_p : p;
+            const double c0 = N - c / min_p;
+            const double c1 = 0.5 * c / (min_p * min_p);
+            const double a = radius;
+            const double d = (p < min_p) ? c0 + 2 * c1 * (p - min_p) : N - c / pos;
+            const double dzf = N * (p >= a ? 1.0 : (-1.0 / (a * a)) * (p * p) + 2 * p / a);
+            dterms = (c == 0) ? dzf : d;
+            const double h = (p < min_p) ? 2 * c1 : c / (pos * pos);
+            const double hzf = (p >= a) ? 0.0 : N * ((-2.0 / (a * a)) * p + 2.0 / a);
+            hterms = (c == 0) ? hzf : h;
+        }
+        dterms_out[k] = dterms;
+        hterms_out[k] = hterms;
+    }
+}
+
+hipError_t launch_objective_coeffs(int kind, const double* probs, const double* counts, const double* totals, int64_t n, double min_p,
+                                   double radius, double* dterms, double* hterms, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(objective_coeffs_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, s, kind, probs,
+                       counts, totals, n, min_p, radius, dterms, hterms);
+    return hipGetLastError();
+}
+
+// Hessian block of the objective from device-resident pieces (TimeIndependentMDCObjectiveFunction._hessian_from_block,
+// objectivefns.py:4914-4968):  out[i][j] = sum_e  hterms[e] * d1[e][i] * d2[e][j] + dterms[e] * H[e][i][j].
+// Thread = column j, 8 rows i per thread, one slab of elements per blockIdx.y; H is read exactly once, coalesced.
+constexpr int HB_IC = 8;
+__global__ __launch_bounds__(256) void hessian_block_kernel(const double* __restrict__ H, const double* __restrict__ d1,
+                                                           const double* __restrict__ d2, const double* __restrict__ dco,
+                                                           const double* __restrict__ hco, int64_t nE, int n1, int n2,
+                                                           int64_t slab, double* __restrict__ part)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.z * HB_IC;
+    const int64_t e0 = (int64_t)blockIdx.y * slab, e1 = (e0 + slab < nE) ? e0 + slab : nE;
+    if (j >= n2) return;
+    double acc[HB_IC];
+#pragma unroll
+    for (int t = 0; t < HB_IC; t++) acc[t] = 0.0;
+    for (int64_t e = e0; e < e1; e++) {
+        const double hd2 = hco[e] * d2[e * n2 + j];
+        const double dc = dco[e];
+        const double* Hrow = H + (e * n1 + i0) * (int64_t)n2 + j;
+        const double* d1row = d1 + e * n1 + i0;
+#pragma unroll
+        for (int t = 0; t < HB_IC; t++) {
+            if (i0 + t < n1) acc[t] = __builtin_fma(dc, Hrow[(int64_t)t * n2], __builtin_fma(hd2, d1row[t], acc[t]));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < HB_IC; t++)
+        if (i0 + t < n1) part[((int64_t)blockIdx.y * n1 + i0 + t) * n2 + j] = acc[t];
+}
+__global__ void hessian_block_reduce_kernel(const double* __restrict__ part, int n_slabs, int64_t total, double* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int k = 0; k < n_slabs; k++) s += part[(int64_t)k * total + i];
+        out[i] = s;
+    }
+}
+int hessian_block_slabs(int64_t nE, int n1, int n2)
+{
+    const int64_t tiles = (int64_t)((n2 + 255) / 256) * ((n1 + HB_IC - 1) / HB_IC);
+    int64_t slabs = (4096 + tiles - 1) / tiles;
+    if (slabs > (nE + 63) / 64) slabs = (nE + 63) / 64;
+    if (slabs < 1) slabs = 1;
+    if (slabs > 1024) slabs = 1024;
+    return (int)slabs;
+}
+hipError_t launch_hessian_block(const double* H, const double* d1, const double* d2, const double* dco, const double* hco, int64_t nE,
+                                int n1, int n2, double* part, int n_slabs, double* out, hipStream_t s)
+{
+    if (nE <= 0 || n1 <= 0 || n2 <= 0) return hipSuccess;
+    const int64_t slab = (nE + n_slabs - 1) / n_slabs;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(hessian_block_kernel, dim3((unsigned)((n2 + 255) / 256), (unsigned)n_slabs, (unsigned)((n1 + HB_IC - 1) / HB_IC)),
+                       dim3(256), 0, s, H, d1, d2, dco, hco, nE, n1, n2, slab, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t total = (int64_t)n1 * n2;
+    hipLaunchKernelGGL(hessian_block_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, (total + 255) / 256)), dim3(256), 0, s, part,
+                       n_slabs, total, out);
     return hipGetLastError();
 }
 

@@ -317,6 +317,35 @@ class HipMapForwardSimulator:
                     plan.device_free(d)
         return total
 
+    def bulk_fill_objective_hessian(self, hessian, layout, counts, total_counts, objective="logl", min_prob_clip=1e-4,
+                                    radius=1e-4, prob_clip_interval=None, row_block=16, max_block_bytes=64e9):
+        """The objective's Hessian (num_params x num_params) the way `_construct_hessian` assembles it from rectangles
+        (pygsti/objectivefns/objectivefns.py:1640-1690, 4914-4968): for every atom and every block of `row_block` rows,
+        FD-of-FD hprobs and FD dprobs are produced and contracted with the objective's dterms / hterms ON THE DEVICE
+        (gst_objective_hessian_block); only the block's row_block x num_params numbers come back.  `hessian` is summed
+        over this process's atoms (ranks all-reduce it, as `_gather_hessian` does).  Map-path semantics: both
+        derivative levels are finite differences with `hessian_eps`."""
+        nP = self.model.num_params
+        hessian[...] = 0.0
+        counts = np.asarray(counts, np.float64)
+        total_counts = np.asarray(total_counts, np.float64)
+        cols = np.arange(nP, dtype=np.int64)
+        for atom in layout.atoms:
+            plan = self._prepare_atom(atom)
+            nE = atom.num_elements
+            es = atom.element_slice
+            rb = int(max(1, min(row_block, max_block_bytes // max(1, nE * nP * 8))))
+            d_c = plan.device_malloc(max(nE * 8, 8)); d_N = plan.device_malloc(max(nE * 8, 8))
+            try:
+                plan.memcpy_h2d(d_c, counts[es]); plan.memcpy_h2d(d_N, total_counts[es])
+                for r0 in range(0, nP, rb):
+                    rows = np.arange(r0, min(nP, r0 + rb), dtype=np.int64)
+                    hessian[rows, :] += plan.objective_hessian_block(objective, d_c, d_N, rows, cols, self.hessian_eps,
+                                                                     min_prob_clip, radius, prob_clip_interval)
+            finally:
+                plan.device_free(d_c); plan.device_free(d_N)
+        return hessian
+
     # -- convenience (forwardsim.py:171-277, 415-582) -------------------------------------------------------------------
     def bulk_probs(self, circuits, clip_to=None, resource_alloc=None, smartc=None):
         layout = self.create_layout(circuits, array_types=("e",))

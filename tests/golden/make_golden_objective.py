@@ -30,10 +30,12 @@ with np.errstate(all="ignore"):
     out["chi2_lsvec"] = chi2.lsvec(probs, counts, N, freqs)
     out["chi2_dterms"] = chi2.dterms(probs, counts, N, freqs)
     out["chi2_dlsvec"] = chi2.dlsvec(probs, counts, N, freqs)
+    out["chi2_hterms"] = chi2.hterms(probs, counts, N, freqs)
     pl = O.RawPoissonPicDeltaLogLFunction({"min_prob_clip": 1e-4, "radius": 1e-4})
     out["logl_terms"] = pl.terms(probs, counts, N, freqs)
     out["logl_lsvec"] = pl.lsvec(probs, counts, N, freqs)
     out["logl_dterms"] = pl.dterms(probs, counts, N, freqs)
+    out["logl_hterms"] = pl.hterms(probs, counts, N, freqs)
     ls = out["logl_lsvec"]
     p5 = 0.5 / ls
     p5[np.abs(ls) < 1e-100] = 0.0

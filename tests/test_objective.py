@@ -114,3 +114,60 @@ def test_gpu_fused_lsq_step(objective):
     assert np.allclose(jtj, ref_jtj, rtol=1e-10, atol=1e-10 * np.abs(ref_jtj).max())
     assert np.allclose(jtf, ref_jtf, rtol=1e-10, atol=1e-10 * np.abs(ref_jtf).max())
     assert np.array_equal(jtj, jtj.T)
+
+
+@pytest.mark.parametrize("kind", [OO.CHI2, OO.DLOGL])
+def test_objective_coeffs_oracle_matches_reference_vectors(kind):
+    g = np.load(VEC)
+    d, h = OO.objective_coeffs(kind, g["probs"], g["counts"], g["total_counts"], float(g["min_prob_clip"]), float(g["radius"]))
+    assert np.array_equal(d, g[NAMES[kind] + "_dterms"]) and np.array_equal(h, g[NAMES[kind] + "_hterms"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("objective", ["chi2", "logl"])
+def test_gpu_objective_hessian_block(objective):
+    """A block of the objective's Hessian contracted on the device == _hessian_from_block's formula
+    (objectivefns.py:4914-4968) evaluated with numpy on the host-side hprobs / dprobs of the same plan."""
+    from pygsti_amd import modelpacks
+    from pygsti_amd.layout import HipCOPALayout
+    pack = modelpacks.smq1Q_XYI
+    model = pack.target_model().depolarize(op_noise=0.02, spam_noise=0.01)
+    circuits = pack.create_gst_circuits(8)
+    layout = HipCOPALayout(circuits, model, num_atoms=1, devices=[0], rank=0, size=1)
+    plan = layout.atoms[0].plan()
+    plan.set_model(*layout.model_arrays(model)); plan.set_param_map(*layout.param_map(model))
+    nE, nP = layout.num_elements, model.num_params
+    rng = np.random.default_rng(17)
+    i1 = np.sort(rng.choice(nP, 11, replace=False)); i2 = np.arange(nP)
+    eps = 1e-5
+    probs = np.empty(nE)
+    J = plan.fill_dprobs(param_idx=np.arange(nP), eps=eps, probs_out=probs)      # the Hessian path differentiates with eps
+    H = plan.fill_hprobs(idx1=i1, idx2=i2, eps=eps)
+    N = np.full(nE, 500.0)
+    counts = rng.binomial(500, np.clip(probs + rng.normal(0, 0.02, nE), 0, 1)).astype(np.float64)
+    counts[::17] = 0.0
+    kind = OO.CHI2 if objective == "chi2" else OO.DLOGL
+    dt, ht = OO.objective_coeffs(kind, probs, counts, N)
+    ref = np.einsum("e,ei,ej->ij", ht, J[:, i1], J[:, i2]) + np.einsum("e,eij->ij", dt, H)
+    d_c = plan.device_malloc(nE * 8); d_N = plan.device_malloc(nE * 8)
+    try:
+        plan.memcpy_h2d(d_c, counts); plan.memcpy_h2d(d_N, N)
+        got = plan.objective_hessian_block(objective, d_c, d_N, i1, i2, eps=eps)
+    finally:
+        plan.device_free(d_c); plan.device_free(d_N)
+    assert got.shape == (len(i1), nP)
+    assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+    # the whole Hessian through the simulator's rectangle loop (two atoms, 7-row blocks) is the sum of such blocks
+    from pygsti_amd.forwardsim import HipMapForwardSimulator
+    sim = HipMapForwardSimulator(model, num_atoms=2, hessian_eps=eps)
+    lay2 = sim.create_layout(circuits, array_types=("epp",))
+    pr2 = np.empty(nE); J2 = np.empty((nE, nP)); sim.bulk_fill_dprobs(J2, lay2, pr_array_to_fill=pr2)
+    c2 = rng.binomial(500, np.clip(pr2, 0, 1)).astype(np.float64)
+    full = np.empty((nP, nP))
+    sim.bulk_fill_objective_hessian(full, lay2, c2, N, objective=objective, row_block=7)
+    sim_fd = HipMapForwardSimulator(model, num_atoms=2, derivative_eps=eps, hessian_eps=eps)
+    Jfd = np.empty((nE, nP)); sim_fd.bulk_fill_dprobs(Jfd, lay2)
+    Hfull = np.empty((nE, nP, nP)); sim_fd.bulk_fill_hprobs(Hfull, lay2)
+    dt2, ht2 = OO.objective_coeffs(kind, pr2, c2, N)
+    ref2 = np.einsum("e,ei,ej->ij", ht2, Jfd, Jfd) + np.einsum("e,eij->ij", dt2, Hfull)
+    assert np.abs(full - ref2).max() <= 1e-10 * np.abs(ref2).max()

@@ -15,6 +15,17 @@ plan.set_model(*layout.model_arrays(model)); plan.set_param_map(*layout.param_ma
 nE = layout.num_elements
 st = plan.stats()
 print("design: %d circuits, nE=%d, applies/pass %d, tasks %d" % (len(circuits), nE, st["applies_per_pass"], st["n_tasks"]))
+rng = np.random.default_rng(0)
+pb = plan.fill_probs()
+d_c = plan.device_malloc(nE * 8); d_N = plan.device_malloc(nE * 8)
+plan.memcpy_h2d(d_c, rng.binomial(1000, np.clip(pb, 0, 1)).astype(np.float64)); plan.memcpy_h2d(d_N, np.full(nE, 1000.0))
+for n1, n2 in ((16, 1616),):
+    i1 = np.arange(80, 80 + n1); i2 = np.arange(0, n2)
+    plan.objective_hessian_block("logl", d_c, d_N, i1, i2)
+    t0 = time.perf_counter()
+    Hb = plan.objective_hessian_block("logl", d_c, d_N, i1, i2)
+    t = time.perf_counter() - t0
+    print("objective Hessian block %d x %d contracted on the device: %.1f ms in all (%d numbers come back)" % (n1, n2, 1e3 * t, n1 * n2))
 for n1, n2 in ((4, 256), (8, 512), (16, 1616)):
     i1 = np.arange(80, 80 + n1); i2 = np.arange(0, n2) if n2 == 1616 else np.arange(80, 80 + n2)
     H = plan.fill_hprobs(idx1=i1, idx2=i2, eps=1e-5)
