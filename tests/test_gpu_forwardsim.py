@@ -124,3 +124,53 @@ def test_full_size_properties():
     p = outs[0][0].reshape(-1, 4)
     assert np.abs(p.sum(axis=1) - 1.0).max() < 1e-12 and p.min() > -1e-12
     assert np.isfinite(outs[0][1]).all()
+
+
+def test_baseline_size_checksums():
+    """The bench workload itself (2Q L<=1024 FULL design: 136,275 circuits x 1,616 parameters, a 7 GB Jacobian that
+    stays in HBM) through size-independent properties: probabilities of every circuit sum to 1; J^T f -- a checksum of
+    every Jacobian element, reduced on the device in a fixed order -- is BITWISE the same for two different task
+    decompositions (any prefix-sharing schedule gives the same states); it is linear in f; and the
+    analytic Jacobian's checksum agrees with the finite-difference one to the FD truncation error."""
+    from pygsti_amd import _lib
+    from pygsti_amd.layout import HipCOPALayout
+    pack = MP.smq2Q_XYICNOT
+    model = pack.target_model().depolarize(0.01, 0.01)
+    circuits = pack.create_gst_circuits(1024, lite=False)
+    assert len(circuits) == 136275
+    nP = model.num_params
+    pidx = np.arange(nP, dtype=np.int64)
+    rng = np.random.default_rng(42)
+    sums = {}
+    for tt in (0, 777):
+        layout = HipCOPALayout(circuits, model, num_atoms=1, devices=[0], rank=0, size=1, target_tasks=tt)
+        plan = layout.atoms[0].plan()
+        plan.set_model(*layout.model_arrays(model)); plan.set_param_map(*layout.param_map(model))
+        nE = layout.num_elements
+        assert nE == 545100
+        f1 = rng.standard_normal(nE) if tt == 0 else f1
+        f2 = rng.standard_normal(nE) if tt == 0 else f2
+        bufs = [plan.device_malloc(n) for n in (nE * nP * 8, nE * 8, nE * 8, nP * 8)]
+        d_J, d_p, d_f, d_y = bufs
+        try:
+            def jtf(f):
+                plan.memcpy_h2d(d_f, f)
+                plan.fill_jtf_dev(d_J, nE, nP, nP, d_f, d_y)
+                return plan.memcpy_d2h(np.empty(nP), d_y)
+            plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_FD)
+            probs = plan.memcpy_d2h(np.empty(nE), d_p)
+            y1, y2, y12 = jtf(f1), jtf(f2), jtf(f1 + f2)
+            sums[tt] = (probs, y1)
+            if tt == 0:
+                assert np.abs(probs.reshape(-1, 4).sum(axis=1) - 1.0).max() < 1e-12 and probs.min() > -1e-12
+                assert np.abs(y12 - (y1 + y2)).max() <= 1e-9 * np.abs(y1).max()          # linearity of the checksum
+                plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_ANALYTIC)
+                ya = jtf(f1)
+                assert np.abs(ya - y1).max() <= 2e-4 * np.abs(ya).max()                   # FD truncation (eps = 1e-7, depth 1030)
+                assert np.abs(ya - y1).max() > 0
+        finally:
+            for b in bufs:
+                plan.device_free(b)
+        plan.close()
+    assert_bitwise(sums[0][0], sums[777][0], "probabilities vs task decomposition at full size")
+    assert_bitwise(sums[0][1], sums[777][1], "J^T f checksum vs task decomposition at full size")
