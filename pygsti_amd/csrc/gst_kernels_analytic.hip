@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(dest_l >> 32), 16 * x);
                 dest_u[x] = (int64_t)(((uint64_t)hi << 32) | lo);
             }
+            const bool fast4 = nE == 4 && e_u[0] == 0 && e_u[1] == 1 && e_u[2] == 2 && e_u[3] == 3;
             if (on) {
                 // dp/dE[a] = F_n[a] for the outcome's own effect, exact zeros for the others; dp/drho[b] = B_0[b]
                 const double FL = a.base_cache[(int64_t)fleaf * D + i];
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                     const int32_t ce = a.colmap_eff[e2 * D + i];
                     if (ce >= 0) a.out[dest_l * a.ld + ce] = (e2 == e_l) ? FL : 0.0;
                 }
-                const double B0 = a.rev_cache[((int64_t)rleaf * nE + e_l) * D + i];
+                const double B0 = a.rev_cache[((int64_t)rleaf * D + i) * nE + e_l];      // [state][component][effect]
                 for (int r2 = 0; r2 < a.n_rhos; r2++) {
                     const int32_t cr = a.colmap_rho[r2 * D + i];
                     if (cr >= 0) a.out[dest_l * a.ld + cr] = (r2 == rsym) ? B0 : 0.0;
@@ -280,29 +281,44 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                     // uniform 64-bit bases + 32-bit per-lane byte offsets (both caches are < 4 GB, checked on the host):
                     // one offset register serves the F load / the NX backward loads of a gathered application
                     const char* const fb = (const char*)a.base_cache;
-                    const char* rbx[NX];
-#pragma unroll
-                    for (int x = 0; x < NX; x++) rbx[x] = (const char*)a.rev_cache + (uint32_t)e_u[x] * (D * 8);
+                    const char* const rb = (const char*)a.rev_cache;
                     const uint32_t lane_b = (uint32_t)i * 8u;
+                    const uint32_t lane_r = (uint32_t)i * (uint32_t)nE * 8u;       // backward cache is [state][component][effect]
                     const uint32_t rstride = (uint32_t)nE * (D * 8);
+                    // pair indices of the first block; inside the loop the NEXT block's indices are requested before this
+                    // block's state vectors, so that only one memory round trip per block is exposed
+                    int32_t fi[M], ri[M];
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        const int64_t pi = p0 + 4 * m + kk;
+                        const int64_t pc = pi <= last ? pi : last;
+                        fi[m] = a.pair_f[pc]; ri[m] = a.pair_r[pc];
+                    }
                     for (int64_t q = p0; q < p1; q += 4 * M) {
-                        int32_t fi[M], ri[M];
                         bool ok[M];
+                        int32_t fn[M], rn[M];
 #pragma unroll
                         for (int m = 0; m < M; m++) {
-                            const int64_t pi = q + 4 * m + kk;
-                            ok[m] = pi <= last;
-                            const int64_t pc = ok[m] ? pi : last;
-                            fi[m] = a.pair_f[pc]; ri[m] = a.pair_r[pc];
+                            ok[m] = q + 4 * m + kk <= last;
+                            const int64_t pi = q + 4 * M + 4 * m + kk;
+                            const int64_t pc = pi <= last ? pi : last;
+                            fn[m] = a.pair_f[pc]; rn[m] = a.pair_r[pc];
                         }
                         double Fv[M], Bv[M][NX];
 #pragma unroll
                         for (int m = 0; m < M; m++) {
                             const uint32_t fo = (uint32_t)fi[m] * (D * 8) + lane_b;
-                            const uint32_t ro = (uint32_t)ri[m] * rstride + lane_b;
+                            const uint32_t ro = (uint32_t)ri[m] * rstride + lane_r;
                             Fv[m] = *(const double*)(fb + fo);
+                            if (fast4) {         // the usual case: 4 effects, outcome x <-> effect x: one 32-byte read
+                                typedef double d2_t __attribute__((ext_vector_type(2)));
+                                const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + ro, 16);
+                                const d2_t t0 = q2[0], t1 = q2[1];
+                                Bv[m][0] = t0.x; Bv[m][1] = t0.y; Bv[m][2] = t1.x; Bv[m][3] = t1.y;
+                            } else {
 #pragma unroll
-                            for (int x = 0; x < NX; x++) Bv[m][x] = *(const double*)(rbx[x] + ro);
+                                for (int x = 0; x < NX; x++) Bv[m][x] = *(const double*)(rb + ro + (uint32_t)e_u[x] * 8u);
+                            }
                         }
 #pragma unroll
                         for (int m = 0; m < M; m++) {
@@ -310,6 +326,8 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
 #pragma unroll
                             for (int x = 0; x < NX; x++) acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fz, acc[x], 0, 0, 0);
                         }
+#pragma unroll
+                        for (int m = 0; m < M; m++) { fi[m] = fn[m]; ri[m] = rn[m]; }
                     }
                 }
 #pragma unroll

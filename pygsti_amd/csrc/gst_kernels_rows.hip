@@ -837,14 +837,15 @@ __global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a, const i
     // State-cache addressing.  Normal pass: every lane group holds the same state, group 0 stores it at
     // cache[id][D].  Multi-start pass (a.multi_start = number of start vectors, used for the backward states of the
     // analytic mode): lane group q walks from start vector a.start0 + q (RHO loads rhos[a.start0 + q] whatever its
-    // argument) and stores at cache[id][a.start0 + q][D] -- the walk program, the gates and their order are the same,
+    // argument) and stores at cache[id][component][a.start0 + q] -- the walk program, the gates and their order are the same,
     // so one pass propagates 64/D start vectors.
     double* const cache = a.base_cache_w;
     const bool multi = a.multi_start > 0;
     const int my_start = a.start0 + grp;
     const bool store_on = multi ? (my_start < a.multi_start) : (grp == 0);
     const int64_t node_stride = multi ? (int64_t)a.multi_start * D : (int64_t)D;
-    const int lane_off = multi ? (store_on ? my_start * D + li : 0) : lane;
+    // (multi-start states are stored [state][component][start]: the consumer reads all starts of a component at once)
+    const int lane_off = multi ? (store_on ? li * a.multi_start + my_start : 0) : lane;
     double* const slot_lane = lds + grp * D + li;            // save slot s of this lane group: + s * 64
     int32_t lo = 0;                          // words [lo, lo + W) are resident, word i at ldsP[i % W]
     int32_t pc = 0;                          // index of the current word
