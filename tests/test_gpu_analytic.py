@@ -48,3 +48,16 @@ def test_analytic_column_window_and_permutation():
     pl.fill_dprobs(out=out, param_idx=cols, dest_idx=np.arange(300) + 7, mode=_lib.DERIV_ANALYTIC)
     assert np.array_equal(out[:, 7:307], full[:, cols])
     assert (out[:, :7] == -3.0).all() and (out[:, 307:] == -3.0).all()
+
+
+def test_analytic_valu_kernel_fallback(monkeypatch):
+    """GST_ANALYTIC_MFMA=0 (read when the plan is created) keeps the one-wavefront-per-circuit VALU kernel alive at D = 16:
+    same vectors, same tolerance, and the two paths agree far below it."""
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    J_mfma = plan_from_fixture(fx).fill_dprobs(param_idx=fx["dprobs_cols"], mode=_lib.DERIV_ANALYTIC)
+    monkeypatch.setenv("GST_ANALYTIC_MFMA", "0")
+    J_valu = plan_from_fixture(fx).fill_dprobs(param_idx=fx["dprobs_cols"], mode=_lib.DERIV_ANALYTIC)
+    rows = fx["matrix_rows"]
+    assert np.abs(J_valu[rows] - fx["dprobs_matrix"]).max() < TOL
+    assert np.abs(J_valu - J_mfma).max() < 1e-12
+    assert not np.array_equal(J_valu, J_mfma)          # (different summation orders: they are different kernels)
