@@ -15,6 +15,8 @@ outcome k % nOutcomes) with circuits in the caller's order (tests/golden fixture
 as in the reference, the element order then differs from the caller's circuit order and
 `indices_for_index` is the map.  Atoms are the unit of multi-GPU sharding (distlayout.py:326-332).
 """
+import itertools
+
 import numpy as np
 
 from . import _lib
@@ -91,8 +93,9 @@ class HipCOPALayout:
         self._circ_len = np.fromiter((len(c) for c in self.circuits), dtype=np.int64, count=self.num_circuits)
         self._circ_ptr = np.zeros(self.num_circuits + 1, np.int64)
         np.cumsum(self._circ_len, out=self._circ_ptr[1:])
-        self._circ_gates = np.fromiter((lookup[g] for c in self.circuits for g in c), dtype=np.int32,
-                                       count=int(self._circ_ptr[-1]))
+        # (C-level iteration: 32 M labels for the 2Q L<=1024 design)
+        self._circ_gates = np.fromiter(map(lookup.__getitem__, itertools.chain.from_iterable(self.circuits)),
+                                       dtype=np.int32, count=int(self._circ_ptr[-1]))
         self._rank, self._size = rank, size
 
         # ---- deal circuits to atoms ------------------------------------------------------------------
