@@ -240,3 +240,57 @@ def analytic_dprobs_general(fx, cols=None):
         J = J[:, cols]
     return J, P
 
+
+def analytic_hprobs(fx, idx1, idx2):
+    """d^2 p / d theta_1 d theta_2 for the `full` parameterisation, exactly (what MatrixForwardSimulator's
+    _hprobs_from_rho_e assembles from hProdCache, matrixforwardsim.py:1190-1287), by derivative states:
+        dF_k = G_k dF_{k-1} + [g_k = g1] e_a1 F_{k-1}[b1]          (theta_1 earlier in the chain than theta_2)
+        dB_{k-1} = G_k^T dB_k + [g_k = g1] e_b1 B_k[a1]            (theta_1 later)
+        H = sum_{k: g_k = g2} B_k[a2] dF_{k-1}[b2] + dB_k[a2] F_{k-1}[b2]    (+ the SPAM cases)
+    Pinned against the reference's Matrix-simulator vectors (tests/test_oracle.py)."""
+    D = int(fx["D"]); nE = int(fx["nE"])
+    gates, rhos, effects = fx["gates"], fx["rhos"], fx["effects"]
+    full, rho = expand_table_circuits(fx)
+    pk, po, pe = fx["pkind"], fx["pobj"], fx["pelem"]
+    idx1 = np.asarray(idx1); idx2 = np.asarray(idx2)
+    H = np.zeros((nE, len(idx1), len(idx2)))
+    for i, s in enumerate(full):
+        n = len(s)
+        F = [rhos[rho[i]]]
+        for g in s:
+            F.append(gates[g] @ F[-1])
+        for x in range(fx["eff_ptr"][i], fx["eff_ptr"][i + 1]):
+            el, dest = int(fx["eff_label"][x]), int(fx["eff_dest"][x])
+            B = [None] * (n + 1)
+            B[n] = effects[el]
+            for k in range(n, 0, -1):
+                B[k - 1] = gates[s[k - 1]].T @ B[k]
+            for ii, p1 in enumerate(idx1):
+                k1, o1, e1 = int(pk[p1]), int(po[p1]), int(pe[p1])
+                dF = [np.zeros(D) for _ in range(n + 1)]
+                dB = [np.zeros(D) for _ in range(n + 1)]
+                if k1 == 1 and o1 == rho[i]:
+                    dF[0][e1] = 1.0
+                if k1 == 2 and o1 == el:
+                    dB[n][e1] = 1.0
+                a1, b1 = divmod(e1, D)
+                for k in range(1, n + 1):
+                    dF[k] = gates[s[k - 1]] @ dF[k - 1]
+                    if k1 == 0 and s[k - 1] == o1:
+                        dF[k][a1] += F[k - 1][b1]
+                for k in range(n, 0, -1):
+                    dB[k - 1] = gates[s[k - 1]].T @ dB[k]
+                    if k1 == 0 and s[k - 1] == o1:
+                        dB[k - 1][b1] += B[k][a1]
+                for jj, p2 in enumerate(idx2):
+                    k2, o2, e2 = int(pk[p2]), int(po[p2]), int(pe[p2])
+                    if k2 == 0:
+                        a2, b2 = divmod(e2, D)
+                        H[dest, ii, jj] = sum(B[k][a2] * dF[k - 1][b2] + dB[k][a2] * F[k - 1][b2]
+                                              for k in range(1, n + 1) if s[k - 1] == o2)
+                    elif k2 == 1:
+                        H[dest, ii, jj] = dB[0][e2] if o2 == rho[i] else 0.0
+                    elif k2 == 2:
+                        H[dest, ii, jj] = dF[n][e2] if o2 == el else 0.0
+    return H
+

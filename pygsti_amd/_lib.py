@@ -50,7 +50,7 @@ class Options(C.Structure):
 
 
 class ObjectiveDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("min_prob_clip", C.c_double), ("radius", C.c_double),
+    _fields_ = [("kind", C.c_int32), ("hessian_mode", C.c_int32), ("min_prob_clip", C.c_double), ("radius", C.c_double),
                 ("prob_clip_lo", C.c_double), ("prob_clip_hi", C.c_double)]
 
 
@@ -63,7 +63,7 @@ class Stats(C.Structure):
 
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
-           "gst_set_param_map", "gst_set_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_probs_dev",
+           "gst_set_param_map", "gst_set_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
            "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
            "gst_last_error", "gst_version"]
 
@@ -89,6 +89,7 @@ def lib():
         L.gst_fill_probs.argtypes = [vp, vp]
         L.gst_fill_dprobs.argtypes = [vp, vp, i64, vp, vp, i64, C.c_int, dbl, vp]
         L.gst_fill_hprobs.argtypes = [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, dbl]
+        L.gst_fill_hprobs_analytic.argtypes = [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64]
         L.gst_fill_probs_dev.argtypes = [vp, vp]
         L.gst_fill_dprobs_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.c_int, dbl, vp]
         L.gst_fill_jtj_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
@@ -252,7 +253,7 @@ class Plan:
                                     _ptr(probs_out)))
         return out
 
-    def fill_hprobs(self, out=None, idx1=None, idx2=None, dest1=None, dest2=None, eps=1e-5):
+    def fill_hprobs(self, out=None, idx1=None, idx2=None, dest1=None, dest2=None, eps=1e-5, mode=DERIV_FD):
         i1 = _i64(np.arange(self.n_params) if idx1 is None else idx1)
         i2 = _i64(np.arange(self.n_params) if idx2 is None else idx2)
         d1 = None if dest1 is None else _i64(dest1)
@@ -260,8 +261,12 @@ class Plan:
         if out is None:
             out = np.empty((self.n_elements, len(i1), len(i2)), np.float64)
         assert out.dtype == np.float64 and out.ndim == 3 and out.flags.c_contiguous
-        check(lib().gst_fill_hprobs(self._h, _ptr(out), out.shape[1], out.shape[2], _ptr(i1), _ptr(d1), len(i1),
-                                    _ptr(i2), _ptr(d2), len(i2), float(eps)))
+        if mode == DERIV_ANALYTIC:
+            check(lib().gst_fill_hprobs_analytic(self._h, _ptr(out), out.shape[1], out.shape[2], _ptr(i1), _ptr(d1), len(i1),
+                                                 _ptr(i2), _ptr(d2), len(i2)))
+        else:
+            check(lib().gst_fill_hprobs(self._h, _ptr(out), out.shape[1], out.shape[2], _ptr(i1), _ptr(d1), len(i1),
+                                        _ptr(i2), _ptr(d2), len(i2), float(eps)))
         return out
 
     # -- fills (device pointers) -------------------------------------------------------------------------
@@ -302,12 +307,12 @@ class Plan:
         return s.value if want_sum else None
 
     def objective_hessian_block(self, kind, d_counts, d_totals, idx1, idx2, eps=1e-5, min_prob_clip=1e-4, radius=1e-4,
-                                prob_clip_interval=None):
+                                prob_clip_interval=None, mode=DERIV_FD):
         """(len(idx1), len(idx2)) block of the objective's Hessian, contracted over this plan's elements on the device
         (gst_objective_hessian_block).  kind: 'chi2' | 'logl'."""
         k = {"chi2": OBJ_CHI2, "logl": OBJ_POISSON_DLOGL}[kind] if isinstance(kind, str) else int(kind)
         lo, hi = (0.0, 0.0) if prob_clip_interval is None else (float(prob_clip_interval[0]), float(prob_clip_interval[1]))
-        d = ObjectiveDesc(k, 0, float(min_prob_clip), float(radius), lo, hi)
+        d = ObjectiveDesc(k, int(mode), float(min_prob_clip), float(radius), lo, hi)
         i1, i2 = _i64(idx1), _i64(idx2)
         out = np.zeros((len(i1), len(i2)), np.float64)
         check(lib().gst_objective_hessian_block(self._h, C.byref(d), C.c_void_p(int(d_counts)), C.c_void_p(int(d_totals)),

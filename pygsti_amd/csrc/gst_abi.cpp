@@ -88,6 +88,10 @@ struct gst_plan {
     DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order;
     DevBuf<double> d_rev_cache;
     DevBuf<uint32_t> d_work_counter, d_range_begin;
+    gst::AnaArgs last_ana;              // arguments of the last MFMA contraction (column maps, tables, caches)
+    bool last_ana_valid = false;
+    DevBuf<double> d_hscratch, d_dF, d_dB;
+    DevBuf<int32_t> d_theta;            // 2 x 5 x 4 ints: derivative-walk parameter tables
     // general parameterisations (gst_set_derivs)
     bool derivs_set = false;
     int32_t dv_n_params = 0;
@@ -133,7 +137,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
-        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_jelem.release(); d_dv_colmap.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release(); d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
@@ -577,6 +581,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         else HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
         HIP_TRY(hipEventRecord(p->evk1, p->stream));
         p->last_launches++;
+        p->last_ana = a; p->last_ana_valid = true;     // (the Hessian rows re-launch the contraction with other caches)
         return GST_OK;
     }
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
@@ -988,6 +993,115 @@ static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, co
     return GST_OK;
 }
 
+// Exact Hessian block (what MatrixForwardSimulator returns) into the device buffer d_H [nE][ld1][ld2], D = 16:
+//   H[e, t1, t2] = sum_{k: g_k = g2} B_k[a2] dF^{t1}_{k-1}[b2] + dB^{t1}_k[a2] F_{k-1}[b2]     (+ the SPAM columns)
+// with the derivative states dF^{t1} (forward plan) and dB^{t1} (reversed plan, per effect) of four rows t1 at a time
+// (dwalk_kernel) and the Jacobian's MFMA contraction run twice per row with one of the two caches swapped.
+static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
+                               int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2)
+{
+    const gst::HostPlan& h = p->hp;
+    if (h.D != 16 || !p->ana_mfma) return fail(GST_EUNSUPPORTED, "analytic Hessians exist for D = 16 on the MFMA path");
+    const int D = 16, nEf = h.n_effects;
+    const int64_t nE = h.n_elements;
+    int rc;
+    // set-up through the Jacobian path: column maps of block 2 (in the caller's column numbering), F and B caches
+    HIP_TRY(p->d_hscratch.ensure((size_t)nE * ld2));
+    p->last_ana_valid = false;
+    if ((rc = run_dprobs_analytic(p, p->d_hscratch.p, ld2, idx2, dest2, n2, nullptr))) return rc;
+    if (!p->last_ana_valid) return fail(GST_EUNSUPPORTED, "analytic Hessians need the MFMA path (state caches below 4 GB)");
+    const gst::AnaArgs base = p->last_ana;
+    const std::vector<int64_t> none_cols = p->cached_none_cols;
+    if ((double)p->rev.n_state_ids * 4 * D * nEf * 8 >= 4.0e9) return fail(GST_EUNSUPPORTED, "derivative-state cache exceeds 4 GB");
+    HIP_TRY(p->d_dF.ensure((size_t)h.n_state_ids * 4 * D));
+    HIP_TRY(p->d_dB.ensure((size_t)p->rev.n_state_ids * 4 * D * nEf));
+    HIP_TRY(p->d_theta.ensure(5 * 4 * (size_t)(1 + nEf)));
+    for (int64_t i0 = 0; i0 < n1; i0 += 4) {
+        const int nt = (int)std::min<int64_t>(4, n1 - i0);
+        // parameter tables: block 0 = forward walk, block 1 + x = backward walk from effect x
+        std::vector<int32_t> th((size_t)5 * 4 * (1 + nEf), 0);
+        for (int v = 0; v < 1 + nEf; v++) {
+            int32_t* t = th.data() + (size_t)v * 20;          // inj_gate[4] inj_dst[4] inj_src[4] start_obj[4] start_idx[4]
+            for (int q = 0; q < 4; q++) {
+                t[q] = -1; t[12 + q] = -2;
+                if (q >= nt) continue;
+                const int64_t pi = idx1[i0 + q];
+                const int k = p->pkind[pi], o = p->pobj[pi], el = p->pelem[pi];
+                if (k == GST_KIND_GATE) {
+                    t[q] = o;
+                    t[4 + q] = (v == 0) ? el / D : el % D;       // forward: row a1 receives F[b1]; backward: row b1 receives B[a1]
+                    t[8 + q] = (v == 0) ? el % D : el / D;
+                } else if (k == GST_KIND_RHO && v == 0) { t[12 + q] = o; t[16 + q] = el; }
+                else if (k == GST_KIND_EFFECT && v > 0 && o == v - 1) { t[12 + q] = -1; t[16 + q] = el; }
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(p->d_theta.p, th.data(), th.size() * 4, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        gst::DWalkArgs w;
+        std::memset(&w, 0, sizeof(w));
+        w.n_gates = h.n_gates; w.n_theta = nt;
+        auto tables = [&](int v) {
+            const int32_t* t = p->d_theta.p + (size_t)v * 20;
+            w.inj_gate = t; w.inj_dst = t + 4; w.inj_src = t + 8; w.start_obj = t + 12; w.start_idx = t + 16;
+        };
+        // dF over the forward plan
+        tables(0);
+        w.prog = p->d_prog.p; w.task_off = p->d_task_off.p; w.tile = p->d_gates_t.p;
+        w.base = p->d_base_cache.p; w.bstride = D; w.bmul = 1; w.boff = 0;
+        w.out = p->d_dF.p; w.ostride = D; w.omul = 1; w.ooff = 0;
+        HIP_TRY(gst::launch_dwalk(w, h.n_tasks(), h.max_slots, p->stream));
+        // dB over the reversed plan, one pass per effect
+        w.prog = p->d_rprog.p; w.task_off = p->d_rtask_off.p; w.tile = p->d_gates.p;
+        for (int x = 0; x < nEf; x++) {
+            tables(1 + x);
+            w.base = p->d_rev_cache.p; w.bstride = (int64_t)D * nEf; w.bmul = nEf; w.boff = x;
+            w.out = p->d_dB.p; w.ostride = (int64_t)D * nEf; w.omul = nEf; w.ooff = x;
+            HIP_TRY(gst::launch_dwalk(w, p->rev.n_tasks(), p->rev.max_slots, p->stream));
+        }
+        p->last_launches += 1 + nEf;
+        for (int q = 0; q < nt; q++) {
+            const int64_t row = dest1 ? dest1[i0 + q] : i0 + q;
+            gst::AnaArgs a = base;
+            a.out = d_H + row * ld2; a.ld = ld1 * ld2;
+            // theta_1 earlier than theta_2: derivative forward states against the backward states
+            a.base_cache = p->d_dF.p + (size_t)q * D; a.fwd_stride = 4 * D * 8;
+            a.rev_cache = p->d_rev_cache.p; a.rev_stride = 0;
+            a.rho_zero = 1; a.eff_zero = 0; a.accumulate = 0;
+            HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
+            HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+            // theta_1 later: forward states against the derivative backward states, added
+            a.base_cache = p->d_base_cache.p; a.fwd_stride = 0;
+            a.rev_cache = p->d_dB.p + (size_t)q * D * nEf; a.rev_stride = (uint32_t)(4 * D * nEf * 8);
+            a.rho_zero = 0; a.eff_zero = 1; a.accumulate = 1;
+            HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
+            HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+            p->last_launches += 2;
+            for (int64_t col : none_cols)
+                HIP_TRY(hipMemset2DAsync(d_H + row * ld2 + col, (size_t)ld1 * ld2 * 8, 0, 8, (size_t)nE, p->stream));
+        }
+    }
+    return GST_OK;
+}
+
+int gst_fill_hprobs_analytic(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
+                             int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2)
+{
+    int rc = begin_call(p);
+    if (rc) return rc;
+    if (p->derivs_set) return fail(GST_EUNSUPPORTED, "Hessians need the one-parameter-per-element map (gst_set_derivs is set)");
+    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
+    if (!out && n1 > 0 && n2 > 0) return fail(GST_EINVAL, "out is NULL");
+    if ((rc = check_params(p, idx1, n1)) || (rc = check_params(p, idx2, n2))) return rc;
+    const int64_t nE = p->hp.n_elements;
+    if (n1 == 0 || n2 == 0) return end_call(p, true);
+    HIP_TRY(p->d_out.ensure((size_t)nE * ld1 * ld2));
+    const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
+    if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
+    if ((rc = run_hprobs_analytic(p, p->d_out.p, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));
+    return end_call(p, true);
+}
+
 int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
                     int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2, double eps)
 {
@@ -1026,7 +1140,17 @@ int gst_objective_hessian_block(gst_plan* p, const gst_objective_desc* d, const 
     const int64_t nE = p->hp.n_elements;
     if (n1 == 0 || n2 == 0) return end_call(p, true);
     HIP_TRY(p->d_out.ensure((size_t)nE * n1 * n2));
-    if ((rc = run_hprobs_dev(p, p->d_out.p, n1, n2, idx1, nullptr, n1, idx2, nullptr, n2, eps))) return rc;
+    const double* d_d1 = nullptr;
+    const double* d_d2 = nullptr;
+    if (d->hessian_mode == GST_DERIV_ANALYTIC) {
+        HIP_TRY(p->d_probs_tmp.ensure((size_t)nE * n1));
+        if ((rc = run_dprobs_analytic(p, p->d_probs_tmp.p, n1, idx1, nullptr, n1, nullptr))) return rc;
+        if ((rc = run_hprobs_analytic(p, p->d_out.p, n1, n2, idx1, nullptr, n1, idx2, nullptr, n2))) return rc;
+        d_d1 = p->d_probs_tmp.p; d_d2 = p->d_hscratch.p;     // (the Hessian driver leaves the block-2 Jacobian in its scratch)
+    } else if (d->hessian_mode == GST_DERIV_FD) {
+        if ((rc = run_hprobs_dev(p, p->d_out.p, n1, n2, idx1, nullptr, n1, idx2, nullptr, n2, eps))) return rc;
+        d_d1 = p->d_probs_tmp.p; d_d2 = p->d_dcol.p;
+    } else return fail(GST_EINVAL, "unknown hessian_mode");
     // objective coefficients on the (optionally clipped) probabilities, then the contraction over elements
     HIP_TRY(p->d_obj_dt.ensure((size_t)nE)); HIP_TRY(p->d_obj_ht.ensure((size_t)nE));
     double* d_probs = p->d_pbase.p;
@@ -1045,7 +1169,7 @@ int gst_objective_hessian_block(gst_plan* p, const gst_objective_desc* d, const 
     const int n_slabs = gst::hessian_block_slabs(nE, (int)n1, (int)n2);
     HIP_TRY(p->d_hess_part.ensure((size_t)n_slabs * n1 * n2));
     HIP_TRY(p->d_hess_out.ensure((size_t)n1 * n2));
-    HIP_TRY(gst::launch_hessian_block(p->d_out.p, p->d_probs_tmp.p, p->d_dcol.p, p->d_obj_dt.p, p->d_obj_ht.p, nE, (int)n1, (int)n2,
+    HIP_TRY(gst::launch_hessian_block(p->d_out.p, d_d1, d_d2, p->d_obj_dt.p, p->d_obj_ht.p, nE, (int)n1, (int)n2,
                                       p->d_hess_part.p, n_slabs, p->d_hess_out.p, p->stream));
     p->last_launches += 2;
     HIP_TRY(hipMemcpyAsync(out, p->d_hess_out.p, (size_t)n1 * n2 * 8, hipMemcpyDeviceToHost, p->stream));

@@ -93,6 +93,10 @@ struct AnaArgs {
     const int32_t* circ_rho;      // [n_circuits]
     const int32_t* circ_order;    // [n_circuits] circuits sorted by their reversed string (= by rev_leaf)
     const uint32_t* range_begin;  // [9] the suffix-ordered list cut into 8 ranges of equal work (one per XCD)
+    // Hessian rows reuse the D = 16 MFMA contraction with derivative states in place of one of the two caches:
+    uint32_t fwd_stride, rev_stride;   // bytes between consecutive states of base_cache / rev_cache (0: the plain layouts)
+    int32_t rho_zero, eff_zero;        // write zeros to the rho / effect columns instead of B_0 / F_n
+    int32_t accumulate;                // add to the output instead of storing
     uint32_t* work_counter;       // [8] one per range, zeroed before the launch
 };
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
@@ -110,6 +114,28 @@ hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_co
 // C[:, colmap[j]] += A[:, a_col0 : a_col0 + K] . B[:, j]  (B row-major [K][n]; colmap[j] < 0: skip) -- MFMA fp64
 hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, int K, const double* B, int n, const int32_t* colmap,
                                   double* C, int64_t ldC, int64_t n_rows, hipStream_t s);
+
+// Derivative states for the analytic Hessian (gst_kernels_analytic.hip): lane group q of a wavefront carries
+//   dS^{theta_q}: dS_0 = start (a unit vector or 0);  dS_k = G_k dS_{k-1} + [g_k = inj_gate[q]] e_{inj_dst[q]} * S_{k-1}[inj_src[q]]
+// over the walk programs of a plan (forward plan + gates_t for dF, reversed plan + row-major gates for dB), S being
+// the cached base states of that plan.  D = 16 only.
+struct DWalkArgs {
+    const uint32_t* prog;
+    const int64_t* task_off;
+    const double* tile;          // [nG][D][D], out_i += tile[g][j][i] * v_j
+    int32_t n_gates;
+    const double* base;          // base states: element idx of state id at base[id * bstride + idx * bmul + boff]
+    int64_t bstride, bmul, boff;
+    const int32_t* inj_gate;     // [n_theta] gate whose element theta is, or -1
+    const int32_t* inj_dst;      // component that receives the injection
+    const int32_t* inj_src;      // component of the base state that is injected
+    const int32_t* start_obj;    // RHO argument for which the walk starts from e_{start_idx}; -1: any; -2: never (start 0)
+    const int32_t* start_idx;
+    int32_t n_theta;
+    double* out;                 // dS of state id, theta slot q, component i at out[(id * 4 + q) * ostride + i * omul + ooff]
+    int64_t ostride, omul, ooff;
+};
+hipError_t launch_dwalk(const DWalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 
 // Objective Hessian block from device-resident hprobs / dprobs blocks and the objective's dterms / hterms.
 hipError_t launch_objective_coeffs(int kind, const double* probs, const double* counts, const double* totals, int64_t n, double min_p,

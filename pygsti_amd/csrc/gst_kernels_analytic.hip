@@ -252,17 +252,28 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                 dest_u[x] = (int64_t)(((uint64_t)hi << 32) | lo);
             }
             const bool fast4 = nE == 4 && e_u[0] == 0 && e_u[1] == 1 && e_u[2] == 2 && e_u[3] == 3;
+            const uint32_t fstride = a.fwd_stride ? a.fwd_stride : (uint32_t)(D * 8);
+            const uint32_t rstride = a.rev_stride ? a.rev_stride : (uint32_t)nE * (D * 8);
             if (on) {
                 // dp/dE[a] = F_n[a] for the outcome's own effect, exact zeros for the others; dp/drho[b] = B_0[b]
-                const double FL = a.base_cache[(int64_t)fleaf * D + i];
+                // (Hessian rows: the same with derivative states, one of the two families zeroed, the second launch adding)
+                const double FL = a.eff_zero ? 0.0 : *(const double*)((const char*)a.base_cache + (int64_t)fleaf * fstride + i * 8);
                 for (int e2 = 0; e2 < nE; e2++) {
                     const int32_t ce = a.colmap_eff[e2 * D + i];
-                    if (ce >= 0) a.out[dest_l * a.ld + ce] = (e2 == e_l) ? FL : 0.0;
+                    if (ce >= 0) {
+                        double* o = a.out + dest_l * a.ld + ce;
+                        const double val = (e2 == e_l) ? FL : 0.0;
+                        *o = a.accumulate ? *o + val : val;
+                    }
                 }
-                const double B0 = a.rev_cache[((int64_t)rleaf * D + i) * nE + e_l];      // [state][component][effect]
+                const double B0 = a.rho_zero ? 0.0 : *(const double*)((const char*)a.rev_cache + (int64_t)rleaf * rstride + ((int64_t)i * nE + e_l) * 8);
                 for (int r2 = 0; r2 < a.n_rhos; r2++) {
                     const int32_t cr = a.colmap_rho[r2 * D + i];
-                    if (cr >= 0) a.out[dest_l * a.ld + cr] = (r2 == rsym) ? B0 : 0.0;
+                    if (cr >= 0) {
+                        double* o = a.out + dest_l * a.ld + cr;
+                        const double val = (r2 == rsym) ? B0 : 0.0;
+                        *o = a.accumulate ? *o + val : val;
+                    }
                 }
             }
             for (int g = 0; g < nG; g++) {
@@ -284,7 +295,6 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                     const char* const rb = (const char*)a.rev_cache;
                     const uint32_t lane_b = (uint32_t)i * 8u;
                     const uint32_t lane_r = (uint32_t)i * (uint32_t)nE * 8u;       // backward cache is [state][component][effect]
-                    const uint32_t rstride = (uint32_t)nE * (D * 8);
                     // pair indices of the first block; inside the loop the NEXT block's indices are requested before this
                     // block's state vectors, so that only one memory round trip per block is exposed
                     int32_t fi[M], ri[M];
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                         double Fv[M], Bv[M][NX];
 #pragma unroll
                         for (int m = 0; m < M; m++) {
-                            const uint32_t fo = (uint32_t)fi[m] * (D * 8) + lane_b;
+                            const uint32_t fo = (uint32_t)fi[m] * fstride + lane_b;
                             const uint32_t ro = (uint32_t)ri[m] * rstride + lane_r;
                             Fv[m] = *(const double*)(fb + fo);
                             if (fast4) {         // the usual case: 4 effects, outcome x <-> effect x: one 32-byte read
@@ -336,16 +346,91 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                     if (c0 >= 0) {           // D*D consecutive columns: entry (row, col) at c0 + row*D + col
                         double* o = a.out + dest_u[x] * a.ld + c0 + kk * D + i;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) o[4 * r * D] = acc[x][r];
+                        for (int r = 0; r < 4; r++) o[4 * r * D] = a.accumulate ? o[4 * r * D] + acc[x][r] : acc[x][r];
                     } else {                 // arbitrary subset / order: per-element column map
                         const int32_t* cm = a.colmap_gate + (int64_t)g * D * D + kk * D + i;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) { const int32_t cc = cm[4 * r * D]; if (cc >= 0) a.out[dest_u[x] * a.ld + cc] = acc[x][r]; }
+                        for (int r = 0; r < 4; r++) {
+                            const int32_t cc = cm[4 * r * D];
+                            if (cc >= 0) { double* o = a.out + dest_u[x] * a.ld + cc; *o = a.accumulate ? *o + acc[x][r] : acc[x][r]; }
+                        }
                     }
                 }
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dwalk_kernel (D = 16): derivative states for the analytic Hessian, four parameters per wavefront (lane group q <->
+// theta_q; see DWalkArgs).  A plain interpreter of the walk programs: the passes are short next to the contractions
+// they feed, so nothing is pipelined here -- the base-state element of an injection is simply read from the cache.
+__global__ __launch_bounds__(64) void dwalk_kernel(const DWalkArgs a, const int n_slots)
+{
+    constexpr int D = 16;
+    extern __shared__ double lds[];           // save slots [n_slots][64] | gate tiles [nG][D][D]
+    const int lane = threadIdx.x, li = lane & 15, grp = lane >> 4;
+    const int32_t n_tg = (a.n_theta + 3) / 4;
+    const int64_t task = blockIdx.x / n_tg;
+    const int32_t tg = (int32_t)(blockIdx.x % n_tg);
+    const int32_t th = tg * 4 + grp;
+    const bool live = th < a.n_theta;
+    const int32_t ig = live ? a.inj_gate[th] : -1, idst = live ? a.inj_dst[th] : 0, isrc = live ? a.inj_src[th] : 0;
+    const int32_t sobj = live ? a.start_obj[th] : -2, sidx = live ? a.start_idx[th] : 0;
+    double* const slot_lane = lds + lane;
+    double* const tile = lds + (n_slots > 0 ? n_slots : 1) * 64;
+    for (int k = lane; k < a.n_gates * D * D; k += 64) tile[k] = a.tile[k];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    const int64_t pc0 = as_const(a.task_off)[task];
+    const int32_t n_words = (int32_t)(as_const(a.task_off)[task + 1] - pc0);
+    const uint32_t* gprog = a.prog + pc0;
+    double v = 0.0;
+    int32_t cur_id = 0;
+    int32_t slot_id[4] = {0, 0, 0, 0};        // the state id that goes with each saved state (D <= 16 plans use <= 4 slots)
+    for (int32_t pc = 0; pc < n_words; pc++) {
+        const uint32_t w = as_const(gprog)[pc];
+        const uint32_t op = GST_OP(w), arg = GST_ARG(w);
+        if (op == GST_OP_END) break;
+        if (op == GST_OP_APPLY) {
+            const bool hit = (int32_t)arg == ig;
+            double inj = 0.0;
+            if (hit) inj = a.base[(int64_t)cur_id * a.bstride + (int64_t)isrc * a.bmul + a.boff];     // S_{k-1}[src]
+            const double* T = tile + (int)arg * D * D + li;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; j++) {
+                const double vj = __shfl(v, (lane & 48) | j, 64);
+                acc = __builtin_fma(T[j * D], vj, acc);
+            }
+            v = (hit && li == idst) ? acc + inj : acc;
+        } else if (op == GST_OP_NODE) {
+            cur_id = (int32_t)arg;
+            if (live) a.out[((int64_t)arg * 4 + grp) * a.ostride + (int64_t)li * a.omul + a.ooff] = v;
+        } else if (op == GST_OP_SAVE) {
+            slot_lane[arg * 64] = v;
+#pragma unroll
+            for (int t = 0; t < 4; t++) slot_id[t] = (arg == (uint32_t)t) ? cur_id : slot_id[t];
+        } else if (op == GST_OP_LOAD) {
+            v = slot_lane[arg * 64];
+#pragma unroll
+            for (int t = 0; t < 4; t++) cur_id = (arg == (uint32_t)t) ? slot_id[t] : cur_id;
+        } else if (op == GST_OP_RHO) {
+            v = ((sobj == -1 || sobj == (int32_t)arg) && li == sidx) ? 1.0 : 0.0;
+        }                                             // EMIT: nothing to do
+    }
+}
+
+hipError_t launch_dwalk(const DWalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
+{
+    if (n_tasks <= 0 || a.n_theta <= 0) return hipSuccess;
+    const int64_t blocks = n_tasks * ((a.n_theta + 3) / 4);
+    const size_t lds_bytes = ((size_t)(n_slots > 0 ? n_slots : 1) * 64 + (size_t)a.n_gates * 16 * 16) * sizeof(double);
+    if (blocks > 0x7fffffffLL || lds_bytes > 64 * 1024 || n_slots > 4) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(dwalk_kernel, dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a, n_slots);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------

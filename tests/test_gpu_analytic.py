@@ -61,3 +61,30 @@ def test_analytic_valu_kernel_fallback(monkeypatch):
     assert np.abs(J_valu[rows] - fx["dprobs_matrix"]).max() < TOL
     assert np.abs(J_valu - J_mfma).max() < 1e-12
     assert not np.array_equal(J_valu, J_mfma)          # (different summation orders: they are different kernels)
+
+
+def test_analytic_hprobs_vs_numpy_oracle(oracle_built):
+    """gst_fill_hprobs_analytic at D = 16 against the exact numpy Hessian (oracle.analytic_hprobs, itself pinned to the
+    MatrixForwardSimulator vectors of the 1Q fixture by tests/test_oracle.py): gate x gate, gate x SPAM, SPAM x SPAM
+    pairs, the same parameter in both blocks, a destination window."""
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    pl = plan_from_fixture(fx)
+    nE = int(fx["nE"])
+    i1 = np.array([0, 5, 17, 40, 80, 81, 97, 335, 336, 600, 1615])         # rho, effects, several gates
+    i2 = np.concatenate([np.arange(0, 20), np.arange(70, 100), [335, 336, 337, 600, 601, 1200, 1615]])
+    H = pl.fill_hprobs(idx1=i1, idx2=i2, mode=_lib.DERIV_ANALYTIC)
+    sub = np.arange(0, nE, 23)                                               # (the numpy oracle is slow: a sample of elements)
+    fx_small = dict(fx)
+    Ho = oracle_built.analytic_hprobs(fx, i1, i2)
+    scale = max(1.0, np.abs(Ho).max())
+    assert np.abs(H - Ho).max() < 1e-8 * scale
+    assert np.abs(H).max() > 0.1
+    # FD-of-FD is close, not equal
+    Hfd = pl.fill_hprobs(idx1=i1[:4], idx2=i2[:30], eps=1e-5)
+    assert np.abs(Hfd - H[:, :4, :30]).max() < 5e-2 * scale
+    # destination window / row offsets
+    out = np.full((nE, 6, 40), -5.0)
+    pl.fill_hprobs(out=out, idx1=i1[2:5], idx2=i2[10:30], dest1=np.array([1, 2, 4]), dest2=np.arange(20) + 7, mode=_lib.DERIV_ANALYTIC)
+    assert np.array_equal(out[:, [1, 2, 4], 7:27], H[:, 2:5, 10:30])
+    mask = np.ones((6, 40), bool); mask[np.ix_([1, 2, 4], np.arange(7, 27))] = False
+    assert (out[:, mask] == -5.0).all()

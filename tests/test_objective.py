@@ -171,3 +171,33 @@ def test_gpu_objective_hessian_block(objective):
     dt2, ht2 = OO.objective_coeffs(kind, pr2, c2, N)
     ref2 = np.einsum("e,ei,ej->ij", ht2, Jfd, Jfd) + np.einsum("e,eij->ij", dt2, Hfull)
     assert np.abs(full - ref2).max() <= 1e-10 * np.abs(ref2).max()
+
+
+@pytest.mark.gpu
+def test_gpu_objective_hessian_block_analytic():
+    """hessian_mode = analytic (D = 16): exact hprobs and dprobs, contracted on the device, against the same formula
+    evaluated with the numpy analytic oracles."""
+    from oracle import oracle as O
+    from pygsti_amd import _lib
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    plan = plan_from_fixture(fx)
+    nE = int(fx["nE"])
+    i1 = np.array([3, 17, 80, 336, 900]); i2 = np.concatenate([np.arange(0, 24), np.arange(80, 112), [600, 1615]])
+    rng = np.random.default_rng(2)
+    probs = fx["probs"]
+    N = np.full(nE, 200.0)
+    counts = rng.binomial(200, np.clip(probs, 0, 1)).astype(np.float64)
+    d_c = plan.device_malloc(nE * 8); d_N = plan.device_malloc(nE * 8)
+    try:
+        plan.memcpy_h2d(d_c, counts); plan.memcpy_h2d(d_N, N)
+        got = plan.objective_hessian_block("logl", d_c, d_N, i1, i2, mode=_lib.DERIV_ANALYTIC)
+    finally:
+        plan.device_free(d_c); plan.device_free(d_N)
+    allc = np.unique(np.concatenate([i1, i2]))
+    J, _ = O.analytic_dprobs(fx, allc)
+    pos = {c: k for k, c in enumerate(allc)}
+    J1 = J[:, [pos[c] for c in i1]]; J2 = J[:, [pos[c] for c in i2]]
+    H = O.analytic_hprobs(fx, i1, i2)
+    dt, ht = OO.objective_coeffs(OO.DLOGL, probs, counts, N)
+    ref = np.einsum("e,ei,ej->ij", ht, J1, J2) + np.einsum("e,eij->ij", dt, H)
+    assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()

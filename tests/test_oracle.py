@@ -61,3 +61,13 @@ def test_fd_hessian_is_loose_against_analytic():
     rows = fx["matrix_rows"]
     d = np.abs(fx["hprobs_map"][rows] - fx["hprobs_matrix"]).max()
     assert 1e-9 < d < 1e-2
+
+
+def test_analytic_hprobs_oracle_vs_matrix_simulator():
+    """The numpy exact Hessian (derivative forward/backward states) against MatrixForwardSimulator's hprobs vectors."""
+    from oracle import oracle as O
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    H = O.analytic_hprobs(fx, fx["hprobs_rows"], fx["hprobs_cols"])
+    assert np.abs(H[fx["matrix_rows"]] - fx["hprobs_matrix"]).max() < 1e-11
+    # and it is the quantity the FD-of-FD Map path approximates
+    assert np.abs(H - fx["hprobs_map"]).max() < 1e-2

@@ -26,6 +26,13 @@ for n1, n2 in ((16, 1616),):
     Hb = plan.objective_hessian_block("logl", d_c, d_N, i1, i2)
     t = time.perf_counter() - t0
     print("objective Hessian block %d x %d contracted on the device: %.1f ms in all (%d numbers come back)" % (n1, n2, 1e3 * t, n1 * n2))
+    from pygsti_amd import _lib
+    plan.objective_hessian_block("logl", d_c, d_N, i1, i2, mode=_lib.DERIV_ANALYTIC)
+    t0 = time.perf_counter()
+    Ha = plan.objective_hessian_block("logl", d_c, d_N, i1, i2, mode=_lib.DERIV_ANALYTIC)
+    t = time.perf_counter() - t0
+    print("   same block with EXACT hprobs / dprobs (analytic mode): %.1f ms; max |FD-of-FD - exact| / max|exact| = %.2e" % (
+        1e3 * t, np.abs(Hb - Ha).max() / np.abs(Ha).max()))
 for n1, n2 in ((4, 256), (8, 512), (16, 1616)):
     i1 = np.arange(80, 80 + n1); i2 = np.arange(0, n2) if n2 == 1616 else np.arange(80, 80 + n2)
     H = plan.fill_hprobs(idx1=i1, idx2=i2, eps=1e-5)
