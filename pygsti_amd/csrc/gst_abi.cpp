@@ -993,7 +993,7 @@ static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, co
     return GST_OK;
 }
 
-// Exact Hessian block (what MatrixForwardSimulator returns) into the device buffer d_H [nE][ld1][ld2], D = 16:
+// Exact Hessian block (what MatrixForwardSimulator returns) into the device buffer d_H [nE][ld1][ld2], D = 16 / 64:
 //   H[e, t1, t2] = sum_{k: g_k = g2} B_k[a2] dF^{t1}_{k-1}[b2] + dB^{t1}_k[a2] F_{k-1}[b2]     (+ the SPAM columns)
 // with the derivative states dF^{t1} (forward plan) and dB^{t1} (reversed plan, per effect) of four rows t1 at a time
 // (dwalk_kernel) and the Jacobian's MFMA contraction run twice per row with one of the two caches swapped.
@@ -1001,8 +1001,8 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
                                int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2)
 {
     const gst::HostPlan& h = p->hp;
-    if (h.D != 16 || !p->ana_mfma) return fail(GST_EUNSUPPORTED, "analytic Hessians exist for D = 16 on the MFMA path");
-    const int D = 16, nEf = h.n_effects;
+    if ((h.D != 16 && h.D != 64) || !p->ana_mfma) return fail(GST_EUNSUPPORTED, "analytic Hessians exist for D = 16 and 64 on the MFMA path");
+    const int D = h.D, nEf = h.n_effects;
     const int64_t nE = h.n_elements;
     int rc;
     // set-up through the Jacobian path: column maps of block 2 (in the caller's column numbering), F and B caches
@@ -1049,14 +1049,17 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
         w.prog = p->d_prog.p; w.task_off = p->d_task_off.p; w.tile = p->d_gates_t.p;
         w.base = p->d_base_cache.p; w.bstride = D; w.bmul = 1; w.boff = 0;
         w.out = p->d_dF.p; w.ostride = D; w.omul = 1; w.ooff = 0;
-        HIP_TRY(gst::launch_dwalk(w, h.n_tasks(), h.max_slots, p->stream));
+        HIP_TRY(gst::launch_dwalk(D, w, h.n_tasks(), h.max_slots, p->stream));
         // dB over the reversed plan, one pass per effect
         w.prog = p->d_rprog.p; w.task_off = p->d_rtask_off.p; w.tile = p->d_gates.p;
         for (int x = 0; x < nEf; x++) {
             tables(1 + x);
-            w.base = p->d_rev_cache.p; w.bstride = (int64_t)D * nEf; w.bmul = nEf; w.boff = x;
-            w.out = p->d_dB.p; w.ostride = (int64_t)D * nEf; w.omul = nEf; w.ooff = x;
-            HIP_TRY(gst::launch_dwalk(w, p->rev.n_tasks(), p->rev.max_slots, p->stream));
+            // backward-state layouts: D = 16 [state][component][effect], D = 64 [state][effect][component]
+            w.base = p->d_rev_cache.p; w.bstride = (int64_t)D * nEf;
+            w.out = p->d_dB.p; w.ostride = (int64_t)D * nEf;
+            if (D == 16) { w.bmul = nEf; w.boff = x; w.omul = nEf; w.ooff = x; }
+            else { w.bmul = 1; w.boff = (int64_t)x * D; w.omul = 1; w.ooff = (int64_t)x * D; }
+            HIP_TRY(gst::launch_dwalk(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream));
         }
         p->last_launches += 1 + nEf;
         for (int q = 0; q < nt; q++) {
@@ -1068,13 +1071,13 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
             a.rev_cache = p->d_rev_cache.p; a.rev_stride = 0;
             a.rho_zero = 1; a.eff_zero = 0; a.accumulate = 0;
             HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
-            HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+            if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream)); else HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
             // theta_1 later: forward states against the derivative backward states, added
             a.base_cache = p->d_base_cache.p; a.fwd_stride = 0;
             a.rev_cache = p->d_dB.p + (size_t)q * D * nEf; a.rev_stride = (uint32_t)(4 * D * nEf * 8);
             a.rho_zero = 0; a.eff_zero = 1; a.accumulate = 1;
             HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
-            HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+            if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream)); else HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
             p->last_launches += 2;
             for (int64_t col : none_cols)
                 HIP_TRY(hipMemset2DAsync(d_H + row * ld2 + col, (size_t)ld1 * ld2 * 8, 0, 8, (size_t)nE, p->stream));

@@ -118,7 +118,7 @@ hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, 
 // Derivative states for the analytic Hessian (gst_kernels_analytic.hip): lane group q of a wavefront carries
 //   dS^{theta_q}: dS_0 = start (a unit vector or 0);  dS_k = G_k dS_{k-1} + [g_k = inj_gate[q]] e_{inj_dst[q]} * S_{k-1}[inj_src[q]]
 // over the walk programs of a plan (forward plan + gates_t for dF, reversed plan + row-major gates for dB), S being
-// the cached base states of that plan.  D = 16 only.
+// the cached base states of that plan.  D = 16: four thetas per wavefront (lane groups); D = 64: one per wavefront.
 struct DWalkArgs {
     const uint32_t* prog;
     const int64_t* task_off;
@@ -135,7 +135,7 @@ struct DWalkArgs {
     double* out;                 // dS of state id, theta slot q, component i at out[(id * 4 + q) * ostride + i * omul + ooff]
     int64_t ostride, omul, ooff;
 };
-hipError_t launch_dwalk(const DWalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
+hipError_t launch_dwalk(int D, const DWalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);   // D = 16, 64
 
 // Objective Hessian block from device-resident hprobs / dprobs blocks and the objective's dterms / hterms.
 hipError_t launch_objective_coeffs(int kind, const double* probs, const double* counts, const double* totals, int64_t n, double min_p,

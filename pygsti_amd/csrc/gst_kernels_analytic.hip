@@ -422,13 +422,65 @@ __global__ __launch_bounds__(64) void dwalk_kernel(const DWalkArgs a, const int 
     }
 }
 
-hipError_t launch_dwalk(const DWalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
+// D = 64: one parameter per wavefront (lane = state row, coefficients streamed from L2 like walk_rows_kernel<64>);
+// blockIdx -> (task, theta); the theta slot q of DWalkArgs' output layout is theta % 4.
+__global__ __launch_bounds__(64) void dwalk64_kernel(const DWalkArgs a, const int n_slots)
+{
+    constexpr int D = 64;
+    extern __shared__ double lds[];           // save slots [n_slots][64], then their state ids
+    const int lane = threadIdx.x;
+    const int64_t task = blockIdx.x / a.n_theta;
+    const int32_t th = (int32_t)(blockIdx.x % a.n_theta);
+    const int32_t ig = as_const(a.inj_gate)[th], idst = as_const(a.inj_dst)[th], isrc = as_const(a.inj_src)[th];
+    const int32_t sobj = as_const(a.start_obj)[th], sidx = as_const(a.start_idx)[th];
+    int32_t* const slot_id = (int32_t*)(lds + (n_slots > 0 ? n_slots : 1) * 64);
+    const int64_t pc0 = as_const(a.task_off)[task];
+    const int32_t n_words = (int32_t)(as_const(a.task_off)[task + 1] - pc0);
+    const uint32_t* gprog = a.prog + pc0;
+    double v = 0.0;
+    int32_t cur_id = 0;
+    for (int32_t pc = 0; pc < n_words; pc++) {
+        const uint32_t w = as_const(gprog)[pc];
+        const uint32_t op = GST_OP(w), arg = GST_ARG(w);
+        if (op == GST_OP_END) break;
+        if (op == GST_OP_APPLY) {
+            const bool hit = (int32_t)arg == ig;
+            const double inj = hit ? a.base[(int64_t)cur_id * a.bstride + (int64_t)isrc * a.bmul + a.boff] : 0.0;
+            const double* T = a.tile + (int64_t)arg * D * D + lane;
+            double acc = 0.0;
+#pragma unroll 16
+            for (int j = 0; j < D; j++) acc = __builtin_fma(T[j * D], __shfl(v, j, 64), acc);
+            v = (hit && lane == idst) ? acc + inj : acc;
+        } else if (op == GST_OP_NODE) {
+            cur_id = (int32_t)arg;
+            a.out[((int64_t)arg * 4 + (th & 3)) * a.ostride + (int64_t)lane * a.omul + a.ooff] = v;
+        } else if (op == GST_OP_SAVE) {
+            lds[arg * 64 + lane] = v;
+            if (lane == 0) slot_id[arg] = cur_id;
+        } else if (op == GST_OP_LOAD) {
+            v = lds[arg * 64 + lane];
+            cur_id = slot_id[arg];
+        } else if (op == GST_OP_RHO) {
+            v = ((sobj == -1 || sobj == (int32_t)arg) && lane == sidx) ? 1.0 : 0.0;
+        }
+    }
+}
+
+hipError_t launch_dwalk(int D, const DWalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
 {
     if (n_tasks <= 0 || a.n_theta <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    if (D == 64) {
+        const int64_t blocks = n_tasks * a.n_theta;
+        const size_t lds_bytes = (size_t)(n_slots > 0 ? n_slots : 1) * (64 * sizeof(double) + sizeof(int32_t));
+        if (blocks > 0x7fffffffLL || lds_bytes > 64 * 1024 || a.n_theta > 4) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(dwalk64_kernel, dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a, n_slots);
+        return hipGetLastError();
+    }
+    if (D != 16) return hipErrorInvalidValue;
     const int64_t blocks = n_tasks * ((a.n_theta + 3) / 4);
     const size_t lds_bytes = ((size_t)(n_slots > 0 ? n_slots : 1) * 64 + (size_t)a.n_gates * 16 * 16) * sizeof(double);
     if (blocks > 0x7fffffffLL || lds_bytes > 64 * 1024 || n_slots > 4) return hipErrorInvalidValue;
-    (void)hipGetLastError();
     hipLaunchKernelGGL(dwalk_kernel, dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a, n_slots);
     return hipGetLastError();
 }
@@ -457,23 +509,26 @@ __global__ __launch_bounds__(256, 2) void analytic_mfma64_kernel(const AnaArgs a
         const int64_t dest = as_const(a.eff_dest)[x];
         const int32_t fleaf = as_const(a.circ_leaf)[c], rleaf = as_const(a.rev_leaf)[c], rsym = as_const(a.circ_rho)[c];
         double* const orow = a.out + dest * a.ld;
+        const uint32_t fstride = a.fwd_stride ? a.fwd_stride : (uint32_t)(D * 8);
+        const uint32_t rstride = a.rev_stride ? a.rev_stride : (uint32_t)nE * (D * 8);
+        const bool accum = a.accumulate != 0;
         // SPAM columns: dp/dE[a] = F_n[a] (own effect; zeros for the others), dp/drho[b] = B_0[b]
+        // (Hessian rows: derivative states in one of the two caches, the other family zeroed, the second launch adding)
         {
-            const double FL = a.base_cache[(int64_t)fleaf * D + lane];
+            const double FL = a.eff_zero ? 0.0 : *(const double*)((const char*)a.base_cache + (int64_t)fleaf * fstride + lane * 8);
             for (int e2 = 0; e2 < nE; e2++) {
                 const int32_t ce = a.colmap_eff[e2 * D + lane];
-                if (ce >= 0) orow[ce] = (e2 == e) ? FL : 0.0;
+                if (ce >= 0) { const double val = (e2 == e) ? FL : 0.0; orow[ce] = accum ? orow[ce] + val : val; }
             }
-            const double B0 = a.rev_cache[((int64_t)rleaf * nE + e) * D + lane];
+            const double B0 = a.rho_zero ? 0.0 : *(const double*)((const char*)a.rev_cache + (int64_t)rleaf * rstride + ((int64_t)e * D + lane) * 8);
             for (int r2 = 0; r2 < a.n_rhos; r2++) {
                 const int32_t cr = a.colmap_rho[r2 * D + lane];
-                if (cr >= 0) orow[cr] = (r2 == rsym) ? B0 : 0.0;
+                if (cr >= 0) { const double val = (r2 == rsym) ? B0 : 0.0; orow[cr] = accum ? orow[cr] + val : val; }
             }
         }
         const char* const fb = (const char*)a.base_cache;
         const char* const rb = (const char*)a.rev_cache + (uint32_t)e * (D * 8);
         const uint32_t lane_b = (uint32_t)i * 8u;
-        const uint32_t rstride = (uint32_t)nE * (D * 8);
         for (int g = 0; g < nG; g++) {
             const int32_t c0 = as_const(a.gate_col0)[g];
             if (c0 == -2) continue;
@@ -488,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void analytic_mfma64_kernel(const AnaArgs a
                 const int64_t pi = q + kk;
                 const bool ok = pi <= last;
                 const int64_t pc = ok ? pi : last;
-                const uint32_t fo = (uint32_t)a.pair_f[pc] * (D * 8) + lane_b;
+                const uint32_t fo = (uint32_t)a.pair_f[pc] * fstride + lane_b;
                 const uint32_t ro = (uint32_t)a.pair_r[pc] * rstride + lane_b;
                 double Fv[4], Bv[4];
 #pragma unroll
@@ -511,7 +566,10 @@ __global__ __launch_bounds__(256, 2) void analytic_mfma64_kernel(const AnaArgs a
 #pragma unroll
                     for (int tc = 0; tc < 4; tc++)
 #pragma unroll
-                        for (int r = 0; r < 4; r++) orow[c0 + (16 * tr + kk + 4 * r) * D + 16 * tc + i] = acc[tr][tc][r];
+                        for (int r = 0; r < 4; r++) {
+                            double* o = orow + c0 + (16 * tr + kk + 4 * r) * D + 16 * tc + i;
+                            *o = accum ? *o + acc[tr][tc][r] : acc[tr][tc][r];
+                        }
             } else {
                 const int32_t* cm = a.colmap_gate + (int64_t)g * D * D;
 #pragma unroll
@@ -521,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void analytic_mfma64_kernel(const AnaArgs a
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const int32_t cc = cm[(16 * tr + kk + 4 * r) * D + 16 * tc + i];
-                            if (cc >= 0) orow[cc] = acc[tr][tc][r];
+                            if (cc >= 0) orow[cc] = accum ? orow[cc] + acc[tr][tc][r] : acc[tr][tc][r];
                         }
             }
         }

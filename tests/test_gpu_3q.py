@@ -91,3 +91,17 @@ def test_3q_analytic_dprobs_vs_numpy_oracle(oracle_built):
     # the finite-difference Jacobian is close but not equal (truncation error of the FD step)
     Jfd = pl.fill_dprobs(param_idx=cols[:200], eps=1e-7)
     assert np.abs(Jfd - J[:, :200]).max() < 1e-4 * scale
+
+
+def test_3q_analytic_hprobs_vs_numpy_oracle(oracle_built):
+    """gst_fill_hprobs_analytic at D = 64 (dwalk64_kernel + the 64x64 MFMA contraction, two launches per row) against
+    the exact numpy Hessian."""
+    pl, tbl, mdl, nP = _make(n_circ=24, max_len=48, seed=9)
+    fx = dict(tbl); fx.update(mdl)
+    i1 = np.array([0, 63, 64 + 5, 64 + 64 * 3 + 7, 576, 576 + 65, 576 + 4096 * 4 + 130, nP - 1])
+    i2 = np.concatenate([[1, 62, 64, 64 + 64 * 3 + 7, 575], 576 + np.arange(0, 40), 576 + 4096 * 4 + np.arange(120, 140), [nP - 1]])
+    H = pl.fill_hprobs(idx1=i1, idx2=i2, mode=_lib.DERIV_ANALYTIC)
+    Ho = oracle_built.analytic_hprobs(fx, i1, i2)
+    scale = max(1.0, np.abs(Ho).max())
+    assert np.abs(H - Ho).max() < 1e-8 * scale
+    assert np.abs(Ho).max() > 1e-3

@@ -69,6 +69,9 @@ def three_q(n_circ=400, max_len=256, n_cols=4096):
     plan.device_free(d_Jf)
     i1 = np.arange(576, 576 + 16, dtype=np.int64); i2 = np.arange(576, 576 + 256, dtype=np.int64)
     t0 = time.perf_counter(); H = plan.fill_hprobs(idx1=i1, idx2=i2, eps=1e-5); t_h = time.perf_counter() - t0
+    plan.fill_hprobs(idx1=i1[:4], idx2=i2, mode=_lib.DERIV_ANALYTIC)
+    t0 = time.perf_counter(); Ha = plan.fill_hprobs(idx1=i1, idx2=i2, mode=_lib.DERIV_ANALYTIC); t_ha = time.perf_counter() - t0
+    h_diff = float(np.abs(H - Ha).max() / max(np.abs(Ha).max(), 1e-300))
     flops = n_cols * 2.0 * D * D * st["applies_per_pass"]
     return {"config": "3-qubit explicit dense model (BASELINE configs[4] shape): D=64, 10 gates, 8 outcomes, nP=%d; %d seeded random circuits, "
                       "lengths 1..%d, nE=%d" % (nP, n_circ, max_len, nE),
@@ -79,6 +82,7 @@ def three_q(n_circ=400, max_len=256, n_cols=4096):
             "dprobs_analytic_full_ms": 1e3 * t_anf, "dprobs_analytic_full_el_per_s": nE * nP / t_anf,
             "dprobs_analytic_full_GBps": 8.0 * nE * nP / t_anf / 1e9,
             "hprobs_block": "16 x 256", "hprobs_ms_incl_d2h": 1e3 * t_h, "hprobs_el_per_s": nE * 16 * 256 / t_h,
+            "hprobs_analytic_ms_incl_d2h": 1e3 * t_ha, "hprobs_fd_vs_exact_rel": h_diff,
             "applies_per_pass": st["applies_per_pass"], "n_tasks": st["n_tasks"],
             "note": "FD: bit-exact, register-blocked kernel (16 models per wavefront), no MFMA -- separate multiply/add is what parity "
                     "with the reference Map path requires; analytic: backward states over the suffix trie + 64x64 MFMA fp64 blocks"}
