@@ -37,7 +37,8 @@ def _label_str(lbl):
 
 
 def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hprobs=False,
-              hprobs_blk=None, circuit_subset_for_matrix=None, extra=None, general_params=False):
+              hprobs_blk=None, circuit_subset_for_matrix=None, extra=None, general_params=False,
+              matrix_hprobs_blocks=None):
     """Build a 1-atom Map layout for `circuits`, run the reference, save everything."""
     assert model.sim.calclib.__name__.endswith('calc_densitymx'), "reference Cython path not built!"
     model = model.copy()
@@ -219,6 +220,13 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
                 rows_mat.append(inds_mat[list(outs_mat).index(o)])
         rows_map = np.array(rows_map, np.int64)
         rows_mat = np.array(rows_mat, np.int64)
+        for bi, (s1, s2) in enumerate(matrix_hprobs_blocks or []):
+            # exact Hessian blocks straight from the Matrix simulator's per-atom seam (parameter SLICES)
+            Hb = np.empty((lay2.num_elements, s1.stop - s1.start, s2.stop - s2.start), 'd')
+            m2.sim._bulk_fill_hprobs_atom(Hb, None, None, lay2.atoms[0], s1, s2, lay2.resource_alloc('param-processing'))
+            out['mh%d_idx1' % bi] = np.arange(s1.start, s1.stop)
+            out['mh%d_idx2' % bi] = np.arange(s2.start, s2.stop)
+            out['mh%d_hprobs' % bi] = Hb[rows_mat]
         out['matrix_rows'] = rows_map                      # Map-layout element index of each stored row
         out['probs_matrix'] = p2[rows_mat]
         out['dprobs_matrix'] = J2[rows_mat][:, dprobs_cols]
@@ -297,7 +305,9 @@ def main():
                                        rng.choice(np.arange(80, 1616), 67, replace=False)]))
         sub = list(range(0, len(circs), 9))
         dump_case('smq2Q_XYICNOT_L2_depol', m, circs, dprobs_cols=cols, want_matrix=True,
-                  circuit_subset_for_matrix=sub)
+                  circuit_subset_for_matrix=sub,
+                  matrix_hprobs_blocks=[(slice(74, 90), slice(0, 140)), (slice(328, 344), slice(1560, 1616)),
+                                        (slice(8, 20), slice(590, 620))])
 
     if '2qdeep' in which:  # SURVEY C3 slice: whole germ-power families at L<=1024, 64 columns
         m = smq2Q_XYICNOT.target_model().depolarize(op_noise=0.01, spam_noise=0.01)

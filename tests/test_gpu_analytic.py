@@ -88,3 +88,16 @@ def test_analytic_hprobs_vs_numpy_oracle(oracle_built):
     assert np.array_equal(out[:, [1, 2, 4], 7:27], H[:, 2:5, 10:30])
     mask = np.ones((6, 40), bool); mask[np.ix_([1, 2, 4], np.arange(7, 27))] = False
     assert (out[:, mask] == -5.0).all()
+
+
+def test_analytic_hprobs_vs_matrix_simulator_blocks():
+    """Exact Hessian blocks against MatrixForwardSimulator._bulk_fill_hprobs_atom vectors (2Q, three parameter
+    rectangles covering rho x gate, effect x gate, gate x gate within one gate and across two gates)."""
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    pl = plan_from_fixture(fx)
+    rows = fx["matrix_rows"]
+    for b in range(3):
+        i1, i2, ref = fx["mh%d_idx1" % b], fx["mh%d_idx2" % b], fx["mh%d_hprobs" % b]
+        H = pl.fill_hprobs(idx1=i1, idx2=i2, mode=_lib.DERIV_ANALYTIC)
+        assert np.abs(H[rows] - ref).max() < TOL * max(1.0, np.abs(ref).max()), b
+        assert np.abs(ref).max() > 1e-3

@@ -71,3 +71,15 @@ def test_analytic_hprobs_oracle_vs_matrix_simulator():
     assert np.abs(H[fx["matrix_rows"]] - fx["hprobs_matrix"]).max() < 1e-11
     # and it is the quantity the FD-of-FD Map path approximates
     assert np.abs(H - fx["hprobs_map"]).max() < 1e-2
+
+
+def test_analytic_hprobs_oracle_vs_matrix_simulator_2q_blocks():
+    from oracle import oracle as O
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    rows = fx["matrix_rows"][::5]
+    # (the numpy Hessian is slow: restrict the fixture to a sample of circuits by masking the effect CSR)
+    for b in (0, 2):
+        i1, i2 = fx["mh%d_idx1" % b][:6], fx["mh%d_idx2" % b][::4]
+        H = O.analytic_hprobs(fx, i1, i2)
+        ref = fx["mh%d_hprobs" % b][::5][:, :6][:, :, ::4]
+        assert np.abs(H[rows] - ref).max() < 1e-11
