@@ -162,9 +162,9 @@ int gst_fill_hprobs(gst_plan *plan, double *out, int64_t ld1, int64_t ld2,
                     const int64_t *idx2, const int64_t *dest2, int64_t n2, double eps);
 
 /* The same block with EXACT second derivatives -- what MatrixForwardSimulator._bulk_fill_hprobs_atom returns
- * (pygsti/forwardsims/matrixforwardsim.py:1190-1287, 1289-1381) -- for the `full` parameterisation, D = 16 and 64:
+ * (pygsti/forwardsims/matrixforwardsim.py:1190-1287, 1289-1381) -- for the `full` parameterisation:
  * derivative forward / backward states of every row parameter over the prefix / suffix tries, contracted with the
- * cached backward / forward states on the MFMA cores.  Same argument meaning as gst_fill_hprobs (no step size). */
+ * cached backward / forward states (on the MFMA cores at D = 16 and 64).  Same argument meaning as gst_fill_hprobs (no step size). */
 int gst_fill_hprobs_analytic(gst_plan *plan, double *out, int64_t ld1, int64_t ld2, const int64_t *idx1,
                              const int64_t *dest1, int64_t n1, const int64_t *idx2, const int64_t *dest2, int64_t n2);
 
@@ -206,7 +206,7 @@ int gst_memcpy_h2d(gst_plan *plan, void *d_dst, const void *src, int64_t nbytes)
 typedef struct gst_objective_desc {
     int32_t kind;            /* GST_OBJ_* */
     int32_t hessian_mode;    /* gst_objective_hessian_block only: GST_DERIV_FD (0) = FD-of-FD hprobs and FD dprobs, the Map
-                                path's semantics; GST_DERIV_ANALYTIC (1) = exact hprobs and dprobs, the Matrix path's (D = 16, 64) */
+                                path's semantics; GST_DERIV_ANALYTIC (1) = exact hprobs and dprobs, the Matrix path's */
     double min_prob_clip;    /* chi^2: min_prob_clip_for_weighting; dlogl: min_prob_clip ('minp' regularisation) */
     double radius;           /* dlogl: zero-frequency radius ("harsh" regularisation) */
     double prob_clip_lo, prob_clip_hi;

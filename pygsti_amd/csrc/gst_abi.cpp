@@ -88,6 +88,7 @@ struct gst_plan {
     DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order;
     DevBuf<double> d_rev_cache;
     DevBuf<uint32_t> d_work_counter, d_range_begin;
+    bool want_cache_path = false;       // set by the Hessian driver around its set-up Jacobian call
     gst::AnaArgs last_ana;              // arguments of the last MFMA contraction (column maps, tables, caches)
     bool last_ana_valid = false;
     DevBuf<double> d_hscratch, d_dF, d_dB;
@@ -545,7 +546,9 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     // (the MFMA kernel addresses both state caches with 32-bit byte offsets)
     const bool caches_small = (double)h.n_state_ids * D * 8 < 4.0e9;
     if (D == 64 && !caches_small) return fail(GST_EUNSUPPORTED, "forward-state cache exceeds 4 GB");
-    if ((D == 16 || D == 64) && p->ana_mfma && caches_small) {
+    // the two-cache contraction: MFMA at D = 16 / 64; at D = 4 (VALU) only when a Hessian needs its tables -- a plain 1Q
+    // Jacobian is launch-bound and the single backward-walking kernel below is one launch instead of three
+    if (p->ana_mfma && caches_small && (D != 4 || p->want_cache_path)) {
         if ((rc = ensure_reverse(p))) return rc;
         if ((double)p->rev.n_state_ids * h.n_effects * D * 8 >= 4.0e9)
             return fail(GST_EUNSUPPORTED, "backward-state cache exceeds 4 GB: set GST_ANALYTIC_MFMA=0 for this plan");
@@ -578,7 +581,8 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         a.pos_ptr = p->d_pos_ptr.p; a.circ_rho = p->d_circ_rho.p; a.circ_order = p->d_circ_order.p; a.work_counter = p->d_work_counter.p; a.range_begin = p->d_range_begin.p;
         HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
         if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
-        else HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+        else if (D == 16) HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+        else HIP_TRY(gst::launch_analytic_small(a, p->stream));
         HIP_TRY(hipEventRecord(p->evk1, p->stream));
         p->last_launches++;
         p->last_ana = a; p->last_ana_valid = true;     // (the Hessian rows re-launch the contraction with other caches)
@@ -1001,14 +1005,17 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
                                int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2)
 {
     const gst::HostPlan& h = p->hp;
-    if ((h.D != 16 && h.D != 64) || !p->ana_mfma) return fail(GST_EUNSUPPORTED, "analytic Hessians exist for D = 16 and 64 on the MFMA path");
+    if (!p->ana_mfma) return fail(GST_EUNSUPPORTED, "analytic Hessians need the two-cache contraction path (GST_ANALYTIC_MFMA=0 is set)");
     const int D = h.D, nEf = h.n_effects;
     const int64_t nE = h.n_elements;
     int rc;
     // set-up through the Jacobian path: column maps of block 2 (in the caller's column numbering), F and B caches
     HIP_TRY(p->d_hscratch.ensure((size_t)nE * ld2));
     p->last_ana_valid = false;
-    if ((rc = run_dprobs_analytic(p, p->d_hscratch.p, ld2, idx2, dest2, n2, nullptr))) return rc;
+    p->want_cache_path = true;
+    rc = run_dprobs_analytic(p, p->d_hscratch.p, ld2, idx2, dest2, n2, nullptr);
+    p->want_cache_path = false;
+    if (rc) return rc;
     if (!p->last_ana_valid) return fail(GST_EUNSUPPORTED, "analytic Hessians need the MFMA path (state caches below 4 GB)");
     const gst::AnaArgs base = p->last_ana;
     const std::vector<int64_t> none_cols = p->cached_none_cols;
@@ -1054,10 +1061,10 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
         w.prog = p->d_rprog.p; w.task_off = p->d_rtask_off.p; w.tile = p->d_gates.p;
         for (int x = 0; x < nEf; x++) {
             tables(1 + x);
-            // backward-state layouts: D = 16 [state][component][effect], D = 64 [state][effect][component]
+            // backward-state layouts: D <= 16 [state][component][effect], D = 64 [state][effect][component]
             w.base = p->d_rev_cache.p; w.bstride = (int64_t)D * nEf;
             w.out = p->d_dB.p; w.ostride = (int64_t)D * nEf;
-            if (D == 16) { w.bmul = nEf; w.boff = x; w.omul = nEf; w.ooff = x; }
+            if (D <= 16) { w.bmul = nEf; w.boff = x; w.omul = nEf; w.ooff = x; }
             else { w.bmul = 1; w.boff = (int64_t)x * D; w.omul = 1; w.ooff = (int64_t)x * D; }
             HIP_TRY(gst::launch_dwalk(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream));
         }
@@ -1071,13 +1078,17 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
             a.rev_cache = p->d_rev_cache.p; a.rev_stride = 0;
             a.rho_zero = 1; a.eff_zero = 0; a.accumulate = 0;
             HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
-            if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream)); else HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+            if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
+            else if (D == 16) HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+            else HIP_TRY(gst::launch_analytic_small(a, p->stream));
             // theta_1 later: forward states against the derivative backward states, added
             a.base_cache = p->d_base_cache.p; a.fwd_stride = 0;
             a.rev_cache = p->d_dB.p + (size_t)q * D * nEf; a.rev_stride = (uint32_t)(4 * D * nEf * 8);
             a.rho_zero = 0; a.eff_zero = 1; a.accumulate = 1;
             HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
-            if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream)); else HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+            if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
+            else if (D == 16) HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+            else HIP_TRY(gst::launch_analytic_small(a, p->stream));
             p->last_launches += 2;
             for (int64_t col : none_cols)
                 HIP_TRY(hipMemset2DAsync(d_H + row * ld2 + col, (size_t)ld1 * ld2 * 8, 0, 8, (size_t)nE, p->stream));

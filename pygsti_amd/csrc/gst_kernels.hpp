@@ -102,6 +102,7 @@ struct AnaArgs {
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
 hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream);   // D = 16
 hipError_t launch_analytic_mfma64(const AnaArgs& a, hipStream_t stream); // D = 64 (uses work_counter[0] only)
+hipError_t launch_analytic_small(const AnaArgs& a, hipStream_t stream);  // D = 4: same contraction, VALU (no counter)
 
 hipError_t launch_scale_rows(double* J, int64_t n_rows, int64_t n_cols, int64_t ld, const double* w, hipStream_t s);
 hipError_t launch_symmetrize(double* C, int64_t n, hipStream_t s);
@@ -118,7 +119,7 @@ hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, 
 // Derivative states for the analytic Hessian (gst_kernels_analytic.hip): lane group q of a wavefront carries
 //   dS^{theta_q}: dS_0 = start (a unit vector or 0);  dS_k = G_k dS_{k-1} + [g_k = inj_gate[q]] e_{inj_dst[q]} * S_{k-1}[inj_src[q]]
 // over the walk programs of a plan (forward plan + gates_t for dF, reversed plan + row-major gates for dB), S being
-// the cached base states of that plan.  D = 16: four thetas per wavefront (lane groups); D = 64: one per wavefront.
+// the cached base states of that plan.  D = 4, 16: four thetas per wavefront (lane groups); D = 64: one per wavefront.
 struct DWalkArgs {
     const uint32_t* prog;
     const int64_t* task_off;

@@ -365,16 +365,17 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
 // dwalk_kernel (D = 16): derivative states for the analytic Hessian, four parameters per wavefront (lane group q <->
 // theta_q; see DWalkArgs).  A plain interpreter of the walk programs: the passes are short next to the contractions
 // they feed, so nothing is pipelined here -- the base-state element of an injection is simply read from the cache.
+template <int D>
 __global__ __launch_bounds__(64) void dwalk_kernel(const DWalkArgs a, const int n_slots)
 {
-    constexpr int D = 16;
+    static_assert(D == 4 || D == 16, "lane groups of D lanes, four of them in use");
     extern __shared__ double lds[];           // save slots [n_slots][64] | gate tiles [nG][D][D]
-    const int lane = threadIdx.x, li = lane & 15, grp = lane >> 4;
+    const int lane = threadIdx.x, li = lane % D, grp = lane / D;
     const int32_t n_tg = (a.n_theta + 3) / 4;
     const int64_t task = blockIdx.x / n_tg;
     const int32_t tg = (int32_t)(blockIdx.x % n_tg);
     const int32_t th = tg * 4 + grp;
-    const bool live = th < a.n_theta;
+    const bool live = grp < 4 && th < a.n_theta;
     const int32_t ig = live ? a.inj_gate[th] : -1, idst = live ? a.inj_dst[th] : 0, isrc = live ? a.inj_src[th] : 0;
     const int32_t sobj = live ? a.start_obj[th] : -2, sidx = live ? a.start_idx[th] : 0;
     double* const slot_lane = lds + lane;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(64) void dwalk_kernel(const DWalkArgs a, const int 
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < D; j++) {
-                const double vj = __shfl(v, (lane & 48) | j, 64);
+                const double vj = __shfl(v, (lane - li) + j, 64);
                 acc = __builtin_fma(T[j * D], vj, acc);
             }
             v = (hit && li == idst) ? acc + inj : acc;
@@ -477,11 +478,12 @@ hipError_t launch_dwalk(int D, const DWalkArgs& a, int64_t n_tasks, int n_slots,
         hipLaunchKernelGGL(dwalk64_kernel, dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a, n_slots);
         return hipGetLastError();
     }
-    if (D != 16) return hipErrorInvalidValue;
+    if (D != 16 && D != 4) return hipErrorInvalidValue;
     const int64_t blocks = n_tasks * ((a.n_theta + 3) / 4);
-    const size_t lds_bytes = ((size_t)(n_slots > 0 ? n_slots : 1) * 64 + (size_t)a.n_gates * 16 * 16) * sizeof(double);
+    const size_t lds_bytes = ((size_t)(n_slots > 0 ? n_slots : 1) * 64 + (size_t)a.n_gates * D * D) * sizeof(double);
     if (blocks > 0x7fffffffLL || lds_bytes > 64 * 1024 || n_slots > 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dwalk_kernel, dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a, n_slots);
+    if (D == 16) hipLaunchKernelGGL(dwalk_kernel<16>, dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a, n_slots);
+    else hipLaunchKernelGGL(dwalk_kernel<4>, dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a, n_slots);
     return hipGetLastError();
 }
 
@@ -593,6 +595,72 @@ hipError_t launch_analytic_mfma64(const AnaArgs& a, hipStream_t stream)
     if (blocks > 256 * 4) blocks = 256 * 4;       // persistent wavefronts pulling (circuit, outcome) items
     (void)hipGetLastError();
     hipLaunchKernelGGL(analytic_mfma64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// analytic_small_kernel (D = 4, one qubit): the same contraction from the two state caches without matrix
+// instructions -- a 4 x 4 block per (outcome, gate) is too small for an MFMA tile.  One wavefront per circuit; lane
+// (x, a, b) = 4 outcomes x 16 block entries accumulates sum_k B^x_k[a] F_{k-1}[b] over the gate's applications (two
+// 8-byte gathers and one FMA per application).  Same options as the MFMA kernels (strides, zeroed families, accumulate).
+__global__ __launch_bounds__(256) void analytic_small_kernel(const AnaArgs a)
+{
+    constexpr int D = 4, NX = 4;
+    const int lane = threadIdx.x & 63;
+    const int xg = lane >> 4, ea = (lane >> 2) & 3, eb = lane & 3;       // outcome slot, block row a, block column b
+    const int nE = a.n_effects, nG = a.n_gates;
+    const uint32_t fstride = a.fwd_stride ? a.fwd_stride : (uint32_t)(D * 8);
+    const uint32_t rstride = a.rev_stride ? a.rev_stride : (uint32_t)nE * (D * 8);
+    const bool accum = a.accumulate != 0;
+    const int64_t total_waves = (int64_t)gridDim.x * 4;
+    for (int64_t ci = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ci < a.n_circuits; ci += total_waves) {
+        const int64_t c = as_const(a.circ_order)[ci];
+        const int32_t x0 = as_const(a.eff_ptr)[c], x1 = as_const(a.eff_ptr)[c + 1];
+        const int32_t fleaf = as_const(a.circ_leaf)[c], rleaf = as_const(a.rev_leaf)[c], rsym = as_const(a.circ_rho)[c];
+        for (int32_t xb = x0; xb < x1; xb += NX) {
+            const bool on = xb + xg < x1;
+            const int32_t e = a.eff_label[on ? xb + xg : x0];
+            const int64_t dest = a.eff_dest[on ? xb + xg : x0];
+            double* const orow = a.out + dest * a.ld;
+            if (on && ea == 0) {             // SPAM columns, component eb: dp/dE = F_n (own effect), dp/drho = B_0
+                const double FL = a.eff_zero ? 0.0 : *(const double*)((const char*)a.base_cache + (int64_t)fleaf * fstride + eb * 8);
+                for (int e2 = 0; e2 < nE; e2++) {
+                    const int32_t ce = a.colmap_eff[e2 * D + eb];
+                    if (ce >= 0) { const double val = (e2 == e) ? FL : 0.0; orow[ce] = accum ? orow[ce] + val : val; }
+                }
+                const double B0 = a.rho_zero ? 0.0 : *(const double*)((const char*)a.rev_cache + (int64_t)rleaf * rstride + ((int64_t)eb * nE + e) * 8);
+                for (int r2 = 0; r2 < a.n_rhos; r2++) {
+                    const int32_t cr = a.colmap_rho[r2 * D + eb];
+                    if (cr >= 0) { const double val = (r2 == rsym) ? B0 : 0.0; orow[cr] = accum ? orow[cr] + val : val; }
+                }
+            }
+            for (int g = 0; g < nG; g++) {
+                const int32_t c0 = as_const(a.gate_col0)[g];
+                if (c0 == -2) continue;
+                const int64_t p0 = as_const(a.pos_ptr)[c * nG + g], p1 = as_const(a.pos_ptr)[c * nG + g + 1];
+                double acc = 0.0;
+                for (int64_t q = p0; q < p1; q++) {
+                    const int32_t fid = as_const(a.pair_f)[q], rid = as_const(a.pair_r)[q];
+                    const double Fv = *(const double*)((const char*)a.base_cache + (int64_t)fid * fstride + eb * 8);
+                    const double Bv = *(const double*)((const char*)a.rev_cache + (int64_t)rid * rstride + ((int64_t)ea * nE + e) * 8);
+                    acc = __builtin_fma(Bv, Fv, acc);
+                }
+                if (on) {
+                    const int32_t cc = (c0 >= 0) ? c0 + ea * D + eb : a.colmap_gate[(int64_t)g * D * D + ea * D + eb];
+                    if (cc >= 0) orow[cc] = accum ? orow[cc] + acc : acc;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_analytic_small(const AnaArgs& a, hipStream_t stream)
+{
+    if (a.n_circuits <= 0) return hipSuccess;
+    int64_t blocks = (a.n_circuits + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(analytic_small_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -145,9 +145,9 @@ class HipMapForwardSimulator:
         i1, i2 = _to_index_array(param_slice1, nP), _to_index_array(param_slice2, nP)
         d1 = None if dest_param_slice1 is None else _to_index_array(dest_param_slice1, array_to_fill.shape[1])
         d2 = None if dest_param_slice2 is None else _to_index_array(dest_param_slice2, array_to_fill.shape[2])
-        # "analytic": exact second derivatives (MatrixForwardSimulator's values) where the device has them (D = 16, 64);
+        # "analytic": exact second derivatives (MatrixForwardSimulator's values) (D = 4, 16, 64);
         # "fd": the Map simulator's FD-of-FD, bit for bit
-        mode = _lib.DERIV_ANALYTIC if (self.derivative_mode == "analytic" and self.model.dim in (16, 64)) else _lib.DERIV_FD
+        mode = _lib.DERIV_ANALYTIC if (self.derivative_mode == "analytic") else _lib.DERIV_FD
         if array_to_fill.flags.c_contiguous:
             plan.fill_hprobs(array_to_fill, i1, i2, d1, d2, self.hessian_eps, mode)
         else:
@@ -327,14 +327,14 @@ class HipMapForwardSimulator:
         FD-of-FD hprobs and FD dprobs are produced and contracted with the objective's dterms / hterms ON THE DEVICE
         (gst_objective_hessian_block); only the block's row_block x num_params numbers come back.  `hessian` is summed
         over this process's atoms (ranks all-reduce it, as `_gather_hessian` does).  Map-path semantics: both
-        derivative levels are finite differences with `hessian_eps` -- or, with derivative_mode="analytic" at D = 16 / 64, exact
+        derivative levels are finite differences with `hessian_eps` -- or, with derivative_mode="analytic", exact
         derivatives at both levels (Matrix-path semantics)."""
         nP = self.model.num_params
         hessian[...] = 0.0
         counts = np.asarray(counts, np.float64)
         total_counts = np.asarray(total_counts, np.float64)
         cols = np.arange(nP, dtype=np.int64)
-        mode = _lib.DERIV_ANALYTIC if (self.derivative_mode == "analytic" and self.model.dim in (16, 64)) else _lib.DERIV_FD
+        mode = _lib.DERIV_ANALYTIC if (self.derivative_mode == "analytic") else _lib.DERIV_FD
         for atom in layout.atoms:
             plan = self._prepare_atom(atom)
             nE = atom.num_elements

@@ -132,7 +132,7 @@ def atom_plan(model, atom, device=-1, target_tasks=0):
 class HipMapForwardSimulator(_MapForwardSimulator):
     """MapForwardSimulator whose atom fills run on the GPU.  `derivative_mode="fd"` (default): bit-identical to the
     Map simulator's finite differences; `"analytic"`: exact first derivatives (what MatrixForwardSimulator returns,
-    to <= 1e-8), several times faster, and exact Hessian blocks for two- and three-qubit models (FD-of-FD at D = 4)."""
+    to <= 1e-8), several times faster, and exact Hessian blocks."""
 
     def __init__(self, model=None, max_cache_size=None, num_atoms=None, processor_grid=None, param_blk_sizes=None,
                  derivative_eps=1e-7, hessian_eps=1e-5, device=-1, derivative_mode="fd"):
@@ -201,9 +201,9 @@ class HipMapForwardSimulator(_MapForwardSimulator):
         i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)
         d1 = None if dest_param_slice1 is None else _slct.to_array(dest_param_slice1)
         d2 = None if dest_param_slice2 is None else _slct.to_array(dest_param_slice2)
-        # derivative_mode="analytic": exact second derivatives (MatrixForwardSimulator's values) where the device has them
-        # (D = 16, 64); otherwise the Map simulator's FD-of-FD, bit for bit
-        mode = _lib.DERIV_ANALYTIC if (self.derivative_mode == "analytic" and self.model.dim in (16, 64)) else _lib.DERIV_FD
+        # derivative_mode="analytic": exact second derivatives (MatrixForwardSimulator's values) 
+        # (D = 4, 16, 64); otherwise the Map simulator's FD-of-FD, bit for bit
+        mode = _lib.DERIV_ANALYTIC if (self.derivative_mode == "analytic") else _lib.DERIV_FD
         if array_to_fill.flags.c_contiguous:
             plan.fill_hprobs(array_to_fill, i1, i2, d1, d2, self.hessian_eps, mode)
         else:

@@ -101,3 +101,16 @@ def test_analytic_hprobs_vs_matrix_simulator_blocks():
         H = pl.fill_hprobs(idx1=i1, idx2=i2, mode=_lib.DERIV_ANALYTIC)
         assert np.abs(H[rows] - ref).max() < TOL * max(1.0, np.abs(ref).max()), b
         assert np.abs(ref).max() > 1e-3
+
+
+def test_analytic_hprobs_1q_vs_matrix_simulator():
+    """D = 4: exact Hessian block against the MatrixForwardSimulator hprobs vectors of the 1Q fixture (the two-cache
+    contraction without MFMA: analytic_small_kernel + dwalk_kernel<4>)."""
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    pl = plan_from_fixture(fx)
+    H = pl.fill_hprobs(idx1=fx["hprobs_rows"], idx2=fx["hprobs_cols"], mode=_lib.DERIV_ANALYTIC)
+    ref = fx["hprobs_matrix"]
+    assert np.abs(H[fx["matrix_rows"]] - ref).max() < TOL * max(1.0, np.abs(ref).max())
+    full = pl.fill_hprobs(mode=_lib.DERIV_ANALYTIC)                       # the whole 60 x 60 Hessian of every element
+    assert np.abs(full - np.transpose(full, (0, 2, 1))).max() < 1e-11     # symmetric
+    assert np.array_equal(full[:, fx["hprobs_rows"]][:, :, fx["hprobs_cols"]], H)
