@@ -130,6 +130,19 @@ int gst_set_model(gst_plan *plan, const double *gates, const double *rhos, const
 int gst_set_param_map(gst_plan *plan, int32_t n_params, const int32_t *kind, const int32_t *obj,
                       const int32_t *elem);
 
+/* "full TP" POVMs in the finite-difference modes.  The last effect of a TPPOVM is not parameterised: it is
+ * identity - sum(other effects), recomputed whenever one of the others changes
+ * (pygsti/modelmembers/povms/complementeffect.py:72-78, called from TPPOVM.from_vector), so the FD step of an
+ * effect parameter also moves the complement's outcome.  Declares effect `comp_index` to be such a complement of
+ * effects others[0..n_others) (in the reference's summation order) with the given identity vector [D].  While set,
+ * GST_DERIV_FD columns of GST_KIND_EFFECT parameters are evaluated on the cached final states with the complement
+ * recomputed the way the reference does it (bit-identical); no parameter may map to the complement itself;
+ * gst_fill_hprobs (FD of FD) and the GST_DERIV_ANALYTIC element map return GST_EUNSUPPORTED (use gst_set_derivs for
+ * exact derivatives of such models).  TPState / FullTPOp need nothing beyond gst_set_param_map: their parameters are
+ * plain dense elements.  comp_index < 0 clears.  One complement per plan (one POVM per atom alphabet). */
+int gst_set_complement_effect(gst_plan *plan, int32_t comp_index, const double *identity, int32_t n_others,
+                              const int32_t *others);
+
 /* General parameterisations (TP, CPTP, ... -- anything whose members answer deriv_wrt_params) in GST_DERIV_ANALYTIC:
  * what MatrixForwardSimulator assembles from `_doperation` = member.deriv_wrt_params()
  * (pygsti/forwardsims/matrixforwardsim.py:126-190; modelmembers/.../deriv_wrt_params).  Object o = (kind[o], obj[o])

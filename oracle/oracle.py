@@ -221,6 +221,25 @@ def derivs_from_fixture(fx):
     return out
 
 
+def tp_param_map(fx):
+    """(kind, obj, elem) per parameter of a "full TP" fixture, read off the members' deriv_wrt_params: TPState, FullTPOp
+    and the non-complement effects of a TPPOVM are one parameter <-> one dense element (a single 1.0 per derivative
+    column); the complement effect (columns of -1.0, fx["comp_index"]) carries no parameter of its own."""
+    nP = int(fx["nP"])
+    pk = np.full(nP, -1, np.int32); po = np.zeros(nP, np.int32); pe = np.zeros(nP, np.int32)
+    comp = int(fx["comp_index"]) if "comp_index" in fx else -1
+    for k, o, pidx, dm in derivs_from_fixture(fx):
+        if k == 2 and o == comp:
+            assert set(np.unique(dm)) <= {0.0, -1.0}
+            continue
+        for j, pi in enumerate(pidx):
+            rows = np.nonzero(dm[:, j])[0]
+            assert len(rows) == 1 and dm[rows[0], j] == 1.0, "not a one-parameter-per-element member"
+            assert pk[pi] == -1
+            pk[pi], po[pi], pe[pi] = k, o, rows[0]
+    return pk, po, pe
+
+
 def analytic_dprobs_general(fx, cols=None):
     """Jacobian w.r.t. model parameters of a general (TP, CPTP, ...) parameterisation: element Jacobian x the members'
     deriv_wrt_params -- what MatrixForwardSimulator._dprobs_from_rho_e assembles from `_doperation`

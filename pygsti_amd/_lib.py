@@ -63,7 +63,7 @@ class Stats(C.Structure):
 
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
-           "gst_set_param_map", "gst_set_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
+           "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
            "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
            "gst_last_error", "gst_version"]
 
@@ -95,6 +95,7 @@ def lib():
         L.gst_fill_jtj_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
         L.gst_fill_jtf_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
         L.gst_set_derivs.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+        L.gst_set_complement_effect.argtypes = [vp, i32, vp, i32, vp]
         L.gst_objective_rows_dev.argtypes = [vp, C.POINTER(ObjectiveDesc), vp, vp, vp, i64, vp, vp, vp, C.POINTER(C.c_double)]
         L.gst_objective_hessian_block.argtypes = [vp, C.POINTER(ObjectiveDesc), vp, vp, vp, i64, vp, i64, C.c_double, vp]
         L.gst_memcpy_h2d.argtypes = [vp, vp, vp, i64]
@@ -207,6 +208,17 @@ class Plan:
         assert len(k) == len(o) == len(e)
         check(lib().gst_set_param_map(self._h, len(k), _ptr(k), _ptr(o), _ptr(e)))
         self.n_params = len(k)
+
+    def set_complement_effect(self, comp_index, identity=None, others=()):
+        """Declare effect `comp_index` as a TP POVM's complement, identity - sum(effects[others]) in that order
+        (gst_set_complement_effect); comp_index < 0 clears.  Only the FD Jacobian honours it."""
+        if comp_index is None or comp_index < 0:
+            check(lib().gst_set_complement_effect(self._h, -1, None, 0, None))
+            return
+        ident = _f64(np.asarray(identity, np.float64).ravel())
+        assert ident.size == self.D, "identity must have D components"
+        oth = _i32(others)
+        check(lib().gst_set_complement_effect(self._h, int(comp_index), _ptr(ident), len(oth), _ptr(oth)))
 
     def set_derivs(self, n_params, objs):
         """General parameterisations for the analytic mode: objs = [(kind, obj, param_idx[n], deriv[n_elem, n]), ...]

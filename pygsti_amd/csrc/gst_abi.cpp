@@ -95,6 +95,15 @@ struct gst_plan {
     DevBuf<int32_t> d_theta;            // 2 x 5 x 4 ints: derivative-walk parameter tables
     // general parameterisations (gst_set_derivs)
     bool derivs_set = false;
+    // TP POVM complement (gst_set_complement_effect)
+    int32_t comp_index = -1;
+    std::vector<int32_t> comp_others;
+    std::vector<double> comp_identity;
+    std::vector<int32_t> ecol_tab;            // [4][n_ecols]: effect, component, output column, touches-complement
+    std::vector<double> ecol_val;             // [2][n_ecols]: perturbed own component, recomputed complement component
+    DevBuf<int32_t> d_ecol_tab;
+    DevBuf<double> d_ecol_val;
+    bool leaf_uploaded = false;
     int32_t dv_n_params = 0;
     std::vector<int32_t> dv_kind, dv_obj, dv_ncols;
     std::vector<int64_t> dv_param_idx, dv_off_cols, dv_off_deriv;
@@ -138,7 +147,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
-        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release(); d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release(); d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
@@ -340,8 +349,33 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     if (!p->request_cached(1, param_idx, dest_idx, n_param)) {
         // (an optimizer asks for the same columns every iteration: pack and upload the lane tables once)
         LaneLayout L;
-        if (rows) pack_waves(p, param_idx, dest_idx, n_param, L);     // one perturbed model per wavefront
-        else pack_lanes(p, param_idx, dest_idx, n_param, L);
+        // a declared complement effect: effect-parameter columns leave the walk (effect_fd_kernel below does them on
+        // the cached final states, where the recomputed complement can be substituted)
+        std::vector<int64_t> w_idx, w_dest;
+        p->ecol_tab.clear();
+        if (p->comp_index >= 0) {
+            std::vector<int32_t> eo, ee, ed, et;
+            for (int64_t c = 0; c < n_param; c++) {
+                const int64_t pi = param_idx[c];
+                const int64_t dst = dest_idx ? dest_idx[c] : c;
+                if (p->pkind[pi] != GST_KIND_EFFECT) { w_idx.push_back(pi); w_dest.push_back(dst); continue; }
+                const int32_t e = p->pobj[pi];
+                if (e == p->comp_index) return fail(GST_EINVAL, "a parameter maps to the complement effect");
+                eo.push_back(e); ee.push_back(p->pelem[pi]); ed.push_back((int32_t)dst);
+                et.push_back(std::find(p->comp_others.begin(), p->comp_others.end(), e) != p->comp_others.end() ? 1 : 0);
+            }
+            p->ecol_tab.insert(p->ecol_tab.end(), eo.begin(), eo.end());
+            p->ecol_tab.insert(p->ecol_tab.end(), ee.begin(), ee.end());
+            p->ecol_tab.insert(p->ecol_tab.end(), ed.begin(), ed.end());
+            p->ecol_tab.insert(p->ecol_tab.end(), et.begin(), et.end());
+            if ((rc = upload_i32(p->d_ecol_tab, p->ecol_tab, p->stream))) return rc;
+        }
+        const bool filtered = p->comp_index >= 0;
+        const int64_t* l_idx = filtered ? w_idx.data() : param_idx;
+        const int64_t* l_dest = filtered ? w_dest.data() : dest_idx;
+        const int64_t l_n = filtered ? (int64_t)w_idx.size() : n_param;
+        if (rows) pack_waves(p, l_idx, l_dest, l_n, L);     // one perturbed model per wavefront
+        else pack_lanes(p, l_idx, l_dest, l_n, L);
         p->cached_kind = 0;
         if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
         if ((rc = upload_i32(p->d_lane[1], L.kind[0], p->stream))) return rc;
@@ -404,7 +438,41 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     a.n_pwaves = p->cached_n_waves;
     a.block_order = p->have_block_order ? p->d_block_order.p : nullptr;
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
-    if (rows) {
+    if (p->comp_index >= 0 && !p->ecol_tab.empty()) {
+        const int D = p->hp.D;
+        const int32_t nc = (int32_t)(p->ecol_tab.size() / 4);
+        // this call's perturbed values: theta + eps for the effect itself; identity - sum(others), the others summed
+        // from 0 in the declared order (Python's sum()), for the complement (complementeffect.py:72-78)
+        p->ecol_val.assign((size_t)2 * nc, 0.0);
+        for (int32_t k = 0; k < nc; k++) {
+            const int32_t e = p->ecol_tab[k], i = p->ecol_tab[nc + k];
+            const double own = p->h_effects[(size_t)e * D + i] + eps;
+            double sum = 0.0;
+            for (int32_t o : p->comp_others) sum = sum + (o == e ? own : p->h_effects[(size_t)o * D + i]);
+            p->ecol_val[k] = own;
+            p->ecol_val[nc + k] = p->comp_identity[i] - sum;
+        }
+        HIP_TRY(p->d_ecol_val.ensure(p->ecol_val.size()));
+        HIP_TRY(hipMemcpyAsync(p->d_ecol_val.p, p->ecol_val.data(), p->ecol_val.size() * 8, hipMemcpyHostToDevice, p->stream));
+        if (!p->leaf_uploaded) {
+            if ((rc = upload_i32(p->d_circ_leaf, p->hp.circ_leaf, p->stream))) return rc;
+            p->leaf_uploaded = true;
+        }
+        gst::EffectFDArgs ea;
+        std::memset(&ea, 0, sizeof(ea));
+        ea.n_circuits = p->hp.n_circuits; ea.n_cols = nc; ea.D = D; ea.comp_index = p->comp_index;
+        ea.circ_leaf = p->d_circ_leaf.p; ea.eff_ptr = p->d_eff_ptr.p; ea.eff_label = p->d_eff_label.p; ea.eff_dest = p->d_eff_dest.p;
+        ea.effects = p->d_effects.p; ea.base_cache = p->d_base_cache.p; ea.pbase = d_base;
+        ea.col_obj = p->d_ecol_tab.p; ea.col_elem = p->d_ecol_tab.p + nc; ea.col_dest = p->d_ecol_tab.p + 2 * nc;
+        ea.col_touches_comp = p->d_ecol_tab.p + 3 * nc;
+        ea.col_own = p->d_ecol_val.p; ea.col_comp = p->d_ecol_val.p + nc;
+        ea.out = d_out; ea.ld = ld; ea.raw = d_raw; ea.ldraw = ldraw; ea.eps = eps;
+        HIP_TRY(gst::launch_effect_fd(ea, p->stream));
+        p->last_launches++;
+    }
+    if (a.n_pwaves == 0) {
+        // (every requested column was an effect parameter)
+    } else if (rows) {
         a.rows_S = 1;
         HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     } else {
@@ -481,6 +549,8 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
                         int64_t n_param, double* d_probs_out)
 {
     const gst::HostPlan& h = p->hp;
+    if (p->comp_index >= 0 && !p->derivs_set)
+        return fail(GST_EUNSUPPORTED, "a complement effect is declared: exact derivatives of TP POVMs need gst_set_derivs");
     if (h.D != 4 && h.D != 16 && h.D != 64) return fail(GST_EUNSUPPORTED, "the analytic mode supports D = 4, 16 and 64");
     if (h.D == 64 && !p->ana_mfma) return fail(GST_EUNSUPPORTED, "D = 64 analytic derivatives exist on the MFMA path only");
     double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
@@ -734,6 +804,25 @@ int gst_set_param_map(gst_plan* p, int32_t n_params, const int32_t* kind, const 
     return GST_OK;
 }
 
+int gst_set_complement_effect(gst_plan* p, int32_t comp_index, const double* identity, int32_t n_others, const int32_t* others)
+{
+    if (!p) return fail(GST_EINVAL, "plan is NULL");
+    p->cached_kind = 0;
+    if (comp_index < 0) { p->comp_index = -1; p->comp_others.clear(); p->comp_identity.clear(); return GST_OK; }
+    if (comp_index >= p->hp.n_effects || !identity || n_others < 0 || (n_others > 0 && !others))
+        return fail(GST_EINVAL, "bad complement description");
+    for (int32_t k = 0; k < n_others; k++) {
+        if (others[k] < 0 || others[k] >= p->hp.n_effects || others[k] == comp_index)
+            return fail(GST_EINVAL, "complement: other effect " + std::to_string(k) + " out of range");
+        for (int32_t m = 0; m < k; m++)
+            if (others[m] == others[k]) return fail(GST_EINVAL, "complement: an effect is listed twice");
+    }
+    p->comp_index = comp_index;
+    p->comp_others.assign(others, others + n_others);
+    p->comp_identity.assign(identity, identity + p->hp.D);
+    return GST_OK;
+}
+
 int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t* kind, const int32_t* obj,
                    const int32_t* n_cols, const int64_t* param_idx, const double* deriv)
 {
@@ -919,6 +1008,7 @@ static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, co
                           int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2, double eps)
 {
     int rc;
+    if (p->comp_index >= 0) return fail(GST_EUNSUPPORTED, "Hessians are not implemented for plans with a complement effect");
     const int64_t nE = p->hp.n_elements;
     // (1) dprobs over block 2 at theta (mapforwardsim.py:420-421), FD step = eps
     HIP_TRY(p->d_dcol.ensure((size_t)nE * n2));

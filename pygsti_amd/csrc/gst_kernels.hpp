@@ -155,6 +155,31 @@ hipError_t launch_objective_rows(int kind, double* probs, const double* counts, 
 int rows_group(int D, int n_slots);
 
 // Row-per-lane variant (gst_kernels_rows.hip): one model per wavefront; D = 4, 16 or 64; S = a.rows_S.
+// FD columns of effect parameters evaluated on the cached final states (TP POVMs: see effect_fd_kernel)
+struct EffectFDArgs {
+    int64_t n_circuits;
+    int32_t n_cols, D, comp_index;
+    const int32_t* circ_leaf;
+    const int32_t* eff_ptr;
+    const int32_t* eff_label;
+    const int32_t* eff_dest;
+    const double* effects;
+    const double* base_cache;
+    const double* pbase;
+    const int32_t* col_obj;           // [n_cols] effect the column's parameter belongs to
+    const int32_t* col_elem;          // [n_cols] its component
+    const int32_t* col_dest;          // [n_cols] output column
+    const int32_t* col_touches_comp;  // [n_cols] the effect is one of the complement's "other" effects
+    const double* col_own;            // [n_cols] perturbed component of the effect itself
+    const double* col_comp;           // [n_cols] the same component of the recomputed complement
+    double* out;
+    int64_t ld;
+    double* raw;
+    int64_t ldraw;
+    double eps;
+};
+hipError_t launch_effect_fd(const EffectFDArgs& a, hipStream_t stream);
+
 hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 
 }  // namespace gst

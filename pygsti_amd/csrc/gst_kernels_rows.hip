@@ -982,6 +982,56 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
 }
 
 
+// FD columns of effect parameters, from the cached final states.  Perturbing an element of an effect vector changes no
+// propagated state, so the column is (E'.F_n - p)/eps on the circuits' final states -- E' being the perturbed effect for
+// outcomes of that effect, the RECOMPUTED complement for the outcome of a TP POVM's complement effect
+// (complementeffect.py:72-78: identity - sum(others); the host passes the one changed component), and the unperturbed
+// effect -- an exact zero -- otherwise.  Same dot product as the walk kernels' EMIT (ascending j, separate mul / add).
+// One thread per (circuit, column).
+__global__ __launch_bounds__(256) void effect_fd_kernel(EffectFDArgs a)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.n_circuits * (int64_t)a.n_cols) return;
+    const int64_t c = t / a.n_cols;
+    const int k = (int)(t - c * a.n_cols);
+    const int D = a.D;
+    const int e = a.col_obj[k], i = a.col_elem[k];
+    const int64_t col = a.col_dest[k];
+    const double own = a.col_own[k], cmp = a.col_comp[k];
+    const bool touches_comp = a.col_touches_comp[k] != 0;
+    const double* F = a.base_cache + (int64_t)a.circ_leaf[c] * D;
+    for (int32_t x = a.eff_ptr[c]; x < a.eff_ptr[c + 1]; x++) {
+        const int l = a.eff_label[x];
+        const int64_t dest = a.eff_dest[x];
+        const bool is_own = (l == e), is_comp = (l == a.comp_index) && touches_comp;
+        double d = 0.0, praw = a.pbase[dest];
+        if (is_own || is_comp) {
+            const double sub = is_own ? own : cmp;
+            const double* E = a.effects + (int64_t)l * D;
+            double acc = 0.0;
+            for (int j = 0; j < D; j++) {
+                const double ev = (j == i) ? sub : E[j];
+                acc = acc + ev * F[j];
+            }
+            praw = acc;
+            d = (acc - a.pbase[dest]) / a.eps;
+        }
+        a.out[dest * a.ld + col] = d;
+        if (a.raw) a.raw[dest * a.ldraw + col] = praw;
+    }
+}
+
+hipError_t launch_effect_fd(const EffectFDArgs& a, hipStream_t stream)
+{
+    const int64_t n = a.n_circuits * (int64_t)a.n_cols;
+    if (n <= 0) return hipSuccess;
+    const int64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(effect_fd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
 {
     if (D == 4) return launch_rows<4>(a, n_tasks, n_slots, stream);

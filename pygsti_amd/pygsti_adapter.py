@@ -77,6 +77,57 @@ def atom_param_map(model, atom):
     return kind, obj, elem
 
 
+_ELEMENT_SUBSET_MEMBERS = ("FullArbitraryOp", "FullTPOp", "FullState", "TPState", "FullPOVMEffect")
+
+
+def atom_tp_map(model, atom):
+    """Parameter map of a "full TP"-style model for the FD mode: TPState / FullTPOp parameters are plain dense elements
+    (from_vector writes them into the dense array, modelmembers/states/tpstate.py, operations/fulltpop.py), and a
+    TPPOVM's last effect is the complement identity - sum(others) (povms/complementeffect.py:72-78).
+    Returns (kind, obj, elem, complement) with complement = None or (index, identity[D], others); loud failure for
+    any other kind of member."""
+    D, nP = model.dim, model.num_params
+    kind = -np.ones(nP, np.int32); obj = np.zeros(nP, np.int32); elem = np.zeros(nP, np.int32)
+    eff_labels = atom._hip_eff_labels
+    eff_members = [model._circuit_layer_operator(l, "povm") for l in eff_labels]
+    complement = None
+    for k, labels, typ in ((_lib.KIND_GATE, list(atom.op_labels), "op"), (_lib.KIND_RHO, list(atom.rho_labels), "prep"),
+                           (_lib.KIND_EFFECT, eff_labels, "povm")):
+        n_el = D * D if k == _lib.KIND_GATE else D
+        for oi, lbl in enumerate(labels):
+            member = model._circuit_layer_operator(lbl, typ)
+            idx = member.gpindices_as_array()
+            if len(idx) == 0:
+                continue
+            cls = type(member).__name__
+            if cls == "ComplementPOVMEffect":
+                if complement is not None:
+                    raise NotImplementedError("more than one complement effect in one atom")
+                others = []
+                for oe in member.other_effects:
+                    hits = [j for j, m in enumerate(eff_members) if m is oe]
+                    if len(hits) != 1:
+                        raise NotImplementedError("a complement effect's terms are not all in this atom")
+                    others.append(hits[0])
+                ident = np.ascontiguousarray(np.real(member.identity.to_dense()), dtype=np.float64).ravel()
+                complement = (oi, ident, np.array(others, np.int32))
+                continue
+            dm = np.asarray(member.deriv_wrt_params()).reshape(n_el, -1) if cls in _ELEMENT_SUBSET_MEMBERS else None
+            rows = None
+            if dm is not None and dm.shape[1] == len(idx):
+                nz = [np.nonzero(dm[:, j])[0] for j in range(dm.shape[1])]
+                if all(len(r) == 1 and dm[r[0], j] == 1.0 for j, r in enumerate(nz)):
+                    rows = np.array([r[0] for r in nz])
+            if rows is None or len(set(rows.tolist())) != len(rows):
+                raise NotImplementedError(
+                    "member %s (%s) is not one-parameter-per-dense-element: finite differences over its parameters "
+                    "are not on the device" % (str(lbl), cls))
+            if (kind[idx] != -1).any():
+                raise NotImplementedError("parameter shared between members")
+            kind[idx] = k; obj[idx] = oi; elem[idx] = rows
+    return kind, obj, elem, complement
+
+
 def atom_derivs(model, atom):
     """[(kind, object, gpindices, deriv_wrt_params [n_elem, n])] of every member the atom uses -- the input of
     gst_set_derivs for parameterisations that are not one-parameter-per-element (TP, CPTP, ...), exactly what
@@ -164,13 +215,27 @@ class HipMapForwardSimulator(_MapForwardSimulator):
         if layout_atom._hip_pmap is not None:
             if plan.n_params != self.model.num_params or getattr(plan, "_hip_mode", None) != "elements":
                 plan.set_derivs(self.model.num_params, [])
+                plan.set_complement_effect(-1)
                 plan.set_param_map(*layout_atom._hip_pmap)
                 plan._hip_mode = "elements"
+        elif self.derivative_mode != "analytic":
+            # TP-style models: element-subset members + a complement effect, bit-identical finite differences
+            if getattr(layout_atom, "_hip_tpmap_model", None) is not self.model:
+                try:
+                    layout_atom._hip_tpmap = atom_tp_map(self.model, layout_atom)
+                except NotImplementedError as e:
+                    raise NotImplementedError(
+                        str(e) + "; use HipMapForwardSimulator(derivative_mode='analytic') (exact derivatives through "
+                        "deriv_wrt_params)")
+                layout_atom._hip_tpmap_model = self.model
+            k, o, e, comp = layout_atom._hip_tpmap
+            if plan.n_params != self.model.num_params or getattr(plan, "_hip_mode", None) != "tp-elements":
+                plan.set_derivs(self.model.num_params, [])
+                plan.set_param_map(k, o, e)
+                if comp is not None:
+                    plan.set_complement_effect(comp[0], comp[1], comp[2])
+                plan._hip_mode = "tp-elements"
         else:
-            if self.derivative_mode != "analytic":
-                raise NotImplementedError(
-                    "this model is not fully parameterised: finite differences over its parameters are not on the device; "
-                    "use HipMapForwardSimulator(derivative_mode='analytic') (exact derivatives through deriv_wrt_params)")
             # (re-sent every call: the derivatives of a non-linear parameterisation move with the parameters)
             plan.set_derivs(self.model.num_params, atom_derivs(self.model, layout_atom))
             plan._hip_mode = "derivs"

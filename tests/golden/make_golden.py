@@ -106,6 +106,18 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
                 k_l.append(kind); o_l.append(oi); n_l.append(len(idx)); pi_l.append(idx); d_l.append(dm.ravel())
         dv = dict(dv_kind=np.array(k_l, np.int32), dv_obj=np.array(o_l, np.int32), dv_ncols=np.array(n_l, np.int32),
                   dv_param_idx=np.concatenate(pi_l).astype(np.int64), dv_deriv=np.concatenate(d_l))
+        # TP POVMs: the complement effect = identity - sum(other effects) (modelmembers/povms/complementeffect.py:72-78)
+        from pygsti.modelmembers.povms.complementeffect import ComplementPOVMEffect
+        for oi, lbl in enumerate(eff_labels):
+            member = model._circuit_layer_operator(lbl, 'povm')
+            if isinstance(member, ComplementPOVMEffect):
+                others = []
+                for oe in member.other_effects:
+                    hits = [k for k, l2 in enumerate(eff_labels) if model._circuit_layer_operator(l2, 'povm') is oe]
+                    assert len(hits) == 1
+                    others.append(hits[0])
+                dv.update(comp_index=np.int32(oi), comp_others=np.array(others, np.int32),
+                          comp_identity=np.ascontiguousarray(np.real(member.identity.to_dense()), dtype=np.float64).ravel())
 
     # ---- reference prefix table as flat ints -----------------------------------------
     op_lookup = {l: i for i, l in enumerate(op_labels)}

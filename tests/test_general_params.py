@@ -59,3 +59,73 @@ def test_gpu_general_parameterisation_dprobs(name):
     pl.set_derivs(nP, [])
     J0 = pl.fill_dprobs(param_idx=np.arange(min(nP, 5)), mode=_lib.DERIV_FD)     # kind -1 everywhere: exact zeros
     assert (J0 == 0).all()
+
+
+TP_CASES = ["smq1Q_XYI_L4_TP", "smq2Q_XYICNOT_L1_TP"]
+
+
+@pytest.mark.parametrize("name", TP_CASES)
+def test_tp_fixtures_describe_the_complement(name):
+    """The complement effect stored in the fixture is identity - sum(others) in the recorded order, bit for bit
+    (complementeffect.py:72-78), and the TP parameter map covers every parameter exactly once."""
+    fx = load_fixture(name)
+    ci, others, ident = int(fx["comp_index"]), fx["comp_others"], fx["comp_identity"]
+    assert np.array_equal(fx["effects"][ci], ident - sum([fx["effects"][o] for o in others]))
+    pk, po, pe = O.tp_param_map(fx)
+    assert (pk >= 0).all() and not ((pk == 2) & (po == ci)).any()
+    assert len(set(zip(pk.tolist(), po.tolist(), pe.tolist()))) == int(fx["nP"])
+
+
+def test_complement_effect_arguments_are_validated():
+    from pygsti_amd import _lib
+    fx = load_fixture("smq1Q_XYI_L4_TP")
+    pl = plan_from_fixture(fx)
+    ident = fx["comp_identity"]
+    with pytest.raises(ValueError):
+        pl.set_complement_effect(7, ident, [0])            # no such effect
+    with pytest.raises(ValueError):
+        pl.set_complement_effect(1, ident, [1])            # the complement cannot be one of its own terms
+    with pytest.raises(ValueError):
+        pl.set_complement_effect(1, ident, [0, 0])
+    pl.set_complement_effect(1, ident, [0])
+    pl.set_complement_effect(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TP_CASES)
+def test_gpu_tp_model_fd_dprobs_bitwise(name):
+    """FD Jacobian of a "full TP" model, bit for bit what the reference's Map simulator returns for it
+    (fixture dprobs_map = MapForwardSimulator._bulk_fill_dprobs_atom on the TP model): TPState / FullTPOp parameters
+    are dense elements; an effect parameter also moves the TPPOVM's complement outcome."""
+    from pygsti_amd import _lib
+    fx = load_fixture(name)
+    pl = plan_from_fixture(fx)
+    pl.set_param_map(*O.tp_param_map(fx))
+    pl.set_complement_effect(int(fx["comp_index"]), fx["comp_identity"], fx["comp_others"])
+    cols = fx["dprobs_cols"]
+    pr = np.empty(int(fx["nE"]))
+    J = pl.fill_dprobs(param_idx=cols, probs_out=pr, eps=float(fx["derivative_eps"]), mode=_lib.DERIV_FD)
+    assert np.array_equal(pr, fx["probs"])
+    assert np.array_equal(J, fx["dprobs_map"])
+    pk, po, _ = O.tp_param_map(fx)
+    eff_cols = np.nonzero(pk[cols] == 2)[0]
+    assert len(eff_cols) > 0
+    # the complement's outcome really moves with the other effects' parameters
+    comp_rows = np.nonzero(fx["eff_label"] == int(fx["comp_index"]))[0]
+    assert np.abs(J[fx["eff_dest"][comp_rows]][:, eff_cols]).max() > 0
+    # effect columns only (no walk launch), scattered into a wider output
+    sub = cols[eff_cols]
+    out = np.full((int(fx["nE"]), len(sub) + 3), -3.0)
+    pl.fill_dprobs(out=out, param_idx=sub, dest_idx=np.arange(len(sub)) + 2, eps=float(fx["derivative_eps"]), mode=_lib.DERIV_FD)
+    assert np.array_equal(out[:, 2:2 + len(sub)], J[:, eff_cols]) and (out[:, :2] == -3.0).all() and (out[:, -1] == -3.0).all()
+    # exact derivatives and Hessians of such a plan are refused (gst_set_derivs is the exact route)
+    with pytest.raises(Exception):
+        pl.fill_dprobs(param_idx=cols[:2], mode=_lib.DERIV_ANALYTIC)
+    with pytest.raises(Exception):
+        pl.fill_hprobs(cols[:2], cols[:2])
+    # without the declaration the complement outcome would be wrong: the test is sensitive to it
+    pl.set_complement_effect(-1)
+    J2 = pl.fill_dprobs(param_idx=cols, eps=float(fx["derivative_eps"]), mode=_lib.DERIV_FD)
+    assert not np.array_equal(J2, fx["dprobs_map"])
+    ncomp = np.setdiff1d(np.arange(int(fx["nE"])), fx["eff_dest"][comp_rows])
+    assert np.array_equal(J2[ncomp], fx["dprobs_map"][ncomp])

@@ -85,8 +85,22 @@ def test_adapter_non_full_parameterisations():
     for k, o, i, d in mine:
         i2, d2 = by_label[(k, names_mine[k][o])]
         assert np.array_equal(i, i2) and np.array_equal(d, d2)
-    if _lib.device_count() == 0:      # FD over a non-full model is refused before any device work
+    # FD mode over the TP model: element-subset map + the complement effect, as the fixture records them
+    k_m, o_m, e_m, comp = A.atom_tp_map(mtp, atom_tp)
+    k_r, o_r, e_r = O.tp_param_map(fx)
+    assert np.array_equal(k_m, k_r) and np.array_equal(e_m, e_r)
+    assert [names_mine[k][o] for k, o in zip(k_m, o_m)] == [names_ref[k][o] for k, o in zip(k_r, o_r)]
+    assert names_mine[2][comp[0]] == names_ref[2][int(fx["comp_index"])]
+    assert [names_mine[2][o] for o in comp[2]] == [names_ref[2][o] for o in fx["comp_others"]]
+    assert np.array_equal(comp[1], fx["comp_identity"])
+    with pytest.raises(NotImplementedError):      # CPTPLND members are not element subsets: FD stays refused, loudly
+        A.atom_tp_map(model, atom)
+    if _lib.device_count() == 0:      # no device here: the TP FD request reaches the library and fails there, loudly
         mtp.sim = A.HipMapForwardSimulator(derivative_mode="fd", num_atoms=1)
         lay = mtp.sim.create_layout(list(smq1Q_XYI.create_gst_experiment_design(1).all_circuits_needing_data), array_types=("ep",))
-        with pytest.raises((NotImplementedError, _lib.GstDeviceError)):
+        with pytest.raises(_lib.GstDeviceError):
             mtp.sim.bulk_fill_dprobs(np.empty((lay.num_elements, mtp.num_params)), lay)
+        model.sim = A.HipMapForwardSimulator(derivative_mode="fd", num_atoms=1)
+        lay = model.sim.create_layout(list(smq1Q_XYI.create_gst_experiment_design(1).all_circuits_needing_data), array_types=("ep",))
+        with pytest.raises((NotImplementedError, _lib.GstDeviceError)):
+            model.sim.bulk_fill_dprobs(np.empty((lay.num_elements, model.num_params)), lay)
