@@ -152,10 +152,15 @@ __device__ __forceinline__ double dot_r(const double (&r)[D], const double (&v)[
 // launch has NW times more, smaller pieces -- what a 1/8 atom (4.4 pairs per SIMD) needs to balance.
 constexpr int XPAD = 2;      // exchange-buffer lane stride D + 2 doubles: 16-byte accesses stay bank-conflict free
 
-template <int D, int S, int WPS, int NW = 1>
-__global__ __launch_bounds__(64 * NW, WPS) void walk_kernel(const WalkArgs a)
+// PERSIST: the workgroup is as many wavefronts as one CU holds and stays for the whole launch; each wavefront pops pairs
+// from the queue of the SIMD it runs on (queues the host packed to equal estimated work, WalkArgs::bin_ptr), then from
+// the other SIMDs' queues.  The hardware dispatcher places a new one-wavefront workgroup wherever a slot frees up,
+// blind to how much work the slot's SIMD neighbours still hold; with ~4 pairs per SIMD (a 1/8 atom) that costs 8 %.
+template <int D, int S, int WPS, int NW = 1, bool PERSIST = false>
+__global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS) void walk_kernel(const WalkArgs a)
 {
     static_assert(NW == 1 || (S == 1 && D % NW == 0), "row splitting is implemented for the single-perturbation passes");
+    static_assert(!PERSIST || (NW == 1 && S == 1), "the persistent form exists for the Jacobian pass");
     constexpr int RPW = D / NW;
     // Save slots (states kept while the children of a branching trie node are walked) live in LDS:
     // slot s, component j, lane l at lds[(s*D + j)*64 + l] -- lane-consecutive 8-byte words, conflict
@@ -165,7 +170,50 @@ __global__ __launch_bounds__(64 * NW, WPS) void walk_kernel(const WalkArgs a)
     const int lane = threadIdx.x & 63;
     const int wv = (NW > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int i0 = wv * RPW;                 // first state row this wavefront computes
-    const int64_t bid = a.block_order ? (int64_t)a.block_order[blockIdx.x] : (int64_t)blockIdx.x;
+  for (;;) {                                 // PERSIST: one iteration per popped pair; otherwise exactly one
+    int64_t bid;
+    if constexpr (PERSIST) {
+        const GST_CONST WalkArgs* c = (const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t* const head = c->bin_head;
+        ci32_p bptr = as_const(c->bin_ptr);
+        const int32_t nb = c->n_bins;
+        // HW_REG_HW_ID (id 4) bits [5:4]: the SIMD this wavefront was placed on
+        const int32_t home_bin = (int32_t)blockIdx.x * 4 + (int32_t)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3u);
+        int64_t item = -1;
+        {
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(&head[home_bin], 1u);
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+            const int32_t b0 = bptr[home_bin], b1 = bptr[home_bin + 1];
+            if ((int64_t)k < (int64_t)(b1 - b0)) item = (int64_t)c->bin_items[b0 + (int32_t)k];
+        }
+        for (int32_t base = 0; item < 0 && base < nb - 1; base += 64) {      // other queues: 64 inspected per step
+            const int32_t off = base + lane;
+            int32_t vb = home_bin + 1 + off;
+            vb = vb >= nb ? vb - nb : vb;
+            bool cand = false;
+            if (off < nb - 1) {
+                const uint32_t h = __hip_atomic_load(&head[vb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cand = (int64_t)h < (int64_t)(bptr[vb + 1] - bptr[vb]);
+            }
+            uint64_t m = __ballot(cand);
+            while (m != 0 && item < 0) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const int32_t vv = __builtin_amdgcn_readlane(vb, l);
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&head[vv], 1u);
+                k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                const int32_t b0 = bptr[vv], b1 = bptr[vv + 1];
+                if ((int64_t)k < (int64_t)(b1 - b0)) item = (int64_t)c->bin_items[b0 + (int32_t)k];
+            }
+        }
+        if (item < 0) break;
+        bid = (int64_t)__builtin_amdgcn_readfirstlane((int)item);
+    } else {
+        bid = a.block_order ? (int64_t)a.block_order[blockIdx.x] : (int64_t)blockIdx.x;
+    }
+    const unsigned long long t_begin = (S == 1 && a.trace) ? wall_clock64() : 0ull;
     const int32_t pw = (int32_t)(bid % a.n_pwaves);
     const int64_t task = bid / a.n_pwaves;
     const int64_t q = (int64_t)pw * 64 + lane;
@@ -247,7 +295,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void walk_kernel(const WalkArgs a)
 
     // LDS: [exchange buffers: 2 x 64 lanes x (D + XPAD), NW > 1 only] [save slots]
     constexpr int XB = (NW > 1) ? 2 * 64 * (D + XPAD) : 0;
-    double* const slots = lds + XB;
+    double* const slots = PERSIST ? lds + (int64_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * a.lds_wave_doubles
+                                  : lds + XB;
     int xsel = 0;
 
     double v[D];
@@ -488,6 +537,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void walk_kernel(const WalkArgs a)
         }
         GST_FETCH();
     }
+    if (S == 1) {
+        unsigned long long* tr = ((const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr())->trace;
+        if (tr && lane == 0) {
+            const unsigned long long k = atomicAdd(tr, 1ull);
+            tr[1 + 4 * k] = (unsigned long long)bid; tr[2 + 4 * k] = t_begin; tr[3 + 4 * k] = wall_clock64();
+            tr[4 + 4 * k] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4)) |
+                            ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);
+        }
+    }
+    if constexpr (!PERSIST) break;
+  }
 #undef GST_FETCH
 #undef GST_HIT
 }
@@ -532,6 +592,27 @@ static hipError_t launch_one(const WalkArgs& a, int64_t n_tasks, int n_slots, hi
     if (lds_bytes > 64 * 1024 || n_slots > 4) return hipErrorInvalidValue;   // MAXSLOT tags in the kernel
     (void)hipGetLastError();   // drop any stale sticky error (e.g. an event query) so that we report OUR launch
     hipLaunchKernelGGL((walk_kernel<D, S, WPS, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_walk_persistent(int D, const WalkArgs& a, int n_wg, int n_slots, hipStream_t stream)
+{
+    constexpr int waves = 16;
+    if (n_wg <= 0 || n_slots > 4 || (D != 4 && D != 16)) return hipErrorInvalidValue;
+    const size_t lds_bytes = (size_t)waves * a.lds_wave_doubles * sizeof(double);
+    if ((size_t)a.lds_wave_doubles < (size_t)n_slots * D * 64 || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    if (D == 16) {
+        auto k = walk_kernel<16, 1, 4, 1, true>;
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k, dim3((unsigned)n_wg), dim3(64 * waves), lds_bytes, stream, a);
+    } else {
+        auto k = walk_kernel<4, 1, 4, 1, true>;
+        hipLaunchKernelGGL(k, dim3((unsigned)n_wg), dim3(64 * waves), lds_bytes, stream, a);
+    }
     return hipGetLastError();
 }
 

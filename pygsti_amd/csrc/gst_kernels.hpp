@@ -40,6 +40,14 @@ struct WalkArgs {
     int32_t multi_start, start0;   // walk_base_kernel only: > 0 = walk from `multi_start` start vectors (rhos[]), lane group q
                                    // from rhos[start0 + q], states stored at base_cache_w[id][start0 + q][D]
     const uint32_t* block_order;   // optional: blockIdx.x -> task * n_pwaves + pw, expensive pairs first (NULL: identity)
+    // persistent launch (launch_walk_persistent): one workgroup per CU; its wavefronts pop (task, wavefront) pairs from
+    // per-SIMD queues the host packed to equal estimated work, then take from the other queues
+    const int32_t* bin_ptr;        // [n_bins + 1]
+    const uint32_t* bin_items;     // pair ids (task * n_pwaves + pw), longest first inside a queue
+    uint32_t* bin_head;            // [n_bins] next unpopped position (zeroed before the launch)
+    int32_t n_bins;
+    int32_t lds_wave_doubles;      // LDS doubles (save slots) per wavefront of the workgroup
+    unsigned long long* trace;     // development aid (GST_FD_TRACE): [0] = record count, then (pair, t0, t1, hw_id) records
     int32_t n_pwaves;        // wavefronts along the parameter dimension (grid.x)
     int32_t rows_S;          // walk_rows_kernel only: number of perturbations per wavefront (0, 1, 2); its
                              // `lanes` tables then hold ONE entry per wavefront instead of one per lane
@@ -180,6 +188,8 @@ struct EffectFDArgs {
 };
 hipError_t launch_effect_fd(const EffectFDArgs& a, hipStream_t stream);
 
+// Persistent form of the D <= 16 FD walk: n_wg workgroups of 16 wavefronts (see WalkArgs::bin_ptr)
+hipError_t launch_walk_persistent(int D, const WalkArgs& a, int n_wg, int n_slots, hipStream_t stream);
 hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 
 }  // namespace gst

@@ -41,6 +41,20 @@ def test_dprobs_fd_row_split_variants_bitwise(fd_split):
         assert_bitwise(J, fx['dprobs_map'], "dprobs fd_split=%d %s" % (fd_split, name))
 
 
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_dprobs_fd_launch_forms_bitwise(mode, monkeypatch):
+    """The two forms of the FD launch -- one workgroup per (task, wavefront) pair placed by the dispatcher
+    (GST_FD_PERSIST=0), and persistent workgroups popping pairs from per-SIMD queues (=2: always) -- run the same
+    arithmetic: same bits.  (The default picks by the number of pairs per SIMD.)"""
+    monkeypatch.setenv("GST_FD_PERSIST", mode)
+    for name in ("smq1Q_XYI_L128_depol", "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep"):
+        fx = load_fixture(name)
+        pl = plan_from_fixture(fx)
+        J = pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']))
+        assert_bitwise(J, fx['dprobs_map'], "dprobs GST_FD_PERSIST=%s %s" % (mode, name))
+        assert_bitwise(pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps'])), J, "repeat " + name)
+
+
 def test_dprobs_column_window_and_dest_indices():
     """dest_param_slice semantics (distforwardsim.py:130-144): fill a column window of a wider 'ep' array."""
     fx = load_fixture("smq1Q_XYI_L4_depol")
