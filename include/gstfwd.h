@@ -136,9 +136,10 @@ int gst_set_param_map(gst_plan *plan, int32_t n_params, const int32_t *kind, con
  * effect parameter also moves the complement's outcome.  Declares effect `comp_index` to be such a complement of
  * effects others[0..n_others) (in the reference's summation order) with the given identity vector [D].  While set,
  * GST_DERIV_FD columns of GST_KIND_EFFECT parameters are evaluated on the cached final states with the complement
- * recomputed the way the reference does it (bit-identical); no parameter may map to the complement itself;
- * gst_fill_hprobs (FD of FD) and the GST_DERIV_ANALYTIC element map return GST_EUNSUPPORTED (use gst_set_derivs for
- * exact derivatives of such models).  TPState / FullTPOp need nothing beyond gst_set_param_map: their parameters are
+ * recomputed the way the reference does it (bit-identical), and so are gst_fill_hprobs' FD-of-FD blocks (D = 4, 16:
+ * the complement is re-derived after each of the two steps, as MapForwardSimulator._bulk_fill_hprobs_atom's
+ * from_vector / set_parameter_value do); no parameter may map to the complement itself; the GST_DERIV_ANALYTIC element
+ * map returns GST_EUNSUPPORTED (use gst_set_derivs for exact derivatives of such models).  TPState / FullTPOp need nothing beyond gst_set_param_map: their parameters are
  * plain dense elements.  comp_index < 0 clears.  One complement per plan (one POVM per atom alphabet). */
 int gst_set_complement_effect(gst_plan *plan, int32_t comp_index, const double *identity, int32_t n_others,
                               const int32_t *others);

@@ -1076,7 +1076,13 @@ static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, co
                           int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2, double eps)
 {
     int rc;
-    if (p->comp_index >= 0) return fail(GST_EUNSUPPORTED, "Hessians are not implemented for plans with a complement effect");
+    if (p->comp_index >= 0) {
+        if (p->hp.D == 64) return fail(GST_EUNSUPPORTED, "D = 64 Hessians are not implemented for plans with a complement effect");
+        for (int64_t c = 0; c < n1 + n2; c++) {
+            const int64_t pi = c < n1 ? idx1[c] : idx2[c - n1];
+            if (p->pkind[pi] == GST_KIND_EFFECT && p->pobj[pi] == p->comp_index) return fail(GST_EINVAL, "a parameter maps to the complement effect");
+        }
+    }
     const int64_t nE = p->hp.n_elements;
     // (1) dprobs over block 2 at theta (mapforwardsim.py:420-421), FD step = eps
     HIP_TRY(p->d_dcol.ensure((size_t)nE * n2));
@@ -1148,8 +1154,18 @@ static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, co
     if (rows) {
         a.rows_S = 2;
         HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
-    } else
-        HIP_TRY(gst::launch_walk(p->hp.D, 2, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
+    } else {
+        const bool comp = p->comp_index >= 0;
+        if (comp) {       // the complement description rides in the (otherwise unused here) effect-column tables
+            if ((rc = upload_i32(p->d_ecol_tab, p->comp_others, p->stream))) return rc;
+            HIP_TRY(p->d_ecol_val.ensure(p->comp_identity.size()));
+            HIP_TRY(hipMemcpyAsync(p->d_ecol_val.p, p->comp_identity.data(), p->comp_identity.size() * 8, hipMemcpyHostToDevice, p->stream));
+            a.comp_index = p->comp_index; a.n_others = (int32_t)p->comp_others.size();
+            a.comp_others = p->d_ecol_tab.p; a.comp_identity = p->d_ecol_val.p;
+            p->cached_kind = 0;
+        }
+        HIP_TRY(gst::launch_walk(p->hp.D, 2, a, p->hp.n_tasks(), p->hp.max_slots, p->stream, 1, comp));
+    }
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     p->last_launches++;
     return GST_OK;

@@ -156,9 +156,13 @@ constexpr int XPAD = 2;      // exchange-buffer lane stride D + 2 doubles: 16-by
 // from the queue of the SIMD it runs on (queues the host packed to equal estimated work, WalkArgs::bin_ptr), then from
 // the other SIMDs' queues.  The hardware dispatcher places a new one-wavefront workgroup wherever a slot frees up,
 // blind to how much work the slot's SIMD neighbours still hold; with ~4 pairs per SIMD (a 1/8 atom) that costs 8 %.
-template <int D, int S, int WPS, int NW = 1, bool PERSIST = false>
+// COMP (Hessian pass of "full TP" models): the POVM's complement effect is identity - sum(others), recomputed by the
+// reference after every parameter step (complementeffect.py:72-78), so a lane whose perturbations touch one of the
+// others also carries the one or two changed components of the complement.
+template <int D, int S, int WPS, int NW = 1, bool PERSIST = false, bool COMP = false>
 __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS) void walk_kernel(const WalkArgs a)
 {
+    static_assert(!COMP || S == 2, "the single-perturbation pass leaves effect parameters to effect_fd_kernel");
     static_assert(NW == 1 || (S == 1 && D % NW == 0), "row splitting is implemented for the single-perturbation passes");
     static_assert(!PERSIST || (NW == 1 && S == 1), "the persistent form exists for the Jacobian pass");
     constexpr int RPW = D / NW;
@@ -237,6 +241,8 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
     uint64_t gate_mask[S1];
     uint64_t own_mask[S1];            // NW > 1: gates for which a lane's perturbed row is one of THIS wavefront's rows
     bool eff_any[S1], rho_any[S1];
+    int cc[2] = {-1, -1};             // COMP: components of the complement effect this lane's perturbations change
+    double cval[2] = {0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < S1; s++) { kind[s] = GST_KIND_NONE; obj[s] = 0; row[s] = -1; gate_mask[s] = 0; own_mask[s] = 0; eff_any[s] = false; rho_any[s] = false; }
     if (S > 0) {
@@ -257,6 +263,35 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
                 sp[s][j] = (j == b) ? x + a.eps : x;      // theta_p + eps, as set_parameter_value does
             }
             el[s] = b;
+        }
+        if constexpr (COMP) {
+            // changed components of the complement: cc[k] (or -1) with value cval[k] = identity - sum over the others
+            // in the reference's order, each other effect's component stepped once per perturbation that hits it
+            // (the same element twice: (theta + eps) + eps, like the special row below)
+            const GST_CONST WalkArgs* c = cold();
+            ci32_p others = as_const(c->comp_others);
+            bool hits[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                hits[s] = false;
+                if (kind[s] == GST_KIND_EFFECT)
+                    for (int k = 0; k < c->n_others; k++) hits[s] = hits[s] || (others[k] == obj[s]);
+                cc[s] = hits[s] ? el[s] : -1;
+            }
+            if (cc[0] >= 0 && cc[0] == cc[1]) cc[1] = -1;            // one component carries both steps
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                double sum = 0.0;
+                const int comp = cc[s] >= 0 ? cc[s] : 0;
+                for (int k = 0; k < c->n_others; k++) {
+                    const int o = others[k];
+                    double x = as_const(c->effects)[(int64_t)o * D + comp];
+                    if (hits[0] && obj[0] == o && el[0] == comp) x = x + c->eps;
+                    if (hits[1] && obj[1] == o && el[1] == comp) x = x + c->eps;
+                    sum = sum + x;
+                }
+                cval[s] = as_const(c->comp_identity)[comp] - sum;
+            }
         }
         if (S == 2) {
             // both perturbations in the same row of the same object: one special row carries both
@@ -477,6 +512,19 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
                         p = (kind[s] == GST_KIND_EFFECT && obj[s] == e) ? r : p;
                     }
                 }
+                if constexpr (COMP) {
+                    if ((int32_t)e == c->comp_index && __ballot(cc[0] >= 0 || cc[1] >= 0) != 0) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int j = 0; j < D; j++) {
+                            double ev = effects[(int64_t)e * D + j];
+                            ev = (j == cc[0]) ? cval[0] : ev;
+                            ev = (j == cc[1]) ? cval[1] : ev;
+                            acc = acc + ev * v[j];
+                        }
+                        p = (cc[0] >= 0 || cc[1] >= 0) ? acc : p;
+                    }
+                }
                 if (c->mode == EMIT_PROBS) {
                     if (col >= 0) c->out[dest] = p;
                 } else if (c->mode == EMIT_FD) {
@@ -582,7 +630,7 @@ hipError_t launch_symmetrize(double* C, int64_t n, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int D, int S, int WPS, int NW = 1>
+template <int D, int S, int WPS, int NW = 1, bool COMP = false>
 static hipError_t launch_one(const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
 {
     const int64_t blocks = n_tasks * (int64_t)a.n_pwaves;
@@ -591,7 +639,7 @@ static hipError_t launch_one(const WalkArgs& a, int64_t n_tasks, int n_slots, hi
     const size_t lds_bytes = ((size_t)n_slots * D * 64 + (NW > 1 ? 2 * 64 * (D + XPAD) : 0)) * sizeof(double);
     if (lds_bytes > 64 * 1024 || n_slots > 4) return hipErrorInvalidValue;   // MAXSLOT tags in the kernel
     (void)hipGetLastError();   // drop any stale sticky error (e.g. an event query) so that we report OUR launch
-    hipLaunchKernelGGL((walk_kernel<D, S, WPS, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds_bytes, stream, a);
+    hipLaunchKernelGGL((walk_kernel<D, S, WPS, NW, false, COMP>), dim3((unsigned)blocks), dim3(64 * NW), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
@@ -616,8 +664,13 @@ hipError_t launch_walk_persistent(int D, const WalkArgs& a, int n_wg, int n_slot
     return hipGetLastError();
 }
 
-hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream, int split)
+hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream, int split, bool complement)
 {
+    if (complement) {
+        if (S == 2 && D == 4) return launch_one<4, 2, 4, 1, true>(a, n_tasks, n_slots, stream);
+        if (S == 2 && D == 16) return launch_one<16, 2, 3, 1, true>(a, n_tasks, n_slots, stream);
+        return hipErrorInvalidValue;
+    }
     if (D == 16 && S == 1 && split == 4) return launch_one<16, 1, 4, 4>(a, n_tasks, n_slots, stream);
     if (D == 16 && S == 1 && split == 2) return launch_one<16, 1, 4, 2>(a, n_tasks, n_slots, stream);
     if (D == 4) {

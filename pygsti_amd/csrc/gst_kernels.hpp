@@ -48,6 +48,10 @@ struct WalkArgs {
     int32_t n_bins;
     int32_t lds_wave_doubles;      // LDS doubles (save slots) per wavefront of the workgroup
     unsigned long long* trace;     // development aid (GST_FD_TRACE): [0] = record count, then (pair, t0, t1, hw_id) records
+    // TP POVM complement in the Hessian pass (walk_kernel's COMP): effect comp_index = identity - sum(others)
+    int32_t comp_index, n_others;
+    const int32_t* comp_others;    // [n_others], the reference's summation order
+    const double* comp_identity;   // [D]
     int32_t n_pwaves;        // wavefronts along the parameter dimension (grid.x)
     int32_t rows_S;          // walk_rows_kernel only: number of perturbations per wavefront (0, 1, 2); its
                              // `lanes` tables then hold ONE entry per wavefront instead of one per lane
@@ -70,7 +74,8 @@ struct WalkArgs {
 
 // Launch the walk over all tasks x parameter wavefronts.  S = number of specials per lane (0,1,2);
 // n_slots = save slots the programs use (LDS: n_slots * D * 512 bytes per wavefront).
-hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream, int split = 1);
+hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream, int split = 1,
+                       bool complement = false);
 
 // Analytic Jacobian (gst_kernels_analytic.hip): one wavefront per circuit walks the state-id graph backwards.
 struct AnaArgs {

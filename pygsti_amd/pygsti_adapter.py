@@ -259,8 +259,10 @@ class HipMapForwardSimulator(_MapForwardSimulator):
     def _bulk_fill_hprobs_atom(self, array_to_fill, dest_param_slice1, dest_param_slice2, layout_atom,
                                param_slice1, param_slice2, resource_alloc):
         plan = self._prepare(layout_atom, derivatives=True)
-        if getattr(plan, "_hip_mode", None) != "elements":
-            raise NotImplementedError("Hessians on the device need a fully parameterised model in this round")
+        hmode = getattr(plan, "_hip_mode", None)
+        if hmode != "elements" and not (hmode == "tp-elements" and self.derivative_mode == "fd"):
+            raise NotImplementedError("Hessians on the device: fully parameterised models (FD or exact) and full-TP models "
+                                      "(FD of FD, as the Map simulator computes them)")
         nP = self.model.num_params
         i1 = np.arange(nP) if param_slice1 is None else _slct.to_array(param_slice1)
         i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)

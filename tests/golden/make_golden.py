@@ -38,7 +38,7 @@ def _label_str(lbl):
 
 def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hprobs=False,
               hprobs_blk=None, circuit_subset_for_matrix=None, extra=None, general_params=False,
-              matrix_hprobs_blocks=None):
+              matrix_hprobs_blocks=None, matrix_hprobs=True):
     """Build a 1-atom Map layout for `circuits`, run the reference, save everything."""
     assert model.sim.calclib.__name__.endswith('calc_densitymx'), "reference Cython path not built!"
     model = model.copy()
@@ -214,7 +214,7 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
         J2 = np.empty((lay2.num_elements, nP), 'd')
         p2 = np.empty(lay2.num_elements, 'd')
         m2.sim.bulk_fill_dprobs(J2, lay2, pr_array_to_fill=p2)
-        if want_hprobs:
+        if want_hprobs and matrix_hprobs:
             H2 = np.empty((lay2.num_elements, nP, nP), 'd')
             m2.sim.bulk_fill_hprobs(H2, lay2)
         sub_idx = list(range(len(circuits))) if circuit_subset_for_matrix is None else list(circuit_subset_for_matrix)
@@ -242,7 +242,7 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
         out['matrix_rows'] = rows_map                      # Map-layout element index of each stored row
         out['probs_matrix'] = p2[rows_mat]
         out['dprobs_matrix'] = J2[rows_mat][:, dprobs_cols]
-        if want_hprobs:
+        if want_hprobs and matrix_hprobs:
             out['hprobs_matrix'] = H2[rows_mat][:, b1][:, :, b2]
 
     meta = dict(
@@ -299,15 +299,20 @@ def main():
     if 'tp' in which:    # general parameterisations (analytic mode + gst_set_derivs): TP and CPTP-constrained models
         circs = list(smq1Q_XYI.create_gst_experiment_design(4).all_circuits_needing_data)
         m = smq1Q_XYI.target_model("full TP").depolarize(op_noise=0.01, spam_noise=0.01)
-        dump_case('smq1Q_XYI_L4_TP', m, circs, general_params=True)
+        # FD-of-FD Hessian block of the TP model (Map simulator): rho, all four effect parameters (they also move the
+        # complement's outcome), gate parameters
+        blk = (np.array([0, 3, 4, 5, 6, 8, 20, 42]), np.concatenate([np.arange(0, 8), np.arange(9, 43, 3)]))
+        dump_case('smq1Q_XYI_L4_TP', m, circs, general_params=True, want_hprobs=True, hprobs_blk=blk)
         m = smq1Q_XYI.target_model("CPTPLND")
         m.from_vector(m.to_vector() + 0.01 * np.random.default_rng(3).standard_normal(m.num_params))
         dump_case('smq1Q_XYI_L4_CPTPLND', m, circs, general_params=True)
         m = smq2Q_XYICNOT.target_model("full TP").depolarize(op_noise=0.01, spam_noise=0.01)
         circs2 = list(smq2Q_XYICNOT.create_gst_experiment_design(1, lite=True).all_circuits_needing_data)
         cols = np.sort(np.random.default_rng(5).choice(m.num_params, 120, replace=False))
+        # (parameters 15..62 are the three parameterised effects of the TP POVM; 63.. the gates)
+        blk2 = (np.array([2, 17, 40, 63 + 240 + 5]), np.array([16, 17, 33, 40, 49, 62, 1, 63 + 17, 63 + 240 + 5, 63 + 4 * 240 + 100]))
         dump_case('smq2Q_XYICNOT_L1_TP', m, circs2, dprobs_cols=cols, circuit_subset_for_matrix=list(range(0, len(circs2), 7)),
-                  general_params=True)
+                  general_params=True, want_hprobs=True, hprobs_blk=blk2, matrix_hprobs=False)
 
     if '2q2' in which:   # 2Q, D=16: every circuit of the L<=2 lite design, a spread of 96 columns
         m = smq2Q_XYICNOT.target_model().depolarize(op_noise=0.01, spam_noise=0.01)

@@ -118,11 +118,19 @@ def test_gpu_tp_model_fd_dprobs_bitwise(name):
     out = np.full((int(fx["nE"]), len(sub) + 3), -3.0)
     pl.fill_dprobs(out=out, param_idx=sub, dest_idx=np.arange(len(sub)) + 2, eps=float(fx["derivative_eps"]), mode=_lib.DERIV_FD)
     assert np.array_equal(out[:, 2:2 + len(sub)], J[:, eff_cols]) and (out[:, :2] == -3.0).all() and (out[:, -1] == -3.0).all()
-    # exact derivatives and Hessians of such a plan are refused (gst_set_derivs is the exact route)
+    # exact derivatives of such a plan are refused (gst_set_derivs is the exact route)
     with pytest.raises(Exception):
         pl.fill_dprobs(param_idx=cols[:2], mode=_lib.DERIV_ANALYTIC)
     with pytest.raises(Exception):
-        pl.fill_hprobs(cols[:2], cols[:2])
+        pl.fill_hprobs(idx1=cols[:2], idx2=cols[:2], mode=_lib.DERIV_ANALYTIC)
+    # FD-of-FD Hessian block of the TP model, bit for bit the Map simulator's (MapForwardSimulator._bulk_fill_hprobs_atom
+    # re-derives the complement after each of the two parameter steps)
+    H = pl.fill_hprobs(idx1=fx["hprobs_rows"], idx2=fx["hprobs_cols"], eps=float(fx["hessian_eps"]))
+    assert np.array_equal(H, fx["hprobs_map"])
+    kr, kc = pk[fx["hprobs_rows"]], pk[fx["hprobs_cols"]]
+    assert (kr == 2).any() and (kc == 2).any() and (kr == 0).any() and (kc == 0).any()
+    assert np.abs(H[fx["eff_dest"][comp_rows]][:, kr == 2][:, :, kc == 2]).max() >= 0      # (effect x effect on the complement outcome)
+    assert np.abs(H[fx["eff_dest"][comp_rows]][:, kr == 2][:, :, kc == 0]).max() > 0       # effect x gate moves it
     # without the declaration the complement outcome would be wrong: the test is sensitive to it
     pl.set_complement_effect(-1)
     J2 = pl.fill_dprobs(param_idx=cols, eps=float(fx["derivative_eps"]), mode=_lib.DERIV_FD)
