@@ -178,7 +178,12 @@ int gst_fill_hprobs(gst_plan *plan, double *out, int64_t ld1, int64_t ld2,
 /* The same block with EXACT second derivatives -- what MatrixForwardSimulator._bulk_fill_hprobs_atom returns
  * (pygsti/forwardsims/matrixforwardsim.py:1190-1287, 1289-1381) -- for the `full` parameterisation:
  * derivative forward / backward states of every row parameter over the prefix / suffix tries, contracted with the
- * cached backward / forward states (on the MFMA cores at D = 16 and 64).  Same argument meaning as gst_fill_hprobs (no step size). */
+ * cached backward / forward states (on the MFMA cores at D = 16 and 64).  Same argument meaning as gst_fill_hprobs (no step size).
+ * While gst_set_derivs is set the block is that of the general parameterisation, for members whose dense elements are
+ * LINEAR in their parameters (TP: has_nonzero_hessian() is False for every member): the element Hessian of the elements
+ * the requested parameters touch, contracted with the derivative columns on both sides.  Members with second
+ * derivatives (CPTPLND, ...) need the extra J_elem . hessian_wrt_params term, which is not implemented: the caller must
+ * not ask (the pyGSTi adapter checks has_nonzero_hessian()). */
 int gst_fill_hprobs_analytic(gst_plan *plan, double *out, int64_t ld1, int64_t ld2, const int64_t *idx1,
                              const int64_t *dest1, int64_t n1, const int64_t *idx2, const int64_t *dest2, int64_t n2);
 

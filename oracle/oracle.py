@@ -260,6 +260,37 @@ def analytic_dprobs_general(fx, cols=None):
     return J, P
 
 
+def analytic_hprobs_general(fx, idx1, idx2):
+    """Exact Hessian block of a LINEAR general parameterisation (TP, ...): the element Hessian contracted with the
+    members' deriv_wrt_params on both sides (their hessian_wrt_params vanish) -- what MatrixForwardSimulator's
+    _hprobs_from_rho_e returns for such models (matrixforwardsim.py:1190-1287)."""
+    D = int(fx["D"]); nR, nEl = len(fx["rhos"]), len(fx["effects"])
+    fe = dict(fx)
+    fe["pkind"], fe["pobj"], fe["pelem"] = element_param_map(fx)
+    base = {1: 0, 2: nR * D, 0: nR * D + nEl * D}
+    idx1 = np.asarray(idx1); idx2 = np.asarray(idx2)
+
+    def weights(idx):
+        pos = {int(p): k for k, p in enumerate(idx)}
+        trip = []
+        for k, o, pidx, dm in derivs_from_fixture(fx):
+            ne = D * D if k == 0 else D
+            a = base[k] + o * ne
+            for c, pi in enumerate(pidx):
+                if int(pi) in pos:
+                    for r in np.nonzero(dm[:, c])[0]:
+                        trip.append((a + int(r), pos[int(pi)], dm[r, c]))
+        elems = sorted(set(t[0] for t in trip))
+        W = np.zeros((len(elems), len(idx)))
+        for a, j, w in trip:
+            W[elems.index(a), j] += w
+        return np.array(elems, np.int64), W
+    e1, W1 = weights(idx1)
+    e2, W2 = weights(idx2)
+    He = analytic_hprobs(fe, e1, e2)
+    return np.einsum("eab,ai,bj->eij", He, W1, W2)
+
+
 def analytic_hprobs(fx, idx1, idx2):
     """d^2 p / d theta_1 d theta_2 for the `full` parameterisation, exactly (what MatrixForwardSimulator's
     _hprobs_from_rho_e assembles from hProdCache, matrixforwardsim.py:1190-1287), by derivative states:

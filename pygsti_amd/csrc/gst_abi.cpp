@@ -108,6 +108,9 @@ struct gst_plan {
     int32_t dv_n_params = 0;
     std::vector<int32_t> dv_kind, dv_obj, dv_ncols;
     std::vector<int64_t> dv_param_idx, dv_off_cols, dv_off_deriv;
+    std::vector<double> dv_deriv_h;     // host copy (the Hessian chain rule reads its sparsity)
+    DevBuf<double> d_helem, d_hw;       // element-Hessian block, CSC weights
+    DevBuf<int32_t> d_hcsc;             // CSC pointers / rows / destinations of both blocks
     DevBuf<double> d_dv_deriv, d_jelem;
     DevBuf<double> d_obj_dt, d_obj_ht, d_obj_pc, d_obj_tmp, d_hess_part, d_hess_out;   // objective Hessian blocks
     DevBuf<int32_t> d_dv_colmap;
@@ -155,7 +158,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
-        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release(); d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release(); d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release(); d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_helem.release(); d_hw.release(); d_hcsc.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release(); d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
@@ -915,6 +918,7 @@ int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t*
     p->dv_param_idx.assign(param_idx, param_idx + off_c[n_objs]);
     p->dv_off_cols = off_c; p->dv_off_deriv = off_d;
     p->dv_n_params = n_params;
+    p->dv_deriv_h.assign(deriv, deriv + off_d[n_objs]);
     HIP_TRY(p->d_dv_deriv.ensure((size_t)std::max<int64_t>(off_d[n_objs], 1)));
     if (off_d[n_objs] > 0) {
         HIP_TRY(hipMemcpyAsync(p->d_dv_deriv.p, deriv, (size_t)off_d[n_objs] * 8, hipMemcpyHostToDevice, p->stream));
@@ -1271,21 +1275,124 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
     return GST_OK;
 }
 
+// Exact Hessian block with gst_set_derivs, for parameterisations whose dense elements are LINEAR in the parameters
+// (TP, ...): H_param[p1][p2] = sum_{a, b} (d elem_a / d p1) H_elem[a][b] (d elem_b / d p2), what
+// MatrixForwardSimulator._hprobs_from_rho_e assembles when the members' hessian_wrt_params vanish
+// (matrixforwardsim.py:1190-1287).  The element block is computed for the elements the requested parameters touch
+// (identity element map, as run_dprobs_general does) and contracted with the sparse derivative columns on the device.
+static int run_hprobs_general(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
+                              int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2)
+{
+    const gst::HostPlan& h = p->hp;
+    const int D = h.D;
+    const int64_t nE = h.n_elements;
+    const int64_t n_el = (int64_t)h.n_rhos * D + (int64_t)h.n_effects * D + (int64_t)h.n_gates * D * D;
+    const int64_t base_rho = 0, base_eff = (int64_t)h.n_rhos * D, base_gate = base_eff + (int64_t)h.n_effects * D;
+    struct Csc { std::vector<int32_t> ptr, row, dest; std::vector<double> w; std::vector<int64_t> elems; };
+    auto build = [&](const int64_t* idx, const int64_t* dest, int64_t n, Csc& c) -> int {
+        std::vector<int32_t> pos((size_t)p->dv_n_params, -1);
+        for (int64_t k = 0; k < n; k++) {
+            if (idx[k] < 0 || idx[k] >= p->dv_n_params) return fail(GST_EINVAL, "parameter index out of range");
+            if (pos[(size_t)idx[k]] >= 0) return fail(GST_EINVAL, "a parameter is requested twice (not supported with gst_set_derivs)");
+            pos[(size_t)idx[k]] = (int32_t)k;
+        }
+        std::vector<std::vector<std::pair<int64_t, double>>> cols((size_t)n);      // (global element, weight) per requested parameter
+        for (size_t o = 0; o < p->dv_kind.size(); o++) {
+            const int k = p->dv_kind[o];
+            const int K = k == GST_KIND_GATE ? D * D : D;
+            const int64_t a0 = (k == GST_KIND_GATE ? base_gate : k == GST_KIND_RHO ? base_rho : base_eff) + (int64_t)p->dv_obj[o] * K;
+            const int nc = p->dv_ncols[o];
+            const double* dm = p->dv_deriv_h.data() + p->dv_off_deriv[o];
+            for (int c2 = 0; c2 < nc; c2++) {
+                const int32_t at = pos[(size_t)p->dv_param_idx[(size_t)p->dv_off_cols[o] + c2]];
+                if (at < 0) continue;
+                for (int r = 0; r < K; r++)
+                    if (dm[(size_t)r * nc + c2] != 0.0) cols[(size_t)at].emplace_back(a0 + r, dm[(size_t)r * nc + c2]);
+            }
+        }
+        std::vector<int64_t> el;
+        for (auto& v : cols) for (auto& e : v) el.push_back(e.first);
+        std::sort(el.begin(), el.end());
+        el.erase(std::unique(el.begin(), el.end()), el.end());
+        c.elems = el;
+        c.ptr.assign((size_t)n + 1, 0);
+        for (int64_t k = 0; k < n; k++) {
+            for (auto& e : cols[(size_t)k]) {
+                c.row.push_back((int32_t)(std::lower_bound(el.begin(), el.end(), e.first) - el.begin()));
+                c.w.push_back(e.second);
+            }
+            c.ptr[(size_t)k + 1] = (int32_t)c.row.size();
+            c.dest.push_back((int32_t)(dest ? dest[k] : k));
+        }
+        return GST_OK;
+    };
+    Csc c1, c2;
+    int rc;
+    if ((rc = build(idx1, dest1, n1, c1)) || (rc = build(idx2, dest2, n2, c2))) return rc;
+    const int64_t m1 = (int64_t)c1.elems.size(), m2 = (int64_t)c2.elems.size();
+    // (m1 == 0 or m2 == 0: nothing the atom applies depends on one of the blocks; the contraction then writes exact zeros)
+    if ((double)nE * (double)std::max<int64_t>(m1, 1) * (double)std::max<int64_t>(m2, 1) * 8.0 > 64.0e9)
+        return fail(GST_ENOMEM, "element-Hessian block too large: request smaller parameter blocks");
+    HIP_TRY(p->d_helem.ensure((size_t)std::max<int64_t>(nE * m1 * m2, 1)));
+    if (m1 > 0 && m2 > 0) {
+        // element Hessian through the `full` path with the identity element map
+        std::vector<int32_t> ek((size_t)n_el), eo((size_t)n_el), ee((size_t)n_el);
+        int64_t q = 0;
+        for (int r = 0; r < h.n_rhos; r++) for (int j = 0; j < D; j++, q++) { ek[q] = GST_KIND_RHO; eo[q] = r; ee[q] = j; }
+        for (int e = 0; e < h.n_effects; e++) for (int j = 0; j < D; j++, q++) { ek[q] = GST_KIND_EFFECT; eo[q] = e; ee[q] = j; }
+        for (int g = 0; g < h.n_gates; g++) for (int j = 0; j < D * D; j++, q++) { ek[q] = GST_KIND_GATE; eo[q] = g; ee[q] = j; }
+        p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
+        p->cached_kind = 0;
+        const bool ds = p->derivs_set;
+        const int32_t ci = p->comp_index;          // (a complement declared for the FD modes plays no role here: the
+        p->derivs_set = false;                     //  derivative columns already carry its -1 entries)
+        p->comp_index = -1;
+        rc = run_hprobs_analytic(p, p->d_helem.p, m1, m2, c1.elems.data(), nullptr, m1, c2.elems.data(), nullptr, m2);
+        p->derivs_set = ds;
+        p->comp_index = ci;
+        p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
+        p->cached_kind = 0;
+        if (rc) return rc;
+    }
+    // CSC tables: [ptr1 | row1 | dest1 | ptr2 | row2 | dest2], weights [w1 | w2]
+    std::vector<int32_t> tab;
+    const size_t o_p1 = 0, o_r1 = o_p1 + c1.ptr.size(), o_d1 = o_r1 + c1.row.size(), o_p2 = o_d1 + c1.dest.size(),
+                 o_r2 = o_p2 + c2.ptr.size(), o_d2 = o_r2 + c2.row.size();
+    tab.insert(tab.end(), c1.ptr.begin(), c1.ptr.end()); tab.insert(tab.end(), c1.row.begin(), c1.row.end());
+    tab.insert(tab.end(), c1.dest.begin(), c1.dest.end());
+    tab.insert(tab.end(), c2.ptr.begin(), c2.ptr.end()); tab.insert(tab.end(), c2.row.begin(), c2.row.end());
+    tab.insert(tab.end(), c2.dest.begin(), c2.dest.end());
+    std::vector<double> w(c1.w);
+    w.insert(w.end(), c2.w.begin(), c2.w.end());
+    if (w.empty()) w.push_back(0.0);
+    if ((rc = upload_i32(p->d_hcsc, tab, p->stream))) return rc;
+    HIP_TRY(p->d_hw.ensure(w.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_hw.p, w.data(), w.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(gst::launch_hessian_chain_rule(p->d_helem.p, nE, (int)m1, (int)m2, p->d_hcsc.p + o_p1, p->d_hcsc.p + o_r1, p->d_hw.p,
+                                           p->d_hcsc.p + o_d1, (int)n1, p->d_hcsc.p + o_p2, p->d_hcsc.p + o_r2,
+                                           p->d_hw.p + c1.w.size(), p->d_hcsc.p + o_d2, (int)n2, d_H, ld1, ld2, p->stream));
+    p->last_launches++;
+    HIP_TRY(hipStreamSynchronize(p->stream));          // the host tables go out of scope
+    return GST_OK;
+}
+
 int gst_fill_hprobs_analytic(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
                              int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2)
 {
     int rc = begin_call(p);
     if (rc) return rc;
-    if (p->derivs_set) return fail(GST_EUNSUPPORTED, "Hessians need the one-parameter-per-element map (gst_set_derivs is set)");
-    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
+    if (!p->derivs_set && !p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
     if (!out && n1 > 0 && n2 > 0) return fail(GST_EINVAL, "out is NULL");
-    if ((rc = check_params(p, idx1, n1)) || (rc = check_params(p, idx2, n2))) return rc;
+    if (n1 < 0 || n2 < 0 || (n1 > 0 && !idx1) || (n2 > 0 && !idx2)) return fail(GST_EINVAL, "bad parameter list");
+    if (!p->derivs_set && ((rc = check_params(p, idx1, n1)) || (rc = check_params(p, idx2, n2)))) return rc;
     const int64_t nE = p->hp.n_elements;
     if (n1 == 0 || n2 == 0) return end_call(p, true);
     HIP_TRY(p->d_out.ensure((size_t)nE * ld1 * ld2));
     const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
     if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
-    if ((rc = run_hprobs_analytic(p, p->d_out.p, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2))) return rc;
+    if (p->derivs_set) rc = run_hprobs_general(p, p->d_out.p, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2);
+    else rc = run_hprobs_analytic(p, p->d_out.p, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));
     return end_call(p, true);
 }

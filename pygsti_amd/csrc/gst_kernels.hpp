@@ -154,6 +154,13 @@ hipError_t launch_dwalk(int D, const DWalkArgs& a, int64_t n_tasks, int n_slots,
 // Objective Hessian block from device-resident hprobs / dprobs blocks and the objective's dterms / hterms.
 hipError_t launch_objective_coeffs(int kind, const double* probs, const double* counts, const double* totals, int64_t n, double min_p,
                                    double radius, double* dterms, double* hterms, hipStream_t s);
+// Chain rule of a Hessian block for linear parameterisations: out[e][dest1[i]][dest2[j]] =
+// sum over (a, w1) in column i of W1 and (b, w2) in column j of W2 of w1 * w2 * H[e][a][b]   (W1, W2 in CSC form,
+// rows = positions in the element-Hessian block H [nE][m1][m2])
+hipError_t launch_hessian_chain_rule(const double* H, int64_t nE, int m1, int m2, const int32_t* ptr1, const int32_t* row1,
+                                     const double* w1, const int32_t* dest1, int n1, const int32_t* ptr2, const int32_t* row2,
+                                     const double* w2, const int32_t* dest2, int n2, double* out, int64_t ld1, int64_t ld2,
+                                     hipStream_t s);
 int hessian_block_slabs(int64_t nE, int n1, int n2);
 hipError_t launch_hessian_block(const double* H, const double* d1, const double* d2, const double* dco, const double* hco, int64_t nE,
                                 int n1, int n2, double* part, int n_slabs, double* out, hipStream_t s);

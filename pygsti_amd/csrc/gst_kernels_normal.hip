@@ -420,4 +420,44 @@ hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_co
     return hipGetLastError();
 }
 
+// ---- chain rule of a Hessian block (linear parameterisations) --------------------------------------------------
+__global__ __launch_bounds__(256) void hessian_chain_rule_kernel(const double* __restrict__ H, int64_t nE, int m1, int m2,
+                                                                 const int32_t* __restrict__ ptr1, const int32_t* __restrict__ row1,
+                                                                 const double* __restrict__ w1, const int32_t* __restrict__ dest1, int n1,
+                                                                 const int32_t* __restrict__ ptr2, const int32_t* __restrict__ row2,
+                                                                 const double* __restrict__ w2, const int32_t* __restrict__ dest2, int n2,
+                                                                 double* __restrict__ out, int64_t ld1, int64_t ld2)
+{
+    const int64_t total = nE * (int64_t)n1 * n2;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int j = (int)(t % n2);
+        const int64_t r = t / n2;
+        const int i = (int)(r % n1);
+        const int64_t e = r / n1;
+        const double* He = H + e * (int64_t)m1 * m2;
+        double acc = 0.0;
+        for (int32_t x = ptr1[i]; x < ptr1[i + 1]; x++) {
+            const double* Ha = He + (int64_t)row1[x] * m2;
+            double inner = 0.0;
+            for (int32_t y = ptr2[j]; y < ptr2[j + 1]; y++) inner += w2[y] * Ha[row2[y]];
+            acc += w1[x] * inner;
+        }
+        out[(e * ld1 + dest1[i]) * ld2 + dest2[j]] = acc;
+    }
+}
+
+hipError_t launch_hessian_chain_rule(const double* H, int64_t nE, int m1, int m2, const int32_t* ptr1, const int32_t* row1,
+                                     const double* w1, const int32_t* dest1, int n1, const int32_t* ptr2, const int32_t* row2,
+                                     const double* w2, const int32_t* dest2, int n2, double* out, int64_t ld1, int64_t ld2,
+                                     hipStream_t s)
+{
+    const int64_t total = nE * (int64_t)n1 * n2;
+    if (total <= 0) return hipSuccess;
+    const int64_t blocks = std::min<int64_t>((total + 255) / 256, 65536);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(hessian_chain_rule_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, nE, m1, m2, ptr1, row1, w1, dest1, n1,
+                       ptr2, row2, w2, dest2, n2, out, ld1, ld2);
+    return hipGetLastError();
+}
+
 }  // namespace gst

@@ -260,9 +260,16 @@ class HipMapForwardSimulator(_MapForwardSimulator):
                                param_slice1, param_slice2, resource_alloc):
         plan = self._prepare(layout_atom, derivatives=True)
         hmode = getattr(plan, "_hip_mode", None)
-        if hmode != "elements" and not (hmode == "tp-elements" and self.derivative_mode == "fd"):
-            raise NotImplementedError("Hessians on the device: fully parameterised models (FD or exact) and full-TP models "
-                                      "(FD of FD, as the Map simulator computes them)")
+        if hmode == "derivs":
+            # exact Hessians of a general parameterisation: only when every member is linear in its parameters
+            for labels, typ in ((layout_atom.op_labels, "op"), (layout_atom.rho_labels, "prep"), (layout_atom._hip_eff_labels, "povm")):
+                for lbl in labels:
+                    if self.model._circuit_layer_operator(lbl, typ).has_nonzero_hessian():
+                        raise NotImplementedError("member %s has second derivatives with respect to its parameters: exact "
+                                                  "Hessians on the device cover linear parameterisations (full, TP)" % str(lbl))
+        elif hmode != "elements" and not (hmode == "tp-elements" and self.derivative_mode == "fd"):
+            raise NotImplementedError("Hessians on the device: fully parameterised models (FD or exact), full-TP models "
+                                      "(FD of FD as the Map simulator computes them, or exact)")
         nP = self.model.num_params
         i1 = np.arange(nP) if param_slice1 is None else _slct.to_array(param_slice1)
         i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)

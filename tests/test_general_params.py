@@ -137,3 +137,49 @@ def test_gpu_tp_model_fd_dprobs_bitwise(name):
     assert not np.array_equal(J2, fx["dprobs_map"])
     ncomp = np.setdiff1d(np.arange(int(fx["nE"])), fx["eff_dest"][comp_rows])
     assert np.array_equal(J2[ncomp], fx["dprobs_map"][ncomp])
+
+
+def test_oracle_tp_exact_hessian_matches_matrix_simulator():
+    """The numpy chain rule of the element Hessian, against MatrixForwardSimulator.bulk_fill_hprobs on the TP model."""
+    fx = load_fixture("smq1Q_XYI_L4_TP")
+    H = O.analytic_hprobs_general(fx, fx["hprobs_rows"], fx["hprobs_cols"])
+    ref = fx["hprobs_matrix"]
+    assert np.abs(H[fx["matrix_rows"]] - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(ref).max() > 0.1
+
+
+@pytest.mark.gpu
+def test_gpu_tp_exact_hessian_block():
+    """gst_fill_hprobs_analytic with gst_set_derivs (linear parameterisation): <= 1e-8 against MatrixForwardSimulator's
+    Hessian of the TP model, and against the numpy chain rule on the 2Q TP fixture (rows/columns over rho, effects that
+    share the complement, gates)."""
+    from pygsti_amd import _lib
+    fx = load_fixture("smq1Q_XYI_L4_TP")
+    pl = plan_from_fixture(fx)
+    pl.set_derivs(int(fx["nP"]), O.derivs_from_fixture(fx))
+    r, c = fx["hprobs_rows"], fx["hprobs_cols"]
+    H = pl.fill_hprobs(idx1=r, idx2=c, mode=_lib.DERIV_ANALYTIC)
+    ref = fx["hprobs_matrix"]
+    assert np.abs(H[fx["matrix_rows"]] - ref).max() < 1e-8
+    assert np.abs(H - O.analytic_hprobs_general(fx, r, c)).max() < 1e-10
+    # FD of FD on the same model agrees to the accuracy of finite differences
+    pl.set_derivs(int(fx["nP"]), [])
+    pl.set_param_map(*O.tp_param_map(fx))
+    pl.set_complement_effect(int(fx["comp_index"]), fx["comp_identity"], fx["comp_others"])
+    Hfd = pl.fill_hprobs(idx1=r, idx2=c, eps=float(fx["hessian_eps"]))
+    assert np.abs(Hfd - H).max() < 2e-3 * max(1.0, np.abs(H).max())
+    # destination windows inside a larger block
+    pl.set_derivs(int(fx["nP"]), O.derivs_from_fixture(fx))
+    out = np.full((int(fx["nE"]), len(r) + 2, len(c) + 3), -5.0)
+    pl.fill_hprobs(out=out, idx1=r, idx2=c, dest1=np.arange(len(r)) + 1, dest2=np.arange(len(c)) + 2, mode=_lib.DERIV_ANALYTIC)
+    assert np.array_equal(out[:, 1:1 + len(r), 2:2 + len(c)], H)
+    assert (out[:, 0] == -5.0).all() and (out[:, :, :2] == -5.0).all() and (out[:, -1] == -5.0).all() and (out[:, :, -1] == -5.0).all()
+    # 2Q
+    fx2 = load_fixture("smq2Q_XYICNOT_L1_TP")
+    pl2 = plan_from_fixture(fx2)
+    pl2.set_derivs(int(fx2["nP"]), O.derivs_from_fixture(fx2))
+    r2, c2 = fx2["hprobs_rows"], fx2["hprobs_cols"]
+    H2 = pl2.fill_hprobs(idx1=r2, idx2=c2, mode=_lib.DERIV_ANALYTIC)
+    Ho = O.analytic_hprobs_general(fx2, r2, c2)
+    assert np.abs(H2 - Ho).max() < 1e-10 * max(1.0, np.abs(Ho).max())
+    assert np.abs(H2 - fx2["hprobs_map"]).max() < 2e-3 * max(1.0, np.abs(Ho).max())      # vs the Map simulator's FD of FD
