@@ -243,7 +243,10 @@ int gst_objective_rows_dev(gst_plan *plan, const gst_objective_desc *desc, doubl
  * Map path), dterms / hterms the raw objective's first and second derivatives in the probabilities (chi^2 or Poisson
  * dlogl, on the clipped probabilities when the interval is given).  d_counts / d_totals: device, per element.
  * out: host, row-major [n1][n2]; atoms / ranks add their blocks.  The (nE x n1 x n2) hprobs block lives in device
- * memory only for the duration of the call -- size the rectangles to fit. */
+ * memory only for the duration of the call -- size the rectangles to fit.
+ * desc->hessian_mode = GST_DERIV_ANALYTIC uses the exact dprobs / hprobs instead; with gst_set_derivs set (linear
+ * general parameterisations, see gst_fill_hprobs_analytic) that is the only mode.  A complement effect
+ * (gst_set_complement_effect) is honoured by the FD mode. */
 int gst_objective_hessian_block(gst_plan *plan, const gst_objective_desc *desc, const double *d_counts,
                                 const double *d_totals, const int64_t *idx1, int64_t n1, const int64_t *idx2,
                                 int64_t n2, double eps, double *out);

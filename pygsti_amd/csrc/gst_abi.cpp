@@ -1427,17 +1427,27 @@ int gst_objective_hessian_block(gst_plan* p, const gst_objective_desc* d, const 
     if (d->kind != GST_OBJ_CHI2 && d->kind != GST_OBJ_POISSON_DLOGL) return fail(GST_EINVAL, "unknown objective kind");
     if (!(d->min_prob_clip > 0.0) || (d->kind == GST_OBJ_POISSON_DLOGL && !(d->radius > 0.0)))
         return fail(GST_EINVAL, "min_prob_clip and radius must be positive");
-    if (p->derivs_set) return fail(GST_EUNSUPPORTED, "Hessians need the one-parameter-per-element map (gst_set_derivs is set)");
-    if (!p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
+    if (p->derivs_set && d->hessian_mode != GST_DERIV_ANALYTIC)
+        return fail(GST_EUNSUPPORTED, "general parameterisations (gst_set_derivs) exist in GST_DERIV_ANALYTIC only");
+    if (!p->derivs_set && !p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
     if (!out && n1 > 0 && n2 > 0) return fail(GST_EINVAL, "out is NULL");
-    if ((rc = check_params(p, idx1, n1)) || (rc = check_params(p, idx2, n2))) return rc;
+    if (n1 < 0 || n2 < 0 || (n1 > 0 && !idx1) || (n2 > 0 && !idx2)) return fail(GST_EINVAL, "bad parameter list");
+    if (!p->derivs_set && ((rc = check_params(p, idx1, n1)) || (rc = check_params(p, idx2, n2)))) return rc;
     if (n1 > 0x7fffffff || n2 > 0x7fffffff) return fail(GST_EINVAL, "block too large");
     const int64_t nE = p->hp.n_elements;
     if (n1 == 0 || n2 == 0) return end_call(p, true);
     HIP_TRY(p->d_out.ensure((size_t)nE * n1 * n2));
     const double* d_d1 = nullptr;
     const double* d_d2 = nullptr;
-    if (d->hessian_mode == GST_DERIV_ANALYTIC) {
+    if (d->hessian_mode == GST_DERIV_ANALYTIC && p->derivs_set) {
+        // linear general parameterisation (TP): chain-ruled Jacobians of both blocks and the chain-ruled Hessian block
+        HIP_TRY(p->d_probs_tmp.ensure((size_t)nE * n1));
+        HIP_TRY(p->d_dcol.ensure((size_t)nE * n2));
+        if ((rc = run_hprobs_general(p, p->d_out.p, n1, n2, idx1, nullptr, n1, idx2, nullptr, n2))) return rc;
+        if ((rc = run_dprobs_general(p, p->d_probs_tmp.p, n1, idx1, nullptr, n1, nullptr))) return rc;
+        if ((rc = run_dprobs_general(p, p->d_dcol.p, n2, idx2, nullptr, n2, nullptr))) return rc;
+        d_d1 = p->d_probs_tmp.p; d_d2 = p->d_dcol.p;
+    } else if (d->hessian_mode == GST_DERIV_ANALYTIC) {
         HIP_TRY(p->d_probs_tmp.ensure((size_t)nE * n1));
         if ((rc = run_dprobs_analytic(p, p->d_probs_tmp.p, n1, idx1, nullptr, n1, nullptr))) return rc;
         if ((rc = run_hprobs_analytic(p, p->d_out.p, n1, n2, idx1, nullptr, n1, idx2, nullptr, n2))) return rc;

@@ -201,3 +201,33 @@ def test_gpu_objective_hessian_block_analytic():
     dt, ht = OO.objective_coeffs(OO.DLOGL, probs, counts, N)
     ref = np.einsum("e,ei,ej->ij", ht, J1, J2) + np.einsum("e,eij->ij", dt, H)
     assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_gpu_objective_hessian_block_tp_model():
+    """The same contraction for a "full TP" model (gst_set_derivs, linear parameterisation): chain-ruled Jacobians and
+    Hessian block on the device, against the numpy chain-rule oracles."""
+    from oracle import oracle as O
+    from pygsti_amd import _lib
+    fx = load_fixture("smq1Q_XYI_L4_TP")
+    plan = plan_from_fixture(fx)
+    nE, nP = int(fx["nE"]), int(fx["nP"])
+    plan.set_derivs(nP, O.derivs_from_fixture(fx))
+    i1 = fx["hprobs_rows"]; i2 = np.arange(nP)
+    rng = np.random.default_rng(5)
+    probs = fx["probs"]
+    N = np.full(nE, 300.0)
+    counts = rng.binomial(300, np.clip(probs, 0, 1)).astype(np.float64)
+    d_c = plan.device_malloc(nE * 8); d_N = plan.device_malloc(nE * 8)
+    try:
+        plan.memcpy_h2d(d_c, counts); plan.memcpy_h2d(d_N, N)
+        got = plan.objective_hessian_block("logl", d_c, d_N, i1, i2, mode=_lib.DERIV_ANALYTIC)
+        with pytest.raises(Exception):        # finite differences do not exist for gst_set_derivs
+            plan.objective_hessian_block("logl", d_c, d_N, i1, i2, mode=_lib.DERIV_FD)
+    finally:
+        plan.device_free(d_c); plan.device_free(d_N)
+    J, _ = O.analytic_dprobs_general(fx)
+    H = O.analytic_hprobs_general(fx, i1, i2)
+    dt, ht = OO.objective_coeffs(OO.DLOGL, probs, counts, N)
+    ref = np.einsum("e,ei,ej->ij", ht, J[:, i1], J[:, i2]) + np.einsum("e,eij->ij", dt, H)
+    assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
