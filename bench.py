@@ -345,8 +345,8 @@ def main():
             "analytic_dprobs": ana_info,
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,
-            "roofline": roof or {"bound": "valu_f64",
-                         "bound_note": "compute-bound on the fp64 VECTOR ALU (no matrix instruction can reproduce the reference's un-fused, ordered sums); its 78.6 TFLOP/s FMA peak equals MI355X's dense fp64 MFMA peak, so `frac` reads the same against either",
+            "roofline": roof or {"bound": "mfma", "compute_unit": "valu_f64",
+                         "bound_note": "the compute roof (\"mfma\" in this line's vocabulary): dense fp64 peak 78.6 TFLOP/s, which on MI355X is both the MFMA and the vector-FMA rate. The kernel runs on the fp64 VECTOR ALU -- no matrix instruction can reproduce the reference's un-fused, ordered sums -- so `frac` is against the roof the contract names and `compute_unit` says which pipe does the work",
                          "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
                          "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (k_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
