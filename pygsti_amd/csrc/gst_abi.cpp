@@ -63,7 +63,8 @@ struct gst_plan {
     int device = -1;
     bool dev_ready = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+    hipStream_t stream2 = nullptr;      // the backward chain pass of the analytic mode runs beside the forward one
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
 
     // device copies of the plan
     DevBuf<uint32_t> d_prog;
@@ -169,6 +170,9 @@ struct gst_plan {
         if (ev1) (void)hipEventDestroy(ev1);
         if (evk0) (void)hipEventDestroy(evk0);
         if (evk1) (void)hipEventDestroy(evk1);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -221,6 +225,8 @@ int ensure_device(gst_plan* p)
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&p->ev0)); HIP_TRY(hipEventCreate(&p->ev1));
     HIP_TRY(hipEventCreate(&p->evk0)); HIP_TRY(hipEventCreate(&p->evk1));
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     const gst::HostPlan& h = p->hp;
     HIP_TRY(p->d_prog.ensure(h.prog.size()));
     HIP_TRY(p->d_task_off.ensure(h.task_off.size()));
@@ -625,6 +631,8 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (h.D != 4 && h.D != 16 && h.D != 64) return fail(GST_EUNSUPPORTED, "the analytic mode supports D = 4, 16 and 64");
     if (h.D == 64 && !p->ana_mfma) return fail(GST_EUNSUPPORTED, "D = 64 analytic derivatives exist on the MFMA path only");
     double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
+    // (the backward chain pass needs only the model arrays already on their way: it forks here, onto the second stream)
+    HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
     int rc = run_probs(p, d_base, n_param > 0);        // probabilities + every forward state
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
@@ -707,17 +715,22 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         w.base_cache_w = p->d_rev_cache.p;
         w.multi_start = h.n_effects;
         HIP_TRY(hipEventRecord(p->evk0, p->stream));
+        // Both chain passes are latency-bound (one wavefront per task, a fraction of the SIMDs): the backward one runs
+        // on the second stream beside the forward pass launched above, and the contraction waits for both.
+        HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
         if (D == 64) {                                         // one wavefront per (task, effect), a single launch
             w.start0 = 0; w.n_pwaves = h.n_effects;
-            HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream));
+            HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));
             p->last_launches++;
         } else {
             for (int e0 = 0; e0 < h.n_effects; e0 += 64 / D) {  // four effects (lane groups) per pass of the chain kernel
                 w.start0 = e0;
-                HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream));
+                HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));
                 p->last_launches++;
             }
         }
+        HIP_TRY(hipEventRecord(p->ev_join, p->stream2));
+        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
         a.rev_cache = p->d_rev_cache.p; a.rev_leaf = p->d_rev_leaf.p; a.pair_f = p->d_pair_f.p; a.pair_r = p->d_pair_r.p;
         a.pos_ptr = p->d_pos_ptr.p; a.circ_rho = p->d_circ_rho.p; a.circ_order = p->d_circ_order.p; a.work_counter = p->d_work_counter.p; a.range_begin = p->d_range_begin.p;
         HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));

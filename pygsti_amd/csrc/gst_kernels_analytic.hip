@@ -346,7 +346,10 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                     if (c0 >= 0) {           // D*D consecutive columns: entry (row, col) at c0 + row*D + col
                         double* o = a.out + dest_u[x] * a.ld + c0 + kk * D + i;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) o[4 * r * D] = a.accumulate ? o[4 * r * D] + acc[x][r] : acc[x][r];
+                        for (int r = 0; r < 4; r++) {
+                            if (a.accumulate) o[4 * r * D] = o[4 * r * D] + acc[x][r];
+                            else __builtin_nontemporal_store(acc[x][r], &o[4 * r * D]);     // written once, never re-read here: do not displace the state caches in L2
+                        }
                     } else {                 // arbitrary subset / order: per-element column map
                         const int32_t* cm = a.colmap_gate + (int64_t)g * D * D + kk * D + i;
 #pragma unroll
