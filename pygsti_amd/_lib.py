@@ -187,8 +187,28 @@ class Plan:
 
     def close(self):
         if self._h is not None and self._h.value:
+            for ptr, _ in getattr(self, "_workspaces", {}).values():
+                try:
+                    lib().gst_device_free(self._h, C.c_void_p(int(ptr)))
+                except Exception:
+                    pass
+            self._workspaces = {}
             lib().gst_plan_destroy(self._h)
         self._h = None
+
+    def workspace(self, name, nbytes):
+        """A named device buffer that lives as long as the plan (grown on demand): what an optimizer's iterations reuse
+        instead of allocating the Jacobian every call."""
+        ws = self.__dict__.setdefault("_workspaces", {})
+        have = ws.get(name)
+        if have is not None and have[1] >= nbytes:
+            return have[0]
+        if have is not None:
+            self.device_free(have[0])
+            del ws[name]
+        ptr = self.device_malloc(max(int(nbytes), 8))
+        ws[name] = (ptr, int(nbytes))
+        return ptr
 
     def __del__(self):
         try:

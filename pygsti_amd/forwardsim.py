@@ -299,25 +299,22 @@ class HipMapForwardSimulator:
             plan = self._prepare_atom(atom)
             nE = atom.num_elements
             es = atom.element_slice
-            bufs = [plan.device_malloc(max(nb, 8)) for nb in (nE * nP * 8, nE * 8, nE * 8, nE * 8, nE * 8, nE * 8,
-                                                               nP * nP * 8, nP * 8)]
+            # (plan-lifetime workspaces: an optimizer calls this every iteration)
+            sizes = (nE * nP * 8, nE * 8, nE * 8, nE * 8, nE * 8, nE * 8, nP * nP * 8, nP * 8)
+            bufs = [plan.workspace("lsq%d" % k, nb) for k, nb in enumerate(sizes)]
             d_J, d_pr, d_c, d_N, d_ls, d_w, d_jtj, d_jtf = bufs
-            try:
-                plan.memcpy_h2d(d_c, counts[es]); plan.memcpy_h2d(d_N, total_counts[es])
-                plan.fill_dprobs_dev(d_J, nP, pidx, None, self.derivative_eps, d_pr, mode)
-                total += plan.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius,
-                                                 prob_clip_interval)
-                plan.fill_jtj_dev(d_J, nE, nP, nP, d_jtj, d_w)          # scales the rows of J in place first
-                plan.fill_jtf_dev(d_J, nE, nP, nP, d_ls, d_jtf)
-                part = np.empty((nP, nP)); plan.memcpy_d2h(part, d_jtj); jtj += part
-                pv = np.empty(nP); plan.memcpy_d2h(pv, d_jtf); jtf += pv
-                if lsvec_to_fill is not None:
-                    plan.memcpy_d2h(lsvec_to_fill[es], d_ls)
-                if pr_array_to_fill is not None:
-                    plan.memcpy_d2h(pr_array_to_fill[es], d_pr)
-            finally:
-                for d in bufs:
-                    plan.device_free(d)
+            plan.memcpy_h2d(d_c, counts[es]); plan.memcpy_h2d(d_N, total_counts[es])
+            plan.fill_dprobs_dev(d_J, nP, pidx, None, self.derivative_eps, d_pr, mode)
+            total += plan.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius,
+                                             prob_clip_interval)
+            plan.fill_jtj_dev(d_J, nE, nP, nP, d_jtj, d_w)          # scales the rows of J in place first
+            plan.fill_jtf_dev(d_J, nE, nP, nP, d_ls, d_jtf)
+            part = np.empty((nP, nP)); plan.memcpy_d2h(part, d_jtj); jtj += part
+            pv = np.empty(nP); plan.memcpy_d2h(pv, d_jtf); jtf += pv
+            if lsvec_to_fill is not None:
+                plan.memcpy_d2h(lsvec_to_fill[es], d_ls)
+            if pr_array_to_fill is not None:
+                plan.memcpy_d2h(pr_array_to_fill[es], d_pr)
         return total
 
     def bulk_fill_objective_hessian(self, hessian, layout, counts, total_counts, objective="logl", min_prob_clip=1e-4,
