@@ -9,15 +9,16 @@
 // Tiling (gfx950, wave64, v_mfma_f64_16x16x4_f64):
 //   * The A operand of the MFMA wants lane l to hold A[i = l&15][k = l>>4], the B operand B[k = l>>4][j = l&15].
 //     With A[i][k] = J[k][i0+i] and B[k][j] = J[k][j0+j] BOTH are plain 4-row x 16-column patches of the row-major
-//     Jacobian, 128 contiguous bytes per row: no transposition, no LDS -- operands go HBM/L2 -> VGPR directly.
+//     Jacobian, 128 contiguous bytes per row: no transposition anywhere; a workgroup stages its 8-row panel in LDS.
 //   * One wavefront owns a 64 x 64 block of JtJ (4 x 4 MFMA tiles, 64 fp64 accumulators per lane); a 256-thread
 //     workgroup owns a 128 x 128 tile over ONE SLAB of rows (split-K: the row dimension is cut into slabs so that
-//     tiles x slabs >> 256 CUs); per 4 rows a wavefront loads 4 + 4 patches and issues 16 MFMAs.
+//     tiles x slabs >> 256 CUs); per 4 rows a wavefront reads 4 + 4 patches and issues 16 MFMAs.
 //   * Only tiles on or above the diagonal are computed; partial tiles of every slab go to a scratch buffer and a
 //     second kernel sums the slabs in a fixed order (deterministic, no atomics) and mirrors the triangle.
 #include "gst_kernels.hpp"
 
 #include <algorithm>
+#include <cstdint>
 
 namespace gst {
 
@@ -26,14 +27,19 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int JTJ_TILE = 128;     // workgroup tile of JtJ
 constexpr int JTJ_WT = 64;        // wavefront tile
 
-__global__ __launch_bounds__(256, 2) void jtj_mfma_kernel(const double* __restrict__ J, int64_t n_rows, int n_cols,
-                                                          int64_t ld, int64_t slab_rows, int n_tiles,
-                                                          double* __restrict__ part /* [n_slabs][n_cols][n_cols] */)
+// The row panel is staged through LDS: the four wavefronts of a workgroup need the same 8 rows x (128 + 128) columns,
+// so the workgroup fetches them ONCE (64 bytes per thread, coalesced 1 KB runs) and every wavefront reads its 4 + 4
+// operand patches from LDS.  That halves the L2 -> CU traffic of the first version, in which each wavefront loaded its
+// own patches straight into the MFMA layout (33.7 -> 30.7 ms on the 2Q design, 42 -> 46 TFLOP/s).  Two panels in LDS:
+// the next one is in flight (global -> registers) while the current one feeds 32 MFMAs per wavefront; one barrier per
+// 8 rows.  (Three workgroups per CU instead of two: 168 VGPRs, spills, 35.5 ms.)
+constexpr int JTJ_LDS_STRIDE = 2 * JTJ_TILE + 8;        // doubles per staged row (+8: the 4 rows of a patch start in different banks)
+
+__global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __restrict__ J, int64_t n_rows, int n_cols,
+                                                              int64_t ld, int64_t slab_rows, int n_tiles,
+                                                              double* __restrict__ part)
 {
-    // blockIdx.x -> (tile pair index p, slab s); pairs enumerate ti <= tj
-    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  All tile
-    // pairs of one slab of rows are given to ONE XCD, so the ~64 workgroups resident there sweep the same rows
-    // at the same pace and share them through that XCD's 4 MB L2 instead of each pulling them from HBM.
+    __shared__ __attribute__((aligned(16))) double panel[2][8 * JTJ_LDS_STRIDE];
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
     const int xcd = blockIdx.x % 8, q = blockIdx.x / 8;
     const int p = q % n_pairs;
@@ -42,8 +48,7 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_kernel(const double* __restri
     while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ti++; }
     const int tj = ti + rem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = ti * JTJ_TILE + (wave >> 1) * JTJ_WT;      // first JtJ row of this wavefront
-    const int j0 = tj * JTJ_TILE + (wave & 1) * JTJ_WT;       // first JtJ column
+    const int wi = (wave >> 1) * JTJ_WT, wj = (wave & 1) * JTJ_WT;       // this wavefront's 64 x 64 block inside the tile
     const int lk = lane >> 4, lc = lane & 15;
 
     d4_t acc[4][4];
@@ -54,36 +59,58 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_kernel(const double* __restri
 
     const int64_t k_begin = s * slab_rows;
     const int64_t k_end = (k_begin + slab_rows < n_rows) ? k_begin + slab_rows : n_rows;
-    // column guards (the last tile is partial); out-of-range operands are zero
-    bool ca[4], cb[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) { ca[t] = i0 + 16 * t + lc < n_cols; cb[t] = j0 + 16 * t + lc < n_cols; }
-
-    auto load = [&](int64_t k, double (&a)[4], double (&b)[4]) {
-        const int64_t r = k + lk;
+    // staging role of this thread: row (0..7) of the panel, segment (A columns of tile ti / B columns of tile tj), 8 doubles
+    const int sr = threadIdx.x >> 5, sseg = (threadIdx.x >> 4) & 1, sch = threadIdx.x & 15;
+    const int scol = (sseg ? tj : ti) * JTJ_TILE + sch * 8;
+    double* const sdst0 = &panel[0][sr * JTJ_LDS_STRIDE + sseg * JTJ_TILE + sch * 8];
+    double* const sdst1 = &panel[1][sr * JTJ_LDS_STRIDE + sseg * JTJ_TILE + sch * 8];
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    d2_t g[4];
+    auto fetch = [&](int64_t k) {
+        const int64_t r = k + sr;
         const bool rv = r < k_end;
-        const double* row = J + (rv ? r : 0) * ld;
+        const double* src = J + (rv ? r : 0) * ld + scol;
+        if (rv && scol + 8 <= n_cols && (((uintptr_t)src & 15) == 0)) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            a[t] = (rv && ca[t]) ? row[i0 + 16 * t + lc] : 0.0;
-            b[t] = (rv && cb[t]) ? row[j0 + 16 * t + lc] : 0.0;
+            for (int t = 0; t < 4; t++) g[t] = *(const d2_t*)(src + 2 * t);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                g[t].x = (rv && scol + 2 * t < n_cols) ? src[2 * t] : 0.0;
+                g[t].y = (rv && scol + 2 * t + 1 < n_cols) ? src[2 * t + 1] : 0.0;
+            }
         }
     };
-    double a0[4], b0[4], a1[4], b1[4];
-    load(k_begin, a0, b0);
-    for (int64_t k = k_begin; k < k_end; k += 8) {           // two 4-row steps per iteration, operands double-buffered
-        load(k + 4, a1, b1);
+    auto stash = [&](double* dst) {
 #pragma unroll
-        for (int x = 0; x < 4; x++)
-#pragma unroll
-            for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], b0[y], acc[x][y], 0, 0, 0);
-        load(k + 8, a0, b0);
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-#pragma unroll
-            for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], b1[y], acc[x][y], 0, 0, 0);
+        for (int t = 0; t < 4; t++) *(d2_t*)(dst + 2 * t) = g[t];
+    };
+    if (k_begin < k_end) {
+        fetch(k_begin);
+        stash(sdst0);
     }
-    // D layout of v_mfma_f64_16x16x4_f64: lane l, register r -> row (l>>4) + 4r, column l&15
+    __syncthreads();
+    int cur = 0;
+    for (int64_t k = k_begin; k < k_end; k += 8) {
+        const bool more = k + 8 < k_end;
+        if (more) fetch(k + 8);                                  // next panel: global -> registers, lands during the MFMAs
+        const double* pc = panel[cur];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                            // two 4-row steps per panel
+            const double* row = pc + (4 * h + lk) * JTJ_LDS_STRIDE;
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { a[t] = row[wi + 16 * t + lc]; b[t] = row[JTJ_TILE + wj + 16 * t + lc]; }
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+#pragma unroll
+                for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+        if (more) stash(cur ? sdst0 : sdst1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int i0 = ti * JTJ_TILE + wi, j0 = tj * JTJ_TILE + wj;
     double* out = part + (int64_t)s * n_cols * n_cols;
 #pragma unroll
     for (int x = 0; x < 4; x++)
@@ -399,7 +426,7 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
     int64_t slab_rows = (n_rows + n_slabs - 1) / n_slabs;
     slab_rows = (slab_rows + 7) / 8 * 8;                         // the k loop advances 8 rows per iteration
     (void)hipGetLastError();
-    hipLaunchKernelGGL(jtj_mfma_kernel, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), 0, s, J, n_rows, n_cols, ld,
+    hipLaunchKernelGGL(jtj_mfma_lds_kernel, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), 0, s, J, n_rows, n_cols, ld,
                        slab_rows, n_tiles, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
