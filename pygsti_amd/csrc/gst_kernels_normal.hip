@@ -30,16 +30,20 @@ constexpr int JTJ_WT = 64;        // wavefront tile
 // The row panel is staged through LDS: the four wavefronts of a workgroup need the same 8 rows x (128 + 128) columns,
 // so the workgroup fetches them ONCE (64 bytes per thread, coalesced 1 KB runs) and every wavefront reads its 4 + 4
 // operand patches from LDS.  That halves the L2 -> CU traffic of the first version, in which each wavefront loaded its
-// own patches straight into the MFMA layout (33.7 -> 30.7 ms on the 2Q design, 42 -> 46 TFLOP/s).  Two panels in LDS:
-// the next one is in flight (global -> registers) while the current one feeds 32 MFMAs per wavefront; one barrier per
-// 8 rows.  (Three workgroups per CU instead of two: 168 VGPRs, spills, 35.5 ms.)
+// own patches straight into the MFMA layout (33.7 -> 29.2 ms on the 2Q design, 42 -> 49 TFLOP/s).  Two panels in LDS:
+// the next one is in flight (global -> registers) while the current one feeds 64 MFMAs per wavefront; one barrier per
+// JTJ_PANEL = 16 rows.  (Three workgroups per CU instead of two: 168 VGPRs, spills, 35.5 ms.)
 constexpr int JTJ_LDS_STRIDE = 2 * JTJ_TILE + 8;        // doubles per staged row (+8: the 4 rows of a patch start in different banks)
+
+constexpr int JTJ_PANEL = 16;                           // rows staged per barrier
 
 __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __restrict__ J, int64_t n_rows, int n_cols,
                                                               int64_t ld, int64_t slab_rows, int n_tiles,
                                                               double* __restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) double panel[2][8 * JTJ_LDS_STRIDE];
+    extern __shared__ __attribute__((aligned(16))) double panel_mem[];      // [2][JTJ_PANEL * JTJ_LDS_STRIDE]
+    double* const panel0 = panel_mem;
+    double* const panel1 = panel_mem + JTJ_PANEL * JTJ_LDS_STRIDE;
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
     const int xcd = blockIdx.x % 8, q = blockIdx.x / 8;
     const int p = q % n_pairs;
@@ -59,44 +63,49 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __re
 
     const int64_t k_begin = s * slab_rows;
     const int64_t k_end = (k_begin + slab_rows < n_rows) ? k_begin + slab_rows : n_rows;
-    // staging role of this thread: row (0..7) of the panel, segment (A columns of tile ti / B columns of tile tj), 8 doubles
+    // staging role of this thread: rows sr and sr + 8 of the panel, segment (A columns of tile ti / B columns of
+    // tile tj), 8 doubles
     const int sr = threadIdx.x >> 5, sseg = (threadIdx.x >> 4) & 1, sch = threadIdx.x & 15;
     const int scol = (sseg ? tj : ti) * JTJ_TILE + sch * 8;
-    double* const sdst0 = &panel[0][sr * JTJ_LDS_STRIDE + sseg * JTJ_TILE + sch * 8];
-    double* const sdst1 = &panel[1][sr * JTJ_LDS_STRIDE + sseg * JTJ_TILE + sch * 8];
+    const int soff = sr * JTJ_LDS_STRIDE + sseg * JTJ_TILE + sch * 8;
     typedef double d2_t __attribute__((ext_vector_type(2)));
-    d2_t g[4];
+    d2_t g[JTJ_PANEL / 8][4];
     auto fetch = [&](int64_t k) {
-        const int64_t r = k + sr;
-        const bool rv = r < k_end;
-        const double* src = J + (rv ? r : 0) * ld + scol;
-        if (rv && scol + 8 <= n_cols && (((uintptr_t)src & 15) == 0)) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) g[t] = *(const d2_t*)(src + 2 * t);
-        } else {
+        for (int u = 0; u < JTJ_PANEL / 8; u++) {
+            const int64_t r = k + sr + 8 * u;
+            const bool rv = r < k_end;
+            const double* src = J + (rv ? r : 0) * ld + scol;
+            if (rv && scol + 8 <= n_cols && (((uintptr_t)src & 15) == 0)) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                g[t].x = (rv && scol + 2 * t < n_cols) ? src[2 * t] : 0.0;
-                g[t].y = (rv && scol + 2 * t + 1 < n_cols) ? src[2 * t + 1] : 0.0;
+                for (int t = 0; t < 4; t++) g[u][t] = *(const d2_t*)(src + 2 * t);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    g[u][t].x = (rv && scol + 2 * t < n_cols) ? src[2 * t] : 0.0;
+                    g[u][t].y = (rv && scol + 2 * t + 1 < n_cols) ? src[2 * t + 1] : 0.0;
+                }
             }
         }
     };
-    auto stash = [&](double* dst) {
+    auto stash = [&](double* pan) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) *(d2_t*)(dst + 2 * t) = g[t];
+        for (int u = 0; u < JTJ_PANEL / 8; u++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) *(d2_t*)(pan + soff + 8 * u * JTJ_LDS_STRIDE + 2 * t) = g[u][t];
     };
     if (k_begin < k_end) {
         fetch(k_begin);
-        stash(sdst0);
+        stash(panel0);
     }
     __syncthreads();
     int cur = 0;
-    for (int64_t k = k_begin; k < k_end; k += 8) {
-        const bool more = k + 8 < k_end;
-        if (more) fetch(k + 8);                                  // next panel: global -> registers, lands during the MFMAs
-        const double* pc = panel[cur];
+    for (int64_t k = k_begin; k < k_end; k += JTJ_PANEL) {
+        const bool more = k + JTJ_PANEL < k_end;
+        if (more) fetch(k + JTJ_PANEL);                          // next panel: global -> registers, lands during the MFMAs
+        const double* pc = cur ? panel1 : panel0;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {                            // two 4-row steps per panel
+        for (int h = 0; h < JTJ_PANEL / 4; h++) {                // 4-row steps of the panel
             const double* row = pc + (4 * h + lk) * JTJ_LDS_STRIDE;
             double a[4], b[4];
 #pragma unroll
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __re
 #pragma unroll
                 for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
         }
-        if (more) stash(cur ? sdst0 : sdst1);
+        if (more) stash(cur ? panel0 : panel1);
         __syncthreads();
         cur ^= 1;
     }
@@ -424,9 +433,16 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
     const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
     int64_t slab_rows = (n_rows + n_slabs - 1) / n_slabs;
-    slab_rows = (slab_rows + 7) / 8 * 8;                         // the k loop advances 8 rows per iteration
+    slab_rows = (slab_rows + JTJ_PANEL - 1) / JTJ_PANEL * JTJ_PANEL;        // the k loop advances one panel per iteration
     (void)hipGetLastError();
-    hipLaunchKernelGGL(jtj_mfma_lds_kernel, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), 0, s, J, n_rows, n_cols, ld,
+    const size_t lds_bytes = (size_t)2 * JTJ_PANEL * JTJ_LDS_STRIDE * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set && lds_bytes > 64 * 1024) {
+        hipError_t ea = hipFuncSetAttribute((const void*)jtj_mfma_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (ea != hipSuccess) return ea;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(jtj_mfma_lds_kernel, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld,
                        slab_rows, n_tiles, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
