@@ -87,7 +87,8 @@ struct gst_plan {
     bool rev_ready = false;
     DevBuf<uint32_t> d_rprog;
     DevBuf<int64_t> d_rtask_off, d_pos_ptr;
-    DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order;
+    DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order, d_circ_partner, d_pair_common;
+    bool ana_pairs = true;              // GST_ANALYTIC_PAIRS=0: one circuit per work item in the D = 16 contraction
     DevBuf<double> d_rev_cache;
     DevBuf<uint32_t> d_work_counter, d_range_begin;
     bool want_cache_path = false;       // set by the Hessian driver around its set-up Jacobian call
@@ -159,7 +160,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
-        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release(); d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_helem.release(); d_hw.release(); d_hcsc.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release(); d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release(); d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_circ_partner.release(); d_pair_common.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_helem.release(); d_hw.release(); d_hcsc.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release(); d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
@@ -198,6 +199,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     p->device = opt ? opt->device : -1;
     p->fd_split = opt ? opt->fd_split : 0;
     if (const char* e = std::getenv("GST_FD_SPLIT")) p->fd_split = std::atoi(e);     // development override
+    if (const char* e = std::getenv("GST_ANALYTIC_PAIRS")) p->ana_pairs = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_PERSIST")) { p->fd_persist = std::atoi(e) != 0; p->fd_persist_always = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
@@ -592,21 +594,76 @@ int ensure_reverse(gst_plan* p)
     std::vector<int32_t> order((size_t)h.n_circuits);
     for (int64_t c = 0; c < h.n_circuits; c++) order[(size_t)c] = (int32_t)c;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->rev.circ_leaf[x] < p->rev.circ_leaf[y]; });
-    if ((rc = upload_i32(p->d_circ_order, order, p->stream))) return rc;
-    // 8 contiguous ranges of the ordered list with equal numbers of gate applications (+ a constant per circuit)
+    // Work items of the D = 16 contraction: a circuit, or TWO neighbours of the suffix order whose last applications
+    // coincide (same germ power and measurement fiducial behind different preparation fiducials): over the common
+    // tail their backward states are the same vectors and the kernel gathers them once for both.
+    std::vector<int32_t> item_first, item_partner, item_common;
+    const int nG = h.n_gates;
+    const bool pairing = h.D == 16 && h.n_effects == 4 && p->ana_pairs;
+    auto plain4 = [&](int32_t c) {
+        if (h.eff_ptr[c + 1] - h.eff_ptr[c] != 4) return false;
+        for (int x = 0; x < 4; x++) if (h.eff_label[(size_t)h.eff_ptr[c] + x] != x) return false;
+        return true;
+    };
+    for (int64_t k = 0; k < h.n_circuits; k++) {
+        const int32_t c = order[(size_t)k];
+        bool paired = false;
+        if (pairing && k + 1 < h.n_circuits) {
+            const int32_t c2 = order[(size_t)k + 1];
+            if (plain4(c) && plain4(c2)) {
+                std::vector<int32_t> cg((size_t)nG, 0);
+                int64_t common = 0;
+                for (int g = 0; g < nG; g++) {
+                    const int64_t a0 = pos_ptr[(size_t)c * nG + g], a1 = pos_ptr[(size_t)c * nG + g + 1];
+                    const int64_t b0 = pos_ptr[(size_t)c2 * nG + g], b1 = pos_ptr[(size_t)c2 * nG + g + 1];
+                    int64_t n = 0;
+                    while (n < a1 - a0 && n < b1 - b0 && pr[(size_t)(a1 - 1 - n)] == pr[(size_t)(b1 - 1 - n)]) n++;
+                    cg[(size_t)g] = (int32_t)n;
+                    common += n;
+                }
+                const int64_t longer = std::max(h.circ_ptr[c + 1] - h.circ_ptr[c], h.circ_ptr[c2 + 1] - h.circ_ptr[c2]);
+                if (common >= 8 && 2 * common >= longer) {
+                    item_first.push_back(c); item_partner.push_back(c2);
+                    item_common.insert(item_common.end(), cg.begin(), cg.end());
+                    paired = true;
+                    k++;
+                }
+            }
+        }
+        if (!paired) {
+            item_first.push_back(c); item_partner.push_back(-1);
+            item_common.insert(item_common.end(), (size_t)nG, 0);
+        }
+    }
+    const int64_t n_items = (int64_t)item_first.size();
+    if (h.D == 16) {
+        if ((rc = upload_i32(p->d_circ_order, item_first, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_circ_partner, item_partner, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_pair_common, item_common, p->stream))) return rc;
+    } else {
+        if ((rc = upload_i32(p->d_circ_order, order, p->stream))) return rc;
+    }
+    // 8 contiguous ranges of the item list with equal numbers of gate applications (+ a constant per circuit)
     std::vector<uint32_t> range_begin(9, 0);
     {
+        auto work = [&](int64_t k) {
+            double w = (double)(h.circ_ptr[item_first[(size_t)k] + 1] - h.circ_ptr[item_first[(size_t)k]]) + 24.0;
+            if (item_partner[(size_t)k] >= 0) w += (double)(h.circ_ptr[item_partner[(size_t)k] + 1] - h.circ_ptr[item_partner[(size_t)k]]) + 24.0;
+            return w;
+        };
         double total = 0;
-        for (int64_t c = 0; c < h.n_circuits; c++) total += (double)(h.circ_ptr[c + 1] - h.circ_ptr[c]) + 24.0;
+        for (int64_t k = 0; k < n_items; k++) total += work(k);
         double acc = 0;
         int r = 1;
-        for (int64_t k = 0; k < h.n_circuits && r < 8; k++) {
-            const int32_t c = order[(size_t)k];
-            acc += (double)(h.circ_ptr[c + 1] - h.circ_ptr[c]) + 24.0;
+        for (int64_t k = 0; k < n_items && r < 8; k++) {
+            acc += work(k);
             while (r < 8 && acc >= total * r / 8.0) range_begin[r++] = (uint32_t)(k + 1);
         }
-        for (; r < 8; r++) range_begin[r] = (uint32_t)h.n_circuits;
-        range_begin[8] = (uint32_t)h.n_circuits;
+        for (; r < 8; r++) range_begin[r] = (uint32_t)n_items;
+        range_begin[8] = (uint32_t)n_items;
+    }
+    if (h.D != 16) {            // (the other contraction kernels index the plain permutation; their ranges are unused)
+        for (int r = 0; r <= 8; r++) range_begin[r] = (uint32_t)(h.n_circuits * r / 8);
     }
     HIP_TRY(p->d_range_begin.ensure(9));
     HIP_TRY(hipMemcpyAsync(p->d_range_begin.p, range_begin.data(), 9 * 4, hipMemcpyHostToDevice, p->stream));
@@ -732,6 +789,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         HIP_TRY(hipEventRecord(p->ev_join, p->stream2));
         HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
         a.rev_cache = p->d_rev_cache.p; a.rev_leaf = p->d_rev_leaf.p; a.pair_f = p->d_pair_f.p; a.pair_r = p->d_pair_r.p;
+        a.circ_partner = D == 16 ? p->d_circ_partner.p : nullptr; a.pair_common = D == 16 ? p->d_pair_common.p : nullptr;
         a.pos_ptr = p->d_pos_ptr.p; a.circ_rho = p->d_circ_rho.p; a.circ_order = p->d_circ_order.p; a.work_counter = p->d_work_counter.p; a.range_begin = p->d_range_begin.p;
         HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
         if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));

@@ -105,6 +105,8 @@ struct AnaArgs {
     const int64_t* pos_ptr;       // [n_circuits * n_gates + 1]
     const int32_t* circ_rho;      // [n_circuits]
     const int32_t* circ_order;    // [n_circuits] circuits sorted by their reversed string (= by rev_leaf)
+    const int32_t* circ_partner;  // D = 16: [n_items] second circuit of a work item (same last applications), or -1; NULL: none
+    const int32_t* pair_common;   // [n_items * n_gates] applications of each gate in the common tail of a two-circuit item
     const uint32_t* range_begin;  // [9] the suffix-ordered list cut into 8 ranges of equal work (one per XCD)
     // Hessian rows reuse the D = 16 MFMA contraction with derivative states in place of one of the two caches:
     uint32_t fwd_stride, rev_stride;   // bytes between consecutive states of base_cache / rev_cache (0: the plain layouts)

@@ -20,6 +20,8 @@
 // Roofline: the Jacobian write (8*nE*nP bytes) against ~5 FMA-issue cycles per element and gate application.
 #include "gst_kernels.hpp"
 
+#include <type_traits>
+
 #include "../../include/gstfwd.h"
 
 namespace gst {
@@ -221,10 +223,131 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
     const int lane = threadIdx.x & 63;
     const int kk = lane >> 4, i = lane & 15;
     const int nE = a.n_effects, nG = a.n_gates;
-    // Work distribution: the suffix-ordered circuit list is cut into 8 contiguous ranges of equal work, one per XCD
-    // (workgroup b runs on XCD b % 8 -- observed dispatch rule, used for locality only): neighbours in that order share
-    // their backward chains and, over a longer stretch, the forward chains of their germ, so both stay in that XCD's
-    // 4 MB L2 instead of being pulled from HBM by all eight.  A wavefront that finds its range empty helps the next.
+    const uint32_t fstride = a.fwd_stride ? a.fwd_stride : (uint32_t)(D * 8);
+    const uint32_t rstride = a.rev_stride ? a.rev_stride : (uint32_t)nE * (D * 8);
+    // uniform 64-bit bases + 32-bit per-lane byte offsets (both caches are < 4 GB, checked on the host): one offset
+    // register serves the F load / the NX backward loads of a gathered application
+    const char* const fb = (const char*)a.base_cache;
+    const char* const rb = (const char*)a.rev_cache;
+    const uint32_t lane_b = (uint32_t)i * 8u;
+    const uint32_t lane_r = (uint32_t)i * (uint32_t)nE * 8u;       // backward cache is [state][component][effect]
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+
+    // outcome labels / destinations of one circuit's block of (up to) NX outcomes, made wave-uniform
+    auto outcomes = [&](int32_t x0, int32_t xb, int nx, int32_t& e_l, int64_t& dest_l, int32_t (&e_u)[NX], int64_t (&dest_u)[NX]) {
+        const bool on = kk < nx;
+        e_l = a.eff_label[on ? xb + kk : x0];
+        dest_l = a.eff_dest[on ? xb + kk : x0];
+#pragma unroll
+        for (int x = 0; x < NX; x++) {
+            e_u[x] = __builtin_amdgcn_readlane(e_l, 16 * x);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(dest_l & 0xffffffffLL), 16 * x);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(dest_l >> 32), 16 * x);
+            dest_u[x] = (int64_t)(((uint64_t)hi << 32) | lo);
+        }
+    };
+    // dp/dE[a] = F_n[a] for the outcome's own effect, exact zeros for the others; dp/drho[b] = B_0[b]
+    // (Hessian rows: the same with derivative states, one of the two families zeroed, the second launch adding)
+    auto spam_columns = [&](int64_t c, int32_t e_l, int64_t dest_l) {
+        const int32_t fleaf = as_const(a.circ_leaf)[c], rleaf = as_const(a.rev_leaf)[c], rsym = as_const(a.circ_rho)[c];
+        const double FL = a.eff_zero ? 0.0 : *(const double*)((const char*)a.base_cache + (int64_t)fleaf * fstride + i * 8);
+        for (int e2 = 0; e2 < nE; e2++) {
+            const int32_t ce = a.colmap_eff[e2 * D + i];
+            if (ce >= 0) {
+                double* o = a.out + dest_l * a.ld + ce;
+                const double val = (e2 == e_l) ? FL : 0.0;
+                *o = a.accumulate ? *o + val : val;
+            }
+        }
+        const double B0 = a.rho_zero ? 0.0 : *(const double*)((const char*)a.rev_cache + (int64_t)rleaf * rstride + ((int64_t)i * nE + e_l) * 8);
+        for (int r2 = 0; r2 < a.n_rhos; r2++) {
+            const int32_t cr = a.colmap_rho[r2 * D + i];
+            if (cr >= 0) {
+                double* o = a.out + dest_l * a.ld + cr;
+                const double val = (r2 == rsym) ? B0 : 0.0;
+                *o = a.accumulate ? *o + val : val;
+            }
+        }
+    };
+    // acc[x] += sum over the applications [p0, p1) of the pair tables of B_k (outcome x) (x) F_{k-1}.
+    // Blocks of M chunks (4*M applications): all pair indices of the block are requested first, then all state vectors,
+    // then the 4*M MFMAs -- two memory round trips per block instead of per chunk; the NEXT block's indices are
+    // requested before this block's state vectors.  Lanes past the end re-read the last pair (always a valid address)
+    // and multiply by a zeroed F.
+    auto sweep = [&](auto m_tag, int64_t p0, int64_t p1, const bool fast4, const int32_t (&e_u)[NX], d4_t (&acc)[NX]) {
+        constexpr int M = decltype(m_tag)::value;
+        if (p1 <= p0) return;
+        const int64_t last = p1 - 1;
+        int32_t fi[M], ri[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const int64_t pi = p0 + 4 * m + kk;
+            const int64_t pc = pi <= last ? pi : last;
+            fi[m] = a.pair_f[pc]; ri[m] = a.pair_r[pc];
+        }
+        for (int64_t q = p0; q < p1; q += 4 * M) {
+            bool ok[M];
+            int32_t fn[M], rn[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                ok[m] = q + 4 * m + kk <= last;
+                const int64_t pi = q + 4 * M + 4 * m + kk;
+                const int64_t pc = pi <= last ? pi : last;
+                fn[m] = a.pair_f[pc]; rn[m] = a.pair_r[pc];
+            }
+            double Fv[M], Bv[M][NX];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t fo = (uint32_t)fi[m] * fstride + lane_b;
+                const uint32_t ro = (uint32_t)ri[m] * rstride + lane_r;
+                Fv[m] = *(const double*)(fb + fo);
+                if (fast4) {         // the usual case: 4 effects, outcome x <-> effect x: one 32-byte read
+                    const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + ro, 16);
+                    const d2_t t0 = q2[0], t1 = q2[1];
+                    Bv[m][0] = t0.x; Bv[m][1] = t0.y; Bv[m][2] = t1.x; Bv[m][3] = t1.y;
+                } else {
+#pragma unroll
+                    for (int x = 0; x < NX; x++) Bv[m][x] = *(const double*)(rb + ro + (uint32_t)e_u[x] * 8u);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const double Fz = ok[m] ? Fv[m] : 0.0;
+#pragma unroll
+                for (int x = 0; x < NX; x++) acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fz, acc[x], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) { fi[m] = fn[m]; ri[m] = rn[m]; }
+        }
+    };
+    // a circuit's 16 x 16 block of gate g for (up to) NX outcomes -> Jacobian rows (D-matrix layout of the MFMA)
+    auto store_block = [&](int g, int32_t c0, int nx, const int64_t (&dest_u)[NX], const d4_t (&acc)[NX]) {
+#pragma unroll
+        for (int x = 0; x < NX; x++) {
+            if (x >= nx) break;
+            if (c0 >= 0) {           // D*D consecutive columns: entry (row, col) at c0 + row*D + col
+                double* o = a.out + dest_u[x] * a.ld + c0 + kk * D + i;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (a.accumulate) o[4 * r * D] = o[4 * r * D] + acc[x][r];
+                    else __builtin_nontemporal_store(acc[x][r], &o[4 * r * D]);     // written once, never re-read here: do not displace the state caches in L2
+                }
+            } else {                 // arbitrary subset / order: per-element column map
+                const int32_t* cm = a.colmap_gate + (int64_t)g * D * D + kk * D + i;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int32_t cc = cm[4 * r * D];
+                    if (cc >= 0) { double* o = a.out + dest_u[x] * a.ld + cc; *o = a.accumulate ? *o + acc[x][r] : acc[x][r]; }
+                }
+            }
+        }
+    };
+
+    // Work distribution: the suffix-ordered list of work items (a circuit, or two circuits that end with the same
+    // gates) is cut into 8 contiguous ranges of equal work, one per XCD (workgroup b runs on XCD b % 8 -- observed
+    // dispatch rule, used for locality only): neighbours in that order share their backward chains and, over a longer
+    // stretch, the forward chains of their germ, so both stay in that XCD's 4 MB L2 instead of being pulled from HBM
+    // by all eight.  A wavefront that finds its range empty helps the next.
     const int xcd = blockIdx.x & 7;
     for (int probe = 0; probe < 8;) {
         const int rg = (xcd + probe) & 7;
@@ -234,48 +357,87 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
         const int64_t ci = (int64_t)r_begin + (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
         if (ci >= (int64_t)r_end) { probe++; continue; }
         const int64_t c = as_const(a.circ_order)[ci];
+        const int64_t c2 = a.circ_partner ? (int64_t)as_const(a.circ_partner)[ci] : -1;
+        if (c2 >= 0) {
+            // Two circuits whose last applications coincide (same germ power and measurement fiducial, different
+            // preparation fiducial): over that common tail the backward states are THE SAME vectors, so they are
+            // gathered once and multiplied with both circuits' forward states -- 128 + 128 + 512 bytes per application
+            // pair instead of 2 x 640.  (The host pairs only circuits with the plain 4-outcome block.)
+            int32_t e_l, e_l2, e_u[NX], e_u2[NX];
+            int64_t dest_l, dest_l2, dest_u[NX], dest_u2[NX];
+            const int32_t x0 = as_const(a.eff_ptr)[c], x02 = as_const(a.eff_ptr)[c2];
+            outcomes(x0, x0, NX, e_l, dest_l, e_u, dest_u);
+            outcomes(x02, x02, NX, e_l2, dest_l2, e_u2, dest_u2);
+            spam_columns(c, e_l, dest_l);
+            spam_columns(c2, e_l2, dest_l2);
+            for (int g = 0; g < nG; g++) {
+                const int32_t c0 = as_const(a.gate_col0)[g];
+                if (c0 == -2) continue;
+                const int64_t p0 = as_const(a.pos_ptr)[c * nG + g], p1 = as_const(a.pos_ptr)[c * nG + g + 1];
+                const int64_t q0 = as_const(a.pos_ptr)[c2 * nG + g], q1 = as_const(a.pos_ptr)[c2 * nG + g + 1];
+                const int64_t cg = (int64_t)as_const(a.pair_common)[ci * nG + g];
+                d4_t acc[NX], acc2[NX];
+#pragma unroll
+                for (int x = 0; x < NX; x++) { acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc2[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
+                // common tail: applications p1 - cg .. p1 - 1 of c and q1 - cg .. q1 - 1 of c2 have equal backward ids
+                constexpr int M2 = 2;
+                if (cg > 0) {
+                    int32_t f1[M2], f2[M2], rr[M2];
+#pragma unroll
+                    for (int m = 0; m < M2; m++) {              // pair indices of the first block
+                        const int64_t off = 4 * m + kk;
+                        const int64_t oc = off < cg ? off : cg - 1;
+                        f1[m] = a.pair_f[p1 - cg + oc]; f2[m] = a.pair_f[q1 - cg + oc]; rr[m] = a.pair_r[p1 - cg + oc];
+                    }
+                    for (int64_t t = 0; t < cg; t += 4 * M2) {
+                        bool ok[M2];
+                        int32_t f1n[M2], f2n[M2], rrn[M2];
+#pragma unroll
+                        for (int m = 0; m < M2; m++) {          // the next block's indices travel with this block's vectors
+                            ok[m] = t + 4 * m + kk < cg;
+                            const int64_t off = t + 4 * M2 + 4 * m + kk;
+                            const int64_t oc = off < cg ? off : cg - 1;
+                            f1n[m] = a.pair_f[p1 - cg + oc]; f2n[m] = a.pair_f[q1 - cg + oc]; rrn[m] = a.pair_r[p1 - cg + oc];
+                        }
+                        double F1[M2], F2[M2], Bv[M2][NX];
+#pragma unroll
+                        for (int m = 0; m < M2; m++) {
+                            F1[m] = *(const double*)(fb + (uint32_t)f1[m] * fstride + lane_b);
+                            F2[m] = *(const double*)(fb + (uint32_t)f2[m] * fstride + lane_b);
+                            const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + (uint32_t)rr[m] * rstride + lane_r, 16);
+                            const d2_t t0 = q2[0], t1 = q2[1];
+                            Bv[m][0] = t0.x; Bv[m][1] = t0.y; Bv[m][2] = t1.x; Bv[m][3] = t1.y;
+                        }
+#pragma unroll
+                        for (int m = 0; m < M2; m++) {
+                            const double Fa = ok[m] ? F1[m] : 0.0, Fb2 = ok[m] ? F2[m] : 0.0;
+#pragma unroll
+                            for (int x = 0; x < NX; x++) {
+                                acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fa, acc[x], 0, 0, 0);
+                                acc2[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fb2, acc2[x], 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int m = 0; m < M2; m++) { f1[m] = f1n[m]; f2[m] = f2n[m]; rr[m] = rrn[m]; }
+                    }
+                }
+                // the applications before the common tail, each circuit on its own
+                sweep(std::integral_constant<int, 2>{}, p0, p1 - cg, true, e_u, acc);
+                sweep(std::integral_constant<int, 2>{}, q0, q1 - cg, true, e_u2, acc2);
+                store_block(g, c0, NX, dest_u, acc);
+                store_block(g, c0, NX, dest_u2, acc2);
+            }
+            continue;
+        }
         const int32_t x0 = as_const(a.eff_ptr)[c], x1 = as_const(a.eff_ptr)[c + 1];
-        const int32_t fleaf = as_const(a.circ_leaf)[c], rleaf = as_const(a.rev_leaf)[c], rsym = as_const(a.circ_rho)[c];
         for (int32_t xb = x0; xb < x1; xb += NX) {
             const int nx = (x1 - xb < NX) ? (x1 - xb) : NX;
             // lane group kk looks after outcome xb + kk for the SPAM columns; the gate blocks need all NX labels uniform
-            const bool on = kk < nx;
-            const int32_t e_l = a.eff_label[on ? xb + kk : x0];
-            const int64_t dest_l = a.eff_dest[on ? xb + kk : x0];
-            int32_t e_u[NX];
-            int64_t dest_u[NX];
-#pragma unroll
-            for (int x = 0; x < NX; x++) {
-                e_u[x] = __builtin_amdgcn_readlane(e_l, 16 * x);
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(dest_l & 0xffffffffLL), 16 * x);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(dest_l >> 32), 16 * x);
-                dest_u[x] = (int64_t)(((uint64_t)hi << 32) | lo);
-            }
+            int32_t e_l, e_u[NX];
+            int64_t dest_l, dest_u[NX];
+            outcomes(x0, xb, nx, e_l, dest_l, e_u, dest_u);
             const bool fast4 = nE == 4 && e_u[0] == 0 && e_u[1] == 1 && e_u[2] == 2 && e_u[3] == 3;
-            const uint32_t fstride = a.fwd_stride ? a.fwd_stride : (uint32_t)(D * 8);
-            const uint32_t rstride = a.rev_stride ? a.rev_stride : (uint32_t)nE * (D * 8);
-            if (on) {
-                // dp/dE[a] = F_n[a] for the outcome's own effect, exact zeros for the others; dp/drho[b] = B_0[b]
-                // (Hessian rows: the same with derivative states, one of the two families zeroed, the second launch adding)
-                const double FL = a.eff_zero ? 0.0 : *(const double*)((const char*)a.base_cache + (int64_t)fleaf * fstride + i * 8);
-                for (int e2 = 0; e2 < nE; e2++) {
-                    const int32_t ce = a.colmap_eff[e2 * D + i];
-                    if (ce >= 0) {
-                        double* o = a.out + dest_l * a.ld + ce;
-                        const double val = (e2 == e_l) ? FL : 0.0;
-                        *o = a.accumulate ? *o + val : val;
-                    }
-                }
-                const double B0 = a.rho_zero ? 0.0 : *(const double*)((const char*)a.rev_cache + (int64_t)rleaf * rstride + ((int64_t)i * nE + e_l) * 8);
-                for (int r2 = 0; r2 < a.n_rhos; r2++) {
-                    const int32_t cr = a.colmap_rho[r2 * D + i];
-                    if (cr >= 0) {
-                        double* o = a.out + dest_l * a.ld + cr;
-                        const double val = (r2 == rsym) ? B0 : 0.0;
-                        *o = a.accumulate ? *o + val : val;
-                    }
-                }
-            }
+            if (kk < nx) spam_columns(c, e_l, dest_l);
             for (int g = 0; g < nG; g++) {
                 const int32_t c0 = as_const(a.gate_col0)[g];
                 if (c0 == -2) continue;                                // no parameter of this gate was requested
@@ -283,82 +445,8 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                 d4_t acc[NX];
 #pragma unroll
                 for (int x = 0; x < NX; x++) acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0};
-                if (p1 > p0) {
-                    // Blocks of M chunks (4*M applications): all pair indices of the block are requested first, then all
-                    // state vectors, then the 4*M MFMAs -- two memory round trips per block instead of per chunk.  Lanes
-                    // past the end re-read the last pair (always a valid address) and multiply by a zeroed F.
-                    constexpr int M = ANA_MFMA_M;
-                    const int64_t last = p1 - 1;
-                    // uniform 64-bit bases + 32-bit per-lane byte offsets (both caches are < 4 GB, checked on the host):
-                    // one offset register serves the F load / the NX backward loads of a gathered application
-                    const char* const fb = (const char*)a.base_cache;
-                    const char* const rb = (const char*)a.rev_cache;
-                    const uint32_t lane_b = (uint32_t)i * 8u;
-                    const uint32_t lane_r = (uint32_t)i * (uint32_t)nE * 8u;       // backward cache is [state][component][effect]
-                    // pair indices of the first block; inside the loop the NEXT block's indices are requested before this
-                    // block's state vectors, so that only one memory round trip per block is exposed
-                    int32_t fi[M], ri[M];
-#pragma unroll
-                    for (int m = 0; m < M; m++) {
-                        const int64_t pi = p0 + 4 * m + kk;
-                        const int64_t pc = pi <= last ? pi : last;
-                        fi[m] = a.pair_f[pc]; ri[m] = a.pair_r[pc];
-                    }
-                    for (int64_t q = p0; q < p1; q += 4 * M) {
-                        bool ok[M];
-                        int32_t fn[M], rn[M];
-#pragma unroll
-                        for (int m = 0; m < M; m++) {
-                            ok[m] = q + 4 * m + kk <= last;
-                            const int64_t pi = q + 4 * M + 4 * m + kk;
-                            const int64_t pc = pi <= last ? pi : last;
-                            fn[m] = a.pair_f[pc]; rn[m] = a.pair_r[pc];
-                        }
-                        double Fv[M], Bv[M][NX];
-#pragma unroll
-                        for (int m = 0; m < M; m++) {
-                            const uint32_t fo = (uint32_t)fi[m] * fstride + lane_b;
-                            const uint32_t ro = (uint32_t)ri[m] * rstride + lane_r;
-                            Fv[m] = *(const double*)(fb + fo);
-                            if (fast4) {         // the usual case: 4 effects, outcome x <-> effect x: one 32-byte read
-                                typedef double d2_t __attribute__((ext_vector_type(2)));
-                                const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + ro, 16);
-                                const d2_t t0 = q2[0], t1 = q2[1];
-                                Bv[m][0] = t0.x; Bv[m][1] = t0.y; Bv[m][2] = t1.x; Bv[m][3] = t1.y;
-                            } else {
-#pragma unroll
-                                for (int x = 0; x < NX; x++) Bv[m][x] = *(const double*)(rb + ro + (uint32_t)e_u[x] * 8u);
-                            }
-                        }
-#pragma unroll
-                        for (int m = 0; m < M; m++) {
-                            const double Fz = ok[m] ? Fv[m] : 0.0;
-#pragma unroll
-                            for (int x = 0; x < NX; x++) acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fz, acc[x], 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int m = 0; m < M; m++) { fi[m] = fn[m]; ri[m] = rn[m]; }
-                    }
-                }
-#pragma unroll
-                for (int x = 0; x < NX; x++) {
-                    if (x >= nx) break;
-                    if (c0 >= 0) {           // D*D consecutive columns: entry (row, col) at c0 + row*D + col
-                        double* o = a.out + dest_u[x] * a.ld + c0 + kk * D + i;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            if (a.accumulate) o[4 * r * D] = o[4 * r * D] + acc[x][r];
-                            else __builtin_nontemporal_store(acc[x][r], &o[4 * r * D]);     // written once, never re-read here: do not displace the state caches in L2
-                        }
-                    } else {                 // arbitrary subset / order: per-element column map
-                        const int32_t* cm = a.colmap_gate + (int64_t)g * D * D + kk * D + i;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int32_t cc = cm[4 * r * D];
-                            if (cc >= 0) { double* o = a.out + dest_u[x] * a.ld + cc; *o = a.accumulate ? *o + acc[x][r] : acc[x][r]; }
-                        }
-                    }
-                }
+                sweep(std::integral_constant<int, ANA_MFMA_M>{}, p0, p1, fast4, e_u, acc);
+                store_block(g, c0, nx, dest_u, acc);
             }
         }
     }
