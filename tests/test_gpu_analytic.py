@@ -63,6 +63,21 @@ def test_analytic_valu_kernel_fallback(monkeypatch):
     assert not np.array_equal(J_valu, J_mfma)          # (different summation orders: they are different kernels)
 
 
+def test_analytic_two_circuit_items_vs_single(monkeypatch):
+    """The D = 16 contraction pairs circuits that end with the same applications and gathers their common backward
+    states once (default); GST_ANALYTIC_PAIRS=0 hands out one circuit per item.  Same sums in a slightly different
+    order: the two agree far below the tolerance, on the design fixture and on the deep germ-power families."""
+    for name, cols in (("smq2Q_XYICNOT_L2_depol", np.arange(1616)), ("smq2Q_XYICNOT_L1024_deep", np.arange(80, 1616, 3))):
+        fx = load_fixture(name)
+        J_pairs = plan_from_fixture(fx).fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+        monkeypatch.setenv("GST_ANALYTIC_PAIRS", "0")
+        J_single = plan_from_fixture(fx).fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+        monkeypatch.delenv("GST_ANALYTIC_PAIRS")
+        scale = max(1.0, np.abs(J_single).max())
+        assert np.abs(J_pairs - J_single).max() < 1e-12 * scale
+        assert (J_pairs != 0).any()
+
+
 def test_analytic_hprobs_vs_numpy_oracle(oracle_built):
     """gst_fill_hprobs_analytic at D = 16 against the exact numpy Hessian (oracle.analytic_hprobs, itself pinned to the
     MatrixForwardSimulator vectors of the 1Q fixture by tests/test_oracle.py): gate x gate, gate x SPAM, SPAM x SPAM
