@@ -157,7 +157,7 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
     circ_ptr = np.zeros(len(circuits) + 1, np.int64)
     cg = []
     for ci, c in enumerate(circuits):
-        cg.extend(op_lookup[l] for l in c.layertup)  # circuits hold no SPAM labels here
+        cg.extend(op_lookup[l] for l in c.layertup if l in op_lookup)  # (explicit prep / POVM labels are not gates)
         circ_ptr[ci + 1] = len(cg)
     circ_gates = np.array(cg, np.int32)
     # element k <-> (circuit index, outcome index into eff_labels-less outcome tuple)
@@ -169,8 +169,10 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
         outs = layout.outcomes_for_index(ci)
         inds = np.arange(inds.start, inds.stop, inds.step or 1) if isinstance(inds, slice) else np.asarray(inds)
         if outcome_names is None:
-            outcome_names = [''.join(o) for o in outs]
+            outcome_names = []
         for k, o in zip(inds, outs):
+            if ''.join(o) not in outcome_names:
+                outcome_names.append(''.join(o))
             el_circuit[k] = ci
             el_outcome[k] = outcome_names.index(''.join(o))
 
@@ -290,6 +292,26 @@ def main():
         m = smq1Q_XYI.target_model().depolarize(op_noise=0.01, spam_noise=0.01).kick(0.1, seed=1234)
         circs = list(smq1Q_XYI.create_gst_experiment_design(4).all_circuits_needing_data)
         dump_case('smq1Q_XYI_L4_kick', m, circs, want_hprobs=False)
+
+    if 'multispam' in which:   # two preparations and two POVMs (one of them with three effects), explicit in the circuits
+        import pygsti
+        from pygsti.circuits import Circuit
+        from pygsti.modelmembers.povms import UnconstrainedPOVM
+        from pygsti.modelmembers.states import FullState
+        m = smq1Q_XYI.target_model().depolarize(op_noise=0.02, spam_noise=0.01).kick(0.05, seed=7)
+        rng = np.random.default_rng(11)
+        m.preps['rho1'] = FullState(np.array([1 / np.sqrt(2), 0.1, -0.2, -0.55]) + 0.01 * rng.standard_normal(4), evotype=m.evotype, state_space=m.state_space)
+        e0 = np.array([0.5, 0.1, 0.2, 0.1]); e1 = np.array([0.4, -0.1, 0.05, 0.2]); e2 = np.array([np.sqrt(2), 0, 0, 0]) - e0 - e1
+        m.povms['Mtri'] = UnconstrainedPOVM([('a', e0), ('b', e1), ('c', e2)], evotype=m.evotype, state_space=m.state_space)
+        base = list(smq1Q_XYI.create_gst_experiment_design(2).all_circuits_needing_data)
+        circs = []
+        for k, c in enumerate(base):
+            prep = 'rho0' if k % 3 else 'rho1'
+            povm = 'Mdefault' if k % 2 else 'Mtri'
+            circs.append(Circuit((prep,) + tuple(c.layertup) + (povm,), line_labels=c.line_labels))
+        circs.append(Circuit(('rho1', 'Mtri'), line_labels=base[0].line_labels))          # empty gate string
+        blk = (np.arange(0, m.num_params, 9), np.arange(2, m.num_params, 4))
+        dump_case('smq1Q_multispam_L2', m, circs, want_hprobs=True, hprobs_blk=blk)
 
     if '1q128' in which:  # BASELINE configs[1] / SURVEY C2
         m = smq1Q_XYI.target_model().depolarize(op_noise=0.01, spam_noise=0.01)

@@ -12,7 +12,7 @@ TOL = 1e-8
 
 
 @pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_XYI_L4_kick", "smq1Q_XYI_L128_depol",
-                                  "smq2Q_XYICNOT_L2_depol"])
+                                  "smq2Q_XYICNOT_L2_depol", "smq1Q_multispam_L2"])
 def test_analytic_dprobs_vs_matrix_simulator(name):
     fx = load_fixture(name)
     pl = plan_from_fixture(fx)
@@ -118,14 +118,16 @@ def test_analytic_hprobs_vs_matrix_simulator_blocks():
         assert np.abs(ref).max() > 1e-3
 
 
-def test_analytic_hprobs_1q_vs_matrix_simulator():
-    """D = 4: exact Hessian block against the MatrixForwardSimulator hprobs vectors of the 1Q fixture (the two-cache
-    contraction without MFMA: analytic_small_kernel + dwalk_kernel<4>)."""
-    fx = load_fixture("smq1Q_XYI_L4_depol")
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2"])
+def test_analytic_hprobs_1q_vs_matrix_simulator(name):
+    """D = 4: exact Hessian block against the MatrixForwardSimulator hprobs vectors of the 1Q fixtures (the two-cache
+    contraction without MFMA: analytic_small_kernel + dwalk_kernel<4>); the second one has two preparations and two
+    POVMs."""
+    fx = load_fixture(name)
     pl = plan_from_fixture(fx)
     H = pl.fill_hprobs(idx1=fx["hprobs_rows"], idx2=fx["hprobs_cols"], mode=_lib.DERIV_ANALYTIC)
     ref = fx["hprobs_matrix"]
     assert np.abs(H[fx["matrix_rows"]] - ref).max() < TOL * max(1.0, np.abs(ref).max())
-    full = pl.fill_hprobs(mode=_lib.DERIV_ANALYTIC)                       # the whole 60 x 60 Hessian of every element
+    full = pl.fill_hprobs(mode=_lib.DERIV_ANALYTIC)                       # the whole nP x nP Hessian of every element
     assert np.abs(full - np.transpose(full, (0, 2, 1))).max() < 1e-11     # symmetric
     assert np.array_equal(full[:, fx["hprobs_rows"]][:, :, fx["hprobs_cols"]], H)

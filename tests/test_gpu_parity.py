@@ -9,7 +9,8 @@ from conftest import load_fixture, assert_bitwise, plan_from_fixture
 pytestmark = pytest.mark.gpu
 
 FIXTURES = ["smq1Q_XYI_L4_depol", "smq1Q_XYI_L4_kick", "smq1Q_XYI_L128_depol",
-            "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep"]
+            "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep",
+            "smq1Q_multispam_L2"]       # two preparations, two POVMs (2 and 3 effects), an empty gate string
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -70,8 +71,9 @@ def test_dprobs_column_window_and_dest_indices():
     assert_bitwise(full[:, 3:11], fx['dprobs_map'][:, 0:8], "view")
 
 
-def test_hprobs_fd_bitwise_vs_reference():
-    fx = load_fixture("smq1Q_XYI_L4_depol")
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2"])
+def test_hprobs_fd_bitwise_vs_reference(name):
+    fx = load_fixture(name)
     pl = plan_from_fixture(fx)
     H = pl.fill_hprobs(idx1=fx['hprobs_rows'], idx2=fx['hprobs_cols'], eps=float(fx['hessian_eps']))
     assert_bitwise(H, fx['hprobs_map'], "hprobs")

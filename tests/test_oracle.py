@@ -8,8 +8,10 @@ import pytest
 
 from conftest import load_fixture, assert_bitwise, ROOT
 
-FIXTURES = ["smq1Q_XYI_L4_depol", "smq1Q_XYI_L4_kick", "smq1Q_XYI_L128_depol",
-            "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep"]
+DESIGN_FIXTURES = ["smq1Q_XYI_L4_depol", "smq1Q_XYI_L4_kick", "smq1Q_XYI_L128_depol",
+                   "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep"]
+# + two preparations, two POVMs (2 and 3 effects), explicit SPAM labels in the circuits, an empty gate string
+FIXTURES = DESIGN_FIXTURES + ["smq1Q_multispam_L2"]
 HAVE_REF = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgst_ref.so")) or \
     os.path.isdir("/root/reference/pygsti/evotypes/densitymx")
 KINDS = ["port"] + (["reference"] if HAVE_REF else [])
@@ -26,14 +28,15 @@ def test_probs_and_dprobs_bitwise(oracle_built, name, kind):
     assert_bitwise(J, fx["dprobs_map"], "dprobs")
 
 
-def test_hprobs_bitwise(oracle_built):
-    fx = load_fixture("smq1Q_XYI_L4_depol")
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2"])
+def test_hprobs_bitwise(oracle_built, name):
+    fx = load_fixture(name)
     H = oracle_built.from_fixture(fx).hprobs(fx["hprobs_rows"], fx["hprobs_cols"], eps=float(fx["hessian_eps"]))
     assert_bitwise(H, fx["hprobs_map"], "hprobs")
 
 
 @pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_XYI_L4_kick", "smq1Q_XYI_L128_depol",
-                                  "smq2Q_XYICNOT_L2_depol"])
+                                  "smq2Q_XYICNOT_L2_depol", "smq1Q_multispam_L2"])
 def test_numpy_analytic_jacobian_matches_matrix_simulator(oracle_built, name):
     """The independent forward/backward analytic Jacobian agrees with MatrixForwardSimulator's golden
     vectors to 1e-10 (both exact derivatives); the FD Map Jacobian does NOT (SURVEY finding 3)."""
@@ -45,7 +48,7 @@ def test_numpy_analytic_jacobian_matches_matrix_simulator(oracle_built, name):
     assert np.abs(P - fx["probs"]).max() < 1e-12
 
 
-@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("name", DESIGN_FIXTURES)
 def test_prefix_table_restatement_is_identical_to_reference_table(name):
     from oracle import prefix_table as PT
     fx = load_fixture(name)
@@ -63,10 +66,11 @@ def test_fd_hessian_is_loose_against_analytic():
     assert 1e-9 < d < 1e-2
 
 
-def test_analytic_hprobs_oracle_vs_matrix_simulator():
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2"])
+def test_analytic_hprobs_oracle_vs_matrix_simulator(name):
     """The numpy exact Hessian (derivative forward/backward states) against MatrixForwardSimulator's hprobs vectors."""
     from oracle import oracle as O
-    fx = load_fixture("smq1Q_XYI_L4_depol")
+    fx = load_fixture(name)
     H = O.analytic_hprobs(fx, fx["hprobs_rows"], fx["hprobs_cols"])
     assert np.abs(H[fx["matrix_rows"]] - fx["hprobs_matrix"]).max() < 1e-11
     # and it is the quantity the FD-of-FD Map path approximates
