@@ -168,6 +168,15 @@ int gst_fill_probs(gst_plan *plan, double *out);
 int gst_fill_dprobs(gst_plan *plan, double *out, int64_t ld, const int64_t *param_idx,
                     const int64_t *dest_idx, int64_t n_param, int mode, double eps, double *probs_out);
 
+/* Second derivatives of the dense elements with respect to the parameters, for the objects of the last gst_set_derivs
+ * call, in the same order: what MatrixForwardSimulator._hoperation = member.hessian_wrt_params() feeds into the exact
+ * Hessian (pygsti/forwardsims/matrixforwardsim.py:192-224, 1190-1287) for members that are not linear in their
+ * parameters (CPTPLND / exponentiated error generators, ...).  nonzero[o] != 0 marks the objects that have such a
+ * tensor; hess holds them concatenated, each row-major [n_elem][n_cols[o]][n_cols[o]].  While set,
+ * gst_fill_hprobs_analytic / gst_objective_hessian_block(analytic) add  sum_a (d p / d elem_a) d^2 elem_a / d p1 d p2.
+ * Cleared by gst_set_derivs (call it first); n_objs = 0 clears. */
+int gst_set_second_derivs(gst_plan *plan, int32_t n_objs, const int32_t *nonzero, const double *hess);
+
 /* hprobs block: out[(k*ld1 + dest1[a])*ld2 + dest2[b]] = d2 p_k / d theta_{idx1[a]} d theta_{idx2[b]}
  * by finite differences of finite differences with step eps, bit-for-bit
  * MapForwardSimulator._mapfill_hprobs_atom (mapforwardsim.py:394-438). */
@@ -182,8 +191,7 @@ int gst_fill_hprobs(gst_plan *plan, double *out, int64_t ld1, int64_t ld2,
  * While gst_set_derivs is set the block is that of the general parameterisation, for members whose dense elements are
  * LINEAR in their parameters (TP: has_nonzero_hessian() is False for every member): the element Hessian of the elements
  * the requested parameters touch, contracted with the derivative columns on both sides.  Members with second
- * derivatives (CPTPLND, ...) need the extra J_elem . hessian_wrt_params term, which is not implemented: the caller must
- * not ask (the pyGSTi adapter checks has_nonzero_hessian()). */
+ * derivatives (CPTPLND, ...) additionally need gst_set_second_derivs (the J_elem . hessian_wrt_params term). */
 int gst_fill_hprobs_analytic(gst_plan *plan, double *out, int64_t ld1, int64_t ld2, const int64_t *idx1,
                              const int64_t *dest1, int64_t n1, const int64_t *idx2, const int64_t *dest2, int64_t n2);
 

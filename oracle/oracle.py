@@ -240,6 +240,20 @@ def tp_param_map(fx):
     return pk, po, pe
 
 
+def second_derivs_from_fixture(fx):
+    """Per object of derivs_from_fixture: hessian_wrt_params [n_elem, n, n], or None for a linear member."""
+    out, h0 = [], 0
+    D = int(fx["D"])
+    for k, n, nz in zip(fx["dv_kind"], fx["dv_ncols"], fx["dv2_nonzero"]):
+        ne = D * D if k == 0 else D
+        if nz:
+            out.append(np.asarray(fx["dv2_hess"][h0:h0 + ne * n * n], np.float64).reshape(ne, n, n))
+            h0 += ne * n * n
+        else:
+            out.append(None)
+    return out
+
+
 def analytic_dprobs_general(fx, cols=None):
     """Jacobian w.r.t. model parameters of a general (TP, CPTP, ...) parameterisation: element Jacobian x the members'
     deriv_wrt_params -- what MatrixForwardSimulator._dprobs_from_rho_e assembles from `_doperation`
@@ -288,7 +302,24 @@ def analytic_hprobs_general(fx, idx1, idx2):
     e1, W1 = weights(idx1)
     e2, W2 = weights(idx2)
     He = analytic_hprobs(fe, e1, e2)
-    return np.einsum("eab,ai,bj->eij", He, W1, W2)
+    H = np.einsum("eab,ai,bj->eij", He, W1, W2)
+    # members that are not linear in their parameters (CPTPLND, ...): + sum_a (d p / d elem_a) d^2 elem_a / d p1 d p2,
+    # with the members' hessian_wrt_params (fixture arrays dv2_*), as _hoperation feeds it into the same assembly
+    if "dv2_nonzero" in fx and np.any(fx["dv2_nonzero"]):
+        Je, _ = analytic_dprobs(fe)
+        pos1 = {int(p): k for k, p in enumerate(idx1)}
+        pos2 = {int(p): k for k, p in enumerate(idx2)}
+        for (k, o, pidx, dm), S in zip(derivs_from_fixture(fx), second_derivs_from_fixture(fx)):
+            if S is None:
+                continue
+            ne = D * D if k == 0 else D
+            a = base[k] + o * ne
+            c1 = [(c, pos1[int(pi)]) for c, pi in enumerate(pidx) if int(pi) in pos1]
+            c2 = [(c, pos2[int(pi)]) for c, pi in enumerate(pidx) if int(pi) in pos2]
+            for ca, i in c1:
+                for cb, j in c2:
+                    H[:, i, j] += Je[:, a:a + ne] @ S[:, ca, cb]
+    return H
 
 
 def analytic_hprobs(fx, idx1, idx2):

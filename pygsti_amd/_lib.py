@@ -63,7 +63,7 @@ class Stats(C.Structure):
 
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
-           "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
+           "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
            "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
            "gst_last_error", "gst_version"]
 
@@ -96,6 +96,7 @@ def lib():
         L.gst_fill_jtf_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
         L.gst_set_derivs.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
         L.gst_set_complement_effect.argtypes = [vp, i32, vp, i32, vp]
+        L.gst_set_second_derivs.argtypes = [vp, i32, vp, vp]
         L.gst_objective_rows_dev.argtypes = [vp, C.POINTER(ObjectiveDesc), vp, vp, vp, i64, vp, vp, vp, C.POINTER(C.c_double)]
         L.gst_objective_hessian_block.argtypes = [vp, C.POINTER(ObjectiveDesc), vp, vp, vp, i64, vp, i64, C.c_double, vp]
         L.gst_memcpy_h2d.argtypes = [vp, vp, vp, i64]
@@ -256,6 +257,18 @@ class Plan:
         der = _f64(np.concatenate([np.ascontiguousarray(o[3], np.float64).ravel() for o in objs]))
         check(lib().gst_set_derivs(self._h, int(n_params), len(objs), _ptr(kind), _ptr(obj), _ptr(ncols), _ptr(pidx), _ptr(der)))
         self.n_params = int(n_params)
+
+    def set_second_derivs(self, hessians):
+        """hessian_wrt_params of the objects given to set_derivs, in the same order: a list whose entries are None
+        (member linear in its parameters) or arrays [n_elem, n, n] (gst_set_second_derivs); an empty list clears."""
+        hs = list(hessians)
+        if not hs:
+            check(lib().gst_set_second_derivs(self._h, 0, None, None))
+            return
+        nz = _i32([0 if h is None else 1 for h in hs])
+        parts = [np.ascontiguousarray(h, np.float64).ravel() for h in hs if h is not None]
+        flat = _f64(np.concatenate(parts)) if parts else np.zeros(1)
+        check(lib().gst_set_second_derivs(self._h, len(hs), _ptr(nz), _ptr(flat)))
 
     # -- fills (host arrays) ---------------------------------------------------------------------------
     def fill_probs(self, out=None):

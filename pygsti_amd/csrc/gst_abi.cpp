@@ -111,6 +111,9 @@ struct gst_plan {
     std::vector<int32_t> dv_kind, dv_obj, dv_ncols;
     std::vector<int64_t> dv_param_idx, dv_off_cols, dv_off_deriv;
     std::vector<double> dv_deriv_h;     // host copy (the Hessian chain rule reads its sparsity)
+    std::vector<int64_t> dv2_off;       // per object: offset of its second-derivative tensor in d_dv2 (-1: linear member)
+    DevBuf<double> d_dv2;
+    bool dv2_set = false;
     DevBuf<double> d_helem, d_hw;       // element-Hessian block, CSC weights
     DevBuf<int32_t> d_hcsc;             // CSC pointers / rows / destinations of both blocks
     DevBuf<double> d_dv_deriv, d_jelem;
@@ -160,7 +163,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
-        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release(); d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_circ_partner.release(); d_pair_common.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_helem.release(); d_hw.release(); d_hcsc.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release(); d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
+        d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release(); d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_circ_partner.release(); d_pair_common.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_dv2.release(); d_helem.release(); d_hw.release(); d_hcsc.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release(); d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
         d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
@@ -970,7 +973,7 @@ int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t*
 {
     if (!p || n_params < 0 || n_objs < 0) return fail(GST_EINVAL, "bad argument");
     p->cached_kind = 0;
-    if (n_objs == 0) { p->derivs_set = false; return GST_OK; }
+    if (n_objs == 0) { p->derivs_set = false; p->dv2_set = false; p->dv2_off.clear(); return GST_OK; }
     if (!kind || !obj || !n_cols || !param_idx || !deriv) return fail(GST_EINVAL, "bad argument");
     const int D = p->hp.D;
     std::vector<int64_t> off_c((size_t)n_objs + 1, 0), off_d((size_t)n_objs + 1, 0);
@@ -990,6 +993,7 @@ int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t*
     p->dv_off_cols = off_c; p->dv_off_deriv = off_d;
     p->dv_n_params = n_params;
     p->dv_deriv_h.assign(deriv, deriv + off_d[n_objs]);
+    p->dv2_set = false; p->dv2_off.clear();
     HIP_TRY(p->d_dv_deriv.ensure((size_t)std::max<int64_t>(off_d[n_objs], 1)));
     if (off_d[n_objs] > 0) {
         HIP_TRY(hipMemcpyAsync(p->d_dv_deriv.p, deriv, (size_t)off_d[n_objs] * 8, hipMemcpyHostToDevice, p->stream));
@@ -997,6 +1001,60 @@ int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t*
     }
     p->derivs_set = true;
     return GST_OK;
+}
+
+int gst_set_second_derivs(gst_plan* p, int32_t n_objs, const int32_t* nonzero, const double* hess)
+{
+    if (!p || n_objs < 0) return fail(GST_EINVAL, "bad argument");
+    if (n_objs == 0) { p->dv2_set = false; p->dv2_off.clear(); return GST_OK; }
+    if (!p->derivs_set || (size_t)n_objs != p->dv_kind.size()) return fail(GST_ESTATE, "gst_set_second_derivs follows gst_set_derivs, object for object");
+    if (!nonzero) return fail(GST_EINVAL, "bad argument");
+    const int D = p->hp.D;
+    std::vector<int64_t> off((size_t)n_objs, -1);
+    int64_t total = 0;
+    for (int32_t o = 0; o < n_objs; o++) {
+        if (!nonzero[o]) continue;
+        const int64_t K = p->dv_kind[o] == GST_KIND_GATE ? D * D : D;
+        off[(size_t)o] = total;
+        total += K * p->dv_ncols[o] * (int64_t)p->dv_ncols[o];
+    }
+    if (total > 0 && !hess) return fail(GST_EINVAL, "hess is NULL");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    HIP_TRY(p->d_dv2.ensure((size_t)std::max<int64_t>(total, 1)));
+    if (total > 0) {
+        HIP_TRY(hipMemcpyAsync(p->d_dv2.p, hess, (size_t)total * 8, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    p->dv2_off = off;
+    p->dv2_set = total > 0;
+    return GST_OK;
+}
+
+// The element Jacobian [nE][n_el] ([rhos | effects | gates] of the `full` layout) of the current model into d_jelem,
+// through the ordinary analytic path with the identity element map.
+int run_element_jacobian(gst_plan* p, double* d_probs_out)
+{
+    const gst::HostPlan& h = p->hp;
+    const int D = h.D;
+    const int64_t nE = h.n_elements;
+    const int64_t n_el = (int64_t)h.n_rhos * D + (int64_t)h.n_effects * D + (int64_t)h.n_gates * D * D;
+    std::vector<int32_t> ek((size_t)n_el), eo((size_t)n_el), ee((size_t)n_el);
+    {
+        int64_t q = 0;
+        for (int r = 0; r < h.n_rhos; r++) for (int j = 0; j < D; j++, q++) { ek[q] = GST_KIND_RHO; eo[q] = r; ee[q] = j; }
+        for (int e = 0; e < h.n_effects; e++) for (int j = 0; j < D; j++, q++) { ek[q] = GST_KIND_EFFECT; eo[q] = e; ee[q] = j; }
+        for (int g = 0; g < h.n_gates; g++) for (int j = 0; j < D * D; j++, q++) { ek[q] = GST_KIND_GATE; eo[q] = g; ee[q] = j; }
+    }
+    std::vector<int64_t> all((size_t)n_el);
+    for (int64_t q = 0; q < n_el; q++) all[(size_t)q] = q;
+    HIP_TRY(p->d_jelem.ensure((size_t)std::max<int64_t>(nE * n_el, 1)));
+    p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
+    p->cached_kind = 0;
+    int rc = run_dprobs_analytic(p, p->d_jelem.p, n_el, all.data(), nullptr, n_el, d_probs_out);
+    p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
+    p->cached_kind = 0;
+    return rc;
 }
 
 // GST_DERIV_ANALYTIC with gst_set_derivs: element Jacobian (the `full` layout [rhos | effects | gates]) into scratch,
@@ -1015,22 +1073,7 @@ int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* pa
         if (dest_of[(size_t)param_idx[c]] >= 0) return fail(GST_EINVAL, "a parameter is requested twice (not supported with gst_set_derivs)");
         dest_of[(size_t)param_idx[c]] = (int32_t)(dest_idx ? dest_idx[c] : c);
     }
-    // element Jacobian through the ordinary analytic path with the identity element map
-    std::vector<int32_t> ek((size_t)n_el), eo((size_t)n_el), ee((size_t)n_el);
-    {
-        int64_t q = 0;
-        for (int r = 0; r < h.n_rhos; r++) for (int j = 0; j < D; j++, q++) { ek[q] = GST_KIND_RHO; eo[q] = r; ee[q] = j; }
-        for (int e = 0; e < h.n_effects; e++) for (int j = 0; j < D; j++, q++) { ek[q] = GST_KIND_EFFECT; eo[q] = e; ee[q] = j; }
-        for (int g = 0; g < h.n_gates; g++) for (int j = 0; j < D * D; j++, q++) { ek[q] = GST_KIND_GATE; eo[q] = g; ee[q] = j; }
-    }
-    std::vector<int64_t> all((size_t)n_el);
-    for (int64_t q = 0; q < n_el; q++) all[(size_t)q] = q;
-    HIP_TRY(p->d_jelem.ensure((size_t)std::max<int64_t>(nE * n_el, 1)));
-    p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
-    p->cached_kind = 0;
-    int rc = run_dprobs_analytic(p, p->d_jelem.p, n_el, all.data(), nullptr, n_el, d_probs_out);
-    p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
-    p->cached_kind = 0;
+    int rc = run_element_jacobian(p, d_probs_out);
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
     // zero the requested columns, then accumulate object by object
@@ -1444,6 +1487,38 @@ static int run_hprobs_general(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2
                                            p->d_hw.p + c1.w.size(), p->d_hcsc.p + o_d2, (int)n2, d_H, ld1, ld2, p->stream));
     p->last_launches++;
     HIP_TRY(hipStreamSynchronize(p->stream));          // the host tables go out of scope
+    if (p->dv2_set) {
+        // members that are not linear in their parameters: + sum_a (d p / d elem_a) d^2 elem_a / d p1 d p2, one MFMA
+        // product per such object: [nE x K] (element Jacobian) . [K x (n_o x n_o)] scattered into the block's entries
+        if (ld1 * ld2 > 0x7fffffffLL) return fail(GST_EINVAL, "Hessian block too wide");
+        if ((rc = run_element_jacobian(p, nullptr))) return rc;
+        std::vector<int32_t> pos1((size_t)p->dv_n_params, -1), pos2((size_t)p->dv_n_params, -1);
+        for (int64_t k = 0; k < n1; k++) pos1[(size_t)idx1[k]] = (int32_t)(dest1 ? dest1[k] : k);
+        for (int64_t k = 0; k < n2; k++) pos2[(size_t)idx2[k]] = (int32_t)(dest2 ? dest2[k] : k);
+        for (size_t o = 0; o < p->dv_kind.size(); o++) {
+            if (p->dv2_off[o] < 0) continue;
+            const int k = p->dv_kind[o];
+            const int K = k == GST_KIND_GATE ? D * D : D;
+            const int nc = p->dv_ncols[o];
+            const int64_t a0 = (k == GST_KIND_GATE ? base_gate : k == GST_KIND_RHO ? base_rho : base_eff) + (int64_t)p->dv_obj[o] * K;
+            std::vector<int32_t> cmap((size_t)nc * nc, -1);
+            bool any = false;
+            for (int ca = 0; ca < nc; ca++) {
+                const int32_t i = pos1[(size_t)p->dv_param_idx[(size_t)p->dv_off_cols[o] + ca]];
+                if (i < 0) continue;
+                for (int cb = 0; cb < nc; cb++) {
+                    const int32_t j = pos2[(size_t)p->dv_param_idx[(size_t)p->dv_off_cols[o] + cb]];
+                    if (j >= 0) { cmap[(size_t)ca * nc + cb] = (int32_t)((int64_t)i * ld2 + j); any = true; }
+                }
+            }
+            if (!any) continue;
+            if ((rc = upload_i32(p->d_dv_colmap, cmap, p->stream))) return rc;
+            HIP_TRY(gst::launch_chain_rule_gemm(p->d_jelem.p, n_el, a0, K, p->d_dv2.p + p->dv2_off[o], nc * nc, p->d_dv_colmap.p,
+                                                d_H, ld1 * ld2, nE, p->stream));
+            p->last_launches++;
+            HIP_TRY(hipStreamSynchronize(p->stream));      // `cmap` goes out of scope; the next object reuses the buffer
+        }
+    }
     return GST_OK;
 }
 

@@ -147,6 +147,24 @@ def atom_derivs(model, atom):
     return out
 
 
+def atom_second_derivs(model, atom):
+    """hessian_wrt_params [n_elem, n, n] (or None for members linear in their parameters) of the objects atom_derivs
+    lists, in its order -- what MatrixForwardSimulator._hoperation consumes (matrixforwardsim.py:192-224)."""
+    D = model.dim
+    out = []
+    for k, labels, typ in ((_lib.KIND_GATE, list(atom.op_labels), "op"), (_lib.KIND_RHO, list(atom.rho_labels), "prep"),
+                           (_lib.KIND_EFFECT, atom._hip_eff_labels, "povm")):
+        n_el = D * D if k == _lib.KIND_GATE else D
+        for lbl in labels:
+            member = model._circuit_layer_operator(lbl, typ)
+            n = len(member.gpindices_as_array())
+            if n == 0:
+                continue
+            out.append(np.ascontiguousarray(np.real(member.hessian_wrt_params()), dtype=np.float64).reshape(n_el, n, n)
+                       if member.has_nonzero_hessian() else None)
+    return out
+
+
 def atom_plan(model, atom, device=-1, target_tasks=0):
     """The libgstfwd plan of a `_MapCOPALayoutAtom`, built from its prefix table and cached on the atom."""
     plan = getattr(atom, "_hip_plan", None)
@@ -261,12 +279,9 @@ class HipMapForwardSimulator(_MapForwardSimulator):
         plan = self._prepare(layout_atom, derivatives=True)
         hmode = getattr(plan, "_hip_mode", None)
         if hmode == "derivs":
-            # exact Hessians of a general parameterisation: only when every member is linear in its parameters
-            for labels, typ in ((layout_atom.op_labels, "op"), (layout_atom.rho_labels, "prep"), (layout_atom._hip_eff_labels, "povm")):
-                for lbl in labels:
-                    if self.model._circuit_layer_operator(lbl, typ).has_nonzero_hessian():
-                        raise NotImplementedError("member %s has second derivatives with respect to its parameters: exact "
-                                                  "Hessians on the device cover linear parameterisations (full, TP)" % str(lbl))
+            # exact Hessians of a general parameterisation: members that are not linear in their parameters also send
+            # their hessian_wrt_params (the objects and their order are atom_derivs')
+            plan.set_second_derivs(atom_second_derivs(self.model, layout_atom))
         elif hmode != "elements" and not (hmode == "tp-elements" and self.derivative_mode == "fd"):
             raise NotImplementedError("Hessians on the device: fully parameterised models (FD or exact), full-TP models "
                                       "(FD of FD as the Map simulator computes them, or exact)")

@@ -97,6 +97,7 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
     dv = {}
     if general_params:
         k_l, o_l, n_l, pi_l, d_l = [], [], [], [], []
+        h_l, hz_l = [], []
         for kind, labels, typ in ((0, op_labels, 'op'), (1, rho_labels, 'prep'), (2, eff_labels, 'povm')):
             for oi, lbl in enumerate(labels):
                 member = model._circuit_layer_operator(lbl, typ)
@@ -104,8 +105,17 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
                 idx = member.gpindices_as_array()
                 assert dm.shape == ((D * D if kind == 0 else D), len(idx))
                 k_l.append(kind); o_l.append(oi); n_l.append(len(idx)); pi_l.append(idx); d_l.append(dm.ravel())
+                # second derivatives of the dense elements (zero for linear parameterisations): what
+                # MatrixForwardSimulator._hoperation consumes (matrixforwardsim.py:192-224)
+                if member.has_nonzero_hessian():
+                    hm = np.ascontiguousarray(np.real(member.hessian_wrt_params()), dtype=np.float64)
+                    assert hm.shape == (dm.shape[0], len(idx), len(idx))
+                    h_l.append(hm.ravel()); hz_l.append(1)
+                else:
+                    h_l.append(np.zeros(0)); hz_l.append(0)
         dv = dict(dv_kind=np.array(k_l, np.int32), dv_obj=np.array(o_l, np.int32), dv_ncols=np.array(n_l, np.int32),
-                  dv_param_idx=np.concatenate(pi_l).astype(np.int64), dv_deriv=np.concatenate(d_l))
+                  dv_param_idx=np.concatenate(pi_l).astype(np.int64), dv_deriv=np.concatenate(d_l),
+                  dv2_nonzero=np.array(hz_l, np.int32), dv2_hess=np.concatenate(h_l))
         # TP POVMs: the complement effect = identity - sum(other effects) (modelmembers/povms/complementeffect.py:72-78)
         from pygsti.modelmembers.povms.complementeffect import ComplementPOVMEffect
         for oi, lbl in enumerate(eff_labels):
@@ -327,7 +337,8 @@ def main():
         dump_case('smq1Q_XYI_L4_TP', m, circs, general_params=True, want_hprobs=True, hprobs_blk=blk)
         m = smq1Q_XYI.target_model("CPTPLND")
         m.from_vector(m.to_vector() + 0.01 * np.random.default_rng(3).standard_normal(m.num_params))
-        dump_case('smq1Q_XYI_L4_CPTPLND', m, circs, general_params=True)
+        blk = (np.array([0, 2, 7, 8, 13, 25, 26, 40, 59]), np.arange(0, 60, 3))
+        dump_case('smq1Q_XYI_L4_CPTPLND', m, circs, general_params=True, want_hprobs=True, hprobs_blk=blk)
         m = smq2Q_XYICNOT.target_model("full TP").depolarize(op_noise=0.01, spam_noise=0.01)
         circs2 = list(smq2Q_XYICNOT.create_gst_experiment_design(1, lite=True).all_circuits_needing_data)
         cols = np.sort(np.random.default_rng(5).choice(m.num_params, 120, replace=False))

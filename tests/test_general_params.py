@@ -183,3 +183,44 @@ def test_gpu_tp_exact_hessian_block():
     Ho = O.analytic_hprobs_general(fx2, r2, c2)
     assert np.abs(H2 - Ho).max() < 1e-10 * max(1.0, np.abs(Ho).max())
     assert np.abs(H2 - fx2["hprobs_map"]).max() < 2e-3 * max(1.0, np.abs(Ho).max())      # vs the Map simulator's FD of FD
+
+
+def test_oracle_cptplnd_exact_hessian_matches_matrix_simulator():
+    """Members that are not linear in their parameters: the chain rule plus the J_elem . hessian_wrt_params term, against
+    MatrixForwardSimulator.bulk_fill_hprobs on the CPTPLND model."""
+    fx = load_fixture("smq1Q_XYI_L4_CPTPLND")
+    assert fx["dv2_nonzero"].all()
+    H = O.analytic_hprobs_general(fx, fx["hprobs_rows"], fx["hprobs_cols"])
+    ref = fx["hprobs_matrix"]
+    assert np.abs(H[fx["matrix_rows"]] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+    # the second-derivative term matters: without it the block is visibly wrong
+    fx0 = dict(fx); fx0["dv2_nonzero"] = np.zeros_like(fx["dv2_nonzero"])
+    H0 = O.analytic_hprobs_general(fx0, fx["hprobs_rows"], fx["hprobs_cols"])
+    assert np.abs(H0[fx["matrix_rows"]] - ref).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_cptplnd_exact_hessian_block():
+    """gst_set_derivs + gst_set_second_derivs: exact Hessian block of the CPTPLND model, <= 1e-8 against
+    MatrixForwardSimulator (every member there is an exponentiated error generator: all six objects carry a second-
+    derivative tensor; the two effects share their parameters)."""
+    from pygsti_amd import _lib
+    fx = load_fixture("smq1Q_XYI_L4_CPTPLND")
+    pl = plan_from_fixture(fx)
+    pl.set_derivs(int(fx["nP"]), O.derivs_from_fixture(fx))
+    pl.set_second_derivs(O.second_derivs_from_fixture(fx))
+    r, c = fx["hprobs_rows"], fx["hprobs_cols"]
+    H = pl.fill_hprobs(idx1=r, idx2=c, mode=_lib.DERIV_ANALYTIC)
+    ref = fx["hprobs_matrix"]
+    assert np.abs(H[fx["matrix_rows"]] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+    assert np.abs(H - O.analytic_hprobs_general(fx, r, c)).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    # destination window, and the whole 60 x 60 Hessian is symmetric
+    out = np.full((int(fx["nE"]), len(r) + 1, len(c) + 2), 9.0)
+    pl.fill_hprobs(out=out, idx1=r, idx2=c, dest1=np.arange(len(r)) + 1, dest2=np.arange(len(c)) + 1, mode=_lib.DERIV_ANALYTIC)
+    assert np.array_equal(out[:, 1:, 1:1 + len(c)], H) and (out[:, 0] == 9.0).all() and (out[:, :, 0] == 9.0).all() and (out[:, :, -1] == 9.0).all()
+    full = pl.fill_hprobs(mode=_lib.DERIV_ANALYTIC)
+    assert np.abs(full - np.transpose(full, (0, 2, 1))).max() < 1e-9 * max(1.0, np.abs(full).max())
+    # without the tensors the linear chain rule alone is returned (and is not the Hessian of this model)
+    pl.set_second_derivs([])
+    H_lin = pl.fill_hprobs(idx1=r, idx2=c, mode=_lib.DERIV_ANALYTIC)
+    assert np.abs(H_lin[fx["matrix_rows"]] - ref).max() > 1e-3
