@@ -454,8 +454,8 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
             }
             // Persistent launch (D <= 16): pack the pairs into one queue per SIMD with equal estimated work -- longest
             // first, each into the least loaded queue -- instead of leaving the placement to the dispatcher.
-            // Measured on MI355X (2Q design, kernel ms, queues vs dispatcher): 1/8 atom 4.46 vs 4.62, 1/4 atom 7.10 vs
-            // 7.44, 1/2 atom 14.28 vs 13.55, whole 25.15 vs 25.37 -- with many pairs per SIMD the dispatcher's dynamic
+            // Measured on MI355X (2Q design, kernel ms, interleaved repeats, queues vs dispatcher): 1/8 atom 4.54 vs
+            // 4.63, 1/4 atom 7.17 vs 7.37, 1/2 atom 14.3 vs 13.6 -- with many pairs per SIMD the dispatcher's dynamic
             // placement is as good or better, so the queues are used below 10 pairs per SIMD.
             p->have_bins = false;
             if (!rows && p->fd_persist && p->hp.max_slots <= 4 && (p->fd_persist_always || items.size() <= (size_t)40 * p->n_cus) &&

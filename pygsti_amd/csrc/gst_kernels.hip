@@ -155,7 +155,7 @@ constexpr int XPAD = 2;      // exchange-buffer lane stride D + 2 doubles: 16-by
 // PERSIST: the workgroup is as many wavefronts as one CU holds and stays for the whole launch; each wavefront pops pairs
 // from the queue of the SIMD it runs on (queues the host packed to equal estimated work, WalkArgs::bin_ptr), then from
 // the other SIMDs' queues.  The hardware dispatcher places a new one-wavefront workgroup wherever a slot frees up,
-// blind to how much work the slot's SIMD neighbours still hold; with ~4 pairs per SIMD (a 1/8 atom) that costs 8 %.
+// blind to how much work the slot's SIMD neighbours still hold; with ~4-9 pairs per SIMD (1/8, 1/4 atoms) that costs 2-3 %.
 // COMP (Hessian pass of "full TP" models): the POVM's complement effect is identity - sum(others), recomputed by the
 // reference after every parameter step (complementeffect.py:72-78), so a lane whose perturbations touch one of the
 // others also carries the one or two changed components of the complement.
