@@ -73,7 +73,16 @@ struct gst_plan {
     // model
     std::vector<double> h_gates, h_gates_t, h_rhos, h_effects;
     bool have_model = false;
-    DevBuf<double> d_gates, d_gates_t, d_rhos, d_effects;
+    // the model arrays [gates | gates transposed | rhos | effects] live in ONE device buffer filled by ONE copy from a
+    // pinned staging buffer per gst_set_model (a 1Q fill is launch-bound: four pageable copies were a third of it)
+    struct DevView { double* p = nullptr; };
+    DevView d_gates, d_gates_t, d_rhos, d_effects;
+    DevBuf<double> d_model;
+    double* h_model_pinned[2] = {nullptr, nullptr};      // two staging buffers, used alternately
+    hipEvent_t ev_upload[2] = {nullptr, nullptr};        // "the copy out of staging buffer i has been done"
+    size_t h_model_pinned_n = 0;
+    int upload_turn = 0;
+    bool model_dirty = true;
     // parameter map
     std::vector<int32_t> pkind, pobj, pelem;
     bool have_pmap = false;
@@ -164,7 +173,11 @@ struct gst_plan {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
         d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release(); d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release(); d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release(); d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_circ_partner.release(); d_pair_common.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release(); d_dv_deriv.release(); d_dv2.release(); d_helem.release(); d_hw.release(); d_hcsc.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release(); d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release(); d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release(); d_eff_label.release(); d_eff_dest.release();
-        d_gates.release(); d_gates_t.release(); d_rhos.release(); d_effects.release();
+        d_model.release();
+        for (int i = 0; i < 2; i++) {
+            if (h_model_pinned[i]) (void)hipHostFree(h_model_pinned[i]);
+            if (ev_upload[i]) (void)hipEventDestroy(ev_upload[i]);
+        }
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
         d_wave_row.release(); d_wave_rowidx.release(); d_lane_colidx.release();
@@ -252,18 +265,31 @@ int ensure_device(gst_plan* p)
 
 int upload_model(gst_plan* p)
 {
-    const gst::HostPlan& h = p->hp;
-    HIP_TRY(p->d_gates.ensure(p->h_gates.size()));
-    HIP_TRY(p->d_gates_t.ensure(p->h_gates_t.size()));
-    HIP_TRY(p->d_rhos.ensure(p->h_rhos.size()));
-    HIP_TRY(p->d_effects.ensure(p->h_effects.size()));
-    if (!p->h_gates.empty()) {
-        HIP_TRY(hipMemcpyAsync(p->d_gates.p, p->h_gates.data(), p->h_gates.size() * 8, hipMemcpyHostToDevice, p->stream));
-        HIP_TRY(hipMemcpyAsync(p->d_gates_t.p, p->h_gates_t.data(), p->h_gates_t.size() * 8, hipMemcpyHostToDevice, p->stream));
+    const size_t ng = p->h_gates.size(), nr = p->h_rhos.size(), ne = p->h_effects.size();
+    const size_t total = 2 * ng + nr + ne;
+    if (!p->model_dirty && p->d_model.p) return GST_OK;           // same arrays as the last call: already resident
+    HIP_TRY(p->d_model.ensure(std::max<size_t>(total, 1)));
+    if (p->h_model_pinned_n < total || !p->ev_upload[0]) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        for (int i = 0; i < 2; i++) {
+            if (p->h_model_pinned[i]) (void)hipHostFree(p->h_model_pinned[i]);
+            p->h_model_pinned[i] = nullptr;
+            HIP_TRY(hipHostMalloc((void**)&p->h_model_pinned[i], std::max<size_t>(total, 1) * 8, hipHostMallocDefault));
+            if (!p->ev_upload[i]) HIP_TRY(hipEventCreateWithFlags(&p->ev_upload[i], hipEventDisableTiming));
+        }
+        p->h_model_pinned_n = total;
     }
-    HIP_TRY(hipMemcpyAsync(p->d_rhos.p, p->h_rhos.data(), p->h_rhos.size() * 8, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->d_effects.p, p->h_effects.data(), p->h_effects.size() * 8, hipMemcpyHostToDevice, p->stream));
-    (void)h;
+    p->d_gates.p = p->d_model.p; p->d_gates_t.p = p->d_model.p + ng; p->d_rhos.p = p->d_model.p + 2 * ng; p->d_effects.p = p->d_model.p + 2 * ng + nr;
+    const int turn = p->upload_turn;
+    p->upload_turn ^= 1;
+    HIP_TRY(hipEventSynchronize(p->ev_upload[turn]));          // (the copy that last used this staging buffer: long done)
+    double* h = p->h_model_pinned[turn];
+    if (ng) { std::memcpy(h, p->h_gates.data(), ng * 8); std::memcpy(h + ng, p->h_gates_t.data(), ng * 8); }
+    std::memcpy(h + 2 * ng, p->h_rhos.data(), nr * 8);
+    std::memcpy(h + 2 * ng + nr, p->h_effects.data(), ne * 8);
+    if (total) HIP_TRY(hipMemcpyAsync(p->d_model.p, h, total * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipEventRecord(p->ev_upload[turn], p->stream));
+    p->model_dirty = false;
     return GST_OK;
 }
 
@@ -926,6 +952,7 @@ int gst_set_model(gst_plan* p, const double* gates, const double* rhos, const do
     p->h_rhos.assign(rhos, rhos + (size_t)p->hp.n_rhos * D);
     p->h_effects.assign(effects, effects + (size_t)p->hp.n_effects * D);
     p->have_model = true;
+    p->model_dirty = true;
     return GST_OK;
 }
 
