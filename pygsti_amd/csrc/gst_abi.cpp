@@ -482,9 +482,10 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
             // first, each into the least loaded queue -- instead of leaving the placement to the dispatcher.
             // Measured on MI355X (2Q design, kernel ms, interleaved repeats, queues vs dispatcher): 1/8 atom 4.54 vs
             // 4.63, 1/4 atom 7.17 vs 7.37, 1/2 atom 14.3 vs 13.6 -- with many pairs per SIMD the dispatcher's dynamic
-            // placement is as good or better, so the queues are used below 10 pairs per SIMD.
+            // placement is as good or better, so the queues are used below 10 pairs per SIMD -- and not below one pair
+            // per SIMD, where a fill is launch-bound and the extra memset and pops cost 10 us (1Q L<=128: 100 vs 110 us).
             p->have_bins = false;
-            if (!rows && p->fd_persist && p->hp.max_slots <= 4 && (p->fd_persist_always || items.size() <= (size_t)40 * p->n_cus) &&
+            if (!rows && p->fd_persist && p->hp.max_slots <= 4 && (p->fd_persist_always || (items.size() <= (size_t)40 * p->n_cus && items.size() >= (size_t)4 * p->n_cus)) &&
                 (size_t)16 * std::max(p->hp.max_slots, 1) * p->hp.D * 64 * 8 <= 160 * 1024) {
                 const int n_bins = 4 * p->n_cus;
                 std::vector<std::vector<uint32_t>> bins(n_bins);
