@@ -1,6 +1,7 @@
 """Development aid: randomized parity sweep on the GPU box -- many random plans (shapes, slot budgets, task targets, both
 FD launch forms) through the C ABI against the CPU oracle, bit for bit (probs, FD dprobs, FD-of-FD hprobs), and the
-analytic Jacobian against the numpy forward/backward oracle.  Usage: python tools/fuzz_gpu.py [n_cases] [seed0]"""
+analytic Jacobian against the numpy forward/backward oracle.  Usage: python tools/fuzz_gpu.py [n_cases] [seed0] [d64]
+(third argument "d64": 3-qubit shapes, D = 64, through the register-blocked / shared-tile / row kernels)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +12,7 @@ from pygsti_amd import _lib
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+d64 = len(sys.argv) > 3 and sys.argv[3] == "d64"
 t0 = time.time()
 bad = 0
 for k in range(n_cases):
@@ -20,6 +22,9 @@ for k in range(n_cases):
     nG = int(rng.integers(1, 8)); nR = int(rng.integers(1, 4)); nEl = int(rng.integers(1, 7))
     max_len = int(rng.choice([6, 40, 150, 400]))
     max_slots = int(rng.integers(0, 5)); target_tasks = int(rng.choice([0, 0, 1, 3, 17, 200]))
+    if d64:
+        D = 64; n_circ = int(rng.choice([10, 40, 120])); nG = int(rng.integers(1, 5)); nEl = int(rng.integers(1, 9))
+        max_len = int(rng.choice([4, 20, 60])); max_slots = int(rng.choice([0, 1, 2, 3, 6, 12]))
     persist = str(rng.choice(["0", "2"]))
     os.environ["GST_FD_PERSIST"] = persist
     a, tbl, mdl, nP = _random_case(D, seed0 + k, n_circ=n_circ, nG=nG, nR=nR, nEl=nEl, max_len=max_len)
@@ -32,7 +37,7 @@ for k in range(n_cases):
         pl.set_param_map(mdl["pkind"], mdl["pobj"], mdl["pelem"])
         orc = O.Oracle(tbl, mdl)
         assert np.array_equal(pl.fill_probs(), orc.probs()), "probs"
-        cols = rng.permutation(nP)[: min(nP, int(rng.choice([1, 30, 200, nP])))]
+        cols = rng.permutation(nP)[: min(nP, int(rng.choice([1, 30, 200, nP if not d64 else 700])))]
         J = pl.fill_dprobs(param_idx=cols, eps=1e-7)
         assert np.array_equal(J, orc.dprobs(cols, eps=1e-7)), "dprobs"
         assert np.array_equal(pl.fill_dprobs(param_idx=cols, eps=1e-7), J), "dprobs (repeat)"
