@@ -49,6 +49,10 @@ for k in range(n_cases):
         Ja = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
         Jo, _ = O.analytic_dprobs(fx, cols)
         assert np.abs(Ja - Jo).max() <= 1e-8 * max(1.0, np.abs(Jo).max()), "analytic dprobs"
+        if a["nE"] > 0 and n_circ <= 80 and max_len <= 60:       # exact Hessian block against the numpy derivative-state oracle
+            Ha = pl.fill_hprobs(idx1=i1[:3], idx2=i2[:12], mode=_lib.DERIV_ANALYTIC)
+            Ho = O.analytic_hprobs(fx, i1[:3], i2[:12])
+            assert np.abs(Ha - Ho).max() <= 1e-8 * max(1.0, np.abs(Ho).max()), "analytic hprobs"
         pl.close()
     except Exception as e:           # noqa
         bad += 1
