@@ -98,6 +98,7 @@ struct gst_plan {
     DevBuf<int64_t> d_rtask_off, d_pos_ptr;
     DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order, d_circ_partner, d_pair_common;
     bool ana_pairs = true;              // GST_ANALYTIC_PAIRS=0: one circuit per work item in the D = 16 contraction
+    bool ana_germ_order = true;         // GST_ANALYTIC_GERM_ORDER=0: pure suffix order of the work items
     DevBuf<double> d_rev_cache;
     DevBuf<uint32_t> d_work_counter, d_range_begin;
     bool want_cache_path = false;       // set by the Hessian driver around its set-up Jacobian call
@@ -225,6 +226,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     p->fd_split = opt ? opt->fd_split : 0;
     if (const char* e = std::getenv("GST_FD_SPLIT")) p->fd_split = std::atoi(e);     // development override
     if (const char* e = std::getenv("GST_ANALYTIC_PAIRS")) p->ana_pairs = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_ANALYTIC_GERM_ORDER")) p->ana_germ_order = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_PERSIST")) { p->fd_persist = std::atoi(e) != 0; p->fd_persist_always = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
@@ -633,11 +635,61 @@ int ensure_reverse(gst_plan* p)
     std::vector<int32_t> order((size_t)h.n_circuits);
     for (int64_t c = 0; c < h.n_circuits; c++) order[(size_t)c] = (int32_t)c;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->rev.circ_leaf[x] < p->rev.circ_leaf[y]; });
+    const int nG = h.n_gates;
+    // applications of every gate that two circuits have in common at their ends (equal backward-state ids)
+    auto common_tail = [&](int32_t c, int32_t c2, int32_t* per_gate) {
+        int64_t common = 0;
+        for (int g = 0; g < nG; g++) {
+            const int64_t a0 = pos_ptr[(size_t)c * nG + g], a1 = pos_ptr[(size_t)c * nG + g + 1];
+            const int64_t b0 = pos_ptr[(size_t)c2 * nG + g], b1 = pos_ptr[(size_t)c2 * nG + g + 1];
+            int64_t n = 0;
+            while (n < a1 - a0 && n < b1 - b0 && pr[(size_t)(a1 - 1 - n)] == pr[(size_t)(b1 - 1 - n)]) n++;
+            if (per_gate) per_gate[g] = (int32_t)n;
+            common += n;
+        }
+        return common;
+    };
+    auto similar = [&](int32_t c, int32_t c2, int64_t common) {
+        const int64_t longer = std::max(h.circ_ptr[c + 1] - h.circ_ptr[c], h.circ_ptr[c2 + 1] - h.circ_ptr[c2]);
+        return common >= 8 && 2 * common >= longer;
+    };
+    if (h.D == 16 && p->ana_germ_order && h.n_circuits > 1) {
+        // Locality of the FORWARD states.  Pure suffix order keeps the backward chains of neighbours together but walks
+        // through every prefix family (preparation fiducial x germ) for each measurement fiducial and germ power, so the
+        // forward chains -- 128 bytes per application of every item -- never stay in an XCD's 4 MB L2.  Runs of
+        // neighbours that end alike (one germ power and measurement fiducial behind all the preparation fiducials)
+        // are kept whole, and the runs are ordered by the forward-trie family their first member belongs to (the root
+        // of its state's parent chain = the task of the forward plan): all the runs of one germ become consecutive, their
+        // 16 forward chains (2 MB) stay in L2 while the germ's backward chains stream through once.
+        std::vector<int32_t> root((size_t)h.n_state_ids, -2);
+        auto root_of = [&](int32_t id) {
+            int32_t r = id;
+            while (root[(size_t)r] == -2 && h.node_parent[(size_t)r] >= 0) r = h.node_parent[(size_t)r];
+            const int32_t top = root[(size_t)r] == -2 ? r : root[(size_t)r];
+            for (int32_t q = id; q != r; q = h.node_parent[(size_t)q]) root[(size_t)q] = top;
+            root[(size_t)r] = top;
+            return top;
+        };
+        std::vector<int32_t> run_of((size_t)h.n_circuits, 0), run_key;
+        int32_t run = 0;
+        run_key.push_back(root_of(h.circ_leaf[(size_t)order[0]]));
+        for (int64_t k = 1; k < h.n_circuits; k++) {
+            const int32_t c = order[(size_t)k - 1], c2 = order[(size_t)k];
+            if (!similar(c, c2, common_tail(c, c2, nullptr))) { run++; run_key.push_back(0x7fffffff); }
+            run_of[(size_t)k] = run;
+            run_key[(size_t)run] = std::min(run_key[(size_t)run], root_of(h.circ_leaf[(size_t)c2]));
+        }
+        std::vector<int32_t> posn((size_t)h.n_circuits);
+        for (int64_t k = 0; k < h.n_circuits; k++) posn[(size_t)k] = (int32_t)k;
+        std::stable_sort(posn.begin(), posn.end(), [&](int32_t x, int32_t y) { return run_key[(size_t)run_of[(size_t)x]] < run_key[(size_t)run_of[(size_t)y]]; });
+        std::vector<int32_t> reordered((size_t)h.n_circuits);
+        for (int64_t k = 0; k < h.n_circuits; k++) reordered[(size_t)k] = order[(size_t)posn[(size_t)k]];
+        order.swap(reordered);
+    }
     // Work items of the D = 16 contraction: a circuit, or TWO neighbours of the suffix order whose last applications
     // coincide (same germ power and measurement fiducial behind different preparation fiducials): over the common
     // tail their backward states are the same vectors and the kernel gathers them once for both.
     std::vector<int32_t> item_first, item_partner, item_common;
-    const int nG = h.n_gates;
     const bool pairing = h.D == 16 && h.n_effects == 4 && p->ana_pairs;
     auto plain4 = [&](int32_t c) {
         if (h.eff_ptr[c + 1] - h.eff_ptr[c] != 4) return false;
@@ -651,17 +703,8 @@ int ensure_reverse(gst_plan* p)
             const int32_t c2 = order[(size_t)k + 1];
             if (plain4(c) && plain4(c2)) {
                 std::vector<int32_t> cg((size_t)nG, 0);
-                int64_t common = 0;
-                for (int g = 0; g < nG; g++) {
-                    const int64_t a0 = pos_ptr[(size_t)c * nG + g], a1 = pos_ptr[(size_t)c * nG + g + 1];
-                    const int64_t b0 = pos_ptr[(size_t)c2 * nG + g], b1 = pos_ptr[(size_t)c2 * nG + g + 1];
-                    int64_t n = 0;
-                    while (n < a1 - a0 && n < b1 - b0 && pr[(size_t)(a1 - 1 - n)] == pr[(size_t)(b1 - 1 - n)]) n++;
-                    cg[(size_t)g] = (int32_t)n;
-                    common += n;
-                }
-                const int64_t longer = std::max(h.circ_ptr[c + 1] - h.circ_ptr[c], h.circ_ptr[c2 + 1] - h.circ_ptr[c2]);
-                if (common >= 8 && 2 * common >= longer) {
+                const int64_t common = common_tail(c, c2, cg.data());
+                if (similar(c, c2, common)) {
                     item_first.push_back(c); item_partner.push_back(c2);
                     item_common.insert(item_common.end(), cg.begin(), cg.end());
                     paired = true;
