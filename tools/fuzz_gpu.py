@@ -13,6 +13,7 @@ from pygsti_amd import _lib
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 d64 = len(sys.argv) > 3 and sys.argv[3] == "d64"
+big = len(sys.argv) > 3 and sys.argv[3] == "big"       # thousands of circuits: the default (size-dependent) launch form
 t0 = time.time()
 bad = 0
 for k in range(n_cases):
@@ -22,11 +23,17 @@ for k in range(n_cases):
     nG = int(rng.integers(1, 8)); nR = int(rng.integers(1, 4)); nEl = int(rng.integers(1, 7))
     max_len = int(rng.choice([6, 40, 150, 400]))
     max_slots = int(rng.integers(0, 5)); target_tasks = int(rng.choice([0, 0, 1, 3, 17, 200]))
+    if big:
+        D = 16; n_circ = int(rng.choice([1500, 3000])); nG = int(rng.integers(3, 8)); max_len = int(rng.choice([100, 600]))
+        persist = ""
     if d64:
         D = 64; n_circ = int(rng.choice([10, 40, 120])); nG = int(rng.integers(1, 5)); nEl = int(rng.integers(1, 9))
         max_len = int(rng.choice([4, 20, 60])); max_slots = int(rng.choice([0, 1, 2, 3, 6, 12]))
     persist = str(rng.choice(["0", "2"]))
-    os.environ["GST_FD_PERSIST"] = persist
+    if persist:
+        os.environ["GST_FD_PERSIST"] = persist
+    else:
+        os.environ.pop("GST_FD_PERSIST", None)
     a, tbl, mdl, nP = _random_case(D, seed0 + k, n_circ=n_circ, nG=nG, nR=nR, nEl=nEl, max_len=max_len)
     tag = "case %d: D=%d circuits=%d nG=%d nR=%d nEl=%d max_len=%d slots=%d tasks=%d persist=%s" % (
         k, D, n_circ, nG, nR, nEl, max_len, max_slots, target_tasks, persist)
