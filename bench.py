@@ -51,12 +51,16 @@ def build_workload(design, max_len, world, rank, device, target_tasks, max_slots
     return pack, model, circuits, layout
 
 
-def cpu_baseline(pack, model, max_len):
-    """Time the CPU checker on a bounded sample: the `lite` sub-design (15 of the 88 germs; every one of its
-    circuits is in the full design), walking the reference-format prefix table for a fixed number of passes
-    (one pass = one finite-difference column)."""
+def cpu_baseline(pack, model, max_len, design):
+    """Time the CPU checker on a bounded sample of THE SAME workload: the reference-format prefix table of the
+    benchmarked design (restated PrefixTable, oracle/prefix_table.py) walked for a fixed number of passes -- one pass =
+    one finite-difference column = one `dm_mapfill_probs` (mapforwardsim_calc_densitymx.pyx:194-287).  Returns the
+    1-core figure (`cpu_baseline`) and the all-host-cores figure (`cpu_baseline_allcores`: the FD columns are
+    independent, so every core walks the table for its own columns -- what OpenMP over columns / the reference's
+    parameter-processor MPI split, distlayout.py:478-506, would do)."""
+    import concurrent.futures as cf
     from oracle import oracle as O, prefix_table as PT
-    circuits = pack.create_gst_circuits(max_len, lite=True)
+    circuits = pack.create_gst_circuits(max_len, lite=(design == "lite"))
     lookup = {l: i for i, l in enumerate(model.operations.keys())}
     ptr = np.zeros(len(circuits) + 1, np.int64)
     ptr[1:] = np.cumsum([len(c) for c in circuits])
@@ -70,17 +74,44 @@ def cpu_baseline(pack, model, max_len):
     nP = model.num_params
     mdl = dict(gates=G, rhos=R, effects=E, pkind=-np.ones(nP, np.int32), pobj=np.zeros(nP, np.int32),
                pelem=np.zeros(nP, np.int32))
-    kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgst_ref.so")) else "port"
+    have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgst_ref.so"))
+    kind = "reference" if have_ref else "port"
     orc = O.Oracle(tbl, mdl, kind)
-    t1 = orc.time_passes(4)                      # calibrate
-    n_pass = int(max(8, min(400, 12.0 / max(t1 / 4, 1e-6))))
-    t = orc.time_passes(n_pass)
     nE = tbl["nE"]
-    return {"value": nE * n_pass / t, "unit": "Jacobian-elements/s", "cores": 1, "kind": kind,
-            "sample": "%d FD columns (probability passes) over the lite sub-design (%d of the workload's circuits, "
-                      "nE=%d, %d gate applications per pass on the reference prefix table), %.1f s"
-                      % (n_pass, len(circuits), nE, len(tbl["gate_idx"]), t),
-            "probs_per_s": nE * n_pass / t}
+    t1 = orc.time_passes(2)                      # calibrate
+    n_pass = int(max(4, min(400, 10.0 / max(t1 / 2, 1e-6))))
+    t = orc.time_passes(n_pass)
+    what = "%s germs design itself (%d circuits, nE=%d, %d gate applications per pass on the reference-format prefix table)" % (
+        design, len(circuits), nE, len(tbl["gate_idx"]))
+    one = {"value": nE * n_pass / t, "unit": "Jacobian-elements/s", "cores": 1, "kind": kind,
+           "sample": "%d FD columns (probability passes) over the %s, %.1f s" % (n_pass, what, t),
+           "probs_per_s": nE * n_pass / t}
+    # the restatement next to the reference's own C++ on the same table (maps "port" numbers back to "reference")
+    if have_ref:
+        n_r = max(2, n_pass // 8)
+        port = O.Oracle(tbl, mdl, "port")
+        tp = port.time_passes(n_r); tr = orc.time_passes(n_r)
+        one["port_over_reference_time_ratio"] = tp / tr
+    # all host cores: one thread per core, each with its own workspace (ctypes releases the GIL)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per = int(max(2, min(n_pass, 12.0 / max(t / n_pass, 1e-6))))
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda _: O.Oracle(tbl, mdl, kind).time_passes(per), range(cores)))
+    ta = time.perf_counter() - t0
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    allc = {"value": nE * per * cores / ta, "unit": "Jacobian-elements/s", "cores": cores, "kind": kind,
+            "cpu_model": cpu_model, "nproc": os.cpu_count(),
+            "sample": "%d threads x %d FD columns each over the %s, %.1f s" % (cores, per, what, ta),
+            "speedup_over_1_core": (nE * per * cores / ta) / (nE * n_pass / t)}
+    return one, allc
 
 
 def main():
@@ -93,8 +124,11 @@ def main():
     ap.add_argument("--target-tasks", type=int, default=0)
     ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--jtj", action="store_true", help="also time J^T J and J^T f on the resident Jacobian (row f1)")
-    ap.add_argument("--gather", action="store_true", help="N>1: also all-gather the probability row blocks (RCCL)")
+    ap.add_argument("--jtj", action="store_true", help="also time J^T J and J^T f on the resident Jacobian (row f1); "
+                    "N>1: plus the all-reduce of the partial products between device buffers (RCCL)")
+    ap.add_argument("--no-jacobian-gather", action="store_true",
+                    help="N>1: skip the secondary timing of the fan-in of the Jacobian row blocks to rank 0")
+    ap.add_argument("--no-host-fill", action="store_true", help="N=1: skip the secondary end-to-end fill into a host array")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1: weak = one full design per rank (N designs in all); strong = one design dealt to N atoms")
     ap.add_argument("--no-analytic", action="store_true", help="skip the secondary analytic-derivative timing")
@@ -112,30 +146,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-    dist = None
-    backend = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        ndev = max(torch.cuda.device_count(), 1)
-        device = local_rank % ndev                  # (ranks share a GPU only in the 1-GPU plumbing test)
-        torch.cuda.set_device(device)
-        backend = os.environ.get("GST_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend)
-        local_rank = device
+
+    from pygsti_amd import _lib, dist as gdist
+    device = local_rank % max(_lib.device_count(), 1)      # (ranks share a GPU only in 1-GPU plumbing runs)
+    # control plane: a gloo group (rendezvous, barriers, max-over-ranks); data plane: the C ABI's device communicator
+    # (RCCL over xGMI; the IPC transport when RCCL cannot start, e.g. ranks sharing a GPU)
+    ctx = gdist.init(device=device, transport="auto") if world > 1 else gdist.DistContext(0, 1, local_rank, None, None)
+    comm = ctx.comm
 
     def barrier_sync(plan):
         plan.sync()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+        ctx.barrier()
 
     lay_world, lay_rank = (args.emulate_ranks, 0) if (world == 1 and args.emulate_ranks > 1) else (world, rank)
-    pack, model, circuits, layout = build_workload(args.design, args.max_len, lay_world, lay_rank, local_rank,
+    pack, model, circuits, layout = build_workload(args.design, args.max_len, lay_world, lay_rank, device,
                                                     args.target_tasks, args.max_slots, args.scaling)
     atom = layout.atoms[0]
     plan = atom.plan()
@@ -148,16 +172,43 @@ def main():
     if lay_world != world:
         nE_total = nE_local                       # --emulate-ranks: one atom's share only
     n_circ_total = len(circuits) * (world if args.scaling == "weak" else 1)
-    d_out = plan.device_malloc(nE_local * nP * 8)
-    d_probs = plan.device_malloc(nE_local * 8)
+    # row blocks of the assembled element dimension: (owner rank, first row, rows)
+    if world > 1 and args.scaling == "strong":
+        blocks = gdist.row_blocks(layout, world)
+        row0 = atom.element_slice.start
+    elif world > 1:
+        blocks = [(r, r * nE_local, nE_local) for r in range(world)]
+        row0 = rank * nE_local
+    else:
+        blocks, row0 = [(0, 0, nE_local)], 0
+    d_out = plan.device_malloc(nE_local * nP * 8)          # this rank's Jacobian rows (stay distributed, as in the reference)
+    d_pfull = plan.device_malloc(nE_total * 8)             # the ASSEMBLED probabilities: own rows filled in place
+    d_probs = d_pfull + row0 * 8
     pidx = np.arange(nP, dtype=np.int64)
 
-    from pygsti_amd import _lib
     mode = _lib.DERIV_ANALYTIC if args.deriv == "analytic" else _lib.DERIV_FD
+    exchange = None
+    if world > 1:
+        exchange = {"transport": ctx.transport, "rccl_ranks": world if ctx.transport == "rccl" else 0,
+                    "rccl_version": comm.info()["rccl_version"] if comm is not None else 0,
+                    "what": "every step: probability row blocks all-gathered between device buffers (Allgatherv of "
+                            "resourceallocation.py:316-348); Jacobian rows stay on their ranks as bulk_fill_dprobs leaves them",
+                    "fallback_reason": ctx.comm_error}
+    host_stage = np.empty(nE_total) if (world > 1 and comm is None) else None
+
+    def exchange_probs():
+        if world == 1:
+            return
+        if comm is not None:
+            comm.allgather_rows(d_pfull, 1, blocks, plan)          # stream-ordered behind the fill (RCCL)
+        elif args.scaling == "strong":                             # no device transport at all: host-staged, flagged
+            plan.memcpy_d2h(host_stage[row0:row0 + nE_local], d_probs)
+            plan.memcpy_h2d(d_pfull, gdist.gather_elements(host_stage, layout))
 
     def step():
         plan.set_model(gates, rhos, effects)          # from_vector -> new dense arrays -> H2D
         plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)
+        exchange_probs()
 
     for _ in range(args.warmup):
         step()
@@ -170,16 +221,16 @@ def main():
             plan.sync()                                # N=1: per-step HIP-event read-out (stream stays ordered)
             kernel_ms.append(plan.stats()["last_kernel_ms"])
     barrier_sync(plan)
-    dt = time.perf_counter() - t0
+    dt = ctx.max_over_ranks(time.perf_counter() - t0)
     if not kernel_ms:
         kernel_ms = [plan.stats()["last_kernel_ms"]]
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
-    # secondary: probabilities only
+    if world > 1:
+        # every rank must now hold every circuit's probabilities: they sum to 1 per circuit
+        pf = plan.memcpy_d2h(np.empty(nE_total), d_pfull)
+        assert abs(pf.sum() - n_circ_total) < 1e-6 * n_circ_total, "assembled probabilities must sum to 1 per circuit"
+
+    # secondary: probabilities only (+ their all-gather)
     for _ in range(2):
         plan.fill_probs_dev(d_probs)
     barrier_sync(plan)
@@ -188,8 +239,9 @@ def main():
     for _ in range(n_pr):
         plan.set_model(gates, rhos, effects)
         plan.fill_probs_dev(d_probs)
+        exchange_probs()
     barrier_sync(plan)
-    dtp = time.perf_counter() - tp0
+    dtp = ctx.max_over_ranks(time.perf_counter() - tp0)
 
     # secondary: the same Jacobian by analytic derivatives (MatrixForwardSimulator semantics, <= 1e-8 vs that simulator)
     ana_info = None
@@ -202,18 +254,52 @@ def main():
         for _ in range(n_an):
             plan.set_model(gates, rhos, effects)
             plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
+            exchange_probs()
         barrier_sync(plan)
-        dta = time.perf_counter() - ta0
-        if dist is not None:
-            import torch
-            tt = torch.tensor([dta], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dta = float(tt.item())
+        dta = ctx.max_over_ranks(time.perf_counter() - ta0)
         ana_info = {"value": nE_total * nP * n_an / dta, "unit": "Jacobian-elements/s", "ms_per_step": 1e3 * dta / n_an,
                     "kernel_ms": plan.stats()["last_kernel_ms"],
                     "note": "analytic derivatives (reference MatrixForwardSimulator semantics); secondary figure, not `value`"}
-        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the FD Jacobian resident for --jtj
+        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the FD Jacobian resident
         barrier_sync(plan)
+
+    # secondary (N>1): the fan-in of the Jacobian row blocks to rank 0 between device buffers (Gatherv,
+    # resourceallocation.py:329-348 -- what `gather_local_array('ep', ...)` is for), alone and behind a fill
+    if world > 1 and comm is not None and not args.no_jacobian_gather and args.scaling == "strong":
+        d_jfull = plan.device_malloc(nE_total * nP * 8) if rank == 0 else None
+        try:
+            if rank == 0:       # the root's own rows in place (one device-to-device copy per fill in a real run)
+                plan.fill_dprobs_dev(d_jfull + row0 * nP * 8, nP, pidx, None, 1e-7, d_probs, mode)
+            comm.gather_rows(d_out, d_jfull, nP, blocks, 0, plan)                       # warm-up (maps peers, opens links)
+            barrier_sync(plan)
+            tg = time.perf_counter()
+            n_g = 3
+            for _ in range(n_g):
+                comm.gather_rows(d_out, d_jfull, nP, blocks, 0, plan)
+            barrier_sync(plan)
+            t_gather = ctx.max_over_ranks(time.perf_counter() - tg) / n_g
+            tg = time.perf_counter()
+            for _ in range(n_g):
+                plan.set_model(gates, rhos, effects)
+                dst = d_jfull + row0 * nP * 8 if rank == 0 else d_out
+                plan.fill_dprobs_dev(dst, nP, pidx, None, 1e-7, d_probs, mode)
+                comm.gather_rows(d_out, d_jfull, nP, blocks, 0, plan)
+            barrier_sync(plan)
+            t_both = ctx.max_over_ranks(time.perf_counter() - tg) / n_g
+            moved = 8.0 * (nE_total - nE_local) * nP if rank == 0 else 0.0
+            moved = ctx.max_over_ranks(moved)
+            exchange["jacobian_gather_to_rank0"] = {
+                "ms": 1e3 * t_gather, "GB": moved / 1e9, "GBps_into_rank0": moved / t_gather / 1e9,
+                "fill_plus_gather_ms": 1e3 * t_both,
+                "elements_per_s_with_gather": nE_total * nP / t_both,
+                "note": "secondary: rows of the other ranks written into rank 0's assembled [nE][nP] array, each block "
+                        "over its own xGMI link (grouped point-to-point under RCCL, peer copies under IPC)"}
+            if rank == 0:
+                chk = plan.memcpy_d2h(np.empty(nP), d_jfull + ((nE_total - 1) * nP) * 8)
+                assert np.isfinite(chk).all()
+        finally:
+            if d_jfull is not None:
+                plan.device_free(d_jfull)
 
     jtj_info = None
     if args.jtj:
@@ -255,54 +341,55 @@ def main():
                     "jtj_with_row_scale_ms": 1e3 * t_jtj_scaled,
                     "jtf_ms": 1e3 * t_jtf, "jtf_GBps": 8.0 * nE_local * nP / t_jtf / 1e9,
                     "note": "element-wise objective kernel + hand-written split-K MFMA fp64 SYRK / streaming GEMV on the device-resident Jacobian of this rank (flops counted for the triangle: nE*nP^2)"}
-        if dist is not None:
+        if world > 1 and comm is not None:
             # the path's one real exchange step: every rank holds the partial J^T J of its rows; the optimizer needs
-            # the sum -> one all-reduce of nP^2 doubles (RCCL over xGMI under nccl), cf. distlayout.py:1259,1355
-            import torch
-            host = np.empty((nP, nP)); plan.memcpy_d2h(host, d_jtj)
-            tj = torch.from_numpy(host).to("cuda" if backend == "nccl" else "cpu")
+            # the sum -> one all-reduce of nP^2 (+ nP) doubles between the device buffers, cf. distlayout.py:1259,1355
+            comm.allreduce_sum(d_jtj, nP * nP, plan)               # warm-up
             barrier_sync(plan)
             ta = time.perf_counter()
-            dist.all_reduce(tj)
+            for _ in range(5):
+                comm.allreduce_sum(d_jtj, nP * nP, plan)
+                comm.allreduce_sum(d_jtf, nP, plan)
             barrier_sync(plan)
-            jtj_info["allreduce_ms"] = 1e3 * (time.perf_counter() - ta)
-            jtj_info["allreduce_MB"] = nP * nP * 8 / 1e6
+            jtj_info["allreduce_ms"] = 1e3 * ctx.max_over_ranks(time.perf_counter() - ta) / 5
+            jtj_info["allreduce_MB"] = (nP * nP + nP) * 8 / 1e6
+            jtj_info["allreduce_transport"] = ctx.transport
         for d in (d_jtj, d_jtf, d_ls, d_w, d_c, d_N):
             plan.device_free(d)
 
-    gather_ms = None
-    if dist is not None and args.gather and args.scaling == "strong":
-        # the reference's `gather_local_array` equivalent: row blocks of the probabilities travel to every rank
-        # (RCCL all-gather over xGMI under nccl); the Jacobian stays distributed, as bulk_fill_dprobs leaves it
-        import torch
-        from pygsti_amd import dist as gdist
-        dev = "cuda" if backend == "nccl" else "cpu"
-        loc = torch.zeros(nE_total, dtype=torch.float64, device=dev)
-        host = np.empty(nE_local)
-        plan.memcpy_d2h(host, d_probs)
-        loc[atom.element_slice.start:atom.element_slice.stop] = torch.from_numpy(host).to(dev)
-        barrier_sync(plan)
-        tg = time.perf_counter()
-        full = gdist.gather_elements(loc, layout)
-        barrier_sync(plan)
-        gather_ms = 1e3 * (time.perf_counter() - tg)
-        s = float(full.sum().item())
-        assert abs(s - len(circuits)) < 1e-6 * len(circuits), "gathered probabilities must sum to 1 per circuit"
+    # secondary (N=1): the reference API end to end -- bulk_fill_dprobs into the caller's HOST 'ep' array, PCIe included
+    host_fill = None
+    if world == 1 and lay_world == 1 and not args.no_host_fill:
+        J_host = layout.allocate_local_array("ep", "d")            # page-locked (registered) by the layout
+        pr_host = np.empty(nE_local)
+        plan.fill_dprobs(J_host, pidx, None, 1e-7, pr_host, mode)  # warm-up
+        th = time.perf_counter()
+        n_h = 3
+        for _ in range(n_h):
+            plan.set_model(gates, rhos, effects)
+            plan.fill_dprobs(J_host, pidx, None, 1e-7, pr_host, mode)
+        t_host = (time.perf_counter() - th) / n_h
+        host_fill = {"ms": 1e3 * t_host, "elements_per_s": nE_local * nP / t_host, "GBps": 8.0 * nE_local * nP / t_host / 1e9,
+                     "pinned": bool(getattr(layout, "last_array_pinned", False)),
+                     "note": "gst_fill_dprobs into a host numpy 'ep' array from layout.allocate_local_array (what "
+                             "bulk_fill_dprobs(array, layout) returns in the reference): kernel + 7 GB over PCIe; never `value`"}
+        layout.free_local_array(J_host)
 
     def measured_traffic(kernel_prefix):
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
-        (profiles/r01_hbm_counters.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; KB -> bytes, and
+        (profiles/r0x_hbm_counters.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; KB -> bytes, and
         FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md).  None when no profile matches."""
         if world != 1 or lay_world != 1 or args.design != "full" or args.max_len != 1024:
             return None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_counters.json")) as f:
-                prof = json.load(f)[args.deriv]
-            for k, v in prof.items():
-                if kernel_prefix in k:
-                    return (2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0
-        except Exception:
-            pass
+        for name in ("r02_hbm_counters.json", "r01_hbm_counters.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    prof = json.load(f)[args.deriv]
+                for k, v in prof.items():
+                    if kernel_prefix in k:
+                        return (2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0
+            except Exception:
+                pass
         return None
 
     st = plan.stats()
@@ -340,9 +427,10 @@ def main():
                                       if args.deriv == "fd" else "analytic (reference MatrixForwardSimulator semantics)"),
                        "parallelism": "atoms%d" % world if lay_world == world else
                                       "rank 0 of atoms%d emulated on one GPU" % lay_world},
-            "gather_probs_ms": gather_ms,
+            "exchange": exchange,
             "normal_equations": jtj_info,
             "analytic_dprobs": ana_info,
+            "host_fill": host_fill,
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,
             "roofline": roof or {"bound": "mfma", "compute_unit": "valu_f64",
@@ -350,7 +438,7 @@ def main():
                          "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
                          "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (k_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
-                         "note": "flops = the reference schedule's nP*(2*D^2*A + 2*D*nE); the kernel executes ~0.56 of them (the rest is provably bit-identical to the base pass) as separate v_mul_f64+v_add_f64 (no FMA: bitwise parity), whose own ceiling is 0.5 of the FMA peak; VALU issue utilisation 93% (profiles/r01_bench_pmc_sq_current.json)",
+                         "note": "flops = the reference schedule's nP*(2*D^2*A + 2*D*nE); the kernel executes ~0.56 of them (the rest is provably bit-identical to the base pass) as separate v_mul_f64+v_add_f64 (no FMA: bitwise parity), whose own ceiling is 0.5 of the FMA peak",
                          "kernel_ms": k_ms, "flops_per_launch": flops,
                          "hbm_write_GBps": jac_bytes / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
                          "traffic": measured_traffic("walk_kernel<16, 1")},
@@ -358,11 +446,14 @@ def main():
                                         "n_tasks", "prog_words", "max_slots")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pack, model, args.max_len)
+            out["cpu_baseline"], out["cpu_baseline_allcores"] = cpu_baseline(pack, model, args.max_len, args.design)
         print(json.dumps(out))
     plan.device_free(d_out)
-    plan.device_free(d_probs)
-    if dist is not None:
+    plan.device_free(d_pfull)
+    if world > 1:
+        ctx.barrier()
+        ctx.close()
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -208,10 +208,15 @@ int gst_sync(gst_plan *plan);
  * pygsti/layouts/distlayout.py:1220-1359, copalayout.py:549-598, consumed by optimize/simplerlm.py:677-678).
  * d_J is a device-resident row-major [n_rows][ld] Jacobian block (n_cols <= ld columns used), e.g. what
  * gst_fill_dprobs_dev left in HBM -- so the 7 GB Jacobian never crosses PCIe, only n_cols^2 + n_cols numbers do.
- *   d_row_scale (may be NULL): per-row factor w_k applied on the fly, J_s = diag(w) J  (the objective's dlsvec scaling)
+ *   d_row_scale (may be NULL): per-row factor w_k, J_s = diag(w) J (the objective's dlsvec scaling).  The rows of d_J are
+ *       multiplied IN PLACE by one streaming pass before the product (the reference scales its Jacobian in place, too:
+ *       objectivefns.py:4633-4665), so d_J holds J_s afterwards: call gst_fill_jtj_dev with the scale ONCE per Jacobian,
+ *       then gst_fill_jtf_dev (which has no scale argument and contracts whatever d_J holds); a second scaled call
+ *       would scale the rows twice.  Pass NULL to contract d_J as it is.
  *   gst_fill_jtj_dev: d_jtj[n_cols][n_cols] = J_s^T J_s   (full symmetric matrix; split-K MFMA fp64 kernel)
- *   gst_fill_jtf_dev: d_jtf[n_cols] = J_s^T f,  f = d_f[n_rows]
- * With several ranks each computes the partial sums of its own rows; the caller all-reduces (RCCL) n_cols^2 doubles. */
+ *   gst_fill_jtf_dev: d_jtf[n_cols] = d_J^T f,  f = d_f[n_rows]   (= J_s^T f after a scaled gst_fill_jtj_dev)
+ * With several ranks each computes the partial sums of its own rows; gst_comm_allreduce_sum (RCCL) adds the
+ * n_cols^2 doubles on the device. */
 int gst_fill_jtj_dev(gst_plan *plan, double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
                      const double *d_row_scale, double *d_jtj);
 int gst_fill_jtf_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
@@ -259,11 +264,70 @@ int gst_objective_hessian_block(gst_plan *plan, const gst_objective_desc *desc, 
                                 const double *d_totals, const int64_t *idx1, int64_t n1, const int64_t *idx2,
                                 int64_t n2, double eps, double *out);
 
+/* ---- Multi-GPU exchange: one process per GPU, row blocks and normal equations travel between DEVICE buffers -------------
+ * The path shards by layout atoms (disjoint circuit groups with contiguous element slices, pygsti/layouts/
+ * distlayout.py:326-332, 404-415): every rank fills the rows of its own atoms and no collective is needed inside a fill.
+ * What the reference then does with MPI on host arrays -- Gatherv / Allgatherv of row blocks
+ * (pygsti/baseobjs/resourceallocation.py:316-348 `gather_base`, used by layout.gather_local_array / allgather_local_array,
+ * layouts/distlayout.py:1010-1156, copalayout.py:479-518) and Allreduce(SUM) of J^T J / J^T f
+ * (resourceallocation.py:441-508 `allreduce_sum`, used by fill_jtj / fill_jtf, distlayout.py:1220-1359) -- these entry
+ * points do from device pointers, over xGMI:
+ *   GST_TRANSPORT_RCCL: RCCL (librccl, bound at run time with dlopen: single-GPU users never load it).  Row blocks move
+ *       as ONE grouped ncclSend/ncclRecv exchange -- every pair of GPUs has its own xGMI link, so a fan-in / all-to-all of
+ *       point-to-point transfers uses all links at once where a ring is bound by one; sums use ncclAllReduce.
+ *       Stream-ordered: operations are enqueued behind the fills on the plan's stream (gst_sync / gst_comm_sync wait).
+ *   GST_TRANSPORT_IPC: intra-node peer writes -- every rank maps the destination buffers of the others through HIP IPC
+ *       handles published in a POSIX shared-memory mailbox and copies its blocks straight into them (SDMA engines, no
+ *       compute units); sums gather every rank's copy and add them in rank order (bit-reproducible).  Works when ranks
+ *       share a GPU (which RCCL refuses), and is the fallback when RCCL cannot initialise.  Blocking: returns when the
+ *       data has landed on every receiver.
+ * Rendezvous: rank 0 calls gst_comm_get_unique_id, the caller distributes the GST_COMM_ID_BYTES bytes by any means
+ * (MPI, a torch.distributed store, a file), every rank calls gst_comm_create (collective).  `plan` (may be NULL) selects
+ * the stream: the plan's stream when given (must live on the comm's device), else the comm's own stream. */
+typedef struct gst_comm gst_comm;
+#define GST_COMM_ID_BYTES 128
+#define GST_TRANSPORT_RCCL 0
+#define GST_TRANSPORT_IPC 1
+int gst_comm_get_unique_id(int transport, void *id_out);
+int gst_comm_create(int transport, int device, int rank, int size, const void *id, gst_comm **out);
+int gst_comm_destroy(gst_comm *comm);
+
+/* Row blocks of a row-major [n_rows][row_doubles] f64 array: block b = rows [blk_row0[b], blk_row0[b] + blk_rows[b]) of the
+ * ASSEMBLED array, owned (filled) by rank blk_owner[b] (a rank may own several: atoms r, r + size, ...).  Every rank passes
+ * the same block list.
+ *   gst_comm_allgather_rows: d_full is the full-size array on EVERY rank with the rank's own blocks already in place
+ *       (the _dev fills write there directly); on return (stream order) every rank holds all blocks.
+ *   gst_comm_gather_rows: only `root` holds the full-size array (d_full, own blocks in place); the other ranks pass
+ *       d_local = their own blocks packed one after another in block order (d_full is ignored there).  Gatherv. */
+int gst_comm_allgather_rows(gst_comm *comm, gst_plan *plan, double *d_full, int64_t row_doubles, int32_t n_blocks,
+                            const int32_t *blk_owner, const int64_t *blk_row0, const int64_t *blk_rows);
+int gst_comm_gather_rows(gst_comm *comm, gst_plan *plan, const double *d_local, double *d_full, int64_t row_doubles,
+                         int32_t n_blocks, const int32_t *blk_owner, const int64_t *blk_row0, const int64_t *blk_rows,
+                         int32_t root);
+/* d_buf[0..n) <- sum over ranks of their d_buf, on every rank (in place). */
+int gst_comm_allreduce_sum(gst_comm *comm, gst_plan *plan, double *d_buf, int64_t n);
+int gst_comm_barrier(gst_comm *comm);                 /* all ranks have reached this call; outstanding exchanges done */
+int gst_comm_sync(gst_comm *comm);                    /* the comm's own stream (plan == NULL operations) */
+typedef struct {
+    int32_t transport, rank, size, device;
+    int32_t rccl_version;        /* ncclGetVersion code of the library bound at run time (0 for the IPC transport) */
+    int32_t reserved[3];
+} gst_comm_info;
+int gst_comm_get_info(const gst_comm *comm, gst_comm_info *out);
+
 /* Plain device-buffer helpers on the plan's device, so that callers without any GPU framework can
  * keep results resident (bench.py, tests).  Buffers from any other allocator work equally. */
 int gst_device_malloc(gst_plan *plan, int64_t nbytes, void **d_ptr);
 int gst_device_free(gst_plan *plan, void *d_ptr);
 int gst_memcpy_d2h(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
+
+/* Page-lock a caller-owned host array (hipHostRegister, portable across devices) so that the host-output fills
+ * (gst_fill_probs / gst_fill_dprobs / gst_fill_hprobs*) copy into it at full PCIe rate instead of through the runtime's
+ * pageable staging -- the counterpart of the reference allocating its 'ep' arrays once per objective
+ * (layout.allocate_local_array, pygsti/layouts/copalayout.py:284-361) and reusing them every iteration.  Unregister before
+ * the memory is freed.  Both fail with GST_ENODEVICE when no device exists (the array then simply stays pageable). */
+int gst_host_register(void *ptr, int64_t nbytes);
+int gst_host_unregister(void *ptr);
 
 /* Introspection (tests, bench, DESIGN.md numbers). */
 int gst_get_stats(const gst_plan *plan, gst_stats *out);

@@ -17,6 +17,8 @@ GST_EINVAL, GST_ENODEVICE, GST_EHIP, GST_ENOMEM, GST_ESTATE, GST_EUNSUPPORTED = 
 KIND_NONE, KIND_GATE, KIND_RHO, KIND_EFFECT = -1, 0, 1, 2
 DERIV_FD, DERIV_ANALYTIC = 0, 1
 OBJ_CHI2, OBJ_POISSON_DLOGL = 0, 1
+TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1
+COMM_ID_BYTES = 128
 
 OP_END, OP_RHO, OP_APPLY, OP_SAVE, OP_LOAD, OP_EMIT, OP_NODE = 0, 1, 2, 3, 4, 5, 6
 
@@ -54,6 +56,11 @@ class ObjectiveDesc(C.Structure):
                 ("prob_clip_lo", C.c_double), ("prob_clip_hi", C.c_double)]
 
 
+class CommInfo(C.Structure):
+    _fields_ = [("transport", C.c_int32), ("rank", C.c_int32), ("size", C.c_int32), ("device", C.c_int32),
+                ("rccl_version", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
 class Stats(C.Structure):
     _fields_ = [("n_circuits", C.c_int64), ("n_elements", C.c_int64), ("sum_depth", C.c_int64),
                 ("trie_nodes", C.c_int64), ("applies_per_pass", C.c_int64), ("n_tasks", C.c_int64),
@@ -65,7 +72,9 @@ class Stats(C.Structure):
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
            "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
-           "gst_last_error", "gst_version"]
+           "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
+           "gst_comm_get_unique_id", "gst_comm_create", "gst_comm_destroy", "gst_comm_allgather_rows",
+           "gst_comm_gather_rows", "gst_comm_allreduce_sum", "gst_comm_barrier", "gst_comm_sync", "gst_comm_get_info"]
 
 _lib = None
 
@@ -108,6 +117,17 @@ def lib():
         L.gst_get_program.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64]
         L.gst_get_state_graph.argtypes = [vp, vp, vp, i64, vp, i64, C.POINTER(i64)]
         L.gst_device_count.argtypes = [C.POINTER(i32)]
+        L.gst_host_register.argtypes = [vp, i64]
+        L.gst_host_unregister.argtypes = [vp]
+        L.gst_comm_get_unique_id.argtypes = [C.c_int, vp]
+        L.gst_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+        L.gst_comm_destroy.argtypes = [vp]
+        L.gst_comm_allgather_rows.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
+        L.gst_comm_gather_rows.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, i32]
+        L.gst_comm_allreduce_sum.argtypes = [vp, vp, vp, i64]
+        L.gst_comm_barrier.argtypes = [vp]
+        L.gst_comm_sync.argtypes = [vp]
+        L.gst_comm_get_info.argtypes = [vp, C.POINTER(CommInfo)]
         _lib = L
     return _lib
 
@@ -133,6 +153,38 @@ def device_count():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def pin_host_array(arr):
+    """Page-lock a C-contiguous numpy array for full-rate PCIe copies (gst_host_register); the lock is released when
+    the array is garbage-collected or through `unpin_host_array`.  Returns True when pinned, False when no device
+    exists (the array then stays pageable -- fills still work where a device is)."""
+    import weakref
+    if not arr.flags.c_contiguous or arr.nbytes == 0:
+        return False
+    addr = arr.ctypes.data
+    try:
+        check(lib().gst_host_register(C.c_void_p(addr), arr.nbytes))
+    except (GstDeviceError, GstError):
+        return False
+    _pinned[addr] = weakref.finalize(arr, _unregister, addr)
+    return True
+
+
+def unpin_host_array(arr):
+    fin = _pinned.pop(arr.ctypes.data, None)
+    if fin is not None:
+        fin()
+
+
+def _unregister(addr):
+    try:
+        lib().gst_host_unregister(C.c_void_p(addr))
+    except Exception:
+        pass
+
+
+_pinned = {}
 
 
 def _i32(x):
@@ -404,3 +456,66 @@ class Plan:
         off = np.empty(nt + 1, np.int64)
         check(lib().gst_get_program(self._h, _ptr(words), n.value, C.byref(n), _ptr(off), nt + 1))
         return words[:n.value], off
+
+
+class Comm:
+    """The device-side exchange between one-process-per-GPU ranks (gst_comm_* of include/gstfwd.h): RCCL over xGMI
+    (`TRANSPORT_RCCL`), or intra-node peer writes through HIP IPC (`TRANSPORT_IPC`, also for ranks sharing a GPU).
+    Row blocks are (owner rank, first row, number of rows) triples of the assembled row-major array."""
+
+    @staticmethod
+    def unique_id(transport=TRANSPORT_RCCL):
+        """Rank 0: the rendezvous token (bytes) every rank must pass to `Comm(...)`."""
+        buf = (C.c_char * COMM_ID_BYTES)()
+        check(lib().gst_comm_get_unique_id(int(transport), buf))
+        return bytes(buf)
+
+    def __init__(self, rank, size, uid, device=-1, transport=TRANSPORT_RCCL):
+        assert len(uid) == COMM_ID_BYTES
+        self._h = C.c_void_p()
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(uid)
+        check(lib().gst_comm_create(int(transport), int(device), int(rank), int(size), buf, C.byref(self._h)))
+        self.rank, self.size, self.transport = int(rank), int(size), int(transport)
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().gst_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _blocks(blocks):
+        owner = _i32([b[0] for b in blocks]); row0 = _i64([b[1] for b in blocks]); rows = _i64([b[2] for b in blocks])
+        return owner, row0, rows
+
+    def allgather_rows(self, d_full, row_doubles, blocks, plan=None):
+        owner, row0, rows = self._blocks(blocks)
+        check(lib().gst_comm_allgather_rows(self._h, None if plan is None else plan._h, C.c_void_p(int(d_full)),
+                                            int(row_doubles), len(owner), _ptr(owner), _ptr(row0), _ptr(rows)))
+
+    def gather_rows(self, d_local, d_full, row_doubles, blocks, root=0, plan=None):
+        owner, row0, rows = self._blocks(blocks)
+        check(lib().gst_comm_gather_rows(self._h, None if plan is None else plan._h,
+                                         None if d_local is None else C.c_void_p(int(d_local)),
+                                         None if d_full is None else C.c_void_p(int(d_full)), int(row_doubles),
+                                         len(owner), _ptr(owner), _ptr(row0), _ptr(rows), int(root)))
+
+    def allreduce_sum(self, d_buf, n, plan=None):
+        check(lib().gst_comm_allreduce_sum(self._h, None if plan is None else plan._h, C.c_void_p(int(d_buf)), int(n)))
+
+    def barrier(self):
+        check(lib().gst_comm_barrier(self._h))
+
+    def sync(self):
+        check(lib().gst_comm_sync(self._h))
+
+    def info(self):
+        i = CommInfo()
+        check(lib().gst_comm_get_info(self._h, C.byref(i)))
+        return {"transport": "rccl" if i.transport == TRANSPORT_RCCL else "ipc", "rank": i.rank, "size": i.size,
+                "device": i.device, "rccl_version": i.rccl_version}

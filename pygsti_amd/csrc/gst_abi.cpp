@@ -13,10 +13,12 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../../include/gstfwd.h"
+#include "gst_internal.hpp"
 #include "gst_kernels.hpp"
 #include "gst_plan.hpp"
 
@@ -39,6 +41,23 @@ int fail(int code, const std::string& msg)
             return fail(code_, std::string(#expr) + ": " + hipGetErrorString(e_));              \
         }                                                                                       \
     } while (0)
+
+// No exception may cross the C ABI (it would reach std::terminate): every extern "C" entry runs inside this guard.
+template <typename F>
+int guarded(F&& body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(GST_ENOMEM, "out of host memory");
+    } catch (const std::length_error& e) {
+        return fail(GST_EINVAL, std::string("invalid size: ") + e.what());
+    } catch (const std::exception& e) {
+        return fail(GST_EINVAL, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(GST_EINVAL, "internal error (unknown exception)");
+    }
+}
 
 template <typename T>
 struct DevBuf {
@@ -408,6 +427,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     const bool rows = (p->hp.D == 64);
     if (!p->request_cached(1, param_idx, dest_idx, n_param)) {
         // (an optimizer asks for the same columns every iteration: pack and upload the lane tables once)
+        p->cached_kind = 0;            // nothing below may leave a half-updated request looking cached when it fails
         LaneLayout L;
         // a declared complement effect: effect-parameter columns leave the walk (effect_fd_kernel below does them on
         // the cached final states, where the recomputed complement can be substituted)
@@ -836,7 +856,13 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (D == 64 && !caches_small) return fail(GST_EUNSUPPORTED, "forward-state cache exceeds 4 GB");
     // the two-cache contraction: MFMA at D = 16 / 64; at D = 4 (VALU) only when a Hessian needs its tables -- a plain 1Q
     // Jacobian is launch-bound and the single backward-walking kernel below is one launch instead of three
-    if (p->ana_mfma && caches_small && (D != 4 || p->want_cache_path)) {
+    // D <= 16: the backward pass needs the chain kernel, whose tables (all gates, effects, emit ring) live in LDS; a gate
+    // set too large for it takes the single-kernel path below (Jacobians) or is refused (Hessians need the caches)
+    const bool chain_ok = D == 64 || gst::chain_kernel_fits(D, h.n_gates, h.n_effects, 4);
+    if (!chain_ok && p->want_cache_path)
+        return fail(GST_EUNSUPPORTED, "exact Hessians at D <= 16 need the gate set in LDS (at most " +
+                                          std::to_string(128 * 1024 / (D * D * 8)) + " gates at this D)");
+    if (p->ana_mfma && caches_small && chain_ok && (D != 4 || p->want_cache_path)) {
         if ((rc = ensure_reverse(p))) return rc;
         if ((double)p->rev.n_state_ids * h.n_effects * D * 8 >= 4.0e9)
             return fail(GST_EUNSUPPORTED, "backward-state cache exceeds 4 GB: set GST_ANALYTIC_MFMA=0 for this plan");
@@ -882,6 +908,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         p->last_ana = a; p->last_ana_valid = true;     // (the Hessian rows re-launch the contraction with other caches)
         return GST_OK;
     }
+    if (D == 64) return fail(GST_EUNSUPPORTED, "D = 64 analytic derivatives exist on the MFMA path only");
     HIP_TRY(hipEventRecord(p->evk0, p->stream));
     HIP_TRY(gst::launch_analytic(D, a, p->stream));
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
@@ -917,6 +944,13 @@ int end_call(gst_plan* p, bool sync)
 
 }  // namespace
 
+namespace gst {
+int set_error(int code, const std::string& msg) { return fail(code, msg); }
+int plan_ensure_device(gst_plan* plan) { return plan ? ensure_device(plan) : fail(GST_EINVAL, "plan is NULL"); }
+hipStream_t plan_stream(const gst_plan* plan) { return plan->stream; }
+int plan_device(const gst_plan* plan) { return plan->device; }
+}  // namespace gst
+
 extern "C" {
 
 const char* gst_last_error(void) { return g_err.c_str(); }
@@ -924,15 +958,18 @@ const char* gst_version(void) { return "gstfwd 0.1 (gfx950)"; }
 
 int gst_device_count(int32_t* n)
 {
+    return guarded([&]() -> int {
     if (!n) return fail(GST_EINVAL, "n is NULL");
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
     *n = (e == hipSuccess) ? c : 0;
     return GST_OK;
+    });
 }
 
 int gst_plan_create_from_table(const gst_table_desc* d, const gst_options* opt, gst_plan** out)
 {
+    return guarded([&]() -> int {
     if (!d || !out) return fail(GST_EINVAL, "NULL argument");
     *out = nullptr;
     gst_plan* p = new (std::nothrow) gst_plan();
@@ -941,13 +978,15 @@ int gst_plan_create_from_table(const gst_table_desc* d, const gst_options* opt, 
         gst::HostPlan& h = p->hp;
         h.D = d->D; h.n_gates = d->n_gates; h.n_rhos = d->n_rhos; h.n_effects = d->n_effects;
         h.n_elements = d->n_elements;
+        if (d->n_elements < 0 || d->n_elements > 0x7fffffffLL) { delete p; return fail(GST_EINVAL, "n_elements out of range"); }
         if (d->n_rows < 0 || !d->t_dest || !d->t_start || !d->t_cache || !d->t_rho || !d->row_ptr || !d->eff_ptr) {
             delete p; return fail(GST_EINVAL, "table arrays missing");
         }
         std::string err = gst::expand_table(h, d->n_rows, d->cache_size, d->t_dest, d->t_start, d->t_cache,
                                             d->t_rho, d->row_ptr, d->gate_idx);
         if (!err.empty()) { delete p; return fail(GST_EINVAL, err); }
-        if (d->eff_ptr[d->n_rows] > 0x7fffffffLL) { delete p; return fail(GST_EINVAL, "too many elements"); }
+        if (d->eff_ptr[d->n_rows] > 0x7fffffffLL || d->eff_ptr[d->n_rows] < 0) { delete p; return fail(GST_EINVAL, "bad eff_ptr"); }
+        if (d->eff_ptr[d->n_rows] > 0 && (!d->eff_label || !d->eff_dest)) { delete p; return fail(GST_EINVAL, "effect arrays missing"); }
         h.eff_ptr.resize(d->n_rows + 1);
         for (int32_t i = 0; i <= d->n_rows; i++) h.eff_ptr[i] = (int32_t)d->eff_ptr[i];
         h.eff_label.assign(d->eff_label, d->eff_label + d->eff_ptr[d->n_rows]);
@@ -956,10 +995,12 @@ int gst_plan_create_from_table(const gst_table_desc* d, const gst_options* opt, 
     } catch (const std::bad_alloc&) {
         delete p; return fail(GST_ENOMEM, "out of host memory while compiling the plan");
     }
+    });
 }
 
 int gst_plan_create_from_circuits(const gst_circuits_desc* d, const gst_options* opt, gst_plan** out)
 {
+    return guarded([&]() -> int {
     if (!d || !out) return fail(GST_EINVAL, "NULL argument");
     *out = nullptr;
     gst_plan* p = new (std::nothrow) gst_plan();
@@ -968,6 +1009,7 @@ int gst_plan_create_from_circuits(const gst_circuits_desc* d, const gst_options*
         gst::HostPlan& h = p->hp;
         h.D = d->D; h.n_gates = d->n_gates; h.n_rhos = d->n_rhos; h.n_effects = d->n_effects;
         h.n_elements = d->n_elements; h.n_circuits = d->n_circuits;
+        if (d->n_elements < 0 || d->n_elements > 0x7fffffffLL) { delete p; return fail(GST_EINVAL, "n_elements out of range"); }
         if (d->n_circuits < 0 || !d->circ_rho || !d->circ_ptr || !d->eff_ptr) { delete p; return fail(GST_EINVAL, "circuit arrays missing"); }
         const int64_t nC = d->n_circuits;
         h.circ_rho.assign(d->circ_rho, d->circ_rho + nC);
@@ -975,6 +1017,7 @@ int gst_plan_create_from_circuits(const gst_circuits_desc* d, const gst_options*
         if (h.circ_ptr[nC] < 0) { delete p; return fail(GST_EINVAL, "bad circ_ptr"); }
         if (h.circ_ptr[nC] > 0) h.circ_gates.assign(d->circ_gates, d->circ_gates + h.circ_ptr[nC]);
         if (d->eff_ptr[nC] > 0x7fffffffLL || d->eff_ptr[nC] < 0) { delete p; return fail(GST_EINVAL, "bad eff_ptr"); }
+        if (d->eff_ptr[nC] > 0 && (!d->eff_label || !d->eff_dest)) { delete p; return fail(GST_EINVAL, "effect arrays missing"); }
         h.eff_ptr.resize(nC + 1);
         for (int64_t i = 0; i <= nC; i++) h.eff_ptr[i] = (int32_t)d->eff_ptr[i];
         h.eff_label.assign(d->eff_label, d->eff_label + d->eff_ptr[nC]);
@@ -983,16 +1026,20 @@ int gst_plan_create_from_circuits(const gst_circuits_desc* d, const gst_options*
     } catch (const std::bad_alloc&) {
         delete p; return fail(GST_ENOMEM, "out of host memory while compiling the plan");
     }
+    });
 }
 
 int gst_plan_destroy(gst_plan* plan)
 {
+    return guarded([&]() -> int {
     delete plan;
     return GST_OK;
+    });
 }
 
 int gst_set_model(gst_plan* p, const double* gates, const double* rhos, const double* effects)
 {
+    return guarded([&]() -> int {
     if (!p || !rhos || !effects || (p->hp.n_gates > 0 && !gates)) return fail(GST_EINVAL, "NULL argument");
     const int D = p->hp.D;
     const size_t ng = (size_t)p->hp.n_gates * D * D;
@@ -1007,10 +1054,12 @@ int gst_set_model(gst_plan* p, const double* gates, const double* rhos, const do
     p->have_model = true;
     p->model_dirty = true;
     return GST_OK;
+    });
 }
 
 int gst_set_param_map(gst_plan* p, int32_t n_params, const int32_t* kind, const int32_t* obj, const int32_t* elem)
 {
+    return guarded([&]() -> int {
     if (!p || n_params < 0 || (n_params > 0 && (!kind || !obj || !elem))) return fail(GST_EINVAL, "bad argument");
     const int D = p->hp.D;
     for (int32_t i = 0; i < n_params; i++) {
@@ -1027,10 +1076,12 @@ int gst_set_param_map(gst_plan* p, int32_t n_params, const int32_t* kind, const 
     p->have_pmap = true;
     p->cached_kind = 0;      // device lane tables / column maps describe the old map
     return GST_OK;
+    });
 }
 
 int gst_set_complement_effect(gst_plan* p, int32_t comp_index, const double* identity, int32_t n_others, const int32_t* others)
 {
+    return guarded([&]() -> int {
     if (!p) return fail(GST_EINVAL, "plan is NULL");
     p->cached_kind = 0;
     if (comp_index < 0) { p->comp_index = -1; p->comp_others.clear(); p->comp_identity.clear(); return GST_OK; }
@@ -1046,11 +1097,13 @@ int gst_set_complement_effect(gst_plan* p, int32_t comp_index, const double* ide
     p->comp_others.assign(others, others + n_others);
     p->comp_identity.assign(identity, identity + p->hp.D);
     return GST_OK;
+    });
 }
 
 int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t* kind, const int32_t* obj,
                    const int32_t* n_cols, const int64_t* param_idx, const double* deriv)
 {
+    return guarded([&]() -> int {
     if (!p || n_params < 0 || n_objs < 0) return fail(GST_EINVAL, "bad argument");
     p->cached_kind = 0;
     if (n_objs == 0) { p->derivs_set = false; p->dv2_set = false; p->dv2_off.clear(); return GST_OK; }
@@ -1081,10 +1134,12 @@ int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t*
     }
     p->derivs_set = true;
     return GST_OK;
+    });
 }
 
 int gst_set_second_derivs(gst_plan* p, int32_t n_objs, const int32_t* nonzero, const double* hess)
 {
+    return guarded([&]() -> int {
     if (!p || n_objs < 0) return fail(GST_EINVAL, "bad argument");
     if (n_objs == 0) { p->dv2_set = false; p->dv2_off.clear(); return GST_OK; }
     if (!p->derivs_set || (size_t)n_objs != p->dv_kind.size()) return fail(GST_ESTATE, "gst_set_second_derivs follows gst_set_derivs, object for object");
@@ -1109,6 +1164,7 @@ int gst_set_second_derivs(gst_plan* p, int32_t n_objs, const int32_t* nonzero, c
     p->dv2_off = off;
     p->dv2_set = total > 0;
     return GST_OK;
+    });
 }
 
 // The element Jacobian [nE][n_el] ([rhos | effects | gates] of the `full` layout) of the current model into d_jelem,
@@ -1184,6 +1240,7 @@ int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* pa
 
 int gst_fill_probs_dev(gst_plan* p, double* d_out)
 {
+    return guarded([&]() -> int {
     int rc = begin_call(p);
     if (rc) return rc;
     if (!d_out) return fail(GST_EINVAL, "d_out is NULL");
@@ -1191,10 +1248,12 @@ int gst_fill_probs_dev(gst_plan* p, double* d_out)
     if ((rc = run_probs(p, d_out, false))) return rc;
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     return end_call(p, false);
+    });
 }
 
 int gst_fill_probs(gst_plan* p, double* out)
 {
+    return guarded([&]() -> int {
     int rc = begin_call(p);
     if (rc) return rc;
     if (!out) return fail(GST_EINVAL, "out is NULL");
@@ -1203,11 +1262,13 @@ int gst_fill_probs(gst_plan* p, double* out)
     HIP_TRY(hipEventRecord(p->evk1, p->stream));
     HIP_TRY(hipMemcpyAsync(out, p->d_pbase.p, p->hp.n_elements * 8, hipMemcpyDeviceToHost, p->stream));
     return end_call(p, true);
+    });
 }
 
 int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
                         int64_t n_param, int mode, double eps, double* d_probs_out)
 {
+    return guarded([&]() -> int {
     int rc = begin_call(p);
     if (rc) return rc;
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
@@ -1224,11 +1285,13 @@ int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     else rc = run_dprobs_fd(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out, nullptr, 0);
     if (rc) return rc;
     return end_call(p, false);
+    });
 }
 
 int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
                     int64_t n_param, int mode, double eps, double* probs_out)
 {
+    return guarded([&]() -> int {
     int rc = begin_call(p);
     if (rc) return rc;
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
@@ -1266,6 +1329,7 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
         for (int64_t k = 0; k < nE; k++)
             for (int64_t c = 0; c < n_param; c++) out[k * ld + dest_idx[c]] = stage[(size_t)k * n_param + c];
     return GST_OK;
+    });
 }
 
 // FD-of-FD Hessian block into the device buffer d_H [nE][ld1][ld2] (mapforwardsim.py:394-438).  Leaves behind, on the
@@ -1391,7 +1455,9 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
     if (!p->last_ana_valid) return fail(GST_EUNSUPPORTED, "analytic Hessians need the MFMA path (state caches below 4 GB)");
     const gst::AnaArgs base = p->last_ana;
     const std::vector<int64_t> none_cols = p->cached_none_cols;
-    if ((double)p->rev.n_state_ids * 4 * D * nEf * 8 >= 4.0e9) return fail(GST_EUNSUPPORTED, "derivative-state cache exceeds 4 GB");
+    // (the contraction kernels address both derivative-state caches with 32-bit byte offsets)
+    if ((double)p->rev.n_state_ids * 4 * D * nEf * 8 >= 4.0e9 || (double)h.n_state_ids * 4 * D * 8 >= 4.0e9)
+        return fail(GST_EUNSUPPORTED, "derivative-state cache exceeds 4 GB: split the circuits over more atoms");
     HIP_TRY(p->d_dF.ensure((size_t)h.n_state_ids * 4 * D));
     HIP_TRY(p->d_dB.ensure((size_t)p->rev.n_state_ids * 4 * D * nEf));
     HIP_TRY(p->d_theta.ensure(5 * 4 * (size_t)(1 + nEf)));
@@ -1605,6 +1671,7 @@ static int run_hprobs_general(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2
 int gst_fill_hprobs_analytic(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
                              int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2)
 {
+    return guarded([&]() -> int {
     int rc = begin_call(p);
     if (rc) return rc;
     if (!p->derivs_set && !p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
@@ -1621,11 +1688,13 @@ int gst_fill_hprobs_analytic(gst_plan* p, double* out, int64_t ld1, int64_t ld2,
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));
     return end_call(p, true);
+    });
 }
 
 int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
                     int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2, double eps)
 {
+    return guarded([&]() -> int {
     int rc = begin_call(p);
     if (rc) return rc;
     if (p->derivs_set) return fail(GST_EUNSUPPORTED, "Hessians need the one-parameter-per-element map (gst_set_derivs is set)");
@@ -1642,11 +1711,13 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     if ((rc = run_hprobs_dev(p, p->d_out.p, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2, eps))) return rc;
     HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));
     return end_call(p, true);
+    });
 }
 
 int gst_objective_hessian_block(gst_plan* p, const gst_objective_desc* d, const double* d_counts, const double* d_totals,
                                 const int64_t* idx1, int64_t n1, const int64_t* idx2, int64_t n2, double eps, double* out)
 {
+    return guarded([&]() -> int {
     int rc = begin_call(p);
     if (rc) return rc;
     if (!d || !d_counts || !d_totals) return fail(GST_EINVAL, "bad argument");
@@ -1705,11 +1776,13 @@ int gst_objective_hessian_block(gst_plan* p, const gst_objective_desc* d, const 
     p->last_launches += 2;
     HIP_TRY(hipMemcpyAsync(out, p->d_hess_out.p, (size_t)n1 * n2 * 8, hipMemcpyDeviceToHost, p->stream));
     return end_call(p, true);
+    });
 }
 
 int gst_fill_jtj_dev(gst_plan* p, double* d_J, int64_t n_rows, int64_t n_cols, int64_t ld, const double* d_row_scale,
                      double* d_jtj)
 {
+    return guarded([&]() -> int {
     if (!p || !d_J || !d_jtj || n_rows < 0 || n_cols < 0 || ld < n_cols || n_cols > 0x7fffffff) return fail(GST_EINVAL, "bad argument");
     int rc = ensure_device(p);
     if (rc) return rc;
@@ -1724,11 +1797,13 @@ int gst_fill_jtj_dev(gst_plan* p, double* d_J, int64_t n_rows, int64_t n_cols, i
     }
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
     return GST_OK;
+    });
 }
 
 int gst_fill_jtf_dev(gst_plan* p, const double* d_J, int64_t n_rows, int64_t n_cols, int64_t ld, const double* d_f,
                      double* d_jtf)
 {
+    return guarded([&]() -> int {
     if (!p || !d_J || !d_f || !d_jtf || n_rows < 0 || n_cols < 0 || ld < n_cols || n_cols > 0x7fffffff) return fail(GST_EINVAL, "bad argument");
     int rc = ensure_device(p);
     if (rc) return rc;
@@ -1737,12 +1812,14 @@ int gst_fill_jtf_dev(gst_plan* p, const double* d_J, int64_t n_rows, int64_t n_c
     HIP_TRY(p->d_jtf_part.ensure((size_t)n_slabs * n_cols));
     HIP_TRY(gst::launch_jtf(d_J, d_f, n_rows, (int)n_cols, ld, p->d_jtf_part.p, n_slabs, d_jtf, p->stream));
     return GST_OK;
+    });
 }
 
 int gst_objective_rows_dev(gst_plan* p, const gst_objective_desc* d, double* d_probs, const double* d_counts,
                            const double* d_totals, int64_t n, double* d_lsvec, double* d_rowscale, double* d_terms,
                            double* sum_terms)
 {
+    return guarded([&]() -> int {
     if (!p || !d || !d_probs || !d_counts || !d_totals || !d_lsvec || !d_rowscale || n < 0) return fail(GST_EINVAL, "bad argument");
     if (d->kind != GST_OBJ_CHI2 && d->kind != GST_OBJ_POISSON_DLOGL) return fail(GST_EINVAL, "unknown objective kind");
     if (!(d->min_prob_clip > 0.0) || (d->kind == GST_OBJ_POISSON_DLOGL && !(d->radius > 0.0)))
@@ -1764,48 +1841,82 @@ int gst_objective_rows_dev(gst_plan* p, const gst_objective_desc* d, double* d_p
         *sum_terms = s;
     }
     return GST_OK;
+    });
 }
 
 int gst_memcpy_h2d(gst_plan* p, void* d_dst, const void* src, int64_t nbytes)
 {
+    return guarded([&]() -> int {
     if (!p || !d_dst || !src || nbytes < 0) return fail(GST_EINVAL, "bad argument");
     int rc = ensure_device(p);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_dst, src, (size_t)nbytes, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return GST_OK;
+    });
 }
 
 int gst_device_malloc(gst_plan* p, int64_t nbytes, void** d_ptr)
 {
+    return guarded([&]() -> int {
     if (!p || !d_ptr || nbytes < 0) return fail(GST_EINVAL, "bad argument");
     int rc = ensure_device(p);
     if (rc) return rc;
     HIP_TRY(hipMalloc(d_ptr, (size_t)std::max<int64_t>(nbytes, 1)));
     return GST_OK;
+    });
 }
 
 int gst_device_free(gst_plan* p, void* d_ptr)
 {
+    return guarded([&]() -> int {
     if (!p) return fail(GST_EINVAL, "plan is NULL");
     int rc = ensure_device(p);
     if (rc) return rc;
     HIP_TRY(hipFree(d_ptr));
     return GST_OK;
+    });
 }
 
 int gst_memcpy_d2h(gst_plan* p, void* dst, const void* d_src, int64_t nbytes)
 {
+    return guarded([&]() -> int {
     if (!p || !dst || !d_src || nbytes < 0) return fail(GST_EINVAL, "bad argument");
     int rc = ensure_device(p);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy(dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost));
     return GST_OK;
+    });
+}
+
+int gst_host_register(void* ptr, int64_t nbytes)
+{
+    return guarded([&]() -> int {
+        if (!ptr || nbytes <= 0) return fail(GST_EINVAL, "bad argument");
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) return fail(GST_ENODEVICE, std::string("no HIP device available (") + hipGetErrorString(e) + ")");
+        HIP_TRY(hipHostRegister(ptr, (size_t)nbytes, hipHostRegisterPortable));
+        return GST_OK;
+    });
+}
+
+int gst_host_unregister(void* ptr)
+{
+    return guarded([&]() -> int {
+        if (!ptr) return fail(GST_EINVAL, "bad argument");
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) return fail(GST_ENODEVICE, std::string("no HIP device available (") + hipGetErrorString(e) + ")");
+        HIP_TRY(hipHostUnregister(ptr));
+        return GST_OK;
+    });
 }
 
 int gst_sync(gst_plan* p)
 {
+    return guarded([&]() -> int {
     if (!p) return fail(GST_EINVAL, "plan is NULL");
     if (!p->dev_ready) return GST_OK;
     HIP_TRY(hipSetDevice(p->device));
@@ -1814,10 +1925,12 @@ int gst_sync(gst_plan* p)
     if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_total_ms = ms;
     if (hipEventElapsedTime(&ms, p->evk0, p->evk1) == hipSuccess) p->last_kernel_ms = ms;
     return GST_OK;
+    });
 }
 
 int gst_get_stats(const gst_plan* p, gst_stats* s)
 {
+    return guarded([&]() -> int {
     if (!p || !s) return fail(GST_EINVAL, "NULL argument");
     const gst::HostPlan& h = p->hp;
     s->n_circuits = h.n_circuits; s->n_elements = h.n_elements; s->sum_depth = h.sum_depth;
@@ -1825,11 +1938,13 @@ int gst_get_stats(const gst_plan* p, gst_stats* s)
     s->prog_words = (int64_t)h.prog.size(); s->max_slots = h.max_slots; s->max_depth = h.max_depth;
     s->last_kernel_ms = p->last_kernel_ms; s->last_total_ms = p->last_total_ms; s->last_launches = p->last_launches;
     return GST_OK;
+    });
 }
 
 int gst_get_state_graph(const gst_plan* p, int32_t* node_parent, int32_t* node_sym, int64_t cap_nodes,
                         int32_t* circ_leaf, int64_t cap_circuits, int64_t* n_nodes)
 {
+    return guarded([&]() -> int {
     if (!p || !n_nodes) return fail(GST_EINVAL, "NULL argument");
     const gst::HostPlan& h = p->hp;
     *n_nodes = h.n_state_ids;
@@ -1839,10 +1954,12 @@ int gst_get_state_graph(const gst_plan* p, int32_t* node_parent, int32_t* node_s
     }
     if (circ_leaf && cap_circuits >= h.n_circuits) std::memcpy(circ_leaf, h.circ_leaf.data(), sizeof(int32_t) * h.n_circuits);
     return GST_OK;
+    });
 }
 
 int gst_get_program(const gst_plan* p, uint32_t* words, int64_t cap, int64_t* n_words, int64_t* task_off, int64_t cap_tasks)
 {
+    return guarded([&]() -> int {
     if (!p || !n_words) return fail(GST_EINVAL, "NULL argument");
     const gst::HostPlan& h = p->hp;
     *n_words = (int64_t)h.prog.size();
@@ -1850,6 +1967,7 @@ int gst_get_program(const gst_plan* p, uint32_t* words, int64_t cap, int64_t* n_
     if (task_off && cap_tasks >= (int64_t)h.task_off.size())
         std::memcpy(task_off, h.task_off.data(), sizeof(int64_t) * h.task_off.size());
     return GST_OK;
+    });
 }
 
 }  // extern "C"

@@ -175,6 +175,9 @@ hipError_t launch_objective_rows(int kind, double* probs, const double* counts, 
 // D = 64 derivative passes run NWB = rows_group(D, n_slots) models per workgroup (walk_rows_shared_kernel); a block_order
 // for launch_walk_rows then indexes (task, group of NWB parameter wavefronts) pairs.  1 when not applicable.
 int rows_group(int D, int n_slots);
+// D <= 16: whether the chain kernel (walk_base_kernel: gates, effects, emit ring and program window in LDS) can run this
+// model -- it is the only kernel with multi-start (backward, one lane group per effect) walks
+bool chain_kernel_fits(int D, int n_gates, int n_effects, int n_slots);
 
 // Row-per-lane variant (gst_kernels_rows.hip): one model per wavefront; D = 4, 16 or 64; S = a.rows_S.
 // FD columns of effect parameters evaluated on the cached final states (TP POVMs: see effect_fd_kernel)

@@ -15,6 +15,7 @@
 //     tiles x slabs >> 256 CUs); per 4 rows a wavefront reads 4 + 4 patches and issues 16 MFMAs.
 //   * Only tiles on or above the diagonal are computed; partial tiles of every slab go to a scratch buffer and a
 //     second kernel sums the slabs in a fixed order (deterministic, no atomics) and mirrors the triangle.
+#include "gst_internal.hpp"
 #include "gst_kernels.hpp"
 
 #include <algorithm>
@@ -436,11 +437,9 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
     slab_rows = (slab_rows + JTJ_PANEL - 1) / JTJ_PANEL * JTJ_PANEL;        // the k loop advances one panel per iteration
     (void)hipGetLastError();
     const size_t lds_bytes = (size_t)2 * JTJ_PANEL * JTJ_LDS_STRIDE * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set && lds_bytes > 64 * 1024) {
+    if (lds_bytes > 64 * 1024) {          // per device (a process may drive several GPUs): set on every launch, it is cheap
         hipError_t ea = hipFuncSetAttribute((const void*)jtj_mfma_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (ea != hipSuccess) return ea;
-        attr_set = true;
     }
     hipLaunchKernelGGL(jtj_mfma_lds_kernel, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld,
                        slab_rows, n_tiles, part);
@@ -500,6 +499,25 @@ hipError_t launch_hessian_chain_rule(const double* H, int64_t nE, int m1, int m2
     (void)hipGetLastError();
     hipLaunchKernelGGL(hessian_chain_rule_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, nE, m1, m2, ptr1, row1, w1, dest1, n1,
                        ptr2, row2, w2, dest2, n2, out, ld1, ld2);
+    return hipGetLastError();
+}
+
+// Sum of per-rank copies in rank order (the deterministic all-reduce of the IPC transport, gst_comm.cpp).
+__global__ void sum_slots_kernel(const double* __restrict__ slots, int n_slots, int64_t stride, int64_t n, double* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double acc = slots[i];
+        for (int r = 1; r < n_slots; r++) acc += slots[(int64_t)r * stride + i];
+        out[i] = acc;
+    }
+}
+
+hipError_t launch_sum_slots(const double* slots, int n_slots, int64_t stride, int64_t n, double* out, hipStream_t s)
+{
+    if (n <= 0 || n_slots <= 0) return hipSuccess;
+    const int64_t blocks = std::min<int64_t>((n + 255) / 256, 4096);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(sum_slots_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slots, n_slots, stride, n, out);
     return hipGetLastError();
 }
 

@@ -789,6 +789,16 @@ int rows_group(int D, int n_slots)
 constexpr int BASE_PW = 1024;                // program window (words) in LDS
 constexpr int BASE_ER = 64;                  // emit ring: one lane per parked circuit at evaluation time
 
+// Does walk_base_kernel (the only D <= 16 kernel with multi-start walks) fit its tables into LDS for this model?
+bool chain_kernel_fits(int D, int n_gates, int n_effects, int n_slots)
+{
+    if (D > 16 || n_gates <= 0) return false;
+    const size_t gate_bytes = (size_t)n_gates * D * D * sizeof(double);
+    const size_t extra = ((size_t)n_effects * D + BASE_ER * (D + 1)) * sizeof(double) + (BASE_ER + BASE_PW) * sizeof(int32_t);
+    const size_t slot_bytes = (size_t)(n_slots > 0 ? n_slots : 1) * 64 * sizeof(double);
+    return gate_bytes <= 128 * 1024 && slot_bytes + extra + gate_bytes <= 156 * 1024;
+}
+
 // global -> LDS copy by one wavefront, 8 loads in flight per lane (a load-wait-store loop costs one L2 round trip per
 // 64 elements, which at 12 KB of gates + 4 KB of program is tens of microseconds of pure latency per task)
 template <typename T, typename F>
@@ -943,8 +953,13 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
     if (blocks > 0x7fffffffLL || n_slots > 64) return hipErrorInvalidValue;
     size_t lds_bytes = (size_t)(n_slots > 0 ? n_slots : 1) * D * sizeof(double);
     const size_t gate_bytes = (size_t)a.n_gates * D * D * sizeof(double);
-    const bool ldsg = (D <= 16) && gate_bytes > 0 && gate_bytes <= 48 * 1024;
+    // gates in LDS: up to 128 KB of the CU's 160 KB (64 gates at D = 16); above 64 KB the kernel needs its dynamic-LDS
+    // limit raised, per device and per kernel (cheap, so done on every such launch)
+    const bool ldsg = (D <= 16) && gate_bytes > 0 && gate_bytes <= 128 * 1024;
     (void)hipGetLastError();
+    auto raise_lds = [](const void* fn, size_t bytes) -> hipError_t {
+        return bytes > 64 * 1024 ? hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess;
+    };
     if constexpr (D == 64) {
         constexpr int NWB = ROWS_SHARED_NWB;
         const size_t sh_bytes = ((size_t)D * D + (size_t)NWB * (n_slots > 0 ? n_slots : 1) * D) * sizeof(double) + 3 * NWB * sizeof(uint64_t);
@@ -966,7 +981,8 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
             const size_t extra = ((size_t)a.n_effects * D + BASE_ER * (D + 1)) * sizeof(double) +
                                  (BASE_ER + BASE_PW) * sizeof(int32_t);
             const size_t slot_bytes = (size_t)(n_slots > 0 ? n_slots : 1) * 64 * sizeof(double);   // one state per lane group
-            if (slot_bytes + extra + gate_bytes <= 60 * 1024) {
+            if (slot_bytes + extra + gate_bytes <= 156 * 1024) {
+                if (hipError_t ea = raise_lds((const void*)walk_base_kernel<D>, slot_bytes + extra + gate_bytes)) return ea;
                 hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)blocks), dim3(64), slot_bytes + extra + gate_bytes,
                                    stream, a, n_slots);
                 return hipGetLastError();
@@ -974,8 +990,10 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
         }
         if (a.multi_start > 0) return hipErrorInvalidValue;        // D <= 16: only the chain kernel implements multi-start walks
     }
-    if (ldsg)
+    if (ldsg) {
+        if (hipError_t ea = raise_lds((const void*)walk_rows_kernel<D, true>, lds_bytes + gate_bytes)) return ea;
         hipLaunchKernelGGL((walk_rows_kernel<D, true>), dim3((unsigned)blocks), dim3(64), lds_bytes + gate_bytes, stream, a, n_slots);
+    }
     else
         hipLaunchKernelGGL((walk_rows_kernel<D, false>), dim3((unsigned)blocks), dim3(64), lds_bytes, stream, a, n_slots);
     return hipGetLastError();

@@ -1,19 +1,24 @@
-"""One-process-per-GPU sharding helpers (torch.distributed: backend "nccl" == RCCL over xGMI on ROCm,
-"gloo" for the CPU tests).  PyTorch is plumbing here -- process groups and the gather collective; the
-compute never goes through it.
+"""One process per GPU: process-group plumbing and the row-block exchange.
 
-How the path shards: layout atoms are disjoint circuit groups with contiguous element
-slices and no data dependence between them (distlayout.py:326-332, 404-415), so rank r of N owns the
-atoms r, r+N, ...; every rank fills its own rows of the 'e' / 'ep' array and NO collective is needed
-inside a fill -- exactly as the reference's bulk_fill_* leaves rows distributed.  Only when the caller
-asks for the assembled array (the reference's `layout.gather_local_array`, distlayout.py:1143-1147,
-built on Gatherv / Allgatherv, resourceallocation.py:316-348) do row blocks travel: `gather_elements`
-below is that collective -- an all-gather of max-padded row blocks (every rank gets the result, as
-`allgather_local_array` does) or a gather to rank 0.
+How the path shards: layout atoms are disjoint circuit groups with contiguous element slices and no
+data dependence between them (distlayout.py:326-332, 404-415), so rank r of N owns the atoms r, r+N, ...; every rank
+fills its own rows of the 'e' / 'ep' array and NO collective is needed inside a fill -- exactly as the reference's
+bulk_fill_* leaves rows distributed.  Data moves only when the caller asks for the assembled array (the reference's
+`layout.gather_local_array` / `allgather_local_array`, distlayout.py:1010-1156 and copalayout.py:479-518, built on
+Gatherv / Allgatherv, resourceallocation.py:316-348) or for summed normal equations (`fill_jtj` / `fill_jtf`,
+distlayout.py:1220-1359, on `allreduce_sum`, resourceallocation.py:441-508).
+
+Two planes:
+  * control (rendezvous, barriers, max-over-ranks timing, small host arrays): a `torch.distributed` *gloo* group --
+    PyTorch is plumbing here and never sees device data;
+  * data (row blocks of probabilities / Jacobians, J^T J sums): `_lib.Comm`, the C ABI's gst_comm_* -- RCCL over xGMI
+    between device pointers, or the intra-node IPC transport (ranks sharing a GPU; fallback when RCCL cannot start).
 """
 import os
 
 import numpy as np
+
+from . import _lib
 
 
 def env_rank_size():
@@ -34,25 +39,135 @@ def owned_row_blocks(layout, rank, size):
     return [(at.element_slice.start, at.element_slice.stop) for a, at in enumerate(layout.all_atoms) if a % size == rank]
 
 
-def gather_elements(local, layout, group=None, dst=None):
-    """Assemble a full element-dimension array from per-rank row blocks.
+def row_blocks(layout, size):
+    """The block list of the C ABI's row exchanges: (owner rank, first row, rows) per atom, in atom order."""
+    return [(a % size, at.element_slice.start, at.element_slice.stop - at.element_slice.start)
+            for a, at in enumerate(layout.all_atoms)]
 
-    local : torch tensor of shape (num_elements, ...) in which THIS rank's rows are filled (device
-            tensor under nccl, CPU tensor under gloo).  Rows owned by other ranks are ignored.
-    dst   : None -> all ranks receive the assembled tensor (all_gather of padded blocks);
-            int  -> only that rank does (gather).
+
+class DistContext:
+    """Control group (gloo) + data communicator (gst_comm) of this process.  `comm` is None when size == 1 or when
+    no device transport could be created (`comm_error` says why): callers then stay on the host paths."""
+
+    def __init__(self, rank, size, local_rank, group, comm, comm_error=None):
+        self.rank, self.size, self.local_rank = rank, size, local_rank
+        self.group, self.comm, self.comm_error = group, comm, comm_error
+
+    @property
+    def transport(self):
+        return None if self.comm is None else self.comm.info()["transport"]
+
+    def barrier(self):
+        if self.size > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.group)
+
+    def max_over_ranks(self, x):
+        if self.size == 1:
+            return float(x)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def all_ok(self, ok):
+        """True iff `ok` on every rank."""
+        return self.max_over_ranks(0.0 if ok else 1.0) == 0.0
+
+    def broadcast_bytes(self, payload, src=0):
+        if self.size == 1:
+            return payload
+        import torch.distributed as dist
+        box = [payload if self.rank == src else None]
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+
+def init(device=None, transport="auto", want_comm=True):
+    """Join the job `torch.distributed.run` (or any launcher exporting RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)
+    started: a gloo control group, then the device communicator.  transport: 'rccl', 'ipc' or 'auto' (RCCL, and if any
+    rank fails to create it -- e.g. ranks sharing a GPU -- all ranks fall back to IPC together).  GST_TRANSPORT in the
+    environment overrides `transport`."""
+    rank, size, local_rank = env_rank_size()
+    if size == 1:
+        return DistContext(0, 1, local_rank, None, None)
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    ctx = DistContext(rank, size, local_rank, None, None)
+    if not want_comm:
+        return ctx
+    transport = os.environ.get("GST_TRANSPORT", transport)
+    if device is None:
+        device = local_rank % max(_lib.device_count(), 1)
+    errors = []
+    for tr in (["rccl", "ipc"] if transport == "auto" else [transport]):
+        code = {"rccl": _lib.TRANSPORT_RCCL, "ipc": _lib.TRANSPORT_IPC}[tr]
+        uid, err = None, None
+        if rank == 0:
+            try:
+                uid = _lib.Comm.unique_id(code)
+            except Exception as e:          # e.g. no librccl on this box
+                err = "%s: %s" % (type(e).__name__, e)
+        uid = ctx.broadcast_bytes(uid)
+        comm = None
+        if uid is not None:
+            try:
+                comm = _lib.Comm(rank, size, uid, device, code)
+            except Exception as e:
+                err = "%s: %s" % (type(e).__name__, e)
+        if ctx.all_ok(comm is not None):
+            ctx.comm = comm
+            break
+        if comm is not None:
+            comm.close()
+        errors.append("%s transport: %s" % (tr, err or "failed on another rank"))
+    ctx.comm_error = "; ".join(errors) if errors else None
+    return ctx
+
+
+# ---- device arrays -------------------------------------------------------------------------------------------------
+def allgather_elements_dev(ctx, layout, d_full, row_doubles=1, plan=None):
+    """`allgather_local_array` on a device array [num_elements][row_doubles] in which this rank's atoms are filled:
+    afterwards (stream order under RCCL) every rank holds every row."""
+    if ctx.size > 1:
+        ctx.comm.allgather_rows(d_full, row_doubles, row_blocks(layout, ctx.size), plan)
+
+
+def gather_elements_dev(ctx, layout, d_local, d_full, row_doubles=1, root=0, plan=None):
+    """`gather_local_array` (Gatherv to `root`) of device row blocks: non-root ranks pass their own atoms' rows packed
+    in atom order (d_local), the root its full-size array with its own rows in place."""
+    if ctx.size > 1:
+        ctx.comm.gather_rows(d_local, d_full, row_doubles, row_blocks(layout, ctx.size), root, plan)
+
+
+# ---- host arrays (the reference's semantics on numpy arrays; small ones: probabilities, objective terms) --------------
+def gather_elements(local, layout, group=None, dst=None):
+    """Assemble a full element-dimension HOST array from per-rank row blocks through the control group.
+
+    local : numpy array or CPU torch tensor of shape (num_elements, ...) in which THIS rank's rows are filled.
+    dst   : None -> all ranks receive the assembled array (all_gather of padded blocks); int -> only that rank does.
     """
     import torch
     import torch.distributed as dist
+    as_numpy = isinstance(local, np.ndarray)
+    loc = torch.from_numpy(np.ascontiguousarray(local)) if as_numpy else local
     rank, size = dist.get_rank(group), dist.get_world_size(group)
     blocks = [owned_row_blocks(layout, r, size) for r in range(size)]
     rows = [sum(b - a for a, b in bl) for bl in blocks]
     pad = max(rows)
-    tail = tuple(local.shape[1:])
-    send = torch.zeros((pad,) + tail, dtype=local.dtype, device=local.device)
+    tail = tuple(loc.shape[1:])
+    send = torch.zeros((pad,) + tail, dtype=loc.dtype, device=loc.device)
     off = 0
     for a, b in blocks[rank]:
-        send[off:off + (b - a)] = local[a:b]
+        send[off:off + (b - a)] = loc[a:b]
         off += b - a
     if dst is None:
         recv = [torch.empty_like(send) for _ in range(size)]
@@ -62,10 +177,23 @@ def gather_elements(local, layout, group=None, dst=None):
         dist.gather(send, recv, dst=dst, group=group)
         if rank != dst:
             return None
-    out = torch.empty_like(local)
+    out = torch.empty_like(loc)
     for r in range(size):
         off = 0
         for a, b in blocks[r]:
             out[a:b] = recv[r][off:off + (b - a)]
             off += b - a
-    return out
+    return out.numpy() if as_numpy else out
+
+
+def allreduce_sum_host(arr, group=None):
+    """In-place sum of a host numpy array over the control group (`allreduce_sum`, resourceallocation.py:441-508)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return arr
+    t = torch.from_numpy(arr) if arr.flags.c_contiguous else torch.from_numpy(np.ascontiguousarray(arr))
+    dist.all_reduce(t, group=group)
+    if not arr.flags.c_contiguous:
+        arr[...] = t.numpy()
+    return arr

@@ -88,6 +88,8 @@ class HipCOPALayout:
         self.num_outcomes = len(self._outcomes)
         self.target_tasks = target_tasks
         self.max_slots = max_slots
+        self.pin_arrays = True          # allocate_local_array page-locks large element-dimension arrays
+        self.last_array_pinned = False
         self._num_params = model.num_params
         lookup = {l: i for i, l in enumerate(self.model_gate_labels)}
         self._circ_len = np.fromiter((len(c) for c in self.circuits), dtype=np.int64, count=self.num_circuits)
@@ -187,14 +189,77 @@ class HipCOPALayout:
     def allocate_local_array(self, array_type, dtype="d", zero_out=False, memory_tracker=None, extra_elements=0):
         nE, nP = self.num_elements + extra_elements, self._num_params
         shape = {"e": (nE,), "ep": (nE, nP), "ep2": (nE, nP), "epp": (nE, nP, nP), "p": (nP,), "jtj": (nP, nP),
-                 "jtf": (nP,), "c": (self.num_circuits,), "cp": (self.num_circuits, nP)}[array_type]
-        return np.zeros(shape, dtype) if zero_out else np.empty(shape, dtype)
+                 "jtf": (nP,), "c": (self.num_circuits,), "cp": (self.num_circuits, nP),
+                 "cp2": (self.num_circuits, nP), "cpp": (self.num_circuits, nP, nP)}[array_type]
+        arr = np.zeros(shape, dtype) if zero_out else np.empty(shape, dtype)
+        # element-dimension arrays are what the fills copy into: page-lock the large ones once, here, so that every
+        # later bulk_fill_* runs at PCIe rate (the reference allocates these once per objective and reuses them)
+        self.last_array_pinned = False
+        if array_type in ("e", "ep", "ep2", "epp") and arr.nbytes >= (1 << 22) and self.pin_arrays:
+            self.last_array_pinned = _lib.pin_host_array(arr)
+        return arr
 
     def free_local_array(self, local_array):
-        pass
+        if isinstance(local_array, np.ndarray):
+            _lib.unpin_host_array(local_array)
 
     def gather_local_array(self, array_type, array_portion, extra_elements=0, all_gather=False, return_shared=False):
-        return array_portion
+        """Assemble the global array from the ranks' portions (distlayout.py:1010-1156): element-dimension arrays
+        ('e', 'ep', 'ep2', 'epp') are full-size on every rank with only the rank's own atoms filled, so the row blocks
+        travel to rank 0 (Gatherv) or to every rank (`all_gather`); the other ranks get None, as in the reference.
+        Host arrays go through the control group (pygsti_amd.dist); device arrays have `dist.gather_elements_dev`."""
+        if self._size == 1 or array_type not in ("e", "ep", "ep2", "epp"):
+            return array_portion
+        from . import dist as _dist
+        nE = self.global_num_elements
+        body = _dist.gather_elements(np.ascontiguousarray(array_portion[:nE]), self, dst=None if all_gather else 0)
+        if body is None:
+            return None
+        if extra_elements:
+            body = np.concatenate([body, array_portion[nE:nE + extra_elements]], axis=0)
+        return body
+
+    def allgather_local_array(self, array_type, array_portion, extra_elements=0, return_shared=False):
+        """copalayout.py:479-518"""
+        return self.gather_local_array(array_type, array_portion, extra_elements, True, return_shared)
+
+    # ---- normal equations (distlayout.py:1220-1359; copalayout.py:549-598) --------------------------------------------
+    def _owned_rows_to_device(self, atom, arr, name):
+        plan = atom.plan()
+        rows = np.ascontiguousarray(arr[atom.element_slice], dtype=np.float64)
+        d = plan.workspace(name, max(rows.nbytes, 8))
+        plan.memcpy_h2d(d, rows)
+        return plan, d
+
+    def fill_jtj(self, j, jtj):
+        """jtj[:] = j.T @ j for a host 'ep' array: each owned atom's rows are contracted by the split-K MFMA kernel on
+        that atom's GPU, the partial products are added and all-reduced over the ranks (fill_jtj, distlayout.py:1259)."""
+        nP = j.shape[1]
+        acc = np.zeros((nP, nP))
+        for atom in self.atoms:
+            plan, d_j = self._owned_rows_to_device(atom, j, "njJ")
+            d_out = plan.workspace("njC", nP * nP * 8)
+            plan.fill_jtj_dev(d_j, atom.num_elements, nP, nP, d_out)
+            part = np.empty((nP, nP)); plan.memcpy_d2h(part, d_out); acc += part
+        if self._size > 1:
+            from . import dist as _dist
+            _dist.allreduce_sum_host(acc)
+        jtj[...] = acc
+
+    def fill_jtf(self, j, f, jtf):
+        """jtf[:] = j.T @ f (distlayout.py:1220-1257), same arrangement as fill_jtj."""
+        nP = j.shape[1]
+        acc = np.zeros(nP)
+        for atom in self.atoms:
+            plan, d_j = self._owned_rows_to_device(atom, j, "njJ")
+            _, d_f = self._owned_rows_to_device(atom, f, "njF")
+            d_out = plan.workspace("njV", nP * 8)
+            plan.fill_jtf_dev(d_j, atom.num_elements, nP, nP, d_f, d_out)
+            part = np.empty(nP); plan.memcpy_d2h(part, d_out); acc += part
+        if self._size > 1:
+            from . import dist as _dist
+            _dist.allreduce_sum_host(acc)
+        jtf[...] = acc
 
     def resource_alloc(self, sub_alloc_name=None, empty_if_missing=True):
         return _ResourceAlloc(self._rank, self._size)

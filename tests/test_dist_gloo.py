@@ -18,7 +18,8 @@ def _worker(rank, size, port, q):
     from pygsti_amd import modelpacks as MP, dist as gdist
     from pygsti_amd.layout import HipCOPALayout
     from _interp import run_programs
-    dist.init_process_group("gloo", rank=rank, world_size=size)
+    ctx = gdist.init(want_comm=False)          # the control plane (gloo); no device communicator on a CPU box
+    assert (ctx.rank, ctx.size) == (rank, size) and ctx.comm is None
     pack = MP.smq1Q_XYI
     model = pack.target_model().depolarize(0.01, 0.01)
     circuits = pack.create_gst_circuits(8)
@@ -35,6 +36,16 @@ def _worker(rank, size, port, q):
     full = gdist.gather_elements(local, lay)                  # all ranks
     root = gdist.gather_elements(local, lay, dst=0)           # rank 0 only
     ok_root = (root is None) if rank != 0 else bool(torch.equal(root, full))
+    # the layout's own gather (distlayout.py:1010-1156 semantics) on a host numpy array, + block bookkeeping
+    arr = local.numpy().copy()
+    g_all = lay.allgather_local_array("ep", arr)
+    g_root = lay.gather_local_array("ep", arr)
+    ok_root = ok_root and np.array_equal(g_all, full.numpy()) and ((g_root is None) if rank != 0 else np.array_equal(g_root, g_all))
+    blocks = gdist.row_blocks(lay, size)
+    ok_root = ok_root and [b[0] for b in blocks] == [a % size for a in range(len(lay.all_atoms))] \
+        and sum(b[2] for b in blocks) == lay.global_num_elements
+    part = np.full(3, float(rank + 1)); gdist.allreduce_sum_host(part)
+    ok_root = ok_root and np.array_equal(part, np.full(3, 3.0)) and ctx.max_over_ranks(rank) == 1.0
     q.put((rank, full.numpy(), ok_root, [(a.element_slice.start, a.element_slice.stop) for a in lay.atoms]))
     dist.destroy_process_group()
 

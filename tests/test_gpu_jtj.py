@@ -58,3 +58,58 @@ def test_simulator_level_normal_equations_multi_atom():
         assert _close(jtj, Js.T @ Js, 1e-11) and _close(jtf, Js.T @ f, 1e-11)
         p2 = np.empty(lay.num_elements); sim.bulk_fill_probs(p2, lay)
         assert np.array_equal(pr, p2)
+
+
+@pytest.mark.parametrize("n_rows,n_cols,pad", [(5003, 1616, 3), (3077, 1616, 0), (70001, 200, 1), (4099, 129, 0)])
+def test_jtj_benchmark_shape_synthetic(n_rows, n_cols, pad):
+    """The shape bench.py --jtj runs (1,616 columns: 13 x 13 column tiles incl. the partial 80-column edge tile and every
+    off-diagonal pair, 48 row slabs with a ragged last panel) on a synthetic Jacobian whose row count is not a multiple
+    of the 16-row panel; plus a tall narrow case that crosses the 64-slab cap."""
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    pl = plan_from_fixture(fx)
+    rng = np.random.default_rng(n_rows + n_cols)
+    ld = n_cols + pad
+    Jp = rng.standard_normal((n_rows, ld)) * np.exp(rng.uniform(-3, 3, size=(1, ld)))
+    J = Jp[:, :n_cols]
+    w = rng.random(n_rows) + 0.5; f = rng.standard_normal(n_rows)
+    d_J = pl.device_malloc(Jp.nbytes); d_jtj = pl.device_malloc(n_cols * n_cols * 8); d_jtf = pl.device_malloc(n_cols * 8)
+    d_w = pl.device_malloc(n_rows * 8); d_f = pl.device_malloc(n_rows * 8)
+    pl.memcpy_h2d(d_J, Jp); pl.memcpy_h2d(d_w, w); pl.memcpy_h2d(d_f, f)
+    pl.fill_jtj_dev(d_J, n_rows, n_cols, ld, d_jtj); pl.fill_jtf_dev(d_J, n_rows, n_cols, ld, d_f, d_jtf)
+    jtj = pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_jtj); jtf = pl.memcpy_d2h(np.empty(n_cols), d_jtf)
+    want = J.T @ J
+    # entry-wise: relative to the norms of the two columns (Cauchy-Schwarz scale of each entry)
+    scale = np.sqrt(np.outer(np.diag(want), np.diag(want)))
+    assert (np.abs(jtj - want) <= 1e-12 * scale).all(), np.abs((jtj - want) / scale).max()
+    assert np.array_equal(jtj, jtj.T)
+    assert np.abs(jtf - J.T @ f).max() <= 1e-12 * np.abs(J.T @ f).max()
+    # the padding columns of the row-major array must not leak in, and the scaled call must scale rows exactly once
+    pl.fill_jtj_dev(d_J, n_rows, n_cols, ld, d_jtj, d_w)
+    Js = J * w[:, None]
+    want = Js.T @ Js
+    scale = np.sqrt(np.outer(np.diag(want), np.diag(want)))
+    assert (np.abs(pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_jtj) - want) <= 1e-12 * scale).all()
+    for d in (d_J, d_jtj, d_jtf, d_w, d_f): pl.device_free(d)
+
+
+def test_jtj_on_the_2q_design_jacobian():
+    """J^T J / J^T f of the REAL 2Q Jacobian (smq2Q_XYICNOT lite germs L<=64: 55,832 x 1,616, FD, left resident) against
+    numpy on the same Jacobian copied to the host -- the bench workload's column count and value distribution."""
+    pack = MP.smq2Q_XYICNOT
+    model = pack.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
+    from pygsti_amd.layout import HipCOPALayout
+    lay = HipCOPALayout(pack.create_gst_circuits(64, lite=True), model)
+    pl = lay.atoms[0].plan()
+    pl.set_model(*lay.model_arrays(model)); pl.set_param_map(*lay.param_map(model))
+    nE, nP = lay.num_elements, model.num_params
+    d_J = pl.device_malloc(nE * nP * 8); d_jtj = pl.device_malloc(nP * nP * 8); d_jtf = pl.device_malloc(nP * 8); d_f = pl.device_malloc(nE * 8)
+    f = np.random.default_rng(5).standard_normal(nE); pl.memcpy_h2d(d_f, f)
+    pl.fill_dprobs_dev(d_J, nP, np.arange(nP), None, 1e-7)
+    pl.fill_jtj_dev(d_J, nE, nP, nP, d_jtj); pl.fill_jtf_dev(d_J, nE, nP, nP, d_f, d_jtf)
+    J = pl.memcpy_d2h(np.empty((nE, nP)), d_J)
+    jtj = pl.memcpy_d2h(np.empty((nP, nP)), d_jtj); jtf = pl.memcpy_d2h(np.empty(nP), d_jtf)
+    want = J.T @ J
+    scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1e-300
+    assert (np.abs(jtj - want) <= 1e-12 * scale).all(), np.abs((jtj - want) / scale).max()
+    assert np.abs(jtf - J.T @ f).max() <= 1e-12 * np.abs(J.T @ f).max()
+    for d in (d_J, d_jtj, d_jtf, d_f): pl.device_free(d)
