@@ -51,6 +51,27 @@ def build_workload(design, max_len, world, rank, device, target_tasks, max_slots
     return pack, model, circuits, layout
 
 
+def usable_cores():
+    """CPUs this process may actually use: scheduler affinity, capped by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                   # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:                                                          # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(pack, model, max_len, design):
     """Time the CPU checker on a bounded sample of THE SAME workload: the reference-format prefix table of the
     benchmarked design (restated PrefixTable, oracle/prefix_table.py) walked for a fixed number of passes -- one pass =
@@ -92,13 +113,18 @@ def cpu_baseline(pack, model, max_len, design):
         port = O.Oracle(tbl, mdl, "port")
         tp = port.time_passes(n_r); tr = orc.time_passes(n_r)
         one["port_over_reference_time_ratio"] = tp / tr
-    # all host cores: one thread per core, each with its own workspace (ctypes releases the GIL)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    per = int(max(2, min(n_pass, 12.0 / max(t / n_pass, 1e-6))))
-    t0 = time.perf_counter()
+    # all host cores: one thread per usable core, each with its own workspace (ctypes releases the GIL).  "Usable" =
+    # the scheduler affinity capped by the container's CPU quota (a box may show 256 CPUs and grant 8)
+    cores = usable_cores()
+    workers = [O.Oracle(tbl, mdl, kind) for _ in range(cores)]
     with cf.ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda _: O.Oracle(tbl, mdl, kind).time_passes(per), range(cores)))
-    ta = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        list(ex.map(lambda w: w.time_passes(1), workers))          # calibrate under full load
+        t_conc = time.perf_counter() - t0
+        per = int(max(1, min(n_pass, 10.0 / max(t_conc, 1e-6))))
+        t0 = time.perf_counter()
+        list(ex.map(lambda w: w.time_passes(per), workers))
+        ta = time.perf_counter() - t0
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -108,10 +134,19 @@ def cpu_baseline(pack, model, max_len, design):
     except OSError:
         pass
     allc = {"value": nE * per * cores / ta, "unit": "Jacobian-elements/s", "cores": cores, "kind": kind,
-            "cpu_model": cpu_model, "nproc": os.cpu_count(),
+            "cpu_model": cpu_model, "nproc": os.cpu_count(), "cgroup_limited": cores < (os.cpu_count() or 1),
             "sample": "%d threads x %d FD columns each over the %s, %.1f s" % (cores, per, what, ta),
             "speedup_over_1_core": (nE * per * cores / ta) / (nE * n_pass / t)}
     return one, allc
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (stdout carries the one JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -161,8 +196,10 @@ def main():
     lay_world, lay_rank = (args.emulate_ranks, 0) if (world == 1 and args.emulate_ranks > 1) else (world, rank)
     pack, model, circuits, layout = build_workload(args.design, args.max_len, lay_world, lay_rank, device,
                                                     args.target_tasks, args.max_slots, args.scaling)
+    log("workload built: %d circuits" % len(circuits))
     atom = layout.atoms[0]
     plan = atom.plan()
+    log("plan compiled")
     gates, rhos, effects = layout.model_arrays(model)
     plan.set_model(gates, rhos, effects)
     plan.set_param_map(*layout.param_map(model))
@@ -213,6 +250,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier_sync(plan)
+    log("warm-up done")
     t0 = time.perf_counter()
     kernel_ms = []
     for _ in range(args.steps):
@@ -230,6 +268,7 @@ def main():
         pf = plan.memcpy_d2h(np.empty(nE_total), d_pfull)
         assert abs(pf.sum() - n_circ_total) < 1e-6 * n_circ_total, "assembled probabilities must sum to 1 per circuit"
 
+    log("timed steps done: %.2f ms/step" % (1e3 * dt / args.steps))
     # secondary: probabilities only (+ their all-gather)
     for _ in range(2):
         plan.fill_probs_dev(d_probs)
@@ -263,6 +302,7 @@ def main():
         plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the FD Jacobian resident
         barrier_sync(plan)
 
+    log("probs / analytic legs done")
     # secondary (N>1): the fan-in of the Jacobian row blocks to rank 0 between device buffers (Gatherv,
     # resourceallocation.py:329-348 -- what `gather_local_array('ep', ...)` is for), alone and behind a fill
     if world > 1 and comm is not None and not args.no_jacobian_gather and args.scaling == "strong":
@@ -301,6 +341,7 @@ def main():
             if d_jfull is not None:
                 plan.device_free(d_jfull)
 
+    log("exchange legs done")
     jtj_info = None
     if args.jtj:
         # One Levenberg-Marquardt iteration's worth of data reduction on the resident Jacobian (row f1):
@@ -357,10 +398,12 @@ def main():
         for d in (d_jtj, d_jtf, d_ls, d_w, d_c, d_N):
             plan.device_free(d)
 
+    log("normal-equation leg done")
     # secondary (N=1): the reference API end to end -- bulk_fill_dprobs into the caller's HOST 'ep' array, PCIe included
     host_fill = None
     if world == 1 and lay_world == 1 and not args.no_host_fill:
         J_host = layout.allocate_local_array("ep", "d")            # page-locked (registered) by the layout
+        log("host array allocated, pinned=%s" % layout.last_array_pinned)
         pr_host = np.empty(nE_local)
         plan.fill_dprobs(J_host, pidx, None, 1e-7, pr_host, mode)  # warm-up
         th = time.perf_counter()
@@ -374,6 +417,7 @@ def main():
                      "note": "gst_fill_dprobs into a host numpy 'ep' array from layout.allocate_local_array (what "
                              "bulk_fill_dprobs(array, layout) returns in the reference): kernel + 7 GB over PCIe; never `value`"}
         layout.free_local_array(J_host)
+        log("host-fill leg done: %.1f ms per fill" % (1e3 * t_host))
 
     def measured_traffic(kernel_prefix):
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
@@ -447,6 +491,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["cpu_baseline_allcores"] = cpu_baseline(pack, model, args.max_len, args.design)
+            log("cpu baseline done")
         print(json.dumps(out))
     plan.device_free(d_out)
     plan.device_free(d_pfull)
