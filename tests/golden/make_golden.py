@@ -290,7 +290,7 @@ def circuit_list_hash(circ_ptr, circ_gates):
 
 def main():
     from pygsti.modelpacks import smq1Q_XYI, smq2Q_XYICNOT
-    which = sys.argv[1:] or ['1q4', '1q4k', '1q128', '2q2', '2qdeep', 'designs', 'tp']
+    which = sys.argv[1:] or ['1q4', '1q4k', '1q128', '2q2', '2qdeep', 'designs', 'tp', 'multispam', '3q']
 
     if '1q4' in which:   # BASELINE configs[0] / SURVEY C1: smq1Q_XYI L in {1,2,4}
         m = smq1Q_XYI.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
@@ -377,6 +377,30 @@ def main():
         fam = [c for c in dict.fromkeys(fam) if c in allset]
         cols = np.arange(336, 400)
         dump_case('smq2Q_XYICNOT_L1024_deep', m, fam, dprobs_cols=cols, want_matrix=False)
+
+    if '3q' in which:    # BASELINE configs[4] / SURVEY C5: 3-qubit explicit densitymx model, D = 64, 10 gates, nP = 41,536
+        from pygsti.processors import QubitProcessorSpec
+        from pygsti.models import modelconstruction as mc
+        from pygsti.circuits import Circuit
+        ps = QubitProcessorSpec(3, ['Gxpi2', 'Gypi2', 'Gcnot'], geometry='line')
+        m = mc.create_explicit_model(ps, ideal_gate_type='full', ideal_spam_type='full')
+        m = m.depolarize(op_noise=0.01, spam_noise=0.01).kick(0.02, seed=64)       # generic dense values
+        ops = list(m.operations.keys())
+        assert m.num_params == 41536 and m.dim == 64 and len(ops) == 10
+        rng = np.random.default_rng(0)                                             # seeded random strings
+        lens = np.concatenate([[0, 1, 2, 64, 64, 256, 200, 128], rng.integers(1, 65, 200)])
+        strs = [tuple(ops[g] for g in rng.integers(0, len(ops), L)) for L in lens]
+        for k in range(12, len(strs), 5):                                          # shared prefixes (prefix-table hits)
+            strs[k] = strs[k - 1][:len(strs[k - 1]) // 2] + strs[k][:10]
+        circs = [Circuit(s, line_labels=(0, 1, 2)) for s in dict.fromkeys(strs)]
+        nP = m.num_params
+        # 256 FD columns: rho, effects of several outcomes, rows / columns of several gates incl. both ends of the vector
+        cols = np.sort(np.unique(np.concatenate([
+            [0, 1, 63, 64, 65, 64 + 63, 64 + 64, 64 + 7 * 64 + 63, 576, 577, 576 + 63, 576 + 64, 576 + 4095, 576 + 4096, nP - 1],
+            rng.choice(nP, 256, replace=False)]))[:256])
+        blk = (np.array([0, 70, 576, 600, 576 + 64, 9000, 20000, nP - 1]),
+               np.sort(np.unique(np.concatenate([[0, 1, 70, 576, 577, 576 + 64 + 1, 30000, nP - 2], rng.choice(nP, 40, replace=False)]))[:32]))
+        dump_case('3q_explicit_L64', m, circs, dprobs_cols=cols, want_matrix=False, want_hprobs=True, hprobs_blk=blk)
 
     if 'designs' in which:
         # pins for the build's own circuit generator: counts and sha256 of integerised lists, plus

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 FIXTURES = ["smq1Q_XYI_L4_depol", "smq1Q_XYI_L4_kick", "smq1Q_XYI_L128_depol",
             "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep",
-            "smq1Q_multispam_L2"]       # two preparations, two POVMs (2 and 3 effects), an empty gate string
+            "smq1Q_multispam_L2",       # two preparations, two POVMs (2 and 3 effects), an empty gate string
+            "3q_explicit_L64"]          # 3 qubits, D = 64, 41,536 parameters: vectors of the reference's Cython Map path
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -71,7 +72,7 @@ def test_dprobs_column_window_and_dest_indices():
     assert_bitwise(full[:, 3:11], fx['dprobs_map'][:, 0:8], "view")
 
 
-@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2"])
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2", "3q_explicit_L64"])
 def test_hprobs_fd_bitwise_vs_reference(name):
     fx = load_fixture(name)
     pl = plan_from_fixture(fx)

@@ -11,7 +11,8 @@ from conftest import load_fixture, assert_bitwise, ROOT
 DESIGN_FIXTURES = ["smq1Q_XYI_L4_depol", "smq1Q_XYI_L4_kick", "smq1Q_XYI_L128_depol",
                    "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep"]
 # + two preparations, two POVMs (2 and 3 effects), explicit SPAM labels in the circuits, an empty gate string
-FIXTURES = DESIGN_FIXTURES + ["smq1Q_multispam_L2"]
+# + the 3-qubit explicit model (D = 64, 10 gates, 41,536 parameters; BASELINE configs[4]): 207 seeded random circuits
+FIXTURES = DESIGN_FIXTURES + ["smq1Q_multispam_L2", "3q_explicit_L64"]
 HAVE_REF = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgst_ref.so")) or \
     os.path.isdir("/root/reference/pygsti/evotypes/densitymx")
 KINDS = ["port"] + (["reference"] if HAVE_REF else [])
@@ -28,7 +29,7 @@ def test_probs_and_dprobs_bitwise(oracle_built, name, kind):
     assert_bitwise(J, fx["dprobs_map"], "dprobs")
 
 
-@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2"])
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2", "3q_explicit_L64"])
 def test_hprobs_bitwise(oracle_built, name):
     fx = load_fixture(name)
     H = oracle_built.from_fixture(fx).hprobs(fx["hprobs_rows"], fx["hprobs_cols"], eps=float(fx["hessian_eps"]))
