@@ -168,6 +168,28 @@ int gst_fill_probs(gst_plan *plan, double *out);
 int gst_fill_dprobs(gst_plan *plan, double *out, int64_t ld, const int64_t *param_idx,
                     const int64_t *dest_idx, int64_t n_param, int mode, double eps, double *probs_out);
 
+/* Finite-difference Jacobian columns for ANY parameterisation (CPTPLND, composed / embedded / exponentiated members,
+ * parameters shared between members ...): what mapfill_dprobs_atom computes by stepping the model itself,
+ *     for each parameter i:  model.set_parameter_value(i, orig + eps);  probs2 = probabilities;  (probs2 - probs) / eps
+ * (pygsti/forwardsims/mapforwardsim_calc_densitymx.pyx:349-381, models/model.py:1198-1310).  The caller steps ITS model
+ * on the host and hands over the n_models perturbed models as complete dense sets -- gates[m][n_gates][D][D],
+ * rhos[m][n_rhos][D], effects[m][n_effects][D], m < n_models, C-contiguous f64 (what to_dense('minimal') returns after
+ * each step) -- so nothing is assumed about which elements a parameter moves.  Column dest_idx[m] (m when dest_idx is
+ * NULL) of `out` receives (p(model set m) - p(base)) / eps, the base being the model of gst_set_model; probs_out (may be
+ * NULL) the base probabilities.  gst_set_param_map / gst_set_derivs are not needed.  The device runs every (walk
+ * program, model set) pair as an independent probability walk -- no state is shared with the base pass, which is the
+ * price of generality: members that are one-parameter-per-element (full, full TP) should use gst_fill_dprobs.
+ * Accuracy: the reference propagates non-dense members (ComposedOp / ExpErrorgenOp reps, opcreps.cpp:242-524) factor by
+ * factor, this path through their dense product, so probabilities agree to rounding (~1e-16) and the quotients to
+ * ~1e-16 / eps, not bit for bit. */
+int gst_fill_dprobs_models(gst_plan *plan, int64_t n_models, const double *gates, const double *rhos,
+                           const double *effects, double *out, int64_t ld, const int64_t *dest_idx, double eps,
+                           double *probs_out);
+/* device-resident output (d_out, d_probs_out on the plan's device); the model sets are still host arrays */
+int gst_fill_dprobs_models_dev(gst_plan *plan, int64_t n_models, const double *gates, const double *rhos,
+                               const double *effects, double *d_out, int64_t ld, const int64_t *dest_idx, double eps,
+                               double *d_probs_out);
+
 /* Second derivatives of the dense elements with respect to the parameters, for the objects of the last gst_set_derivs
  * call, in the same order: what MatrixForwardSimulator._hoperation = member.hessian_wrt_params() feeds into the exact
  * Hessian (pygsti/forwardsims/matrixforwardsim.py:192-224, 1190-1287) for members that are not linear in their

@@ -73,6 +73,7 @@ EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_p
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
            "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
+           "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_comm_get_unique_id", "gst_comm_create", "gst_comm_destroy", "gst_comm_allgather_rows",
            "gst_comm_gather_rows", "gst_comm_allreduce_sum", "gst_comm_barrier", "gst_comm_sync", "gst_comm_get_info"]
 
@@ -117,6 +118,8 @@ def lib():
         L.gst_get_program.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64]
         L.gst_get_state_graph.argtypes = [vp, vp, vp, i64, vp, i64, C.POINTER(i64)]
         L.gst_device_count.argtypes = [C.POINTER(i32)]
+        L.gst_fill_dprobs_models.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp]
+        L.gst_fill_dprobs_models_dev.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp]
         L.gst_host_register.argtypes = [vp, i64]
         L.gst_host_unregister.argtypes = [vp]
         L.gst_comm_get_unique_id.argtypes = [C.c_int, vp]
@@ -348,6 +351,28 @@ class Plan:
             assert probs_out.dtype == np.float64 and probs_out.flags.c_contiguous and probs_out.size == self.n_elements
         check(lib().gst_fill_dprobs(self._h, _ptr(out), ld, _ptr(pi), _ptr(di), len(pi), int(mode), float(eps),
                                     _ptr(probs_out)))
+        return out
+
+    def fill_dprobs_models(self, gates, rhos, effects, out=None, dest_idx=None, eps=1e-7, probs_out=None):
+        """FD columns from explicitly perturbed dense model sets (gst_fill_dprobs_models): gates [n, nG, D, D],
+        rhos [n, nR, D], effects [n, nEl, D]; column dest_idx[m] = (p(set m) - p(base model)) / eps."""
+        r = _f64(rhos).reshape(-1, self.n_rhos, self.D)
+        n = r.shape[0]
+        g = _f64(gates).reshape(n, self.n_gates, self.D, self.D) if self.n_gates else np.zeros((1,), np.float64)
+        e = _f64(effects).reshape(n, self.n_effects, self.D)
+        di = None if dest_idx is None else _i64(dest_idx)
+        if out is None:
+            out = np.empty((self.n_elements, n if di is None else (int(di.max()) + 1 if len(di) else 0)), np.float64)
+        assert out.dtype == np.float64 and out.ndim == 2 and out.shape[0] == self.n_elements
+        if out.shape[1] == 0 or out.shape[0] == 0:
+            ld = max(out.shape[1], 1)
+        else:
+            assert out.strides[1] == 8 and out.strides[0] % 8 == 0, "rows must be contiguous in the parameter dimension"
+            ld = out.strides[0] // 8 if out.shape[0] > 1 else max(out.shape[1], 1)
+        if probs_out is not None:
+            assert probs_out.dtype == np.float64 and probs_out.flags.c_contiguous and probs_out.size == self.n_elements
+        check(lib().gst_fill_dprobs_models(self._h, n, _ptr(g), _ptr(r), _ptr(e), _ptr(out), ld, _ptr(di), float(eps),
+                                           _ptr(probs_out)))
         return out
 
     def fill_hprobs(self, out=None, idx1=None, idx2=None, dest1=None, dest2=None, eps=1e-5, mode=DERIV_FD):

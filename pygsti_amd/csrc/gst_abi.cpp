@@ -151,6 +151,8 @@ struct gst_plan {
     bool ana_mfma = true;               // D = 16 analytic mode on the MFMA path (GST_ANALYTIC_MFMA=0: the VALU kernel)
     int fd_split = 0;                   // gst_options.fd_split: 0 auto, 1 / 2 / 4 wavefronts per (task, 64 columns) pair
     int n_cus = 256;
+    DevBuf<double> d_mm_models, d_mm_raw;   // gst_fill_dprobs_models: perturbed model sets, their probability vectors
+    DevBuf<int32_t> d_mm_dest;
     DevBuf<double> d_obj_part;          // per-block partial sums of the objective terms
     DevBuf<uint32_t> d_block_order;     // FD launch order of the cached request (expensive (task, wavefront) pairs first)
     bool have_block_order = false;
@@ -207,6 +209,7 @@ struct gst_plan {
             if (h_model_pinned[i]) (void)hipHostFree(h_model_pinned[i]);
             if (ev_upload[i]) (void)hipEventDestroy(ev_upload[i]);
         }
+        d_mm_models.release(); d_mm_raw.release(); d_mm_dest.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
         d_wave_row.release(); d_wave_rowidx.release(); d_lane_colidx.release();
@@ -916,6 +919,100 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     return GST_OK;
 }
 
+int end_call(gst_plan* p, bool sync);
+
+// D2H of the dense staging Jacobian p->d_out [nE][n_param] into the caller's (ld, dest_idx) window, then end_call.  A
+// contiguous destination window -- the `dest_param_slice` of the reference's seam (mapforwardsim.py:379-383) -- is one
+// strided 2-D copy; only a scattered dest_idx needs host staging.
+int copy_out_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* dest_idx, int64_t n_param, double* probs_out)
+{
+    const int64_t nE = p->hp.n_elements;
+    bool window = true;
+    for (int64_t c = 1; dest_idx && c < n_param; c++) window = window && dest_idx[c] == dest_idx[0] + c;
+    const int64_t d0 = (dest_idx && n_param > 0) ? dest_idx[0] : 0;
+    std::vector<double> stage;
+    if (n_param > 0) {
+        if (window) {
+            HIP_TRY(hipMemcpy2DAsync(out + d0, (size_t)ld * 8, p->d_out.p, (size_t)n_param * 8, (size_t)n_param * 8, (size_t)nE,
+                                     hipMemcpyDeviceToHost, p->stream));
+        } else {
+            stage.resize((size_t)nE * n_param);
+            HIP_TRY(hipMemcpyAsync(stage.data(), p->d_out.p, (size_t)nE * n_param * 8, hipMemcpyDeviceToHost, p->stream));
+        }
+    }
+    if (probs_out) HIP_TRY(hipMemcpyAsync(probs_out, p->d_pbase.p, nE * 8, hipMemcpyDeviceToHost, p->stream));
+    int rc;
+    if ((rc = end_call(p, true))) return rc;
+    if (n_param > 0 && !window)
+        for (int64_t k = 0; k < nE; k++)
+            for (int64_t c = 0; c < n_param; c++) out[k * ld + dest_idx[c]] = stage[(size_t)k * n_param + c];
+    return GST_OK;
+}
+
+// Finite differences over ANY parameterisation (gst_fill_dprobs_models): column m = (p(model set m) - p(base)) / eps, the
+// base being gst_set_model's model.  Every model set is a complete dense model (what set_parameter_value + to_dense give
+// on the host), so nothing is assumed about which elements a parameter moves; the price is that no state is shared
+// with the base pass -- each (task, model set) pair is a full probability walk (chain kernel at D <= 16, row-per-lane
+// kernel at D = 64).  Model sets are processed in chunks that bound the scratch (probability vectors) to 2 GB.
+int run_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, const double* rhos, const double* effects,
+                      double* d_out, int64_t ld, const int64_t* dest_idx, double eps, double* d_probs_out)
+{
+    const gst::HostPlan& h = p->hp;
+    const int D = h.D;
+    const int64_t nE = h.n_elements;
+    const size_t ng = (size_t)h.n_gates * D * D, nr = (size_t)h.n_rhos * D, ne = (size_t)h.n_effects * D;
+    const size_t stride = ng + nr + ne;
+    double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
+    int rc = run_probs(p, d_base, false);
+    if (rc) return rc;
+    if (n_models == 0) return GST_OK;
+    if (n_models > 0x7fffffffLL) return fail(GST_EINVAL, "too many model sets");
+    const int64_t nT = h.n_tasks();
+    int64_t chunk = std::max<int64_t>(1, (int64_t)(2.0e9 / (8.0 * (double)std::max<int64_t>(nE, 1))));
+    chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, 0x7fffffffLL / std::max<int64_t>(nT, 1)));
+    chunk = std::min<int64_t>(chunk, n_models);
+    HIP_TRY(p->d_mm_models.ensure((size_t)chunk * stride));
+    HIP_TRY(p->d_mm_raw.ensure((size_t)chunk * (size_t)std::max<int64_t>(nE, 1)));
+    std::vector<int32_t> dest32;
+    if (dest_idx) {
+        dest32.resize((size_t)n_models);
+        for (int64_t m = 0; m < n_models; m++) {
+            if (dest_idx[m] < 0 || dest_idx[m] >= ld) return fail(GST_EINVAL, "destination column out of range");
+            dest32[(size_t)m] = (int32_t)dest_idx[m];
+        }
+        if ((rc = upload_i32(p->d_mm_dest, dest32, p->stream))) return rc;
+    } else if (n_models > ld) return fail(GST_EINVAL, "more model sets than columns");
+    std::vector<double> stage((size_t)chunk * stride);
+    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    for (int64_t m0 = 0; m0 < n_models; m0 += chunk) {
+        const int64_t nm = std::min<int64_t>(chunk, n_models - m0);
+        for (int64_t m = 0; m < nm; m++) {
+            double* dst = stage.data() + (size_t)m * stride;
+            const double* G = gates + (size_t)(m0 + m) * ng;
+            for (int g = 0; g < h.n_gates; g++)
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++) dst[((size_t)g * D + j) * D + i] = G[((size_t)g * D + i) * D + j];
+            std::memcpy(dst + ng, rhos + (size_t)(m0 + m) * nr, nr * 8);
+            std::memcpy(dst + ng + nr, effects + (size_t)(m0 + m) * ne, ne * 8);
+        }
+        HIP_TRY(hipMemcpyAsync(p->d_mm_models.p, stage.data(), (size_t)nm * stride * 8, hipMemcpyHostToDevice, p->stream));
+        gst::WalkArgs w;
+        base_args(p, w);
+        w.gates = nullptr;
+        w.gates_t = p->d_mm_models.p; w.rhos = p->d_mm_models.p + ng; w.effects = p->d_mm_models.p + ng + nr;
+        w.n_models = (int32_t)nm; w.model_stride = (int64_t)stride; w.out_model_stride = nE; w.mm_tasks = (int32_t)nT;
+        w.n_pwaves = (int32_t)nm;
+        w.mode = gst::EMIT_PROBS; w.rows_S = 0; w.out = p->d_mm_raw.p;
+        HIP_TRY(gst::launch_walk_rows(D, w, nT, h.max_slots, p->stream));
+        HIP_TRY(gst::launch_fd_from_models(p->d_mm_raw.p, nE, d_base, nE, (int32_t)nm, dest_idx ? p->d_mm_dest.p + m0 : nullptr,
+                                           (int32_t)m0, eps, d_out, ld, p->stream));
+        p->last_launches += 2;
+        HIP_TRY(hipStreamSynchronize(p->stream));          // the staging vector is refilled by the next chunk
+    }
+    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    return GST_OK;
+}
+
 int begin_call(gst_plan* p)
 {
     if (!p) return fail(GST_EINVAL, "plan is NULL");
@@ -1308,27 +1405,37 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     else if (mode == GST_DERIV_ANALYTIC) rc = run_dprobs_analytic(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
     else rc = run_dprobs_fd(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr, nullptr, 0);
     if (rc) return rc;
-    // D2H into the caller's (ld, dest_idx) window.  A contiguous destination window -- the `dest_param_slice` of the
-    // reference's seam (mapforwardsim.py:379-383) -- is one strided 2-D copy; only a scattered dest_idx needs staging.
-    bool window = true;
-    for (int64_t c = 1; dest_idx && c < n_param; c++) window = window && dest_idx[c] == dest_idx[0] + c;
-    const int64_t d0 = (dest_idx && n_param > 0) ? dest_idx[0] : 0;
-    std::vector<double> stage;
-    if (n_param > 0) {
-        if (window) {
-            HIP_TRY(hipMemcpy2DAsync(out + d0, (size_t)ld * 8, p->d_out.p, (size_t)n_param * 8, (size_t)n_param * 8, (size_t)nE,
-                                     hipMemcpyDeviceToHost, p->stream));
-        } else {
-            stage.resize((size_t)nE * n_param);
-            HIP_TRY(hipMemcpyAsync(stage.data(), p->d_out.p, (size_t)nE * n_param * 8, hipMemcpyDeviceToHost, p->stream));
-        }
-    }
-    if (probs_out) HIP_TRY(hipMemcpyAsync(probs_out, p->d_pbase.p, nE * 8, hipMemcpyDeviceToHost, p->stream));
-    if ((rc = end_call(p, true))) return rc;
-    if (n_param > 0 && !window)
-        for (int64_t k = 0; k < nE; k++)
-            for (int64_t c = 0; c < n_param; c++) out[k * ld + dest_idx[c]] = stage[(size_t)k * n_param + c];
-    return GST_OK;
+    return copy_out_dprobs(p, out, ld, dest_idx, n_param, probs_out);
+    });
+}
+
+int gst_fill_dprobs_models_dev(gst_plan* p, int64_t n_models, const double* gates, const double* rhos, const double* effects,
+                               double* d_out, int64_t ld, const int64_t* dest_idx, double eps, double* d_probs_out)
+{
+    return guarded([&]() -> int {
+        int rc = begin_call(p);
+        if (rc) return rc;
+        if (n_models < 0 || (n_models > 0 && (!rhos || !effects || (p->hp.n_gates > 0 && !gates) || !d_out)))
+            return fail(GST_EINVAL, "bad argument");
+        if (!(eps != 0.0)) return fail(GST_EINVAL, "eps must be non-zero");
+        if ((rc = run_dprobs_models(p, n_models, gates, rhos, effects, d_out, ld, dest_idx, eps, d_probs_out))) return rc;
+        return end_call(p, false);
+    });
+}
+
+int gst_fill_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, const double* rhos, const double* effects,
+                           double* out, int64_t ld, const int64_t* dest_idx, double eps, double* probs_out)
+{
+    return guarded([&]() -> int {
+        int rc = begin_call(p);
+        if (rc) return rc;
+        if (n_models < 0 || (n_models > 0 && (!rhos || !effects || (p->hp.n_gates > 0 && !gates) || !out)))
+            return fail(GST_EINVAL, "bad argument");
+        if (!(eps != 0.0)) return fail(GST_EINVAL, "eps must be non-zero");
+        const int64_t nE = p->hp.n_elements;
+        HIP_TRY(p->d_out.ensure((size_t)nE * std::max<int64_t>(n_models, 1)));
+        if ((rc = run_dprobs_models(p, n_models, gates, rhos, effects, p->d_out.p, n_models, nullptr, eps, nullptr))) return rc;
+        return copy_out_dprobs(p, out, ld, dest_idx, n_models, probs_out);
     });
 }
 

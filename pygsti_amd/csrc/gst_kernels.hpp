@@ -52,6 +52,12 @@ struct WalkArgs {
     int32_t comp_index, n_others;
     const int32_t* comp_others;    // [n_others], the reference's summation order
     const double* comp_identity;   // [D]
+    // Whole-model mode of the S = 0 probability pass (gst_fill_dprobs_models: finite differences over ANY
+    // parameterisation): n_models > 0 model sets, each laid out [gates_t | rhos | effects] with model_stride doubles
+    // between consecutive sets; wavefront (task, m) walks task with set m and writes out[m * out_model_stride + dest].
+    int32_t n_models;
+    int64_t model_stride, out_model_stride;
+    int32_t mm_tasks;        // number of tasks (walk_base_kernel derives (task, model) from blockIdx.x)
     int32_t n_pwaves;        // wavefronts along the parameter dimension (grid.x)
     int32_t rows_S;          // walk_rows_kernel only: number of perturbations per wavefront (0, 1, 2); its
                              // `lanes` tables then hold ONE entry per wavefront instead of one per lane
@@ -208,5 +214,9 @@ hipError_t launch_effect_fd(const EffectFDArgs& a, hipStream_t stream);
 // Persistent form of the D <= 16 FD walk: n_wg workgroups of 16 wavefronts (see WalkArgs::bin_ptr)
 hipError_t launch_walk_persistent(int D, const WalkArgs& a, int n_wg, int n_slots, hipStream_t stream);
 hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
+// out[e * ld + dest[m]] = (raw[m * raw_stride + e] - pbase[e]) / eps for m < n_models (dest == NULL: column m0 + m):
+// the finite-difference quotient of gst_fill_dprobs_models, transposed through LDS tiles (correctly rounded division)
+hipError_t launch_fd_from_models(const double* raw, int64_t raw_stride, const double* pbase, int64_t nE, int32_t n_models,
+                                 const int32_t* dest, int32_t m0, double eps, double* out, int64_t ld, hipStream_t stream);
 
 }  // namespace gst

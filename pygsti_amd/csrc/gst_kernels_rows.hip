@@ -35,16 +35,21 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 }
 
 template <int D, bool LDSG>
-__global__ __launch_bounds__(64) void walk_rows_kernel(const WalkArgs a, const int n_slots)
+__global__ __launch_bounds__(64) void walk_rows_kernel(const WalkArgs a_, const int n_slots)
 {
     extern __shared__ double lds[];          // save slots: lds[slot*D + row]; then (LDSG) all gates, transposed
     const int lane = threadIdx.x;
     const int li = lane < D ? lane : 0;      // idle lanes (D < 64) shadow row 0 and never store
     const bool act = lane < D;
+    WalkArgs a = a_;
     const int64_t bid = a.block_order ? (int64_t)a.block_order[blockIdx.x] : (int64_t)blockIdx.x;
     const int32_t pw = (int32_t)(bid % a.n_pwaves);
     const int64_t task = bid / a.n_pwaves;
     const int S = a.rows_S;
+    if (a.n_models > 0) {                    // whole-model mode: wavefront pw of a task carries model set pw
+        a.gates_t += (int64_t)pw * a.model_stride; a.rhos += (int64_t)pw * a.model_stride;
+        a.effects += (int64_t)pw * a.model_stride; a.out += (int64_t)pw * a.out_model_stride;
+    }
 
     // ---- the (up to two) perturbations of this wavefront's model: wave-uniform -------------------------
     int kind[2] = {GST_KIND_NONE, GST_KIND_NONE}, obj[2] = {0, 0}, row[2] = {-1, -1}, cb[2] = {-1, -1};
@@ -820,7 +825,7 @@ __device__ __forceinline__ void stage_lds(T* dst, const int total, const int lan
 }
 
 template <int D>
-__global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a, const int n_slots)
+__global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a_, const int n_slots)
 {
     static_assert(D == 4 || D == 16, "group broadcasts are DPP quad / row operations");
     constexpr int W = BASE_PW, ER = BASE_ER;
@@ -828,7 +833,14 @@ __global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a, const i
     extern __shared__ double lds[];          // save slots | effects | gates_t | emit ring | ring circuits | program window
     const int lane = threadIdx.x;
     const int li = lane % D, grp = lane / D;
-    const int64_t task = blockIdx.x;
+    WalkArgs a = a_;
+    int64_t task = blockIdx.x;
+    if (a.n_models > 0) {                    // whole-model mode: block = (model set, task)
+        const int64_t m = task / a.mm_tasks;
+        task -= m * a.mm_tasks;
+        a.gates_t += m * a.model_stride; a.rhos += m * a.model_stride; a.effects += m * a.model_stride;
+        a.out += m * a.out_model_stride;
+    }
     double* ldsE = lds + (n_slots > 0 ? n_slots : 1) * 64;      // (a save slot holds one state per lane group)
     double* ldsG = ldsE + a.n_effects * D;
     double* ering = ldsG + a.n_gates * D * D;
@@ -988,6 +1000,20 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
                 return hipGetLastError();
             }
         }
+        if (ldsg && a.rows_S == 0 && a.n_models > 0 && a.mode == EMIT_PROBS && a.n_pwaves == a.n_models) {
+            // whole-model mode on the chain kernel: one single-wavefront block per (model set, task)
+            const size_t extra = ((size_t)a.n_effects * D + BASE_ER * (D + 1)) * sizeof(double) +
+                                 (BASE_ER + BASE_PW) * sizeof(int32_t);
+            const size_t slot_bytes = (size_t)(n_slots > 0 ? n_slots : 1) * 64 * sizeof(double);
+            if (slot_bytes + extra + gate_bytes <= 156 * 1024) {
+                if (hipError_t ea = raise_lds((const void*)walk_base_kernel<D>, slot_bytes + extra + gate_bytes)) return ea;
+                WalkArgs b = a;
+                b.mm_tasks = (int32_t)n_tasks; b.n_pwaves = 1;
+                hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)blocks), dim3(64), slot_bytes + extra + gate_bytes,
+                                   stream, b, n_slots);
+                return hipGetLastError();
+            }
+        }
         if (a.multi_start > 0) return hipErrorInvalidValue;        // D <= 16: only the chain kernel implements multi-start walks
     }
     if (ldsg) {
@@ -999,6 +1025,45 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
     return hipGetLastError();
 }
 
+
+// Finite-difference quotients of whole perturbed models (gst_fill_dprobs_models): raw holds one probability vector per
+// model set, [model][element]; the Jacobian wants [element][column].  A 64 x 64 tile goes through LDS so that both
+// the reads (along elements) and the writes (along columns) are coalesced.  (p_m - p) / eps with the correctly rounded
+// fp64 division the FD kernels use (mapforwardsim_calc_densitymx.pyx:378).
+__global__ __launch_bounds__(256) void fd_from_models_kernel(const double* __restrict__ raw, int64_t raw_stride,
+                                                             const double* __restrict__ pbase, int64_t nE, int32_t n_models,
+                                                             const int32_t* __restrict__ dest, int32_t m0, double eps,
+                                                             double* __restrict__ out, int64_t ld)
+{
+    __shared__ double tile[64][65];
+    const int64_t e0 = (int64_t)blockIdx.x * 64;
+    const int32_t c0 = (int32_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;         // 4 rows of the tile per pass
+    for (int j = ty; j < 64; j += 4) {
+        const int32_t m = c0 + j;
+        const int64_t e = e0 + tx;
+        tile[j][tx] = (m < n_models && e < nE) ? raw[(int64_t)m * raw_stride + e] : 0.0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t e = e0 + i;
+        const int32_t m = c0 + tx;
+        if (e < nE && m < n_models) {
+            const int64_t col = dest ? (int64_t)dest[m] : (int64_t)(m0 + m);
+            out[e * ld + col] = (tile[tx][i] - pbase[e]) / eps;
+        }
+    }
+}
+
+hipError_t launch_fd_from_models(const double* raw, int64_t raw_stride, const double* pbase, int64_t nE, int32_t n_models,
+                                 const int32_t* dest, int32_t m0, double eps, double* out, int64_t ld, hipStream_t stream)
+{
+    if (nE <= 0 || n_models <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fd_from_models_kernel, dim3((unsigned)((nE + 63) / 64), (unsigned)((n_models + 63) / 64)), dim3(256), 0, stream,
+                       raw, raw_stride, pbase, nE, n_models, dest, m0, eps, out, ld);
+    return hipGetLastError();
+}
 
 // FD columns of effect parameters, from the cached final states.  Perturbing an element of an effect vector changes no
 // propagated state, so the column is (E'.F_n - p)/eps on the circuits' final states -- E' being the perturbed effect for

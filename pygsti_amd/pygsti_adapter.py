@@ -17,10 +17,13 @@ the atom; each call only re-uploads the dense model arrays (the reference re-mar
 layout on every call, mapforwardsim_calc_densitymx.pyx:170-181).
 
 Scope: `densitymx` models whose members can be densified.  Fully parameterised members (one parameter
-per dense element: FullArbitraryOp / FullState / FullPOVMEffect) run in both derivative modes and for
-Hessians; any other parameterisation (full TP, CPTPLND, ...) runs probabilities and, with
-`derivative_mode="analytic"`, Jacobians through the members' `deriv_wrt_params()` (gst_set_derivs).
-What is not covered raises NotImplementedError -- there is no silent fallback to the CPU path.
+per dense element: FullArbitraryOp / FullState / FullPOVMEffect) and full-TP models run in both derivative modes and
+for Hessians, finite differences bit-identical to the Map simulator.  Any other parameterisation (CPTPLND, composed
+members, shared parameters ...): finite-difference Jacobians by stepping the model on the host exactly as the reference
+does and evaluating every perturbed dense model on the device (gst_fill_dprobs_models; to rounding, <= 1e-8 against the
+Map simulator), and with `derivative_mode="analytic"` exact Jacobians / Hessians through the members'
+`deriv_wrt_params()` / `hessian_wrt_params()` (gst_set_derivs).  FD-of-FD Hessians of such models raise
+NotImplementedError -- there is no silent fallback to the CPU path.
 """
 import numpy as np
 
@@ -126,6 +129,39 @@ def atom_tp_map(model, atom):
                 raise NotImplementedError("parameter shared between members")
             kind[idx] = k; obj[idx] = oi; elem[idx] = rows
     return kind, obj, elem, complement
+
+
+def atom_model_sets(model, atom, param_indices, eps):
+    """The dense model after each finite-difference step of mapfill_dprobs_atom (mapforwardsim_calc_densitymx.pyx:362-381:
+    undo the previous parameter and step the current one with set_parameter_values, models/model.py:1198-1310) -- the
+    input of gst_fill_dprobs_models for members whose parameters are not dense elements (CPTPLND, composed, ...).  Only
+    the members a parameter belongs to are re-densified; the model is left at its original parameter vector.
+    Returns (gates [n, nG, D, D], rhos [n, nR, D], effects [n, nEl, D])."""
+    D = model.dim
+    base_g, base_r, base_e = atom_arrays(model, atom)
+    n = len(param_indices)
+    G = np.repeat(base_g[None], n, axis=0); R = np.repeat(base_r[None], n, axis=0); E = np.repeat(base_e[None], n, axis=0)
+    members = []
+    for arr, labels, typ, shape in ((G, list(atom.op_labels), "op", (D, D)), (R, list(atom.rho_labels), "prep", (D,)),
+                                    (E, atom._hip_eff_labels, "povm", (D,))):
+        for oi, lbl in enumerate(labels):
+            idx = model._circuit_layer_operator(lbl, typ).gpindices_as_array()
+            if len(idx):
+                members.append((arr, oi, lbl, typ, shape, set(int(q) for q in idx)))
+    orig = model.to_vector().copy()
+    prev = None
+    for c, i in enumerate(int(q) for q in param_indices):
+        if prev is None:
+            model.set_parameter_value(i, orig[i] + eps)
+        else:
+            model.set_parameter_values([prev, i], [orig[prev], orig[i] + eps])
+        for arr, oi, lbl, typ, shape, owned in members:
+            if i in owned:
+                arr[c, oi] = np.real(model._circuit_layer_operator(lbl, typ).to_dense("minimal")).reshape(shape)
+        prev = i
+    if prev is not None:
+        model.set_parameter_value(prev, orig[prev])
+    return G, R, E
 
 
 def atom_derivs(model, atom):
@@ -241,11 +277,14 @@ class HipMapForwardSimulator(_MapForwardSimulator):
             if getattr(layout_atom, "_hip_tpmap_model", None) is not self.model:
                 try:
                     layout_atom._hip_tpmap = atom_tp_map(self.model, layout_atom)
-                except NotImplementedError as e:
-                    raise NotImplementedError(
-                        str(e) + "; use HipMapForwardSimulator(derivative_mode='analytic') (exact derivatives through "
-                        "deriv_wrt_params)")
+                except NotImplementedError:
+                    # CPTPLND, composed members, shared parameters ...: the general path -- the model is stepped on the
+                    # host as the reference does and the device evaluates every perturbed dense model
+                    layout_atom._hip_tpmap = None
                 layout_atom._hip_tpmap_model = self.model
+            if layout_atom._hip_tpmap is None:
+                plan._hip_mode = "models"
+                return plan
             k, o, e, comp = layout_atom._hip_tpmap
             if plan.n_params != self.model.num_params or getattr(plan, "_hip_mode", None) != "tp-elements":
                 plan.set_derivs(self.model.num_params, [])
@@ -271,6 +310,11 @@ class HipMapForwardSimulator(_MapForwardSimulator):
         nP = self.model.num_params
         pidx = np.arange(nP) if param_slice is None else _slct.to_array(param_slice)
         didx = None if dest_param_slice is None else _slct.to_array(dest_param_slice)
+        if getattr(plan, "_hip_mode", None) == "models":
+            G, R, E = atom_model_sets(self.model, layout_atom, pidx, self.derivative_eps)
+            plan.set_model(*atom_arrays(self.model, layout_atom))
+            plan.fill_dprobs_models(G, R, E, array_to_fill, didx, self.derivative_eps)
+            return
         mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
         plan.fill_dprobs(array_to_fill, pidx, didx, self.derivative_eps, mode=mode)
 
@@ -284,7 +328,8 @@ class HipMapForwardSimulator(_MapForwardSimulator):
             plan.set_second_derivs(atom_second_derivs(self.model, layout_atom))
         elif hmode != "elements" and not (hmode == "tp-elements" and self.derivative_mode == "fd"):
             raise NotImplementedError("Hessians on the device: fully parameterised models (FD or exact), full-TP models "
-                                      "(FD of FD as the Map simulator computes them, or exact)")
+                                      "(FD of FD as the Map simulator computes them, or exact), any parameterisation "
+                                      "with derivative_mode='analytic' (exact)")
         nP = self.model.num_params
         i1 = np.arange(nP) if param_slice1 is None else _slct.to_array(param_slice1)
         i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)

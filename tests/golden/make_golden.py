@@ -38,7 +38,7 @@ def _label_str(lbl):
 
 def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hprobs=False,
               hprobs_blk=None, circuit_subset_for_matrix=None, extra=None, general_params=False,
-              matrix_hprobs_blocks=None, matrix_hprobs=True):
+              matrix_hprobs_blocks=None, matrix_hprobs=True, model_sets=False, dump_derivs=True):
     """Build a 1-atom Map layout for `circuits`, run the reference, save everything."""
     assert model.sim.calclib.__name__.endswith('calc_densitymx'), "reference Cython path not built!"
     model = model.copy()
@@ -95,7 +95,7 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
     # ---- general parameterisations: d(dense element)/d(parameter) of every object, as the reference's members
     # return it (modelmember.deriv_wrt_params(), consumed by matrixforwardsim.py:_doperation / _dprobs_from_rho_e)
     dv = {}
-    if general_params:
+    if general_params and dump_derivs:
         k_l, o_l, n_l, pi_l, d_l = [], [], [], [], []
         h_l, hz_l = [], []
         for kind, labels, typ in ((0, op_labels, 'op'), (1, rho_labels, 'prep'), (2, eff_labels, 'povm')):
@@ -207,6 +207,32 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
     # the FD loop must restore the model exactly
     assert np.array_equal(model.to_vector(), paramvec)
 
+    if model_sets:
+        # the dense model after each finite-difference step of mapfill_dprobs_atom (pyx:362-381: undo the previous
+        # parameter, step the current one) -- the input of gst_fill_dprobs_models for parameterisations whose parameters
+        # are not dense elements
+        def dense_sets():
+            g = np.array([model._circuit_layer_operator(l, 'op').to_dense('minimal') for l in op_labels])
+            r = np.array([model._circuit_layer_operator(l, 'prep').to_dense('minimal') for l in rho_labels])
+            e = np.array([model._circuit_layer_operator(l, 'povm').to_dense('minimal') for l in eff_labels])
+            return (np.ascontiguousarray(g.real.reshape(len(op_labels), D, D), dtype=np.float64),
+                    np.ascontiguousarray(r.real.reshape(len(rho_labels), D), dtype=np.float64),
+                    np.ascontiguousarray(e.real.reshape(len(eff_labels), D), dtype=np.float64))
+        eps = model.sim.derivative_eps
+        mg, mr, me = [], [], []
+        prev = None
+        for i in dprobs_cols:
+            if prev is None:
+                model.set_parameter_value(int(i), paramvec[i] + eps)
+            else:
+                model.set_parameter_values([int(prev), int(i)], [paramvec[prev], paramvec[i] + eps])
+            g, r, e = dense_sets(); mg.append(g); mr.append(r); me.append(e)
+            prev = i
+        if prev is not None:
+            model.set_parameter_value(int(prev), paramvec[prev])
+        assert np.array_equal(model.to_vector(), paramvec)
+        out.update(mm_gates=np.array(mg), mm_rhos=np.array(mr), mm_effects=np.array(me))
+
     if want_hprobs:
         b1, b2 = hprobs_blk
         b1 = np.asarray(b1, np.int64); b2 = np.asarray(b2, np.int64)
@@ -290,7 +316,7 @@ def circuit_list_hash(circ_ptr, circ_gates):
 
 def main():
     from pygsti.modelpacks import smq1Q_XYI, smq2Q_XYICNOT
-    which = sys.argv[1:] or ['1q4', '1q4k', '1q128', '2q2', '2qdeep', 'designs', 'tp', 'multispam', '3q']
+    which = sys.argv[1:] or ['1q4', '1q4k', '1q128', '2q2', '2qdeep', 'designs', 'tp', 'multispam', '3q', 'cptp2q']
 
     if '1q4' in which:   # BASELINE configs[0] / SURVEY C1: smq1Q_XYI L in {1,2,4}
         m = smq1Q_XYI.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
@@ -338,7 +364,7 @@ def main():
         m = smq1Q_XYI.target_model("CPTPLND")
         m.from_vector(m.to_vector() + 0.01 * np.random.default_rng(3).standard_normal(m.num_params))
         blk = (np.array([0, 2, 7, 8, 13, 25, 26, 40, 59]), np.arange(0, 60, 3))
-        dump_case('smq1Q_XYI_L4_CPTPLND', m, circs, general_params=True, want_hprobs=True, hprobs_blk=blk)
+        dump_case('smq1Q_XYI_L4_CPTPLND', m, circs, general_params=True, want_hprobs=True, hprobs_blk=blk, model_sets=True)
         m = smq2Q_XYICNOT.target_model("full TP").depolarize(op_noise=0.01, spam_noise=0.01)
         circs2 = list(smq2Q_XYICNOT.create_gst_experiment_design(1, lite=True).all_circuits_needing_data)
         cols = np.sort(np.random.default_rng(5).choice(m.num_params, 120, replace=False))
@@ -346,6 +372,16 @@ def main():
         blk2 = (np.array([2, 17, 40, 63 + 240 + 5]), np.array([16, 17, 33, 40, 49, 62, 1, 63 + 17, 63 + 240 + 5, 63 + 4 * 240 + 100]))
         dump_case('smq2Q_XYICNOT_L1_TP', m, circs2, dprobs_cols=cols, circuit_subset_for_matrix=list(range(0, len(circs2), 7)),
                   general_params=True, want_hprobs=True, hprobs_blk=blk2, matrix_hprobs=False)
+
+    if 'cptp2q' in which:   # 2Q CPTPLND (composed static target x exponentiated Lindblad error generator): Map FD columns
+        m = smq2Q_XYICNOT.target_model("CPTPLND")
+        m.from_vector(m.to_vector() + 0.003 * np.random.default_rng(9).standard_normal(m.num_params))
+        circs2 = list(smq2Q_XYICNOT.create_gst_experiment_design(1, lite=True).all_circuits_needing_data)
+        cols = np.sort(np.random.default_rng(6).choice(m.num_params, 40, replace=False))
+        cols[:3] = [0, 1, 2]
+        cols = np.unique(cols)
+        dump_case('smq2Q_XYICNOT_L1_CPTPLND', m, circs2, dprobs_cols=cols, want_matrix=False, general_params=True,
+                  model_sets=True, dump_derivs=False)      # (the members' derivative tensors would be 0.5 GB)
 
     if '2q2' in which:   # 2Q, D=16: every circuit of the L<=2 lite design, a spread of 96 columns
         m = smq2Q_XYICNOT.target_model().depolarize(op_noise=0.01, spam_noise=0.01)

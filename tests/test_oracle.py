@@ -88,3 +88,20 @@ def test_analytic_hprobs_oracle_vs_matrix_simulator_2q_blocks():
         H = O.analytic_hprobs(fx, i1, i2)
         ref = fx["mh%d_hprobs" % b][::5][:, :6][:, :, ::4]
         assert np.abs(H[rows] - ref).max() < 1e-11
+
+
+@pytest.mark.parametrize("name,ptol,jtol", [("smq1Q_XYI_L4_CPTPLND", 1e-15, 1e-8), ("smq2Q_XYICNOT_L1_CPTPLND", 1e-15, 1e-8)])
+def test_dense_model_sets_reproduce_the_map_fd_of_cptplnd_models(oracle_built, name, ptol, jtol):
+    """General parameterisations: the dense model after every FD step (fixture `mm_*`, written by the reference's own
+    set_parameter_value) walked by the oracle gives the reference Map simulator's Jacobian to rounding -- the reference
+    propagates composed / exponentiated members factor by factor, so the agreement is ~1e-16 / eps, not bitwise (observed: probs 3e-16, dprobs 4.4e-9 / 6.1e-9; bar: the north star's 1e-8)."""
+    fx = load_fixture(name)
+    eps = float(fx["derivative_eps"])
+    orc = oracle_built.from_fixture(fx)
+    base = orc.probs()
+    assert np.abs(base - fx["probs"]).max() <= ptol
+    J = np.empty_like(fx["dprobs_map"])
+    for c, (g, r, e) in enumerate(zip(fx["mm_gates"], fx["mm_rhos"], fx["mm_effects"])):
+        orc.set_model(g, r, e)
+        J[:, c] = (orc.probs() - base) / eps
+    assert np.abs(J - fx["dprobs_map"]).max() <= jtol, np.abs(J - fx["dprobs_map"]).max()

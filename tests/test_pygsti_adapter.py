@@ -102,5 +102,33 @@ def test_adapter_non_full_parameterisations():
             mtp.sim.bulk_fill_dprobs(np.empty((lay.num_elements, mtp.num_params)), lay)
         model.sim = A.HipMapForwardSimulator(derivative_mode="fd", num_atoms=1)
         lay = model.sim.create_layout(list(smq1Q_XYI.create_gst_experiment_design(1).all_circuits_needing_data), array_types=("ep",))
-        with pytest.raises((NotImplementedError, _lib.GstDeviceError)):
+        with pytest.raises(_lib.GstDeviceError):       # CPTPLND FD: the general (model-set) path, refused only for lack of a device
             model.sim.bulk_fill_dprobs(np.empty((lay.num_elements, model.num_params)), lay)
+
+
+def test_adapter_general_parameterisation_fd_model_sets():
+    """Default-constructed simulator on a CPTPLND model (the default protocol's parameterisation): finite differences go
+    through the model sets -- the adapter's host stepping reproduces, array for array, the dense models the reference
+    wrote into the committed fixture (tests/golden/make_golden.py 'tp'), and the fill reaches the device."""
+    from pygsti.modelpacks import smq1Q_XYI
+    from conftest import load_fixture
+    fx = load_fixture("smq1Q_XYI_L4_CPTPLND")
+    m = smq1Q_XYI.target_model("CPTPLND")
+    m.from_vector(m.to_vector() + 0.01 * np.random.default_rng(3).standard_normal(m.num_params))
+    assert np.array_equal(m.to_vector(), fx["paramvec"])
+    m.sim = A.HipMapForwardSimulator()                       # defaults: derivative_mode="fd"
+    lay = m.sim.create_layout(list(smq1Q_XYI.create_gst_experiment_design(4).all_circuits_needing_data), array_types=("ep",))
+    atom = lay.atoms[0]
+    A.atom_plan(m, atom)
+    v0 = m.to_vector().copy()
+    G, R, E = A.atom_model_sets(m, atom, np.arange(m.num_params), float(fx["derivative_eps"]))
+    assert np.array_equal(m.to_vector(), v0)
+    eff_mine = [str(l) for l in atom._hip_eff_labels]; eff_ref = list(fx["eff_labels"])
+    perm = [eff_mine.index(l) for l in eff_ref]              # (set iteration order differs between processes)
+    assert [str(l) for l in atom.op_labels] == list(fx["op_labels"])
+    assert np.array_equal(G, fx["mm_gates"]) and np.array_equal(R, fx["mm_rhos"]) and np.array_equal(E[:, perm], fx["mm_effects"])
+    plan = m.sim._prepare(atom, derivatives=True)
+    assert plan._hip_mode == "models"
+    if _lib.device_count() == 0:
+        with pytest.raises(_lib.GstDeviceError):
+            m.sim.bulk_fill_dprobs(np.empty((lay.num_elements, m.num_params)), lay)
