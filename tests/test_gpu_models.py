@@ -22,7 +22,7 @@ CASES = [("smq1Q_XYI_L4_CPTPLND", 1e-15, 1e-8), ("smq2Q_XYICNOT_L1_CPTPLND", 1e-
 
 
 def _oracle_fd(O, fx, eps):
-    orc = O.from_fixture(fx)
+    orc = O.from_fixture({k: np.array(v) for k, v in fx.items()})       # (set_model writes into the oracle's arrays)
     base = orc.probs()
     cols = []
     for g, r, e in zip(fx["mm_gates"], fx["mm_rhos"], fx["mm_effects"]):

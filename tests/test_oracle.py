@@ -97,7 +97,7 @@ def test_dense_model_sets_reproduce_the_map_fd_of_cptplnd_models(oracle_built, n
     propagates composed / exponentiated members factor by factor, so the agreement is ~1e-16 / eps, not bitwise (observed: probs 3e-16, dprobs 4.4e-9 / 6.1e-9; bar: the north star's 1e-8)."""
     fx = load_fixture(name)
     eps = float(fx["derivative_eps"])
-    orc = oracle_built.from_fixture(fx)
+    orc = oracle_built.from_fixture({k: np.array(v) for k, v in fx.items()})      # (set_model writes into the oracle's arrays)
     base = orc.probs()
     assert np.abs(base - fx["probs"]).max() <= ptol
     J = np.empty_like(fx["dprobs_map"])
