@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgstfwd.so")
+LIB_PATH = os.environ.get("GST_LIBGSTFWD") or os.path.join(_HERE, "libgstfwd.so")     # (override: A/B builds in development)
 
 GST_OK = 0
 GST_EINVAL, GST_ENODEVICE, GST_EHIP, GST_ENOMEM, GST_ESTATE, GST_EUNSUPPORTED = -1, -2, -3, -4, -5, -6

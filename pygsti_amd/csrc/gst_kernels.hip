@@ -40,6 +40,19 @@ __device__ __forceinline__ const GST_CONST T* as_const(const T* p)
     return (const GST_CONST T*)(p);
 }
 
+// Wavefronts per SIMD the D = 16 Jacobian pass is compiled for.  The dispatcher-placed launch (whole designs: tens of
+// pairs per SIMD) wants 4 (128 VGPRs, a few spills, best latency hiding: 25.3 vs 25.7 ms on the 2Q design); the persistent
+// launch of small atoms has only 2-3 long walks per SIMD anyway, and with 3 (168 VGPRs, no spills) a 1/8 atom of the
+// 2Q design takes 4.27 instead of 4.48 ms (interleaved repeats, tools/ab_libs.sh).  Measured and NOT kept: scalar-load
+// stages of half a column (one s_load_dwordx16 per 16 VALU instructions): tools/ub_fd.hip shows a lone wavefront 15 %
+// faster that way, the interpreter around the sweep does not (same time at 3 per SIMD, 6 % slower at 4: more spills).
+#ifndef GST_FD_WPS
+#define GST_FD_WPS 4
+#endif
+#ifndef GST_FD_WPS_PERSIST
+#define GST_FD_WPS_PERSIST 3
+#endif
+
 template <int D>
 struct State {
     double x[D];
@@ -645,13 +658,13 @@ static hipError_t launch_one(const WalkArgs& a, int64_t n_tasks, int n_slots, hi
 
 hipError_t launch_walk_persistent(int D, const WalkArgs& a, int n_wg, int n_slots, hipStream_t stream)
 {
-    constexpr int waves = 16;
+    const int waves = (D == 16) ? 4 * GST_FD_WPS_PERSIST : 16;
     if (n_wg <= 0 || n_slots > 4 || (D != 4 && D != 16)) return hipErrorInvalidValue;
     const size_t lds_bytes = (size_t)waves * a.lds_wave_doubles * sizeof(double);
     if ((size_t)a.lds_wave_doubles < (size_t)n_slots * D * 64 || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     (void)hipGetLastError();
     if (D == 16) {
-        auto k = walk_kernel<16, 1, 4, 1, true>;
+        auto k = walk_kernel<16, 1, GST_FD_WPS_PERSIST, 1, true>;
         if (lds_bytes > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return e;
@@ -679,7 +692,7 @@ hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_s
         if (S == 2) return launch_one<4, 2, 4>(a, n_tasks, n_slots, stream);
     } else if (D == 16) {
         if (S == 0) return launch_one<16, 0, 4>(a, n_tasks, n_slots, stream);
-        if (S == 1) return launch_one<16, 1, 4>(a, n_tasks, n_slots, stream);
+        if (S == 1) return launch_one<16, 1, GST_FD_WPS>(a, n_tasks, n_slots, stream);
         if (S == 2) return launch_one<16, 2, 3>(a, n_tasks, n_slots, stream);
     }
     return hipErrorInvalidValue;
