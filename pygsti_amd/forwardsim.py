@@ -101,17 +101,17 @@ class HipMapForwardSimulator:
     # -- layout ---------------------------------------------------------------------------------------------
     def create_layout(self, circuits, dataset=None, resource_alloc=None, array_types=("E",),
                       derivative_dimensions=None, verbosity=0, layout_creation_circuit_cache=None):
-        """Build the element index and one device plan per atom (mapforwardsim.py:206-335).  `dataset` must be
-        None (all outcomes are laid out, copalayout.py:161-164)."""
-        if dataset is not None:
-            raise NotImplementedError("dataset-restricted layouts are not part of the device path yet")
+        """Build the element index and one device plan per atom (mapforwardsim.py:206-335).  With `dataset` None all
+        outcomes are laid out (copalayout.py:161-164); otherwise only the outcomes the data set holds for each circuit,
+        in its order (maplayout.py:69): `dataset[circuit]` must give an object with `.outcomes` or an iterable of outcome
+        labels."""
         rank = getattr(resource_alloc, "comm_rank", 0) if resource_alloc is not None else 0
         size = getattr(resource_alloc, "comm_size", 1) if resource_alloc is not None else 1
         natoms = self._num_atoms if self._num_atoms is not None else max(size, len(self.devices or [0]))
         blk = tuple(self._pblk_sizes) if self._pblk_sizes else (None, None)
         if len(blk) == 1:
             blk = (blk[0], None)
-        return HipCOPALayout(circuits, self.model, natoms, self.devices, rank, size, self.target_tasks, blk)
+        return HipCOPALayout(circuits, self.model, natoms, self.devices, rank, size, self.target_tasks, blk, dataset=dataset)
 
     # -- per-atom seams (mapforwardsim.py:372-391) ---------------------------------------------------------------
     def _prepare_atom(self, layout_atom):

@@ -66,10 +66,15 @@ class HipLayoutAtom:
             gates = np.empty(int(ptr[-1]), np.int32)
             for k, ci in enumerate(self.circuit_indices):
                 gates[ptr[k]:ptr[k + 1]] = L._circ_gates[L._circ_ptr[ci]:L._circ_ptr[ci + 1]]
-            eff_ptr = np.arange(n + 1, dtype=np.int64) * nO
-            eff_label = np.tile(np.arange(nO, dtype=np.int32), n)
-            eff_dest = np.arange(n * nO, dtype=np.int32)
-            self._plan = _lib.Plan.from_circuits(L.dim, L.num_gates, 1, nO, n * nO, np.zeros(n, np.int32), ptr,
+            # effect CSR of this atom's circuits: all outcomes, or only those the data set observed (maplayout.py:69)
+            cnt = L._out_ptr[self.circuit_indices + 1] - L._out_ptr[self.circuit_indices]
+            eff_ptr = np.zeros(n + 1, np.int64)
+            np.cumsum(cnt, out=eff_ptr[1:])
+            eff_label = np.empty(int(eff_ptr[-1]), np.int32)
+            for k, ci in enumerate(self.circuit_indices):
+                eff_label[eff_ptr[k]:eff_ptr[k + 1]] = L._out_idx[L._out_ptr[ci]:L._out_ptr[ci + 1]]
+            eff_dest = np.arange(int(eff_ptr[-1]), dtype=np.int32)
+            self._plan = _lib.Plan.from_circuits(L.dim, L.num_gates, 1, nO, int(eff_ptr[-1]), np.zeros(n, np.int32), ptr,
                                                  gates, eff_ptr, eff_label, eff_dest, device=self.device,
                                                  target_tasks=L.target_tasks, max_slots=L.max_slots)
         return self._plan
@@ -77,7 +82,7 @@ class HipLayoutAtom:
 
 class HipCOPALayout:
     def __init__(self, circuits, model, num_atoms=1, devices=None, rank=0, size=1, target_tasks=0,
-                 param_dimension_blk_sizes=(None, None), max_slots=0):
+                 param_dimension_blk_sizes=(None, None), max_slots=0, dataset=None):
         self.circuits = [tuple(c) for c in circuits]
         self.num_circuits = len(self.circuits)
         self.model_gate_labels = list(model.operations.keys())
@@ -99,17 +104,42 @@ class HipCOPALayout:
         self._circ_gates = np.fromiter(map(lookup.__getitem__, itertools.chain.from_iterable(self.circuits)),
                                        dtype=np.int32, count=int(self._circ_ptr[-1]))
         self._rank, self._size = rank, size
+        # ---- outcomes laid out per circuit (copalayout.py:155-168) ---------------------------------------------------
+        # dataset None: every outcome of the POVM; otherwise only the outcomes the data set holds for the circuit, in
+        # the data set's order (`dataset[circuit].outcomes`; outcomes the model does not know are dropped, as
+        # bulk_expand_instruments_and_separate_povm does, models/model.py:1764-1768).  `dataset` is anything indexable by
+        # the circuit (tuple of gate labels) that returns an object with `.outcomes` or an iterable of outcome labels
+        # ('01' or ('01',)).
+        nO = self.num_outcomes
+        if dataset is None:
+            self._out_ptr = np.arange(self.num_circuits + 1, dtype=np.int64) * nO
+            self._out_idx = np.tile(np.arange(nO, dtype=np.int32), self.num_circuits)
+        else:
+            lookup_o = {o: k for k, o in enumerate(self._outcomes)}
+            ptr = np.zeros(self.num_circuits + 1, np.int64); idx = []
+            for i, c in enumerate(self.circuits):
+                row = dataset[c]
+                outs = getattr(row, "outcomes", row)
+                for o in outs:
+                    o = (o,) if isinstance(o, str) else tuple(o)
+                    if o in lookup_o:
+                        idx.append(lookup_o[o])
+                ptr[i + 1] = len(idx)
+            self._out_ptr, self._out_idx = ptr, np.asarray(idx, np.int32)
+        self._has_dataset = dataset is not None
 
         # ---- deal circuits to atoms ------------------------------------------------------------------
         num_atoms = max(1, int(num_atoms or 1))
         groups = self._partition(num_atoms)
-        self.global_num_elements = self.num_circuits * self.num_outcomes
+        self.global_num_elements = int(self._out_ptr[-1])
         self._circuit_offset = np.empty(self.num_circuits, np.int64)   # first element of each circuit
         atoms, off = [], 0
         devices = list(devices) if devices else [-1]
+        n_out = self._out_ptr[1:] - self._out_ptr[:-1]
         for a, idx in enumerate(groups):
-            n_el = len(idx) * self.num_outcomes
-            self._circuit_offset[idx] = off + np.arange(len(idx)) * self.num_outcomes
+            cnt = n_out[idx]
+            n_el = int(cnt.sum())
+            self._circuit_offset[idx] = off + np.concatenate([[0], np.cumsum(cnt)[:-1]]) if len(idx) else off
             atoms.append(HipLayoutAtom(self, idx, slice(off, off + n_el), devices[a % len(devices)]))
             off += n_el
         self.all_atoms = atoms
@@ -167,10 +197,12 @@ class HipCOPALayout:
 
     def indices_for_index(self, index):
         o = int(self._circuit_offset[index])
-        return slice(o, o + self.num_outcomes)
+        return slice(o, o + int(self._out_ptr[index + 1] - self._out_ptr[index]))
 
     def outcomes_for_index(self, index):
-        return tuple(self._outcomes)
+        if not self._has_dataset:
+            return tuple(self._outcomes)
+        return tuple(self._outcomes[k] for k in self._out_idx[self._out_ptr[index]:self._out_ptr[index + 1]])
 
     def indices_and_outcomes_for_index(self, index):
         return self.indices_for_index(index), self.outcomes_for_index(index)
@@ -179,7 +211,7 @@ class HipCOPALayout:
         return self.indices_for_index(self.circuits.index(tuple(circuit)))
 
     def outcomes(self, circuit):
-        return tuple(self._outcomes)
+        return self.outcomes_for_index(self.circuits.index(tuple(circuit)))
 
     def iter_unique_circuits(self):
         for i, c in enumerate(self.circuits):

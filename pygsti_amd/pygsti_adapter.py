@@ -255,6 +255,24 @@ class HipMapForwardSimulator(_MapForwardSimulator):
                                      self._hip_device, self.derivative_mode)
         return out
 
+    def create_layout(self, circuits, dataset=None, resource_alloc=None, array_types=('E',), derivative_dimensions=None,
+                      verbosity=0, layout_creation_circuit_cache=None, **kwargs):
+        """pyGSTi's own MapCOPALayout (element indexing, atoms, parameter blocks, MPI grid -- everything upstream relies
+        on), built WITHOUT the prefix-cache assessment pass: the library compiles its own prefix trie from the full gate
+        strings (gst_plan_create_from_table re-derives them), so the table's caching choices are never used, and with
+        max_cache_size = 0 `PrefixTable.__init__` skips `_cache_hits` (layouts/prefixtable.py:76-84), the O(rows x cache)
+        tuple-comparison pass that is half of layout creation (2Q L<=1024 lite: 14.6 -> 7.7 s; what remains is pyGSTi's
+        per-circuit completion / POVM separation, models/model.py:1600-1775, which callers amortise with
+        `layout_creation_circuit_cache`).  Results are unchanged: every state is still rho followed by the circuit's
+        gates applied left to right."""
+        keep = self._max_cache_size
+        self._max_cache_size = 0
+        try:
+            return super().create_layout(circuits, dataset, resource_alloc, array_types, derivative_dimensions, verbosity,
+                                         layout_creation_circuit_cache, **kwargs)
+        finally:
+            self._max_cache_size = keep
+
     def _prepare(self, layout_atom, derivatives=False):
         plan = atom_plan(self.model, layout_atom, self._hip_device)
         plan.set_model(*atom_arrays(self.model, layout_atom))

@@ -174,3 +174,23 @@ def test_baseline_size_checksums():
         plan.close()
     assert_bitwise(sums[0][0], sums[777][0], "probabilities vs task decomposition at full size")
     assert_bitwise(sums[0][1], sums[777][1], "J^T f checksum vs task decomposition at full size")
+
+
+def test_dataset_restricted_layout_on_device():
+    """bulk_fill_probs / bulk_fill_dprobs on a layout that holds only the outcomes a data set observed (ragged effect
+    CSR on the device): rows equal the corresponding rows of the reference's all-outcome vectors, bit for bit."""
+    from test_host_mirror import _sparse_dataset
+    fx, model, sim, circuits, full = _setup("smq2Q_XYICNOT_L2_depol", MP.smq2Q_XYICNOT, 2, num_atoms=3)
+    ds = _sparse_dataset(circuits)
+    lay = sim.create_layout(circuits, dataset=ds)
+    assert lay.num_elements < full.num_elements
+    p = lay.allocate_local_array("e", "d"); sim.bulk_fill_probs(p, lay)
+    cols = fx["dprobs_cols"]
+    J = np.empty((lay.num_elements, len(cols)))
+    for atom in lay.atoms:
+        sim._bulk_fill_dprobs_atom(J[atom.element_slice], None, atom, cols)
+    names = ["00", "01", "10", "11"]
+    rows = np.concatenate([[4 * i + names.index(o[0]) for o in lay.outcomes_for_index(i)] for i in range(len(circuits))])
+    order = np.concatenate([np.arange(*lay.indices_for_index(i).indices(lay.num_elements)) for i in range(len(circuits))])
+    assert_bitwise(p[order], fx["probs"][rows], "dataset-restricted probs")
+    assert_bitwise(J[order], fx["dprobs_map"][rows], "dataset-restricted dprobs")

@@ -113,5 +113,64 @@ def test_simulator_surface_and_helpers():
     assert s3.model is None                      # live handles are dropped, the parent model re-attaches
     assert [ (s.start, s.stop) for s in _slice_up_range(10, 3)] == [(0, 4), (4, 7), (7, 10)]
     assert _to_index_array(slice(2, 5), 60).tolist() == [2, 3, 4]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):                 # a data set must be indexable by circuit (see test_dataset_restricted_layout)
         sim.create_layout([()], dataset=object())
+
+
+class _Row:
+    def __init__(self, outcomes):
+        self.outcomes = outcomes
+
+
+def _sparse_dataset(circuits, seed=3):
+    """A data set in which many circuits did not show every outcome (and one shows an outcome the model does not have)."""
+    rng = np.random.default_rng(seed)
+    names = ["00", "01", "10", "11"]
+    ds = {}
+    for k, c in enumerate(circuits):
+        keep = [n for n in rng.permutation(names) if rng.random() < 0.6] or ["00"]
+        if k == 5:
+            keep = keep + ["leak"]                      # not modelled: dropped (models/model.py:1764-1768)
+        ds[tuple(c)] = _Row(tuple((n,) for n in keep)) if k % 2 else [n for n in keep]
+    return ds
+
+
+@pytest.mark.parametrize("natoms", [1, 3])
+def test_dataset_restricted_layout(natoms):
+    """create_layout(dataset=...): only observed outcomes are laid out, in the data set's order (maplayout.py:69,
+    copalayout.py:161-164); probabilities of the laid-out elements equal the all-outcome layout's."""
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    pack = MP.smq2Q_XYICNOT
+    circuits = pack.create_gst_circuits(2)
+    model = _model_from_fixture(fx, pack)
+    ds = _sparse_dataset(circuits)
+    sim = HipMapForwardSimulator(model, num_atoms=natoms)
+    lay = sim.create_layout(circuits, dataset=ds)
+    want_n = 0
+    for c in circuits:
+        row = ds[tuple(c)]; outs = getattr(row, "outcomes", row)
+        want_n += sum(1 for o in outs if (o if isinstance(o, str) else o[0]) != "leak")
+    assert lay.num_elements == want_n < 4 * len(circuits)
+    full = sim.create_layout(circuits)
+    # per-atom plans through the numpy interpreter, ragged effect CSR
+    G, R, E = lay.model_arrays(model)
+    p = np.full(lay.num_elements, np.nan)
+    for atom in lay.all_atoms:
+        pl = atom.plan()
+        w, off = pl.program()
+        cnt = lay._out_ptr[atom.circuit_indices + 1] - lay._out_ptr[atom.circuit_indices]
+        eff_ptr = np.concatenate([[0], np.cumsum(cnt)])
+        eff_label = np.concatenate([lay._out_idx[lay._out_ptr[ci]:lay._out_ptr[ci + 1]] for ci in atom.circuit_indices])
+        o, written, _ = run_programs(w, off, G, R, E, eff_ptr, eff_label, np.arange(len(eff_label)), len(eff_label))
+        assert (written == 1).all()
+        p[atom.element_slice] = o
+    assert not np.isnan(p).any()
+    names = ["00", "01", "10", "11"]
+    for i, c in enumerate(circuits):
+        outs = lay.outcomes_for_index(i)
+        row = ds[tuple(c)]; src = getattr(row, "outcomes", row)
+        assert [o[0] for o in outs] == [(o if isinstance(o, str) else o[0]) for o in src if (o if isinstance(o, str) else o[0]) != "leak"]
+        ref = fx["probs"][4 * i:4 * i + 4]
+        assert_bitwise(p[lay.indices_for_index(i)], ref[[names.index(o[0]) for o in outs]], "circuit %d" % i)
+        assert lay.outcomes(c) == outs
+    assert full.num_elements == 4 * len(circuits)

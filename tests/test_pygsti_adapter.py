@@ -27,6 +27,9 @@ def test_adapter_plan_matches_pygsti():
     assert isinstance(model.sim, MapForwardSimulator) and model.sim.model is model
     layout = model.sim.create_layout(circuits, array_types=("e", "ep"))      # pyGSTi's own MapCOPALayout
     assert len(layout.atoms) == 2
+    # the adapter skips pyGSTi's prefix-cache pass (the library builds its own trie): trivial table, same results
+    assert all(at.cache_size == 0 and all(row[1] is None for row in at.table.contents) for at in layout.atoms)
+    assert all(at.cache_size > 0 for at in lay_ref.atoms)
     out = np.empty(layout.num_elements)
     for atom in layout.atoms:
         plan = A.atom_plan(model, atom)
