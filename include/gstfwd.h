@@ -99,7 +99,10 @@ typedef struct {
     int32_t max_slots;       /* 0 = default; save slots (LDS-resident states) a walk program may use */
     int32_t fd_split;        /* 0 = auto; 1, 2 or 4 wavefronts share one (task, 64 columns) pair of the FD Jacobian
                                 (rows of every mat-vec split over them; same results, finer scheduling granularity) */
-    int32_t reserved[4];
+    int32_t timing;          /* HIP events behind gst_stats.last_kernel_ms / last_total_ms: 0 = auto (recorded unless the plan
+                                is launch-bound: <= 65,536 states, where six event records were a third of a fill),
+                                1 = always, 2 = never */
+    int32_t reserved[3];
 } gst_options;
 
 typedef struct {

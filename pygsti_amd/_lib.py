@@ -48,7 +48,7 @@ class CircuitsDesc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("target_tasks", C.c_int32), ("max_slots", C.c_int32),
-                ("fd_split", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("fd_split", C.c_int32), ("timing", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class ObjectiveDesc(C.Structure):
@@ -214,7 +214,8 @@ class Plan:
     # -- construction --------------------------------------------------------------------------
     @classmethod
     def from_table(cls, D, n_gates, n_rhos, n_effects, n_elements, cache_size, t_dest, t_start, t_cache, t_rho,
-                   row_ptr, gate_idx, eff_ptr, eff_label, eff_dest, device=-1, target_tasks=0, max_slots=0, fd_split=0):
+                   row_ptr, gate_idx, eff_ptr, eff_label, eff_dest, device=-1, target_tasks=0, max_slots=0, fd_split=0,
+                   timing=0):
         a = dict(t_dest=_i32(t_dest), t_start=_i32(t_start), t_cache=_i32(t_cache), t_rho=_i32(t_rho),
                  row_ptr=_i64(row_ptr), gate_idx=_i32(gate_idx) if len(gate_idx) else np.zeros(1, np.int32),
                  eff_ptr=_i64(eff_ptr), eff_label=_i32(eff_label), eff_dest=_i32(eff_dest))
@@ -222,21 +223,21 @@ class Plan:
                       int(n_elements), _ptr(a["t_dest"]), _ptr(a["t_start"]), _ptr(a["t_cache"]), _ptr(a["t_rho"]),
                       _ptr(a["row_ptr"]), _ptr(a["gate_idx"]), _ptr(a["eff_ptr"]), _ptr(a["eff_label"]),
                       _ptr(a["eff_dest"]))
-        opt = Options(int(device), int(target_tasks), int(max_slots), int(fd_split))
+        opt = Options(int(device), int(target_tasks), int(max_slots), int(fd_split), int(timing))
         h = C.c_void_p()
         check(lib().gst_plan_create_from_table(C.byref(d), C.byref(opt), C.byref(h)))
         return cls(h, int(D), int(n_gates), int(n_rhos), int(n_effects), n_elements)
 
     @classmethod
     def from_circuits(cls, D, n_gates, n_rhos, n_effects, n_elements, circ_rho, circ_ptr, circ_gates,
-                      eff_ptr, eff_label, eff_dest, device=-1, target_tasks=0, max_slots=0, fd_split=0):
+                      eff_ptr, eff_label, eff_dest, device=-1, target_tasks=0, max_slots=0, fd_split=0, timing=0):
         a = dict(circ_rho=_i32(circ_rho), circ_ptr=_i64(circ_ptr),
                  circ_gates=_i32(circ_gates) if len(circ_gates) else np.zeros(1, np.int32),
                  eff_ptr=_i64(eff_ptr), eff_label=_i32(eff_label), eff_dest=_i32(eff_dest))
         d = CircuitsDesc(int(D), int(n_gates), int(n_rhos), int(n_effects), len(a["circ_rho"]), int(n_elements),
                          _ptr(a["circ_rho"]), _ptr(a["circ_ptr"]), _ptr(a["circ_gates"]),
                          _ptr(a["eff_ptr"]), _ptr(a["eff_label"]), _ptr(a["eff_dest"]))
-        opt = Options(int(device), int(target_tasks), int(max_slots), int(fd_split))
+        opt = Options(int(device), int(target_tasks), int(max_slots), int(fd_split), int(timing))
         h = C.c_void_p()
         check(lib().gst_plan_create_from_circuits(C.byref(d), C.byref(opt), C.byref(h)))
         return cls(h, int(D), int(n_gates), int(n_rhos), int(n_effects), n_elements)

@@ -59,6 +59,13 @@ int guarded(F&& body)
     }
 }
 
+// Timing events (HIP events around the dominant kernel / the whole call) cost a few microseconds of device time each;
+// on launch-bound plans (1Q) they were a third of a fill, so they are recorded only when the plan asks for them.
+#define TIME_REC(p, ev)                                                      \
+    do {                                                                     \
+        if ((p)->timing) HIP_TRY(hipEventRecord((p)->ev, (p)->stream));      \
+    } while (0)
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -163,6 +170,8 @@ struct gst_plan {
     bool have_bins = false;
     bool fd_persist = true;             // GST_FD_PERSIST=0: one workgroup per pair, placed by the dispatcher
     bool fd_persist_always = false;     // GST_FD_PERSIST=2: per-SIMD queues whatever the number of pairs
+    bool fd_fused = true;               // GST_FD_FUSED=0: launch-bound plans keep the separate base pass
+    bool cached_fused = false;          // the cached lane tables were packed for the fused form
     std::vector<int32_t> task_cost;     // gst::task_gate_costs, computed at the first FD request
     DevBuf<int32_t> d_wave_row, d_wave_rowidx, d_lane_colidx;
     DevBuf<int32_t> d_node_parent, d_node_sym, d_node_run, d_circ_leaf, d_gate_col0, d_cm_gate, d_cm_rho, d_cm_eff;
@@ -189,6 +198,7 @@ struct gst_plan {
 
     double last_kernel_ms = 0, last_total_ms = 0;
     int64_t last_launches = 0;
+    bool timing = true;         // gst_options.timing: record the HIP events behind gst_stats.last_*_ms
 
     ~gst_plan()
     {
@@ -246,11 +256,17 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (!err.empty()) { delete p; return fail(GST_EINVAL, err); }
     p->device = opt ? opt->device : -1;
     p->fd_split = opt ? opt->fd_split : 0;
+    {   // timing events: auto = only where they are noise (plans that are not launch-bound)
+        const int t = opt ? opt->timing : 0;
+        p->timing = t == 1 || (t != 2 && p->hp.n_state_ids > 65536);
+        if (const char* e = std::getenv("GST_TIMING")) p->timing = std::atoi(e) != 0;
+    }
     if (const char* e = std::getenv("GST_FD_SPLIT")) p->fd_split = std::atoi(e);     // development override
     if (const char* e = std::getenv("GST_ANALYTIC_PAIRS")) p->ana_pairs = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_ANALYTIC_GERM_ORDER")) p->ana_germ_order = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_PERSIST")) { p->fd_persist = std::atoi(e) != 0; p->fd_persist_always = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
     return GST_OK;
@@ -363,7 +379,8 @@ struct LaneLayout {
 // perturb the same gate (the special-row work is paid per gate per wavefront): SPAM parameters are
 // packed together, each gate's parameters start on a wavefront boundary when the gate has >= 32
 // requested parameters.
-void pack_lanes(const gst_plan* p, const int64_t* param_idx, const int64_t* dest_idx, int64_t n, LaneLayout& L)
+void pack_lanes(const gst_plan* p, const int64_t* param_idx, const int64_t* dest_idx, int64_t n, LaneLayout& L,
+                bool keep_lane63_idle = false)
 {
     struct Item { int32_t kind, obj, elem, col; };
     std::vector<Item> spam, none;
@@ -375,7 +392,9 @@ void pack_lanes(const gst_plan* p, const int64_t* param_idx, const int64_t* dest
         else if (it.kind == GST_KIND_NONE) none.push_back(it);
         else spam.push_back(it);
     }
+    auto idle = [&]() { L.col.push_back(-1); L.kind[0].push_back(GST_KIND_NONE); L.obj[0].push_back(0); L.elem[0].push_back(0); };
     auto push = [&](const Item& it) {
+        if (keep_lane63_idle && L.col.size() % 64 == 63) idle();       // (fused base lane: see WalkArgs::fused)
         L.col.push_back(it.col); L.kind[0].push_back(it.kind); L.obj[0].push_back(it.obj); L.elem[0].push_back(it.elem);
     };
     auto pad = [&]() {
@@ -387,6 +406,7 @@ void pack_lanes(const gst_plan* p, const int64_t* param_idx, const int64_t* dest
         if (g.size() >= 32) pad();
         for (auto& it : g) push(it);
     }
+    if (keep_lane63_idle && L.col.empty()) idle();
     pad();
     L.n_waves = (int32_t)(L.col.size() / 64);
 }
@@ -424,10 +444,16 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
 {
     // base probabilities (pyx:349)
     double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
-    int rc = run_probs(p, d_base, n_param > 0);
+    const bool rows = (p->hp.D == 64);
+    // Launch-bound plans (1Q fits: a fill is two ~30 us chains behind each other): ONE launch -- lane 63 of every
+    // wavefront walks the unperturbed model, so neither the base pass nor its state cache is needed.  Not for
+    // complement effects (their columns are evaluated on the cached final states) and not for the Hessian driver's
+    // passes (d_raw), which reuse the base pass's by-products.
+    const bool fused = !rows && n_param > 0 && p->hp.n_state_ids <= 65536 && p->comp_index < 0 && !d_raw && p->fd_fused;
+    int rc = fused ? GST_OK : run_probs(p, d_base, n_param > 0);
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
-    const bool rows = (p->hp.D == 64);
+    if (p->cached_fused != fused) p->cached_kind = 0;
     if (!p->request_cached(1, param_idx, dest_idx, n_param)) {
         // (an optimizer asks for the same columns every iteration: pack and upload the lane tables once)
         p->cached_kind = 0;            // nothing below may leave a half-updated request looking cached when it fails
@@ -458,8 +484,9 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         const int64_t* l_dest = filtered ? w_dest.data() : dest_idx;
         const int64_t l_n = filtered ? (int64_t)w_idx.size() : n_param;
         if (rows) pack_waves(p, l_idx, l_dest, l_n, L);     // one perturbed model per wavefront
-        else pack_lanes(p, l_idx, l_dest, l_n, L);
+        else pack_lanes(p, l_idx, l_dest, l_n, L, fused);
         p->cached_kind = 0;
+        p->cached_fused = fused;
         if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
         if ((rc = upload_i32(p->d_lane[1], L.kind[0], p->stream))) return rc;
         if ((rc = upload_i32(p->d_lane[2], L.obj[0], p->stream))) return rc;
@@ -557,6 +584,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     a.out = d_out; a.ld = ld; a.eps = eps; a.pbase = d_base;
     a.raw = d_raw; a.ldraw = ldraw;
     a.base_cache = p->d_base_cache.p;
+    a.fused = fused ? 1 : 0; a.probs_out = fused ? d_base : nullptr;
     a.lanes.col = p->d_lane[0].p; a.lanes.kind[0] = p->d_lane[1].p; a.lanes.obj[0] = p->d_lane[2].p; a.lanes.elem[0] = p->d_lane[3].p;
     a.n_pwaves = p->cached_n_waves;
     a.block_order = p->have_block_order ? p->d_block_order.p : nullptr;
@@ -567,7 +595,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         HIP_TRY(hipMemsetAsync(p->d_trace.p, 0, 8, p->stream));
         a.trace = (unsigned long long*)p->d_trace.p;
     }
-    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    TIME_REC(p, evk0);
     if (p->comp_index >= 0 && !p->ecol_tab.empty()) {
         const int D = p->hp.D;
         const int32_t nc = (int32_t)(p->ecol_tab.size() / 4);
@@ -619,7 +647,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         } else
             HIP_TRY(gst::launch_walk(p->hp.D, 1, a, p->hp.n_tasks(), p->hp.max_slots, p->stream, split));
     }
-    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    TIME_REC(p, evk1);
     p->last_launches++;
     if (a.trace) {
         std::vector<uint64_t> h(1 + 4 * n_trace);
@@ -793,8 +821,10 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (h.D != 4 && h.D != 16 && h.D != 64) return fail(GST_EUNSUPPORTED, "the analytic mode supports D = 4, 16 and 64");
     if (h.D == 64 && !p->ana_mfma) return fail(GST_EUNSUPPORTED, "D = 64 analytic derivatives exist on the MFMA path only");
     double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
-    // (the backward chain pass needs only the model arrays already on their way: it forks here, onto the second stream)
-    HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
+    // (the backward chain pass needs only the model arrays already on their way: it forks here, onto the second stream --
+    //  only where the two-cache contraction will run: a plain 1Q Jacobian is launch-bound and takes the single kernel)
+    const bool will_fork = p->ana_mfma && (h.D != 4 || p->want_cache_path);
+    if (will_fork) HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
     int rc = run_probs(p, d_base, n_param > 0);        // probabilities + every forward state
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
@@ -865,7 +895,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (!chain_ok && p->want_cache_path)
         return fail(GST_EUNSUPPORTED, "exact Hessians at D <= 16 need the gate set in LDS (at most " +
                                           std::to_string(128 * 1024 / (D * D * 8)) + " gates at this D)");
-    if (p->ana_mfma && caches_small && chain_ok && (D != 4 || p->want_cache_path)) {
+    if (will_fork && caches_small && chain_ok) {
         if ((rc = ensure_reverse(p))) return rc;
         if ((double)p->rev.n_state_ids * h.n_effects * D * 8 >= 4.0e9)
             return fail(GST_EUNSUPPORTED, "backward-state cache exceeds 4 GB: set GST_ANALYTIC_MFMA=0 for this plan");
@@ -882,7 +912,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         HIP_TRY(p->d_rev_cache.ensure((size_t)p->rev.n_state_ids * h.n_effects * D));
         w.base_cache_w = p->d_rev_cache.p;
         w.multi_start = h.n_effects;
-        HIP_TRY(hipEventRecord(p->evk0, p->stream));
+        TIME_REC(p, evk0);
         // Both chain passes are latency-bound (one wavefront per task, a fraction of the SIMDs): the backward one runs
         // on the second stream beside the forward pass launched above, and the contraction waits for both.
         HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
@@ -906,15 +936,15 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
         else if (D == 16) HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
         else HIP_TRY(gst::launch_analytic_small(a, p->stream));
-        HIP_TRY(hipEventRecord(p->evk1, p->stream));
+        TIME_REC(p, evk1);
         p->last_launches++;
         p->last_ana = a; p->last_ana_valid = true;     // (the Hessian rows re-launch the contraction with other caches)
         return GST_OK;
     }
     if (D == 64) return fail(GST_EUNSUPPORTED, "D = 64 analytic derivatives exist on the MFMA path only");
-    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    TIME_REC(p, evk0);
     HIP_TRY(gst::launch_analytic(D, a, p->stream));
-    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    TIME_REC(p, evk1);
     p->last_launches++;
     return GST_OK;
 }
@@ -983,7 +1013,7 @@ int run_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, const 
         if ((rc = upload_i32(p->d_mm_dest, dest32, p->stream))) return rc;
     } else if (n_models > ld) return fail(GST_EINVAL, "more model sets than columns");
     std::vector<double> stage((size_t)chunk * stride);
-    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    TIME_REC(p, evk0);
     for (int64_t m0 = 0; m0 < n_models; m0 += chunk) {
         const int64_t nm = std::min<int64_t>(chunk, n_models - m0);
         for (int64_t m = 0; m < nm; m++) {
@@ -1009,7 +1039,7 @@ int run_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, const 
         p->last_launches += 2;
         HIP_TRY(hipStreamSynchronize(p->stream));          // the staging vector is refilled by the next chunk
     }
-    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    TIME_REC(p, evk1);
     return GST_OK;
 }
 
@@ -1021,20 +1051,20 @@ int begin_call(gst_plan* p)
     if (!p->have_model) return fail(GST_ESTATE, "gst_set_model has not been called");
     p->last_launches = 0;
     p->last_kernel_ms = 0;
-    HIP_TRY(hipEventRecord(p->ev0, p->stream));
-    HIP_TRY(hipEventRecord(p->evk0, p->stream));
-    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    TIME_REC(p, ev0);
+    TIME_REC(p, evk0);
+    TIME_REC(p, evk1);
     return upload_model(p);
 }
 
 int end_call(gst_plan* p, bool sync)
 {
-    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    TIME_REC(p, ev1);
     if (sync) {
         HIP_TRY(hipStreamSynchronize(p->stream));
         float ms = 0;
-        if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_total_ms = ms;
-        if (hipEventElapsedTime(&ms, p->evk0, p->evk1) == hipSuccess) p->last_kernel_ms = ms;
+        if (p->timing && hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_total_ms = ms;
+        if (p->timing && hipEventElapsedTime(&ms, p->evk0, p->evk1) == hipSuccess) p->last_kernel_ms = ms;
     }
     return GST_OK;
 }
@@ -1341,9 +1371,9 @@ int gst_fill_probs_dev(gst_plan* p, double* d_out)
     int rc = begin_call(p);
     if (rc) return rc;
     if (!d_out) return fail(GST_EINVAL, "d_out is NULL");
-    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    TIME_REC(p, evk0);
     if ((rc = run_probs(p, d_out, false))) return rc;
-    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    TIME_REC(p, evk1);
     return end_call(p, false);
     });
 }
@@ -1354,9 +1384,9 @@ int gst_fill_probs(gst_plan* p, double* out)
     int rc = begin_call(p);
     if (rc) return rc;
     if (!out) return fail(GST_EINVAL, "out is NULL");
-    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    TIME_REC(p, evk0);
     if ((rc = run_probs(p, p->d_pbase.p, false))) return rc;
-    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    TIME_REC(p, evk1);
     HIP_TRY(hipMemcpyAsync(out, p->d_pbase.p, p->hp.n_elements * 8, hipMemcpyDeviceToHost, p->stream));
     return end_call(p, true);
     });
@@ -1519,7 +1549,7 @@ static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, co
     }
     a.wave_row = p->d_wave_row.p; a.wave_rowidx = p->d_wave_rowidx.p; a.lane_colidx = p->d_lane_colidx.p;
     a.n_pwaves = L.n_waves;
-    HIP_TRY(hipEventRecord(p->evk0, p->stream));
+    TIME_REC(p, evk0);
     if (rows) {
         a.rows_S = 2;
         HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
@@ -1535,7 +1565,7 @@ static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, co
         }
         HIP_TRY(gst::launch_walk(p->hp.D, 2, a, p->hp.n_tasks(), p->hp.max_slots, p->stream, 1, comp));
     }
-    HIP_TRY(hipEventRecord(p->evk1, p->stream));
+    TIME_REC(p, evk1);
     p->last_launches++;
     return GST_OK;
 }
@@ -1893,16 +1923,16 @@ int gst_fill_jtj_dev(gst_plan* p, double* d_J, int64_t n_rows, int64_t n_cols, i
     if (!p || !d_J || !d_jtj || n_rows < 0 || n_cols < 0 || ld < n_cols || n_cols > 0x7fffffff) return fail(GST_EINVAL, "bad argument");
     int rc = ensure_device(p);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    TIME_REC(p, ev0);
     if (d_row_scale && n_rows > 0 && n_cols > 0) HIP_TRY(gst::launch_scale_rows(d_J, n_rows, n_cols, ld, d_row_scale, p->stream));
     if (n_cols > 0) {
         const int n_slabs = gst::jtj_num_slabs(n_rows, (int)n_cols);
         HIP_TRY(p->d_jtj_part.ensure((size_t)n_slabs * n_cols * n_cols));
-        HIP_TRY(hipEventRecord(p->evk0, p->stream));
+        TIME_REC(p, evk0);
         HIP_TRY(gst::launch_jtj(d_J, n_rows, (int)n_cols, ld, p->d_jtj_part.p, n_slabs, d_jtj, p->stream));
-        HIP_TRY(hipEventRecord(p->evk1, p->stream));
+        TIME_REC(p, evk1);
     }
-    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    TIME_REC(p, ev1);
     return GST_OK;
     });
 }
@@ -2029,8 +2059,8 @@ int gst_sync(gst_plan* p)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     float ms = 0;
-    if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_total_ms = ms;
-    if (hipEventElapsedTime(&ms, p->evk0, p->evk1) == hipSuccess) p->last_kernel_ms = ms;
+    if (p->timing && hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_total_ms = ms;
+    if (p->timing && hipEventElapsedTime(&ms, p->evk0, p->evk1) == hipSuccess) p->last_kernel_ms = ms;
     return GST_OK;
     });
 }

@@ -104,6 +104,28 @@ __device__ __forceinline__ void matvec_t(cdouble_p __restrict__ Mt, const int i0
     for (int i = 0; i < RPW; i++) o[i] = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; s++) r[s] = 0.0;
+    if constexpr (D == 4 && RPW == D) {
+        // D = 4 walks are launch / latency bound: a column is only 10 VALU instructions, far less than the ~95 cycles one
+        // scalar load takes, so the column pipeline degenerates into four exposed round trips per mat-vec.  The whole
+        // 4 x 4 gate (16 coefficients, two s_load_dwordx16) is fetched with ONE wait instead.
+        double c[D * D];
+        {
+            cdouble_p p = Mt;
+            asm volatile("" : "+s"(p));
+#pragma unroll
+            for (int i = 0; i < D * D; i++) c[i] = p[i];
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const double vj = v[j];
+#pragma unroll
+            for (int i = 0; i < D; i++) o[i] = o[i] + c[j * D + i] * vj;
+#pragma unroll
+            for (int s = 0; s < NS; s++) r[s] = r[s] + sp[s][j] * vj;
+        }
+        return;
+    }
     double cur[CPS][RPW], nxt[CPS][RPW];
 #pragma unroll
     for (int c = 0; c < CPS; c++) {
@@ -366,6 +388,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
     bool wave_rho = false, wave_eff = false;
 #pragma unroll
     for (int s = 0; s < S; s++) { wave_gates |= gate_mask[s]; wave_rho = wave_rho || rho_any[s]; wave_eff = wave_eff || eff_any[s]; }
+    if (S == 1 && a.fused) wave_rho = true;     // fused base lane: every path starts from the preparation, nothing is "clean"
     bool dirty = (S == 0);
     int32_t cur_id = 0;
     int32_t slot_tag[MAXSLOT];          // >= 0: the slot "holds" clean state id; -1: real data in LDS
@@ -541,7 +564,15 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
                 if (c->mode == EMIT_PROBS) {
                     if (col >= 0) c->out[dest] = p;
                 } else if (c->mode == EMIT_FD) {
-                    if (col >= 0) {
+                    if (S == 1 && c->fused) {
+                        // the base model's probability sits in lane 63 of this very wavefront
+                        const long long pbits = __double_as_longlong(p);
+                        const int plo = __builtin_amdgcn_readlane((int)(pbits & 0xffffffffLL), 63);
+                        const int phi = __builtin_amdgcn_readlane((int)(pbits >> 32), 63);
+                        const double pb = __longlong_as_double(((long long)phi << 32) | (unsigned int)plo);
+                        if (col >= 0) c->out[dest * c->ld + col] = (p - pb) / c->eps;
+                        if (lane == 63 && pw == 0 && c->probs_out) c->probs_out[dest] = p;
+                    } else if (col >= 0) {
                         const double pb = as_const(c->pbase)[dest];
                         c->out[dest * c->ld + col] = (p - pb) / c->eps;
                         if (c->raw) c->raw[dest * c->ldraw + col] = p;

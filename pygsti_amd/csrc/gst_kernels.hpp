@@ -58,6 +58,11 @@ struct WalkArgs {
     int32_t n_models;
     int64_t model_stride, out_model_stride;
     int32_t mm_tasks;        // number of tasks (walk_base_kernel derives (task, model) from blockIdx.x)
+    // Fused base lane (launch-bound plans, S = 1): lane 63 of every wavefront carries NO perturbation, i.e. the base
+    // model; the quotient uses ITS probability instead of pbase[], nothing is taken from the base-state cache, and the
+    // separate base pass is not launched at all.  Lane 63 of parameter wavefront 0 writes probs_out (may be NULL).
+    int32_t fused;
+    double* probs_out;
     int32_t n_pwaves;        // wavefronts along the parameter dimension (grid.x)
     int32_t rows_S;          // walk_rows_kernel only: number of perturbations per wavefront (0, 1, 2); its
                              // `lanes` tables then hold ONE entry per wavefront instead of one per lane

@@ -129,7 +129,10 @@ def test_kind_none_columns_are_exact_zero():
 
 def test_stats_report_device_time():
     fx = load_fixture("smq1Q_XYI_L128_depol")
-    pl = plan_from_fixture(fx)
+    pl = plan_from_fixture(fx, timing=1)         # (launch-bound plans record no timing events unless asked: gst_options.timing)
     pl.fill_dprobs()
     st = pl.stats()
     assert st['last_kernel_ms'] > 0 and st['last_total_ms'] >= st['last_kernel_ms']
+    quiet = plan_from_fixture(fx)
+    quiet.fill_dprobs()
+    assert quiet.stats()['last_kernel_ms'] == 0

@@ -31,7 +31,19 @@ def one_q():
     t_fd = timed(lambda: plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_FD), plan, 200)
     t_an = timed(lambda: plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_ANALYTIC), plan, 200)
     st = plan.stats()
+    # one blocking fill at a time (what a caller that needs the result sees), host arrays included
+    J = np.empty((nE, nP)); pr = np.empty(nE)
+    def lat(fn, reps=200):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+    l_p = lat(lambda: plan.fill_probs(pr))
+    l_fd = lat(lambda: plan.fill_dprobs(J, pidx, None, 1e-7, pr, _lib.DERIV_FD))
+    l_an = lat(lambda: plan.fill_dprobs(J, pidx, None, 1e-7, pr, _lib.DERIV_ANALYTIC))
     return {"config": "smq1Q_XYI L<=128 (BASELINE configs[1]): %d circuits, nE=%d, nP=%d, D=4" % (len(circuits), nE, nP),
+            "blocking_host_fill_us": {"probs": 1e6 * l_p, "dprobs_fd": 1e6 * l_fd, "dprobs_analytic": 1e6 * l_an},
             "probs_us": 1e6 * t_p, "probs_per_s": nE / t_p,
             "dprobs_fd_us": 1e6 * t_fd, "dprobs_fd_el_per_s": nE * nP / t_fd,
             "dprobs_analytic_us": 1e6 * t_an, "dprobs_analytic_el_per_s": nE * nP / t_an,
