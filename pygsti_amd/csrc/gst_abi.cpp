@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <queue>
+#include <set>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -171,6 +172,14 @@ struct gst_plan {
     bool fd_persist = true;             // GST_FD_PERSIST=0: one workgroup per pair, placed by the dispatcher
     bool fd_persist_always = false;     // GST_FD_PERSIST=2: per-SIMD queues whatever the number of pairs
     bool fd_fused = true;               // GST_FD_FUSED=0: launch-bound plans keep the separate base pass
+    int fd_handover = 1;                // GST_FD_HANDOVER: 0 never cut a walk, 1 cut to balance the per-SIMD queues, 2 cut every walk
+    bool split_ready = false;
+    std::vector<int32_t> split_pc;      // gst::task_split_points
+    std::vector<float> split_frac;
+    int32_t n_split = 0;
+    DevBuf<int32_t> d_task_split_pc, d_ho_index, d_ho_id;
+    DevBuf<uint32_t> d_ho_flag;
+    DevBuf<double> d_ho_state;
     bool cached_fused = false;          // the cached lane tables were packed for the fused form
     std::vector<int32_t> task_cost;     // gst::task_gate_costs, computed at the first FD request
     DevBuf<int32_t> d_wave_row, d_wave_rowidx, d_lane_colidx;
@@ -220,6 +229,7 @@ struct gst_plan {
             if (ev_upload[i]) (void)hipEventDestroy(ev_upload[i]);
         }
         d_mm_models.release(); d_mm_raw.release(); d_mm_dest.release();
+        d_task_split_pc.release(); d_ho_index.release(); d_ho_id.release(); d_ho_flag.release(); d_ho_state.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
         d_wave_row.release(); d_wave_rowidx.release(); d_lane_colidx.release();
@@ -267,6 +277,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_FD_PERSIST")) { p->fd_persist = std::atoi(e) != 0; p->fd_persist_always = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_FD_HANDOVER")) p->fd_handover = std::atoi(e);
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
     return GST_OK;
@@ -546,29 +557,105 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
             // placement is as good or better, so the queues are used below 10 pairs per SIMD -- and not below one pair
             // per SIMD, where a fill is launch-bound and the extra memset and pops cost 10 us (1Q L<=128: 100 vs 110 us).
             p->have_bins = false;
-            if (!rows && p->fd_persist && p->hp.max_slots <= 4 && (p->fd_persist_always || (items.size() <= (size_t)40 * p->n_cus && items.size() >= (size_t)4 * p->n_cus)) &&
+            if (!rows && p->fd_persist && p->hp.max_slots <= 4 && items.size() < (1u << 30) && (p->fd_persist_always || (items.size() <= (size_t)40 * p->n_cus && items.size() >= (size_t)4 * p->n_cus)) &&
                 (size_t)16 * std::max(p->hp.max_slots, 1) * p->hp.D * 64 * 8 <= 160 * 1024) {
                 const int n_bins = 4 * p->n_cus;
-                std::vector<std::vector<uint32_t>> bins(n_bins);
+                struct BinItem { uint32_t id; int64_t cost; int32_t part; };
+                std::vector<std::vector<BinItem>> bins(n_bins);
+                std::vector<int64_t> load((size_t)n_bins, 0);
                 typedef std::pair<int64_t, int32_t> LB;                  // (load, queue): min-heap
-                std::priority_queue<LB, std::vector<LB>, std::greater<LB>> heap;
-                for (int b = 0; b < n_bins; b++) heap.emplace(0, b);
-                for (const auto& it : items) {
-                    LB t = heap.top(); heap.pop();
-                    bins[t.second].push_back(it.second);
-                    heap.emplace(t.first + (int64_t)(-it.first) + 8, t.second);
+                {
+                    std::priority_queue<LB, std::vector<LB>, std::greater<LB>> heap;
+                    for (int b = 0; b < n_bins; b++) heap.emplace(0, b);
+                    for (const auto& it : items) {
+                        LB t = heap.top(); heap.pop();
+                        const int64_t c = (int64_t)(-it.first) + 8;
+                        bins[t.second].push_back(BinItem{it.second, c, 0});
+                        load[(size_t)t.second] = t.first + c;
+                        heap.emplace(t.first + c, t.second);
+                    }
+                }
+                // Hand-over: with 2-3 whole-chain walks per SIMD the queues differ by a whole walk.  A walk of an overfull
+                // queue is cut at its task's slot-free middle (gst::task_split_points): the first half stays -- at the
+                // FRONT of its queue, so that it runs first -- and the second half goes to the END of the emptiest
+                // queue, whose wavefront waits for the first half's states.  Same program words, same arithmetic, same
+                // bits; the kernel's run time follows the fullest queue.
+                int32_t n_split = 0;
+                std::vector<int32_t> ho_index;
+                if (p->fd_handover != 0) {
+                    if (!p->split_ready) {
+                        gst::task_split_points(p->hp, p->split_pc, p->split_frac);
+                        if ((rc = upload_i32(p->d_task_split_pc, p->split_pc, p->stream))) return rc;
+                        p->split_ready = true;
+                    }
+                    ho_index.assign((size_t)nT * (size_t)n_units, -1);
+                    int64_t total = 0;
+                    for (int64_t l : load) total += l;
+                    const int64_t mean = total / n_bins;
+                    std::set<LB> by_load;
+                    for (int b = 0; b < n_bins; b++) by_load.emplace(load[(size_t)b], b);
+                    const bool force = p->fd_handover == 2;              // (tests: cut every walk that can be cut)
+                    for (int iter = 0; iter < 4 * n_bins && by_load.size() >= 2; iter++) {
+                        const LB top = *by_load.rbegin();
+                        const int bmax = top.second;
+                        int best = -1;
+                        for (size_t k = 0; k < bins[(size_t)bmax].size(); k++) {
+                            const BinItem& bi = bins[(size_t)bmax][k];
+                            const int64_t t = (int64_t)(bi.id / (uint32_t)n_units);
+                            if (bi.part != 0 || p->split_pc[(size_t)t] < 0) continue;
+                            if (!force && bi.cost < std::max<int64_t>(64, mean / 4)) continue;
+                            if (best < 0 || bi.cost > bins[(size_t)bmax][(size_t)best].cost) best = (int)k;
+                        }
+                        if (best < 0) { by_load.erase(top); continue; }  // nothing to cut in the fullest queue: look at the next
+                        const LB low = *by_load.begin();
+                        const int bmin = low.second;
+                        BinItem whole = bins[(size_t)bmax][(size_t)best];
+                        const double frac = p->split_frac[(size_t)(whole.id / (uint32_t)n_units)];
+                        const int64_t c1 = (int64_t)((double)whole.cost * frac) + 24, c2 = whole.cost - (int64_t)((double)whole.cost * frac) + 24;
+                        const int64_t new_hi = std::max(load[(size_t)bmax] - whole.cost + c1, load[(size_t)bmin] + c2);
+                        if (bmin == bmax) break;
+                        if (!force && new_hi + 16 >= load[(size_t)bmax]) { by_load.erase(top); continue; }   // no gain here: next queue
+                        by_load.erase(top); by_load.erase(low);
+                        bins[(size_t)bmax].erase(bins[(size_t)bmax].begin() + best);
+                        bins[(size_t)bmax].insert(bins[(size_t)bmax].begin(), BinItem{whole.id, c1, 1});
+                        {   // second half: in cost order behind the receiver's longer items (not behind its short ones:
+                            // picked up late, its work would land at the very end of that queue)
+                            auto& rb = bins[(size_t)bmin];
+                            size_t at = 0;
+                            while (at < rb.size() && (rb[at].part == 1 || rb[at].cost >= c2)) at++;
+                            rb.insert(rb.begin() + (long)at, BinItem{whole.id, c2, 2});
+                        }
+                        load[(size_t)bmax] += c1 - whole.cost;
+                        load[(size_t)bmin] += c2;
+                        ho_index[(size_t)whole.id] = n_split++;
+                        if (bmin != bmax) by_load.emplace(load[(size_t)bmin], bmin);
+                        by_load.emplace(load[(size_t)bmax], bmax);
+                    }
                 }
                 std::vector<int32_t> bptr(n_bins + 1, 0);
                 std::vector<uint32_t> bitems;
-                bitems.reserve(items.size());
+                bitems.reserve(items.size() + (size_t)n_split);
                 for (int b = 0; b < n_bins; b++) {
-                    bitems.insert(bitems.end(), bins[b].begin(), bins[b].end());
+                    for (const BinItem& bi : bins[(size_t)b]) bitems.push_back(bi.id | ((uint32_t)bi.part << 30));
                     bptr[b + 1] = (int32_t)bitems.size();
                 }
                 if ((rc = upload_i32(p->d_bin_ptr, bptr, p->stream))) return rc;
                 HIP_TRY(p->d_bin_items.ensure(bitems.size()));
                 HIP_TRY(hipMemcpyAsync(p->d_bin_items.p, bitems.data(), bitems.size() * 4, hipMemcpyHostToDevice, p->stream));
                 HIP_TRY(p->d_bin_head.ensure(n_bins));
+                p->n_split = n_split;
+                if (std::getenv("GST_FD_DEBUG")) {
+                    int64_t lo = load[0], hi = load[0];
+                    for (int64_t l : load) { lo = std::min(lo, l); hi = std::max(hi, l); }
+                    std::fprintf(stderr, "[gstfwd] per-SIMD queues: %zu pairs, %d hand-overs, estimated load min %lld max %lld\n",
+                                 items.size(), n_split, (long long)lo, (long long)hi);
+                }
+                if (n_split > 0) {
+                    if ((rc = upload_i32(p->d_ho_index, ho_index, p->stream))) return rc;
+                    HIP_TRY(p->d_ho_state.ensure((size_t)n_split * p->hp.D * 64));
+                    HIP_TRY(p->d_ho_id.ensure((size_t)n_split));
+                    HIP_TRY(p->d_ho_flag.ensure((size_t)n_split));
+                }
                 HIP_TRY(hipStreamSynchronize(p->stream));
                 p->n_bins = n_bins;
                 p->have_bins = true;
@@ -589,7 +676,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     a.n_pwaves = p->cached_n_waves;
     a.block_order = p->have_block_order ? p->d_block_order.p : nullptr;
     const char* trace_path = std::getenv("GST_FD_TRACE");          // development aid: per-pair timestamps (tools/trace_stats.py)
-    const size_t n_trace = (size_t)p->hp.n_tasks() * (size_t)std::max(p->cached_n_waves, 1);
+    const size_t n_trace = (size_t)p->hp.n_tasks() * (size_t)std::max(p->cached_n_waves, 1) + (size_t)std::max(p->n_split, 0);
     if (trace_path && !rows) {
         HIP_TRY(p->d_trace.ensure(1 + 4 * n_trace));
         HIP_TRY(hipMemsetAsync(p->d_trace.p, 0, 8, p->stream));
@@ -641,6 +728,11 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         if (split == 1 && p->have_bins && p->have_block_order) {
             // persistent launch: one 16-wavefront workgroup per CU, pairs popped from the per-SIMD queues
             a.bin_ptr = p->d_bin_ptr.p; a.bin_items = p->d_bin_items.p; a.bin_head = p->d_bin_head.p; a.n_bins = p->n_bins;
+            if (p->n_split > 0) {
+                a.task_split_pc = p->d_task_split_pc.p; a.ho_index = p->d_ho_index.p; a.ho_state = p->d_ho_state.p;
+                a.ho_id = p->d_ho_id.p; a.ho_flag = p->d_ho_flag.p;
+                HIP_TRY(hipMemsetAsync(p->d_ho_flag.p, 0, (size_t)p->n_split * 4, p->stream));
+            }
             a.lds_wave_doubles = std::max(p->hp.max_slots, 1) * p->hp.D * 64;
             HIP_TRY(hipMemsetAsync(p->d_bin_head.p, 0, (size_t)p->n_bins * 4, p->stream));
             HIP_TRY(gst::launch_walk_persistent(p->hp.D, a, p->n_cus, p->hp.max_slots, p->stream));

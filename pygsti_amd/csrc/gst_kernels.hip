@@ -211,6 +211,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
     const int i0 = wv * RPW;                 // first state row this wavefront computes
   for (;;) {                                 // PERSIST: one iteration per popped pair; otherwise exactly one
     int64_t bid;
+    int32_t part = 0;                        // PERSIST: 0 whole pair, 1 first half (up to the split), 2 second half
     if constexpr (PERSIST) {
         const GST_CONST WalkArgs* c = (const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr();
         uint32_t* const head = c->bin_head;
@@ -248,7 +249,9 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
             }
         }
         if (item < 0) break;
-        bid = (int64_t)__builtin_amdgcn_readfirstlane((int)item);
+        const uint32_t raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+        part = (int32_t)(raw >> 30);
+        bid = (int64_t)(raw & 0x3fffffffu);
     } else {
         bid = a.block_order ? (int64_t)a.block_order[blockIdx.x] : (int64_t)blockIdx.x;
     }
@@ -430,9 +433,54 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
             out = out || (((g) < 64) ? ((own_mask[s_] >> (g)) & 1ull) : (own_mask[s_] != 0));         \
     } while (0)
 
+    int32_t stop_pc = -1, ho = -1;
+    if constexpr (PERSIST) {
+        if (part != 0) {
+            const GST_CONST WalkArgs* c = cold();
+            stop_pc = as_const(c->task_split_pc)[task];
+            ho = as_const(c->ho_index)[bid];
+        }
+        if (part == 2) {
+            // second half: the first half (on another SIMD, possibly another XCD with its own L2) stores the lane states
+            // and then raises the flag
+            const GST_CONST WalkArgs* c = cold();
+            uint32_t* const flag = c->ho_flag + ho;
+            // (every access to the hand-over buffers is a system-scope relaxed atomic, i.e. a load / store that bypasses
+            //  the non-coherent caches: no fence, hence no write-back or invalidation of a whole L2, is needed)
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) __builtin_amdgcn_s_sleep(64);
+            const int32_t id = __hip_atomic_load(c->ho_id + ho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (id >= 0) { dirty = false; cur_id = id; }
+            else {
+                double* hs = c->ho_state + (int64_t)ho * D * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < D; j++) v[j] = __hip_atomic_load(hs + j * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                dirty = true;
+            }
+            pc = stop_pc;
+            wbase = stop_pc & ~63;
+            win_cur = (wbase + lane < n_words) ? gprog[wbase + lane] : 0u;
+            win_nxt = (wbase + 64 + lane < n_words) ? gprog[wbase + 64 + lane] : 0u;
+        }
+    }
     GST_FETCH();
     for (;;) {
         if (op == GST_OP_END) break;
+        if constexpr (PERSIST) {
+            if (part == 1 && pc - 1 == stop_pc) {
+                // first half done: hand the walk over (no save slot is live here, so the state is everything)
+                const GST_CONST WalkArgs* c = cold();
+                if (dirty) {
+                    double* hs = c->ho_state + (int64_t)ho * D * 64 + lane;
+#pragma unroll
+                    for (int j = 0; j < D; j++) __hip_atomic_store(hs + j * 64, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (lane == 0) __hip_atomic_store(c->ho_id + ho, dirty ? -1 : cur_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __builtin_amdgcn_s_waitcnt(0);           // the write-through stores above have been acknowledged
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) __hip_atomic_store(c->ho_flag + ho, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
         if (op == GST_OP_APPLY) {
             // Runs of (APPLY, NODE) pairs -- the chains of the trie -- are handled in two tight inner loops so
             // that the state vector stays in place (one loop-carried definition) instead of being shuffled

@@ -47,6 +47,14 @@ struct WalkArgs {
     uint32_t* bin_head;            // [n_bins] next unpopped position (zeroed before the launch)
     int32_t n_bins;
     int32_t lds_wave_doubles;      // LDS doubles (save slots) per wavefront of the workgroup
+    // hand-over of a walk between two SIMDs (persistent launch): queue items carry a part in their top two bits --
+    // 1: walk the pair up to its task's split position, store the 64 lane states, raise the flag; 2: wait for the
+    // flag, pick the states up, walk the rest (gst::task_split_points)
+    const int32_t* task_split_pc;  // [n_tasks] word index relative to the task start, or -1
+    const int32_t* ho_index;       // [n_tasks * n_pwaves] hand-over buffer of a split pair, or -1
+    double* ho_state;              // [n_split][D][64]
+    int32_t* ho_id;                // [n_split] >= 0: the state is the clean base state of that id (nothing stored)
+    uint32_t* ho_flag;             // [n_split] zeroed before the launch
     unsigned long long* trace;     // development aid (GST_FD_TRACE): [0] = record count, then (pair, t0, t1, hw_id) records
     // TP POVM complement in the Hessian pass (walk_kernel's COMP): effect comp_index = identity - sum(others)
     int32_t comp_index, n_others;

@@ -3,6 +3,7 @@
 #include "gst_plan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -388,6 +389,46 @@ void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost)
             else if (op == GST_OP_RHO) dirty = 0;
             else if (op == GST_OP_EMIT) c[nG + 1]++;
         }
+    }
+}
+
+void task_split_points(const HostPlan& P, std::vector<int32_t>& split_pc, std::vector<float>& split_frac)
+{
+    const int64_t nT = P.n_tasks();
+    split_pc.assign((size_t)nT, -1);
+    split_frac.assign((size_t)nT, 0.0f);
+    std::vector<uint64_t> live;
+    for (int64_t t = 0; t < nT; t++) {
+        const int64_t k0 = P.task_off[t], k1 = P.task_off[t + 1];
+        const int64_t n = k1 - k0;
+        if (n < 64) continue;
+        // backward liveness of the save slots: live[k] = slots that hold data some later LOAD still needs, before word k
+        live.assign((size_t)n + 1, 0);
+        bool ok = true;
+        for (int64_t k = n - 1; k >= 0; k--) {
+            const uint32_t w = P.prog[k0 + k], op = GST_OP(w), arg = GST_ARG(w);
+            uint64_t l = live[(size_t)k + 1];
+            if (op == GST_OP_LOAD || op == GST_OP_SAVE) {
+                if (arg >= 64) { ok = false; break; }
+                if (op == GST_OP_LOAD) l |= 1ull << arg; else l &= ~(1ull << arg);
+            }
+            live[(size_t)k] = l;
+        }
+        if (!ok) continue;
+        const int64_t total = P.task_applies[(size_t)t];
+        if (total < 32) continue;
+        int64_t before = 0, best = -1, best_before = 0;
+        for (int64_t k = 0; k < n; k++) {
+            const uint32_t w = P.prog[k0 + k], op = GST_OP(w);
+            const bool after_load = k > 0 && GST_OP(P.prog[k0 + k - 1]) == GST_OP_LOAD;
+            if (k > 2 && live[(size_t)k] == 0 && (op == GST_OP_EMIT || after_load) && op != GST_OP_END) {
+                if (best < 0 || std::llabs(2 * before - total) < std::llabs(2 * best_before - total)) { best = k; best_before = before; }
+            }
+            if (op == GST_OP_APPLY) before++;
+        }
+        if (best < 0 || 10 * best_before < 3 * total || 10 * best_before > 7 * total) continue;     // (no useful middle)
+        split_pc[(size_t)t] = (int32_t)best;
+        split_frac[(size_t)t] = (float)best_before / (float)total;
     }
 }
 

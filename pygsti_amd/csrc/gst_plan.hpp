@@ -58,6 +58,13 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots);
 // (task, wavefront) pairs first.  Empty result when n_gates > 64.
 void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost);
 
+// Hand-over points of the derivative walks (persistent launch of small atoms): for every task a program position
+// (word index relative to the task's first word, or -1) at which NO save slot is live, so that a walk can be cut there
+// into two halves that run on different SIMDs -- the first stores its 64 lane states, the second picks them up -- and
+// the fraction of the task's gate applications that lie before it.  The position closest to the middle is chosen; it
+// is always an op the interpreter's outer loop sees (the word after a LOAD, or an EMIT).
+void task_split_points(const HostPlan& P, std::vector<int32_t>& split_pc, std::vector<float>& split_frac);
+
 // Analytic derivatives (gst_kernels_analytic.hip, MFMA path): the plan of the REVERSED circuits (one dummy start, the
 // gates of every circuit in reverse order, no effects).  Walking it with the transposed gates from every effect
 // vector gives the backward states B_k = (G_n ... G_{k+1})^T E shared over common SUFFIXES, exactly as the forward

@@ -43,6 +43,23 @@ def test_dprobs_fd_row_split_variants_bitwise(fd_split):
         assert_bitwise(J, fx['dprobs_map'], "dprobs fd_split=%d %s" % (fd_split, name))
 
 
+@pytest.mark.parametrize("handover", ["0", "1", "2"])
+def test_dprobs_fd_walk_handover_bitwise(handover, monkeypatch):
+    """Persistent launch with walks cut at their task's slot-free middle and handed from one SIMD to another
+    (GST_FD_HANDOVER=2: every walk that can be cut; 1: only to balance the queues; 0: never): the second half picks up
+    the 64 lane states the first half stored -- same program words, same arithmetic, same bits."""
+    monkeypatch.setenv("GST_FD_PERSIST", "2")
+    monkeypatch.setenv("GST_FD_HANDOVER", handover)
+    for name in ("smq2Q_XYICNOT_L1024_deep", "smq2Q_XYICNOT_L2_depol", "smq1Q_XYI_L128_depol"):
+        fx = load_fixture(name)
+        for tt in (0, 3):
+            pl = plan_from_fixture(fx, target_tasks=tt)
+            pr = np.empty(int(fx['nE']))
+            J = pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']), probs_out=pr)
+            assert_bitwise(J, fx['dprobs_map'], "dprobs GST_FD_HANDOVER=%s %s tasks=%d" % (handover, name, tt))
+            assert_bitwise(pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps'])), J, "repeat " + name)
+
+
 @pytest.mark.parametrize("mode", ["0", "2"])
 def test_dprobs_fd_launch_forms_bitwise(mode, monkeypatch):
     """The two forms of the FD launch -- one workgroup per (task, wavefront) pair placed by the dispatcher
