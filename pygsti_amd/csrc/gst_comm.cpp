@@ -63,16 +63,18 @@ std::mutex g_rccl_mutex;
 RcclApi g_rccl;
 std::string g_rccl_error;
 
-// An already loaded librccl (e.g. the copy PyTorch ships, same SONAME) is reused so that a process never holds two.
 int load_rccl(const RcclApi** out)
 {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (!g_rccl.handle) {
         if (!g_rccl_error.empty()) return set_error(GST_EUNSUPPORTED, g_rccl_error);
         std::vector<std::string> names;
+        // ROCm's own RCCL first: libgstfwd links ROCm's HIP runtime, and an RCCL built against another runtime release
+        // (e.g. the copy a Python framework bundles, which a bare SONAME lookup would return once that framework is
+        // imported) is not a combination anyone tests
         if (const char* e = std::getenv("GST_RCCL_LIBRARY")) names.push_back(e);
-        names.push_back("librccl.so.1");
         names.push_back("/opt/rocm/lib/librccl.so.1");
+        names.push_back("librccl.so.1");
         names.push_back("librccl.so");
         std::string tried;
         void* h = nullptr;

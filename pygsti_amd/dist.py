@@ -97,6 +97,7 @@ def init(device=None, transport="auto", want_comm=True):
     rank, size, local_rank = env_rank_size()
     if size == 1:
         return DistContext(0, 1, local_rank, None, None)
+    _lib.lib()          # libgstfwd (and with it ROCm's HIP runtime) is loaded BEFORE torch brings its bundled copies
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

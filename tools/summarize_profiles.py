@@ -2,7 +2,7 @@
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof")
+SRC = os.path.join(ROOT, "gpurun_out", os.environ.get("GST_PROF_DIR", "prof"))
 DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
