@@ -497,9 +497,10 @@ def main():
     plan.device_free(d_pfull)
     if world > 1:
         ctx.barrier()
-        ctx.close()
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        with gdist._StdoutToStderr():          # (communicator teardown may print as well)
+            ctx.close()
+            import torch.distributed as dist
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

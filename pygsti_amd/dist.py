@@ -45,6 +45,31 @@ def row_blocks(layout, size):
             for a, at in enumerate(layout.all_atoms)]
 
 
+class _StdoutToStderr:
+    """While active, file descriptor 1 points at stderr, and C stdio is flushed before it is restored: RCCL and gloo
+    print banners to the process's stdout (fully buffered when it is a pipe, i.e. they would surface at exit), which
+    must not end up in front of a caller's own output -- bench.py prints exactly one JSON line there."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        import sys
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class DistContext:
     """Control group (gloo) + data communicator (gst_comm) of this process.  `comm` is None when size == 1 or when
     no device transport could be created (`comm_error` says why): callers then stay on the host paths."""
@@ -101,10 +126,17 @@ def init(device=None, transport="auto", want_comm=True):
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        with _StdoutToStderr():
+            dist.init_process_group("gloo")
     ctx = DistContext(rank, size, local_rank, None, None)
     if not want_comm:
         return ctx
+    with _StdoutToStderr():
+        _create_comm(ctx, rank, size, local_rank, device, transport)
+    return ctx
+
+
+def _create_comm(ctx, rank, size, local_rank, device, transport):
     transport = os.environ.get("GST_TRANSPORT", transport)
     if device is None:
         device = local_rank % max(_lib.device_count(), 1)
@@ -131,7 +163,6 @@ def init(device=None, transport="auto", want_comm=True):
             comm.close()
         errors.append("%s transport: %s" % (tr, err or "failed on another rank"))
     ctx.comm_error = "; ".join(errors) if errors else None
-    return ctx
 
 
 # ---- device arrays -------------------------------------------------------------------------------------------------
