@@ -63,6 +63,7 @@ class HipMapForwardSimulator:
         # "analytic": exact first derivatives, what MatrixForwardSimulator computes (matrixforwardsim.py:1059-1140)
         assert derivative_mode in ("fd", "analytic")
         self.derivative_mode = derivative_mode
+        self.concurrent_fills = None     # None: two-phase (enqueue everywhere, then collect) fills when atoms sit on several GPUs
         if model is not None:
             self.model = model
 
@@ -156,7 +157,28 @@ class HipMapForwardSimulator:
             array_to_fill[...] = tmp
 
     # -- bulk fills (forwardsim.py:584-753, distforwardsim.py:92-234) ------------------------------------------------
+    def _concurrent_devices(self, layout):
+        """Several atoms on several GPUs in ONE process (SURVEY 8(e)'s single-process shortcut, `devices=[0..7]`): the
+        fills are enqueued on every atom's own stream first and collected afterwards, so the GPUs work side by side."""
+        if self.concurrent_fills is not None:
+            return bool(self.concurrent_fills) and len(layout.atoms) > 1
+        return len(layout.atoms) > 1 and len({at.device for at in layout.atoms}) > 1
+
     def bulk_fill_probs(self, array_to_fill, layout):
+        if self._concurrent_devices(layout):
+            jobs = []
+            for atom in layout.atoms:
+                plan = self._prepare_atom(atom)
+                d = plan.workspace("bfp", atom.num_elements * 8)
+                plan.fill_probs_dev(d)                               # asynchronous, on the atom's device
+                jobs.append((atom, plan, d))
+            for atom, plan, d in jobs:
+                out = array_to_fill[atom.element_slice]
+                if out.flags.c_contiguous:
+                    plan.memcpy_d2h(out, d)                         # waits for that device only
+                else:
+                    out[...] = plan.memcpy_d2h(np.empty(atom.num_elements), d)
+            return
         for atom in layout.atoms:
             self._bulk_fill_probs_atom(array_to_fill[atom.element_slice], atom)
 
@@ -164,6 +186,26 @@ class HipMapForwardSimulator:
         blk = layout.param_dimension_blk_sizes[0]
         gps = layout.global_param_slice
         Np = _slice_len(gps, self.model.num_params)
+        if blk is None and self._concurrent_devices(layout) and array_to_fill.flags.c_contiguous and Np > 0 \
+                and array_to_fill.shape[1] == Np:
+            pidx = _to_index_array(gps, self.model.num_params)
+            mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
+            jobs = []
+            for atom in layout.atoms:
+                plan = self._prepare_atom(atom)
+                d_J = plan.workspace("bfJ", atom.num_elements * Np * 8)
+                d_p = plan.workspace("bfp", atom.num_elements * 8)
+                plan.fill_dprobs_dev(d_J, Np, pidx, None, self.derivative_eps, d_p, mode)      # asynchronous
+                jobs.append((atom, plan, d_J, d_p))
+            for atom, plan, d_J, d_p in jobs:
+                plan.memcpy_d2h(array_to_fill[atom.element_slice, :], d_J)
+                if pr_array_to_fill is not None:
+                    pr = pr_array_to_fill[atom.element_slice]
+                    if pr.flags.c_contiguous:
+                        plan.memcpy_d2h(pr, d_p)
+                    else:
+                        pr[...] = plan.memcpy_d2h(np.empty(atom.num_elements), d_p)
+            return
         for atom in layout.atoms:
             es = atom.element_slice
             pr = None if pr_array_to_fill is None else pr_array_to_fill[es]

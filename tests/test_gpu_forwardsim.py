@@ -194,3 +194,16 @@ def test_dataset_restricted_layout_on_device():
     order = np.concatenate([np.arange(*lay.indices_for_index(i).indices(lay.num_elements)) for i in range(len(circuits))])
     assert_bitwise(p[order], fx["probs"][rows], "dataset-restricted probs")
     assert_bitwise(J[order], fx["dprobs_map"][rows], "dataset-restricted dprobs")
+
+
+def test_two_phase_fills_over_several_atoms_bitwise():
+    """The single-process multi-GPU form of bulk_fill_probs / bulk_fill_dprobs (all atoms enqueued on their own streams,
+    then collected) -- forced here on one device -- gives the same bits as the atom-by-atom loop."""
+    fx, model, sim, circuits, layout = _setup("smq1Q_XYI_L128_depol", MP.smq1Q_XYI, 128, num_atoms=4)
+    sim.concurrent_fills = True
+    p = layout.allocate_local_array("e", "d"); sim.bulk_fill_probs(p, layout)
+    J = layout.allocate_local_array("ep", "d"); pr = layout.allocate_local_array("e", "d")
+    sim.bulk_fill_dprobs(J, layout, pr_array_to_fill=pr)
+    assert_bitwise(_by_circuit(p, layout, circuits), fx["probs"], "two-phase probs")
+    assert_bitwise(_by_circuit(pr, layout, circuits), fx["probs"], "two-phase pr_array_to_fill")
+    assert_bitwise(_by_circuit(J, layout, circuits), fx["dprobs_map"], "two-phase dprobs")
