@@ -87,3 +87,35 @@ def test_walk_kernels_have_no_fma_outside_division():
     n_mul = len(re.findall(r"\bv_mul_f64\b", asm))
     assert n_mul > 1000
     assert n_div > 0 and n_fma <= 8 * n_div, (n_fma, n_div)
+
+
+def test_comm_entry_points_fail_loudly_without_a_device():
+    """The exchange entry points validate their arguments and need a device; the IPC rendezvous token is plain data."""
+    uid = _lib.Comm.unique_id(_lib.TRANSPORT_IPC)
+    assert len(uid) == _lib.COMM_ID_BYTES and uid.startswith(b"/gstfwd_")
+    assert _lib.Comm.unique_id(_lib.TRANSPORT_IPC) != uid
+    with pytest.raises(ValueError):
+        _lib.Comm.unique_id(7)                                   # unknown transport
+    with pytest.raises(ValueError):
+        _lib.Comm(3, 2, uid, 0, _lib.TRANSPORT_IPC)               # rank >= size
+    if _no_gpu():
+        with pytest.raises(_lib.GstDeviceError):
+            _lib.Comm(0, 1, uid, 0, _lib.TRANSPORT_IPC)
+        assert _lib.pin_host_array(np.zeros(1 << 20)) is False    # stays pageable, no exception
+
+
+def test_bad_plan_descriptions_are_rejected_not_fatal():
+    """Negative sizes / offsets come back as ValueError (GST_EINVAL): nothing may reach std::terminate across the ABI."""
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    args = [fx['D'], 3, 1, 2, fx['nE'], fx['cache_size'], fx['t_dest'], fx['t_start'], fx['t_cache'], fx['t_rho'],
+            fx['row_ptr'], fx['gate_idx'], fx['eff_ptr'], fx['eff_label'], fx['eff_dest']]
+    bad = list(args); bad[4] = -5
+    with pytest.raises(ValueError):
+        _lib.Plan.from_table(*bad)
+    bad = list(args); ep = np.array(fx['eff_ptr']).copy(); ep[-1] = -1; bad[12] = ep
+    with pytest.raises(ValueError):
+        _lib.Plan.from_table(*bad)
+    n = len(fx['circ_ptr']) - 1
+    with pytest.raises(ValueError):
+        _lib.Plan.from_circuits(fx['D'], 3, 1, 2, -1, np.zeros(n, np.int32), fx['circ_ptr'], fx['circ_gates'],
+                                np.arange(n + 1) * 2, np.tile([0, 1], n), np.arange(2 * n))

@@ -131,3 +131,38 @@ def test_analytic_hprobs_1q_vs_matrix_simulator(name):
     full = pl.fill_hprobs(mode=_lib.DERIV_ANALYTIC)                       # the whole nP x nP Hessian of every element
     assert np.abs(full - np.transpose(full, (0, 2, 1))).max() < 1e-11     # symmetric
     assert np.array_equal(full[:, fx["hprobs_rows"]][:, :, fx["hprobs_cols"]], H)
+
+
+def test_exact_hessian_refuses_forward_derivative_caches_beyond_4gb():
+    """The contraction kernels address the derivative-state caches with 32-bit byte offsets: a plan whose FORWARD trie is
+    large (8.4 M states: 4 x 16 x 8 bytes each = 4.3 GB of dF) while its suffix trie is small must be refused loudly, not
+    answered with wrapped offsets (round-1 advisor finding).  8,400 circuits of depth 1,000: distinct random prefixes of
+    200 gates in front of one common suffix of 800."""
+    from pygsti_amd import _lib
+    rng = np.random.default_rng(0)
+    D, nG, nEl, nC, L = 16, 6, 4, 8400, 1000
+    suffix = rng.integers(0, nG, 800)
+    circs = [np.concatenate([rng.integers(0, nG, L - 800), suffix]) for _ in range(nC)]
+    ptr = np.arange(nC + 1, dtype=np.int64) * L
+    g = np.concatenate(circs).astype(np.int32)
+    nE = nC * nEl
+    pl = _lib.Plan.from_circuits(D, nG, 1, nEl, nE, np.zeros(nC, np.int32), ptr, g, np.arange(nC + 1, dtype=np.int64) * nEl,
+                                 np.tile(np.arange(nEl, dtype=np.int32), nC), np.arange(nE, dtype=np.int32))
+    st = pl.stats()
+    assert st["trie_nodes"] > 8.3e6
+    gates = np.eye(D)[None] * 0.98 + 0.01 * rng.standard_normal((nG, D, D))
+    rho = np.zeros((1, D)); rho[0, 0] = 0.5
+    eff = 0.05 * rng.standard_normal((nEl, D)); eff[:, 0] += 0.5
+    pl.set_model(gates, rho, eff)
+    nP = D + nEl * D + nG * D * D
+    kind = np.concatenate([np.full(D, 1), np.full(nEl * D, 2), np.full(nG * D * D, 0)]).astype(np.int32)
+    obj = np.concatenate([np.zeros(D), np.repeat(np.arange(nEl), D), np.repeat(np.arange(nG), D * D)]).astype(np.int32)
+    elem = np.concatenate([np.arange(D), np.tile(np.arange(D), nEl), np.tile(np.arange(D * D), nG)]).astype(np.int32)
+    pl.set_param_map(kind, obj, elem)
+    out = np.zeros((nE, 1, 2))
+    with pytest.raises(_lib.GstError, match="4 GB"):
+        pl.fill_hprobs(out, np.array([80]), np.array([81, 82]), mode=_lib.DERIV_ANALYTIC)
+    # the Jacobian of the same plan is fine (its caches are below the limit) and probabilities still sum to ~1 per circuit
+    p = pl.fill_probs()
+    assert np.isfinite(p).all()
+    pl.close()
