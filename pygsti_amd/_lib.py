@@ -376,6 +376,28 @@ class Plan:
                                            _ptr(probs_out)))
         return out
 
+    def fill_hprobs_models(self, gates, rhos, effects, eps=1e-5):
+        """FD-of-FD Hessian block from two-level perturbed dense model sets, composed exactly as
+        MapForwardSimulator._mapfill_hprobs_atom does (mapforwardsim.py:420-436): gates [n1+1, n2+1, nG, D, D] (rhos,
+        effects alike); [r, 0] is the model at theta (r = 0) or theta + eps e_{i_r} (r >= 1), [r, 1+c] that model after the
+        FD step of column parameter c.  Row r's Jacobian block comes from gst_fill_dprobs_models with [r, 0] as the base
+        model; H[:, r-1, :] = (dprobs_r - dprobs_0) / eps on the host, as the reference's numpy line does."""
+        r = _f64(rhos)
+        n1p, n2p = r.shape[0], r.shape[1]
+        g = _f64(gates).reshape(n1p, n2p, self.n_gates, self.D, self.D)
+        r = r.reshape(n1p, n2p, self.n_rhos, self.D)
+        e = _f64(effects).reshape(n1p, n2p, self.n_effects, self.D)
+        H = np.empty((self.n_elements, n1p - 1, n2p - 1), np.float64)
+        d0 = None
+        for k in range(n1p):
+            self.set_model(g[k, 0], r[k, 0], e[k, 0])
+            dk = self.fill_dprobs_models(g[k, 1:], r[k, 1:], e[k, 1:], eps=eps)
+            if k == 0:
+                d0 = dk
+            else:
+                H[:, k - 1, :] = (dk - d0) / eps
+        return H
+
     def fill_hprobs(self, out=None, idx1=None, idx2=None, dest1=None, dest2=None, eps=1e-5, mode=DERIV_FD):
         i1 = _i64(np.arange(self.n_params) if idx1 is None else idx1)
         i2 = _i64(np.arange(self.n_params) if idx2 is None else idx2)

@@ -22,8 +22,8 @@ for Hessians, finite differences bit-identical to the Map simulator.  Any other 
 members, shared parameters ...): finite-difference Jacobians by stepping the model on the host exactly as the reference
 does and evaluating every perturbed dense model on the device (gst_fill_dprobs_models; to rounding, <= 1e-8 against the
 Map simulator), and with `derivative_mode="analytic"` exact Jacobians / Hessians through the members'
-`deriv_wrt_params()` / `hessian_wrt_params()` (gst_set_derivs).  FD-of-FD Hessians of such models raise
-NotImplementedError -- there is no silent fallback to the CPU path.
+`deriv_wrt_params()` / `hessian_wrt_params()` (gst_set_derivs); their FD-of-FD Hessian blocks are composed from
+model-set Jacobians exactly as `_mapfill_hprobs_atom` composes them.  There is no silent fallback to the CPU path.
 """
 import numpy as np
 
@@ -344,6 +344,31 @@ class HipMapForwardSimulator(_MapForwardSimulator):
             # exact Hessians of a general parameterisation: members that are not linear in their parameters also send
             # their hessian_wrt_params (the objects and their order are atom_derivs')
             plan.set_second_derivs(atom_second_derivs(self.model, layout_atom))
+        elif hmode == "models":
+            # FD of FD over a general parameterisation, composed as _mapfill_hprobs_atom does (mapforwardsim.py:420-436):
+            # the model is moved to theta + eps e_i on the host, its FD Jacobian over block 2 comes from the device
+            # (model sets), and (dprobs2 - dprobs) / eps is the reference's own numpy line
+            eps = self.hessian_eps
+            nP = self.model.num_params
+            i1 = np.arange(nP) if param_slice1 is None else _slct.to_array(param_slice1)
+            i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)
+            d1 = np.arange(len(i1)) if dest_param_slice1 is None else _slct.to_array(dest_param_slice1)
+            d2 = np.arange(len(i2)) if dest_param_slice2 is None else _slct.to_array(dest_param_slice2)
+            orig = self.model.to_vector().copy()
+
+            def dprobs_here():
+                G, R, E = atom_model_sets(self.model, layout_atom, i2, eps)
+                plan.set_model(*atom_arrays(self.model, layout_atom))
+                return plan.fill_dprobs_models(G, R, E, eps=eps)
+            dprobs = dprobs_here()
+            try:
+                for i, i_final in sorted(zip((int(q) for q in i1), (int(q) for q in d1))):
+                    vec = orig.copy(); vec[i] += eps
+                    self.model.from_vector(vec, close=True)
+                    array_to_fill[:, i_final, d2] = (dprobs_here() - dprobs) / eps
+            finally:
+                self.model.from_vector(orig)
+            return
         elif hmode != "elements" and not (hmode == "tp-elements" and self.derivative_mode == "fd"):
             raise NotImplementedError("Hessians on the device: fully parameterised models (FD or exact), full-TP models "
                                       "(FD of FD as the Map simulator computes them, or exact), any parameterisation "

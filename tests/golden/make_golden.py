@@ -233,6 +233,42 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
         assert np.array_equal(model.to_vector(), paramvec)
         out.update(mm_gates=np.array(mg), mm_rhos=np.array(mr), mm_effects=np.array(me))
 
+    if model_sets and want_hprobs:
+        # two-level stepping of _mapfill_hprobs_atom (mapforwardsim.py:420-436): for a few rows i the model at
+        # theta + eps e_i (from_vector(..., close=True)) and, from there, after every FD step over a few columns j
+        # (set_parameter_value(s), pyx:362-381); index 0 of the first axis = the unstepped model
+        eps_h = model.sim.hessian_eps
+        rows2 = np.asarray(hprobs_blk[0], np.int64)[:3]
+        cols2 = np.asarray(hprobs_blk[1], np.int64)[:6]
+
+        def dense_sets2():
+            g = np.array([model._circuit_layer_operator(l, 'op').to_dense('minimal') for l in op_labels])
+            r = np.array([model._circuit_layer_operator(l, 'prep').to_dense('minimal') for l in rho_labels])
+            e = np.array([model._circuit_layer_operator(l, 'povm').to_dense('minimal') for l in eff_labels])
+            return (np.ascontiguousarray(g.real.reshape(len(op_labels), D, D), dtype=np.float64),
+                    np.ascontiguousarray(r.real.reshape(len(rho_labels), D), dtype=np.float64),
+                    np.ascontiguousarray(e.real.reshape(len(eff_labels), D), dtype=np.float64))
+        G2, R2, E2 = [], [], []
+        for i in [None] + [int(q) for q in rows2]:
+            vec = paramvec.copy()
+            if i is not None:
+                vec[i] += eps_h
+            model.from_vector(vec, close=True)
+            gs, rs, es = [], [], []
+            g, r, e = dense_sets2(); gs.append(g); rs.append(r); es.append(e)
+            prev = None
+            for j in (int(q) for q in cols2):
+                if prev is None:
+                    model.set_parameter_value(j, vec[j] + eps_h)
+                else:
+                    model.set_parameter_values([prev, j], [vec[prev], vec[j] + eps_h])
+                g, r, e = dense_sets2(); gs.append(g); rs.append(r); es.append(e)
+                prev = j
+            model.set_parameter_value(prev, vec[prev])
+            G2.append(gs); R2.append(rs); E2.append(es)
+        model.from_vector(paramvec)
+        out.update(mm2_rows=rows2, mm2_cols=cols2, mm2_gates=np.array(G2), mm2_rhos=np.array(R2), mm2_effects=np.array(E2))
+
     if want_hprobs:
         b1, b2 = hprobs_blk
         b1 = np.asarray(b1, np.int64); b2 = np.asarray(b2, np.int64)

@@ -84,3 +84,32 @@ def test_models_fd_equals_element_fd_on_a_full_model(oracle_built):
         G.append(g); R.append(r); E.append(e)
     J = pl.fill_dprobs_models(np.array(G), np.array(R), np.array(E), eps=eps)
     assert_bitwise(J, fx["dprobs_map"][:, ::3], "general path == reference Map FD on a full model")
+
+
+def test_models_fd_of_fd_hessian_block(oracle_built):
+    """FD-of-FD Hessian block of the CPTPLND model from two-level model sets (fixture `mm2_*`: the dense model at
+    theta + eps e_i and after every column step from there): the device composition equals the CPU oracle's bit for bit,
+    and the reference's Map vectors to rounding / eps^2 (1e-16 / 1e-10: the bound is 2e-5 absolute; observed 6.7e-6 at max|H| = 2.0)."""
+    fx = load_fixture("smq1Q_XYI_L4_CPTPLND")
+    eps = float(fx["hessian_eps"])
+    pl = plan_from_fixture(fx)
+    H = pl.fill_hprobs_models(fx["mm2_gates"], fx["mm2_rhos"], fx["mm2_effects"], eps=eps)
+    # the same composition on the CPU oracle
+    O = oracle_built
+    orc = O.from_fixture({k: np.array(v) for k, v in fx.items()})
+    d = []
+    for k in range(fx["mm2_gates"].shape[0]):
+        orc.set_model(fx["mm2_gates"][k, 0], fx["mm2_rhos"][k, 0], fx["mm2_effects"][k, 0]); base = orc.probs()
+        cols = []
+        for c in range(1, fx["mm2_gates"].shape[1]):
+            orc.set_model(fx["mm2_gates"][k, c], fx["mm2_rhos"][k, c], fx["mm2_effects"][k, c])
+            cols.append((orc.probs() - base) / eps)
+        d.append(np.array(cols).T)
+    Ho = np.stack([(d[k] - d[0]) / eps for k in range(1, len(d))], axis=1)
+    assert_bitwise(H, Ho, "FD-of-FD Hessian from model sets vs oracle")
+    rows = [list(fx["hprobs_rows"]).index(r) for r in fx["mm2_rows"]]
+    cols = [list(fx["hprobs_cols"]).index(c) for c in fx["mm2_cols"]]
+    ref = fx["hprobs_map"][:, rows][:, :, cols]
+    err = np.abs(H - ref).max()
+    print("max|hprobs - reference| = %.2e (max|H| = %.2f)" % (err, np.abs(ref).max()))
+    assert err <= 2e-5

@@ -105,3 +105,24 @@ def test_dense_model_sets_reproduce_the_map_fd_of_cptplnd_models(oracle_built, n
         orc.set_model(g, r, e)
         J[:, c] = (orc.probs() - base) / eps
     assert np.abs(J - fx["dprobs_map"]).max() <= jtol, np.abs(J - fx["dprobs_map"]).max()
+
+
+def test_two_level_model_sets_reproduce_the_map_fd_of_fd_hessian(oracle_built):
+    """FD-of-FD Hessian block of the CPTPLND model composed from two-level dense model sets on the oracle vs the
+    reference Map simulator's block: rounding amplified by 1 / eps^2 = 1e10 (bound 2e-5 absolute)."""
+    fx = load_fixture("smq1Q_XYI_L4_CPTPLND")
+    eps = float(fx["hessian_eps"])
+    orc = oracle_built.from_fixture({k: np.array(v) for k, v in fx.items()})
+    d = []
+    for k in range(fx["mm2_gates"].shape[0]):
+        orc.set_model(fx["mm2_gates"][k, 0], fx["mm2_rhos"][k, 0], fx["mm2_effects"][k, 0]); base = orc.probs()
+        cols = []
+        for c in range(1, fx["mm2_gates"].shape[1]):
+            orc.set_model(fx["mm2_gates"][k, c], fx["mm2_rhos"][k, c], fx["mm2_effects"][k, c])
+            cols.append((orc.probs() - base) / eps)
+        d.append(np.array(cols).T)
+    H = np.stack([(d[k] - d[0]) / eps for k in range(1, len(d))], axis=1)
+    rows = [list(fx["hprobs_rows"]).index(r) for r in fx["mm2_rows"]]
+    cols = [list(fx["hprobs_cols"]).index(c) for c in fx["mm2_cols"]]
+    ref = fx["hprobs_map"][:, rows][:, :, cols]
+    assert np.abs(H - ref).max() <= 2e-5, np.abs(H - ref).max()       # observed 6.7e-6 (max|H| = 2.0)

@@ -135,3 +135,10 @@ def test_adapter_general_parameterisation_fd_model_sets():
     if _lib.device_count() == 0:
         with pytest.raises(_lib.GstDeviceError):
             m.sim.bulk_fill_dprobs(np.empty((lay.num_elements, m.num_params)), lay)
+    # FD-of-FD Hessian blocks of the same model: composed from model-set Jacobians (no NotImplementedError any more);
+    # the two-level stepping leaves the model where it was
+    if _lib.device_count() == 0:
+        H = np.empty((lay.num_elements, 2, 3))
+        with pytest.raises(_lib.GstDeviceError):
+            m.sim._bulk_fill_hprobs_atom(H, None, None, atom, np.array([0, 2]), np.array([0, 3, 6]), None)
+        assert np.array_equal(m.to_vector(), v0)
