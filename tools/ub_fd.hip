@@ -88,6 +88,55 @@ __device__ __forceinline__ void matvec_t2h(cdouble_p __restrict__ Mt, const doub
     }
 }
 
+// hybrid feed: even columns through the scalar cache into SGPRs, odd columns broadcast out of LDS into VGPRs (every lane
+// reads the same 16 bytes: ds_read_b128 of a uniform address); a stage is TWO columns, so one wavefront's serial scalar
+// stream (2 loads per stage) has 272 cycles of arithmetic to hide under
+template <int D>
+__device__ __forceinline__ void matvec_hy(cdouble_p __restrict__ Mt, const double* __restrict__ Lt, const double (&v)[D], double (&o)[D],
+                                          const double (&sp)[1][D], double (&r)[1])
+{
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < D; i++) o[i] = 0.0;
+    r[0] = 0.0;
+    double cs[D], ns[D];          // scalar-fed column (SGPRs)
+    double cl[D], nl[D];          // LDS-fed column (VGPRs)
+    {
+        cdouble_p q = Mt;
+        asm volatile("" : "+s"(q));
+#pragma unroll
+        for (int i = 0; i < D; i++) cs[i] = q[i];
+        const d2_t* l = (const d2_t*)__builtin_assume_aligned(Lt + D, 16);
+#pragma unroll
+        for (int i = 0; i < D; i += 2) { const d2_t t = l[i / 2]; cl[i] = t.x; cl[i + 1] = t.y; }
+    }
+#pragma unroll
+    for (int j = 0; j < D; j += 2) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (j + 2 < D) {
+            cdouble_p q = Mt + (j + 2) * D;
+            asm volatile("" : "+s"(q));
+#pragma unroll
+            for (int i = 0; i < D; i++) ns[i] = q[i];
+            const d2_t* l = (const d2_t*)__builtin_assume_aligned(Lt + (j + 3) * D, 16);
+#pragma unroll
+            for (int i = 0; i < D; i += 2) { const d2_t t = l[i / 2]; nl[i] = t.x; nl[i + 1] = t.y; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double v0 = v[j], v1 = v[j + 1];
+#pragma unroll
+        for (int i = 0; i < D; i++) o[i] = o[i] + cs[i] * v0;
+        r[0] = r[0] + sp[0][j] * v0;
+        pin<D>(o);
+#pragma unroll
+        for (int i = 0; i < D; i++) o[i] = o[i] + cl[i] * v1;
+        r[0] = r[0] + sp[0][j + 1] * v1;
+        pin<D>(o);
+#pragma unroll
+        for (int i = 0; i < D; i++) { cs[i] = ns[i]; cl[i] = nl[i]; }
+    }
+}
+
 // half-column stages: one s_load_dwordx16 (8 coefficients) per stage of 16 + 1 VALU pairs
 template <int D>
 __device__ __forceinline__ void matvec_th(cdouble_p __restrict__ Mt, const double (&v)[D], double (&o)[D], const double (&sp)[1][D], double (&r)[1])
@@ -125,7 +174,7 @@ __device__ __forceinline__ void matvec_th(cdouble_p __restrict__ Mt, const doubl
 }
 
 template <int V>
-__global__ __launch_bounds__(64, ((V == 4 || V == 6) ? 2 : 4)) void k(const double* gates_t, int n_apps, double* out, unsigned long long* cyc, const int* chase)
+__global__ __launch_bounds__(64, ((V == 4 || V == 6) ? 2 : (V == 7 ? 3 : 4))) void k(const double* gates_t, int n_apps, double* out, unsigned long long* cyc, const int* chase)
 {
     constexpr int D = 16;
     const int lane = threadIdx.x;
@@ -146,6 +195,19 @@ __global__ __launch_bounds__(64, ((V == 4 || V == 6) ? 2 : 4)) void k(const doub
             g = (g == 5) ? 0 : g + 1;
         }
         for (int j = 0; j < D; j++) v[j] += w[j];
+    } else if constexpr (V == 7) {
+        __shared__ __attribute__((aligned(16))) double ldsG[6 * D * D];
+        for (int k = lane; k < 6 * D * D; k += 64) ldsG[k] = gates_t[k];
+        __syncthreads();
+        int g = 0;
+        for (int s = 0; s < n_apps; s++) {
+            double o[D], r[1];
+            cdouble_p Mt = gt + (int64_t)g * D * D;
+            asm volatile("" : "+s"(Mt));
+            matvec_hy<D>(Mt, ldsG + g * D * D, v, o, sp, r);
+            for (int j = 0; j < D; j++) v[j] = (lane == j) ? r[0] : o[j] * 0.05;
+            g = (g == 5) ? 0 : g + 1;
+        }
     } else if constexpr (V == 5) {
         int g = 0;
         for (int s = 0; s < n_apps; s++) {
@@ -209,9 +271,10 @@ int main()
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const double ghz = prop.clockRate / 1e6;
     printf("device clock %.2f GHz, %d CUs\n", ghz, prop.multiProcessorCount);
-    for (int V = 0; V < 7; V++) {
+    for (int V : {0, 5, 7}) {
         for (int W : {1, 2, 3, 4}) {
             if ((V == 4 || V == 6) && W > 2) continue;
+            if (V == 7 && W > 3) continue;
             const int blocks = 1024 * W;
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             for (int rep = 0; rep < 2; rep++) {
@@ -221,6 +284,7 @@ int main()
                 if (V == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(64), 0, 0, d_g, n_apps, d_out, d_c, d_chase);
                 if (V == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(64), 0, 0, d_g, n_apps, d_out, d_c, d_chase);
                 if (V == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(64), 0, 0, d_g, n_apps, d_out, d_c, d_chase);
+                if (V == 7) hipLaunchKernelGGL(k<7>, dim3(blocks), dim3(64), 0, 0, d_g, n_apps, d_out, d_c, d_chase);
                 if (V == 6) hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(64), 0, 0, d_g, n_apps, d_out, d_c, d_chase);
                 if (V == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(64), 0, 0, d_g, n_apps, d_out, d_c, d_chase);
                 hipEventRecord(e1); hipEventSynchronize(e1);
