@@ -130,7 +130,8 @@ struct IpcMailbox {
     IpcSlot slot[IPC_MAX_RANKS];
 };
 
-struct OpenedHandle { uint64_t alloc_id = 0; void* base = nullptr; };
+struct OpenedHandle { uint64_t alloc_id = 0; void* base = nullptr; uint64_t last_use = 0; };
+constexpr int IPC_MAPPINGS_PER_PEER = 8;       // a peer's destinations alternate (Jacobian, probabilities, staging ...)
 
 }  // namespace
 
@@ -146,14 +147,15 @@ struct gst_comm {
     std::string shm_name;
     uint32_t local_sense = 0;
     uint64_t next_alloc_id = 1;
-    std::vector<OpenedHandle> opened;                     // per peer rank: the mapping of its current destination
+    std::vector<OpenedHandle> opened;                     // per peer rank: IPC_MAPPINGS_PER_PEER mappings of its recent destinations
+    uint64_t use_clock = 0;
     double* stage = nullptr;                              // all-reduce staging [size][stage_n]
     size_t stage_n = 0;
 };
 
 namespace {
 
-int ipc_barrier(gst_comm* c)
+int ipc_barrier(gst_comm* c, long timeout_s = 600)
 {
     IpcMailbox* b = c->box;
     c->local_sense ^= 1u;
@@ -169,7 +171,7 @@ int ipc_barrier(gst_comm* c)
             if ((spins & 0xffff) == 0) {
                 struct timespec t1;
                 clock_gettime(CLOCK_MONOTONIC, &t1);
-                if (t1.tv_sec - t0.tv_sec > 600) return set_error(GST_EHIP, "IPC barrier timed out (a peer rank is gone?)");
+                if (t1.tv_sec - t0.tv_sec > timeout_s) return set_error(GST_EHIP, "IPC barrier timed out (a peer rank is gone?)");
             }
         }
     }
@@ -198,13 +200,23 @@ int ipc_publish(gst_comm* c, const void* ptr)
 int ipc_peer_ptr(gst_comm* c, int r, char** out)
 {
     const IpcSlot& s = c->box->slot[r];
-    OpenedHandle& o = c->opened[(size_t)r];
-    if (o.alloc_id != s.alloc_id) {
-        if (o.base) { (void)hipIpcCloseMemHandle(o.base); o.base = nullptr; o.alloc_id = 0; }
+    OpenedHandle* set = &c->opened[(size_t)r * IPC_MAPPINGS_PER_PEER];
+    OpenedHandle* hit = nullptr;
+    OpenedHandle* lru = nullptr;               // victim: an empty entry if there is one, else the least recently used
+    for (int k = 0; k < IPC_MAPPINGS_PER_PEER; k++) {
+        if (set[k].base && set[k].alloc_id == s.alloc_id) hit = &set[k];
+        if (!lru) lru = &set[k];
+        else if (lru->base && (!set[k].base || set[k].last_use < lru->last_use)) lru = &set[k];
+    }
+    if (!hit) {
+        if (lru->base) { (void)hipIpcCloseMemHandle(lru->base); lru->base = nullptr; lru->alloc_id = 0; }
         void* p = nullptr;
         HIP_TRYC(hipIpcOpenMemHandle(&p, s.handle, hipIpcMemLazyEnablePeerAccess));
-        o.base = p; o.alloc_id = s.alloc_id;
+        lru->base = p; lru->alloc_id = s.alloc_id;
+        hit = lru;
     }
+    hit->last_use = ++c->use_clock;
+    OpenedHandle& o = *hit;
     *out = (char*)o.base + s.offset;
     return GST_OK;
 }
@@ -411,7 +423,7 @@ int gst_comm_create(int transport, int device, int rank, int size, const void* i
             if (m == MAP_FAILED) { (void)hipStreamDestroy(c->stream); delete c; return set_error(GST_EHIP, "mmap of the shared-memory mailbox failed"); }
             c->box = (IpcMailbox*)m;          // (a fresh segment is zero-filled: counters start at 0)
             if (rank == 0) c->box->size = (uint32_t)size;
-            c->opened.assign((size_t)size, OpenedHandle());
+            c->opened.assign((size_t)size * IPC_MAPPINGS_PER_PEER, OpenedHandle());
             c->box->attached.fetch_add(1, std::memory_order_acq_rel);
             struct timespec t0;
             clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -444,7 +456,7 @@ int gst_comm_destroy(gst_comm* c)
         if (c->transport == GST_TRANSPORT_RCCL) {
             if (c->nccl) (void)c->api->CommDestroy(c->nccl);
         } else if (c->box) {
-            (void)ipc_barrier(c);                   // nobody unmaps a buffer a peer may still be writing
+            (void)ipc_barrier(c, 15);               // nobody unmaps a buffer a peer may still be writing (a vanished peer: move on)
             for (auto& o : c->opened) if (o.base) (void)hipIpcCloseMemHandle(o.base);
             munmap(c->box, sizeof(IpcMailbox));
         }
