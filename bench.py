@@ -415,7 +415,7 @@ def main():
         host_fill = {"ms": 1e3 * t_host, "elements_per_s": nE_local * nP / t_host, "GBps": 8.0 * nE_local * nP / t_host / 1e9,
                      "pinned": bool(getattr(layout, "last_array_pinned", False)),
                      "note": "gst_fill_dprobs into a host numpy 'ep' array from layout.allocate_local_array (what "
-                             "bulk_fill_dprobs(array, layout) returns in the reference): kernel + 7 GB over PCIe; never `value`"}
+                             "bulk_fill_dprobs(array, layout) returns in the reference): the FD kernel stores 7 GB straight into the page-locked array over PCIe; never `value`"}
         layout.free_local_array(J_host)
         log("host-fill leg done: %.1f ms per fill" % (1e3 * t_host))
 

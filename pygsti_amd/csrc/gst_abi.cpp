@@ -172,6 +172,7 @@ struct gst_plan {
     bool fd_persist = true;             // GST_FD_PERSIST=0: one workgroup per pair, placed by the dispatcher
     bool fd_persist_always = false;     // GST_FD_PERSIST=2: per-SIMD queues whatever the number of pairs
     bool fd_fused = true;               // GST_FD_FUSED=0: launch-bound plans keep the separate base pass
+    bool host_direct = true;            // GST_HOST_DIRECT=0: page-locked destinations are filled by a copy, not by the kernel
     int fd_handover = 1;                // GST_FD_HANDOVER: 0 never cut a walk, 1 cut to balance the per-SIMD queues, 2 cut every walk
     bool split_ready = false;
     std::vector<int32_t> split_pc;      // gst::task_split_points
@@ -277,6 +278,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_FD_PERSIST")) { p->fd_persist = std::atoi(e) != 0; p->fd_persist_always = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_HOST_DIRECT")) p->host_direct = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_HANDOVER")) p->fd_handover = std::atoi(e);
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
@@ -1163,6 +1165,28 @@ int end_call(gst_plan* p, bool sync)
 
 }  // namespace
 
+namespace {
+// Host regions the caller page-locked through gst_host_register (mapped into the device's address space): fills whose
+// destination lies inside one write their results straight into it.
+std::mutex g_reg_mutex;
+std::vector<std::pair<char*, size_t>> g_registered;
+
+// Device address of a host pointer inside a registered region covering [ptr, ptr + bytes), or nullptr.
+void* mapped_device_pointer(const void* ptr, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_reg_mutex);
+    for (const auto& r : g_registered) {
+        if ((const char*)ptr >= r.first && (const char*)ptr + bytes <= r.first + r.second) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, const_cast<void*>(ptr), 0) == hipSuccess) return d;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    return nullptr;
+}
+}  // namespace
+
 namespace gst {
 int set_error(int code, const std::string& msg) { return fail(code, msg); }
 int plan_ensure_device(gst_plan* plan) { return plan ? ensure_device(plan) : fail(GST_EINVAL, "plan is NULL"); }
@@ -1521,6 +1545,18 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     if (!p->derivs_set && (rc = check_params(p, param_idx, n_param))) return rc;
     if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
     const int64_t nE = p->hp.n_elements;
+    // A page-locked destination (gst_host_register): the FD kernel writes the Jacobian straight into it -- 512-byte row
+    // segments over PCIe while the walk is still computing -- instead of filling 7 GB of HBM first and copying afterwards
+    // (kernel and transfer overlap completely; the (ld, dest_idx) window is honoured by the kernel itself).
+    if (!p->derivs_set && mode == GST_DERIV_FD && n_param > 0 && nE > 0 && p->hp.D <= 16 && p->comp_index < 0 && p->host_direct) {
+        int64_t max_col = 0;
+        for (int64_t c = 0; c < n_param; c++) max_col = std::max<int64_t>(max_col, dest_idx ? dest_idx[c] : c);
+        if (void* d_host = mapped_device_pointer(out, (size_t)((nE - 1) * ld + max_col + 1) * 8)) {
+            if ((rc = run_dprobs_fd(p, (double*)d_host, ld, param_idx, dest_idx, n_param, eps, nullptr, nullptr, 0))) return rc;
+            if (probs_out) HIP_TRY(hipMemcpyAsync(probs_out, p->d_pbase.p, nE * 8, hipMemcpyDeviceToHost, p->stream));
+            return end_call(p, true);
+        }
+    }
     // device staging is dense [nE][n_param]; scattered into the caller's (ld, dest_idx) window on the host
     HIP_TRY(p->d_out.ensure((size_t)nE * std::max<int64_t>(n_param, 1)));
     if (p->derivs_set) rc = run_dprobs_general(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
@@ -2126,7 +2162,11 @@ int gst_host_register(void* ptr, int64_t nbytes)
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
         if (e != hipSuccess || n <= 0) return fail(GST_ENODEVICE, std::string("no HIP device available (") + hipGetErrorString(e) + ")");
-        HIP_TRY(hipHostRegister(ptr, (size_t)nbytes, hipHostRegisterPortable));
+        HIP_TRY(hipHostRegister(ptr, (size_t)nbytes, hipHostRegisterPortable | hipHostRegisterMapped));
+        {
+            std::lock_guard<std::mutex> lock(g_reg_mutex);
+            g_registered.emplace_back((char*)ptr, (size_t)nbytes);
+        }
         return GST_OK;
     });
 }
@@ -2138,6 +2178,11 @@ int gst_host_unregister(void* ptr)
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
         if (e != hipSuccess || n <= 0) return fail(GST_ENODEVICE, std::string("no HIP device available (") + hipGetErrorString(e) + ")");
+        {
+            std::lock_guard<std::mutex> lock(g_reg_mutex);
+            for (size_t k = 0; k < g_registered.size(); k++)
+                if (g_registered[k].first == (char*)ptr) { g_registered.erase(g_registered.begin() + (long)k); break; }
+        }
         HIP_TRY(hipHostUnregister(ptr));
         return GST_OK;
     });

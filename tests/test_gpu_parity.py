@@ -89,6 +89,33 @@ def test_dprobs_column_window_and_dest_indices():
     assert_bitwise(full[:, 3:11], fx['dprobs_map'][:, 0:8], "view")
 
 
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq2Q_XYICNOT_L2_depol"])
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_dprobs_into_page_locked_array_bitwise(name, direct, monkeypatch):
+    """A destination registered with gst_host_register is written by the FD kernel itself (GST_HOST_DIRECT=1, default) or
+    by a copy from HBM (=0): same bits as the reference either way, (ld, dest_idx) window honoured, nothing outside it
+    touched, and a later pageable destination still works."""
+    from pygsti_amd import _lib
+    monkeypatch.setenv("GST_HOST_DIRECT", direct)
+    fx = load_fixture(name)
+    pl = plan_from_fixture(fx)
+    cols = fx["dprobs_cols"]; nE, n = int(fx["nE"]), len(cols)
+    full = np.full((nE, n + 7), -7.0)
+    assert _lib.pin_host_array(full)
+    pr = np.empty(nE)
+    try:
+        pl.fill_dprobs(out=full, param_idx=cols, dest_idx=np.arange(n) + 3, eps=float(fx["derivative_eps"]), probs_out=pr)
+        assert_bitwise(full[:, 3:3 + n], fx["dprobs_map"], "page-locked destination")
+        assert_bitwise(pr, fx["probs"], "probs_out")
+        assert (full[:, :3] == -7.0).all() and (full[:, 3 + n:] == -7.0).all()
+        # a window that starts inside the registered region
+        pl.fill_dprobs(out=full[:, 1:], param_idx=cols[:5], dest_idx=None, eps=1e-7)
+        assert_bitwise(full[:, 1:6], fx["dprobs_map"][:, :5], "view into the registered array")
+    finally:
+        _lib.unpin_host_array(full)
+    assert_bitwise(pl.fill_dprobs(param_idx=cols, eps=1e-7), fx["dprobs_map"], "pageable destination afterwards")
+
+
 @pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2", "3q_explicit_L64"])
 def test_hprobs_fd_bitwise_vs_reference(name):
     fx = load_fixture(name)
