@@ -352,7 +352,7 @@ int gst_memcpy_d2h(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes)
  * (layout.allocate_local_array, pygsti/layouts/copalayout.py:284-361) and reusing them every iteration.  Unregister before
  * the memory is freed.  Both fail with GST_ENODEVICE when no device exists (the array then simply stays pageable).
  * The region is also mapped into the device's address space: a finite-difference gst_fill_dprobs whose destination lies
- * inside it has its kernel write the Jacobian straight into the host array (512-byte row segments over PCIe while the
+ * inside it (requests of >= 64 columns) has its kernel write the Jacobian straight into the host array (512-byte row segments over PCIe while the
  * walk is still computing; no HBM staging of the result), honouring (ld, dest_idx) as always. */
 int gst_host_register(void *ptr, int64_t nbytes);
 int gst_host_unregister(void *ptr);

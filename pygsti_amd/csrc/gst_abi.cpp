@@ -173,6 +173,7 @@ struct gst_plan {
     bool fd_persist_always = false;     // GST_FD_PERSIST=2: per-SIMD queues whatever the number of pairs
     bool fd_fused = true;               // GST_FD_FUSED=0: launch-bound plans keep the separate base pass
     bool host_direct = true;            // GST_HOST_DIRECT=0: page-locked destinations are filled by a copy, not by the kernel
+    int64_t host_direct_min_cols = 64;  // (narrower column windows would cross PCIe in segments shorter than a wavefront's 512 bytes)
     int fd_handover = 1;                // GST_FD_HANDOVER: 0 never cut a walk, 1 cut to balance the per-SIMD queues, 2 cut every walk
     bool split_ready = false;
     std::vector<int32_t> split_pc;      // gst::task_split_points
@@ -278,7 +279,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_FD_PERSIST")) { p->fd_persist = std::atoi(e) != 0; p->fd_persist_always = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_HOST_DIRECT")) p->host_direct = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_HOST_DIRECT")) { p->host_direct = std::atoi(e) != 0; if (std::atoi(e) == 2) p->host_direct_min_cols = 1; }
     if (const char* e = std::getenv("GST_FD_HANDOVER")) p->fd_handover = std::atoi(e);
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
@@ -1548,7 +1549,7 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     // A page-locked destination (gst_host_register): the FD kernel writes the Jacobian straight into it -- 512-byte row
     // segments over PCIe while the walk is still computing -- instead of filling 7 GB of HBM first and copying afterwards
     // (kernel and transfer overlap completely; the (ld, dest_idx) window is honoured by the kernel itself).
-    if (!p->derivs_set && mode == GST_DERIV_FD && n_param > 0 && nE > 0 && p->hp.D <= 16 && p->comp_index < 0 && p->host_direct) {
+    if (!p->derivs_set && mode == GST_DERIV_FD && n_param >= p->host_direct_min_cols && nE > 0 && p->hp.D <= 16 && p->comp_index < 0 && p->host_direct) {
         int64_t max_col = 0;
         for (int64_t c = 0; c < n_param; c++) max_col = std::max<int64_t>(max_col, dest_idx ? dest_idx[c] : c);
         if (void* d_host = mapped_device_pointer(out, (size_t)((nE - 1) * ld + max_col + 1) * 8)) {

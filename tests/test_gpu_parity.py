@@ -90,7 +90,7 @@ def test_dprobs_column_window_and_dest_indices():
 
 
 @pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq2Q_XYICNOT_L2_depol"])
-@pytest.mark.parametrize("direct", ["1", "0"])
+@pytest.mark.parametrize("direct", ["2", "1", "0"])      # 2: kernel-written whatever the window's width
 def test_dprobs_into_page_locked_array_bitwise(name, direct, monkeypatch):
     """A destination registered with gst_host_register is written by the FD kernel itself (GST_HOST_DIRECT=1, default) or
     by a copy from HBM (=0): same bits as the reference either way, (ld, dest_idx) window honoured, nothing outside it
