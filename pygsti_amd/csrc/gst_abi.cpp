@@ -126,6 +126,7 @@ struct gst_plan {
     DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order, d_circ_partner, d_pair_common;
     bool ana_pairs = true;              // GST_ANALYTIC_PAIRS=0: one circuit per work item in the D = 16 contraction
     bool ana_germ_order = true;         // GST_ANALYTIC_GERM_ORDER=0: pure suffix order of the work items
+    bool ana_group_fetch = true;        // GST_ANALYTIC_GROUP=0: every wavefront of the D = 16 contraction pulls its items alone
     DevBuf<double> d_rev_cache;
     DevBuf<uint32_t> d_work_counter, d_range_begin;
     bool want_cache_path = false;       // set by the Hessian driver around its set-up Jacobian call
@@ -276,6 +277,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_FD_SPLIT")) p->fd_split = std::atoi(e);     // development override
     if (const char* e = std::getenv("GST_ANALYTIC_PAIRS")) p->ana_pairs = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_ANALYTIC_GERM_ORDER")) p->ana_germ_order = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_ANALYTIC_GROUP")) p->ana_group_fetch = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_PERSIST")) { p->fd_persist = std::atoi(e) != 0; p->fd_persist_always = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
@@ -1027,6 +1029,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         a.rev_cache = p->d_rev_cache.p; a.rev_leaf = p->d_rev_leaf.p; a.pair_f = p->d_pair_f.p; a.pair_r = p->d_pair_r.p;
         a.circ_partner = D == 16 ? p->d_circ_partner.p : nullptr; a.pair_common = D == 16 ? p->d_pair_common.p : nullptr;
         a.pos_ptr = p->d_pos_ptr.p; a.circ_rho = p->d_circ_rho.p; a.circ_order = p->d_circ_order.p; a.work_counter = p->d_work_counter.p; a.range_begin = p->d_range_begin.p;
+        a.group_fetch = p->ana_group_fetch ? 1 : 0;
         HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
         if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
         else if (D == 16) HIP_TRY(gst::launch_analytic_mfma(a, p->stream));

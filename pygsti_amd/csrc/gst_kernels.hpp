@@ -132,6 +132,7 @@ struct AnaArgs {
     int32_t rho_zero, eff_zero;        // write zeros to the rho / effect columns instead of B_0 / F_n
     int32_t accumulate;                // add to the output instead of storing
     uint32_t* work_counter;       // [8] one per range, zeroed before the launch
+    int32_t group_fetch;          // D = 16: the 4 wavefronts of a workgroup take 4 consecutive items together (see the kernel)
 };
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
 hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream);   // D = 16

@@ -348,14 +348,43 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
     // dispatch rule, used for locality only): neighbours in that order share their backward chains and, over a longer
     // stretch, the forward chains of their germ, so both stay in that XCD's 4 MB L2 instead of being pulled from HBM
     // by all eight.  A wavefront that finds its range empty helps the next.
+    // Group fetch (a.group_fetch): the four wavefronts of a workgroup take four CONSECUTIVE items together.  The kernel is
+    // bound by the L1's outstanding misses (TCP_PENDING_STALL_CYCLES: 69 % of the launch; 107 M line requests at 613
+    // cycles each, profiles/r02_analytic_mix.json), not by the latency one wavefront sees -- prefetching the gathers a
+    // block ahead changes nothing -- and neighbours of the item order read the same backward vectors: started together
+    // on one CU, part of their requests merge in that CU's L1 instead of each holding a miss slot (-11 % on the launch).
     const int xcd = blockIdx.x & 7;
-    for (int probe = 0; probe < 8;) {
-        const int rg = (xcd + probe) & 7;
-        const uint32_t r_begin = as_const(a.range_begin)[rg], r_end = as_const(a.range_begin)[rg + 1];
-        uint32_t cu = 0;
-        if (lane == 0) cu = atomicAdd(a.work_counter + rg, 1u);
-        const int64_t ci = (int64_t)r_begin + (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
-        if (ci >= (int64_t)r_end) { probe++; continue; }
+    __shared__ uint32_t s_fetch[2];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int probe = 0;;) {
+        int64_t ci;
+        if (a.group_fetch) {
+            __syncthreads();                   // (everybody has read the previous group's s_fetch)
+            if (threadIdx.x == 0) {
+                uint32_t base = 0xffffffffu, end = 0;
+                for (; probe < 8; probe++) {
+                    const int rg = (xcd + probe) & 7;
+                    const uint32_t rb = a.range_begin[rg], re = a.range_begin[rg + 1];
+                    const uint32_t cu = atomicAdd(a.work_counter + rg, 4u);
+                    if ((uint64_t)rb + cu < (uint64_t)re) { base = rb + cu; end = re; break; }
+                }
+                s_fetch[0] = base; s_fetch[1] = end;
+            }
+            __syncthreads();
+            const uint32_t g_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fetch[0]);
+            const uint32_t g_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fetch[1]);
+            if (g_base == 0xffffffffu) break;
+            ci = (int64_t)g_base + wv;
+            if (ci >= (int64_t)g_end) continue;
+        } else {
+            if (probe >= 8) break;
+            const int rg = (xcd + probe) & 7;
+            const uint32_t r_begin = as_const(a.range_begin)[rg], r_end = as_const(a.range_begin)[rg + 1];
+            uint32_t cu = 0;
+            if (lane == 0) cu = atomicAdd(a.work_counter + rg, 1u);
+            ci = (int64_t)r_begin + (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
+            if (ci >= (int64_t)r_end) { probe++; continue; }
+        }
         const int64_t c = as_const(a.circ_order)[ci];
         const int64_t c2 = a.circ_partner ? (int64_t)as_const(a.circ_partner)[ci] : -1;
         if (c2 >= 0) {
