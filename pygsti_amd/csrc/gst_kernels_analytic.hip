@@ -215,9 +215,12 @@ __global__ __launch_bounds__(256, WPS) void analytic_dprobs_kernel(const AnaArgs
 // A wavefront takes circuits from a shared counter (depths range from 1 to 1030) and writes whole 16-column row
 // segments of the Jacobian (D-matrix layout: lane l, register r -> row (l>>4) + 4r, column l&15).
 typedef double d4_t __attribute__((ext_vector_type(4)));
-constexpr int ANA_MFMA_M = 4;      // chunks of 4 gate applications per block of loads
+constexpr int ANA_MFMA_M = 1;      // chunks of 4 gate applications per pipeline block
+// Three wavefronts per SIMD: with the gathers a block ahead of their MFMAs the fourth wavefront buys nothing, and the
+// two register sets of the pipeline do not fit 128 VGPRs next to the 8 accumulator tiles of a two-circuit item.
+constexpr int ANA_MFMA_WPS = 3;
 
-__global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
+__global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const AnaArgs a)
 {
     constexpr int D = 16, NX = 4;
     const int lane = threadIdx.x & 63;
@@ -269,39 +272,37 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
             }
         }
     };
-    // acc[x] += sum over the applications [p0, p1) of the pair tables of B_k (outcome x) (x) F_{k-1}.
-    // Blocks of M chunks (4*M applications): all pair indices of the block are requested first, then all state vectors,
-    // then the 4*M MFMAs -- two memory round trips per block instead of per chunk; the NEXT block's indices are
-    // requested before this block's state vectors.  Lanes past the end re-read the last pair (always a valid address)
-    // and multiply by a zeroed F.
-    auto sweep = [&](auto m_tag, int64_t p0, int64_t p1, const bool fast4, const int32_t (&e_u)[NX], d4_t (&acc)[NX]) {
+    // acc[x] += sum over the applications [p0, p1) of the pair tables of B_k (outcome x) (x) F_{k-1}, as a three-stage
+    // pipeline over blocks of M chunks (4*M applications): while the MFMAs of block b run, the state vectors of block
+    // b + 1 and the pair indices of block b + 2 are in flight (two register sets; the loop is unrolled by two so that
+    // nothing is copied).  Two things make the overlap real: no load sits under a branch (the compiler counts outstanding
+    // loads exactly only on straight-line code; blocks past the end re-read the last pair, always a valid address, and
+    // multiply by a zeroed F), and scheduling fences keep the three stages in program order -- left alone, the
+    // scheduler hoists a stage's index loads in front of the gathers that consume them and waits for them at once.
+#define DB_FENCE() __builtin_amdgcn_sched_barrier(0)
+    auto sweep = [&](auto m_tag, auto fast_tag, int64_t p0, int64_t p1, const int32_t (&e_u)[NX], d4_t (&acc)[NX]) {
         constexpr int M = decltype(m_tag)::value;
+        constexpr bool FAST4 = decltype(fast_tag)::value;
         if (p1 <= p0) return;
-        const int64_t last = p1 - 1;
-        int32_t fi[M], ri[M];
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-            const int64_t pi = p0 + 4 * m + kk;
-            const int64_t pc = pi <= last ? pi : last;
-            fi[m] = a.pair_f[pc]; ri[m] = a.pair_r[pc];
-        }
-        for (int64_t q = p0; q < p1; q += 4 * M) {
-            bool ok[M];
-            int32_t fn[M], rn[M];
+        const int32_t n = (int32_t)(p1 - p0);
+        const int32_t nb = (n + 4 * M - 1) / (4 * M);
+        const int32_t* const pf = a.pair_f + p0;
+        const int32_t* const pr = a.pair_r + p0;
+        auto idx_at = [&](int32_t blk, int32_t (&f)[M], int32_t (&r)[M]) {
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                ok[m] = q + 4 * m + kk <= last;
-                const int64_t pi = q + 4 * M + 4 * m + kk;
-                const int64_t pc = pi <= last ? pi : last;
-                fn[m] = a.pair_f[pc]; rn[m] = a.pair_r[pc];
+                const int32_t pi = (blk * M + m) * 4 + kk;
+                const int32_t pc = pi < n ? pi : n - 1;
+                f[m] = pf[pc]; r[m] = pr[pc];
             }
-            double Fv[M], Bv[M][NX];
+        };
+        auto gather = [&](const int32_t (&f)[M], const int32_t (&r)[M], double (&Fv)[M], double (&Bv)[M][NX]) {
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const uint32_t fo = (uint32_t)fi[m] * fstride + lane_b;
-                const uint32_t ro = (uint32_t)ri[m] * rstride + lane_r;
+                const uint32_t fo = (uint32_t)f[m] * fstride + lane_b;
+                const uint32_t ro = (uint32_t)r[m] * rstride + lane_r;
                 Fv[m] = *(const double*)(fb + fo);
-                if (fast4) {         // the usual case: 4 effects, outcome x <-> effect x: one 32-byte read
+                if constexpr (FAST4) {
                     const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + ro, 16);
                     const d2_t t0 = q2[0], t1 = q2[1];
                     Bv[m][0] = t0.x; Bv[m][1] = t0.y; Bv[m][2] = t1.x; Bv[m][3] = t1.y;
@@ -310,14 +311,34 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                     for (int x = 0; x < NX; x++) Bv[m][x] = *(const double*)(rb + ro + (uint32_t)e_u[x] * 8u);
                 }
             }
+        };
+        auto mma = [&](int32_t blk, const double (&Fv)[M], const double (&Bv)[M][NX]) {
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const double Fz = ok[m] ? Fv[m] : 0.0;
+                const double Fz = ((blk * M + m) * 4 + kk < n) ? Fv[m] : 0.0;
 #pragma unroll
                 for (int x = 0; x < NX; x++) acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fz, acc[x], 0, 0, 0);
             }
-#pragma unroll
-            for (int m = 0; m < M; m++) { fi[m] = fn[m]; ri[m] = rn[m]; }
+        };
+        int32_t fA[M], rA[M], fB[M], rB[M];
+        double F0[M], B0[M][NX], F1[M], B1[M][NX];
+        idx_at(0, fA, rA);
+        idx_at(1, fB, rB);
+        gather(fA, rA, F0, B0);
+        for (int32_t b = 0; b < nb; b += 2) {
+            DB_FENCE();
+            idx_at(b + 2, fA, rA);
+            DB_FENCE();
+            gather(fB, rB, F1, B1);
+            DB_FENCE();
+            mma(b, F0, B0);
+            DB_FENCE();
+            idx_at(b + 3, fB, rB);
+            DB_FENCE();
+            gather(fA, rA, F0, B0);
+            DB_FENCE();
+            mma(b + 1, F1, B1);
+            DB_FENCE();
         }
     };
     // a circuit's 16 x 16 block of gate g for (up to) NX outcomes -> Jacobian rows (D-matrix layout of the MFMA)
@@ -408,27 +429,25 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                 d4_t acc[NX], acc2[NX];
 #pragma unroll
                 for (int x = 0; x < NX; x++) { acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc2[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
-                // common tail: applications p1 - cg .. p1 - 1 of c and q1 - cg .. q1 - 1 of c2 have equal backward ids
-                constexpr int M2 = 2;
+                // common tail: applications p1 - cg .. p1 - 1 of c and q1 - cg .. q1 - 1 of c2 have equal backward ids; the
+                // same three-stage pipeline as `sweep`, one backward gather feeding both circuits' MFMAs
+                constexpr int M2 = ANA_MFMA_M;
                 if (cg > 0) {
-                    int32_t f1[M2], f2[M2], rr[M2];
+                    const int32_t n = (int32_t)cg;
+                    const int32_t nb = (n + 4 * M2 - 1) / (4 * M2);
+                    const int32_t* const pf1 = a.pair_f + (p1 - cg);
+                    const int32_t* const pf2 = a.pair_f + (q1 - cg);
+                    const int32_t* const prr = a.pair_r + (p1 - cg);
+                    auto idx_at = [&](int32_t blk, int32_t (&f1)[M2], int32_t (&f2)[M2], int32_t (&rr)[M2]) {
 #pragma unroll
-                    for (int m = 0; m < M2; m++) {              // pair indices of the first block
-                        const int64_t off = 4 * m + kk;
-                        const int64_t oc = off < cg ? off : cg - 1;
-                        f1[m] = a.pair_f[p1 - cg + oc]; f2[m] = a.pair_f[q1 - cg + oc]; rr[m] = a.pair_r[p1 - cg + oc];
-                    }
-                    for (int64_t t = 0; t < cg; t += 4 * M2) {
-                        bool ok[M2];
-                        int32_t f1n[M2], f2n[M2], rrn[M2];
-#pragma unroll
-                        for (int m = 0; m < M2; m++) {          // the next block's indices travel with this block's vectors
-                            ok[m] = t + 4 * m + kk < cg;
-                            const int64_t off = t + 4 * M2 + 4 * m + kk;
-                            const int64_t oc = off < cg ? off : cg - 1;
-                            f1n[m] = a.pair_f[p1 - cg + oc]; f2n[m] = a.pair_f[q1 - cg + oc]; rrn[m] = a.pair_r[p1 - cg + oc];
+                        for (int m = 0; m < M2; m++) {
+                            const int32_t off = (blk * M2 + m) * 4 + kk;
+                            const int32_t oc = off < n ? off : n - 1;
+                            f1[m] = pf1[oc]; f2[m] = pf2[oc]; rr[m] = prr[oc];
                         }
-                        double F1[M2], F2[M2], Bv[M2][NX];
+                    };
+                    auto gather = [&](const int32_t (&f1)[M2], const int32_t (&f2)[M2], const int32_t (&rr)[M2],
+                                      double (&F1)[M2], double (&F2)[M2], double (&Bv)[M2][NX]) {
 #pragma unroll
                         for (int m = 0; m < M2; m++) {
                             F1[m] = *(const double*)(fb + (uint32_t)f1[m] * fstride + lane_b);
@@ -437,22 +456,43 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                             const d2_t t0 = q2[0], t1 = q2[1];
                             Bv[m][0] = t0.x; Bv[m][1] = t0.y; Bv[m][2] = t1.x; Bv[m][3] = t1.y;
                         }
+                    };
+                    auto mma = [&](int32_t blk, const double (&F1)[M2], const double (&F2)[M2], const double (&Bv)[M2][NX]) {
 #pragma unroll
                         for (int m = 0; m < M2; m++) {
-                            const double Fa = ok[m] ? F1[m] : 0.0, Fb2 = ok[m] ? F2[m] : 0.0;
+                            const bool ok = (blk * M2 + m) * 4 + kk < n;
+                            const double Fa = ok ? F1[m] : 0.0, Fb2 = ok ? F2[m] : 0.0;
 #pragma unroll
                             for (int x = 0; x < NX; x++) {
                                 acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fa, acc[x], 0, 0, 0);
                                 acc2[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fb2, acc2[x], 0, 0, 0);
                             }
                         }
-#pragma unroll
-                        for (int m = 0; m < M2; m++) { f1[m] = f1n[m]; f2[m] = f2n[m]; rr[m] = rrn[m]; }
+                    };
+                    int32_t f1A[M2], f2A[M2], rrA[M2], f1B[M2], f2B[M2], rrB[M2];
+                    double F10[M2], F20[M2], B0[M2][NX], F11[M2], F21[M2], B1[M2][NX];
+                    idx_at(0, f1A, f2A, rrA);
+                    idx_at(1, f1B, f2B, rrB);
+                    gather(f1A, f2A, rrA, F10, F20, B0);
+                    for (int32_t b = 0; b < nb; b += 2) {
+                        DB_FENCE();
+                        idx_at(b + 2, f1A, f2A, rrA);
+                        DB_FENCE();
+                        gather(f1B, f2B, rrB, F11, F21, B1);
+                        DB_FENCE();
+                        mma(b, F10, F20, B0);
+                        DB_FENCE();
+                        idx_at(b + 3, f1B, f2B, rrB);
+                        DB_FENCE();
+                        gather(f1A, f2A, rrA, F10, F20, B0);
+                        DB_FENCE();
+                        mma(b + 1, F11, F21, B1);
+                        DB_FENCE();
                     }
                 }
                 // the applications before the common tail, each circuit on its own
-                sweep(std::integral_constant<int, 2>{}, p0, p1 - cg, true, e_u, acc);
-                sweep(std::integral_constant<int, 2>{}, q0, q1 - cg, true, e_u2, acc2);
+                sweep(std::integral_constant<int, ANA_MFMA_M>{}, std::true_type{}, p0, p1 - cg, e_u, acc);
+                sweep(std::integral_constant<int, ANA_MFMA_M>{}, std::true_type{}, q0, q1 - cg, e_u2, acc2);
                 store_block(g, c0, NX, dest_u, acc);
                 store_block(g, c0, NX, dest_u2, acc2);
             }
@@ -474,7 +514,8 @@ __global__ __launch_bounds__(256, 4) void analytic_mfma_kernel(const AnaArgs a)
                 d4_t acc[NX];
 #pragma unroll
                 for (int x = 0; x < NX; x++) acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0};
-                sweep(std::integral_constant<int, ANA_MFMA_M>{}, p0, p1, fast4, e_u, acc);
+                if (fast4) sweep(std::integral_constant<int, ANA_MFMA_M>{}, std::true_type{}, p0, p1, e_u, acc);
+                else sweep(std::integral_constant<int, ANA_MFMA_M>{}, std::false_type{}, p0, p1, e_u, acc);
                 store_block(g, c0, nx, dest_u, acc);
             }
         }
