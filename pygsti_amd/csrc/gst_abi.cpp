@@ -124,6 +124,8 @@ struct gst_plan {
     DevBuf<uint32_t> d_rprog;
     DevBuf<int64_t> d_rtask_off, d_pos_ptr;
     DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order, d_circ_partner, d_pair_common;
+    DevBuf<int32_t> d_blk_f1, d_blk_f2, d_blk_r, d_blk_ptr;   // two-circuit items as one stream of 4-application blocks (ensure_reverse)
+    bool ana_stream = true;             // GST_ANALYTIC_STREAM=0: two-circuit items gate by gate (tail, then the two prefixes)
     bool ana_pairs = true;              // GST_ANALYTIC_PAIRS=0: one circuit per work item in the D = 16 contraction
     bool ana_germ_order = true;         // GST_ANALYTIC_GERM_ORDER=0: pure suffix order of the work items
     bool ana_group_fetch = true;        // GST_ANALYTIC_GROUP=0: every wavefront of the D = 16 contraction pulls its items alone
@@ -221,6 +223,7 @@ struct gst_plan {
         d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release();
         d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_circ_partner.release();
         d_pair_common.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release();
+        d_blk_f1.release(); d_blk_f2.release(); d_blk_r.release(); d_blk_ptr.release();
         d_dv_deriv.release(); d_dv2.release(); d_helem.release(); d_hw.release(); d_hcsc.release();
         d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release();
         d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release();
@@ -278,6 +281,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_ANALYTIC_PAIRS")) p->ana_pairs = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_ANALYTIC_GERM_ORDER")) p->ana_germ_order = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_ANALYTIC_GROUP")) p->ana_group_fetch = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_ANALYTIC_STREAM")) p->ana_stream = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_PERSIST")) { p->fd_persist = std::atoi(e) != 0; p->fd_persist_always = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
@@ -900,6 +904,36 @@ int ensure_reverse(gst_plan* p)
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(p->d_work_counter.ensure(8));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (h.D == 16 && pairing && p->ana_stream && nG <= 63) {
+        // Two-circuit items as ONE stream of blocks of 4 "slots": per gate the common tail (slot = one application of
+        // both circuits: their two forward ids and the shared backward id), then what each circuit has before the tail
+        // (the other circuit's forward id = -1: its operand is zeroed), padded to a multiple of 4 with dead slots.  The
+        // contraction's gather pipeline then runs through a whole item without draining at every gate and segment.
+        std::vector<int32_t> bf1, bf2, br, bptr((size_t)n_items * (size_t)nG + 1, 0);
+        bf1.reserve(pf.size()); bf2.reserve(pf.size()); br.reserve(pf.size());
+        for (int64_t k = 0; k < n_items; k++) {
+            const int32_t c = item_first[(size_t)k], c2 = item_partner[(size_t)k];
+            for (int g = 0; g < nG; g++) {
+                bptr[(size_t)k * nG + g] = (int32_t)(bf1.size() / 4);
+                if (c2 < 0) continue;
+                const int64_t p0 = pos_ptr[(size_t)c * nG + g], p1 = pos_ptr[(size_t)c * nG + g + 1];
+                const int64_t q0 = pos_ptr[(size_t)c2 * nG + g], q1 = pos_ptr[(size_t)c2 * nG + g + 1];
+                const int64_t cg = item_common[(size_t)k * nG + g];
+                for (int64_t t = 0; t < cg; t++) { bf1.push_back(pf[(size_t)(p1 - cg + t)]); bf2.push_back(pf[(size_t)(q1 - cg + t)]); br.push_back(pr[(size_t)(p1 - cg + t)]); }
+                for (int64_t j = p0; j < p1 - cg; j++) { bf1.push_back(pf[(size_t)j]); bf2.push_back(-1); br.push_back(pr[(size_t)j]); }
+                for (int64_t j = q0; j < q1 - cg; j++) { bf1.push_back(-1); bf2.push_back(pf[(size_t)j]); br.push_back(pr[(size_t)j]); }
+                while (bf1.size() % 4) { bf1.push_back(-1); bf2.push_back(-1); br.push_back(br.empty() ? 0 : br.back()); }
+            }
+            if (bf1.size() / 4 > 0x7ffffff0u) return fail(GST_EUNSUPPORTED, "analytic block stream too long");
+        }
+        bptr[(size_t)n_items * nG] = (int32_t)(bf1.size() / 4);
+        if (bf1.empty()) { bf1.assign(4, -1); bf2.assign(4, -1); br.assign(4, 0); }
+        if ((rc = upload_i32(p->d_blk_f1, bf1, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_blk_f2, bf2, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_blk_r, br, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_blk_ptr, bptr, p->stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
     // (the host copies of the reversed programs are not needed any more)
     p->rev.prog.clear(); p->rev.prog.shrink_to_fit();
     p->rev.node_parent.clear(); p->rev.node_parent.shrink_to_fit();
@@ -1030,6 +1064,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         a.circ_partner = D == 16 ? p->d_circ_partner.p : nullptr; a.pair_common = D == 16 ? p->d_pair_common.p : nullptr;
         a.pos_ptr = p->d_pos_ptr.p; a.circ_rho = p->d_circ_rho.p; a.circ_order = p->d_circ_order.p; a.work_counter = p->d_work_counter.p; a.range_begin = p->d_range_begin.p;
         a.group_fetch = p->ana_group_fetch ? 1 : 0;
+        if (D == 16 && p->d_blk_ptr.p) { a.blk_f1 = p->d_blk_f1.p; a.blk_f2 = p->d_blk_f2.p; a.blk_r = p->d_blk_r.p; a.blk_ptr = p->d_blk_ptr.p; }
         HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
         if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
         else if (D == 16) HIP_TRY(gst::launch_analytic_mfma(a, p->stream));

@@ -133,6 +133,9 @@ struct AnaArgs {
     int32_t accumulate;                // add to the output instead of storing
     uint32_t* work_counter;       // [8] one per range, zeroed before the launch
     int32_t group_fetch;          // D = 16: the 4 wavefronts of a workgroup take 4 consecutive items together (see the kernel)
+    // D = 16, two-circuit items as one stream of 4-slot blocks (NULL: gate by gate): slot = forward id of the first circuit,
+    // of the second (-1: that circuit has no application here) and the backward id; blk_ptr[item * nG + g] = first block of gate g
+    const int32_t *blk_f1, *blk_f2, *blk_r, *blk_ptr;
 };
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
 hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream);   // D = 16

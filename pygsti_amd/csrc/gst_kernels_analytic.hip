@@ -420,6 +420,94 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
             outcomes(x02, x02, NX, e_l2, dest_l2, e_u2, dest_u2);
             spam_columns(c, e_l, dest_l);
             spam_columns(c2, e_l2, dest_l2);
+            if (a.blk_ptr) {
+                // The item as ONE stream of 4-slot blocks (host-built, AnaArgs::blk_*): the three-stage pipeline of `sweep`
+                // runs through all gates and segments of the item -- indices two blocks ahead, state vectors one block
+                // ahead, 8 MFMAs per block (both circuits against the shared backward vectors; a circuit without an
+                // application in a slot contributes a zeroed operand) -- and a gate's two 16 x 16 x 4-outcome blocks are
+                // stored when its last block has been multiplied, while the next gate's vectors are already in flight.
+                const int32_t bp_l = a.blk_ptr[ci * nG + (lane <= nG ? lane : nG)];     // lane g: first block of gate g (lane nG: end)
+                const int32_t c0_l = lane < nG ? a.gate_col0[lane] : -2;
+                struct Cur { int g; int32_t pos, end; };
+                const int32_t item_b0 = __builtin_amdgcn_readlane(bp_l, 0);
+                auto seek = [&](int g) {
+                    for (; g < nG; g++) {
+                        const int32_t b0 = __builtin_amdgcn_readlane(bp_l, g), b1 = __builtin_amdgcn_readlane(bp_l, g + 1);
+                        if (__builtin_amdgcn_readlane(c0_l, g) != -2 && b1 > b0) return Cur{g, b0, b1};
+                    }
+                    return Cur{nG, item_b0, item_b0};          // done: a valid block to keep the prefetches in bounds
+                };
+                auto advance = [&](const Cur& q) {
+                    if (q.g >= nG) return q;
+                    if (q.pos + 1 < q.end) return Cur{q.g, q.pos + 1, q.end};
+                    return seek(q.g + 1);
+                };
+                Cur cur0 = seek(0);
+                if (cur0.g < nG) {
+                    d4_t acc[NX], acc2[NX];
+#pragma unroll
+                    for (int x = 0; x < NX; x++) { acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc2[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
+                    auto idx_load = [&](const Cur& q, int32_t& f1, int32_t& f2, int32_t& rr) {
+                        const int64_t o = (int64_t)q.pos * 4 + kk;
+                        f1 = a.blk_f1[o]; f2 = a.blk_f2[o]; rr = a.blk_r[o];
+                    };
+                    auto gather = [&](const bool live, const int32_t f1, const int32_t f2, const int32_t rr,
+                                      double& F1, double& F2, double (&Bv)[NX], bool& ok1, bool& ok2) {
+                        ok1 = live && f1 >= 0; ok2 = live && f2 >= 0;
+                        F1 = *(const double*)(fb + (uint32_t)(f1 < 0 ? 0 : f1) * fstride + lane_b);
+                        F2 = *(const double*)(fb + (uint32_t)(f2 < 0 ? 0 : f2) * fstride + lane_b);
+                        const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + (uint32_t)rr * rstride + lane_r, 16);
+                        const d2_t t0 = q2[0], t1 = q2[1];
+                        Bv[0] = t0.x; Bv[1] = t0.y; Bv[2] = t1.x; Bv[3] = t1.y;
+                    };
+                    auto mma = [&](const double F1, const double F2, const double (&Bv)[NX], const bool ok1, const bool ok2) {
+                        const double Fa = ok1 ? F1 : 0.0, Fb2 = ok2 ? F2 : 0.0;
+#pragma unroll
+                        for (int x = 0; x < NX; x++) {
+                            acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[x], Fa, acc[x], 0, 0, 0);
+                            acc2[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[x], Fb2, acc2[x], 0, 0, 0);
+                        }
+                    };
+                    auto flush_if_last = [&](const Cur& q) {
+                        if (q.pos + 1 != q.end) return;
+                        const int32_t c0 = __builtin_amdgcn_readlane(c0_l, q.g);
+                        store_block(q.g, c0, NX, dest_u, acc);
+                        store_block(q.g, c0, NX, dest_u2, acc2);
+#pragma unroll
+                        for (int x = 0; x < NX; x++) { acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc2[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
+                    };
+                    Cur cur1 = advance(cur0), cur2 = advance(cur1);
+                    int32_t f1A, f2A, rrA, f1B, f2B, rrB;
+                    double F10, F20, B0[NX], F11, F21, B1[NX];
+                    bool ok10, ok20, ok11, ok21;
+                    idx_load(cur0, f1A, f2A, rrA);
+                    idx_load(cur1, f1B, f2B, rrB);
+                    gather(true, f1A, f2A, rrA, F10, F20, B0, ok10, ok20);
+                    for (;;) {
+                        DB_FENCE();
+                        idx_load(cur2, f1A, f2A, rrA);
+                        DB_FENCE();
+                        gather(cur1.g < nG, f1B, f2B, rrB, F11, F21, B1, ok11, ok21);
+                        DB_FENCE();
+                        mma(F10, F20, B0, ok10, ok20);
+                        DB_FENCE();
+                        flush_if_last(cur0);
+                        cur0 = cur1; cur1 = cur2; cur2 = advance(cur2);
+                        if (cur0.g >= nG) break;
+                        DB_FENCE();
+                        idx_load(cur2, f1B, f2B, rrB);
+                        DB_FENCE();
+                        gather(cur1.g < nG, f1A, f2A, rrA, F10, F20, B0, ok10, ok20);
+                        DB_FENCE();
+                        mma(F11, F21, B1, ok11, ok21);
+                        DB_FENCE();
+                        flush_if_last(cur0);
+                        cur0 = cur1; cur1 = cur2; cur2 = advance(cur2);
+                        if (cur0.g >= nG) break;
+                    }
+                }
+                continue;
+            }
             for (int g = 0; g < nG; g++) {
                 const int32_t c0 = as_const(a.gate_col0)[g];
                 if (c0 == -2) continue;
