@@ -374,10 +374,11 @@ void base_args(gst_plan* p, gst::WalkArgs& a)
 
 // Base probabilities into d_dst (device), S = 0 walk: one wavefront per task.  With `fill_cache` the
 // pass also stores every state it produces (the derivative passes start from them).
-int run_probs(gst_plan* p, double* d_dst, bool fill_cache)
+int run_probs(gst_plan* p, double* d_dst, bool fill_cache, int chain_share = 1)
 {
     gst::WalkArgs a;
     base_args(p, a);
+    a.chain_share = chain_share;
     a.mode = gst::EMIT_PROBS;
     a.out = d_dst;
     if (fill_cache) {
@@ -764,7 +765,9 @@ int ensure_reverse(gst_plan* p)
 {
     if (p->rev_ready) return GST_OK;
     const gst::HostPlan& h = p->hp;
-    std::string err = gst::build_reverse_plan(h, p->rev, 0, h.D == 16 ? 1 : (h.D == 64 ? 8 : 4));
+    int32_t rev_tasks = 0;
+    if (const char* e = std::getenv("GST_ANALYTIC_REV_TASKS")) rev_tasks = std::atoi(e);       // development aid
+    std::string err = gst::build_reverse_plan(h, p->rev, rev_tasks, h.D == 16 ? 1 : (h.D == 64 ? 8 : 4));
     if (!err.empty()) return fail(GST_EINVAL, "reversed plan: " + err);
     if (p->rev.max_slots > (h.D == 64 ? 32 : 4)) return fail(GST_EUNSUPPORTED, "reversed plan needs too many save slots");
     std::vector<int32_t> pf, pr;
@@ -909,12 +912,13 @@ int ensure_reverse(gst_plan* p)
         // both circuits: their two forward ids and the shared backward id), then what each circuit has before the tail
         // (the other circuit's forward id = -1: its operand is zeroed), padded to a multiple of 4 with dead slots.  The
         // contraction's gather pipeline then runs through a whole item without draining at every gate and segment.
+        const size_t blk_slots = 4 * (size_t)gst::analytic_stream_chunks();
         std::vector<int32_t> bf1, bf2, br, bptr((size_t)n_items * (size_t)nG + 1, 0);
         bf1.reserve(pf.size()); bf2.reserve(pf.size()); br.reserve(pf.size());
         for (int64_t k = 0; k < n_items; k++) {
             const int32_t c = item_first[(size_t)k], c2 = item_partner[(size_t)k];
             for (int g = 0; g < nG; g++) {
-                bptr[(size_t)k * nG + g] = (int32_t)(bf1.size() / 4);
+                bptr[(size_t)k * nG + g] = (int32_t)(bf1.size() / blk_slots);
                 if (c2 < 0) continue;
                 const int64_t p0 = pos_ptr[(size_t)c * nG + g], p1 = pos_ptr[(size_t)c * nG + g + 1];
                 const int64_t q0 = pos_ptr[(size_t)c2 * nG + g], q1 = pos_ptr[(size_t)c2 * nG + g + 1];
@@ -922,12 +926,12 @@ int ensure_reverse(gst_plan* p)
                 for (int64_t t = 0; t < cg; t++) { bf1.push_back(pf[(size_t)(p1 - cg + t)]); bf2.push_back(pf[(size_t)(q1 - cg + t)]); br.push_back(pr[(size_t)(p1 - cg + t)]); }
                 for (int64_t j = p0; j < p1 - cg; j++) { bf1.push_back(pf[(size_t)j]); bf2.push_back(-1); br.push_back(pr[(size_t)j]); }
                 for (int64_t j = q0; j < q1 - cg; j++) { bf1.push_back(-1); bf2.push_back(pf[(size_t)j]); br.push_back(pr[(size_t)j]); }
-                while (bf1.size() % 4) { bf1.push_back(-1); bf2.push_back(-1); br.push_back(br.empty() ? 0 : br.back()); }
+                while (bf1.size() % blk_slots) { bf1.push_back(-1); bf2.push_back(-1); br.push_back(br.empty() ? 0 : br.back()); }
             }
-            if (bf1.size() / 4 > 0x7ffffff0u) return fail(GST_EUNSUPPORTED, "analytic block stream too long");
+            if (bf1.size() / 4 > 0x1ffffff0u) return fail(GST_EUNSUPPORTED, "analytic block stream too long");
         }
-        bptr[(size_t)n_items * nG] = (int32_t)(bf1.size() / 4);
-        if (bf1.empty()) { bf1.assign(4, -1); bf2.assign(4, -1); br.assign(4, 0); }
+        bptr[(size_t)n_items * nG] = (int32_t)(bf1.size() / blk_slots);
+        if (bf1.empty()) { bf1.assign(blk_slots, -1); bf2.assign(blk_slots, -1); br.assign(blk_slots, 0); }
         if ((rc = upload_i32(p->d_blk_f1, bf1, p->stream))) return rc;
         if ((rc = upload_i32(p->d_blk_f2, bf2, p->stream))) return rc;
         if ((rc = upload_i32(p->d_blk_r, br, p->stream))) return rc;
@@ -956,7 +960,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     //  only where the two-cache contraction will run: a plain 1Q Jacobian is launch-bound and takes the single kernel)
     const bool will_fork = p->ana_mfma && (h.D != 4 || p->want_cache_path);
     if (will_fork) HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
-    int rc = run_probs(p, d_base, n_param > 0);        // probabilities + every forward state
+    int rc = run_probs(p, d_base, n_param > 0, will_fork && n_param > 0 ? 2 : 1);        // probabilities + every forward state
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
     if (!p->request_cached(2, param_idx, dest_idx, n_param)) {
@@ -1043,6 +1047,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         HIP_TRY(p->d_rev_cache.ensure((size_t)p->rev.n_state_ids * h.n_effects * D));
         w.base_cache_w = p->d_rev_cache.p;
         w.multi_start = h.n_effects;
+        w.chain_share = 2;                      // (the forward pass runs beside this one)
         TIME_REC(p, evk0);
         // Both chain passes are latency-bound (one wavefront per task, a fraction of the SIMDs): the backward one runs
         // on the second stream beside the forward pass launched above, and the contraction waits for both.

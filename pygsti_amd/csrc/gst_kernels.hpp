@@ -66,6 +66,7 @@ struct WalkArgs {
     int32_t n_models;
     int64_t model_stride, out_model_stride;
     int32_t mm_tasks;        // number of tasks (walk_base_kernel derives (task, model) from blockIdx.x)
+    int32_t chain_share;     // walk_base_kernel: this many chain passes run side by side on the device (0 / 1: this one alone)
     // Fused base lane (launch-bound plans, S = 1): lane 63 of every wavefront carries NO perturbation, i.e. the base
     // model; the quotient uses ITS probability instead of pbase[], nothing is taken from the base-state cache, and the
     // separate base pass is not launched at all.  Lane 63 of parameter wavefront 0 writes probs_out (may be NULL).
@@ -139,6 +140,7 @@ struct AnaArgs {
 };
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
 hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream);   // D = 16
+int analytic_stream_chunks();        // chunks of 4 slots per block of the D = 16 stream (the host pads every gate's slots to whole blocks)
 hipError_t launch_analytic_mfma64(const AnaArgs& a, hipStream_t stream); // D = 64 (uses work_counter[0] only)
 hipError_t launch_analytic_small(const AnaArgs& a, hipStream_t stream);  // D = 4: same contraction, VALU (no counter)
 

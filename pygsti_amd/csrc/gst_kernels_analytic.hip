@@ -218,7 +218,14 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int ANA_MFMA_M = 1;      // chunks of 4 gate applications per pipeline block
 // Three wavefronts per SIMD: with the gathers a block ahead of their MFMAs the fourth wavefront buys nothing, and the
 // two register sets of the pipeline do not fit 128 VGPRs next to the 8 accumulator tiles of a two-circuit item.
-constexpr int ANA_MFMA_WPS = 3;
+#ifndef GST_ANA_WPS
+#define GST_ANA_WPS 3
+#endif
+constexpr int ANA_MFMA_WPS = GST_ANA_WPS;
+#ifndef GST_ANA_STREAM_M
+#define GST_ANA_STREAM_M 1
+#endif
+constexpr int ANA_STREAM_M = GST_ANA_STREAM_M;
 
 __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const AnaArgs a)
 {
@@ -447,25 +454,35 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                     d4_t acc[NX], acc2[NX];
 #pragma unroll
                     for (int x = 0; x < NX; x++) { acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc2[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
-                    auto idx_load = [&](const Cur& q, int32_t& f1, int32_t& f2, int32_t& rr) {
-                        const int64_t o = (int64_t)q.pos * 4 + kk;
-                        f1 = a.blk_f1[o]; f2 = a.blk_f2[o]; rr = a.blk_r[o];
-                    };
-                    auto gather = [&](const bool live, const int32_t f1, const int32_t f2, const int32_t rr,
-                                      double& F1, double& F2, double (&Bv)[NX], bool& ok1, bool& ok2) {
-                        ok1 = live && f1 >= 0; ok2 = live && f2 >= 0;
-                        F1 = *(const double*)(fb + (uint32_t)(f1 < 0 ? 0 : f1) * fstride + lane_b);
-                        F2 = *(const double*)(fb + (uint32_t)(f2 < 0 ? 0 : f2) * fstride + lane_b);
-                        const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + (uint32_t)rr * rstride + lane_r, 16);
-                        const d2_t t0 = q2[0], t1 = q2[1];
-                        Bv[0] = t0.x; Bv[1] = t0.y; Bv[2] = t1.x; Bv[3] = t1.y;
-                    };
-                    auto mma = [&](const double F1, const double F2, const double (&Bv)[NX], const bool ok1, const bool ok2) {
-                        const double Fa = ok1 ? F1 : 0.0, Fb2 = ok2 ? F2 : 0.0;
+                    constexpr int SM = ANA_STREAM_M;       // chunks of 4 slots per pipeline block (host pads gates to 4 * SM slots)
+                    auto idx_load = [&](const Cur& q, int32_t (&f1)[SM], int32_t (&f2)[SM], int32_t (&rr)[SM]) {
 #pragma unroll
-                        for (int x = 0; x < NX; x++) {
-                            acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[x], Fa, acc[x], 0, 0, 0);
-                            acc2[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[x], Fb2, acc2[x], 0, 0, 0);
+                        for (int m = 0; m < SM; m++) {
+                            const int64_t o = ((int64_t)q.pos * SM + m) * 4 + kk;
+                            f1[m] = a.blk_f1[o]; f2[m] = a.blk_f2[o]; rr[m] = a.blk_r[o];
+                        }
+                    };
+                    auto gather = [&](const bool live, const int32_t (&f1)[SM], const int32_t (&f2)[SM], const int32_t (&rr)[SM],
+                                      double (&F1)[SM], double (&F2)[SM], double (&Bv)[SM][NX], bool (&ok1)[SM], bool (&ok2)[SM]) {
+#pragma unroll
+                        for (int m = 0; m < SM; m++) {
+                            ok1[m] = live && f1[m] >= 0; ok2[m] = live && f2[m] >= 0;
+                            F1[m] = *(const double*)(fb + (uint32_t)(f1[m] < 0 ? 0 : f1[m]) * fstride + lane_b);
+                            F2[m] = *(const double*)(fb + (uint32_t)(f2[m] < 0 ? 0 : f2[m]) * fstride + lane_b);
+                            const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + (uint32_t)rr[m] * rstride + lane_r, 16);
+                            const d2_t t0 = q2[0], t1 = q2[1];
+                            Bv[m][0] = t0.x; Bv[m][1] = t0.y; Bv[m][2] = t1.x; Bv[m][3] = t1.y;
+                        }
+                    };
+                    auto mma = [&](const double (&F1)[SM], const double (&F2)[SM], const double (&Bv)[SM][NX], const bool (&ok1)[SM], const bool (&ok2)[SM]) {
+#pragma unroll
+                        for (int m = 0; m < SM; m++) {
+                            const double Fa = ok1[m] ? F1[m] : 0.0, Fb2 = ok2[m] ? F2[m] : 0.0;
+#pragma unroll
+                            for (int x = 0; x < NX; x++) {
+                                acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fa, acc[x], 0, 0, 0);
+                                acc2[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[m][x], Fb2, acc2[x], 0, 0, 0);
+                            }
                         }
                     };
                     auto flush_if_last = [&](const Cur& q) {
@@ -477,9 +494,9 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                         for (int x = 0; x < NX; x++) { acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc2[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
                     };
                     Cur cur1 = advance(cur0), cur2 = advance(cur1);
-                    int32_t f1A, f2A, rrA, f1B, f2B, rrB;
-                    double F10, F20, B0[NX], F11, F21, B1[NX];
-                    bool ok10, ok20, ok11, ok21;
+                    int32_t f1A[SM], f2A[SM], rrA[SM], f1B[SM], f2B[SM], rrB[SM];
+                    double F10[SM], F20[SM], B0[SM][NX], F11[SM], F21[SM], B1[SM][NX];
+                    bool ok10[SM], ok20[SM], ok11[SM], ok21[SM];
                     idx_load(cur0, f1A, f2A, rrA);
                     idx_load(cur1, f1B, f2B, rrB);
                     gather(true, f1A, f2A, rrA, F10, F20, B0, ok10, ok20);
@@ -912,6 +929,8 @@ hipError_t launch_analytic_small(const AnaArgs& a, hipStream_t stream)
     hipLaunchKernelGGL(analytic_small_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
+
+int analytic_stream_chunks() { return ANA_STREAM_M; }
 
 hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream)
 {

@@ -791,17 +791,29 @@ int rows_group(int D, int n_slots)
                          3 * ROWS_SHARED_NWB * sizeof(uint64_t);
     return bytes <= 64 * 1024 ? ROWS_SHARED_NWB : 1;
 }
-constexpr int BASE_PW = 1024;                // program window (words) in LDS
-constexpr int BASE_ER = 64;                  // emit ring: one lane per parked circuit at evaluation time
+#ifndef GST_BASE_PW
+#define GST_BASE_PW 512
+#endif
+#ifndef GST_BASE_ER
+#define GST_BASE_ER 32
+#endif
+constexpr int BASE_PW = GST_BASE_PW;         // program window (words) in LDS
+constexpr int BASE_ER = GST_BASE_ER;         // emit ring: one lane per parked circuit at evaluation time
+
+constexpr int BASE_MAXW = 8;                 // wavefronts (tasks) per workgroup of walk_base_kernel, at most
+// LDS of one walk_base_kernel workgroup: the model tables once, then one private region per wavefront
+__host__ __device__ inline size_t base_shared_doubles(int D, int n_gates, int n_effects) { return (size_t)n_effects * D + (size_t)n_gates * D * D; }
+__host__ __device__ inline size_t base_wave_doubles(int D, int n_slots)
+{
+    return (size_t)(n_slots > 0 ? n_slots : 1) * 64 + (size_t)BASE_ER * (D + 1) + (BASE_ER + BASE_PW) / 2;
+}
 
 // Does walk_base_kernel (the only D <= 16 kernel with multi-start walks) fit its tables into LDS for this model?
 bool chain_kernel_fits(int D, int n_gates, int n_effects, int n_slots)
 {
     if (D > 16 || n_gates <= 0) return false;
     const size_t gate_bytes = (size_t)n_gates * D * D * sizeof(double);
-    const size_t extra = ((size_t)n_effects * D + BASE_ER * (D + 1)) * sizeof(double) + (BASE_ER + BASE_PW) * sizeof(int32_t);
-    const size_t slot_bytes = (size_t)(n_slots > 0 ? n_slots : 1) * 64 * sizeof(double);
-    return gate_bytes <= 128 * 1024 && slot_bytes + extra + gate_bytes <= 156 * 1024;
+    return gate_bytes <= 128 * 1024 && (base_shared_doubles(D, n_gates, n_effects) + base_wave_doubles(D, n_slots)) * sizeof(double) <= 156 * 1024;
 }
 
 // global -> LDS copy by one wavefront, 8 loads in flight per lane (a load-wait-store loop costs one L2 round trip per
@@ -824,37 +836,51 @@ __device__ __forceinline__ void stage_lds(T* dst, const int total, const int lan
     }
 }
 
+// `wpb` wavefronts per workgroup, one task each (task = blockIdx.x * wpb + wavefront), sharing ONE staged copy of the
+// gates and effects: a pass is a latency chain per wavefront, so what it needs is residency -- every task of the
+// pass (and of the pass running beside it on the other stream, analytic mode) on the chip at once -- and the 12 KB
+// of 2Q gate tables per single-wavefront workgroup were what limited that (6 tasks per CU).
 template <int D>
-__global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a_, const int n_slots)
+__global__ __launch_bounds__(64 * BASE_MAXW) void walk_base_kernel(const WalkArgs a_, const int n_slots, const int wpb, const int64_t n_tasks)
 {
     static_assert(D == 4 || D == 16, "group broadcasts are DPP quad / row operations");
     constexpr int W = BASE_PW, ER = BASE_ER;
     constexpr int ES = D + 1;                // padded state stride of the emit ring (bank spread for lane-per-circuit reads)
-    extern __shared__ double lds[];          // save slots | effects | gates_t | emit ring | ring circuits | program window
-    const int lane = threadIdx.x;
+    extern __shared__ double lds[];          // effects | gates_t | per wavefront: save slots | emit ring | ring circuits | program window
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int li = lane % D, grp = lane / D;
     WalkArgs a = a_;
-    int64_t task = blockIdx.x;
-    if (a.n_models > 0) {                    // whole-model mode: block = (model set, task)
+    int64_t task = (int64_t)blockIdx.x * wpb + wv;
+    const bool have_task = task < n_tasks;
+    if (!have_task) task = 0;                // (stages the shared tables with the others, then leaves)
+    if (a.n_models > 0) {                    // whole-model mode (wpb = 1): block = (model set, task)
         const int64_t m = task / a.mm_tasks;
         task -= m * a.mm_tasks;
         a.gates_t += m * a.model_stride; a.rhos += m * a.model_stride; a.effects += m * a.model_stride;
         a.out += m * a.out_model_stride;
     }
-    double* ldsE = lds + (n_slots > 0 ? n_slots : 1) * 64;      // (a save slot holds one state per lane group)
-    double* ldsG = ldsE + a.n_effects * D;
-    double* ering = ldsG + a.n_gates * D * D;
-    int32_t* ering_circ = (int32_t*)(ering + ER * ES);
-    uint32_t* ldsP = (uint32_t*)(ering_circ + ER);
+    double* const ldsE = lds;
+    double* const ldsG = ldsE + a.n_effects * D;
+    double* const wlds = lds + base_shared_doubles(D, a.n_gates, a.n_effects) + (size_t)wv * base_wave_doubles(D, n_slots);
+    double* const ering = wlds + (n_slots > 0 ? n_slots : 1) * 64;      // (a save slot holds one state per lane group)
+    int32_t* const ering_circ = (int32_t*)(ering + ER * ES);
+    uint32_t* const ldsP = (uint32_t*)(ering_circ + ER);
 
     const int64_t pc0 = as_const(a.task_off)[task];
     const int32_t n_words = (int32_t)(as_const(a.task_off)[task + 1] - pc0);
     const uint32_t* gprog = a.prog + pc0;
     stage_lds(ldsP, W, lane, [&](int k) { return (k < n_words) ? gprog[k] : 0u; });
-    stage_lds(ldsG, a.n_gates * D * D, lane, [&](int k) { return a.gates_t[k]; });
-    stage_lds(ldsE, a.n_effects * D, lane, [&](int k) { return a.effects[k]; });
-    __builtin_amdgcn_s_waitcnt(0);           // single-wavefront block: drain, no barrier needed
-    __builtin_amdgcn_wave_barrier();
+    {   // the shared tables: every wavefront of the workgroup copies its share
+        const int nG2 = a.n_gates * D * D, nE2 = a.n_effects * D;
+        const int per = ((nG2 + wpb - 1) / wpb + 63) / 64 * 64, g0 = wv * per;
+        stage_lds(ldsG + g0, (g0 < nG2) ? ((nG2 - g0 < per) ? nG2 - g0 : per) : 0, lane, [&](int k) { return a.gates_t[g0 + k]; });
+        if (wv == 0) stage_lds(ldsE, nE2, lane, [&](int k) { return a.effects[k]; });
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    if (wpb > 1) __syncthreads();            // (one wavefront: the drain is enough)
+    else __builtin_amdgcn_wave_barrier();
+    if (!have_task) return;
 
     // State-cache addressing.  Normal pass: every lane group holds the same state, group 0 stores it at
     // cache[id][D].  Multi-start pass (a.multi_start = number of start vectors, used for the backward states of the
@@ -868,7 +894,7 @@ __global__ __launch_bounds__(64) void walk_base_kernel(const WalkArgs a_, const 
     const int64_t node_stride = multi ? (int64_t)a.multi_start * D : (int64_t)D;
     // (multi-start states are stored [state][component][start]: the consumer reads all starts of a component at once)
     const int lane_off = multi ? (store_on ? li * a.multi_start + my_start : 0) : lane;
-    double* const slot_lane = lds + grp * D + li;            // save slot s of this lane group: + s * 64
+    double* const slot_lane = wlds + grp * D + li;           // save slot s of this lane group: + s * 64
     int32_t lo = 0;                          // words [lo, lo + W) are resident, word i at ldsP[i % W]
     int32_t pc = 0;                          // index of the current word
     int n_er = 0;                            // parked EMITs (wave-uniform)
@@ -989,28 +1015,38 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
     }
     if constexpr (D <= 16) {
         if (ldsg && a.rows_S == 0 && a.n_pwaves == 1 && a.mode == EMIT_PROBS) {
-            // + effects, emit ring (states, circuits), program window
-            const size_t extra = ((size_t)a.n_effects * D + BASE_ER * (D + 1)) * sizeof(double) +
-                                 (BASE_ER + BASE_PW) * sizeof(int32_t);
-            const size_t slot_bytes = (size_t)(n_slots > 0 ? n_slots : 1) * 64 * sizeof(double);   // one state per lane group
-            if (slot_bytes + extra + gate_bytes <= 156 * 1024) {
-                if (hipError_t ea = raise_lds((const void*)walk_base_kernel<D>, slot_bytes + extra + gate_bytes)) return ea;
-                hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)blocks), dim3(64), slot_bytes + extra + gate_bytes,
-                                   stream, a, n_slots);
+            const size_t sh = base_shared_doubles(D, a.n_gates, a.n_effects) * sizeof(double);
+            const size_t pw = base_wave_doubles(D, n_slots) * sizeof(double);
+            if (sh + pw <= 156 * 1024) {
+                // wavefronts per workgroup: the fewest with which every task of the launch is resident at once (a.chain_share
+                // passes run side by side, each gets its share of the chip); a chain alone on its SIMD steps fastest
+                static const int n_cus = []() {
+                    int dev = 0, n = 0;
+                    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) return n;
+                    return 256;
+                }();
+                const int64_t want = blocks * (int64_t)(a.chain_share > 1 ? a.chain_share : 1);
+                int wpb = 1;
+                for (; wpb < BASE_MAXW; wpb *= 2) {
+                    const int64_t per_cu = std::min<int64_t>((int64_t)(160 * 1024 / (sh + wpb * pw)) * wpb, 20);      // (96 VGPRs: 5 wavefronts per SIMD)
+                    if (per_cu * n_cus >= want) break;
+                    if (sh + 2 * wpb * pw > 156 * 1024) break;
+                }
+                const size_t bytes = sh + wpb * pw;
+                if (hipError_t ea = raise_lds((const void*)walk_base_kernel<D>, bytes)) return ea;
+                hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)((blocks + wpb - 1) / wpb)), dim3(64 * wpb), bytes,
+                                   stream, a, n_slots, wpb, blocks);
                 return hipGetLastError();
             }
         }
         if (ldsg && a.rows_S == 0 && a.n_models > 0 && a.mode == EMIT_PROBS && a.n_pwaves == a.n_models) {
             // whole-model mode on the chain kernel: one single-wavefront block per (model set, task)
-            const size_t extra = ((size_t)a.n_effects * D + BASE_ER * (D + 1)) * sizeof(double) +
-                                 (BASE_ER + BASE_PW) * sizeof(int32_t);
-            const size_t slot_bytes = (size_t)(n_slots > 0 ? n_slots : 1) * 64 * sizeof(double);
-            if (slot_bytes + extra + gate_bytes <= 156 * 1024) {
-                if (hipError_t ea = raise_lds((const void*)walk_base_kernel<D>, slot_bytes + extra + gate_bytes)) return ea;
+            const size_t bytes = (base_shared_doubles(D, a.n_gates, a.n_effects) + base_wave_doubles(D, n_slots)) * sizeof(double);
+            if (bytes <= 156 * 1024) {
+                if (hipError_t ea = raise_lds((const void*)walk_base_kernel<D>, bytes)) return ea;
                 WalkArgs b = a;
                 b.mm_tasks = (int32_t)n_tasks; b.n_pwaves = 1;
-                hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)blocks), dim3(64), slot_bytes + extra + gate_bytes,
-                                   stream, b, n_slots);
+                hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)blocks), dim3(64), bytes, stream, b, n_slots, 1, blocks);
                 return hipGetLastError();
             }
         }
