@@ -66,7 +66,6 @@ struct WalkArgs {
     int32_t n_models;
     int64_t model_stride, out_model_stride;
     int32_t mm_tasks;        // number of tasks (walk_base_kernel derives (task, model) from blockIdx.x)
-    int32_t chain_share;     // walk_base_kernel: this many chain passes run side by side on the device (0 / 1: this one alone)
     // Fused base lane (launch-bound plans, S = 1): lane 63 of every wavefront carries NO perturbation, i.e. the base
     // model; the quotient uses ITS probability instead of pbase[], nothing is taken from the base-state cache, and the
     // separate base pass is not launched at all.  Lane 63 of parameter wavefront 0 writes probs_out (may be NULL).
@@ -90,6 +89,9 @@ struct WalkArgs {
     const int32_t* wave_row;     // EMIT_HESS: per wave: dest row (block-1 position) and its index into prow
     const int32_t* wave_rowidx;
     const int32_t* lane_colidx;  // EMIT_HESS: per lane slot: index into dcol's columns
+    // (new fields go HERE, at the end: the persistent FD kernel re-reads its arguments from the kernarg segment with wide
+    //  scalar loads, and shifting them by 8 bytes -- one int32 inserted mid-struct -- cost 5 % on a 1/8 atom)
+    int32_t chain_share;     // walk_base_kernel: this many chain passes run side by side on the device (0 / 1: this one alone)
 };
 
 // Launch the walk over all tasks x parameter wavefronts.  S = number of specials per lane (0,1,2);
