@@ -166,3 +166,28 @@ def test_exact_hessian_refuses_forward_derivative_caches_beyond_4gb():
     p = pl.fill_probs()
     assert np.isfinite(p).all()
     pl.close()
+
+
+@pytest.mark.parametrize("stream", ["1", "0"])
+def test_analytic_fill_overwrites_every_requested_entry(stream, monkeypatch):
+    """Circuits that never apply some gate must get exact zeros in that gate's columns, not whatever the buffer held:
+    the destination is pre-filled with NaN and a sentinel, in the streamed and the gate-by-gate form of the contraction."""
+    from pygsti_amd import _lib
+    monkeypatch.setenv("GST_ANALYTIC_STREAM", stream)
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    pl = plan_from_fixture(fx)
+    nE, nP = int(fx["nE"]), int(fx["nP"])
+    ld = nP + 3
+    d_J = pl.device_malloc(nE * ld * 8)
+    fill = np.full((nE, ld), np.nan); fill[:, nP:] = -7.0
+    pl.memcpy_h2d(d_J, fill)
+    pl.fill_dprobs_dev(d_J, ld, np.arange(nP), None, 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
+    J = pl.memcpy_d2h(np.empty((nE, ld)), d_J)
+    assert np.isfinite(J[:, :nP]).all(), "entries left unwritten: %d" % int((~np.isfinite(J[:, :nP])).sum())
+    assert (J[:, nP:] == -7.0).all()
+    cols = fx["dprobs_cols"]
+    assert np.abs(J[fx["matrix_rows"]][:, cols] - fx["dprobs_matrix"]).max() < TOL
+    # where the FD Jacobian is exactly zero (a circuit that never applies the column's gate, among others) this one is ~0
+    zero = (fx["dprobs_map"] == 0.0)
+    assert np.abs(J[:, cols][zero]).max() <= 1e-8
+    pl.device_free(d_J)
