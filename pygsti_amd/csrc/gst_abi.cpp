@@ -926,8 +926,6 @@ int ensure_reverse(gst_plan* p)
                 for (int64_t t = 0; t < cg; t++) { bf1.push_back(pf[(size_t)(p1 - cg + t)]); bf2.push_back(pf[(size_t)(q1 - cg + t)]); br.push_back(pr[(size_t)(p1 - cg + t)]); }
                 for (int64_t j = p0; j < p1 - cg; j++) { bf1.push_back(pf[(size_t)j]); bf2.push_back(-1); br.push_back(pr[(size_t)j]); }
                 for (int64_t j = q0; j < q1 - cg; j++) { bf1.push_back(-1); bf2.push_back(pf[(size_t)j]); br.push_back(pr[(size_t)j]); }
-                // (a gate neither circuit applies still gets one block of dead slots: its columns must be written -- as zeros)
-                if (bf1.size() / blk_slots == (size_t)bptr[(size_t)k * nG + g] && bf1.size() % blk_slots == 0) { bf1.push_back(-1); bf2.push_back(-1); br.push_back(0); }
                 while (bf1.size() % blk_slots) { bf1.push_back(-1); bf2.push_back(-1); br.push_back(br.empty() ? 0 : br.back()); }
             }
             if (bf1.size() / 4 > 0x1ffffff0u) return fail(GST_EUNSUPPORTED, "analytic block stream too long");

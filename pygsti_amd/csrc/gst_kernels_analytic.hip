@@ -449,7 +449,20 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                     if (q.pos + 1 < q.end) return Cur{q.g, q.pos + 1, q.end};
                     return seek(q.g + 1);
                 };
+                // gates the item never applies have no blocks, but their columns must be written all the same -- as zeros
+                auto zero_gates = [&](int g_from, int g_to) {
+                    d4_t z[NX];
+#pragma unroll
+                    for (int x = 0; x < NX; x++) z[x] = (d4_t){0.0, 0.0, 0.0, 0.0};
+                    for (int g = g_from; g < g_to; g++) {
+                        const int32_t c0 = __builtin_amdgcn_readlane(c0_l, g);
+                        if (c0 == -2) continue;
+                        store_block(g, c0, NX, dest_u, z);
+                        store_block(g, c0, NX, dest_u2, z);
+                    }
+                };
                 Cur cur0 = seek(0);
+                zero_gates(0, cur0.g);
                 if (cur0.g < nG) {
                     d4_t acc[NX], acc2[NX];
 #pragma unroll
@@ -485,13 +498,14 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                             }
                         }
                     };
-                    auto flush_if_last = [&](const Cur& q) {
+                    auto flush_if_last = [&](const Cur& q, const Cur& next) {
                         if (q.pos + 1 != q.end) return;
                         const int32_t c0 = __builtin_amdgcn_readlane(c0_l, q.g);
                         store_block(q.g, c0, NX, dest_u, acc);
                         store_block(q.g, c0, NX, dest_u2, acc2);
 #pragma unroll
                         for (int x = 0; x < NX; x++) { acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc2[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
+                        zero_gates(q.g + 1, next.g);          // (the gates between this one and the next block's)
                     };
                     Cur cur1 = advance(cur0), cur2 = advance(cur1);
                     int32_t f1A[SM], f2A[SM], rrA[SM], f1B[SM], f2B[SM], rrB[SM];
@@ -508,7 +522,7 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                         DB_FENCE();
                         mma(F10, F20, B0, ok10, ok20);
                         DB_FENCE();
-                        flush_if_last(cur0);
+                        flush_if_last(cur0, cur1);
                         cur0 = cur1; cur1 = cur2; cur2 = advance(cur2);
                         if (cur0.g >= nG) break;
                         DB_FENCE();
@@ -518,7 +532,7 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                         DB_FENCE();
                         mma(F11, F21, B1, ok11, ok21);
                         DB_FENCE();
-                        flush_if_last(cur0);
+                        flush_if_last(cur0, cur1);
                         cur0 = cur1; cur1 = cur2; cur2 = advance(cur2);
                         if (cur0.g >= nG) break;
                     }
