@@ -450,15 +450,29 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                     return seek(q.g + 1);
                 };
                 // gates the item never applies have no blocks, but their columns must be written all the same -- as zeros
+                // (written out on its own, with no accumulator array handed to `store_block` from inside a run-time loop:
+                //  that puts the arrays -- the live MFMA accumulators included -- into scratch memory)
                 auto zero_gates = [&](int g_from, int g_to) {
-                    d4_t z[NX];
-#pragma unroll
-                    for (int x = 0; x < NX; x++) z[x] = (d4_t){0.0, 0.0, 0.0, 0.0};
+                    if (a.accumulate) return;                  // (adding zeros)
                     for (int g = g_from; g < g_to; g++) {
                         const int32_t c0 = __builtin_amdgcn_readlane(c0_l, g);
                         if (c0 == -2) continue;
-                        store_block(g, c0, NX, dest_u, z);
-                        store_block(g, c0, NX, dest_u2, z);
+#pragma unroll
+                        for (int x = 0; x < 2 * NX; x++) {
+                            const int64_t dst = x < NX ? dest_u[x & (NX - 1)] : dest_u2[x & (NX - 1)];
+                            if (c0 >= 0) {
+                                double* o = a.out + dst * a.ld + c0 + kk * D + i;
+#pragma unroll
+                                for (int r = 0; r < 4; r++) __builtin_nontemporal_store(0.0, &o[4 * r * D]);
+                            } else {
+                                const int32_t* cm = a.colmap_gate + (int64_t)g * D * D + kk * D + i;
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    const int32_t cc = cm[4 * r * D];
+                                    if (cc >= 0) a.out[dst * a.ld + cc] = 0.0;
+                                }
+                            }
+                        }
                     }
                 };
                 Cur cur0 = seek(0);

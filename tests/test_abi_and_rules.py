@@ -89,6 +89,34 @@ def test_walk_kernels_have_no_fma_outside_division():
     assert n_div > 0 and n_fma <= 8 * n_div, (n_fma, n_div)
 
 
+def test_hot_kernels_do_not_use_scratch_memory():
+    """A kernel whose arrays (MFMA accumulators, state vectors) end up in scratch memory still computes the right numbers,
+    1.5-2x slower -- it happened when an accumulator array was handed to a lambda from inside a run-time loop.  The code
+    objects' metadata must show a private segment of 0 bytes for the contraction and the walk kernels."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("ROCm llvm tools not found")
+    seen = {}
+    with tempfile.TemporaryDirectory() as td:
+        so = os.path.join(td, "libgstfwd.so")
+        shutil.copy(_lib.LIB_PATH, so)
+        subprocess.check_call([objdump, "--offloading", so], stdout=subprocess.DEVNULL)
+        for co in glob.glob(so + ".*gfx950*"):
+            notes = subprocess.check_output([readelf, "--notes", co]).decode()
+            for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+)", notes, re.S):
+                seen[m.group(1)] = int(m.group(2))
+    hot = {k: v for k, v in seen.items() if re.search(r"analytic_mfma_kernel|walk_kernel|walk_base_kernel|jtj_mfma_lds_kernel", k)}
+    assert len(hot) >= 4, sorted(seen)
+    # (the FD walk kernels keep a handful of spilled registers, 64-80 bytes per lane, outside their inner loops -- measured,
+    #  accepted; an array in scratch shows up as hundreds of bytes)
+    bad = {k: v for k, v in hot.items() if "analytic_mfma64" not in k and v > (128 if "walk_kernel" in k else 0)}
+    assert not bad, bad
+
+
 def test_comm_entry_points_fail_loudly_without_a_device():
     """The exchange entry points validate their arguments and need a device; the IPC rendezvous token is plain data."""
     uid = _lib.Comm.unique_id(_lib.TRANSPORT_IPC)
