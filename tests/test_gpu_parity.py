@@ -116,6 +116,32 @@ def test_dprobs_into_page_locked_array_bitwise(name, direct, monkeypatch):
     assert_bitwise(pl.fill_dprobs(param_idx=cols, eps=1e-7), fx["dprobs_map"], "pageable destination afterwards")
 
 
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2", "smq2Q_XYICNOT_L2_depol", "3q_explicit_L64"])
+@pytest.mark.parametrize("mode", ["fd", "analytic"])
+def test_device_fills_overwrite_every_requested_entry(name, mode):
+    """Fresh device memory is zero, and structural zeros are a third of a GST Jacobian: an entry a kernel forgets to write
+    goes unnoticed unless the destination starts out as NaN (that is how a skipped block of the analytic contraction was
+    found).  Device destination pre-filled with NaN and a sentinel beyond the requested columns, every mode."""
+    from pygsti_amd import _lib
+    fx = load_fixture(name)
+    pl = plan_from_fixture(fx)
+    cols = fx["dprobs_cols"]; nE, n = int(fx["nE"]), len(cols)
+    if mode == "analytic" and int(fx["D"]) == 64 and n > 4096:
+        cols = cols[:4096]; n = len(cols)
+    ld = n + 2
+    d_J = pl.device_malloc(nE * ld * 8)
+    fill = np.full((nE, ld), np.nan); fill[:, n:] = -7.0
+    pl.memcpy_h2d(d_J, fill)
+    pl.fill_dprobs_dev(d_J, ld, cols, None, float(fx["derivative_eps"]), None, _lib.DERIV_FD if mode == "fd" else _lib.DERIV_ANALYTIC)
+    pl.sync()
+    J = pl.memcpy_d2h(np.empty((nE, ld)), d_J)
+    assert np.isfinite(J[:, :n]).all(), "entries left unwritten: %d" % int((~np.isfinite(J[:, :n])).sum())
+    assert (J[:, n:] == -7.0).all()
+    if mode == "fd":
+        assert_bitwise(J[:, :n], fx["dprobs_map"][:, :n], "FD into a NaN-prefilled device array " + name)
+    pl.device_free(d_J)
+
+
 @pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2", "3q_explicit_L64"])
 def test_hprobs_fd_bitwise_vs_reference(name):
     fx = load_fixture(name)
