@@ -142,6 +142,21 @@ def test_device_fills_overwrite_every_requested_entry(name, mode):
     pl.device_free(d_J)
 
 
+@pytest.mark.parametrize("name", FIXTURES)
+def test_device_probs_overwrite_every_element(name):
+    fx = load_fixture(name)
+    pl = plan_from_fixture(fx)
+    nE = int(fx["nE"])
+    d_p = pl.device_malloc((nE + 3) * 8)
+    fill = np.full(nE + 3, np.nan); fill[nE:] = -7.0
+    pl.memcpy_h2d(d_p, fill)
+    pl.fill_probs_dev(d_p); pl.sync()
+    p = pl.memcpy_d2h(np.empty(nE + 3), d_p)
+    assert_bitwise(p[:nE], fx["probs"], "probabilities into a NaN-prefilled device array " + name)
+    assert (p[nE:] == -7.0).all()
+    pl.device_free(d_p)
+
+
 @pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2", "3q_explicit_L64"])
 def test_hprobs_fd_bitwise_vs_reference(name):
     fx = load_fixture(name)
