@@ -140,6 +140,49 @@ def cpu_baseline(pack, model, max_len, design):
     return one, allc
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one rank per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT exported as torch.distributed.run would), let rank 0 own stdout (the one JSON
+    line), send the other ranks' stdout to stderr, and return the worst exit code.  A rank that fails takes the others
+    down (exact PIDs); the whole job is bounded by GST_BENCH_TIMEOUT seconds (default 1500)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.monotonic() + float(os.environ.get("GST_BENCH_TIMEOUT", "1500"))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is not None:
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+        if alive and (rc != 0 or time.monotonic() > deadline):
+            if rc == 0:
+                rc = 124
+                print("[bench] ranks still running at the deadline: stopping them", file=sys.stderr, flush=True)
+            for p in alive:
+                p.terminate()
+            t_kill = time.monotonic() + 10
+            for p in alive:
+                try:
+                    p.wait(max(0.1, t_kill - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+    return rc
+
+
 _T0 = time.perf_counter()
 
 
@@ -175,12 +218,14 @@ def main():
                          "analytic: exact derivatives (MatrixForwardSimulator semantics)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))           # plain `python bench.py --gpus N`: become the launcher of N ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d started inside a job of WORLD_SIZE=%d: launch it with --nproc-per-node %d, or with no "
+                 "launcher at all (it then starts its own ranks)" % (args.gpus, world, args.gpus))
 
     from pygsti_amd import _lib, dist as gdist
     device = local_rank % max(_lib.device_count(), 1)      # (ranks share a GPU only in 1-GPU plumbing runs)
@@ -258,10 +303,14 @@ def main():
         if world == 1:
             plan.sync()                                # N=1: per-step HIP-event read-out (stream stays ordered)
             kernel_ms.append(plan.stats()["last_kernel_ms"])
+    plan.sync()
+    t_local = time.perf_counter() - t0             # this rank's own K steps (the max over ranks, after the barrier, is `dt`)
     barrier_sync(plan)
     dt = ctx.max_over_ranks(time.perf_counter() - t0)
     if not kernel_ms:
         kernel_ms = [plan.stats()["last_kernel_ms"]]
+    per_rank_ms = ctx.all_floats(1e3 * t_local / args.steps)
+    per_rank_kernel_ms = ctx.all_floats(float(np.mean(kernel_ms)))
 
     if world > 1:
         # every rank must now hold every circuit's probabilities: they sum to 1 per circuit
@@ -471,6 +520,8 @@ def main():
                                       if args.deriv == "fd" else "analytic (reference MatrixForwardSimulator semantics)"),
                        "parallelism": "atoms%d" % world if lay_world == world else
                                       "rank 0 of atoms%d emulated on one GPU" % lay_world},
+            "per_rank": {"ms_per_step": per_rank_ms, "dominant_kernel_ms": per_rank_kernel_ms,
+                         "note": "each rank's own time for the K steps before the closing barrier; `ms_per_step` is the max over ranks after it"},
             "exchange": exchange,
             "normal_equations": jtj_info,
             "analytic_dprobs": ana_info,

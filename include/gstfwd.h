@@ -336,7 +336,9 @@ int gst_comm_sync(gst_comm *comm);                    /* the comm's own stream (
 typedef struct {
     int32_t transport, rank, size, device;
     int32_t rccl_version;        /* ncclGetVersion code of the library bound at run time (0 for the IPC transport) */
-    int32_t reserved[3];
+    int32_t ipc_opens;           /* IPC transport: peer allocations this rank has mapped so far (hipIpcOpenMemHandle calls);
+                                    destinations that alternate are re-published under their old id and do not re-open */
+    int32_t reserved[2];
 } gst_comm_info;
 int gst_comm_get_info(const gst_comm *comm, gst_comm_info *out);
 

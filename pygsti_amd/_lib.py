@@ -58,7 +58,7 @@ class ObjectiveDesc(C.Structure):
 
 class CommInfo(C.Structure):
     _fields_ = [("transport", C.c_int32), ("rank", C.c_int32), ("size", C.c_int32), ("device", C.c_int32),
-                ("rccl_version", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("rccl_version", C.c_int32), ("ipc_opens", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Stats(C.Structure):
@@ -566,4 +566,4 @@ class Comm:
         i = CommInfo()
         check(lib().gst_comm_get_info(self._h, C.byref(i)))
         return {"transport": "rccl" if i.transport == TRANSPORT_RCCL else "ipc", "rank": i.rank, "size": i.size,
-                "device": i.device, "rccl_version": i.rccl_version}
+                "device": i.device, "rccl_version": i.rccl_version, "ipc_opens": i.ipc_opens}

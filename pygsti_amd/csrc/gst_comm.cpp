@@ -147,6 +147,11 @@ struct gst_comm {
     std::string shm_name;
     uint32_t local_sense = 0;
     uint64_t next_alloc_id = 1;
+    // publisher side: allocations this rank has published before, so that a destination that comes back (Jacobian /
+    // probabilities / all-reduce staging alternate) is re-published under its OLD id and the peers' mapping caches hit
+    struct Published { hipIpcMemHandle_t handle; uint64_t bytes; uint64_t alloc_id; uint64_t last_use; };
+    std::vector<Published> published;
+    uint64_t ipc_opens = 0;                               // hipIpcOpenMemHandle calls made by this rank (tests: no re-open on A/B/A/B)
     std::vector<OpenedHandle> opened;                     // per peer rank: IPC_MAPPINGS_PER_PEER mappings of its recent destinations
     uint64_t use_clock = 0;
     double* stage = nullptr;                              // all-reduce staging [size][stage_n]
@@ -189,8 +194,22 @@ int ipc_publish(gst_comm* c, const void* ptr)
     hipIpcMemHandle_t h;
     HIP_TRYC(hipIpcGetMemHandle(&h, base));
     if (s.alloc_id == 0 || s.bytes != bytes || std::memcmp(&h, &s.handle, sizeof(h)) != 0) {
+        gst_comm::Published* hit = nullptr;
+        gst_comm::Published* lru = nullptr;
+        for (auto& p : c->published) {
+            if (p.bytes == bytes && std::memcmp(&h, &p.handle, sizeof(h)) == 0) hit = &p;
+            if (!lru || p.last_use < lru->last_use) lru = &p;
+        }
+        if (!hit) {
+            // (as many remembered allocations as a peer keeps mappings: an id evicted here is evicted there, too)
+            if (c->published.size() < (size_t)IPC_MAPPINGS_PER_PEER) { c->published.push_back({}); hit = &c->published.back(); }
+            else hit = lru;
+            hit->handle = h; hit->bytes = bytes;
+            hit->alloc_id = ((uint64_t)(c->rank + 1) << 40) | c->next_alloc_id++;
+        }
+        hit->last_use = ++c->use_clock;
         s.handle = h; s.bytes = bytes; s.device = c->device;
-        s.alloc_id = ((uint64_t)(c->rank + 1) << 40) | c->next_alloc_id++;
+        s.alloc_id = hit->alloc_id;
     }
     s.offset = (uint64_t)((const char*)ptr - (const char*)base);
     return GST_OK;
@@ -212,6 +231,7 @@ int ipc_peer_ptr(gst_comm* c, int r, char** out)
         if (lru->base) { (void)hipIpcCloseMemHandle(lru->base); lru->base = nullptr; lru->alloc_id = 0; }
         void* p = nullptr;
         HIP_TRYC(hipIpcOpenMemHandle(&p, s.handle, hipIpcMemLazyEnablePeerAccess));
+        c->ipc_opens++;
         lru->base = p; lru->alloc_id = s.alloc_id;
         hit = lru;
     }
@@ -263,20 +283,26 @@ int exchange_rows(gst_comm* c, hipStream_t st, const double* d_local, double* d_
     if (c->transport == GST_TRANSPORT_RCCL) {          // (one rank: an empty group -- still a round trip through RCCL)
         const RcclApi* A = c->api;
         NCCL_TRY(A, A->GroupStart());
-        for (int32_t k = 0; k < b.n; k++) {
+        // a failing Send / Recv must not leave the group open (every later RCCL call of this thread would join it):
+        // remember the first error, close the group, then report
+        ncclResult_t bad = ncclSuccess;
+        const char* what = "";
+        for (int32_t k = 0; k < b.n && bad == ncclSuccess; k++) {
             const size_t cnt = (size_t)(b.rows[k] * row_doubles);
             if (cnt == 0) continue;
             const int o = b.owner[k];
             if (o == c->rank) {
-                for (int r = 0; r < c->size; r++) {
+                for (int r = 0; r < c->size && bad == ncclSuccess; r++) {
                     if (r == c->rank || !(all || r == root)) continue;
-                    NCCL_TRY(A, A->Send(src[(size_t)k], cnt, ncclDouble, r, c->nccl, st));
+                    bad = A->Send(src[(size_t)k], cnt, ncclDouble, r, c->nccl, st); what = "ncclSend";
                 }
             } else if (i_receive) {
-                NCCL_TRY(A, A->Recv(d_full + b.row0[k] * row_doubles, cnt, ncclDouble, o, c->nccl, st));
+                bad = A->Recv(d_full + b.row0[k] * row_doubles, cnt, ncclDouble, o, c->nccl, st); what = "ncclRecv";
             }
         }
-        NCCL_TRY(A, A->GroupEnd());
+        const ncclResult_t ended = A->GroupEnd();
+        if (bad != ncclSuccess) return set_error(GST_EHIP, std::string(what) + ": " + A->GetErrorString(bad));
+        if (ended != ncclSuccess) return set_error(GST_EHIP, std::string("ncclGroupEnd: ") + A->GetErrorString(ended));
         return GST_OK;
     }
     // IPC: receivers publish their buffers; once every rank's fills are done (stream sync + barrier) each owner copies its
@@ -424,9 +450,25 @@ int gst_comm_create(int transport, int device, int rank, int size, const void* i
             c->box = (IpcMailbox*)m;          // (a fresh segment is zero-filled: counters start at 0)
             if (rank == 0) c->box->size = (uint32_t)size;
             c->opened.assign((size_t)size * IPC_MAPPINGS_PER_PEER, OpenedHandle());
-            c->box->attached.fetch_add(1, std::memory_order_acq_rel);
             struct timespec t0;
             clock_gettime(CLOCK_MONOTONIC, &t0);
+            // every rank must have been started with the same world size; rank 0 wrote its own into the mailbox before it
+            // attached.  Checked BEFORE the attach wait: a mismatch would otherwise end in that wait's time-out (too few
+            // ranks) or in barriers that release early (too many)
+            for (;;) {
+                const uint32_t theirs = ((volatile IpcMailbox*)c->box)->size;
+                if (theirs == (uint32_t)size) break;
+                struct timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if (theirs != 0 || t1.tv_sec - t0.tv_sec > 120) {
+                    munmap(c->box, sizeof(IpcMailbox));
+                    (void)hipStreamDestroy(c->stream); delete c;
+                    return set_error(GST_EINVAL, "rank " + std::to_string(rank) + " was created with size " + std::to_string(size) +
+                                                     " but rank 0's mailbox says " + std::to_string(theirs));
+                }
+                usleep(200);
+            }
+            c->box->attached.fetch_add(1, std::memory_order_acq_rel);
             while (c->box->attached.load(std::memory_order_acquire) < (uint32_t)size) {
                 usleep(200);
                 struct timespec t1;
@@ -569,6 +611,7 @@ int gst_comm_get_info(const gst_comm* c, gst_comm_info* out)
     std::memset(out, 0, sizeof(*out));
     out->transport = c->transport; out->rank = c->rank; out->size = c->size; out->device = c->device;
     out->rccl_version = c->rccl_version;
+    out->ipc_opens = (int32_t)std::min<uint64_t>(c->ipc_opens, 0x7fffffffu);
     return GST_OK;
 }
 

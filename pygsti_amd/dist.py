@@ -96,6 +96,17 @@ class DistContext:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
+    def all_floats(self, x):
+        """[x of rank 0, x of rank 1, ...] on every rank."""
+        if self.size == 1:
+            return [float(x)]
+        import torch
+        import torch.distributed as dist
+        t = torch.zeros(self.size, dtype=torch.float64)
+        t[self.rank] = float(x)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [float(v) for v in t]
+
     def all_ok(self, ok):
         """True iff `ok` on every rank."""
         return self.max_over_ranks(0.0 if ok else 1.0) == 0.0
@@ -136,6 +147,33 @@ def init(device=None, transport="auto", want_comm=True):
     return ctx
 
 
+def _comm_with_deadline(rank, size, uid, device, code, name, err):
+    """Create the communicator under a deadline (GST_COMM_INIT_TIMEOUT seconds, default 90): ncclCommInitRank is a
+    collective that blocks for as long as a peer is missing, so a rank that died, or a fabric that never comes up, must
+    not hang the job.  The call runs on a helper thread (ctypes releases the GIL); on expiry the rank reports failure --
+    loudly, on stderr -- and `_create_comm` moves every rank to the next transport together.  (The helper thread cannot
+    be cancelled; it is a daemon and dies with the process.)"""
+    import sys
+    import threading
+    timeout = float(os.environ.get("GST_COMM_INIT_TIMEOUT", "90"))
+    box = {}
+
+    def work():
+        try:
+            box["comm"] = _lib.Comm(rank, size, uid, device, code)
+        except Exception as e:
+            box["err"] = "%s: %s" % (type(e).__name__, e)
+
+    th = threading.Thread(target=work, name="gst-comm-init", daemon=True)
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        msg = "%s communicator not up after %.0f s on rank %d (GST_COMM_INIT_TIMEOUT)" % (name, timeout, rank)
+        print("[pygsti_amd.dist] " + msg + " -- falling back", file=sys.stderr, flush=True)
+        return None, msg
+    return box.get("comm"), box.get("err", err)
+
+
 def _create_comm(ctx, rank, size, local_rank, device, transport):
     transport = os.environ.get("GST_TRANSPORT", transport)
     if device is None:
@@ -152,10 +190,7 @@ def _create_comm(ctx, rank, size, local_rank, device, transport):
         uid = ctx.broadcast_bytes(uid)
         comm = None
         if uid is not None:
-            try:
-                comm = _lib.Comm(rank, size, uid, device, code)
-            except Exception as e:
-                err = "%s: %s" % (type(e).__name__, e)
+            comm, err = _comm_with_deadline(rank, size, uid, device, code, tr, err)
         if ctx.all_ok(comm is not None):
             ctx.comm = comm
             break
@@ -163,6 +198,11 @@ def _create_comm(ctx, rank, size, local_rank, device, transport):
             comm.close()
         errors.append("%s transport: %s" % (tr, err or "failed on another rank"))
     ctx.comm_error = "; ".join(errors) if errors else None
+    if errors and rank == 0:
+        import sys
+        print("[pygsti_amd.dist] device transport fallback: %s -> %s" % (
+            ctx.comm_error, "NONE (host-staged exchange)" if ctx.comm is None else
+            {_lib.TRANSPORT_RCCL: "rccl", _lib.TRANSPORT_IPC: "ipc"}.get(ctx.comm.transport, "?")), file=sys.stderr, flush=True)
 
 
 # ---- device arrays -------------------------------------------------------------------------------------------------
@@ -218,11 +258,29 @@ def gather_elements(local, layout, group=None, dst=None):
     return out.numpy() if as_numpy else out
 
 
-def allreduce_sum_host(arr, group=None):
-    """In-place sum of a host numpy array over the control group (`allreduce_sum`, resourceallocation.py:441-508)."""
+def allreduce_sum_host(arr, group=None, expect_size=1, comm=None):
+    """In-place sum of a host numpy array over the ranks (`allreduce_sum`, resourceallocation.py:441-508).
+
+    expect_size : the number of ranks the CALLER's layout was built for.  When it is > 1 the sum must really happen:
+        through the torch.distributed control group when one exists, else through `comm` -- an mpi4py-style
+        communicator (the reference's `ResourceAllocation.comm`) -- else a RuntimeError: handing back one rank's
+        partial J^T J as if it were the sum would be silent corruption."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
+        if expect_size > 1:
+            if comm is not None and hasattr(comm, "Allreduce"):
+                buf = np.ascontiguousarray(arr)
+                out = np.empty_like(buf)
+                comm.Allreduce(buf, out)          # mpi4py: op defaults to SUM
+                arr[...] = out
+                return arr
+            raise RuntimeError("layout spans %d ranks but this process has neither a torch.distributed group "
+                               "(pygsti_amd.dist.init) nor an MPI communicator: cannot sum over ranks" % expect_size)
+        return arr
+    if dist.get_world_size(group) == 1:
+        if expect_size > 1:
+            raise RuntimeError("layout spans %d ranks but the process group has one" % expect_size)
         return arr
     t = torch.from_numpy(arr) if arr.flags.c_contiguous else torch.from_numpy(np.ascontiguousarray(arr))
     dist.all_reduce(t, group=group)

@@ -112,7 +112,8 @@ class HipMapForwardSimulator:
         blk = tuple(self._pblk_sizes) if self._pblk_sizes else (None, None)
         if len(blk) == 1:
             blk = (blk[0], None)
-        return HipCOPALayout(circuits, self.model, natoms, self.devices, rank, size, self.target_tasks, blk, dataset=dataset)
+        return HipCOPALayout(circuits, self.model, natoms, self.devices, rank, size, self.target_tasks, blk, dataset=dataset,
+                             mpi_comm=getattr(resource_alloc, "comm", None))
 
     # -- per-atom seams (mapforwardsim.py:372-391) ---------------------------------------------------------------
     def _prepare_atom(self, layout_atom):

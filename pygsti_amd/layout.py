@@ -82,7 +82,7 @@ class HipLayoutAtom:
 
 class HipCOPALayout:
     def __init__(self, circuits, model, num_atoms=1, devices=None, rank=0, size=1, target_tasks=0,
-                 param_dimension_blk_sizes=(None, None), max_slots=0, dataset=None):
+                 param_dimension_blk_sizes=(None, None), max_slots=0, dataset=None, mpi_comm=None):
         self.circuits = [tuple(c) for c in circuits]
         self.num_circuits = len(self.circuits)
         self.model_gate_labels = list(model.operations.keys())
@@ -104,6 +104,7 @@ class HipCOPALayout:
         self._circ_gates = np.fromiter(map(lookup.__getitem__, itertools.chain.from_iterable(self.circuits)),
                                        dtype=np.int32, count=int(self._circ_ptr[-1]))
         self._rank, self._size = rank, size
+        self._mpi_comm = mpi_comm       # optional mpi4py-style communicator of the caller's ResourceAllocation
         # ---- outcomes laid out per circuit (copalayout.py:155-168) ---------------------------------------------------
         # dataset None: every outcome of the POVM; otherwise only the outcomes the data set holds for the circuit, in
         # the data set's order (`dataset[circuit].outcomes`; outcomes the model does not know are dropped, as
@@ -119,10 +120,16 @@ class HipCOPALayout:
             ptr = np.zeros(self.num_circuits + 1, np.int64); idx = []
             for i, c in enumerate(self.circuits):
                 row = dataset[c]
-                outs = getattr(row, "outcomes", row)
+                # the reference's Map layout takes `unique_outcomes` (maplayout.py:69, mapforwardsim.py:358): a row of
+                # time-stamped data lists an outcome once per time stamp in `.outcomes`
+                outs = getattr(row, "unique_outcomes", None)
+                if outs is None:
+                    outs = getattr(row, "outcomes", row)
+                seen = set()
                 for o in outs:
                     o = (o,) if isinstance(o, str) else tuple(o)
-                    if o in lookup_o:
+                    if o in lookup_o and o not in seen:
+                        seen.add(o)
                         idx.append(lookup_o[o])
                 ptr[i + 1] = len(idx)
             self._out_ptr, self._out_idx = ptr, np.asarray(idx, np.int32)
@@ -275,7 +282,7 @@ class HipCOPALayout:
             part = np.empty((nP, nP)); plan.memcpy_d2h(part, d_out); acc += part
         if self._size > 1:
             from . import dist as _dist
-            _dist.allreduce_sum_host(acc)
+            _dist.allreduce_sum_host(acc, expect_size=self._size, comm=self._mpi_comm)
         jtj[...] = acc
 
     def fill_jtf(self, j, f, jtf):
@@ -290,7 +297,7 @@ class HipCOPALayout:
             part = np.empty(nP); plan.memcpy_d2h(part, d_out); acc += part
         if self._size > 1:
             from . import dist as _dist
-            _dist.allreduce_sum_host(acc)
+            _dist.allreduce_sum_host(acc, expect_size=self._size, comm=self._mpi_comm)
         jtf[...] = acc
 
     def resource_alloc(self, sub_alloc_name=None, empty_if_missing=True):

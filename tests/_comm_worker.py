@@ -61,6 +61,13 @@ def main():
     p0.sync(); ctx.barrier()
     J = np.empty((nE, nC)); p0.memcpy_d2h(J, d_J)
     P = np.empty(nE); p0.memcpy_d2h(P, d_P)
+    # (2b) alternating destinations A / B / A / B: a re-published allocation keeps its id, so no peer re-opens it
+    opens0 = ctx.comm.info()["ipc_opens"]
+    for _ in range(3):
+        gdist.allgather_elements_dev(ctx, lay, d_J, nC, p0)
+        gdist.allgather_elements_dev(ctx, lay, d_P, 1, p0)
+    p0.sync(); ctx.barrier()
+    reopens = ctx.comm.info()["ipc_opens"] - opens0
     # (3) all-reduce of a rank-dependent vector, twice with different lengths (staging growth)
     sums = []
     for n in (1000, 5000):
@@ -72,7 +79,7 @@ def main():
     ctx.barrier()
     idx = np.concatenate([np.arange(*lay.indices_for_index(i).indices(nE)) for i in range(len(circuits))])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), J=J[idx], P=P[idx], J_root=J_root[idx] if rank == 0 else np.zeros(0),
-             s0=sums[0], s1=sums[1], transport=ctx.transport, owned=np.array([a.element_slice.start for a in lay.atoms]))
+             s0=sums[0], s1=sums[1], transport=ctx.transport, reopens=reopens, owned=np.array([a.element_slice.start for a in lay.atoms]))
     for d in (d_J, d_P, d_loc, d_root):
         p0.device_free(d)
     ctx.close()

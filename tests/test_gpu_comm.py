@@ -73,6 +73,7 @@ def test_ranks_sharing_one_gpu_assemble_the_reference_jacobian_bitwise(tmp_path,
     v = [np.sin(np.arange(5000) * (r + 1.0)) * 10.0 ** (r - 3) for r in range(n_ranks)]
     for r, d in enumerate(res):
         assert str(d["transport"]) in ("ipc", "rccl")
+        assert int(d["reopens"]) == 0, "alternating destinations re-opened %d IPC mappings on rank %d" % (int(d["reopens"]), r)
         assert_bitwise(d["J"], fx["dprobs_map"], "all-gathered Jacobian on rank %d" % r)
         assert_bitwise(d["P"], fx["probs"], "all-gathered probabilities on rank %d" % r)
         # rank-order sums: bit-reproducible under the IPC transport

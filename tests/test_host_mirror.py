@@ -174,3 +174,46 @@ def test_dataset_restricted_layout(natoms):
         assert_bitwise(p[lay.indices_for_index(i)], ref[[names.index(o[0]) for o in outs]], "circuit %d" % i)
         assert lay.outcomes(c) == outs
     assert full.num_elements == 4 * len(circuits)
+
+
+class _TimestampedRow:
+    """A row of time-stamped data: `.outcomes` lists one entry per time stamp, `.unique_outcomes` each outcome once
+    (pygsti/data/dataset.py `_DataSetRow.unique_outcomes`, consumed at layouts/maplayout.py:69)."""
+
+    def __init__(self, outcomes):
+        self.outcomes = outcomes
+        self.unique_outcomes = list(dict.fromkeys(outcomes))
+
+
+def test_dataset_rows_with_repeated_outcomes_use_unique_outcomes():
+    pack = MP.smq1Q_XYI
+    circuits = pack.create_gst_circuits(1)[:6]
+    model = pack.target_model()
+    ds = {tuple(c): _TimestampedRow([("0",), ("1",), ("0",), ("0",)]) for c in circuits}
+    ds[tuple(circuits[1])] = [("1",), ("1",), ("0",)]            # no attributes at all: de-duplicated, order kept
+    lay = HipMapForwardSimulator(model).create_layout(circuits, dataset=ds)
+    assert lay.num_elements == 2 * len(circuits)
+    assert lay.outcomes_for_index(0) == (("0",), ("1",))
+    assert lay.outcomes_for_index(1) == (("1",), ("0",))
+
+
+def test_fill_jtj_refuses_to_return_a_partial_sum():
+    """A layout built for 2 ranks with no process group and no communicator must not hand back one rank's partial
+    J^T J: dist.allreduce_sum_host raises; an mpi4py-style `comm` on the resource allocation is used."""
+    from pygsti_amd import dist as gdist
+    part = np.arange(4.0)
+    with pytest.raises(RuntimeError):
+        gdist.allreduce_sum_host(part.copy(), expect_size=2)
+
+    class _FakeMPI:
+        def Allreduce(self, send, recv):
+            recv[...] = 2.0 * send                  # two ranks holding the same partial sum
+    got = gdist.allreduce_sum_host(part.copy(), expect_size=2, comm=_FakeMPI())
+    assert np.array_equal(got, 2.0 * part)
+    assert np.array_equal(gdist.allreduce_sum_host(part.copy(), expect_size=1), part)
+
+    class _RA:
+        comm_rank, comm_size, comm = 0, 2, _FakeMPI()
+    lay = HipMapForwardSimulator(MP.smq1Q_XYI.target_model(), num_atoms=2).create_layout(
+        MP.smq1Q_XYI.create_gst_circuits(1), resource_alloc=_RA())
+    assert lay._size == 2 and isinstance(lay._mpi_comm, _FakeMPI)
