@@ -117,6 +117,10 @@ typedef struct {
     double last_kernel_ms;     /* device time of the dominant kernel of the last fill (HIP events) */
     double last_total_ms;      /* device time of the whole last fill */
     int64_t last_launches;
+    int32_t last_fd_form;      /* last finite-difference fill: 0 = one workgroup per (task, 64 columns) pair; 1 = persistent
+                                  per-SIMD queues; 2 = persistent with the base pass walked inside the same launch */
+    int32_t last_fd_aborted;   /* 1: a bounded wait of that persistent launch ran out (producer workgroup not resident, e.g. a
+                                  shared device) and the stand-by launches behind it produced the result instead */
 } gst_stats;
 
 int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *opt, gst_plan **out);
@@ -365,6 +369,12 @@ int gst_get_stats(const gst_plan *plan, gst_stats *out);
  * *n_words.  task_off (may be NULL) receives n_tasks+1 offsets when cap_tasks suffices. */
 int gst_get_program(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words,
                     int64_t *task_off, int64_t cap_tasks);
+
+/* The per-SIMD queues the persistent finite-difference launch of a small atom would use for these columns (host-side
+ * only, no device needed): estimated work of each of n_queues queues after longest-first packing and hand-overs
+ * (handover: 0 none, 1 balance, 2 cut every walk).  Needs gst_set_param_map.  D <= 16. */
+int gst_get_fd_queues(gst_plan *plan, const int64_t *param_idx, int64_t n_param, int32_t n_queues, int32_t handover,
+                      int64_t *load_out, int32_t *n_pairs, int32_t *n_handovers);
 
 /* The state-id graph behind the NODE markers: parent state id (-1 for a state preparation) and gate / rho index of
  * every state, and the id of each expanded circuit's final state (what the analytic mode walks backwards). */

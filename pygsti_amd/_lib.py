@@ -65,13 +65,14 @@ class Stats(C.Structure):
     _fields_ = [("n_circuits", C.c_int64), ("n_elements", C.c_int64), ("sum_depth", C.c_int64),
                 ("trie_nodes", C.c_int64), ("applies_per_pass", C.c_int64), ("n_tasks", C.c_int64),
                 ("prog_words", C.c_int64), ("max_slots", C.c_int32), ("max_depth", C.c_int32),
-                ("last_kernel_ms", C.c_double), ("last_total_ms", C.c_double), ("last_launches", C.c_int64)]
+                ("last_kernel_ms", C.c_double), ("last_total_ms", C.c_double), ("last_launches", C.c_int64),
+                ("last_fd_form", C.c_int32), ("last_fd_aborted", C.c_int32)]
 
 
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_get_fd_queues", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_comm_get_unique_id", "gst_comm_create", "gst_comm_destroy", "gst_comm_allgather_rows",
@@ -116,6 +117,7 @@ def lib():
         L.gst_memcpy_d2h.argtypes = [vp, vp, vp, i64]
         L.gst_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.gst_get_program.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64]
+        L.gst_get_fd_queues.argtypes = [vp, vp, i64, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
         L.gst_get_state_graph.argtypes = [vp, vp, vp, i64, vp, i64, C.POINTER(i64)]
         L.gst_device_count.argtypes = [C.POINTER(i32)]
         L.gst_fill_dprobs_models.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp]
@@ -486,6 +488,15 @@ class Plan:
         s = Stats()
         check(lib().gst_get_stats(self._h, C.byref(s)))
         return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def fd_queues(self, param_idx, n_queues=1024, handover=1):
+        """Estimated work per queue of the persistent FD launch for these columns (host-side; gst_get_fd_queues)."""
+        pidx = _i64(param_idx)
+        load = np.zeros(int(n_queues), np.int64)
+        n_pairs, n_ho = C.c_int32(0), C.c_int32(0)
+        check(lib().gst_get_fd_queues(self._h, _ptr(pidx), len(pidx), int(n_queues), int(handover), _ptr(load),
+                                      C.byref(n_pairs), C.byref(n_ho)))
+        return load, n_pairs.value, n_ho.value
 
     def state_graph(self):
         n = C.c_int64(0)

@@ -178,11 +178,18 @@ struct gst_plan {
     bool host_direct = true;            // GST_HOST_DIRECT=0: page-locked destinations are filled by a copy, not by the kernel
     int64_t host_direct_min_cols = 64;  // (narrower column windows would cross PCIe in segments shorter than a wavefront's 512 bytes)
     int fd_handover = 1;                // GST_FD_HANDOVER: 0 never cut a walk, 1 cut to balance the per-SIMD queues, 2 cut every walk
+    bool fd_overlap = true;             // GST_FD_OVERLAP=0: the persistent FD launch keeps the separate base pass in front of it
+    bool fd_overlap_diag = false;       // GST_FD_OVERLAP=2 (measurements): the overlap kernel, but base pass in front and no chains
+    bool fd_standby = true;             // GST_FD_STANDBY=0 (measurements only): no stand-by launches behind the persistent one
+    bool last_overlap = false;          // the last FD fill ran its base pass inside the persistent launch
+    int last_fd_form = 0;               // gst_stats.last_fd_form
+    bool test_skip_chains = false;      // GST_FD_TEST_SKIP_CHAINS=1 (tests): the overlap launch walks no chain, so every wait runs out
     bool split_ready = false;
-    std::vector<int32_t> split_pc;      // gst::task_split_points
-    std::vector<float> split_frac;
+    std::vector<int32_t> cand_ptr, cand_pc;      // gst::task_split_candidates: where a walk may be handed over
+    std::vector<float> cand_frac;
+    std::vector<uint32_t> cand_live;
     int32_t n_split = 0;
-    DevBuf<int32_t> d_task_split_pc, d_ho_index, d_ho_id;
+    DevBuf<int32_t> d_task_split_pc, d_ho_index, d_ho_id, d_ho_live, d_ho_tag;
     DevBuf<uint32_t> d_ho_flag;
     DevBuf<double> d_ho_state;
     bool cached_fused = false;          // the cached lane tables were packed for the fused form
@@ -235,7 +242,7 @@ struct gst_plan {
             if (ev_upload[i]) (void)hipEventDestroy(ev_upload[i]);
         }
         d_mm_models.release(); d_mm_raw.release(); d_mm_dest.release();
-        d_task_split_pc.release(); d_ho_index.release(); d_ho_id.release(); d_ho_flag.release(); d_ho_state.release();
+        d_task_split_pc.release(); d_ho_index.release(); d_ho_id.release(); d_ho_live.release(); d_ho_tag.release(); d_ho_flag.release(); d_ho_state.release();
         d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
         for (auto& b : d_lane) b.release();
         d_wave_row.release(); d_wave_rowidx.release(); d_lane_colidx.release();
@@ -287,6 +294,9 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_HOST_DIRECT")) { p->host_direct = std::atoi(e) != 0; if (std::atoi(e) == 2) p->host_direct_min_cols = 1; }
     if (const char* e = std::getenv("GST_FD_HANDOVER")) p->fd_handover = std::atoi(e);
+    if (const char* e = std::getenv("GST_FD_OVERLAP")) { p->fd_overlap = std::atoi(e) != 0; p->fd_overlap_diag = std::atoi(e) == 2; }
+    if (const char* e = std::getenv("GST_FD_STANDBY")) p->fd_standby = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_FD_TEST_SKIP_CHAINS")) p->test_skip_chains = std::atoi(e) != 0;
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
     return GST_OK;
@@ -374,11 +384,12 @@ void base_args(gst_plan* p, gst::WalkArgs& a)
 
 // Base probabilities into d_dst (device), S = 0 walk: one wavefront per task.  With `fill_cache` the
 // pass also stores every state it produces (the derivative passes start from them).
-int run_probs(gst_plan* p, double* d_dst, bool fill_cache, int chain_share = 1)
+int run_probs(gst_plan* p, double* d_dst, bool fill_cache, int chain_share = 1, const uint32_t* guard = nullptr)
 {
     gst::WalkArgs a;
     base_args(p, a);
     a.chain_share = chain_share;
+    a.guard = guard;
     a.mode = gst::EMIT_PROBS;
     a.out = d_dst;
     if (fill_cache) {
@@ -459,6 +470,41 @@ int check_params(const gst_plan* p, const int64_t* idx, int64_t n)
     return GST_OK;
 }
 
+// Estimated cost of every (task, wavefront) pair of an FD request, longest first: a wavefront's work in a task is set
+// by the objects its lanes perturb (a gate the task never applies costs almost nothing, a gate of the germ costs the
+// whole chain; gst::task_gate_costs).  D = 64: the unit is a group of rows_group() consecutive wavefronts of one task.
+void fd_items(gst_plan* p, const LaneLayout& L, bool rows, std::vector<std::pair<int32_t, uint32_t>>& items, int32_t& n_units)
+{
+    const int nG = p->hp.n_gates;
+    const int64_t nT = p->hp.n_tasks();
+    const int stride = nG + 2;
+    std::vector<uint64_t> wave_gates(L.n_waves, 0);
+    std::vector<uint8_t> wave_rho(L.n_waves, 0);
+    for (size_t q = 0; q < L.col.size(); q++) {
+        if (L.col[q] < 0) continue;
+        const size_t w = rows ? q : q / 64;
+        if (L.kind[0][q] == GST_KIND_GATE) wave_gates[w] |= 1ull << L.obj[0][q];
+        else if (L.kind[0][q] == GST_KIND_RHO) wave_rho[w] = 1;
+    }
+    const int32_t grp = rows ? gst::rows_group(p->hp.D, p->hp.max_slots) : 1;
+    n_units = (L.n_waves + grp - 1) / grp;
+    items.clear();
+    items.reserve((size_t)nT * n_units);
+    for (int64_t t = 0; t < nT; t++) {
+        const int32_t* c = p->task_cost.data() + (size_t)t * stride;
+        for (int32_t u = 0; u < n_units; u++) {
+            int32_t best = c[nG + 1] / 4;
+            for (int32_t w = u * grp; w < std::min<int32_t>((u + 1) * grp, L.n_waves); w++) {
+                if (wave_rho[w]) best = std::max(best, c[nG + 1] / 4 + c[nG]);
+                else
+                    for (uint64_t m = wave_gates[w]; m; m &= m - 1) best = std::max(best, c[nG + 1] / 4 + c[__builtin_ctzll(m)]);
+            }
+            items.emplace_back(-best, (uint32_t)(t * n_units + u));
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+}
+
 // FD Jacobian columns into device memory.  d_raw (optional) receives the perturbed probabilities.
 int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
                   int64_t n_param, double eps, double* d_probs_out, double* d_raw, int64_t ldraw)
@@ -471,9 +517,12 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     // complement effects (their columns are evaluated on the cached final states) and not for the Hessian driver's
     // passes (d_raw), which reuse the base pass's by-products.
     const bool fused = !rows && n_param > 0 && p->hp.n_state_ids <= 65536 && p->comp_index < 0 && !d_raw && p->fd_fused;
-    int rc = fused ? GST_OK : run_probs(p, d_base, n_param > 0);
-    if (rc) return rc;
-    if (n_param == 0) return GST_OK;
+    int rc = GST_OK;
+    p->last_overlap = false;
+    p->last_fd_form = 0;
+    if (n_param == 0) return run_probs(p, d_base, false);
+    // (the base pass itself is enqueued below, once the launch form is known: the persistent launch of a small atom runs
+    //  it inside its own kernel)
     if (p->cached_fused != fused) p->cached_kind = 0;
     if (!p->request_cached(1, param_idx, dest_idx, n_param)) {
         // (an optimizer asks for the same columns every iteration: pack and upload the lane tables once)
@@ -521,33 +570,9 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         const int64_t nT = p->hp.n_tasks();
         if (p->task_cost.empty()) gst::task_gate_costs(p->hp, p->task_cost);
         if (!p->task_cost.empty() && nT * L.n_waves < 0x7fffffffLL && nT * L.n_waves > 1) {
-            const int stride = nG + 2;
-            std::vector<uint64_t> wave_gates(L.n_waves, 0);
-            std::vector<uint8_t> wave_rho(L.n_waves, 0);
-            for (size_t q = 0; q < L.col.size(); q++) {
-                if (L.col[q] < 0) continue;
-                const size_t w = rows ? q : q / 64;
-                if (L.kind[0][q] == GST_KIND_GATE) wave_gates[w] |= 1ull << L.obj[0][q];
-                else if (L.kind[0][q] == GST_KIND_RHO) wave_rho[w] = 1;
-            }
-            // D = 64: the launch unit is a group of `grp` consecutive wavefronts (models) of one task
-            const int32_t grp = rows ? gst::rows_group(p->hp.D, p->hp.max_slots) : 1;
-            const int32_t n_units = (L.n_waves + grp - 1) / grp;
-            std::vector<std::pair<int32_t, uint32_t>> items;       // (-cost, task * n_units + unit)
-            items.reserve((size_t)nT * n_units);
-            for (int64_t t = 0; t < nT; t++) {
-                const int32_t* c = p->task_cost.data() + (size_t)t * stride;
-                for (int32_t u = 0; u < n_units; u++) {
-                    int32_t best = c[nG + 1] / 4;
-                    for (int32_t w = u * grp; w < std::min<int32_t>((u + 1) * grp, L.n_waves); w++) {
-                        if (wave_rho[w]) best = std::max(best, c[nG + 1] / 4 + c[nG]);
-                        else
-                            for (uint64_t m = wave_gates[w]; m; m &= m - 1) best = std::max(best, c[nG + 1] / 4 + c[__builtin_ctzll(m)]);
-                    }
-                    items.emplace_back(-best, (uint32_t)(t * n_units + u));
-                }
-            }
-            std::stable_sort(items.begin(), items.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+            std::vector<std::pair<int32_t, uint32_t>> items;       // (-cost, task * n_units + unit), longest first
+            int32_t n_units = 0;
+            fd_items(p, L, rows, items, n_units);
             std::vector<uint32_t> order(items.size());
             for (size_t i = 0; i < items.size(); i++) order[i] = items[i].second;
             HIP_TRY(p->d_block_order.ensure(order.size()));
@@ -570,89 +595,32 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
             if (!rows && p->fd_persist && p->hp.max_slots <= 4 && items.size() < (1u << 30) && (p->fd_persist_always || (items.size() <= (size_t)40 * p->n_cus && items.size() >= (size_t)4 * p->n_cus)) &&
                 (size_t)16 * std::max(p->hp.max_slots, 1) * p->hp.D * 64 * 8 <= 160 * 1024) {
                 const int n_bins = 4 * p->n_cus;
-                struct BinItem { uint32_t id; int64_t cost; int32_t part; };
-                std::vector<std::vector<BinItem>> bins(n_bins);
-                std::vector<int64_t> load((size_t)n_bins, 0);
-                typedef std::pair<int64_t, int32_t> LB;                  // (load, queue): min-heap
-                {
-                    std::priority_queue<LB, std::vector<LB>, std::greater<LB>> heap;
-                    for (int b = 0; b < n_bins; b++) heap.emplace(0, b);
-                    for (const auto& it : items) {
-                        LB t = heap.top(); heap.pop();
-                        const int64_t c = (int64_t)(-it.first) + 8;
-                        bins[t.second].push_back(BinItem{it.second, c, 0});
-                        load[(size_t)t.second] = t.first + c;
-                        heap.emplace(t.first + c, t.second);
-                    }
+                if (p->fd_handover != 0 && !p->split_ready) {
+                    // Default: cuts only where no save slot is live and the interpreter's outer loop stands (an EMIT, the word
+                    // after a LOAD), the one nearest a walk's middle.  GST_FD_CUT_RICH=1 (development): any position, in
+                    // front of any APPLY as well, live slots travelling along -- with it the packer (GST_FD_CUT=1/2) gets
+                    // the estimated loads within 2 % of the mean (2,924-3,035 against 2,553-3,114 on a 1/8 atom of the 2Q
+                    // design), and the kernel gets SLOWER (4.45 against 4.05 ms): a second part that is popped before its
+                    // first part is done occupies a wavefront, one that is popped late ends late, and neither shows in a
+                    // load estimate.  Measured, kept switchable, not the default.
+                    const bool rich = std::getenv("GST_FD_CUT_RICH") && std::atoi(std::getenv("GST_FD_CUT_RICH")) != 0;
+                    gst::task_split_candidates(p->hp, p->cand_ptr, p->cand_pc, p->cand_frac, rich ? 128 : (1 << 20), rich ? &p->cand_live : nullptr);
+                    if (!rich) p->cand_live.clear();
+                    p->split_ready = true;
                 }
-                // Hand-over: with 2-3 whole-chain walks per SIMD the queues differ by a whole walk.  A walk of an overfull
-                // queue is cut at its task's slot-free middle (gst::task_split_points): the first half stays -- at the
-                // FRONT of its queue, so that it runs first -- and the second half goes to the END of the emptiest
-                // queue, whose wavefront waits for the first half's states.  Same program words, same arithmetic, same
-                // bits; the kernel's run time follows the fullest queue.
-                int32_t n_split = 0;
-                std::vector<int32_t> ho_index;
-                if (p->fd_handover != 0) {
-                    if (!p->split_ready) {
-                        gst::task_split_points(p->hp, p->split_pc, p->split_frac);
-                        if ((rc = upload_i32(p->d_task_split_pc, p->split_pc, p->stream))) return rc;
-                        p->split_ready = true;
-                    }
-                    ho_index.assign((size_t)nT * (size_t)n_units, -1);
-                    int64_t total = 0;
-                    for (int64_t l : load) total += l;
-                    const int64_t mean = total / n_bins;
-                    std::set<LB> by_load;
-                    for (int b = 0; b < n_bins; b++) by_load.emplace(load[(size_t)b], b);
-                    const bool force = p->fd_handover == 2;              // (tests: cut every walk that can be cut)
-                    for (int iter = 0; iter < 4 * n_bins && by_load.size() >= 2; iter++) {
-                        const LB top = *by_load.rbegin();
-                        const int bmax = top.second;
-                        int best = -1;
-                        for (size_t k = 0; k < bins[(size_t)bmax].size(); k++) {
-                            const BinItem& bi = bins[(size_t)bmax][k];
-                            const int64_t t = (int64_t)(bi.id / (uint32_t)n_units);
-                            if (bi.part != 0 || p->split_pc[(size_t)t] < 0) continue;
-                            if (!force && bi.cost < std::max<int64_t>(64, mean / 4)) continue;
-                            if (best < 0 || bi.cost > bins[(size_t)bmax][(size_t)best].cost) best = (int)k;
-                        }
-                        if (best < 0) { by_load.erase(top); continue; }  // nothing to cut in the fullest queue: look at the next
-                        const LB low = *by_load.begin();
-                        const int bmin = low.second;
-                        BinItem whole = bins[(size_t)bmax][(size_t)best];
-                        const double frac = p->split_frac[(size_t)(whole.id / (uint32_t)n_units)];
-                        const int64_t c1 = (int64_t)((double)whole.cost * frac) + 24, c2 = whole.cost - (int64_t)((double)whole.cost * frac) + 24;
-                        const int64_t new_hi = std::max(load[(size_t)bmax] - whole.cost + c1, load[(size_t)bmin] + c2);
-                        if (bmin == bmax) break;
-                        if (!force && new_hi + 16 >= load[(size_t)bmax]) { by_load.erase(top); continue; }   // no gain here: next queue
-                        by_load.erase(top); by_load.erase(low);
-                        bins[(size_t)bmax].erase(bins[(size_t)bmax].begin() + best);
-                        bins[(size_t)bmax].insert(bins[(size_t)bmax].begin(), BinItem{whole.id, c1, 1});
-                        {   // second half: in cost order behind the receiver's longer items (not behind its short ones:
-                            // picked up late, its work would land at the very end of that queue)
-                            auto& rb = bins[(size_t)bmin];
-                            size_t at = 0;
-                            while (at < rb.size() && (rb[at].part == 1 || rb[at].cost >= c2)) at++;
-                            rb.insert(rb.begin() + (long)at, BinItem{whole.id, c2, 2});
-                        }
-                        load[(size_t)bmax] += c1 - whole.cost;
-                        load[(size_t)bmin] += c2;
-                        ho_index[(size_t)whole.id] = n_split++;
-                        if (bmin != bmax) by_load.emplace(load[(size_t)bmin], bmin);
-                        by_load.emplace(load[(size_t)bmax], bmax);
-                    }
-                }
-                std::vector<int32_t> bptr(n_bins + 1, 0);
-                std::vector<uint32_t> bitems;
-                bitems.reserve(items.size() + (size_t)n_split);
-                for (int b = 0; b < n_bins; b++) {
-                    for (const BinItem& bi : bins[(size_t)b]) bitems.push_back(bi.id | ((uint32_t)bi.part << 30));
-                    bptr[b + 1] = (int32_t)bitems.size();
-                }
+                gst::FdQueues Q;
+                gst::pack_fd_queues(items, n_units, nT, n_bins, p->fd_handover, p->cand_ptr, p->cand_pc, p->cand_frac, p->cand_live, Q);
+                const int32_t n_split = Q.n_split;
+                const std::vector<int32_t>& bptr = Q.bin_ptr;
+                const std::vector<uint32_t>& bitems = Q.bin_items;
+                const std::vector<int32_t>& ho_index = Q.ho_index;
+                const std::vector<int32_t>& ho_pc = Q.ho_pc;
+                std::vector<int32_t> ho_live(Q.ho_live.begin(), Q.ho_live.end());
+                const std::vector<int64_t>& load = Q.load;
                 if ((rc = upload_i32(p->d_bin_ptr, bptr, p->stream))) return rc;
                 HIP_TRY(p->d_bin_items.ensure(bitems.size()));
                 HIP_TRY(hipMemcpyAsync(p->d_bin_items.p, bitems.data(), bitems.size() * 4, hipMemcpyHostToDevice, p->stream));
-                HIP_TRY(p->d_bin_head.ensure(n_bins));
+                HIP_TRY(p->d_bin_head.ensure((size_t)n_bins + 1));            // (+ the abort flag)
                 p->n_split = n_split;
                 if (std::getenv("GST_FD_DEBUG")) {
                     int64_t lo = load[0], hi = load[0];
@@ -662,7 +630,10 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
                 }
                 if (n_split > 0) {
                     if ((rc = upload_i32(p->d_ho_index, ho_index, p->stream))) return rc;
-                    HIP_TRY(p->d_ho_state.ensure((size_t)n_split * p->hp.D * 64));
+                    if ((rc = upload_i32(p->d_task_split_pc, ho_pc, p->stream))) return rc;
+                    if ((rc = upload_i32(p->d_ho_live, ho_live, p->stream))) return rc;
+                    HIP_TRY(p->d_ho_state.ensure((size_t)n_split * (size_t)(1 + std::max(p->hp.max_slots, 0)) * p->hp.D * 64));
+                    HIP_TRY(p->d_ho_tag.ensure((size_t)n_split * 4));
                     HIP_TRY(p->d_ho_id.ensure((size_t)n_split));
                     HIP_TRY(p->d_ho_flag.ensure((size_t)n_split));
                 }
@@ -675,6 +646,23 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         p->remember_request(1, param_idx, dest_idx, n_param);
         p->cached_n_waves = L.n_waves;
     }
+    // ---- the base pass ----------------------------------------------------------------------------------------------
+    // Persistent launches (small atoms, D = 16) walk the base chains INSIDE the FD kernel: ~0.45 ms of pure latency that
+    // nothing overlapped (a 1/8 atom of the 2Q design: 4.4 ms per step).  Needs the chain kernel's tables in LDS next to
+    // the walks' save slots and at most two chains per workgroup.
+    const int split_req = (p->fd_split == 2 || p->fd_split == 4) && p->hp.D == 16 ? p->fd_split : 1;
+    const bool persist = !rows && split_req == 1 && p->have_bins && p->have_block_order && p->cached_n_waves > 0;
+    bool overlap = false;
+    int32_t ovl_chain_doubles = 0;
+    if (persist && !fused && p->fd_overlap && p->hp.D == 16 && p->comp_index < 0 && !d_raw &&
+        gst::chain_kernel_fits(p->hp.D, p->hp.n_gates, p->hp.n_effects, p->hp.max_slots)) {
+        const int waves = gst::persistent_waves(p->hp.D);
+        const int64_t chains = (p->hp.n_tasks() + p->n_cus - 1) / p->n_cus;
+        ovl_chain_doubles = (int32_t)((gst::chain_lds_doubles(p->hp.D, p->hp.n_gates, p->hp.n_effects, p->hp.max_slots) + 1) & ~(size_t)1);
+        const size_t lds = ((size_t)waves * std::max(p->hp.max_slots, 1) * p->hp.D * 64 + (size_t)chains * ovl_chain_doubles) * 8;
+        overlap = chains <= 2 && lds <= 160 * 1024;
+    }
+    if (!fused && (!overlap || p->fd_overlap_diag) && (rc = run_probs(p, d_base, true))) return rc;
     gst::WalkArgs a;
     base_args(p, a);
     a.mode = gst::EMIT_FD;
@@ -686,7 +674,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     a.n_pwaves = p->cached_n_waves;
     a.block_order = p->have_block_order ? p->d_block_order.p : nullptr;
     const char* trace_path = std::getenv("GST_FD_TRACE");          // development aid: per-pair timestamps (tools/trace_stats.py)
-    const size_t n_trace = (size_t)p->hp.n_tasks() * (size_t)std::max(p->cached_n_waves, 1) + (size_t)std::max(p->n_split, 0);
+    const size_t n_trace = (size_t)p->hp.n_tasks() * ((size_t)std::max(p->cached_n_waves, 1) + 1) + (size_t)std::max(p->n_split, 0);
     if (trace_path && !rows) {
         HIP_TRY(p->d_trace.ensure(1 + 4 * n_trace));
         HIP_TRY(hipMemsetAsync(p->d_trace.p, 0, 8, p->stream));
@@ -734,18 +722,52 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         // gst_options.fd_split > 1 splits every (task, 64 columns) pair's rows over 2 or 4 wavefronts (walk_kernel's
         // NW).  Bit-identical, but measured on MI355X it costs 1.35-1.45x the SIMD time per pair (one barrier per gate
         // application) and that cancels the balance it buys on a 1/8 atom (4.63 vs 4.70 ms), so "auto" is 1.
-        const int split = (p->fd_split == 2 || p->fd_split == 4) && p->hp.D == 16 ? p->fd_split : 1;
-        if (split == 1 && p->have_bins && p->have_block_order) {
-            // persistent launch: one 16-wavefront workgroup per CU, pairs popped from the per-SIMD queues
+        const int split = split_req;
+        if (persist) {
+            // persistent launch: one workgroup per CU, pairs popped from the per-SIMD queues
+            gst::WalkArgs sb = a;                  // (the stand-by launches' arguments: the plain dispatcher-placed form)
             a.bin_ptr = p->d_bin_ptr.p; a.bin_items = p->d_bin_items.p; a.bin_head = p->d_bin_head.p; a.n_bins = p->n_bins;
             if (p->n_split > 0) {
-                a.task_split_pc = p->d_task_split_pc.p; a.ho_index = p->d_ho_index.p; a.ho_state = p->d_ho_state.p;
+                a.ho_pc = p->d_task_split_pc.p; a.ho_index = p->d_ho_index.p; a.ho_state = p->d_ho_state.p;
                 a.ho_id = p->d_ho_id.p; a.ho_flag = p->d_ho_flag.p;
+                a.ho_live = (const uint32_t*)p->d_ho_live.p; a.ho_tag = p->d_ho_tag.p; a.ho_blocks = 1 + std::max(p->hp.max_slots, 0);
                 HIP_TRY(hipMemsetAsync(p->d_ho_flag.p, 0, (size_t)p->n_split * 4, p->stream));
             }
             a.lds_wave_doubles = std::max(p->hp.max_slots, 1) * p->hp.D * 64;
-            HIP_TRY(hipMemsetAsync(p->d_bin_head.p, 0, (size_t)p->n_bins * 4, p->stream));
+            // queue heads, and behind them the abort flag of the bounded waits (hand-over, overlap)
+            HIP_TRY(hipMemsetAsync(p->d_bin_head.p, 0, ((size_t)p->n_bins + 1) * 4, p->stream));
+            uint32_t* const d_abort = p->d_bin_head.p + p->n_bins;
+            const bool can_wait = p->n_split > 0 || overlap;
+            a.abort_flag = can_wait ? d_abort : nullptr;
+            if (overlap) {
+                HIP_TRY(p->d_base_cache.ensure((size_t)p->hp.n_state_ids * p->hp.D));
+                a.base_cache = p->d_base_cache.p;
+                // consumers tell "not produced yet" from a value by this bit pattern (gst_chain.hpp)
+                if (!p->fd_overlap_diag) {
+                    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_base, (int)gst::OVL_SENTINEL32, (size_t)p->hp.n_elements * 2, p->stream));
+                    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p->d_base_cache.p, (int)gst::OVL_SENTINEL32, (size_t)p->hp.n_state_ids * p->hp.D * 2, p->stream));
+                }
+                a.ovl_n_tasks = (int32_t)p->hp.n_tasks();
+                a.ovl_chain_doubles = ovl_chain_doubles;
+                a.pbase_w = d_base;
+                a.ovl_test_skip = (p->test_skip_chains || p->fd_overlap_diag) ? 1 : 0;
+                p->last_overlap = true;
+            }
             HIP_TRY(gst::launch_walk_persistent(p->hp.D, a, p->n_cus, p->hp.max_slots, p->stream));
+            p->last_fd_form = overlap ? 2 : 1;
+            if (can_wait && p->fd_standby) {
+                // Stand-by launches: the same work in the form that waits for nothing -- separate base pass, one workgroup
+                // per pair, no hand-over -- guarded by the abort flag: every workgroup leaves at once unless a bounded
+                // wait of the launch above ran out (its producer not resident: a shared device).  Costs two empty
+                // launches per fill; buys "never hangs, never returns a half-written Jacobian" without a host round trip.
+                if (overlap) {
+                    if ((rc = run_probs(p, d_base, true, 1, d_abort))) return rc;
+                    p->last_launches--;            // (counted below, once, like every FD fill)
+                }
+                sb.base_cache = p->d_base_cache.p;
+                sb.guard = d_abort;
+                HIP_TRY(gst::launch_walk(p->hp.D, 1, sb, p->hp.n_tasks(), p->hp.max_slots, p->stream, 1));
+            }
         } else
             HIP_TRY(gst::launch_walk(p->hp.D, 1, a, p->hp.n_tasks(), p->hp.max_slots, p->stream, split));
     }
@@ -2255,6 +2277,14 @@ int gst_get_stats(const gst_plan* p, gst_stats* s)
     s->trie_nodes = h.trie_nodes; s->applies_per_pass = h.applies_per_pass; s->n_tasks = h.n_tasks();
     s->prog_words = (int64_t)h.prog.size(); s->max_slots = h.max_slots; s->max_depth = h.max_depth;
     s->last_kernel_ms = p->last_kernel_ms; s->last_total_ms = p->last_total_ms; s->last_launches = p->last_launches;
+    s->last_fd_form = p->last_fd_form; s->last_fd_aborted = 0;
+    if (p->last_fd_form >= 1 && p->d_bin_head.p && p->n_bins > 0 && p->dev_ready) {
+        uint32_t flag = 0;                  // the abort flag sits behind the queue heads
+        HIP_TRY(hipSetDevice(p->device));
+        HIP_TRY(hipMemcpyAsync(&flag, p->d_bin_head.p + p->n_bins, 4, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        s->last_fd_aborted = flag != 0 ? 1 : 0;
+    }
     return GST_OK;
     });
 }
@@ -2284,6 +2314,34 @@ int gst_get_program(const gst_plan* p, uint32_t* words, int64_t cap, int64_t* n_
     if (words && cap > 0) std::memcpy(words, h.prog.data(), sizeof(uint32_t) * std::min<int64_t>(cap, *n_words));
     if (task_off && cap_tasks >= (int64_t)h.task_off.size())
         std::memcpy(task_off, h.task_off.data(), sizeof(int64_t) * h.task_off.size());
+    return GST_OK;
+    });
+}
+
+int gst_get_fd_queues(gst_plan* p, const int64_t* param_idx, int64_t n_param, int32_t n_queues, int32_t handover,
+                      int64_t* load_out, int32_t* n_pairs, int32_t* n_handovers)
+{
+    return guarded([&]() -> int {
+    if (!p || !load_out || n_queues <= 0) return fail(GST_EINVAL, "bad argument");
+    if (p->hp.D == 64) return fail(GST_EUNSUPPORTED, "per-SIMD queues exist for D <= 16");
+    int rc = check_params(p, param_idx, n_param);
+    if (rc) return rc;
+    LaneLayout L;
+    pack_lanes(p, param_idx, nullptr, n_param, L, false);
+    if (p->task_cost.empty()) gst::task_gate_costs(p->hp, p->task_cost);
+    if (p->task_cost.empty()) return fail(GST_EUNSUPPORTED, "no work table (more than 64 gates)");
+    std::vector<std::pair<int32_t, uint32_t>> items;
+    int32_t n_units = 0;
+    fd_items(p, L, false, items, n_units);
+    std::vector<int32_t> cptr, cpc;
+    std::vector<float> cfr;
+    std::vector<uint32_t> clive;
+    if (handover != 0) gst::task_split_candidates(p->hp, cptr, cpc, cfr, 1 << 20, nullptr);
+    gst::FdQueues Q;
+    gst::pack_fd_queues(items, n_units, p->hp.n_tasks(), n_queues, handover, cptr, cpc, cfr, clive, Q);
+    for (int32_t b = 0; b < n_queues; b++) load_out[b] = Q.load[(size_t)b];
+    if (n_pairs) *n_pairs = (int32_t)items.size();
+    if (n_handovers) *n_handovers = Q.n_split;
     return GST_OK;
     });
 }

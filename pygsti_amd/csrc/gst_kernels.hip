@@ -21,6 +21,7 @@
 // and the (nP+1)-pass loop of mapfill_dprobs_atom (:349-381) / _mapfill_hprobs_atom
 // (mapforwardsim.py:394-438): all passes run concurrently, one lane each.
 #include "gst_kernels.hpp"
+#include "gst_chain.hpp"
 
 #include "../../include/gstfwd.h"
 
@@ -194,9 +195,16 @@ constexpr int XPAD = 2;      // exchange-buffer lane stride D + 2 doubles: 16-by
 // COMP (Hessian pass of "full TP" models): the POVM's complement effect is identity - sum(others), recomputed by the
 // reference after every parameter step (complementeffect.py:72-78), so a lane whose perturbations touch one of the
 // others also carries the one or two changed components of the complement.
-template <int D, int S, int WPS, int NW = 1, bool PERSIST = false, bool COMP = false>
+// OVL (persistent launch, D = 16): the base pass runs INSIDE this launch -- one wavefront of a workgroup walks a task's
+// chain first (gst_chain.hpp, publishing states and probabilities with write-through stores) while the others already
+// run finite-difference walks; a walk that reads the sentinel the destinations were pre-filled with waits for the
+// value.  On a 1/8 atom of the 2Q design the base pass was 0.45 ms of a 4.4 ms step that nothing overlapped.
+constexpr unsigned long long WAIT_LIMIT_TICKS = 10000000ull;     // bounded waits: 0.1 s of the 100 MHz wall clock
+
+template <int D, int S, int WPS, int NW = 1, bool PERSIST = false, bool COMP = false, bool OVL = false>
 __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS) void walk_kernel(const WalkArgs a)
 {
+    static_assert(!OVL || (PERSIST && D == 16), "the overlap form belongs to the persistent D = 16 launch");
     static_assert(!COMP || S == 2, "the single-perturbation pass leaves effect parameters to effect_fd_kernel");
     static_assert(NW == 1 || (S == 1 && D % NW == 0), "row splitting is implemented for the single-perturbation passes");
     static_assert(!PERSIST || (NW == 1 && S == 1), "the persistent form exists for the Jacobian pass");
@@ -209,6 +217,57 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
     const int lane = threadIdx.x & 63;
     const int wv = (NW > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int i0 = wv * RPW;                 // first state row this wavefront computes
+    if constexpr (!PERSIST) {
+        // stand-by launch behind an optimistic persistent one (WalkArgs::guard): nothing to do unless that one gave up
+        if (a.guard && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
+    }
+    if constexpr (OVL) {
+        // ---- the chains of the base pass, inside this launch (see WalkArgs::ovl_n_tasks) -------------------------------
+        const GST_CONST WalkArgs* c = (const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        const int n_waves = (int)(blockDim.x >> 6);
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        // chain k of the workgroup on wavefront k: the FIRST wavefronts.  The SIMD's arbiter serves its oldest wavefront
+        // first, so a chain on the youngest wavefront of its SIMD starves behind two finite-difference walks (measured:
+        // the step got 0.25 ms LONGER); raised priority on top, for the chain's duration only -- a chain is a latency
+        // chain of dependent instructions, it leaves most issue slots to the walks anyway
+        const int k = wave;
+        const int64_t t = (int64_t)blockIdx.x + (int64_t)k * gridDim.x;
+        if (t < (int64_t)c->ovl_n_tasks && !c->ovl_test_skip) {
+            const int nG = c->n_gates, nE = c->n_effects;
+            const int n_slots = c->lds_wave_doubles / (D * 64);
+            double* const region = lds + (size_t)n_waves * c->lds_wave_doubles + (size_t)k * c->ovl_chain_doubles;
+            double* const ldsE = region;
+            double* const ldsG = ldsE + nE * D;
+            double* const wlds = region + base_shared_doubles(D, nG, nE);
+            uint32_t* const ldsP = (uint32_t*)((int32_t*)(wlds + (n_slots > 0 ? n_slots : 1) * 64 + BASE_ER * (D + 1)) + BASE_ER);
+            const int64_t pc0 = as_const(c->task_off)[t];
+            const int32_t n_words = (int32_t)(as_const(c->task_off)[t + 1] - pc0);
+            const uint32_t* gprog = c->prog + pc0;
+            const double* gt = c->gates_t;
+            const double* ef = c->effects;
+            stage_lds(ldsP, BASE_PW, lane, [&](int i) { return (i < n_words) ? gprog[i] : 0u; });
+            stage_lds(ldsG, nG * D * D, lane, [&](int i) { return gt[i]; });
+            stage_lds(ldsE, nE * D, lane, [&](int i) { return ef[i]; });
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            ChainArgs ca;
+            ca.gprog = gprog; ca.n_words = n_words;
+            ca.eff_ptr = c->eff_ptr; ca.eff_label = c->eff_label; ca.eff_dest = c->eff_dest;
+            ca.rhos = c->rhos; ca.out = c->pbase_w; ca.cache = (double*)c->base_cache;
+            ca.multi_start = 0; ca.start0 = 0;
+            const unsigned long long tc0 = c->trace ? wall_clock64() : 0ull;
+            __builtin_amdgcn_s_setprio(3);
+            base_chain_walk<D, true>(ca, n_slots, ldsE, ldsG, wlds, lane);
+            __builtin_amdgcn_s_setprio(0);
+            if (c->trace && lane == 0) {           // development aid (GST_FD_TRACE): chains are records with bit 30 set
+                unsigned long long* tr = c->trace;
+                const unsigned long long kk = atomicAdd(tr, 1ull);
+                tr[1 + 4 * kk] = 0x40000000ull | (unsigned long long)t; tr[2 + 4 * kk] = tc0; tr[3 + 4 * kk] = wall_clock64();
+                tr[4 + 4 * kk] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4)) |
+                                 ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);
+            }
+        }
+    }
   for (;;) {                                 // PERSIST: one iteration per popped pair; otherwise exactly one
     int64_t bid;
     int32_t part = 0;                        // PERSIST: 0 whole pair, 1 first half (up to the split), 2 second half
@@ -249,6 +308,8 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
             }
         }
         if (item < 0) break;
+        // somebody's bounded wait ran out (WalkArgs::abort_flag): the stand-by launches behind this one redo everything
+        if (c->abort_flag && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0) return;
         const uint32_t raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
         part = (int32_t)(raw >> 30);
         bid = (int64_t)(raw & 0x3fffffffu);
@@ -398,6 +459,48 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
 #pragma unroll
     for (int i = 0; i < MAXSLOT; i++) slot_tag[i] = -1;
     cdouble_p cache_c = as_const(a.base_cache);
+    // OVL: a value that still shows the sentinel has not been produced yet (or sits in a stale line of this XCD's L2 /
+    // scalar cache): poll it with system-scope loads, which bypass the non-coherent caches.  Returns false when the wait
+    // ran out (the abort flag is then raised).
+    bool ovl_dead = false;
+    auto ovl_poll = [&](const double* g) -> double {
+        const unsigned long long t_wait = wall_clock64();
+        for (;;) {
+            // (every lane reads the same address; the value is made wave-uniform explicitly so that control flow stays scalar)
+            const long long xb = __double_as_longlong(__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+            const int xlo = __builtin_amdgcn_readfirstlane((int)(xb & 0xffffffffLL)), xhi = __builtin_amdgcn_readfirstlane((int)(xb >> 32));
+            const double x = __longlong_as_double(((long long)xhi << 32) | (unsigned int)xlo);
+            if ((unsigned long long)__double_as_longlong(x) != OVL_SENTINEL64) return x;
+            __builtin_amdgcn_s_sleep(16);
+            if (wall_clock64() - t_wait > WAIT_LIMIT_TICKS) {
+                const GST_CONST WalkArgs* c = (const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+                // (all lanes store the same word: a lane-0 branch here is a divergent region the register allocator cannot
+                //  keep the interpreter's scalar state across -- "illegal VGPR to SGPR copy")
+                if (c->abort_flag) __hip_atomic_store(c->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ovl_dead = true;
+                return x;
+            }
+        }
+    };
+    // (a macro, not a lambda: an array captured by reference from inside the interpreter loop ends up in scratch memory)
+#define GST_FETCH_STATE(id_)                                                                              \
+    do {                                                                                                  \
+        cdouble_p b_ = cache_c + (int64_t)(id_) * D;                                                      \
+        uint32_t late_ = 0;                  /* wave-uniform: bit j = component j still shows the sentinel */ \
+        _Pragma("unroll") for (int j = 0; j < D; j++) {                                                   \
+            const double x_ = b_[j];                                                                      \
+            if constexpr (OVL) late_ |= ((unsigned long long)__double_as_longlong(x_) == OVL_SENTINEL64) ? (1u << j) : 0u; \
+            v[j] = x_;                                                                                    \
+        }                                                                                                 \
+        if constexpr (OVL) {                                                                              \
+            if (__builtin_expect(late_ != 0, 0)) {                                                        \
+                const double* g_ = ((const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr())->base_cache + (int64_t)(id_) * D; \
+                _Pragma("unroll") for (int j = 0; j < D; j++)                                             \
+                    if (!ovl_dead && ((late_ >> j) & 1u)) v[j] = ovl_poll(g_ + j);                        \
+                if (ovl_dead) return;                                                                     \
+            }                                                                                             \
+        }                                                                                                 \
+    } while (0)
 
     // Instruction fetch: the program is read 64 words at a time with ONE coalesced vector load (lane l holds
     // word base+l) and the current word is picked with v_readlane; the next window is already in flight.
@@ -437,8 +540,8 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
     if constexpr (PERSIST) {
         if (part != 0) {
             const GST_CONST WalkArgs* c = cold();
-            stop_pc = as_const(c->task_split_pc)[task];
             ho = as_const(c->ho_index)[bid];
+            stop_pc = as_const(c->ho_pc)[ho];
         }
         if (part == 2) {
             // second half: the first half (on another SIMD, possibly another XCD with its own L2) stores the lane states
@@ -447,14 +550,44 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
             uint32_t* const flag = c->ho_flag + ho;
             // (every access to the hand-over buffers is a system-scope relaxed atomic, i.e. a load / store that bypasses
             //  the non-coherent caches: no fence, hence no write-back or invalidation of a whole L2, is needed)
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) __builtin_amdgcn_s_sleep(64);
-            const int32_t id = __hip_atomic_load(c->ho_id + ho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // The wait is BOUNDED: the first half runs in another workgroup, which is only certain to make progress if
+            // it is resident -- not guaranteed when the device is shared (two ranks on one GPU, other kernels holding
+            // CUs).  On expiry: raise the abort flag and leave; the stand-by launches redo the Jacobian without hand-overs.
+            {
+                const unsigned long long t_wait = wall_clock64();
+                while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0) {
+                    __builtin_amdgcn_s_sleep(64);
+                    if (wall_clock64() - t_wait > WAIT_LIMIT_TICKS) {
+                        if (lane == 0 && c->abort_flag) __hip_atomic_store(c->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        return;
+                    }
+                }
+            }
+            // (the loads below are issued after the flag has been seen -- a wavefront does not speculate -- and the
+            //  compiler may not move them above the loop either)
+            asm volatile("" ::: "memory");
+            const int32_t id = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c->ho_id + ho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+            double* const hs0 = c->ho_state + (int64_t)ho * c->ho_blocks * (D * 64) + lane;
             if (id >= 0) { dirty = false; cur_id = id; }
             else {
-                double* hs = c->ho_state + (int64_t)ho * D * 64 + lane;
 #pragma unroll
-                for (int j = 0; j < D; j++) v[j] = __hip_atomic_load(hs + j * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int j = 0; j < D; j++) v[j] = __hip_atomic_load(hs0 + j * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 dirty = true;
+            }
+            // save slots that are live at the cut travel with the walk: a tag (the id of a clean state) or the data
+            const uint32_t lm = c->ho_live ? as_const(c->ho_live)[ho] : 0u;
+#pragma unroll
+            for (int i = 0; i < MAXSLOT; i++) {
+                if ((lm >> i) & 1u) {
+                    const int32_t tg = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c->ho_tag + ho * MAXSLOT + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                    slot_tag[i] = tg;
+                    if (tg < 0) {
+                        const double* hs = hs0 + (int64_t)(1 + i) * (D * 64);
+                        double* sl = slots + (int64_t)i * D * 64 + lane;
+#pragma unroll
+                        for (int j = 0; j < D; j++) sl[j * 64] = __hip_atomic_load(hs + j * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
             }
             pc = stop_pc;
             wbase = stop_pc & ~63;
@@ -467,12 +600,26 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
         if (op == GST_OP_END) break;
         if constexpr (PERSIST) {
             if (part == 1 && pc - 1 == stop_pc) {
-                // first half done: hand the walk over (no save slot is live here, so the state is everything)
+                // first part done: hand the walk over -- the lane states (or the id of a clean state) and the save slots
+                // that are live at this position
                 const GST_CONST WalkArgs* c = cold();
+                double* const hs0 = c->ho_state + (int64_t)ho * c->ho_blocks * (D * 64) + lane;
                 if (dirty) {
-                    double* hs = c->ho_state + (int64_t)ho * D * 64 + lane;
 #pragma unroll
-                    for (int j = 0; j < D; j++) __hip_atomic_store(hs + j * 64, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    for (int j = 0; j < D; j++) __hip_atomic_store(hs0 + j * 64, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                const uint32_t lm = c->ho_live ? as_const(c->ho_live)[ho] : 0u;
+#pragma unroll
+                for (int i = 0; i < MAXSLOT; i++) {
+                    if ((lm >> i) & 1u) {
+                        if (lane == 0) __hip_atomic_store(c->ho_tag + ho * MAXSLOT + i, slot_tag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (slot_tag[i] < 0) {
+                            double* hs = hs0 + (int64_t)(1 + i) * (D * 64);
+                            const double* sl = slots + (int64_t)i * D * 64 + lane;
+#pragma unroll
+                            for (int j = 0; j < D; j++) __hip_atomic_store(hs + j * 64, sl[j * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
                 }
                 if (lane == 0) __hip_atomic_store(c->ho_id + ho, dirty ? -1 : cur_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __builtin_amdgcn_s_waitcnt(0);           // the write-through stores above have been acknowledged
@@ -493,12 +640,11 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
                     cur_id = (int32_t)arg;
                     GST_FETCH();
                     if (op != GST_OP_APPLY) break;
+                    if (PERSIST && pc - 1 == stop_pc) break;          // (a cut inside a chain: handed over at the top of the loop)
                     GST_HIT(arg, hit);
                 }
                 if (op != GST_OP_APPLY || !hit) continue;
-                cdouble_p b = cache_c + (int64_t)cur_id * D;      // first perturbed gate on this path: start from the cache
-#pragma unroll
-                for (int j = 0; j < D; j++) v[j] = b[j];
+                GST_FETCH_STATE(cur_id);                          // first perturbed gate on this path: start from the cache
                 dirty = true;
             }
             do {
@@ -545,7 +691,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
                     if (lane < D) cold()->base_cache_w[(int64_t)arg * D + lane] = x;
                 }
                 GST_FETCH();
-            } while (op == GST_OP_APPLY);
+            } while (op == GST_OP_APPLY && !(PERSIST && pc - 1 == stop_pc));
             continue;
         }
         if (op == GST_OP_NODE) {                         // marker after a RHO
@@ -565,9 +711,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
             const int32_t x0 = eff_ptr[arg], x1 = eff_ptr[arg + 1];
             const bool zero = (S > 0) && !dirty && !wave_eff;
             if (S > 0 && !dirty && wave_eff) {           // effect parameters: real dots on the (clean) cached state
-                cdouble_p b = cache_c + (int64_t)cur_id * D;
-#pragma unroll
-                for (int j = 0; j < D; j++) v[j] = b[j];
+                GST_FETCH_STATE(cur_id);
             }
             for (int32_t x = x0; x < x1; x++) {
                 if (NW > 1 && ((x - x0) % NW) != wv) continue;       // the workgroup's wavefronts share out the outcomes
@@ -620,10 +764,16 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
                         const double pb = __longlong_as_double(((long long)phi << 32) | (unsigned int)plo);
                         if (col >= 0) c->out[dest * c->ld + col] = (p - pb) / c->eps;
                         if (lane == 63 && pw == 0 && c->probs_out) c->probs_out[dest] = p;
-                    } else if (col >= 0) {
-                        const double pb = as_const(c->pbase)[dest];
-                        c->out[dest * c->ld + col] = (p - pb) / c->eps;
-                        if (c->raw) c->raw[dest * c->ldraw + col] = p;
+                    } else if (OVL || col >= 0) {
+                        double pb = as_const(c->pbase)[dest];
+                        if constexpr (OVL) {
+                            if (__builtin_expect((unsigned long long)__double_as_longlong(pb) == OVL_SENTINEL64, 0)) {
+                                pb = ovl_poll(c->pbase + dest);      // the chain has not flushed this circuit yet
+                                if (ovl_dead) return;
+                            }
+                        }
+                        if (col >= 0) c->out[dest * c->ld + col] = (p - pb) / c->eps;
+                        if (col >= 0 && c->raw) c->raw[dest * c->ldraw + col] = p;
                     }
                 } else {
                     if (col >= 0) {
@@ -690,6 +840,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
   }
 #undef GST_FETCH
 #undef GST_HIT
+#undef GST_FETCH_STATE
 }
 
 // ---- small helpers for the normal equations (gst_fill_jtj_dev) ------------------------------------------------
@@ -735,14 +886,30 @@ static hipError_t launch_one(const WalkArgs& a, int64_t n_tasks, int n_slots, hi
     return hipGetLastError();
 }
 
+int persistent_waves(int D) { return (D == 16) ? 4 * GST_FD_WPS_PERSIST : 16; }
+
 hipError_t launch_walk_persistent(int D, const WalkArgs& a, int n_wg, int n_slots, hipStream_t stream)
 {
-    const int waves = (D == 16) ? 4 * GST_FD_WPS_PERSIST : 16;
+    const int waves = persistent_waves(D);
     if (n_wg <= 0 || n_slots > 4 || (D != 4 && D != 16)) return hipErrorInvalidValue;
-    const size_t lds_bytes = (size_t)waves * a.lds_wave_doubles * sizeof(double);
+    size_t lds_bytes = (size_t)waves * a.lds_wave_doubles * sizeof(double);
+    const bool ovl = a.ovl_n_tasks > 0;
+    if (ovl) {
+        // the chains' LDS regions sit behind the wavefronts' save slots; wavefront (waves - 1 - k) walks chain k of its workgroup
+        const int chains = (a.ovl_n_tasks + n_wg - 1) / n_wg;
+        if (D != 16 || chains > waves || a.ovl_chain_doubles <= 0 || !a.pbase_w || !a.base_cache) return hipErrorInvalidValue;
+        lds_bytes += (size_t)chains * (size_t)a.ovl_chain_doubles * sizeof(double);
+    }
     if ((size_t)a.lds_wave_doubles < (size_t)n_slots * D * 64 || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     (void)hipGetLastError();
-    if (D == 16) {
+    if (D == 16 && ovl) {
+        auto k = walk_kernel<16, 1, GST_FD_WPS_PERSIST, 1, true, false, true>;
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k, dim3((unsigned)n_wg), dim3(64 * waves), lds_bytes, stream, a);
+    } else if (D == 16) {
         auto k = walk_kernel<16, 1, GST_FD_WPS_PERSIST, 1, true>;
         if (lds_bytes > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

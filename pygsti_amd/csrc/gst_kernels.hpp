@@ -5,6 +5,13 @@
 
 namespace gst {
 
+// Sentinel of the overlap protocol: the base-state cache and the base probabilities are filled with this bit pattern
+// (both 32-bit halves equal, so one hipMemsetD32Async does it) before the fused launch; a consumer that reads it knows
+// the producing chain has not got there yet.  A quiet NaN with a payload no arithmetic produces.
+constexpr uint32_t OVL_SENTINEL32 = 0x7FF8DEADu;
+constexpr unsigned long long OVL_SENTINEL64 = 0x7FF8DEAD7FF8DEADull;
+
+
 // Per-lane perturbation ("special") tables, one entry per lane slot (n_waves * 64 entries).
 // Lane slot q of wave w = w*64 + q.  kind -1 = no perturbation for that special.
 struct LaneTables {
@@ -49,10 +56,10 @@ struct WalkArgs {
     int32_t lds_wave_doubles;      // LDS doubles (save slots) per wavefront of the workgroup
     // hand-over of a walk between two SIMDs (persistent launch): queue items carry a part in their top two bits --
     // 1: walk the pair up to its task's split position, store the 64 lane states, raise the flag; 2: wait for the
-    // flag, pick the states up, walk the rest (gst::task_split_points)
-    const int32_t* task_split_pc;  // [n_tasks] word index relative to the task start, or -1
+    // flag, pick the states up, walk the rest (gst::task_split_candidates)
+    const int32_t* ho_pc;          // [n_split] where split pair h is cut: word index relative to its task's start
     const int32_t* ho_index;       // [n_tasks * n_pwaves] hand-over buffer of a split pair, or -1
-    double* ho_state;              // [n_split][D][64]
+    double* ho_state;              // [n_split][ho_blocks][D][64]: block 0 = the lane states, 1 + s = save slot s
     int32_t* ho_id;                // [n_split] >= 0: the state is the clean base state of that id (nothing stored)
     uint32_t* ho_flag;             // [n_split] zeroed before the launch
     unsigned long long* trace;     // development aid (GST_FD_TRACE): [0] = record count, then (pair, t0, t1, hw_id) records
@@ -92,6 +99,27 @@ struct WalkArgs {
     // (new fields go HERE, at the end: the persistent FD kernel re-reads its arguments from the kernarg segment with wide
     //  scalar loads, and shifting them by 8 bytes -- one int32 inserted mid-struct -- cost 5 % on a 1/8 atom)
     int32_t chain_share;     // walk_base_kernel: this many chain passes run side by side on the device (0 / 1: this one alone)
+    // ---- overlap of the base pass with the persistent FD launch (walk_kernel<..., OVL>; gst_chain.hpp) ----------------
+    // ovl_n_tasks > 0: the chains (S = 0 walks) of all tasks run INSIDE this launch: task t on workgroup t % gridDim.x, by
+    // its wavefront t / gridDim.x (the first, i.e. oldest, wavefronts), before that wavefront starts popping pairs.  They publish states
+    // (base_cache) and probabilities (pbase_w == pbase) with write-through stores; both buffers were pre-filled with
+    // OVL_SENTINEL64, and a finite-difference walk that reads the sentinel waits for the value (bounded, see abort_flag).
+    int32_t ovl_n_tasks;
+    int32_t ovl_chain_doubles;   // LDS doubles of one chain's region (behind the wavefronts' save slots)
+    double* pbase_w;
+    // Bounded waits: a wavefront whose wait (hand-over flag, sentinel) outlasts ~0.1 s -- its producer sits in a workgroup
+    // that is not resident, e.g. because another process holds the CUs -- raises *abort_flag and leaves; every wavefront
+    // checks the flag when it pops a pair.  The host has ALREADY enqueued stand-by launches of the same work in the safe
+    // form (separate base pass, dispatcher-placed FD walk, no hand-over) behind this one, with guard == abort_flag: they
+    // leave at once unless the flag is raised.  Nothing hangs and nothing is left half-written.
+    uint32_t* abort_flag;
+    const uint32_t* guard;
+    // hand-overs at positions where save slots are live: bit s of ho_live[h] = slot s travels with split pair h (its tag
+    // in ho_tag[h * 4 + s], its data in block 1 + s of the pair's ho_state region of ho_blocks blocks of D * 64 doubles)
+    const uint32_t* ho_live;
+    int32_t* ho_tag;
+    int32_t ho_blocks;
+    int32_t ovl_test_skip;       // tests: walk no chain (every consumer's wait then runs out and the stand-by launches take over)
 };
 
 // Launch the walk over all tasks x parameter wavefronts.  S = number of specials per lane (0,1,2);
@@ -205,6 +233,7 @@ int rows_group(int D, int n_slots);
 // D <= 16: whether the chain kernel (walk_base_kernel: gates, effects, emit ring and program window in LDS) can run this
 // model -- it is the only kernel with multi-start (backward, one lane group per effect) walks
 bool chain_kernel_fits(int D, int n_gates, int n_effects, int n_slots);
+size_t chain_lds_doubles(int D, int n_gates, int n_effects, int n_slots);   // LDS of one single-wavefront chain (tables + private region)
 
 // Row-per-lane variant (gst_kernels_rows.hip): one model per wavefront; D = 4, 16 or 64; S = a.rows_S.
 // FD columns of effect parameters evaluated on the cached final states (TP POVMs: see effect_fd_kernel)
@@ -233,7 +262,9 @@ struct EffectFDArgs {
 hipError_t launch_effect_fd(const EffectFDArgs& a, hipStream_t stream);
 
 // Persistent form of the D <= 16 FD walk: n_wg workgroups of 16 wavefronts (see WalkArgs::bin_ptr)
+// a.ovl_n_tasks > 0 selects the overlap form (D = 16): LDS = wavefronts' save slots + chains_per_wg chain regions
 hipError_t launch_walk_persistent(int D, const WalkArgs& a, int n_wg, int n_slots, hipStream_t stream);
+int persistent_waves(int D);                 // wavefronts per workgroup of the persistent launch
 hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 // out[e * ld + dest[m]] = (raw[m * raw_stride + e] - pbase[e]) / eps for m < n_models (dest == NULL: column m0 + m):
 // the finite-difference quotient of gst_fill_dprobs_models, transposed through LDS tiles (correctly rounded division)

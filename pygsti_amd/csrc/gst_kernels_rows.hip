@@ -14,6 +14,7 @@
 // The walk-program interpreter (RHO/APPLY/NODE/SAVE/LOAD/EMIT), the clean/dirty tracking against the
 // base-state cache and the three EMIT modes are the same as in gst_kernels.hip.
 #include "gst_kernels.hpp"
+#include "gst_chain.hpp"
 
 #include "../../include/gstfwd.h"
 
@@ -725,63 +726,6 @@ __global__ __launch_bounds__(64 * NWB, 2) void walk_quad64_kernel(const WalkArgs
 #undef Q_FETCH
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// walk_base_kernel<D> (D = 4, 16): the S = 0 pass -- probabilities and the base-state cache -- on its own.
-// This pass is a pure latency chain (one wavefront per task, ~1,150 dependent mat-vecs at 2Q L<=1024), so the kernel
-// is organised around the length of one chain step (tools/ub_chain.hip measures the pieces):
-//   * every D-lane group of the wavefront carries the SAME state (lane l holds component l % D; identical
-//     arithmetic, so identical bits): v_j reaches all lanes with ONE v_mov_b64_dpp row_newbcast (D = 16) instead of
-//     two v_readlane + an SGPR hazard;
-//   * gates (transposed), effects AND the task's walk program live in LDS (the program in a 2,048-word window that is
-//     refilled half by half); a chain step reads its two program words one step ahead, and the coefficients of the
-//     NEXT mat-vec stream into the registers the current one has just consumed -- the only vector-memory operation of
-//     a step is the 128-byte store of the produced state into the base-state cache, which nothing ever waits for;
-//   * EMITs only park (state, circuit) in an LDS ring; up to 64 parked circuits are evaluated at once, ONE LANE PER
-//     CIRCUIT (each lane walks its circuit's effects and runs the D-term dot product by itself, ascending index from
-//     0.0 like effectcreps.cpp:39-45), so the element-table lookups of 64 circuits overlap instead of costing two
-//     dependent L2 round trips per circuit.
-// Arithmetic contract as everywhere: acc = 0.0; acc = acc + G[i][j] * v[j], ascending j, separate multiply and add.
-template <int D, int J>
-__device__ __forceinline__ double grp_bcast(double x)
-{
-    if constexpr (D == 16) {
-        return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + J, 0xf, 0xf, true);           // row_newbcast:J
-    } else {
-        constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);                          // quad_perm [J,J,J,J]
-        const long long b = __double_as_longlong(x);
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), ctrl, 0xf, 0xf, true);
-        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), ctrl, 0xf, 0xf, true);
-        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-    }
-}
-// One mat-vec of the chain, phase by phase so that a lone wavefront never issues an instruction that depends on
-// the one just before it except in the final (inherently serial) sum: D broadcasts of v, D products, the D
-// coefficient reads of the NEXT gate into the registers the products just freed, then the ordered sum.
-template <int D, int J>
-__device__ __forceinline__ void bcast_all(double (&bv)[D], const double v)
-{
-    bv[J] = grp_bcast<D, J>(v);
-    if constexpr (J + 1 < D) bcast_all<D, J + 1>(bv, v);
-}
-template <int D>
-__device__ __forceinline__ double matvec_stream(double (&c)[D], const double v, const double* Gn)
-{
-    double bv[D];
-    bcast_all<D, 0>(bv, v);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < D; j++) bv[j] = c[j] * bv[j];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < D; j++) c[j] = Gn[j * D];
-    __builtin_amdgcn_sched_barrier(0);
-    double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < D; j++) acc = acc + bv[j];
-    __builtin_amdgcn_sched_barrier(0);
-    return acc;
-}
-
 constexpr int ROWS_SHARED_NWB = 4;           // wavefronts (models) per workgroup of walk_rows_shared_kernel
 int rows_group(int D, int n_slots)
 {
@@ -791,22 +735,10 @@ int rows_group(int D, int n_slots)
                          3 * ROWS_SHARED_NWB * sizeof(uint64_t);
     return bytes <= 64 * 1024 ? ROWS_SHARED_NWB : 1;
 }
-#ifndef GST_BASE_PW
-#define GST_BASE_PW 512
-#endif
-#ifndef GST_BASE_ER
-#define GST_BASE_ER 32
-#endif
-constexpr int BASE_PW = GST_BASE_PW;         // program window (words) in LDS
-constexpr int BASE_ER = GST_BASE_ER;         // emit ring: one lane per parked circuit at evaluation time
-
+// ---------------------------------------------------------------------------------------------------------------
+// walk_base_kernel<D> (D = 4, 16): the S = 0 pass -- probabilities and the base-state cache -- on its own.  The chain
+// walk itself lives in gst_chain.hpp (the persistent FD kernel of small atoms runs the same walk inside its own launch).
 constexpr int BASE_MAXW = 8;                 // wavefronts (tasks) per workgroup of walk_base_kernel, at most
-// LDS of one walk_base_kernel workgroup: the model tables once, then one private region per wavefront
-__host__ __device__ inline size_t base_shared_doubles(int D, int n_gates, int n_effects) { return (size_t)n_effects * D + (size_t)n_gates * D * D; }
-__host__ __device__ inline size_t base_wave_doubles(int D, int n_slots)
-{
-    return (size_t)(n_slots > 0 ? n_slots : 1) * 64 + (size_t)BASE_ER * (D + 1) + (BASE_ER + BASE_PW) / 2;
-}
 
 // Does walk_base_kernel (the only D <= 16 kernel with multi-start walks) fit its tables into LDS for this model?
 bool chain_kernel_fits(int D, int n_gates, int n_effects, int n_slots)
@@ -815,41 +747,26 @@ bool chain_kernel_fits(int D, int n_gates, int n_effects, int n_slots)
     const size_t gate_bytes = (size_t)n_gates * D * D * sizeof(double);
     return gate_bytes <= 128 * 1024 && (base_shared_doubles(D, n_gates, n_effects) + base_wave_doubles(D, n_slots)) * sizeof(double) <= 156 * 1024;
 }
-
-// global -> LDS copy by one wavefront, 8 loads in flight per lane (a load-wait-store loop costs one L2 round trip per
-// 64 elements, which at 12 KB of gates + 4 KB of program is tens of microseconds of pure latency per task)
-template <typename T, typename F>
-__device__ __forceinline__ void stage_lds(T* dst, const int total, const int lane, F&& src)
+size_t chain_lds_doubles(int D, int n_gates, int n_effects, int n_slots)
 {
-    for (int base = 0; base < total; base += 64 * 8) {
-        T t[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = base + u * 64 + lane;
-            t[u] = (k < total) ? src(k) : T(0);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = base + u * 64 + lane;
-            if (k < total) dst[k] = t[u];
-        }
-    }
+    return base_shared_doubles(D, n_gates, n_effects) + base_wave_doubles(D, n_slots);
 }
 
 // `wpb` wavefronts per workgroup, one task each (task = blockIdx.x * wpb + wavefront), sharing ONE staged copy of the
 // gates and effects: a pass is a latency chain per wavefront, so what it needs is residency -- every task of the
 // pass (and of the pass running beside it on the other stream, analytic mode) on the chip at once -- and the 12 KB
 // of 2Q gate tables per single-wavefront workgroup were what limited that (6 tasks per CU).
+// `guard` (may be NULL): the launch is a stand-by repeat of work an optimistic launch before it may have abandoned
+// (WalkArgs::abort_flag); it leaves at once unless that flag is raised.
 template <int D>
-__global__ __launch_bounds__(64 * BASE_MAXW) void walk_base_kernel(const WalkArgs a_, const int n_slots, const int wpb, const int64_t n_tasks)
+__global__ __launch_bounds__(64 * BASE_MAXW) void walk_base_kernel(const WalkArgs a_, const int n_slots, const int wpb, const int64_t n_tasks,
+                                                                   const uint32_t* guard)
 {
-    static_assert(D == 4 || D == 16, "group broadcasts are DPP quad / row operations");
-    constexpr int W = BASE_PW, ER = BASE_ER;
-    constexpr int ES = D + 1;                // padded state stride of the emit ring (bank spread for lane-per-circuit reads)
+    if (guard && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    constexpr int W = BASE_PW;
     extern __shared__ double lds[];          // effects | gates_t | per wavefront: save slots | emit ring | ring circuits | program window
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int li = lane % D, grp = lane / D;
     WalkArgs a = a_;
     int64_t task = (int64_t)blockIdx.x * wpb + wv;
     const bool have_task = task < n_tasks;
@@ -863,9 +780,7 @@ __global__ __launch_bounds__(64 * BASE_MAXW) void walk_base_kernel(const WalkArg
     double* const ldsE = lds;
     double* const ldsG = ldsE + a.n_effects * D;
     double* const wlds = lds + base_shared_doubles(D, a.n_gates, a.n_effects) + (size_t)wv * base_wave_doubles(D, n_slots);
-    double* const ering = wlds + (n_slots > 0 ? n_slots : 1) * 64;      // (a save slot holds one state per lane group)
-    int32_t* const ering_circ = (int32_t*)(ering + ER * ES);
-    uint32_t* const ldsP = (uint32_t*)(ering_circ + ER);
+    uint32_t* const ldsP = (uint32_t*)((int32_t*)(wlds + (n_slots > 0 ? n_slots : 1) * 64 + BASE_ER * (D + 1)) + BASE_ER);
 
     const int64_t pc0 = as_const(a.task_off)[task];
     const int32_t n_words = (int32_t)(as_const(a.task_off)[task + 1] - pc0);
@@ -881,106 +796,12 @@ __global__ __launch_bounds__(64 * BASE_MAXW) void walk_base_kernel(const WalkArg
     if (wpb > 1) __syncthreads();            // (one wavefront: the drain is enough)
     else __builtin_amdgcn_wave_barrier();
     if (!have_task) return;
-
-    // State-cache addressing.  Normal pass: every lane group holds the same state, group 0 stores it at
-    // cache[id][D].  Multi-start pass (a.multi_start = number of start vectors, used for the backward states of the
-    // analytic mode): lane group q walks from start vector a.start0 + q (RHO loads rhos[a.start0 + q] whatever its
-    // argument) and stores at cache[id][component][a.start0 + q] -- the walk program, the gates and their order are the same,
-    // so one pass propagates 64/D start vectors.
-    double* const cache = a.base_cache_w;
-    const bool multi = a.multi_start > 0;
-    const int my_start = a.start0 + grp;
-    const bool store_on = multi ? (my_start < a.multi_start) : (grp == 0);
-    const int64_t node_stride = multi ? (int64_t)a.multi_start * D : (int64_t)D;
-    // (multi-start states are stored [state][component][start]: the consumer reads all starts of a component at once)
-    const int lane_off = multi ? (store_on ? li * a.multi_start + my_start : 0) : lane;
-    double* const slot_lane = wlds + grp * D + li;           // save slot s of this lane group: + s * 64
-    int32_t lo = 0;                          // words [lo, lo + W) are resident, word i at ldsP[i % W]
-    int32_t pc = 0;                          // index of the current word
-    int n_er = 0;                            // parked EMITs (wave-uniform)
-
-#define BASE_WORD(i_) ldsP[(i_) & (W - 1)]
-#define BASE_REFILL()                                                                                 \
-    do {                                                                                              \
-        if (pc - lo >= W / 2 + 8) {          /* the half behind pc is dead: bring in the next W/2 words */ \
-            uint32_t* const half_ = ldsP + (lo & (W - 1));   /* lo is a multiple of W/2 */             \
-            const int32_t g0_ = lo + W;                                                               \
-            stage_lds(half_, W / 2, lane, [&](int k_) { return (g0_ + k_ < n_words) ? gprog[g0_ + k_] : 0u; }); \
-            lo += W / 2;                                                                              \
-        }                                                                                             \
-    } while (0)
-#define BASE_STORE_STATE(id_)                                                                         \
-    do {                                                                                              \
-        if (cache && store_on) cache[(int64_t)(id_) * node_stride + lane_off] = v;                    \
-    } while (0)
-#define BASE_FLUSH_EMITS()                                                                            \
-    do {                                                                                              \
-        if (lane < n_er) {                                                                            \
-            const int32_t circ_ = ering_circ[lane];                                                   \
-            const int32_t x0_ = a.eff_ptr[circ_], x1_ = a.eff_ptr[circ_ + 1];                         \
-            const double* st_ = ering + lane * ES;                                                    \
-            for (int32_t x_ = x0_; x_ < x1_; x_++) {                                                  \
-                const double* E_ = ldsE + a.eff_label[x_] * D;                                        \
-                const int64_t dest_ = a.eff_dest[x_];                                                 \
-                double p_ = 0.0;                                                                      \
-                _Pragma("unroll") for (int i = 0; i < D; i++) p_ = p_ + E_[i] * st_[i];               \
-                a.out[dest_] = p_;                                                                    \
-            }                                                                                         \
-        }                                                                                             \
-        n_er = 0;                                                                                     \
-    } while (0)
-
-    double v = 0.0;
-    uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)BASE_WORD(0));
-    for (;;) {
-        const uint32_t op = GST_OP(w), arg = GST_ARG(w);
-        if (op == GST_OP_END) break;
-        if (op == GST_OP_APPLY) {
-            double c[D];
-            {
-                const double* G0 = ldsG + (int)arg * D * D + li;
-#pragma unroll
-                for (int j = 0; j < D; j++) c[j] = G0[j * D];
-            }
-            uint32_t g = arg;
-            uint32_t p0 = BASE_WORD(pc + 1), p1 = BASE_WORD(pc + 2);   // this step's NODE marker and what follows
-            for (;;) {
-                const int32_t node_id = (int32_t)GST_ARG((uint32_t)__builtin_amdgcn_readfirstlane((int)p0));
-                const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)p1);
-                const bool more = (GST_OP(x) == GST_OP_APPLY);
-                pc += 2;                                                // at `x`
-                p0 = BASE_WORD(pc + 1); p1 = BASE_WORD(pc + 2);         // the next step's pair, one step ahead
-                const double* Gn = ldsG + (int)(more ? GST_ARG(x) : g) * D * D + li;
-                v = matvec_stream<D>(c, v, Gn);
-                BASE_STORE_STATE(node_id);
-                w = x;
-                if (!more) break;
-                g = GST_ARG(x);
-                BASE_REFILL();
-            }
-            continue;                                                  // `w` holds the next instruction, at pc
-        } else if (op == GST_OP_NODE) {
-            BASE_STORE_STATE(arg);
-        } else if (op == GST_OP_EMIT) {
-            if (grp == 0) ering[n_er * ES + lane] = v;
-            if (lane == 0) ering_circ[n_er] = (int32_t)arg;
-            if (++n_er == ER) BASE_FLUSH_EMITS();
-        } else if (op == GST_OP_SAVE) {
-            slot_lane[arg * 64] = v;
-        } else if (op == GST_OP_LOAD) {
-            v = slot_lane[arg * 64];
-        } else {  // GST_OP_RHO
-            v = multi ? (store_on ? a.rhos[(int64_t)my_start * D + li] : 0.0) : a.rhos[(int64_t)arg * D + li];
-        }
-        pc++;
-        BASE_REFILL();
-        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)BASE_WORD(pc));
-    }
-    BASE_FLUSH_EMITS();
-#undef BASE_FLUSH_EMITS
-#undef BASE_STORE_STATE
-#undef BASE_REFILL
-#undef BASE_WORD
+    ChainArgs ca;
+    ca.gprog = gprog; ca.n_words = n_words;
+    ca.eff_ptr = a.eff_ptr; ca.eff_label = a.eff_label; ca.eff_dest = a.eff_dest;
+    ca.rhos = a.rhos; ca.out = a.out; ca.cache = a.base_cache_w;
+    ca.multi_start = a.multi_start; ca.start0 = a.start0;
+    base_chain_walk<D, false>(ca, n_slots, ldsE, ldsG, wlds, lane);
 }
 
 template <int D>
@@ -1035,7 +856,7 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
                 const size_t bytes = sh + wpb * pw;
                 if (hipError_t ea = raise_lds((const void*)walk_base_kernel<D>, bytes)) return ea;
                 hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)((blocks + wpb - 1) / wpb)), dim3(64 * wpb), bytes,
-                                   stream, a, n_slots, wpb, blocks);
+                                   stream, a, n_slots, wpb, blocks, a.guard);
                 return hipGetLastError();
             }
         }
@@ -1046,7 +867,7 @@ static hipError_t launch_rows(const WalkArgs& a, int64_t n_tasks, int n_slots, h
                 if (hipError_t ea = raise_lds((const void*)walk_base_kernel<D>, bytes)) return ea;
                 WalkArgs b = a;
                 b.mm_tasks = (int32_t)n_tasks; b.n_pwaves = 1;
-                hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)blocks), dim3(64), bytes, stream, b, n_slots, 1, blocks);
+                hipLaunchKernelGGL((walk_base_kernel<D>), dim3((unsigned)blocks), dim3(64), bytes, stream, b, n_slots, 1, blocks, b.guard);
                 return hipGetLastError();
             }
         }

@@ -3,9 +3,13 @@
 #include "gst_plan.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <set>
+#include <queue>
 
 #include "../../include/gstfwd.h"
 
@@ -392,13 +396,17 @@ void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost)
     }
 }
 
-void task_split_points(const HostPlan& P, std::vector<int32_t>& split_pc, std::vector<float>& split_frac)
+void task_split_candidates(const HostPlan& P, std::vector<int32_t>& cand_ptr, std::vector<int32_t>& cand_pc, std::vector<float>& cand_frac,
+                           int max_per_task, std::vector<uint32_t>* cand_live)
 {
     const int64_t nT = P.n_tasks();
-    split_pc.assign((size_t)nT, -1);
-    split_frac.assign((size_t)nT, 0.0f);
+    cand_ptr.assign((size_t)nT + 1, 0);
+    cand_pc.clear(); cand_frac.clear();
+    if (cand_live) cand_live->clear();
     std::vector<uint64_t> live;
+    std::vector<std::pair<int32_t, int64_t>> all;      // (pc, gate applications before it)
     for (int64_t t = 0; t < nT; t++) {
+        cand_ptr[(size_t)t + 1] = (int32_t)cand_pc.size();
         const int64_t k0 = P.task_off[t], k1 = P.task_off[t + 1];
         const int64_t n = k1 - k0;
         if (n < 64) continue;
@@ -417,19 +425,162 @@ void task_split_points(const HostPlan& P, std::vector<int32_t>& split_pc, std::v
         if (!ok) continue;
         const int64_t total = P.task_applies[(size_t)t];
         if (total < 32) continue;
-        int64_t before = 0, best = -1, best_before = 0;
+        all.clear();
+        int64_t before = 0;
         for (int64_t k = 0; k < n; k++) {
             const uint32_t w = P.prog[k0 + k], op = GST_OP(w);
             const bool after_load = k > 0 && GST_OP(P.prog[k0 + k - 1]) == GST_OP_LOAD;
-            if (k > 2 && live[(size_t)k] == 0 && (op == GST_OP_EMIT || after_load) && op != GST_OP_END) {
-                if (best < 0 || std::llabs(2 * before - total) < std::llabs(2 * best_before - total)) { best = k; best_before = before; }
-            }
+            // a position where the 64 lane states are the walk's entire state: no save slot live, and the interpreter is
+            // at an instruction boundary it can resume from (an EMIT, or the word after a LOAD)
+            // (cand_live given: the hand-over carries the live save slots along, so liveness does not restrict the cut)
+            //  and a cut may fall INSIDE a chain, in front of any APPLY: a germ-power family's last trunk segment is half of
+            //  its work with no EMIT or LOAD inside)
+            if (k > 2 && (live[(size_t)k] == 0 || (cand_live && live[(size_t)k] < 16)) &&
+                (op == GST_OP_EMIT || after_load || (cand_live && op == GST_OP_APPLY)) && op != GST_OP_END &&
+                10 * before >= total && 10 * before <= 9 * total && (all.empty() || all.back().second != before))
+                all.emplace_back((int32_t)k, before);
             if (op == GST_OP_APPLY) before++;
         }
-        if (best < 0 || 10 * best_before < 3 * total || 10 * best_before > 7 * total) continue;     // (no useful middle)
-        split_pc[(size_t)t] = (int32_t)best;
-        split_frac[(size_t)t] = (float)best_before / (float)total;
+        // thin out to at most max_per_task, evenly spaced in work
+        const size_t m = all.size();
+        const size_t keep = std::min<size_t>(m, (size_t)std::max(max_per_task, 1));
+        for (size_t i = 0; i < keep; i++) {
+            const auto& c = all[keep == m ? i : (size_t)(((double)i + 0.5) * (double)m / (double)keep)];
+            if (!cand_pc.empty() && (int32_t)cand_pc.size() > cand_ptr[(size_t)t] && cand_pc.back() == c.first) continue;
+            cand_pc.push_back(c.first);
+            cand_frac.push_back((float)c.second / (float)total);
+            if (cand_live) cand_live->push_back((uint32_t)live[(size_t)c.first]);
+        }
+        cand_ptr[(size_t)t + 1] = (int32_t)cand_pc.size();
     }
+}
+
+void task_split_points(const HostPlan& P, std::vector<int32_t>& split_pc, std::vector<float>& split_frac)
+{
+    const int64_t nT = P.n_tasks();
+    split_pc.assign((size_t)nT, -1);
+    split_frac.assign((size_t)nT, 0.0f);
+    std::vector<int32_t> ptr, pc;
+    std::vector<float> fr;
+    task_split_candidates(P, ptr, pc, fr, 1 << 20, nullptr);
+    for (int64_t t = 0; t < nT; t++) {
+        int32_t best = -1;
+        for (int32_t i = ptr[(size_t)t]; i < ptr[(size_t)t + 1]; i++)
+            if (best < 0 || std::fabs(fr[(size_t)i] - 0.5f) < std::fabs(fr[(size_t)best] - 0.5f)) best = i;
+        if (best < 0 || fr[(size_t)best] < 0.3f || fr[(size_t)best] > 0.7f) continue;     // (no useful middle)
+        split_pc[(size_t)t] = pc[(size_t)best];
+        split_frac[(size_t)t] = fr[(size_t)best];
+    }
+}
+
+void pack_fd_queues(const std::vector<std::pair<int32_t, uint32_t>>& items, int32_t n_units, int64_t nT, int n_bins, int handover,
+                    const std::vector<int32_t>& cand_ptr, const std::vector<int32_t>& cand_pc, const std::vector<float>& cand_frac,
+                    const std::vector<uint32_t>& cand_live, FdQueues& out)
+{
+    struct BinItem { uint32_t id; int64_t cost; int32_t part; };
+    std::vector<std::vector<BinItem>> bins((size_t)n_bins);
+    std::vector<int64_t>& load = out.load;
+    load.assign((size_t)n_bins, 0);
+    typedef std::pair<int64_t, int32_t> LB;                  // (load, queue)
+    {
+        std::priority_queue<LB, std::vector<LB>, std::greater<LB>> heap;
+        for (int b = 0; b < n_bins; b++) heap.emplace(0, b);
+        for (const auto& it : items) {
+            LB t = heap.top(); heap.pop();
+            const int64_t c = (int64_t)(-it.first) + 8;
+            bins[(size_t)t.second].push_back(BinItem{it.second, c, 0});
+            load[(size_t)t.second] = t.first + c;
+            heap.emplace(t.first + c, t.second);
+        }
+    }
+    out.n_split = 0;
+    out.ho_index.clear(); out.ho_pc.clear(); out.ho_live.clear();
+    const bool have_cands = cand_ptr.size() == (size_t)nT + 1;
+    if (handover != 0 && have_cands) {
+        out.ho_index.assign((size_t)nT * (size_t)n_units, -1);
+        int64_t total = 0;
+        for (int64_t l : load) total += l;
+        const int64_t mean = total / n_bins;
+        const bool force = handover == 2;
+        // the candidate of task t closest to fraction `want`
+        auto pick = [&](int64_t t, double want) -> int32_t {
+            int32_t best = -1;
+            for (int32_t i = cand_ptr[(size_t)t]; i < cand_ptr[(size_t)t + 1]; i++)
+                if (best < 0 || std::fabs(cand_frac[(size_t)i] - want) < std::fabs(cand_frac[(size_t)best] - want)) best = i;
+            return best;
+        };
+        const int64_t tol = std::max<int64_t>(16, mean / 200);
+        // where a walk is cut: 0 = in its middle (the second part is then long enough to be worth a wavefront's wait and
+        // short enough to end with its queue); 1 = where the donor's load becomes the mean; 2 = where donor and receiver
+        // become equal.  (development switch; the default is what measured best on a 1/8 atom of the 2Q design)
+        int cut_policy = 0;
+        if (const char* e = std::getenv("GST_FD_CUT")) cut_policy = std::atoi(e);
+        double cut_frac = 0.5;
+        if (const char* e = std::getenv("GST_FD_CUT_FRAC")) cut_frac = std::atof(e);
+        int64_t min_gain = 16;
+        if (const char* e = std::getenv("GST_FD_CUT_GAIN")) min_gain = std::atoll(e);
+        // donors: queues above the mean, fullest first; receivers: all queues, emptiest first.  A donor that has nothing
+        // (more) to give leaves the donor set only -- it may still receive.
+        std::set<LB> donors, recv;
+        for (int b = 0; b < n_bins; b++) { donors.emplace(load[(size_t)b], b); recv.emplace(load[(size_t)b], b); }
+        for (int iter = 0; iter < 16 * n_bins && !donors.empty(); iter++) {
+            const LB top = *donors.rbegin();
+            const int bmax = top.second;
+            if (!force && load[(size_t)bmax] - mean <= tol) break;      // the fullest queue is at the mean: done
+            int best = -1;
+            for (size_t k = 0; k < bins[(size_t)bmax].size(); k++) {
+                const BinItem& bi = bins[(size_t)bmax][k];
+                const int64_t t = (int64_t)(bi.id / (uint32_t)n_units);
+                if (bi.part != 0 || cand_ptr[(size_t)t + 1] == cand_ptr[(size_t)t]) continue;
+                if (!force && bi.cost < std::max<int64_t>(64, mean / 4)) continue;
+                if (best < 0 || bi.cost > bins[(size_t)bmax][(size_t)best].cost) best = (int)k;
+            }
+            if (best < 0) { if (std::getenv("GST_FD_DEBUG")) std::fprintf(stderr, "[pack] queue %d load %lld: nothing to cut (%zu items)\n", bmax, (long long)load[(size_t)bmax], bins[(size_t)bmax].size()); donors.erase(top); continue; }  // nothing to cut in the fullest queue: look at the next
+            LB low = *recv.begin();
+            if (low.second == bmax) { if (recv.size() < 2) break; low = *std::next(recv.begin()); }
+            const int bmin = low.second;
+            BinItem whole = bins[(size_t)bmax][(size_t)best];
+            const int64_t tsk = (int64_t)(whole.id / (uint32_t)n_units);
+            // shed x: down to the mean, but never so much that the receiver ends above the donor
+            double want = force ? 0.5 : cut_frac;
+            if (!force && cut_policy != 0) {
+                const double half = 0.5 * (double)(load[(size_t)bmax] - load[(size_t)bmin]);
+                const double x = cut_policy == 2 ? half : std::min((double)(load[(size_t)bmax] - mean), half);
+                want = 1.0 - x / (double)whole.cost;
+            }
+            const int32_t ci = pick(tsk, want);
+            const double frac = cand_frac[(size_t)ci];
+            const int64_t c1 = (int64_t)((double)whole.cost * frac) + 24, c2 = whole.cost - (int64_t)((double)whole.cost * frac) + 24;
+            const int64_t new_hi = std::max(load[(size_t)bmax] - whole.cost + c1, load[(size_t)bmin] + c2);
+            if (!force && new_hi + min_gain >= load[(size_t)bmax]) { if (std::getenv("GST_FD_DEBUG")) std::fprintf(stderr, "[pack] queue %d load %lld -> %d load %lld: no gain (cost %lld frac %.3f want %.3f)\n", bmax, (long long)load[(size_t)bmax], bmin, (long long)load[(size_t)bmin], (long long)whole.cost, frac, want); donors.erase(top); continue; }   // no gain here: next queue
+            donors.erase(top); donors.erase(LB(load[(size_t)bmin], bmin));
+            recv.erase(LB(load[(size_t)bmax], bmax)); recv.erase(low);
+            bins[(size_t)bmax].erase(bins[(size_t)bmax].begin() + best);
+            bins[(size_t)bmax].insert(bins[(size_t)bmax].begin(), BinItem{whole.id, c1, 1});
+            {   // second part: in cost order behind the receiver's longer items (not behind its short ones: picked up
+                // late, its work would land at the very end of that queue)
+                auto& rb = bins[(size_t)bmin];
+                size_t at = 0;
+                while (at < rb.size() && (rb[at].part == 1 || rb[at].cost >= c2)) at++;
+                rb.insert(rb.begin() + (long)at, BinItem{whole.id, c2, 2});
+            }
+            load[(size_t)bmax] += c1 - whole.cost;
+            load[(size_t)bmin] += c2;
+            out.ho_index[(size_t)whole.id] = out.n_split++;
+            out.ho_pc.push_back(cand_pc[(size_t)ci]);
+            out.ho_live.push_back(cand_live.size() == cand_pc.size() ? cand_live[(size_t)ci] : 0u);
+            donors.emplace(load[(size_t)bmin], bmin); donors.emplace(load[(size_t)bmax], bmax);
+            recv.emplace(load[(size_t)bmin], bmin); recv.emplace(load[(size_t)bmax], bmax);
+        }
+    }
+    out.bin_ptr.assign((size_t)n_bins + 1, 0);
+    out.bin_items.clear();
+    out.bin_items.reserve(items.size() + (size_t)out.n_split);
+    for (int b = 0; b < n_bins; b++) {
+        for (const BinItem& bi : bins[(size_t)b]) out.bin_items.push_back(bi.id | ((uint32_t)bi.part << 30));
+        out.bin_ptr[(size_t)b + 1] = (int32_t)out.bin_items.size();
+    }
+    if (out.n_split == 0) out.ho_index.clear();
 }
 
 std::string build_reverse_plan(const HostPlan& P, HostPlan& R, int32_t target_tasks, int32_t max_slots)

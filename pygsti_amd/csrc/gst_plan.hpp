@@ -13,6 +13,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace gst {
@@ -64,6 +65,32 @@ void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost);
 // the fraction of the task's gate applications that lie before it.  The position closest to the middle is chosen; it
 // is always an op the interpreter's outer loop sees (the word after a LOAD, or an EMIT).
 void task_split_points(const HostPlan& P, std::vector<int32_t>& split_pc, std::vector<float>& split_frac);
+// Every position of a task's program at which a walk can be handed from one wavefront to another -- no save slot is
+// live, the 64 lane states are the walk's entire state -- between 10 % and 90 % of its gate applications, thinned to
+// max_per_task evenly spaced ones: cand_pc[cand_ptr[t] .. cand_ptr[t + 1]) (word index relative to the task start,
+// ascending) with cand_frac = fraction of the task's gate applications in front of it.
+// Per-SIMD queues of the persistent FD launch.  `items` = (-estimated cost, pair id = task * n_units + unit), longest
+// first.  Longest-processing-time packing into n_bins queues, then HAND-OVERS: a walk of a queue above the mean is cut
+// at the slot-free position (task_split_candidates) that brings its queue down to the mean; the first part stays at the
+// FRONT of its queue, the second part goes to the emptiest queue, in cost order behind that queue's longer items (its
+// wavefront waits for the first part's states).  handover: 0 = never cut, 1 = cut to balance, 2 = cut every walk that
+// can be cut, in the middle (tests).  bin_items carry the part in their top two bits (0 whole, 1 first, 2 second).
+struct FdQueues {
+    std::vector<int32_t> bin_ptr;        // [n_bins + 1]
+    std::vector<uint32_t> bin_items;
+    std::vector<int64_t> load;           // estimated work per queue
+    int32_t n_split = 0;
+    std::vector<int32_t> ho_index;       // [n_tasks * n_units]: hand-over buffer of a cut pair, or -1 (empty when n_split == 0)
+    std::vector<int32_t> ho_pc;          // [n_split]: where the pair is cut (word index relative to its task's start)
+    std::vector<uint32_t> ho_live;       // [n_split]: save slots that are live at the cut (bit s): they travel with the states
+};
+void pack_fd_queues(const std::vector<std::pair<int32_t, uint32_t>>& items, int32_t n_units, int64_t n_tasks, int n_bins, int handover,
+                    const std::vector<int32_t>& cand_ptr, const std::vector<int32_t>& cand_pc, const std::vector<float>& cand_frac,
+                    const std::vector<uint32_t>& cand_live, FdQueues& out);
+// cand_live (may be NULL): also positions at which save slots ARE live (slots 0..3 only) qualify, and the mask of the
+// live slots is returned per candidate -- the hand-over then carries those slots along with the lane states.
+void task_split_candidates(const HostPlan& P, std::vector<int32_t>& cand_ptr, std::vector<int32_t>& cand_pc, std::vector<float>& cand_frac,
+                           int max_per_task, std::vector<uint32_t>* cand_live);
 
 // Analytic derivatives (gst_kernels_analytic.hip, MFMA path): the plan of the REVERSED circuits (one dummy start, the
 // gates of every circuit in reverse order, no effects).  Walking it with the transposed gates from every effect

@@ -43,6 +43,91 @@ def test_dprobs_fd_row_split_variants_bitwise(fd_split):
         assert_bitwise(J, fx['dprobs_map'], "dprobs fd_split=%d %s" % (fd_split, name))
 
 
+@pytest.mark.parametrize("overlap,handover", [("1", "1"), ("1", "2"), ("1", "0"), ("0", "1")])
+def test_dprobs_fd_base_pass_inside_persistent_launch_bitwise(overlap, handover, monkeypatch):
+    """Persistent launch with the base pass walked INSIDE it (GST_FD_OVERLAP=1, the default for D = 16): designated
+    wavefronts publish states and probabilities with write-through stores, the finite-difference walks wait on the
+    sentinel the buffers were pre-filled with.  Same arithmetic, same bits -- including probs_out, which the chains fill
+    -- whatever the hand-over setting; destinations pre-filled with NaN; repeated fills (stale cache contents)."""
+    monkeypatch.setenv("GST_FD_PERSIST", "2")
+    monkeypatch.setenv("GST_FD_FUSED", "0")            # (plans this small would otherwise take the one-launch fused-lane form)
+    monkeypatch.setenv("GST_FD_OVERLAP", overlap)
+    monkeypatch.setenv("GST_FD_HANDOVER", handover)
+    forms = set()
+    for name in ("smq2Q_XYICNOT_L1024_deep", "smq2Q_XYICNOT_L2_depol"):
+        fx = load_fixture(name)
+        for tt in (0, 3, 40):
+            pl = plan_from_fixture(fx, target_tasks=tt)
+            for rep in range(2):
+                pr = np.full(int(fx['nE']), np.nan)
+                J = np.full((int(fx['nE']), len(fx['dprobs_cols'])), np.nan)
+                pl.fill_dprobs(out=J, param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']), probs_out=pr)
+                st = pl.stats()
+                forms.add(st["last_fd_form"])
+                assert st["last_fd_aborted"] == 0, (name, tt, st)
+                assert_bitwise(pr, fx['probs'], "probs_out overlap=%s %s tasks=%d rep %d" % (overlap, name, tt, rep))
+                assert_bitwise(J, fx['dprobs_map'], "dprobs overlap=%s handover=%s %s tasks=%d rep %d" % (overlap, handover, name, tt, rep))
+            # a different model on the same plan: nothing of the previous fill's cache may survive
+            g2 = np.array(fx['gates']) * 0.999
+            pl.set_model(g2, fx['rhos'], fx['effects'])
+            J2 = pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']))
+            monkeypatch.setenv("GST_FD_PERSIST", "0")
+            pl0 = plan_from_fixture(fx, target_tasks=tt)
+            pl0.set_model(g2, fx['rhos'], fx['effects'])
+            assert_bitwise(J2, pl0.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps'])), "second model " + name)
+            monkeypatch.setenv("GST_FD_PERSIST", "2")
+    assert (2 in forms) == (overlap == "1"), forms
+
+
+def test_dprobs_fd_bounded_waits_fall_back_to_the_standby_launches(monkeypatch):
+    """A wait that cannot end -- here: the overlap launch is told to walk no chain at all (GST_FD_TEST_SKIP_CHAINS), as
+    when the producing workgroup is not resident on a shared device -- runs out after ~0.1 s, raises the abort flag, and
+    the stand-by launches enqueued behind the persistent one (separate base pass, one workgroup per pair, guarded by that
+    flag) produce the reference's Jacobian bit for bit.  Nothing hangs; the next fill is unaffected."""
+    import time
+    monkeypatch.setenv("GST_FD_PERSIST", "2")
+    monkeypatch.setenv("GST_FD_FUSED", "0")
+    monkeypatch.setenv("GST_FD_TEST_SKIP_CHAINS", "1")
+    fx = load_fixture("smq2Q_XYICNOT_L1024_deep")
+    pl = plan_from_fixture(fx)
+    pr = np.full(int(fx['nE']), np.nan)
+    t0 = time.perf_counter()
+    J = pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']), probs_out=pr)
+    dt = time.perf_counter() - t0
+    st = pl.stats()
+    assert st["last_fd_form"] == 2 and st["last_fd_aborted"] == 1, st
+    assert dt < 20.0, "bounded waits must end within a fraction of a second each (took %.1f s)" % dt
+    assert_bitwise(pr, fx['probs'], "probs after the fall-back")
+    assert_bitwise(J, fx['dprobs_map'], "dprobs after the fall-back")
+    monkeypatch.delenv("GST_FD_TEST_SKIP_CHAINS")
+    pl2 = plan_from_fixture(fx)
+    J2 = pl2.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']))
+    assert pl2.stats()["last_fd_aborted"] == 0
+    assert_bitwise(J2, fx['dprobs_map'], "dprobs, next plan")
+
+
+@pytest.mark.parametrize("cut", ["1", "2"])
+def test_dprobs_fd_handover_inside_chains_with_live_slots_bitwise(cut, monkeypatch):
+    """GST_FD_CUT_RICH=1: a walk may be cut in front of ANY gate application, also where save slots are live -- the slots
+    (a clean state's id, or the 64 lanes' data) travel with the lane states -- and the packer places the cut where it
+    balances the queues (GST_FD_CUT=1: donor down to the mean, 2: donor and receiver equal).  Same program words, same
+    arithmetic: same bits.  (Not the default: better balanced on paper, slower on the device; see gst_abi.cpp.)"""
+    monkeypatch.setenv("GST_FD_PERSIST", "2")
+    monkeypatch.setenv("GST_FD_FUSED", "0")
+    monkeypatch.setenv("GST_FD_CUT_RICH", "1")
+    monkeypatch.setenv("GST_FD_CUT", cut)
+    for name in ("smq2Q_XYICNOT_L1024_deep", "smq2Q_XYICNOT_L2_depol"):
+        fx = load_fixture(name)
+        for tt, slots in ((0, 0), (3, 2), (5, 1)):
+            for ho in ("1", "2"):
+                monkeypatch.setenv("GST_FD_HANDOVER", ho)
+                pl = plan_from_fixture(fx, target_tasks=tt, max_slots=slots)
+                J = np.full((int(fx['nE']), len(fx['dprobs_cols'])), np.nan)
+                pl.fill_dprobs(out=J, param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']))
+                assert pl.stats()["last_fd_aborted"] == 0
+                assert_bitwise(J, fx['dprobs_map'], "dprobs rich cuts policy %s handover %s %s tasks=%d slots=%d" % (cut, ho, name, tt, slots))
+
+
 @pytest.mark.parametrize("handover", ["0", "1", "2"])
 def test_dprobs_fd_walk_handover_bitwise(handover, monkeypatch):
     """Persistent launch with walks cut at their task's slot-free middle and handed from one SIMD to another

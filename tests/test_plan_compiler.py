@@ -109,3 +109,20 @@ def test_state_graph_reproduces_every_circuit(name):
     out, written, st = run_programs(words, off, fx['gates'], fx['rhos'], fx['effects'], fx['eff_ptr'],
                                     fx['eff_label'], fx['eff_dest'], int(fx['nE']))
     assert set(leaf.tolist()) <= set(st['node_states'].keys())
+
+
+def test_fd_queue_packing_and_handovers():
+    """gst_get_fd_queues (host side): longest-first packing of (task, 64 columns) pairs into per-SIMD queues, then
+    hand-overs -- walks of the fullest queues cut in two, the second part given to the emptiest -- narrow the spread of
+    the estimated loads; cutting every walk (handover = 2, the tests' setting) cuts more."""
+    fx = load_fixture("smq2Q_XYICNOT_L1024_deep")
+    from conftest import plan_from_fixture
+    pl = plan_from_fixture(fx, target_tasks=0)
+    cols = np.asarray(fx["dprobs_cols"], np.int64)
+    l0, n_pairs, h0 = pl.fd_queues(cols, n_queues=8, handover=0)
+    l1, _, h1 = pl.fd_queues(cols, n_queues=8, handover=1)
+    l2, _, h2 = pl.fd_queues(cols, n_queues=8, handover=2)
+    assert h0 == 0 and n_pairs > 0 and l0.sum() > 0
+    assert l1.max() <= l0.max() and (l1.max() - l1.min()) <= (l0.max() - l0.min())
+    assert h2 >= h1 >= 0
+    assert l1.sum() >= l0.sum()                       # every hand-over adds its bookkeeping cost to the estimate

@@ -6,6 +6,13 @@ import numpy as np
 for path in sys.argv[1:]:
     raw = np.fromfile(path, dtype=np.uint64)
     n = int(raw[0]); rec = raw[1:1 + 4 * n].reshape(n, 4)
+    chain = (rec[:, 0] & np.uint64(0x40000000)) != 0        # base-pass chains walked inside the launch (overlap form)
+    if chain.any():
+        c0 = rec[chain, 1].astype(np.int64); c1 = rec[chain, 2].astype(np.int64); tm = rec[:, 1].astype(np.int64).min()
+        print("== %s: %d chains inside the launch: start (us) min/max %.1f %.1f, end 50/90/100 %.1f %.1f %.1f, duration 50/100 %.1f %.1f" % (
+            (path, int(chain.sum()), (c0.min() - tm) / 100.0, (c0.max() - tm) / 100.0) + tuple(np.percentile((c1 - tm) / 100.0, [50, 90, 100])) +
+            tuple(np.percentile((c1 - c0) / 100.0, [50, 100]))))
+        rec = rec[~chain]; n = len(rec)
     pair = rec[:, 0].astype(np.int64); t0 = rec[:, 1].astype(np.int64); t1 = rec[:, 2].astype(np.int64)
     hw = rec[:, 3]
     hwid = (hw & np.uint64(0xffffffff)).astype(np.int64); xcc = (hw >> np.uint64(32)).astype(np.int64)
