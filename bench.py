@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1: weak = one full design per rank (N designs in all); strong = one design dealt to N atoms")
     ap.add_argument("--no-analytic", action="store_true", help="skip the secondary analytic-derivative timing")
+    ap.add_argument("--no-cptplnd", action="store_true", help="N=1: skip the secondary CPTPLND (Lindblad-parameterised) Jacobian timing")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="development aid (N=1 only): time rank 0's atom of an N-atom strong-scaling layout on this one "
                          "GPU; the printed value counts only that atom's elements")
@@ -350,6 +351,49 @@ def main():
                     "note": "analytic derivatives (reference MatrixForwardSimulator semantics); secondary figure, not `value`"}
         plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the FD Jacobian resident
         barrier_sync(plan)
+
+    # secondary (N=1): the same design under the CPTPLND parameterisation StandardGST fits by default -- every member a
+    # static target composed with an exponentiated Lindblad error generator (1,920 parameters), the dense members built
+    # ON THE DEVICE for the base model and for every finite-difference step (gst_set_lindblad)
+    cptp_info = None
+    if world == 1 and lay_world == 1 and not args.no_cptplnd:
+        from pygsti_amd import lindblad as LBM
+        lmodel = LBM.LindbladModel.from_target(pack.target_model(), layout.model_gate_labels, layout.effect_labels, "CPTPLND")
+        theta = 0.003 * np.random.default_rng(9).standard_normal(lmodel.num_params)
+        nPl = lmodel.num_params
+        plan.set_lindblad(lmodel)
+        d_outl = plan.device_malloc(nE_local * nPl * 8)
+        pidx_l = np.arange(nPl, dtype=np.int64)
+        try:
+            t_set0 = time.perf_counter()
+            plan.set_lindblad_params(theta)
+            t_set = time.perf_counter() - t_set0
+            plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_FD)       # warm-up
+            barrier_sync(plan)
+            n_c = max(2, min(args.steps, 3))
+            tc0 = time.perf_counter()
+            for _ in range(n_c):
+                plan.set_lindblad_params(theta)
+                plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_FD)
+            barrier_sync(plan)
+            dtc = (time.perf_counter() - tc0) / n_c
+            chk = plan.memcpy_d2h(np.empty(nPl), d_outl + ((nE_local - 1) * nPl) * 8)
+            assert np.isfinite(chk).all()
+            cptp_info = {"value": nE_local * nPl / dtc, "unit": "Jacobian-elements/s", "ms_per_step": 1e3 * dtc, "n_params": nPl,
+                         "set_params_ms": 1e3 * t_set,
+                         "note": "bulk_fill_dprobs of the CPTPLND-parameterised model (FD eps=1e-7, Map-simulator semantics, <=1e-8 vs the "
+                                 "reference): every column's changed member assembled and exponentiated on the device (no host to_dense per "
+                                 "column), walks share the base pass's states (dirty programs, 4 columns per wavefront), POVM columns from "
+                                 "the cached final states; round 2's form of the same Jacobian (host-stepped dense model sets, one "
+                                 "independent walk per (program, model)) took 580 ms; secondary figure, not `value`"}
+        finally:
+            plan.device_free(d_outl)
+            plan.set_lindblad(None)
+            plan.set_model(gates, rhos, effects)
+            plan.set_param_map(*layout.param_map(model))
+        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the headline Jacobian resident
+        barrier_sync(plan)
+        log("CPTPLND leg done: %.1f ms per Jacobian" % (1e3 * dtc))
 
     log("probs / analytic legs done")
     # secondary (N>1): the fan-in of the Jacobian row blocks to rank 0 between device buffers (Gatherv,
@@ -525,6 +569,7 @@ def main():
             "exchange": exchange,
             "normal_equations": jtj_info,
             "analytic_dprobs": ana_info,
+            "cptplnd_dprobs": cptp_info,
             "host_fill": host_fill,
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,

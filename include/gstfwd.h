@@ -164,6 +164,52 @@ int gst_set_complement_effect(gst_plan *plan, int32_t comp_index, const double *
 int gst_set_derivs(gst_plan *plan, int32_t n_params, int32_t n_objs, const int32_t *kind, const int32_t *obj,
                    const int32_t *n_cols, const int64_t *param_idx, const double *deriv);
 
+/* Lindblad-parameterised models (CPTPLND, GLND, H+S ...: what `target_model('CPTPLND')` and StandardGST's default modes
+ * build) with the members built ON THE DEVICE from the parameter vector -- SURVEY 8(f) row f4.  In the reference every
+ * member is a static factor composed with an exponentiated Lindblad error generator,
+ *     gate  ComposedOp([static U, ExpErrorgenOp(L)])        dense = expm(L) . U        (modelmembers/operations/composedop.py,
+ *     prep  ComposedState(static rho0, ExpErrorgenOp(L))     dense = expm(L) . rho0      experrorgenop.py:49-213,
+ *     POVM  ComposedPOVM(ExpErrorgenOp(L), base POVM)        effect_i = expm(L)^T e_i    states/composedstate.py, povms/composedpovm.py)
+ * and L is linear in complex coefficients c, L = Re(sum_k c_k S_k) = sum_k Re(c_k) term_re[k] + Im(c_k) term_im[k]
+ * (lindbladerrorgen.py:658-742; S_k = the blocks' Lindblad term superoperators, lindbladcoefficients.py:664-702, 1073-1198 --
+ * the caller passes term_re = Re S_k, term_im = -Im S_k, row-major [D][D] each, in the basis the model's dense members use),
+ * with c the concatenated block_data of the member's coefficient blocks, functions of its real parameters
+ * (lindbladcoefficients.py:164-470):
+ *     block_type 0 'ham', 1 'other_diagonal': n coefficients from n parameters v:  mode 0 'elements' c = v, 1 'cholesky' c = v^2
+ *     block_type 2 'other': n*n coefficients (row-major) from n*n parameters read as a matrix p:
+ *         mode 1 'cholesky' c = C C^dag, C lower triangular, C_ii = p_ii, C_ij = p_ij + i p_ji (i > j)
+ *         mode 0 'elements' c Hermitian, c_ii = p_ii, c_ij = p_ij + i p_ji (i > j)
+ * A member's parameters are model parameters param0 .. param0 + (sum of its blocks' parameter counts), blocks in order.
+ * Members that share a basis share their terms: give them the same term_offset.  EVERY object of the plan must belong
+ * to a member (kind GST_KIND_EFFECT = a POVM: the n_eff consecutive effects from index obj, static_part = their base effect
+ * vectors [n_eff][D]; gates: static_part = U [D][D]; preparations: rho0 [D]).  D = 4, 16.
+ *   gst_set_lindblad         describes the members (copied); n_members = 0 clears.
+ *   gst_set_lindblad_params  takes the model's parameter vector theta[n_params] -- call it where gst_set_model would be
+ *       called, after every model.from_vector(): the device assembles L, exponentiates (scaled Taylor series, fp64) and
+ *       composes every member; the result is the plan's model for ALL fills (gst_get_model reads it back).
+ * While set, GST_DERIV_FD columns of gst_fill_dprobs(_dev) are those of mapfill_dprobs_atom for such a model
+ * (mapforwardsim_calc_densitymx.pyx:349-381: set_parameter_value(i, theta_i + eps), re-propagate, (p2 - p) / eps): the
+ * device builds the dense model after every step itself -- no host densification and no PCIe traffic per column
+ * (gst_fill_dprobs_models is the host-stepped form of the same walk).  Accuracy: the reference propagates through the
+ * composed member factor by factor and exponentiates with a Pade approximant; dense members agree to ~1e-16, probabilities
+ * to ~1e-15, FD quotients to ~1e-8.  GST_DERIV_ANALYTIC keeps using gst_set_derivs / gst_set_param_map. */
+typedef struct {
+    int32_t kind, obj, n_eff, n_blocks;
+    int32_t block_type[4], block_mode[4], block_n[4];
+    int64_t param0;
+    int64_t term_offset;         /* first of this member's terms in term_re / term_im */
+    const double *static_part;
+} gst_lindblad_member;
+int gst_set_lindblad(gst_plan *plan, int32_t n_params, int32_t n_members, const gst_lindblad_member *members,
+                     int64_t n_terms, const double *term_re, const double *term_im);
+int gst_set_lindblad_params(gst_plan *plan, const double *theta);
+/* The plan's current dense model (row-major, the layout of gst_set_model); any pointer may be NULL. */
+int gst_get_model(gst_plan *plan, double *gates, double *rhos, double *effects);
+/* The dense models the device builds for the finite-difference steps of parameters param_idx (theta_p + eps each):
+ * gates[n][n_gates][D][D], rhos[n][n_rhos][D], effects[n][n_effects][D] (host; tests compare them with the reference's). */
+int gst_get_lindblad_model_sets(gst_plan *plan, const int64_t *param_idx, int64_t n_param, double eps, double *gates,
+                                double *rhos, double *effects);
+
 /* probs: out[n_elements] (host). */
 int gst_fill_probs(gst_plan *plan, double *out);
 
@@ -396,6 +442,8 @@ const char *gst_version(void);
 #define GST_OP_NODE 6u   /* marker after every RHO/APPLY: the state just produced has global id arg (the base
                             pass stores it in the base-state cache; derivative passes use it to skip work
                             that is bit-identical to the base pass) */
+#define GST_OP_CACHE 7u  /* derived programs only (finite differences over whole-object perturbations): v <- state arg of the
+                            base pass's cache */
 #define GST_OP(word) ((word) >> 28)
 #define GST_ARG(word) ((word) & 0x0FFFFFFFu)
 

@@ -56,6 +56,12 @@ class ObjectiveDesc(C.Structure):
                 ("prob_clip_lo", C.c_double), ("prob_clip_hi", C.c_double)]
 
 
+class LindbladMemberDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("obj", C.c_int32), ("n_eff", C.c_int32), ("n_blocks", C.c_int32),
+                ("block_type", C.c_int32 * 4), ("block_mode", C.c_int32 * 4), ("block_n", C.c_int32 * 4),
+                ("param0", C.c_int64), ("term_offset", C.c_int64), ("static_part", C.c_void_p)]
+
+
 class CommInfo(C.Structure):
     _fields_ = [("transport", C.c_int32), ("rank", C.c_int32), ("size", C.c_int32), ("device", C.c_int32),
                 ("rccl_version", C.c_int32), ("ipc_opens", C.c_int32), ("reserved", C.c_int32 * 2)]
@@ -75,6 +81,7 @@ EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_p
            "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_get_fd_queues", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
+           "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
            "gst_comm_get_unique_id", "gst_comm_create", "gst_comm_destroy", "gst_comm_allgather_rows",
            "gst_comm_gather_rows", "gst_comm_allreduce_sum", "gst_comm_barrier", "gst_comm_sync", "gst_comm_get_info"]
 
@@ -122,6 +129,10 @@ def lib():
         L.gst_device_count.argtypes = [C.POINTER(i32)]
         L.gst_fill_dprobs_models.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp]
         L.gst_fill_dprobs_models_dev.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp]
+        L.gst_set_lindblad.argtypes = [vp, i32, i32, C.POINTER(LindbladMemberDesc), i64, vp, vp]
+        L.gst_set_lindblad_params.argtypes = [vp, vp]
+        L.gst_get_model.argtypes = [vp, vp, vp, vp]
+        L.gst_get_lindblad_model_sets.argtypes = [vp, vp, i64, dbl, vp, vp, vp]
         L.gst_host_register.argtypes = [vp, i64]
         L.gst_host_unregister.argtypes = [vp]
         L.gst_comm_get_unique_id.argtypes = [C.c_int, vp]
@@ -315,6 +326,60 @@ class Plan:
         der = _f64(np.concatenate([np.ascontiguousarray(o[3], np.float64).ravel() for o in objs]))
         check(lib().gst_set_derivs(self._h, int(n_params), len(objs), _ptr(kind), _ptr(obj), _ptr(ncols), _ptr(pidx), _ptr(der)))
         self.n_params = int(n_params)
+
+    def set_lindblad(self, model):
+        """Lindblad-parameterised members built on the device (gst_set_lindblad): `model` is a
+        pygsti_amd.lindblad.LindbladModel (or anything with .members / .num_params in its shape); None clears."""
+        if model is None:
+            check(lib().gst_set_lindblad(self._h, 0, 0, None, 0, None, None))
+            return
+        members = list(model.members)
+        # members over the same basis with the same block structure share their terms
+        tables, offsets, keep = {}, [], []
+        n_terms = 0
+        for m in members:
+            # (members built from Pauli matrices share a table per block structure; given term arrays are shared when they
+            #  are the same array contents)
+            key = (m.n_qubits, tuple(m.blocks), hash(m.term_re.tobytes()) ^ hash(m.term_im.tobytes()))
+            if key not in tables:
+                tables[key] = n_terms
+                n_terms += m.n_coeffs
+                keep.append(m)
+            offsets.append(tables[key])
+        term_re = _f64(np.concatenate([m.term_re.reshape(m.n_coeffs, -1) for m in keep]))
+        term_im = _f64(np.concatenate([m.term_im.reshape(m.n_coeffs, -1) for m in keep]))
+        arr = (LindbladMemberDesc * len(members))()
+        statics = []
+        for k, m in enumerate(members):
+            st = _f64(m.static)
+            statics.append(st)
+            d = arr[k]
+            d.kind = {0: KIND_GATE, 1: KIND_RHO, 2: KIND_EFFECT}[m.kind]; d.obj = m.obj; d.n_eff = m.n_eff; d.n_blocks = len(m.blocks)
+            for b, (t, mode, n) in enumerate(m.blocks):
+                d.block_type[b] = t; d.block_mode[b] = mode; d.block_n[b] = n
+            d.param0 = m.param0; d.term_offset = offsets[k]; d.static_part = st.ctypes.data
+        check(lib().gst_set_lindblad(self._h, int(model.num_params), len(members), arr, int(n_terms), _ptr(term_re), _ptr(term_im)))
+        self.n_params = int(model.num_params)
+
+    def set_lindblad_params(self, theta):
+        """The model's parameter vector: the device builds every dense member from it (gst_set_lindblad_params)."""
+        th = _f64(theta)
+        assert len(th) == self.n_params
+        check(lib().gst_set_lindblad_params(self._h, _ptr(th)))
+
+    def get_model(self):
+        """(gates, rhos, effects) the plan currently holds (gst_get_model)."""
+        D = self.D
+        g = np.empty((self.n_gates, D, D)); r = np.empty((self.n_rhos, D)); e = np.empty((self.n_effects, D))
+        check(lib().gst_get_model(self._h, _ptr(g), _ptr(r), _ptr(e)))
+        return g, r, e
+
+    def lindblad_model_sets(self, param_idx, eps):
+        """Dense models the device builds for the FD steps of `param_idx` (gst_get_lindblad_model_sets)."""
+        pidx = _i64(param_idx); n = len(pidx); D = self.D
+        g = np.empty((n, self.n_gates, D, D)); r = np.empty((n, self.n_rhos, D)); e = np.empty((n, self.n_effects, D))
+        check(lib().gst_get_lindblad_model_sets(self._h, _ptr(pidx), n, float(eps), _ptr(g), _ptr(r), _ptr(e)))
+        return g, r, e
 
     def set_second_derivs(self, hessians):
         """hessian_wrt_params of the objects given to set_derivs, in the same order: a list whose entries are None

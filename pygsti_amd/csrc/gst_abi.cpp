@@ -163,6 +163,27 @@ struct gst_plan {
     int fd_split = 0;                   // gst_options.fd_split: 0 auto, 1 / 2 / 4 wavefronts per (task, 64 columns) pair
     int n_cus = 256;
     DevBuf<double> d_mm_models, d_mm_raw;   // gst_fill_dprobs_models: perturbed model sets, their probability vectors
+    // gst_set_lindblad: members = static factor x exp(Lindblad error generator), built on the device
+    struct Lindblad {
+        bool set = false, have_theta = false, uploaded = false;
+        int32_t n_params = 0, n_members = 0;
+        std::vector<int32_t> kind, obj, n_eff, n_par, n_blocks, blk_type, blk_mode, blk_n;
+        std::vector<int64_t> param0, term_off, static_off;
+        std::vector<double> statics, term_re, term_im, theta;
+    } lb;
+    DevBuf<int32_t> d_lb_i32;               // kind | obj | n_eff | n_par | n_blocks | blk_type | blk_mode | blk_n
+    DevBuf<int64_t> d_lb_i64, d_lb_setparam;   // param0 | term_off | static_off; the stepped parameter of each set
+    DevBuf<double> d_lb_statics, d_lb_term_re, d_lb_term_im, d_lb_theta, d_lb_base, d_lb_gates_rm, d_lb_pert;
+    DevBuf<int32_t> d_lb_waves;             // walk_pert_kernel's wave tables: kind | obj | n_eff | col0 | ncols | col_dest
+    int32_t lb_n_pwaves = 0, lb_n_zero = 0;
+    int64_t lb_n_items = 0;
+    std::vector<int32_t> lb_povm_cols;      // per POVM member with requested columns: obj, n_eff, col0, ncols
+    gst::DirtyPrograms dirty;               // gst::build_dirty_programs, once per plan
+    bool dirty_ready = false;
+    DevBuf<uint32_t> d_dirty_words;
+    DevBuf<int64_t> d_dirty_off;
+    DevBuf<int32_t> d_lb_item_pw;
+    bool lb_share = true;                   // GST_LB_SHARE=0: every (program, perturbed model) pair walked on its own (round-2 form)
     DevBuf<int32_t> d_mm_dest;
     DevBuf<double> d_obj_part;          // per-block partial sums of the objective terms
     DevBuf<uint32_t> d_block_order;     // FD launch order of the cached request (expensive (task, wavefront) pairs first)
@@ -225,6 +246,8 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
+        d_lb_i32.release(); d_lb_i64.release(); d_lb_setparam.release(); d_lb_statics.release(); d_lb_term_re.release();
+        d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release();
         d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release();
         d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release();
         d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release();
@@ -296,6 +319,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_FD_HANDOVER")) p->fd_handover = std::atoi(e);
     if (const char* e = std::getenv("GST_FD_OVERLAP")) { p->fd_overlap = std::atoi(e) != 0; p->fd_overlap_diag = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_FD_STANDBY")) p->fd_standby = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_LB_SHARE")) p->lb_share = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_TEST_SKIP_CHAINS")) p->test_skip_chains = std::atoi(e) != 0;
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
@@ -566,7 +590,6 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         // chain), so with only a few pairs per SIMD -- a 1/8 atom of the 2Q design has 4.4 -- the order decides how
         // long the last SIMD runs.
         p->have_block_order = false;
-        const int nG = p->hp.n_gates;
         const int64_t nT = p->hp.n_tasks();
         if (p->task_cost.empty()) gst::task_gate_costs(p->hp, p->task_cost);
         if (!p->task_cost.empty() && nT * L.n_waves < 0x7fffffffLL && nT * L.n_waves > 1) {
@@ -1144,6 +1167,27 @@ int copy_out_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* dest_id
 // on the host), so nothing is assumed about which elements a parameter moves; the price is that no state is shared
 // with the base pass -- each (task, model set) pair is a full probability walk (chain kernel at D <= 16, row-per-lane
 // kernel at D = 64).  Model sets are processed in chunks that bound the scratch (probability vectors) to 2 GB.
+// `nm` model sets resident in d_mm_models ([gates_t | rhos | effects] each): one independent probability walk per (walk
+// program, set) into d_mm_raw, then columns m0 .. m0 + nm (or d_dest) of d_out = (p_set - p_base) / eps.
+int run_models_chunk(gst_plan* p, int64_t nm, int64_t m0, const double* d_base, double* d_out, int64_t ld, const int32_t* d_dest, double eps)
+{
+    const gst::HostPlan& h = p->hp;
+    const int D = h.D;
+    const int64_t nE = h.n_elements, nT = h.n_tasks();
+    const size_t ng = (size_t)h.n_gates * D * D, nr = (size_t)h.n_rhos * D, ne = (size_t)h.n_effects * D;
+    gst::WalkArgs w;
+    base_args(p, w);
+    w.gates = nullptr;
+    w.gates_t = p->d_mm_models.p; w.rhos = p->d_mm_models.p + ng; w.effects = p->d_mm_models.p + ng + nr;
+    w.n_models = (int32_t)nm; w.model_stride = (int64_t)(ng + nr + ne); w.out_model_stride = nE; w.mm_tasks = (int32_t)nT;
+    w.n_pwaves = (int32_t)nm;
+    w.mode = gst::EMIT_PROBS; w.rows_S = 0; w.out = p->d_mm_raw.p;
+    HIP_TRY(gst::launch_walk_rows(D, w, nT, h.max_slots, p->stream));
+    HIP_TRY(gst::launch_fd_from_models(p->d_mm_raw.p, nE, d_base, nE, (int32_t)nm, d_dest, (int32_t)m0, eps, d_out, ld, p->stream));
+    p->last_launches += 2;
+    return GST_OK;
+}
+
 int run_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, const double* rhos, const double* effects,
                       double* d_out, int64_t ld, const int64_t* dest_idx, double eps, double* d_probs_out)
 {
@@ -1186,18 +1230,242 @@ int run_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, const 
             std::memcpy(dst + ng + nr, effects + (size_t)(m0 + m) * ne, ne * 8);
         }
         HIP_TRY(hipMemcpyAsync(p->d_mm_models.p, stage.data(), (size_t)nm * stride * 8, hipMemcpyHostToDevice, p->stream));
-        gst::WalkArgs w;
-        base_args(p, w);
-        w.gates = nullptr;
-        w.gates_t = p->d_mm_models.p; w.rhos = p->d_mm_models.p + ng; w.effects = p->d_mm_models.p + ng + nr;
-        w.n_models = (int32_t)nm; w.model_stride = (int64_t)stride; w.out_model_stride = nE; w.mm_tasks = (int32_t)nT;
-        w.n_pwaves = (int32_t)nm;
-        w.mode = gst::EMIT_PROBS; w.rows_S = 0; w.out = p->d_mm_raw.p;
-        HIP_TRY(gst::launch_walk_rows(D, w, nT, h.max_slots, p->stream));
-        HIP_TRY(gst::launch_fd_from_models(p->d_mm_raw.p, nE, d_base, nE, (int32_t)nm, dest_idx ? p->d_mm_dest.p + m0 : nullptr,
-                                           (int32_t)m0, eps, d_out, ld, p->stream));
-        p->last_launches += 2;
+        if ((rc = run_models_chunk(p, nm, m0, d_base, d_out, ld, dest_idx ? p->d_mm_dest.p + m0 : nullptr, eps))) return rc;
         HIP_TRY(hipStreamSynchronize(p->stream));          // the staging vector is refilled by the next chunk
+    }
+    TIME_REC(p, evk1);
+    return GST_OK;
+}
+
+// ---- Lindblad-parameterised members (gst_set_lindblad) -------------------------------------------------------------------
+size_t lb_set_stride(const gst_plan* p)
+{
+    const int D = p->hp.D;
+    return (size_t)p->hp.n_gates * D * D + (size_t)p->hp.n_rhos * D + (size_t)p->hp.n_effects * D;
+}
+
+int lb_upload(gst_plan* p)
+{
+    gst_plan::Lindblad& L = p->lb;
+    if (L.uploaded) return GST_OK;
+    std::vector<int32_t> i32;
+    for (const auto* v : {&L.kind, &L.obj, &L.n_eff, &L.n_par, &L.n_blocks, &L.blk_type, &L.blk_mode, &L.blk_n}) i32.insert(i32.end(), v->begin(), v->end());
+    std::vector<int64_t> i64;
+    for (const auto* v : {&L.param0, &L.term_off, &L.static_off}) i64.insert(i64.end(), v->begin(), v->end());
+    int rc;
+    if ((rc = upload_i32(p->d_lb_i32, i32, p->stream))) return rc;
+    HIP_TRY(p->d_lb_i64.ensure(i64.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_lb_i64.p, i64.data(), i64.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p->d_lb_statics.ensure(L.statics.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_lb_statics.p, L.statics.data(), L.statics.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p->d_lb_term_re.ensure(L.term_re.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_lb_term_re.p, L.term_re.data(), L.term_re.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p->d_lb_term_im.ensure(L.term_im.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_lb_term_im.p, L.term_im.data(), L.term_im.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p->d_lb_theta.ensure((size_t)std::max(L.n_params, 1)));
+    HIP_TRY(p->d_lb_base.ensure(lb_set_stride(p)));
+    HIP_TRY(p->d_lb_gates_rm.ensure(std::max<size_t>((size_t)p->hp.n_gates * p->hp.D * p->hp.D, 1)));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    L.uploaded = true;
+    return GST_OK;
+}
+
+void lb_args(gst_plan* p, gst::LbArgs& a)
+{
+    const gst_plan::Lindblad& L = p->lb;
+    std::memset(&a, 0, sizeof(a));
+    const size_t nm = (size_t)L.n_members;
+    a.n_members = L.n_members; a.n_gates = p->hp.n_gates; a.n_rhos = p->hp.n_rhos; a.n_effects = p->hp.n_effects;
+    const int32_t* i = p->d_lb_i32.p;
+    a.kind = i; a.obj = i + nm; a.n_eff = i + 2 * nm; a.n_params = i + 3 * nm; a.n_blocks = i + 4 * nm;
+    a.blk_type = i + 5 * nm; a.blk_mode = a.blk_type + nm * gst::LB_MAX_BLOCKS; a.blk_n = a.blk_mode + nm * gst::LB_MAX_BLOCKS;
+    const int64_t* l = p->d_lb_i64.p;
+    a.param0 = l; a.term_off = l + nm; a.static_off = l + 2 * nm;
+    a.theta = p->d_lb_theta.p; a.term_re = p->d_lb_term_re.p; a.term_im = p->d_lb_term_im.p; a.statics = p->d_lb_statics.p;
+    a.base_set = p->d_lb_base.p;
+    a.set_stride = (int64_t)lb_set_stride(p);
+}
+
+// FD Jacobian columns of a Lindblad-parameterised model WITH state sharing (gst_kernels_pert.hip): the device builds the
+// one changed member of every column; the base pass fills the state cache; every (task, member) pair whose dirty program
+// is not empty is walked for 64/D columns per wavefront; POVM columns come from the circuits' final base states; every
+// entry no walk reaches is an exact zero, written by one streaming pass.
+int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
+                               int64_t n_param, double eps, double* d_probs_out)
+{
+    const gst::HostPlan& h = p->hp;
+    const int D = h.D, G = 64 / D;
+    const gst_plan::Lindblad& L = p->lb;
+    double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
+    int rc = run_probs(p, d_base, n_param > 0);
+    if (rc || n_param == 0) return rc;
+    const int64_t nT = h.n_tasks();
+    if (!p->dirty_ready) {
+        gst::build_dirty_programs(h, p->dirty);
+        HIP_TRY(p->d_dirty_words.ensure(p->dirty.words.size() + 64));
+        HIP_TRY(hipMemsetAsync(p->d_dirty_words.p, 0, (p->dirty.words.size() + 64) * 4, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_dirty_words.p, p->dirty.words.data(), p->dirty.words.size() * 4, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(p->d_dirty_off.ensure(p->dirty.off.size()));
+        HIP_TRY(hipMemcpyAsync(p->d_dirty_off.p, p->dirty.off.data(), p->dirty.off.size() * 8, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        p->dirty_ready = true;
+    }
+    if (!p->leaf_uploaded) {
+        if ((rc = upload_i32(p->d_circ_leaf, h.circ_leaf, p->stream))) return rc;
+        p->leaf_uploaded = true;
+    }
+    if (!p->request_cached(5, param_idx, dest_idx, n_param)) {
+        p->cached_kind = 0;
+        // columns grouped by member, G per wavefront
+        std::vector<std::vector<int64_t>> by_member((size_t)L.n_members);
+        for (int64_t c = 0; c < n_param; c++) {
+            const int64_t gp = param_idx[c];
+            int m = -1;
+            for (int mm = 0; mm < L.n_members; mm++)
+                if (gp >= L.param0[(size_t)mm] && gp < L.param0[(size_t)mm] + L.n_par[(size_t)mm]) m = mm;
+            if (m < 0) return fail(GST_EINVAL, "parameter " + std::to_string(gp) + " belongs to no Lindblad member");
+            const int64_t dst = dest_idx ? dest_idx[c] : c;
+            if (dst < 0 || dst >= ld) return fail(GST_EINVAL, "destination column out of range");
+            by_member[(size_t)m].push_back(c);
+        }
+        std::vector<int64_t> set_param;
+        std::vector<int32_t> wk, wo, wn, w0, wc, cdest, zero_dest;
+        p->lb_povm_cols.clear();
+        for (int m = 0; m < L.n_members; m++) {
+            const auto& cols = by_member[(size_t)m];
+            if (cols.empty()) continue;
+            const bool povm = L.kind[(size_t)m] == GST_KIND_EFFECT;
+            if (povm) {
+                p->lb_povm_cols.push_back(L.obj[(size_t)m]); p->lb_povm_cols.push_back(L.n_eff[(size_t)m]);
+                p->lb_povm_cols.push_back((int32_t)set_param.size()); p->lb_povm_cols.push_back((int32_t)cols.size());
+            }
+            for (size_t k = 0; k < cols.size(); k += (size_t)G) {
+                const size_t n = std::min<size_t>((size_t)G, cols.size() - k);
+                if (!povm) {
+                    wk.push_back(L.kind[(size_t)m]); wo.push_back(L.obj[(size_t)m]); wn.push_back(L.n_eff[(size_t)m]);
+                    w0.push_back((int32_t)set_param.size()); wc.push_back((int32_t)n);
+                }
+                for (size_t q = 0; q < n; q++) {
+                    const int64_t c = cols[k + q];
+                    set_param.push_back(param_idx[c]);
+                    const int32_t dst = (int32_t)(dest_idx ? dest_idx[c] : c);
+                    cdest.push_back(dst);
+                    if (!povm) zero_dest.push_back(dst);
+                }
+            }
+        }
+        std::sort(zero_dest.begin(), zero_dest.end());
+        const int32_t n_pw = (int32_t)wk.size();
+        // wave tables: kind | obj | n_eff | col0 | ncols (n_pw each), then col_dest (n_param), then the zero-fill list
+        std::vector<int32_t> tab;
+        for (const auto* v : {&wk, &wo, &wn, &w0, &wc, &cdest, &zero_dest}) tab.insert(tab.end(), v->begin(), v->end());
+        if ((rc = upload_i32(p->d_lb_waves, tab, p->stream))) return rc;
+        p->lb_n_zero = (int32_t)zero_dest.size();
+        HIP_TRY(p->d_lb_setparam.ensure(set_param.size()));
+        HIP_TRY(hipMemcpyAsync(p->d_lb_setparam.p, set_param.data(), set_param.size() * 8, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(p->d_lb_pert.ensure((size_t)n_param * D * D));
+        // work items: (dirty program of (task, the wavefront's class), wavefront), expensive first; empty programs -- the task
+        // never shows the member to an outcome -- are no items at all
+        const int nC = p->dirty.n_classes;
+        std::vector<std::pair<int64_t, std::pair<uint32_t, int32_t>>> items;
+        items.reserve((size_t)nT * std::max(n_pw, 1));
+        for (int64_t t = 0; t < nT; t++)
+            for (int32_t w = 0; w < n_pw; w++) {
+                const int cls = wk[(size_t)w] == GST_KIND_GATE ? wo[(size_t)w] : h.n_gates + wo[(size_t)w];
+                const size_t pi = (size_t)t * nC + cls;
+                if (p->dirty.off[pi + 1] == p->dirty.off[pi]) continue;
+                items.push_back({-((int64_t)p->dirty.applies[pi] + p->dirty.emits[pi] / 2 + 8), {(uint32_t)pi, w}});
+            }
+        std::stable_sort(items.begin(), items.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        std::vector<uint32_t> iprog(items.size());
+        std::vector<int32_t> ipw(items.size());
+        for (size_t i = 0; i < items.size(); i++) { iprog[i] = items[i].second.first; ipw[i] = items[i].second.second; }
+        HIP_TRY(p->d_block_order.ensure(iprog.size() + 1));
+        if (!iprog.empty()) HIP_TRY(hipMemcpyAsync(p->d_block_order.p, iprog.data(), iprog.size() * 4, hipMemcpyHostToDevice, p->stream));
+        if ((rc = upload_i32(p->d_lb_item_pw, ipw, p->stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(p->stream));          // the host vectors go out of scope
+        p->lb_n_pwaves = n_pw;
+        p->lb_n_items = (int64_t)items.size();
+        p->remember_request(5, param_idx, dest_idx, n_param);
+    }
+    // the changed member of every column
+    gst::LbArgs b;
+    lb_args(p, b);
+    b.set_param = p->d_lb_setparam.p; b.sets = p->d_lb_pert.p; b.set_stride = (int64_t)D * D; b.member_only = 1; b.eps = eps;
+    HIP_TRY(gst::launch_lindblad_build(D, b, n_param, p->stream));
+    gst::PertArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.prog = p->d_dirty_words.p; a.prog_off = p->d_dirty_off.p;
+    a.item_prog = p->d_block_order.p; a.item_pw = p->d_lb_item_pw.p;
+    a.eff_ptr = p->d_eff_ptr.p; a.eff_label = p->d_eff_label.p; a.eff_dest = p->d_eff_dest.p;
+    a.gates_t = p->d_gates_t.p; a.rhos = p->d_rhos.p; a.effects = p->d_effects.p;
+    a.n_gates = h.n_gates; a.n_effects = h.n_effects;
+    a.base_cache = p->d_base_cache.p; a.pbase = d_base;
+    a.pert = p->d_lb_pert.p; a.pert_stride = (int64_t)D * D;
+    const int32_t npw = p->lb_n_pwaves;
+    const int32_t* t = p->d_lb_waves.p;
+    a.wave_kind = t; a.wave_obj = t + npw; a.wave_neff = t + 2 * npw; a.wave_col0 = t + 3 * npw; a.wave_ncols = t + 4 * npw;
+    a.col_dest = t + 5 * npw;
+    a.n_pwaves = npw;
+    a.out = d_out; a.ld = ld; a.eps = eps;
+    TIME_REC(p, evk0);
+    HIP_TRY(gst::launch_zero_columns(d_out, ld, h.n_elements, a.col_dest + n_param, p->lb_n_zero, -1, p->stream));
+    HIP_TRY(gst::launch_walk_pert(D, a, p->lb_n_items, h.max_slots, p->stream));
+    for (size_t k = 0; k + 3 < p->lb_povm_cols.size(); k += 4)
+        HIP_TRY(gst::launch_effect_columns(D, a, p->d_circ_leaf.p, h.n_circuits, p->lb_povm_cols[k], p->lb_povm_cols[k + 1],
+                                           p->lb_povm_cols[k + 2], p->lb_povm_cols[k + 3], p->stream));
+    TIME_REC(p, evk1);
+    p->last_launches += 3 + (int64_t)p->lb_povm_cols.size() / 4;
+    return GST_OK;
+}
+
+// FD Jacobian columns of a Lindblad-parameterised model: the device builds the dense model after every parameter step
+// (one workgroup per column) and walks every (program, model set) pair; base probabilities from the base model, which
+// gst_set_lindblad_params built.
+int run_dprobs_lindblad(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx, int64_t n_param,
+                        double eps, double* d_probs_out)
+{
+    const gst::HostPlan& h = p->hp;
+    const int64_t nE = h.n_elements, nT = h.n_tasks();
+    if (!p->lb.have_theta) return fail(GST_ESTATE, "gst_set_lindblad_params has not been called");
+    if (!(eps != 0.0)) return fail(GST_EINVAL, "eps must be non-zero");
+    for (int64_t c = 0; c < n_param; c++)
+        if (param_idx[c] < 0 || param_idx[c] >= p->lb.n_params) return fail(GST_EINVAL, "parameter index out of range");
+    if (p->lb_share && gst::pert_kernel_fits(h.D, h.n_gates, h.n_effects, h.max_slots) && h.n_gates <= 64)
+        return run_dprobs_lindblad_shared(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out);
+    p->cached_kind = 0;
+    double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
+    int rc = run_probs(p, d_base, false);
+    if (rc || n_param == 0) return rc;
+    const size_t stride = lb_set_stride(p);
+    int64_t chunk = std::max<int64_t>(1, (int64_t)(2.0e9 / (8.0 * (double)std::max<int64_t>(nE, 1))));
+    chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, 0x7fffffffLL / std::max<int64_t>(nT, 1)));
+    chunk = std::min<int64_t>(chunk, n_param);
+    HIP_TRY(p->d_mm_models.ensure((size_t)chunk * stride));
+    HIP_TRY(p->d_mm_raw.ensure((size_t)chunk * (size_t)std::max<int64_t>(nE, 1)));
+    HIP_TRY(p->d_lb_setparam.ensure((size_t)n_param));
+    HIP_TRY(hipMemcpyAsync(p->d_lb_setparam.p, param_idx, (size_t)n_param * 8, hipMemcpyHostToDevice, p->stream));
+    std::vector<int32_t> dest32;
+    if (dest_idx) {
+        dest32.resize((size_t)n_param);
+        for (int64_t m = 0; m < n_param; m++) {
+            if (dest_idx[m] < 0 || dest_idx[m] >= ld) return fail(GST_EINVAL, "destination column out of range");
+            dest32[(size_t)m] = (int32_t)dest_idx[m];
+        }
+        if ((rc = upload_i32(p->d_mm_dest, dest32, p->stream))) return rc;
+    } else if (n_param > ld) return fail(GST_EINVAL, "more columns than the leading dimension");
+    HIP_TRY(hipStreamSynchronize(p->stream));              // (param_idx / dest32 are the caller's / a local)
+    TIME_REC(p, evk0);
+    for (int64_t m0 = 0; m0 < n_param; m0 += chunk) {
+        const int64_t nm = std::min<int64_t>(chunk, n_param - m0);
+        gst::LbArgs a;
+        lb_args(p, a);
+        a.set_param = p->d_lb_setparam.p + m0;
+        a.sets = p->d_mm_models.p;
+        a.eps = eps;
+        HIP_TRY(gst::launch_lindblad_build(h.D, a, nm, p->stream));
+        p->last_launches++;
+        if ((rc = run_models_chunk(p, nm, m0, d_base, d_out, ld, dest_idx ? p->d_mm_dest.p + m0 : nullptr, eps))) return rc;
     }
     TIME_REC(p, evk1);
     return GST_OK;
@@ -1582,6 +1850,11 @@ int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (rc) return rc;
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!d_out && n_param > 0) return fail(GST_EINVAL, "d_out is NULL");
+    if (p->lb.set && mode == GST_DERIV_FD) {
+        if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
+        if ((rc = run_dprobs_lindblad(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out))) return rc;
+        return end_call(p, false);
+    }
     if (p->derivs_set) {
         if (mode != GST_DERIV_ANALYTIC) return fail(GST_EUNSUPPORTED, "general parameterisations (gst_set_derivs) exist in GST_DERIV_ANALYTIC only");
         if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
@@ -1605,6 +1878,12 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     if (rc) return rc;
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!out && n_param > 0) return fail(GST_EINVAL, "out is NULL");
+    if (p->lb.set && mode == GST_DERIV_FD) {
+        if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
+        HIP_TRY(p->d_out.ensure((size_t)p->hp.n_elements * std::max<int64_t>(n_param, 1)));
+        if ((rc = run_dprobs_lindblad(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr))) return rc;
+        return copy_out_dprobs(p, out, ld, dest_idx, n_param, probs_out);
+    }
     if (p->derivs_set && mode != GST_DERIV_ANALYTIC)
         return fail(GST_EUNSUPPORTED, "general parameterisations (gst_set_derivs) exist in GST_DERIV_ANALYTIC only");
     if (!p->derivs_set && !p->have_pmap) return fail(GST_ESTATE, "gst_set_param_map has not been called");
@@ -2314,6 +2593,150 @@ int gst_get_program(const gst_plan* p, uint32_t* words, int64_t cap, int64_t* n_
     if (words && cap > 0) std::memcpy(words, h.prog.data(), sizeof(uint32_t) * std::min<int64_t>(cap, *n_words));
     if (task_off && cap_tasks >= (int64_t)h.task_off.size())
         std::memcpy(task_off, h.task_off.data(), sizeof(int64_t) * h.task_off.size());
+    return GST_OK;
+    });
+}
+
+int gst_set_lindblad(gst_plan* p, int32_t n_params, int32_t n_members, const gst_lindblad_member* members, int64_t n_terms,
+                     const double* term_re, const double* term_im)
+{
+    return guarded([&]() -> int {
+    if (!p) return fail(GST_EINVAL, "plan is NULL");
+    gst_plan::Lindblad& L = p->lb;
+    if (n_members == 0) { L = gst_plan::Lindblad(); return GST_OK; }
+    const int D = p->hp.D;
+    if (D != 4 && D != 16) return fail(GST_EUNSUPPORTED, "Lindblad members are built on the device for D = 4 and 16");
+    if (n_members < 0 || n_params < 0 || !members || n_terms <= 0 || !term_re || !term_im) return fail(GST_EINVAL, "bad argument");
+    gst_plan::Lindblad N;
+    N.n_params = n_params; N.n_members = n_members;
+    const int nb_max = D - 1;                      // Pauli basis of n qubits without the identity: 4^n - 1 = D - 1
+    std::vector<uint8_t> gate_seen((size_t)p->hp.n_gates, 0), rho_seen((size_t)p->hp.n_rhos, 0), eff_seen((size_t)p->hp.n_effects, 0);
+    for (int32_t m = 0; m < n_members; m++) {
+        const gst_lindblad_member& M = members[m];
+        const std::string who = "member " + std::to_string(m) + ": ";
+        if (!M.static_part) return fail(GST_EINVAL, who + "static_part is NULL");
+        if (M.n_blocks < 1 || M.n_blocks > gst::LB_MAX_BLOCKS) return fail(GST_EINVAL, who + "1.." + std::to_string(gst::LB_MAX_BLOCKS) + " coefficient blocks");
+        int64_t np = 0, nc = 0;
+        for (int b = 0; b < M.n_blocks; b++) {
+            const int bt = M.block_type[b], md = M.block_mode[b], n = M.block_n[b];
+            if (bt < 0 || bt > 2 || md < 0 || md > 1 || n < 1 || n > nb_max) return fail(GST_EINVAL, who + "bad coefficient block");
+            np += bt == 2 ? (int64_t)n * n : n; nc += bt == 2 ? (int64_t)n * n : n;
+        }
+        if (np > gst::lb_max_coeffs(D)) return fail(GST_EUNSUPPORTED, who + "too many parameters for one member");
+        if (M.param0 < 0 || M.param0 + np > n_params) return fail(GST_EINVAL, who + "parameter range outside the model's");
+        if (M.term_offset < 0 || M.term_offset + nc > n_terms) return fail(GST_EINVAL, who + "term range outside the term table");
+        size_t n_static = 0;
+        if (M.kind == GST_KIND_GATE) {
+            if (M.obj < 0 || M.obj >= p->hp.n_gates || gate_seen[(size_t)M.obj]++) return fail(GST_EINVAL, who + "bad or repeated gate index");
+            n_static = (size_t)D * D;
+        } else if (M.kind == GST_KIND_RHO) {
+            if (M.obj < 0 || M.obj >= p->hp.n_rhos || rho_seen[(size_t)M.obj]++) return fail(GST_EINVAL, who + "bad or repeated state index");
+            n_static = (size_t)D;
+        } else if (M.kind == GST_KIND_EFFECT) {
+            if (M.n_eff < 1 || M.obj < 0 || M.obj + M.n_eff > p->hp.n_effects) return fail(GST_EINVAL, who + "bad effect range");
+            for (int e = M.obj; e < M.obj + M.n_eff; e++) if (eff_seen[(size_t)e]++) return fail(GST_EINVAL, who + "effect listed twice");
+            n_static = (size_t)M.n_eff * D;
+        } else return fail(GST_EINVAL, who + "unknown kind");
+        N.kind.push_back(M.kind); N.obj.push_back(M.obj); N.n_eff.push_back(M.kind == GST_KIND_EFFECT ? M.n_eff : 1);
+        N.n_par.push_back((int32_t)np); N.n_blocks.push_back(M.n_blocks);
+        N.param0.push_back(M.param0); N.term_off.push_back(M.term_offset); N.static_off.push_back((int64_t)N.statics.size());
+        N.statics.insert(N.statics.end(), M.static_part, M.static_part + n_static);
+    }
+    // every object of the plan must belong to a member: the device builds the WHOLE model
+    for (uint8_t v : gate_seen) if (!v) return fail(GST_EINVAL, "a gate of the plan belongs to no Lindblad member");
+    for (uint8_t v : rho_seen) if (!v) return fail(GST_EINVAL, "a state preparation of the plan belongs to no Lindblad member");
+    for (uint8_t v : eff_seen) if (!v) return fail(GST_EINVAL, "an effect of the plan belongs to no Lindblad member");
+    N.blk_type.assign((size_t)n_members * gst::LB_MAX_BLOCKS, 0); N.blk_mode = N.blk_type; N.blk_n = N.blk_type;
+    for (int32_t m = 0; m < n_members; m++)
+        for (int b = 0; b < members[m].n_blocks; b++) {
+            N.blk_type[(size_t)m * gst::LB_MAX_BLOCKS + b] = members[m].block_type[b];
+            N.blk_mode[(size_t)m * gst::LB_MAX_BLOCKS + b] = members[m].block_mode[b];
+            N.blk_n[(size_t)m * gst::LB_MAX_BLOCKS + b] = members[m].block_n[b];
+        }
+    N.term_re.assign(term_re, term_re + (size_t)n_terms * D * D);
+    N.term_im.assign(term_im, term_im + (size_t)n_terms * D * D);
+    N.set = true;
+    L = std::move(N);
+    return GST_OK;
+    });
+}
+
+int gst_set_lindblad_params(gst_plan* p, const double* theta)
+{
+    return guarded([&]() -> int {
+    if (!p || !theta) return fail(GST_EINVAL, "NULL argument");
+    if (!p->lb.set) return fail(GST_ESTATE, "gst_set_lindblad has not been called");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    if ((rc = lb_upload(p))) return rc;
+    gst_plan::Lindblad& L = p->lb;
+    L.theta.assign(theta, theta + L.n_params);
+    HIP_TRY(hipMemcpyAsync(p->d_lb_theta.p, L.theta.data(), (size_t)L.n_params * 8, hipMemcpyHostToDevice, p->stream));
+    gst::LbArgs a;
+    lb_args(p, a);
+    a.set_param = nullptr; a.sets = p->d_lb_base.p; a.gates_rowmajor = p->d_lb_gates_rm.p; a.eps = 0.0;
+    HIP_TRY(gst::launch_lindblad_build(p->hp.D, a, L.n_members, p->stream));
+    // the base model also becomes the plan's model (what gst_set_model would have been given): 13 KB back over PCIe
+    const int D = p->hp.D;
+    const size_t ng = (size_t)p->hp.n_gates * D * D, nr = (size_t)p->hp.n_rhos * D, ne = (size_t)p->hp.n_effects * D;
+    std::vector<double> set(ng + nr + ne);
+    p->h_gates.resize(ng);
+    HIP_TRY(hipMemcpyAsync(set.data(), p->d_lb_base.p, set.size() * 8, hipMemcpyDeviceToHost, p->stream));
+    if (ng) HIP_TRY(hipMemcpyAsync(p->h_gates.data(), p->d_lb_gates_rm.p, ng * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->h_gates_t.assign(set.begin(), set.begin() + (long)ng);
+    p->h_rhos.assign(set.begin() + (long)ng, set.begin() + (long)(ng + nr));
+    p->h_effects.assign(set.begin() + (long)(ng + nr), set.end());
+    p->have_model = true;
+    p->model_dirty = true;
+    L.have_theta = true;
+    return GST_OK;
+    });
+}
+
+int gst_get_model(gst_plan* p, double* gates, double* rhos, double* effects)
+{
+    return guarded([&]() -> int {
+    if (!p) return fail(GST_EINVAL, "plan is NULL");
+    if (!p->have_model) return fail(GST_ESTATE, "no model has been set");
+    if (gates) std::memcpy(gates, p->h_gates.data(), p->h_gates.size() * 8);
+    if (rhos) std::memcpy(rhos, p->h_rhos.data(), p->h_rhos.size() * 8);
+    if (effects) std::memcpy(effects, p->h_effects.data(), p->h_effects.size() * 8);
+    return GST_OK;
+    });
+}
+
+int gst_get_lindblad_model_sets(gst_plan* p, const int64_t* param_idx, int64_t n_param, double eps, double* gates, double* rhos, double* effects)
+{
+    return guarded([&]() -> int {
+    if (!p || n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad argument");
+    if (!p->lb.set || !p->lb.have_theta) return fail(GST_ESTATE, "gst_set_lindblad / gst_set_lindblad_params have not been called");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    for (int64_t c = 0; c < n_param; c++)
+        if (param_idx[c] < 0 || param_idx[c] >= p->lb.n_params) return fail(GST_EINVAL, "parameter index out of range");
+    if (n_param == 0) return GST_OK;
+    const int D = p->hp.D;
+    const size_t ng = (size_t)p->hp.n_gates * D * D, nr = (size_t)p->hp.n_rhos * D, ne = (size_t)p->hp.n_effects * D, stride = ng + nr + ne;
+    HIP_TRY(p->d_mm_models.ensure((size_t)n_param * stride));
+    HIP_TRY(p->d_lb_setparam.ensure((size_t)n_param));
+    HIP_TRY(hipMemcpyAsync(p->d_lb_setparam.p, param_idx, (size_t)n_param * 8, hipMemcpyHostToDevice, p->stream));
+    gst::LbArgs a;
+    lb_args(p, a);
+    a.set_param = p->d_lb_setparam.p; a.sets = p->d_mm_models.p; a.eps = eps;
+    HIP_TRY(gst::launch_lindblad_build(D, a, n_param, p->stream));
+    std::vector<double> h((size_t)n_param * stride);
+    HIP_TRY(hipMemcpyAsync(h.data(), p->d_mm_models.p, h.size() * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int64_t m = 0; m < n_param; m++) {
+        const double* s = h.data() + (size_t)m * stride;
+        if (gates)
+            for (int g = 0; g < p->hp.n_gates; g++)
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++) gates[(size_t)m * ng + ((size_t)g * D + i) * D + j] = s[((size_t)g * D + j) * D + i];
+        if (rhos) std::memcpy(rhos + (size_t)m * nr, s + ng, nr * 8);
+        if (effects) std::memcpy(effects + (size_t)m * ne, s + ng + nr, ne * 8);
+    }
     return GST_OK;
     });
 }

@@ -261,6 +261,61 @@ struct EffectFDArgs {
 };
 hipError_t launch_effect_fd(const EffectFDArgs& a, hipStream_t stream);
 
+// Dense members from Lindblad parameters (gst_kernels_lindblad.hip): member m = (static factor) composed with
+// exp(L_m), L_m = sum_k Re(c_k) term_re[term_off[m] + k] + Im(c_k) term_im[...], c = the member's coefficient blocks
+// evaluated at theta[param0[m] .. + n_params[m]).  Block types 0 'ham', 1 'other_diagonal', 2 'other'; modes 0 'elements',
+// 1 'cholesky' (lindbladcoefficients.py).  set_param == NULL: workgroup m builds member m into `sets` (the base model,
+// one set); otherwise workgroup s builds set s = the base model with parameter set_param[s] stepped by eps.
+// A set is [gates_t (n_gates D D) | rhos (n_rhos D) | effects (n_effects D)], set_stride doubles apart.
+constexpr int LB_MAX_BLOCKS = 4;
+constexpr int lb_max_coeffs(int D) { return LB_MAX_BLOCKS * (D - 1) * (D - 1); }   // basis size of n qubits: 4^n - 1 = D - 1
+struct LbArgs {
+    int32_t n_members, n_gates, n_rhos, n_effects;
+    const int32_t *kind, *obj, *n_eff, *n_params, *n_blocks, *blk_type, *blk_mode, *blk_n;   // blk_*: [n_members][LB_MAX_BLOCKS]
+    const int64_t *param0, *term_off, *static_off;
+    const double *theta, *term_re, *term_im, *statics;
+    const double* base_set;        // the base model in set layout (set_param != NULL)
+    const int64_t* set_param;      // [n_sets] global parameter stepped in each set, or NULL (base build)
+    double* sets;
+    int64_t set_stride;
+    double* gates_rowmajor;        // base build only (may be NULL): gates[n_gates][D][D] row-major as well
+    double eps;
+    int32_t member_only;           // set_param != NULL: write ONLY the changed member, at the start of its set (gate: transposed
+                                   // [D][D]; state [D]; POVM [n_eff][D]) -- what walk_pert_kernel reads; no copy of the base model
+};
+hipError_t launch_lindblad_build(int D, const LbArgs& a, int64_t n_sets, hipStream_t stream);
+
+// Finite-difference walks for columns that change a whole object (gst_kernels_pert.hip): a work item is a task's dirty
+// program for the member's class walked for the 64/D columns col0 .. col0 + ncols of ONE member (kind / obj / n_eff of
+// parameter wavefront pw); column c's changed member sits at pert + c * pert_stride (layout as LbArgs::member_only), its
+// Jacobian column is col_dest[c].
+struct PertArgs {
+    const uint32_t* prog;                          // the DIRTY programs (gst::build_dirty_programs), concatenated
+    const int64_t* prog_off;                       // [n_tasks * n_classes + 1]
+    const uint32_t* item_prog;                     // [n_items] work item -> program index (task * n_classes + class), expensive first
+    const int32_t* item_pw;                        // [n_items] work item -> parameter wavefront
+    const int32_t *eff_ptr, *eff_label, *eff_dest;
+    const double *gates_t, *rhos, *effects;       // the base model
+    int32_t n_gates, n_effects;
+    const double* base_cache;                      // states of the base pass
+    const double* pbase;                           // base probabilities
+    const double* pert;
+    int64_t pert_stride;
+    const int32_t *wave_kind, *wave_obj, *wave_neff, *wave_col0, *wave_ncols;   // [n_pwaves]
+    const int32_t* col_dest;
+    int32_t n_pwaves;
+    double* out;
+    int64_t ld;
+    double eps;
+};
+bool pert_kernel_fits(int D, int n_gates, int n_effects, int n_slots);
+hipError_t launch_walk_pert(int D, const PertArgs& a, int64_t n_items, int n_slots, hipStream_t stream);
+// out[e * ld + (dense0 >= 0 ? dense0 + c : col_dest[c])] = 0 for e < nE, c < n_cols
+hipError_t launch_zero_columns(double* out, int64_t ld, int64_t nE, const int32_t* col_dest, int32_t n_cols, int32_t dense0, hipStream_t stream);
+// the columns col0 .. col0 + ncols of ONE POVM member (effects obj .. obj + n_eff), from the circuits' final base states
+hipError_t launch_effect_columns(int D, const PertArgs& a, const int32_t* circ_leaf, int64_t n_circuits, int32_t obj, int32_t n_eff,
+                                 int32_t col0, int32_t ncols, hipStream_t stream);
+
 // Persistent form of the D <= 16 FD walk: n_wg workgroups of 16 wavefronts (see WalkArgs::bin_ptr)
 // a.ovl_n_tasks > 0 selects the overlap form (D = 16): LDS = wavefronts' save slots + chains_per_wg chain regions
 hipError_t launch_walk_persistent(int D, const WalkArgs& a, int n_wg, int n_slots, hipStream_t stream);

@@ -396,6 +396,61 @@ void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost)
     }
 }
 
+void build_dirty_programs(const HostPlan& P, DirtyPrograms& out)
+{
+    const int nG = P.n_gates, nR = P.n_rhos, nC = nG + nR;
+    const int64_t nT = P.n_tasks();
+    out.n_classes = nC;
+    out.words.clear();
+    out.off.assign((size_t)nT * nC + 1, 0);
+    out.applies.assign((size_t)nT * nC, 0);
+    out.emits.assign((size_t)nT * nC, 0);
+    std::vector<int32_t> tag;
+    for (int64_t t = 0; t < nT; t++) {
+        for (int c = 0; c < nC; c++) {
+            const bool is_rho = c >= nG;
+            const uint32_t obj = (uint32_t)(is_rho ? c - nG : c);
+            const size_t start = out.words.size();
+            bool dirty = false;
+            int32_t cur_id = 0;
+            int32_t n_app = 0, n_emit = 0;
+            tag.assign(64, -1);
+            for (int64_t k = P.task_off[t]; k < P.task_off[t + 1]; k++) {
+                const uint32_t w = P.prog[k], op = GST_OP(w), arg = GST_ARG(w);
+                if (op == GST_OP_RHO) {
+                    if (is_rho && arg == obj) { out.words.push_back(w); dirty = true; }
+                    else dirty = false;
+                } else if (op == GST_OP_NODE) {
+                    cur_id = (int32_t)arg;
+                } else if (op == GST_OP_APPLY) {
+                    if (!dirty && !is_rho && arg == obj) {
+                        out.words.push_back((GST_OP_CACHE << 28) | (uint32_t)cur_id);      // start from the base pass's state
+                        dirty = true;
+                    }
+                    if (dirty) { out.words.push_back(w); n_app++; }
+                } else if (op == GST_OP_SAVE) {
+                    if (arg < 64) {
+                        if (dirty) { out.words.push_back(w); tag[arg] = -1; }
+                        else tag[arg] = cur_id;
+                    }
+                } else if (op == GST_OP_LOAD) {
+                    if (arg < 64) {
+                        if (tag[arg] >= 0) { dirty = false; cur_id = tag[arg]; }
+                        else { out.words.push_back(w); dirty = true; }
+                    }
+                } else if (op == GST_OP_EMIT) {
+                    if (dirty) { out.words.push_back(w); n_emit++; }
+                }
+            }
+            if (n_emit == 0) out.words.resize(start);      // nothing observable changes: no program at all
+            else out.words.push_back(GST_OP_END << 28);
+            out.off[(size_t)t * nC + c + 1] = (int64_t)out.words.size();
+            out.applies[(size_t)t * nC + c] = n_emit ? n_app : 0;
+            out.emits[(size_t)t * nC + c] = n_emit;
+        }
+    }
+}
+
 void task_split_candidates(const HostPlan& P, std::vector<int32_t>& cand_ptr, std::vector<int32_t>& cand_pc, std::vector<float>& cand_frac,
                            int max_per_task, std::vector<uint32_t>* cand_live)
 {

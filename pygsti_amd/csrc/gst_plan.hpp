@@ -69,6 +69,21 @@ void task_split_points(const HostPlan& P, std::vector<int32_t>& split_pc, std::v
 // live, the 64 lane states are the walk's entire state -- between 10 % and 90 % of its gate applications, thinned to
 // max_per_task evenly spaced ones: cand_pc[cand_ptr[t] .. cand_ptr[t + 1]) (word index relative to the task start,
 // ascending) with cand_frac = fraction of the task's gate applications in front of it.
+// "Dirty programs" (finite differences over whole-object perturbations, gst_kernels_pert.hip): for every task and every
+// object class c -- gate c for c < n_gates, state preparation c - n_gates after that -- the walk program with everything
+// removed that is bit-identical to the base pass when ONLY that object is perturbed.  What remains starts each perturbed
+// excursion with `CACHE id` (v <- state `id` of the base pass, GST_OP_CACHE) or the perturbed `RHO`, then APPLY / SAVE /
+// LOAD / EMIT as in the task's program (no NODE markers: nothing is cached); EMITs reached in a clean state are dropped
+// (their Jacobian entries are exact zeros).  Program of (task t, class c): words[off[t * n_classes + c] .. off[.. + 1]),
+// empty when the task never shows the object to an outcome.  applies / emits: its gate applications / EMITs.
+struct DirtyPrograms {
+    int32_t n_classes = 0;
+    std::vector<uint32_t> words;
+    std::vector<int64_t> off;
+    std::vector<int32_t> applies, emits;
+};
+void build_dirty_programs(const HostPlan& P, DirtyPrograms& out);
+
 // Per-SIMD queues of the persistent FD launch.  `items` = (-estimated cost, pair id = task * n_units + unit), longest
 // first.  Longest-processing-time packing into n_bins queues, then HAND-OVERS: a walk of a queue above the mean is cut
 // at the slot-free position (task_split_candidates) that brings its queue down to the mean; the first part stays at the

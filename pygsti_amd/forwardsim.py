@@ -119,6 +119,18 @@ class HipMapForwardSimulator:
     def _prepare_atom(self, layout_atom):
         plan = layout_atom.plan()
         L = layout_atom.layout
+        if hasattr(self.model, "lindblad_description"):
+            # Lindblad-parameterised model (CPTPLND, GLND, H+S: pygsti_amd.lindblad): the DEVICE builds the dense members
+            # from the parameter vector, for the base model and for every finite-difference step (gst_set_lindblad)
+            desc = self.model.lindblad_description(L.model_gate_labels, L.effect_labels)
+            if getattr(plan, "_lb_desc", None) is not desc:
+                plan.set_lindblad(desc)
+                plan._lb_desc = desc
+            plan.set_lindblad_params(self.model.to_vector())
+            return plan
+        if getattr(plan, "_lb_desc", None) is not None:
+            plan.set_lindblad(None)
+            plan._lb_desc = None
         plan.set_model(*L.model_arrays(self.model))
         if plan.n_params != self.model.num_params:
             plan.set_param_map(*L.param_map(self.model))

@@ -164,6 +164,67 @@ def atom_model_sets(model, atom, param_indices, eps):
     return G, R, E
 
 
+def atom_lindblad(model, atom):
+    """Describe a model whose every member is (static factor) x exp(Lindblad error generator) -- what
+    `target_model('CPTPLND')` / 'GLND' / 'H+S' build: ComposedOp([static, ExpErrorgenOp(LindbladErrorgen)]),
+    ComposedState(static state, ExpErrorgenOp), ComposedPOVM(ExpErrorgenOp, base POVM) -- for gst_set_lindblad, so that
+    the DEVICE builds the dense members for the base model and for every finite-difference step (no to_dense() per
+    column on the host).  The term superoperators are the reference's own (`combined_lindblad_term_superops`,
+    lindbladerrorgen.py:585-590).  Raises NotImplementedError for anything else (the caller then steps the model on the
+    host: atom_model_sets)."""
+    from . import lindblad as LBM
+    D = model.dim
+    if D not in (4, 16):
+        raise NotImplementedError("Lindblad members are built on the device for one and two qubits")
+    BT = {"ham": LBM.BLOCK_HAM, "other_diagonal": LBM.BLOCK_OTHER_DIAGONAL, "other": LBM.BLOCK_OTHER}
+    MD = {"elements": LBM.MODE_ELEMENTS, "cholesky": LBM.MODE_CHOLESKY}
+
+    def member_of(kind, obj, member, static_dense, expop):
+        if type(expop).__name__ != "ExpErrorgenOp" or type(expop.errorgen).__name__ != "LindbladErrorgen":
+            raise NotImplementedError("not an exponentiated Lindblad error generator")
+        L = expop.errorgen
+        blocks = []
+        for b in L.coefficient_blocks:
+            if b._block_type not in BT or b._param_mode not in MD:
+                raise NotImplementedError("coefficient block %s/%s" % (b._block_type, b._param_mode))
+            blocks.append((BT[b._block_type], MD[b._param_mode], len(b._bel_labels)))
+        gp = np.asarray(member.gpindices_as_array())
+        if len(gp) == 0 or not np.array_equal(gp, np.arange(gp[0], gp[0] + len(gp))) or len(gp) != L.num_params:
+            raise NotImplementedError("a member's parameters are not one contiguous slice of the model's")
+        terms = L.combined_lindblad_term_superops
+        if not isinstance(terms, np.ndarray) or terms.shape[1:] != (D, D):
+            raise NotImplementedError("sparse Lindblad term superoperators")
+        return LBM.LindbladMember.from_terms(kind, obj, int(gp[0]), blocks, static_dense, terms)
+
+    def static_dense(obj, shape):
+        if obj.num_params != 0:
+            raise NotImplementedError("the static factor has parameters")
+        return np.ascontiguousarray(np.real(obj.to_dense("HilbertSchmidt")), dtype=np.float64).reshape(shape)
+
+    members = []
+    for oi, lbl in enumerate(atom.op_labels):
+        m = model._circuit_layer_operator(lbl, "op")
+        f = getattr(m, "factorops", None)
+        if type(m).__name__ != "ComposedOp" or f is None or len(f) != 2:
+            raise NotImplementedError("operation %s is not ComposedOp([static, ExpErrorgenOp])" % str(lbl))
+        members.append(member_of(LBM.KIND_GATE, oi, m, static_dense(f[0], (D, D)), f[1]))
+    for oi, lbl in enumerate(atom.rho_labels):
+        m = model._circuit_layer_operator(lbl, "prep")
+        if type(m).__name__ != "ComposedState":
+            raise NotImplementedError("preparation %s is not a ComposedState" % str(lbl))
+        members.append(member_of(LBM.KIND_RHO, oi, m, static_dense(m.state_vec, (D,)), m.error_map))
+    eff_labels = atom._hip_eff_labels
+    povm_names = {str(l).split("_", 1)[0] for l in eff_labels}
+    if len(povm_names) != 1:
+        raise NotImplementedError("effects of several POVMs in one atom")
+    povm = model.povms[povm_names.pop()]
+    if type(povm).__name__ != "ComposedPOVM":
+        raise NotImplementedError("the POVM is not a ComposedPOVM")
+    base = np.array([static_dense(povm.base_povm[str(l).split("_", 1)[1]], (D,)) for l in eff_labels])
+    members.append(member_of(LBM.KIND_POVM, 0, povm, base, povm.error_map))
+    return LBM.LindbladModel(members, model.num_params, len(atom.op_labels), len(atom.rho_labels), len(eff_labels))
+
+
 def atom_derivs(model, atom):
     """[(kind, object, gpindices, deriv_wrt_params [n_elem, n])] of every member the atom uses -- the input of
     gst_set_derivs for parameterisations that are not one-parameter-per-element (TP, CPTP, ...), exactly what
@@ -240,7 +301,7 @@ class HipMapForwardSimulator(_MapForwardSimulator):
     to <= 1e-8), several times faster, and exact Hessian blocks."""
 
     def __init__(self, model=None, max_cache_size=None, num_atoms=None, processor_grid=None, param_blk_sizes=None,
-                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1, derivative_mode="fd"):
+                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1, derivative_mode="fd", lindblad_on_device=True):
         if not HAVE_PYGSTI:
             raise ImportError("pygsti is not importable; use pygsti_amd.forwardsim.HipMapForwardSimulator instead")
         if derivative_mode not in ("fd", "analytic"):
@@ -248,11 +309,15 @@ class HipMapForwardSimulator(_MapForwardSimulator):
         super().__init__(model, max_cache_size, num_atoms, processor_grid, param_blk_sizes, derivative_eps, hessian_eps)
         self._hip_device = device
         self.derivative_mode = derivative_mode
+        # Lindblad-parameterised models (CPTPLND, GLND, H+S): True = the device builds the dense members from the
+        # parameter vector for every finite-difference step (gst_set_lindblad); False = the model is stepped on the host
+        # and the device evaluates the dense sets (gst_fill_dprobs_models; the validation path)
+        self.lindblad_on_device = bool(lindblad_on_device)
 
     def copy(self, keep_model_attached=True):
         out = HipMapForwardSimulator(self.model if keep_model_attached else None, self._max_cache_size, self._num_atoms,
                                      self._processor_grid, self._pblk_sizes, self.derivative_eps, self.hessian_eps,
-                                     self._hip_device, self.derivative_mode)
+                                     self._hip_device, self.derivative_mode, self.lindblad_on_device)
         return out
 
     def create_layout(self, circuits, dataset=None, resource_alloc=None, array_types=('E',), derivative_dimensions=None,
@@ -301,6 +366,24 @@ class HipMapForwardSimulator(_MapForwardSimulator):
                     layout_atom._hip_tpmap = None
                 layout_atom._hip_tpmap_model = self.model
             if layout_atom._hip_tpmap is None:
+                # Lindblad-parameterised members (CPTPLND, GLND, H+S): the device builds them from the parameter vector,
+                # for the base model and for every FD step
+                if getattr(layout_atom, "_hip_lb_model", None) is not self.model:
+                    try:
+                        layout_atom._hip_lb = atom_lindblad(self.model, layout_atom)
+                    except NotImplementedError:
+                        layout_atom._hip_lb = None
+                    layout_atom._hip_lb_model = self.model
+                if layout_atom._hip_lb is not None and self.lindblad_on_device:
+                    if getattr(plan, "_hip_mode", None) != "lindblad":
+                        plan.set_derivs(self.model.num_params, [])
+                        plan.set_complement_effect(-1)
+                        plan.set_lindblad(layout_atom._hip_lb)
+                        plan._hip_mode = "lindblad"
+                    plan.set_lindblad_params(self.model.to_vector())      # (replaces the host-densified set_model above)
+                    return plan
+                if getattr(plan, "_hip_mode", None) == "lindblad":
+                    plan.set_lindblad(None)
                 plan._hip_mode = "models"
                 return plan
             k, o, e, comp = layout_atom._hip_tpmap
@@ -368,6 +451,25 @@ class HipMapForwardSimulator(_MapForwardSimulator):
                     array_to_fill[:, i_final, d2] = (dprobs_here() - dprobs) / eps
             finally:
                 self.model.from_vector(orig)
+            return
+        elif hmode == "lindblad":
+            # FD of FD composed as _mapfill_hprobs_atom does (mapforwardsim.py:420-436), every Jacobian from the device's
+            # own model builder: theta + eps e_i is just another parameter vector
+            eps = self.hessian_eps
+            nP = self.model.num_params
+            i1 = np.arange(nP) if param_slice1 is None else _slct.to_array(param_slice1)
+            i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)
+            d1 = np.arange(len(i1)) if dest_param_slice1 is None else _slct.to_array(dest_param_slice1)
+            d2 = np.arange(len(i2)) if dest_param_slice2 is None else _slct.to_array(dest_param_slice2)
+            orig = self.model.to_vector().copy()
+            dprobs = plan.fill_dprobs(param_idx=i2, eps=eps)
+            try:
+                for i, i_final in sorted(zip((int(q) for q in i1), (int(q) for q in d1))):
+                    vec = orig.copy(); vec[i] += eps
+                    plan.set_lindblad_params(vec)
+                    array_to_fill[:, i_final, d2] = (plan.fill_dprobs(param_idx=i2, eps=eps) - dprobs) / eps
+            finally:
+                plan.set_lindblad_params(orig)
             return
         elif hmode != "elements" and not (hmode == "tp-elements" and self.derivative_mode == "fd"):
             raise NotImplementedError("Hessians on the device: fully parameterised models (FD or exact), full-TP models "

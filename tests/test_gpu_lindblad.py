@@ -1,0 +1,152 @@
+"""SURVEY 8(f) row f4 on hardware: Lindblad-parameterised (CPTPLND) models with the dense members built ON THE DEVICE
+(gst_set_lindblad / gst_set_lindblad_params) -- against the reference's vectors of such models
+(tests/golden/smq*_CPTPLND.npz: probabilities and Map-simulator FD columns from the real composed reps; `mm_*`: the
+dense model after every FD step the reference took).  Tolerances as the north star states them: dense members 1e-14,
+probabilities 1e-10, FD dprobs 1e-8."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture, plan_from_fixture
+from pygsti_amd import lindblad as LB
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("smq1Q_XYI_L4_CPTPLND", 1), ("smq2Q_XYICNOT_L1_CPTPLND", 2)]
+
+
+def _plan(name, nq):
+    fx, lb = load_fixture(name), load_fixture("lindblad_" + name)
+    pl = plan_from_fixture(fx)                  # (sets the fixture's dense model; replaced below by the device-built one)
+    model = LB.LindbladModel.from_fixture(lb, nq)
+    pl.set_lindblad(model)
+    pl.set_lindblad_params(lb["paramvec"])
+    return fx, lb, model, pl
+
+
+@pytest.mark.parametrize("name,nq", CASES)
+def test_device_built_members_match_the_reference(name, nq):
+    fx, lb, model, pl = _plan(name, nq)
+    G, R, E = pl.get_model()
+    assert np.abs(G - fx["gates"]).max() < 1e-14, np.abs(G - fx["gates"]).max()
+    assert np.abs(R - fx["rhos"]).max() < 1e-14 and np.abs(E - fx["effects"]).max() < 1e-14
+    cols = fx["dprobs_cols"]
+    Gs, Rs, Es = pl.lindblad_model_sets(cols, float(fx["derivative_eps"]))
+    assert np.abs(Gs - fx["mm_gates"]).max() < 1e-14, np.abs(Gs - fx["mm_gates"]).max()
+    assert np.abs(Rs - fx["mm_rhos"]).max() < 1e-14 and np.abs(Es - fx["mm_effects"]).max() < 1e-14
+    # a second parameter vector: larger error generators (scaling and squaring is exercised: ||L|| > 1/4)
+    th2 = lb["paramvec"] * 40.0
+    pl.set_lindblad_params(th2)
+    G2, R2, E2 = pl.get_model()
+    Gh, Rh, Eh = model.dense(th2)
+    scale = max(1.0, np.abs(Gh).max())
+    assert np.abs(G2 - Gh).max() < 1e-12 * scale and np.abs(R2 - Rh).max() < 1e-12 * scale and np.abs(E2 - Eh).max() < 1e-12 * scale
+
+
+@pytest.mark.parametrize("name,nq", CASES)
+def test_probs_and_fd_dprobs_of_cptplnd_models(name, nq):
+    fx, lb, model, pl = _plan(name, nq)
+    p = pl.fill_probs()
+    assert np.abs(p - fx["probs"]).max() < 1e-10
+    cols = fx["dprobs_cols"]
+    pr = np.full(int(fx["nE"]), np.nan)
+    J = np.full((int(fx["nE"]), len(cols) + 3), np.nan)
+    pl.fill_dprobs(out=J, param_idx=cols, dest_idx=np.arange(len(cols)) + 2, eps=float(fx["derivative_eps"]), probs_out=pr)
+    assert np.isnan(J[:, :2]).all() and np.isnan(J[:, -1]).all()
+    assert np.abs(pr - fx["probs"]).max() < 1e-10
+    err = np.abs(J[:, 2:-1] - fx["dprobs_map"]).max()
+    assert err < 1e-8, err
+    # the host-stepped form of the same walk (gst_fill_dprobs_models on the reference's own dense sets) agrees closely
+    J2 = pl.fill_dprobs_models(fx["mm_gates"], fx["mm_rhos"], fx["mm_effects"], eps=float(fx["derivative_eps"]))
+    assert np.abs(J[:, 2:-1] - J2).max() < 2e-8
+    # device-resident output
+    nE, n = int(fx["nE"]), len(cols)
+    d = pl.device_malloc(nE * n * 8)
+    pl.fill_dprobs_dev(d, n, cols, None, float(fx["derivative_eps"]), None)
+    Jd = np.empty((nE, n)); pl.memcpy_d2h(Jd, d); pl.device_free(d)
+    assert np.array_equal(Jd, J[:, 2:-1])
+
+
+@pytest.mark.parametrize("name,nq", CASES)
+def test_state_sharing_walk_agrees_with_independent_walks(name, nq, monkeypatch):
+    """The two device forms of a Lindblad model's FD Jacobian -- walk_pert_kernel (clean/dirty sharing with the base
+    pass, 64/D columns per wavefront; default) and one independent walk per (program, perturbed model) (GST_LB_SHARE=0)
+    -- use the same perturbed members and the same operation order: they agree to the rounding of (p' - p) / eps, for
+    ragged column subsets, repeated and shuffled columns, a destination window, small and large task counts."""
+    fx, lb = load_fixture(name), load_fixture("lindblad_" + name)
+    model = LB.LindbladModel.from_fixture(lb, nq)
+    nP, nE = model.num_params, int(fx["nE"])
+    rng = np.random.default_rng(11)
+    cols = np.concatenate([np.arange(nP) if nP <= 64 else np.sort(rng.choice(nP, 150, replace=False)), [3, 3, 0]])
+    dest = rng.permutation(len(cols) + 5)[:len(cols)]
+    outs = {}
+    for share in ("1", "0"):
+        monkeypatch.setenv("GST_LB_SHARE", share)
+        for tt in (0, 5):
+            pl = plan_from_fixture(fx, target_tasks=tt)
+            pl.set_lindblad(model); pl.set_lindblad_params(lb["paramvec"])
+            J = np.full((nE, len(cols) + 5), np.nan)
+            pr = np.empty(nE)
+            pl.fill_dprobs(out=J, param_idx=cols, dest_idx=dest, eps=1e-7, probs_out=pr)
+            untouched = np.setdiff1d(np.arange(len(cols) + 5), dest)
+            assert np.isnan(J[:, untouched]).all() and not np.isnan(J[:, dest]).any()
+            assert np.abs(pr - fx["probs"]).max() < 1e-10
+            outs[(share, tt)] = J[:, dest]
+            J_again = np.full_like(J, np.nan)
+            pl.fill_dprobs(out=J_again, param_idx=cols, dest_idx=dest, eps=1e-7)
+            assert np.array_equal(J_again[:, dest], J[:, dest])
+    ref = outs[("0", 0)]
+    for k, v in outs.items():
+        assert np.abs(v - ref).max() < 2e-8, (k, np.abs(v - ref).max())
+    known = np.isin(cols, fx["dprobs_cols"])
+    pos = [int(np.nonzero(fx["dprobs_cols"] == c)[0][0]) for c in cols[known]]
+    assert np.abs(outs[("1", 0)][:, known] - fx["dprobs_map"][:, pos]).max() < 1e-8
+
+
+def test_lindblad_description_is_validated():
+    from pygsti_amd import _lib
+    fx, lb, model, pl = _plan("smq1Q_XYI_L4_CPTPLND", 1)
+    bad = LB.LindbladModel(model.members[:-1], model.num_params, model.n_gates, model.n_rhos, model.n_effects)
+    with pytest.raises(ValueError):
+        pl.set_lindblad(bad)                        # the POVM belongs to no member
+    pl.set_lindblad(None)                           # clears: FD needs a parameter map again
+    pl.set_model(fx["gates"], fx["rhos"], fx["effects"])
+    assert np.abs(pl.fill_probs() - fx["probs"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("param", ["CPTPLND", "GLND", "H+S", "H+s"])
+def test_other_lindblad_parameterisations_through_the_simulator(param):
+    """Every coefficient-block kind ('other' cholesky / elements, 'other_diagonal' cholesky / elements) through the host
+    mirror's API: `LindbladExplicitModel` + `HipMapForwardSimulator.bulk_fill_probs / bulk_fill_dprobs`.  The device-built
+    members equal the host restatement (scipy expm) to 1e-13; the Jacobian equals the one from host-stepped dense model
+    sets (gst_fill_dprobs_models) to FD rounding."""
+    from pygsti_amd import modelpacks as MP
+    from pygsti_amd.forwardsim import HipMapForwardSimulator
+    pack = MP.smq1Q_XYI
+    m = LB.LindbladExplicitModel(pack.target_model(), param)
+    rng = np.random.default_rng(5)
+    th = 0.05 * rng.standard_normal(m.num_params)
+    if param == "H+s":
+        th[3:] = np.abs(th[3:])                     # ('elements' stochastic rates: keep them physical)
+    m.from_vector(th)
+    sim = HipMapForwardSimulator(m, num_atoms=2)
+    circuits = pack.create_gst_circuits(4)
+    lay = sim.create_layout(circuits)
+    nE, nP = lay.num_elements, m.num_params
+    p = np.empty(nE); sim.bulk_fill_probs(p, lay)
+    J = np.empty((nE, nP)); pr = np.empty(nE)
+    sim.bulk_fill_dprobs(J, lay, pr_array_to_fill=pr)
+    assert np.array_equal(p, pr)
+    for atom in lay.atoms:
+        pl = atom.plan()
+        desc = m.lindblad_description(lay.model_gate_labels, lay.effect_labels)
+        G, R, E = pl.get_model()
+        Gh, Rh, Eh = desc.dense(th)
+        assert np.abs(G - Gh).max() < 1e-13 and np.abs(R - Rh).max() < 1e-13 and np.abs(E - Eh).max() < 1e-13
+        Gs, Rs, Es = desc.model_sets(th, np.arange(nP), 1e-7)
+        J2 = pl.fill_dprobs_models(Gs, Rs, Es, eps=1e-7)
+        # (both quotients carry the rounding of their probabilities, ~1e-16 |p| / eps; an unconstrained GLND generator
+        #  is not completely positive, so |p| need not stay below 1)
+        tol = 2e-8 * max(1.0, np.abs(pr).max(), np.abs(J2).max())
+        assert np.abs(J[atom.element_slice] - J2).max() < tol, (np.abs(J[atom.element_slice] - J2).max(), tol)
+    # probabilities of every circuit sum to one (trace preservation of every generator)
+    assert np.abs(p.reshape(-1, 2).sum(1) - 1.0).max() < 1e-11 * max(1.0, np.abs(p).max())

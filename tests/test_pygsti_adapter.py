@@ -130,6 +130,13 @@ def test_adapter_general_parameterisation_fd_model_sets():
     perm = [eff_mine.index(l) for l in eff_ref]              # (set iteration order differs between processes)
     assert [str(l) for l in atom.op_labels] == list(fx["op_labels"])
     assert np.array_equal(G, fx["mm_gates"]) and np.array_equal(R, fx["mm_rhos"]) and np.array_equal(E[:, perm], fx["mm_effects"])
+    # default: the device builds the Lindblad members itself (mode "lindblad": its first step needs the device) ...
+    if _lib.device_count() == 0:
+        with pytest.raises(_lib.GstDeviceError):
+            m.sim._prepare(atom, derivatives=True)
+        assert atom._hip_plan._hip_mode == "lindblad"
+    # ... and the host-stepped validation path on request
+    m.sim.lindblad_on_device = False
     plan = m.sim._prepare(atom, derivatives=True)
     assert plan._hip_mode == "models"
     if _lib.device_count() == 0:
@@ -142,3 +149,52 @@ def test_adapter_general_parameterisation_fd_model_sets():
         with pytest.raises(_lib.GstDeviceError):
             m.sim._bulk_fill_hprobs_atom(H, None, None, atom, np.array([0, 2]), np.array([0, 3, 6]), None)
         assert np.array_equal(m.to_vector(), v0)
+
+
+@pytest.mark.parametrize("param,pack_name", [("CPTPLND", "smq1Q_XYI"), ("GLND", "smq1Q_XYI"), ("H+S", "smq1Q_XYI"), ("CPTPLND", "smq2Q_XYICNOT")])
+def test_adapter_describes_lindblad_models_for_the_device(param, pack_name):
+    """`atom_lindblad`: the members of a CPTPLND / GLND / H+S model as (static factor, coefficient blocks, the reference's
+    own term superoperators) -- what gst_set_lindblad takes.  The host restatement of the device's builder on that
+    description reproduces pyGSTi's dense members, and the dense model after every set_parameter_value step
+    (`atom_model_sets`, the path this description replaces), to 1e-14; a `full` model is refused (it has its own, exact
+    path); the native construction from Pauli matrices gives the same term superoperators."""
+    import importlib
+    from pygsti_amd import lindblad as LBM
+    pack = importlib.import_module("pygsti.modelpacks." + pack_name)
+    model = pack.target_model(param)
+    rng = np.random.default_rng(2)
+    model.from_vector(model.to_vector() + 0.01 * rng.standard_normal(model.num_params))
+    model.sim = A.HipMapForwardSimulator()
+    circuits = list(pack.create_gst_experiment_design(1, lite=True).all_circuits_needing_data) if pack_name.startswith("smq2Q") \
+        else list(pack.create_gst_experiment_design(2).all_circuits_needing_data)
+    layout = model.sim.create_layout(circuits, array_types=("e", "ep"))
+    atom = layout.atoms[0]
+    A.atom_plan(model, atom)
+    lm = A.atom_lindblad(model, atom)
+    assert lm.num_params == model.num_params and len(lm.members) == len(atom.op_labels) + 2
+    th = model.to_vector()
+    G, R, E = lm.dense(th)
+    G0, R0, E0 = A.atom_arrays(model, atom)
+    assert np.abs(G - G0).max() < 1e-14 and np.abs(R - R0).max() < 1e-14 and np.abs(E - E0).max() < 1e-14
+    cols = np.sort(rng.choice(model.num_params, 12, replace=False))
+    Gs, Rs, Es = lm.model_sets(th, cols, 1e-7)
+    Gr, Rr, Er = A.atom_model_sets(model, atom, cols, 1e-7)
+    assert np.abs(Gs - Gr).max() < 1e-14 and np.abs(Rs - Rr).max() < 1e-14 and np.abs(Es - Er).max() < 1e-14
+    assert np.array_equal(model.to_vector(), th)                      # (the model is left where it was)
+    # the same members built from Pauli matrices alone
+    nq = 1 if model.dim == 4 else 2
+    for m in lm.members:
+        native = LBM.LindbladMember(m.kind, m.obj, m.param0, m.blocks, m.static, nq)
+        assert np.abs(native.term_re - m.term_re).max() < 1e-14 and np.abs(native.term_im - m.term_im).max() < 1e-14
+    # the plan takes the description (host side of gst_set_lindblad: validation, term sharing)
+    plan = atom._hip_plan
+    plan.set_lindblad(lm)
+    if _lib.device_count() == 0:
+        with pytest.raises(_lib.GstDeviceError):
+            plan.set_lindblad_params(th)
+    full = pack.target_model()
+    full.sim = A.HipMapForwardSimulator()
+    lay2 = full.sim.create_layout(circuits[:5], array_types=("e",))
+    A.atom_plan(full, lay2.atoms[0])
+    with pytest.raises(NotImplementedError):
+        A.atom_lindblad(full, lay2.atoms[0])

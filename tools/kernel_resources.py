@@ -17,7 +17,7 @@ with tempfile.TemporaryDirectory() as td:
             g = lambda k: (re.search(r"\." + k + r":\s+(\S+)", blk) or [None, "?"])[1]
             name = g("name")
             dem = subprocess.check_output([filt, name]).decode().strip()
-            dem = re.sub(r"^void ", "", dem); dem = re.sub(r"\(.*$", "", dem)
+            dem = re.sub(r"^void ", "", dem).replace("(anonymous namespace)::", ""); dem = re.sub(r"\(.*$", "", dem)
             if pat.search(dem):
                 rows.append((dem, g("vgpr_count"), g("sgpr_count"), g("vgpr_spill_count"), g("sgpr_spill_count"),
                              g("group_segment_fixed_size"), g("private_segment_fixed_size"), g("max_flat_workgroup_size")))
