@@ -192,7 +192,12 @@ int gst_set_derivs(gst_plan *plan, int32_t n_params, int32_t n_objs, const int32
  * device builds the dense model after every step itself -- no host densification and no PCIe traffic per column
  * (gst_fill_dprobs_models is the host-stepped form of the same walk).  Accuracy: the reference propagates through the
  * composed member factor by factor and exponentiates with a Pade approximant; dense members agree to ~1e-16, probabilities
- * to ~1e-15, FD quotients to ~1e-8.  GST_DERIV_ANALYTIC keeps using gst_set_derivs / gst_set_param_map. */
+ * to ~1e-15, FD quotients to ~1e-8.
+ * GST_DERIV_ANALYTIC columns are exact: the device computes every member's d(dense)/d(parameter) itself -- the Frechet
+ * derivative of the exponential in the direction dL/dtheta_p, composed with the static factor: what the reference's
+ * ExpErrorgenOp.deriv_wrt_params() (experrorgenop.py:213-260) hands to MatrixForwardSimulator._doperation -- and applies the
+ * chain rule to the element Jacobian (<= 1e-8 against the Matrix simulator).  (An explicit gst_set_derivs still takes
+ * precedence in that mode; exact Hessian blocks of such models need it, with gst_set_second_derivs.) */
 typedef struct {
     int32_t kind, obj, n_eff, n_blocks;
     int32_t block_type[4], block_mode[4], block_n[4];

@@ -1815,6 +1815,55 @@ int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* pa
     return GST_OK;
 }
 
+// GST_DERIV_ANALYTIC for a Lindblad-parameterised model: the members' d(dense)/d(parameter) matrices are computed ON THE
+// DEVICE (lindblad_deriv_kernel: Frechet derivative of the exponential, composed with the static factor) into the
+// buffers gst_set_derivs would have filled from the host's deriv_wrt_params(), then the ordinary chain rule runs.
+int run_dprobs_lindblad_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
+                                 int64_t n_param, double* d_probs_out)
+{
+    const gst::HostPlan& h = p->hp;
+    const int D = h.D;
+    gst_plan::Lindblad& L = p->lb;
+    if (!L.have_theta) return fail(GST_ESTATE, "gst_set_lindblad_params has not been called");
+    // objects in gst_set_derivs' terms: a gate / preparation member is one object, a POVM member one per effect
+    std::vector<int32_t> kind, obj, ncols;
+    std::vector<int64_t> pidx, member_off((size_t)L.n_members, 0), set_param;
+    int64_t doff = 0;
+    for (int m = 0; m < L.n_members; m++) {
+        const int np = L.n_par[(size_t)m];
+        member_off[(size_t)m] = doff;
+        const int reps = L.kind[(size_t)m] == GST_KIND_EFFECT ? L.n_eff[(size_t)m] : 1;
+        for (int e = 0; e < reps; e++) {
+            kind.push_back(L.kind[(size_t)m]); obj.push_back(L.obj[(size_t)m] + e); ncols.push_back(np);
+            for (int q = 0; q < np; q++) pidx.push_back(L.param0[(size_t)m] + q);
+            doff += (int64_t)(L.kind[(size_t)m] == GST_KIND_GATE ? D * D : D) * np;
+        }
+        for (int q = 0; q < np; q++) set_param.push_back(L.param0[(size_t)m] + q);
+    }
+    const int32_t n_objs = (int32_t)kind.size();
+    p->dv_kind = kind; p->dv_obj = obj; p->dv_ncols = ncols; p->dv_param_idx = pidx;
+    p->dv_off_cols.assign((size_t)n_objs + 1, 0); p->dv_off_deriv.assign((size_t)n_objs + 1, 0);
+    for (int32_t o = 0; o < n_objs; o++) {
+        p->dv_off_cols[(size_t)o + 1] = p->dv_off_cols[(size_t)o] + ncols[(size_t)o];
+        p->dv_off_deriv[(size_t)o + 1] = p->dv_off_deriv[(size_t)o] + (int64_t)(kind[(size_t)o] == GST_KIND_GATE ? D * D : D) * ncols[(size_t)o];
+    }
+    p->dv_n_params = L.n_params;
+    p->dv_deriv_h.clear();                 // (no host copy: exact Hessian blocks of Lindblad models still come through gst_set_derivs)
+    p->dv2_set = false; p->dv2_off.clear();
+    HIP_TRY(p->d_dv_deriv.ensure((size_t)std::max<int64_t>(doff, 1)));
+    HIP_TRY(p->d_lb_setparam.ensure(set_param.size() + member_off.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_lb_setparam.p, set_param.data(), set_param.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_lb_setparam.p + set_param.size(), member_off.data(), member_off.size() * 8, hipMemcpyHostToDevice, p->stream));
+    gst::LbArgs a;
+    lb_args(p, a);
+    a.set_param = p->d_lb_setparam.p; a.deriv_out = p->d_dv_deriv.p; a.deriv_off = p->d_lb_setparam.p + set_param.size(); a.eps = 0.0;
+    HIP_TRY(gst::launch_lindblad_derivs(D, a, (int64_t)set_param.size(), p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));          // (the host vectors above go out of scope)
+    p->last_launches++;
+    p->cached_kind = 0;
+    return run_dprobs_general(p, d_out, ld, param_idx, dest_idx, n_param, d_probs_out);
+}
+
 int gst_fill_probs_dev(gst_plan* p, double* d_out)
 {
     return guarded([&]() -> int {
@@ -1850,6 +1899,13 @@ int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (rc) return rc;
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!d_out && n_param > 0) return fail(GST_EINVAL, "d_out is NULL");
+    if (p->lb.set && !p->derivs_set) {
+        if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
+        if (mode == GST_DERIV_FD) rc = run_dprobs_lindblad(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out);
+        else rc = run_dprobs_lindblad_analytic(p, d_out, ld, param_idx, dest_idx, n_param, d_probs_out);
+        if (rc) return rc;
+        return end_call(p, false);
+    }
     if (p->lb.set && mode == GST_DERIV_FD) {
         if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
         if ((rc = run_dprobs_lindblad(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out))) return rc;
@@ -1878,10 +1934,12 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     if (rc) return rc;
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!out && n_param > 0) return fail(GST_EINVAL, "out is NULL");
-    if (p->lb.set && mode == GST_DERIV_FD) {
+    if (p->lb.set && (mode == GST_DERIV_FD || !p->derivs_set)) {
         if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
         HIP_TRY(p->d_out.ensure((size_t)p->hp.n_elements * std::max<int64_t>(n_param, 1)));
-        if ((rc = run_dprobs_lindblad(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr))) return rc;
+        if (mode == GST_DERIV_FD) rc = run_dprobs_lindblad(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr);
+        else rc = run_dprobs_lindblad_analytic(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
+        if (rc) return rc;
         return copy_out_dprobs(p, out, ld, dest_idx, n_param, probs_out);
     }
     if (p->derivs_set && mode != GST_DERIV_ANALYTIC)

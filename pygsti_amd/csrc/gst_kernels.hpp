@@ -280,10 +280,15 @@ struct LbArgs {
     int64_t set_stride;
     double* gates_rowmajor;        // base build only (may be NULL): gates[n_gates][D][D] row-major as well
     double eps;
+    double* deriv_out;             // launch_lindblad_derivs: the members' derivative matrices, member m at deriv_off[m]
+    const int64_t* deriv_off;
     int32_t member_only;           // set_param != NULL: write ONLY the changed member, at the start of its set (gate: transposed
                                    // [D][D]; state [D]; POVM [n_eff][D]) -- what walk_pert_kernel reads; no copy of the base model
 };
 hipError_t launch_lindblad_build(int D, const LbArgs& a, int64_t n_sets, hipStream_t stream);
+// d(dense member)/d(parameter set_param[b]) for workgroup b: column (set_param[b] - param0[m]) of member m's row-major
+// [n_elem][n_params[m]] matrix at deriv_out + deriv_off[m] (a POVM: n_eff matrices [D][n_params] one after another)
+hipError_t launch_lindblad_derivs(int D, const LbArgs& a, int64_t n_params_total, hipStream_t stream);
 
 // Finite-difference walks for columns that change a whole object (gst_kernels_pert.hip): a work item is a task's dirty
 // program for the member's class walked for the 64/D columns col0 .. col0 + ncols of ONE member (kind / obj / n_eff of

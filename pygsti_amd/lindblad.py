@@ -111,6 +111,29 @@ def block_coefficients(block_type, mode, n, v):
     return herm.reshape(-1)
 
 
+def block_coefficient_derivs(block_type, mode, n, v):
+    """d(block_data.ravel()) / d(parameters): complex [n_coeffs][n_params] (lindbladcoefficients.py `block_data_jacobian`,
+    :178, :235, :348-380, :453-470)."""
+    v = np.asarray(v, float)
+    if block_type != BLOCK_OTHER:
+        return (np.eye(n) if mode == MODE_ELEMENTS else 2.0 * np.diag(v)).astype(complex)
+    p = v.reshape(n, n)
+    low = np.tril(p, -1) + 1j * np.triu(p, 1).T + np.diag(np.diag(p))
+    out = np.zeros((n * n, n * n), complex)
+    for a in range(n):
+        for b in range(n):
+            d = np.zeros((n, n), complex)              # dC / dp_ab: one entry
+            if a == b: d[a, a] = 1.0
+            elif a > b: d[a, b] = 1.0
+            else: d[b, a] = 1.0j
+            if mode == MODE_CHOLESKY:
+                dc = d @ low.conj().T + low @ d.conj().T
+            else:
+                dc = d + np.tril(d, -1).conj().T
+            out[:, a * n + b] = dc.reshape(-1)
+    return out
+
+
 class LindbladMember:
     """One model member = (static factor) composed with exp(error generator).  `blocks`: [(block type, mode, n)]."""
 
@@ -163,6 +186,47 @@ class LindbladMember:
         """Dense error generator at this member's parameters theta (lindbladerrorgen.py:699-703)."""
         c = self.coefficients(theta)
         return np.einsum("k,kij->ij", c.real, self.term_re) + np.einsum("k,kij->ij", c.imag, self.term_im)
+
+    def coefficient_derivs(self, theta):
+        """dc/dtheta, complex [n_coeffs][n_params] (block diagonal over the member's blocks)."""
+        out = np.zeros((self.n_coeffs, self.n_params), complex)
+        ko = po = 0
+        for t, m, n in self.blocks:
+            k = block_num_params(t, m, n)
+            d = block_coefficient_derivs(t, m, n, theta[po:po + k])
+            out[ko:ko + d.shape[0], po:po + k] = d
+            ko += d.shape[0]; po += k
+        return out
+
+    def errorgen_deriv(self, theta):
+        """d(error generator)/d(parameters): [n_params][D][D] (LindbladErrorgen.deriv_wrt_params, lindbladerrorgen.py:1342)."""
+        dc = self.coefficient_derivs(theta)
+        return np.einsum("kp,kij->pij", dc.real, self.term_re) + np.einsum("kp,kij->pij", dc.imag, self.term_im)
+
+    def exp_deriv(self, theta):
+        """d exp(L)/d(parameters): [n_params][D][D] -- the Frechet derivative of the matrix exponential in the direction
+        dL/dtheta_p, read off the exponential of the block matrix [[L, dL], [0, L]] (ExpErrorgenOp.deriv_wrt_params,
+        experrorgenop.py:213-260, computes the same thing from a series)."""
+        import scipy.linalg
+        L = self.errorgen(theta)
+        dL = self.errorgen_deriv(theta)
+        D = self.D
+        out = np.empty_like(dL)
+        for p in range(dL.shape[0]):
+            blk = np.zeros((2 * D, 2 * D))
+            blk[:D, :D] = L; blk[D:, D:] = L; blk[:D, D:] = dL[p]
+            out[p] = scipy.linalg.expm(blk)[:D, D:]
+        return out
+
+    def dense_deriv(self, theta):
+        """d(dense member)/d(parameters) as `deriv_wrt_params()` lays it out: [n_elem][n_params] per object -- a list with
+        one array for a gate or a preparation, one per effect for a POVM."""
+        dE = self.exp_deriv(theta)                                # [p][i][j]
+        if self.kind == KIND_GATE:
+            return [np.einsum("pil,lj->ijp", dE, self.static).reshape(self.D * self.D, -1)]
+        if self.kind == KIND_RHO:
+            return [np.einsum("pil,l->ip", dE, self.static.reshape(-1))]
+        return [np.einsum("l,plj->jp", self.static[e], dE) for e in range(self.n_eff)]
 
     def exp(self, theta):
         import scipy.linalg

@@ -338,7 +338,7 @@ class HipMapForwardSimulator(_MapForwardSimulator):
         finally:
             self._max_cache_size = keep
 
-    def _prepare(self, layout_atom, derivatives=False):
+    def _prepare(self, layout_atom, derivatives=False, hessian=False):
         plan = atom_plan(self.model, layout_atom, self._hip_device)
         plan.set_model(*atom_arrays(self.model, layout_atom))
         if not derivatives:
@@ -394,7 +394,27 @@ class HipMapForwardSimulator(_MapForwardSimulator):
                     plan.set_complement_effect(comp[0], comp[1], comp[2])
                 plan._hip_mode = "tp-elements"
         else:
-            # (re-sent every call: the derivatives of a non-linear parameterisation move with the parameters)
+            # exact derivatives of a general parameterisation.  Lindblad-parameterised models: the device computes the
+            # members' d(dense)/d(parameter) itself (Frechet derivative of the exponential); anything else: the members'
+            # deriv_wrt_params() from the host, re-sent every call (they move with the parameters)
+            if self.lindblad_on_device and not hessian:
+                if getattr(layout_atom, "_hip_lb_model", None) is not self.model:
+                    try:
+                        layout_atom._hip_lb = atom_lindblad(self.model, layout_atom)
+                    except NotImplementedError:
+                        layout_atom._hip_lb = None
+                    layout_atom._hip_lb_model = self.model
+                if layout_atom._hip_lb is not None:
+                    if getattr(plan, "_hip_mode", None) != "lindblad":
+                        plan.set_derivs(self.model.num_params, [])
+                        plan.set_complement_effect(-1)
+                        plan.set_lindblad(layout_atom._hip_lb)
+                        plan._hip_mode = "lindblad"
+                    plan.set_lindblad_params(self.model.to_vector())
+                    return plan
+            if getattr(plan, "_hip_mode", None) == "lindblad":
+                plan.set_lindblad(None)
+                plan.set_model(*atom_arrays(self.model, layout_atom))
             plan.set_derivs(self.model.num_params, atom_derivs(self.model, layout_atom))
             plan._hip_mode = "derivs"
         return plan
@@ -421,7 +441,7 @@ class HipMapForwardSimulator(_MapForwardSimulator):
 
     def _bulk_fill_hprobs_atom(self, array_to_fill, dest_param_slice1, dest_param_slice2, layout_atom,
                                param_slice1, param_slice2, resource_alloc):
-        plan = self._prepare(layout_atom, derivatives=True)
+        plan = self._prepare(layout_atom, derivatives=True, hessian=True)
         hmode = getattr(plan, "_hip_mode", None)
         if hmode == "derivs":
             # exact Hessians of a general parameterisation: members that are not linear in their parameters also send

@@ -150,3 +150,38 @@ def test_other_lindblad_parameterisations_through_the_simulator(param):
         assert np.abs(J[atom.element_slice] - J2).max() < tol, (np.abs(J[atom.element_slice] - J2).max(), tol)
     # probabilities of every circuit sum to one (trace preservation of every generator)
     assert np.abs(p.reshape(-1, 2).sum(1) - 1.0).max() < 1e-11 * max(1.0, np.abs(p).max())
+
+
+def test_analytic_jacobian_of_a_cptplnd_model_with_device_computed_member_derivatives():
+    """GST_DERIV_ANALYTIC with gst_set_lindblad: d(dense member)/d(parameter) comes from the device (Frechet derivative of
+    the exponential), not from the host's deriv_wrt_params() -- against the Matrix simulator's Jacobian of the same model
+    (<= 1e-8, fixture `dprobs_matrix`), against the same analytic path fed with the reference's own derivative matrices
+    (gst_set_derivs, fixture `dv_*`), and against the finite-difference columns (to FD accuracy); 2Q: analytic vs FD."""
+    fx, lb, model, pl = _plan("smq1Q_XYI_L4_CPTPLND", 1)
+    from pygsti_amd import _lib
+    nE, nP = int(fx["nE"]), int(fx["nP"])
+    rows = fx["matrix_rows"]
+    Ja = pl.fill_dprobs(param_idx=np.arange(nP), mode=_lib.DERIV_ANALYTIC)
+    err = np.abs(Ja[rows] - fx["dprobs_matrix"]).max()
+    assert err < 1e-8, err
+    # a column window with destinations
+    cols = np.array([59, 3, 17, 30]); win = np.full((nE, 7), np.nan)
+    pl.fill_dprobs(out=win, param_idx=cols, dest_idx=np.array([6, 0, 2, 3]), mode=_lib.DERIV_ANALYTIC)
+    assert np.abs(win[:, [6, 0, 2, 3]] - Ja[:, cols]).max() < 1e-12 and np.isnan(win[:, [1, 4, 5]]).all()
+    # the reference's own member derivatives through gst_set_derivs
+    pl2 = plan_from_fixture(fx)
+    objs, off_c, off_d = [], 0, 0
+    for k, o, n in zip(fx["dv_kind"], fx["dv_obj"], fx["dv_ncols"]):
+        K = 16 if k == 0 else 4
+        objs.append((int(k), int(o), fx["dv_param_idx"][off_c:off_c + n], fx["dv_deriv"][off_d:off_d + K * n].reshape(K, n)))
+        off_c += n; off_d += K * n
+    pl2.set_derivs(nP, objs)
+    Jr = pl2.fill_dprobs(param_idx=np.arange(nP), mode=_lib.DERIV_ANALYTIC)
+    assert np.abs(Ja - Jr).max() < 1e-11, np.abs(Ja - Jr).max()
+    Jf = pl.fill_dprobs(param_idx=np.arange(nP), eps=1e-7)
+    assert np.abs(Ja - Jf).max() < 1e-4            # (forward differences: eps times the second derivative)
+    # two qubits: exact against finite differences on a spread of columns
+    fx2, lb2, model2, pl2q = _plan("smq2Q_XYICNOT_L1_CPTPLND", 2)
+    c2 = fx2["dprobs_cols"]
+    Ja2 = pl2q.fill_dprobs(param_idx=c2, mode=_lib.DERIV_ANALYTIC)
+    assert np.abs(Ja2 - fx2["dprobs_map"]).max() < 1e-4, np.abs(Ja2 - fx2["dprobs_map"]).max()

@@ -112,3 +112,33 @@ def test_lindblad_explicit_model_interface():
     assert [mm.kind for mm in desc.members] == [LB.KIND_RHO, LB.KIND_POVM] + [LB.KIND_GATE] * 3
     m2 = m.copy()
     assert np.array_equal(m2.to_vector(), th) and m2.sim is not m.sim
+
+
+def test_member_derivatives_match_the_reference():
+    """d(error generator)/d(parameter), d exp(L)/d(parameter) and d(dense member)/d(parameter) on the host -- the statement
+    of what lindblad_deriv_kernel computes -- against LindbladErrorgen.deriv_wrt_params, ExpErrorgenOp.deriv_wrt_params
+    (fixture `m*_derrgen`, `m*_dexp`) and the members' deriv_wrt_params (`dv_deriv` of the big fixture)."""
+    fx, lb = load_fixture("smq1Q_XYI_L4_CPTPLND"), load_fixture("lindblad_smq1Q_XYI_L4_CPTPLND")
+    model = LB.LindbladModel.from_fixture(lb, 1)
+    th = lb["paramvec"]
+    for m, mem in enumerate(model.members):
+        loc = th[mem.param0:mem.param0 + mem.n_params]
+        assert np.abs(mem.errorgen_deriv(loc).transpose(1, 2, 0).reshape(16, -1) - lb["m%d_derrgen" % m]).max() < 1e-14
+        assert np.abs(mem.exp_deriv(loc).transpose(1, 2, 0).reshape(16, -1) - lb["m%d_dexp" % m]).max() < 1e-13
+    off = 0
+    for k, o, n in zip(fx["dv_kind"], fx["dv_obj"], fx["dv_ncols"]):
+        K = 16 if k == 0 else 4
+        ref = fx["dv_deriv"][off:off + K * n].reshape(K, n); off += K * n
+        mem = [mm for mm in model.members if (mm.kind == k if k != 2 else mm.kind == LB.KIND_POVM) and (k == 2 or mm.obj == o)][0]
+        dd = mem.dense_deriv(th[mem.param0:mem.param0 + mem.n_params])
+        mine = dd[0] if k != 2 else dd[int(o) - mem.obj]
+        assert np.abs(mine - ref).max() < 1e-13
+    # 'elements' and diagonal blocks: coefficient Jacobians against finite differences
+    rng = np.random.default_rng(1)
+    for bt, md, n in ((LB.BLOCK_OTHER, LB.MODE_ELEMENTS, 3), (LB.BLOCK_OTHER, LB.MODE_CHOLESKY, 3), (LB.BLOCK_OTHER_DIAGONAL, LB.MODE_CHOLESKY, 3)):
+        v = rng.standard_normal(LB.block_num_params(bt, md, n))
+        J = LB.block_coefficient_derivs(bt, md, n, v)
+        for q in range(len(v)):
+            dv = np.zeros_like(v); dv[q] = 1e-6
+            fd = (LB.block_coefficients(bt, md, n, v + dv) - LB.block_coefficients(bt, md, n, v - dv)) / 2e-6
+            assert np.abs(J[:, q] - fd).max() < 1e-8
