@@ -263,7 +263,16 @@ def atom_second_derivs(model, atom):
 
 
 def atom_plan(model, atom, device=-1, target_tasks=0):
-    """The libgstfwd plan of a `_MapCOPALayoutAtom`, built from its prefix table and cached on the atom."""
+    """The libgstfwd plan of a `_MapCOPALayoutAtom`, built once and cached on the atom.
+
+    The adapter's layouts are created with max_cache_size = 0 (see `create_layout`), so every row of the atom's prefix
+    table is a whole circuit -- (iDest, None, (rho, gate, gate, ...), None) -- and the plan is built from the RAW CIRCUITS
+    (gst_plan_create_from_circuits: the library compiles its own prefix trie anyway).  The labels are turned into integers
+    by C-level iteration (`np.fromiter(map(dict.__getitem__, chain.from_iterable(...)))`): the per-label Python loop this
+    replaces was 31.9 M list appends for the 2Q L<=1024 design (reference: convert_maplayout,
+    mapforwardsim_calc_densitymx.pyx:55-77).  A table that does carry cached prefixes (someone else's layout) still goes
+    through gst_plan_create_from_table."""
+    import itertools
     plan = getattr(atom, "_hip_plan", None)
     if plan is not None:
         return plan
@@ -271,26 +280,52 @@ def atom_plan(model, atom, device=-1, target_tasks=0):
     rho_lookup = {l: i for i, l in enumerate(atom.rho_labels)}
     contents = atom.table.contents
     R = len(contents)
-    t_dest = np.empty(R, np.int32); t_start = np.empty(R, np.int32); t_cache = np.empty(R, np.int32)
-    t_rho = -np.ones(R, np.int32); row_ptr = np.zeros(R + 1, np.int64); gidx = []
-    for k, (iDest, iStart, remainder, iCache) in enumerate(contents):   # convert_maplayout, pyx:55-77
-        t_dest[k] = iDest
-        t_start[k] = -1 if iStart is None else iStart
-        t_cache[k] = -1 if iCache is None else iCache
-        rem = list(remainder)
-        if iStart is None:
-            t_rho[k] = rho_lookup[rem[0]]; rem = rem[1:]
-        gidx.extend(op_lookup[g] for g in rem)
-        row_ptr[k + 1] = len(gidx)
-    eff_ptr = np.zeros(R + 1, np.int64); el, ed = [], []
-    for i in range(R):
-        el.extend(atom.elbl_indices_by_expcircuit[i]); ed.extend(atom.elindices_by_expcircuit[i])
-        eff_ptr[i + 1] = len(el)
+    # effect CSR: elbl_indices_by_expcircuit / elindices_by_expcircuit are dicts (or lists) of per-circuit integer lists
+    el_src, ed_src = atom.elbl_indices_by_expcircuit, atom.elindices_by_expcircuit
+    el_lists = [el_src[i] for i in range(R)]
+    ed_lists = [ed_src[i] for i in range(R)]
+    eff_ptr = np.zeros(R + 1, np.int64)
+    np.cumsum(np.fromiter(map(len, el_lists), np.int64, count=R), out=eff_ptr[1:])
+    n_el = int(eff_ptr[-1])
+    el = np.fromiter(itertools.chain.from_iterable(el_lists), np.int32, count=n_el)
+    ed = np.fromiter(itertools.chain.from_iterable(ed_lists), np.int32, count=n_el)
     atom._hip_eff_labels = list(atom.full_effect_labels)
-    plan = _lib.Plan.from_table(model.dim, len(atom.op_labels), len(atom.rho_labels), len(atom._hip_eff_labels),
-                                atom.num_elements, atom.cache_size, t_dest, t_start, t_cache, t_rho, row_ptr,
-                                np.array(gidx, np.int32), eff_ptr, np.array(el, np.int32), np.array(ed, np.int32),
-                                device=device, target_tasks=target_tasks)
+    nG, nR, nEl = len(atom.op_labels), len(atom.rho_labels), len(atom._hip_eff_labels)
+    if all(row[1] is None for row in contents):
+        # cache-free table: row k IS circuit iDest_k
+        dest = np.fromiter((row[0] for row in contents), np.int64, count=R)
+        rems = [row[2] for row in contents]
+        lens = np.fromiter(map(len, rems), np.int64, count=R) - 1
+        assert (lens >= 0).all(), "every expanded circuit starts with a state preparation"
+        order = np.argsort(dest, kind="stable")
+        if not np.array_equal(dest[order], np.arange(R)):
+            raise ValueError("prefix table rows do not enumerate the expanded circuits")
+        circ_rho_rows = np.fromiter((rho_lookup[r[0]] for r in rems), np.int32, count=R)
+        gates_rows = np.fromiter(map(op_lookup.__getitem__, itertools.chain.from_iterable(r[1:] for r in rems)),
+                                 np.int32, count=int(lens.sum()))
+        if np.array_equal(order, np.arange(R)):
+            circ_rho, circ_len, circ_gates = circ_rho_rows, lens, gates_rows
+        else:                                       # rows in evaluation order, circuits in index order: permute
+            ptr_rows = np.zeros(R + 1, np.int64); np.cumsum(lens, out=ptr_rows[1:])
+            circ_rho, circ_len = circ_rho_rows[order], lens[order]
+            circ_gates = np.concatenate([gates_rows[ptr_rows[k]:ptr_rows[k + 1]] for k in order]) if R else gates_rows
+        circ_ptr = np.zeros(R + 1, np.int64); np.cumsum(circ_len, out=circ_ptr[1:])
+        plan = _lib.Plan.from_circuits(model.dim, nG, nR, nEl, atom.num_elements, circ_rho, circ_ptr, circ_gates, eff_ptr, el, ed,
+                                       device=device, target_tasks=target_tasks)
+    else:
+        t_dest = np.empty(R, np.int32); t_start = np.empty(R, np.int32); t_cache = np.empty(R, np.int32)
+        t_rho = -np.ones(R, np.int32); row_ptr = np.zeros(R + 1, np.int64); gidx = []
+        for k, (iDest, iStart, remainder, iCache) in enumerate(contents):   # convert_maplayout, pyx:55-77
+            t_dest[k] = iDest
+            t_start[k] = -1 if iStart is None else iStart
+            t_cache[k] = -1 if iCache is None else iCache
+            rem = list(remainder)
+            if iStart is None:
+                t_rho[k] = rho_lookup[rem[0]]; rem = rem[1:]
+            gidx.extend(op_lookup[g] for g in rem)
+            row_ptr[k + 1] = len(gidx)
+        plan = _lib.Plan.from_table(model.dim, nG, nR, nEl, atom.num_elements, atom.cache_size, t_dest, t_start, t_cache, t_rho,
+                                    row_ptr, np.array(gidx, np.int32), eff_ptr, el, ed, device=device, target_tasks=target_tasks)
     atom._hip_plan = plan
     return plan
 

@@ -198,3 +198,41 @@ def test_adapter_describes_lindblad_models_for_the_device(param, pack_name):
     A.atom_plan(full, lay2.atoms[0])
     with pytest.raises(NotImplementedError):
         A.atom_lindblad(full, lay2.atoms[0])
+
+
+def test_atom_plan_from_raw_circuits_is_cheap_and_equivalent():
+    """SURVEY 8(f) row f2 in the drop-in: the plan is built from the layout's raw circuits with C-level label conversion
+    (gst_plan_create_from_circuits), not by a Python loop over every gate of every row.  Same circuits, same element
+    CSR as the table path; a fraction of pyGSTi's own layout-creation time (measured on the 2Q L<=1024 lite design in the
+    build container: create_layout 6.3 s, atom_plan 0.97 s including the library's plan compile)."""
+    import time
+    from pygsti.modelpacks import smq2Q_XYICNOT
+    model = smq2Q_XYICNOT.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
+    circuits = list(smq2Q_XYICNOT.create_gst_experiment_design(16, lite=True).all_circuits_needing_data)
+    model.sim = A.HipMapForwardSimulator()
+    t0 = time.perf_counter()
+    layout = model.sim.create_layout(circuits, array_types=("e", "ep"))
+    t_layout = time.perf_counter() - t0
+    atom = layout.atoms[0]
+    t0 = time.perf_counter()
+    plan = A.atom_plan(model, atom)
+    t_plan = time.perf_counter() - t0
+    assert t_plan < 0.5 * t_layout + 0.2, (t_plan, t_layout)
+    st = plan.stats()
+    assert st["n_circuits"] == len(atom.table.contents) and st["n_elements"] == atom.num_elements
+    assert st["sum_depth"] == sum(len(row[2]) - 1 for row in atom.table.contents)
+    # the same atom through the reference-format table path gives the same plan
+    op_lookup = {l: i for i, l in enumerate(atom.op_labels)}; rho_lookup = {l: i for i, l in enumerate(atom.rho_labels)}
+    R = len(atom.table.contents)
+    t_dest = np.array([r[0] for r in atom.table.contents], np.int32)
+    row_ptr = np.zeros(R + 1, np.int64); gidx = []; t_rho = np.empty(R, np.int32)
+    for k, row in enumerate(atom.table.contents):
+        t_rho[k] = rho_lookup[row[2][0]]; gidx.extend(op_lookup[g] for g in row[2][1:]); row_ptr[k + 1] = len(gidx)
+    eff_ptr = np.zeros(R + 1, np.int64); el, ed = [], []
+    for i in range(R):
+        el.extend(atom.elbl_indices_by_expcircuit[i]); ed.extend(atom.elindices_by_expcircuit[i]); eff_ptr[i + 1] = len(el)
+    ref = _lib.Plan.from_table(model.dim, len(atom.op_labels), len(atom.rho_labels), len(atom._hip_eff_labels), atom.num_elements, 0,
+                               t_dest, -np.ones(R, np.int32), -np.ones(R, np.int32), t_rho, row_ptr, np.array(gidx, np.int32),
+                               eff_ptr, np.array(el, np.int32), np.array(ed, np.int32))
+    w1, o1 = plan.program(); w2, o2 = ref.program()
+    assert np.array_equal(w1, w2) and np.array_equal(o1, o2)
