@@ -39,6 +39,14 @@ except Exception:   # pragma: no cover - exercised only where pyGSTi is absent
     HAVE_PYGSTI = False
 
 
+def _to_array(slc_or_indices):
+    """slicetools.to_array: a slice (or index list) as an index array."""
+    if isinstance(slc_or_indices, slice):
+        assert slc_or_indices.stop is not None, "open-ended parameter slice"
+        return np.arange(slc_or_indices.start or 0, slc_or_indices.stop, slc_or_indices.step or 1)
+    return np.asarray(slc_or_indices, dtype=np.int64)
+
+
 def atom_arrays(model, atom):
     """Dense model arrays in the atom's own index order (op_labels sorted, full_effect_labels a set whose
     iteration order defines effect indices -- captured once)."""
@@ -330,48 +338,16 @@ def atom_plan(model, atom, device=-1, target_tasks=0):
     return plan
 
 
-class HipMapForwardSimulator(_MapForwardSimulator):
-    """MapForwardSimulator whose atom fills run on the GPU.  `derivative_mode="fd"` (default): bit-identical to the
-    Map simulator's finite differences; `"analytic"`: exact first derivatives (what MatrixForwardSimulator returns,
-    to <= 1e-8), several times faster, and exact Hessian blocks."""
-
-    def __init__(self, model=None, max_cache_size=None, num_atoms=None, processor_grid=None, param_blk_sizes=None,
-                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1, derivative_mode="fd", lindblad_on_device=True):
-        if not HAVE_PYGSTI:
-            raise ImportError("pygsti is not importable; use pygsti_amd.forwardsim.HipMapForwardSimulator instead")
-        if derivative_mode not in ("fd", "analytic"):
-            raise ValueError("derivative_mode must be 'fd' or 'analytic'")
-        super().__init__(model, max_cache_size, num_atoms, processor_grid, param_blk_sizes, derivative_eps, hessian_eps)
-        self._hip_device = device
-        self.derivative_mode = derivative_mode
-        # Lindblad-parameterised models (CPTPLND, GLND, H+S): True = the device builds the dense members from the
-        # parameter vector for every finite-difference step (gst_set_lindblad); False = the model is stepped on the host
-        # and the device evaluates the dense sets (gst_fill_dprobs_models; the validation path)
-        self.lindblad_on_device = bool(lindblad_on_device)
-
-    def copy(self, keep_model_attached=True):
-        out = HipMapForwardSimulator(self.model if keep_model_attached else None, self._max_cache_size, self._num_atoms,
-                                     self._processor_grid, self._pblk_sizes, self.derivative_eps, self.hessian_eps,
-                                     self._hip_device, self.derivative_mode, self.lindblad_on_device)
-        return out
-
-    def create_layout(self, circuits, dataset=None, resource_alloc=None, array_types=('E',), derivative_dimensions=None,
-                      verbosity=0, layout_creation_circuit_cache=None, **kwargs):
-        """pyGSTi's own MapCOPALayout (element indexing, atoms, parameter blocks, MPI grid -- everything upstream relies
-        on), built WITHOUT the prefix-cache assessment pass: the library compiles its own prefix trie from the full gate
-        strings (gst_plan_create_from_table re-derives them), so the table's caching choices are never used, and with
-        max_cache_size = 0 `PrefixTable.__init__` skips `_cache_hits` (layouts/prefixtable.py:76-84), the O(rows x cache)
-        tuple-comparison pass that is half of layout creation (2Q L<=1024 lite: 14.6 -> 7.7 s; what remains is pyGSTi's
-        per-circuit completion / POVM separation, models/model.py:1600-1775, which callers amortise with
-        `layout_creation_circuit_cache`).  Results are unchanged: every state is still rho followed by the circuit's
-        gates applied left to right."""
-        keep = self._max_cache_size
-        self._max_cache_size = 0
-        try:
-            return super().create_layout(circuits, dataset, resource_alloc, array_types, derivative_dimensions, verbosity,
-                                         layout_creation_circuit_cache, **kwargs)
-        finally:
-            self._max_cache_size = keep
+class AtomFillLogic:
+    """Everything the adapter does per layout atom -- choosing how a model's parameters reach the device ("elements",
+    "tp-elements", "lindblad", "models", "derivs") and the three `_bulk_fill_*_atom` seams -- written against the DUCK
+    TYPES of a pyGSTi model and layout atom only (`model._circuit_layer_operator`, `to_vector`, `set_parameter_value(s)`,
+    `from_vector`, `num_params`, `dim`; `atom.op_labels`, `rho_labels`, `full_effect_labels`, `table.contents`,
+    `elbl_indices_by_expcircuit`, `elindices_by_expcircuit`, `num_elements`, `cache_size`).  HipMapForwardSimulator mixes
+    it into pyGSTi's MapForwardSimulator; tests/test_gpu_adapter_modes.py drives it on the GPU box -- where pyGSTi does
+    not exist -- with stand-in models and atoms built from the committed fixtures."""
+    # (expects on `self`: model, derivative_eps, hessian_eps, derivative_mode, lindblad_on_device, _hip_device -- no
+    #  defaults here: class attributes of a mixin would shadow pyGSTi's `model` property)
 
     def _prepare(self, layout_atom, derivatives=False, hessian=False):
         plan = atom_plan(self.model, layout_atom, self._hip_device)
@@ -464,8 +440,8 @@ class HipMapForwardSimulator(_MapForwardSimulator):
     def _bulk_fill_dprobs_atom(self, array_to_fill, dest_param_slice, layout_atom, param_slice, resource_alloc):
         plan = self._prepare(layout_atom, derivatives=True)
         nP = self.model.num_params
-        pidx = np.arange(nP) if param_slice is None else _slct.to_array(param_slice)
-        didx = None if dest_param_slice is None else _slct.to_array(dest_param_slice)
+        pidx = np.arange(nP) if param_slice is None else _to_array(param_slice)
+        didx = None if dest_param_slice is None else _to_array(dest_param_slice)
         if getattr(plan, "_hip_mode", None) == "models":
             G, R, E = atom_model_sets(self.model, layout_atom, pidx, self.derivative_eps)
             plan.set_model(*atom_arrays(self.model, layout_atom))
@@ -488,10 +464,10 @@ class HipMapForwardSimulator(_MapForwardSimulator):
             # (model sets), and (dprobs2 - dprobs) / eps is the reference's own numpy line
             eps = self.hessian_eps
             nP = self.model.num_params
-            i1 = np.arange(nP) if param_slice1 is None else _slct.to_array(param_slice1)
-            i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)
-            d1 = np.arange(len(i1)) if dest_param_slice1 is None else _slct.to_array(dest_param_slice1)
-            d2 = np.arange(len(i2)) if dest_param_slice2 is None else _slct.to_array(dest_param_slice2)
+            i1 = np.arange(nP) if param_slice1 is None else _to_array(param_slice1)
+            i2 = np.arange(nP) if param_slice2 is None else _to_array(param_slice2)
+            d1 = np.arange(len(i1)) if dest_param_slice1 is None else _to_array(dest_param_slice1)
+            d2 = np.arange(len(i2)) if dest_param_slice2 is None else _to_array(dest_param_slice2)
             orig = self.model.to_vector().copy()
 
             def dprobs_here():
@@ -512,10 +488,10 @@ class HipMapForwardSimulator(_MapForwardSimulator):
             # own model builder: theta + eps e_i is just another parameter vector
             eps = self.hessian_eps
             nP = self.model.num_params
-            i1 = np.arange(nP) if param_slice1 is None else _slct.to_array(param_slice1)
-            i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)
-            d1 = np.arange(len(i1)) if dest_param_slice1 is None else _slct.to_array(dest_param_slice1)
-            d2 = np.arange(len(i2)) if dest_param_slice2 is None else _slct.to_array(dest_param_slice2)
+            i1 = np.arange(nP) if param_slice1 is None else _to_array(param_slice1)
+            i2 = np.arange(nP) if param_slice2 is None else _to_array(param_slice2)
+            d1 = np.arange(len(i1)) if dest_param_slice1 is None else _to_array(dest_param_slice1)
+            d2 = np.arange(len(i2)) if dest_param_slice2 is None else _to_array(dest_param_slice2)
             orig = self.model.to_vector().copy()
             dprobs = plan.fill_dprobs(param_idx=i2, eps=eps)
             try:
@@ -531,10 +507,10 @@ class HipMapForwardSimulator(_MapForwardSimulator):
                                       "(FD of FD as the Map simulator computes them, or exact), any parameterisation "
                                       "with derivative_mode='analytic' (exact)")
         nP = self.model.num_params
-        i1 = np.arange(nP) if param_slice1 is None else _slct.to_array(param_slice1)
-        i2 = np.arange(nP) if param_slice2 is None else _slct.to_array(param_slice2)
-        d1 = None if dest_param_slice1 is None else _slct.to_array(dest_param_slice1)
-        d2 = None if dest_param_slice2 is None else _slct.to_array(dest_param_slice2)
+        i1 = np.arange(nP) if param_slice1 is None else _to_array(param_slice1)
+        i2 = np.arange(nP) if param_slice2 is None else _to_array(param_slice2)
+        d1 = None if dest_param_slice1 is None else _to_array(dest_param_slice1)
+        d2 = None if dest_param_slice2 is None else _to_array(dest_param_slice2)
         # derivative_mode="analytic": exact second derivatives (MatrixForwardSimulator's values) 
         # (D = 4, 16, 64); otherwise the Map simulator's FD-of-FD, bit for bit
         mode = _lib.DERIV_ANALYTIC if (self.derivative_mode == "analytic") else _lib.DERIV_FD
@@ -544,3 +520,47 @@ class HipMapForwardSimulator(_MapForwardSimulator):
             tmp = np.ascontiguousarray(array_to_fill)
             plan.fill_hprobs(tmp, i1, i2, d1, d2, self.hessian_eps, mode)
             array_to_fill[...] = tmp
+
+
+class HipMapForwardSimulator(AtomFillLogic, _MapForwardSimulator):
+    """MapForwardSimulator whose atom fills run on the GPU.  `derivative_mode="fd"` (default): bit-identical to the
+    Map simulator's finite differences; `"analytic"`: exact first derivatives (what MatrixForwardSimulator returns,
+    to <= 1e-8), several times faster, and exact Hessian blocks."""
+
+    def __init__(self, model=None, max_cache_size=None, num_atoms=None, processor_grid=None, param_blk_sizes=None,
+                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1, derivative_mode="fd", lindblad_on_device=True):
+        if not HAVE_PYGSTI:
+            raise ImportError("pygsti is not importable; use pygsti_amd.forwardsim.HipMapForwardSimulator instead")
+        if derivative_mode not in ("fd", "analytic"):
+            raise ValueError("derivative_mode must be 'fd' or 'analytic'")
+        super().__init__(model, max_cache_size, num_atoms, processor_grid, param_blk_sizes, derivative_eps, hessian_eps)
+        self._hip_device = device
+        self.derivative_mode = derivative_mode
+        # Lindblad-parameterised models (CPTPLND, GLND, H+S): True = the device builds the dense members from the
+        # parameter vector for every finite-difference step (gst_set_lindblad); False = the model is stepped on the host
+        # and the device evaluates the dense sets (gst_fill_dprobs_models; the validation path)
+        self.lindblad_on_device = bool(lindblad_on_device)
+
+    def copy(self, keep_model_attached=True):
+        out = HipMapForwardSimulator(self.model if keep_model_attached else None, self._max_cache_size, self._num_atoms,
+                                     self._processor_grid, self._pblk_sizes, self.derivative_eps, self.hessian_eps,
+                                     self._hip_device, self.derivative_mode, self.lindblad_on_device)
+        return out
+
+    def create_layout(self, circuits, dataset=None, resource_alloc=None, array_types=('E',), derivative_dimensions=None,
+                      verbosity=0, layout_creation_circuit_cache=None, **kwargs):
+        """pyGSTi's own MapCOPALayout (element indexing, atoms, parameter blocks, MPI grid -- everything upstream relies
+        on), built WITHOUT the prefix-cache assessment pass: the library compiles its own prefix trie from the full gate
+        strings (gst_plan_create_from_table re-derives them), so the table's caching choices are never used, and with
+        max_cache_size = 0 `PrefixTable.__init__` skips `_cache_hits` (layouts/prefixtable.py:76-84), the O(rows x cache)
+        tuple-comparison pass that is half of layout creation (2Q L<=1024 lite: 14.6 -> 7.7 s; what remains is pyGSTi's
+        per-circuit completion / POVM separation, models/model.py:1600-1775, which callers amortise with
+        `layout_creation_circuit_cache`).  Results are unchanged: every state is still rho followed by the circuit's
+        gates applied left to right."""
+        keep = self._max_cache_size
+        self._max_cache_size = 0
+        try:
+            return super().create_layout(circuits, dataset, resource_alloc, array_types, derivative_dimensions, verbosity,
+                                         layout_creation_circuit_cache, **kwargs)
+        finally:
+            self._max_cache_size = keep
