@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1: weak = one full design per rank (N designs in all); strong = one design dealt to N atoms")
     ap.add_argument("--no-analytic", action="store_true", help="skip the secondary analytic-derivative timing")
+    ap.add_argument("--no-other-configs", action="store_true", help="N=1: skip the secondary legs of the other BASELINE configurations (1Q, 3Q, Hessian block)")
     ap.add_argument("--no-cptplnd", action="store_true", help="N=1: skip the secondary CPTPLND (Lindblad-parameterised) Jacobian timing")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="development aid (N=1 only): time rank 0's atom of an N-atom strong-scaling layout on this one "
@@ -346,8 +347,16 @@ def main():
             exchange_probs()
         barrier_sync(plan)
         dta = ctx.max_over_ranks(time.perf_counter() - ta0)
+        ana_kms = plan.stats()["last_kernel_ms"]
+        ana_bytes = 8.0 * nE_local * nP
         ana_info = {"value": nE_total * nP * n_an / dta, "unit": "Jacobian-elements/s", "ms_per_step": 1e3 * dta / n_an,
-                    "kernel_ms": plan.stats()["last_kernel_ms"],
+                    "kernel_ms": ana_kms,
+                    "roofline": {"bound": "hbm", "kernel": "analytic_mfma_kernel (+ the backward chain pass that feeds it)",
+                                 "achieved": ana_bytes / (ana_kms * 1e-3) / 1e9 if ana_kms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ana_bytes / (ana_kms * 1e-3) / 1e9 / HBM_PEAK_GBS if ana_kms > 0 else None,
+                                 "whole_step_frac": ana_bytes / (dta / n_an) / 1e9 / HBM_PEAK_GBS,
+                                 "bytes_per_launch": ana_bytes,
+                                 "note": "algorithmic bytes = the Jacobian write 8*nE*nP; `frac` over the contraction kernel, `whole_step_frac` over the step (chain passes included)"},
                     "note": "analytic derivatives (reference MatrixForwardSimulator semantics); secondary figure, not `value`"}
         plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the FD Jacobian resident
         barrier_sync(plan)
@@ -433,6 +442,26 @@ def main():
         finally:
             if d_jfull is not None:
                 plan.device_free(d_jfull)
+
+    # secondary (N=1): the other BASELINE configurations, each with its own roofline fraction -- 1Q L<=128 (configs[1]),
+    # the 3-qubit D = 64 model (configs[4]: FD block, full analytic Jacobian, a Hessian block) and one rectangle of the 2Q
+    # objective Hessian (FD of FD) -- so that they are driver-timed figures, not builder-only ones
+    other_configs = None
+    if world == 1 and lay_world == 1 and not args.no_other_configs:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+        bc = importlib.util.module_from_spec(spec); spec.loader.exec_module(bc)
+        other_configs = {}
+        for key, fn in (("smq1Q_XYI_L128", bc.one_q), ("3Q_D64", bc.three_q),
+                        ("2Q_objective_hessian_block", lambda: bc.two_q_hessian_block(plan, nE_local, nP, plan.stats()["applies_per_pass"]))):
+            try:
+                other_configs[key] = fn()
+            except Exception as e:                       # a secondary leg must not take the headline down with it
+                other_configs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            log("config %s done" % key)
+        plan.set_model(gates, rhos, effects)
+        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the headline Jacobian resident
+        barrier_sync(plan)
 
     log("exchange legs done")
     jtj_info = None
@@ -570,9 +599,14 @@ def main():
             "normal_equations": jtj_info,
             "analytic_dprobs": ana_info,
             "cptplnd_dprobs": cptp_info,
+            "other_configs": other_configs,
             "host_fill": host_fill,
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,
+            "probs_roofline": {"bound": "mfma", "compute_unit": "valu_f64", "unit": "TFLOP/s", "peak": F64_VALU_PEAK_TFLOPS,
+                               "achieved": (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local) / (dtp / n_pr) / 1e12,
+                               "frac": (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local) / (dtp / n_pr) / 1e12 / F64_VALU_PEAK_TFLOPS,
+                               "note": "one probability pass is a latency chain -- %d tasks of ~%d dependent mat-vecs on 1,024 SIMDs, 221 ns per step -- not a throughput kernel: the fraction of the compute roof SURVEY 8(d) names is what bit-exact sequential order leaves" % (st["n_tasks"], st["applies_per_pass"] // max(st["n_tasks"], 1))},
             "roofline": roof or {"bound": "mfma", "compute_unit": "valu_f64",
                          "bound_note": "the compute roof (\"mfma\" in this line's vocabulary): dense fp64 peak 78.6 TFLOP/s, which on MI355X is both the MFMA and the vector-FMA rate. The kernel runs on the fp64 VECTOR ALU -- no matrix instruction can reproduce the reference's un-fused, ordered sums -- so `frac` is against the roof the contract names and `compute_unit` says which pipe does the work",
                          "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,

@@ -8,6 +8,19 @@ from pygsti_amd import _lib, modelpacks
 from pygsti_amd.layout import HipCOPALayout
 
 
+F64_PEAK_TFLOPS, HBM_PEAK_GBS = 78.6, 8000.0
+
+
+def _roof_compute(flops, seconds):
+    a = flops / seconds / 1e12
+    return {"bound": "mfma", "achieved": a, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / F64_PEAK_TFLOPS}
+
+
+def _roof_hbm(nbytes, seconds):
+    a = nbytes / seconds / 1e9
+    return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS}
+
+
 def timed(fn, plan, reps):
     fn(); plan.sync()
     t0 = time.perf_counter()
@@ -42,7 +55,13 @@ def one_q():
     l_p = lat(lambda: plan.fill_probs(pr))
     l_fd = lat(lambda: plan.fill_dprobs(J, pidx, None, 1e-7, pr, _lib.DERIV_FD))
     l_an = lat(lambda: plan.fill_dprobs(J, pidx, None, 1e-7, pr, _lib.DERIV_ANALYTIC))
+    D = 4
+    fl_pass = 2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE           # flops of one probability pass
+    roof = {"probs": _roof_compute(fl_pass, t_p), "dprobs_fd": _roof_compute(nP * fl_pass, t_fd),
+            "dprobs_analytic": _roof_hbm(8.0 * nE * nP, t_an),
+            "note": "launch / latency bound at this size (a fill is two ~30 us dependent chains): the fractions say how far a 2,240-element problem is from a roof sized for 10^5 circuits"}
     return {"config": "smq1Q_XYI L<=128 (BASELINE configs[1]): %d circuits, nE=%d, nP=%d, D=4" % (len(circuits), nE, nP),
+            "roofline": roof,
             "blocking_host_fill_us": {"probs": 1e6 * l_p, "dprobs_fd": 1e6 * l_fd, "dprobs_analytic": 1e6 * l_an},
             "probs_us": 1e6 * t_p, "probs_per_s": nE / t_p,
             "dprobs_fd_us": 1e6 * t_fd, "dprobs_fd_el_per_s": nE * nP / t_fd,
@@ -85,7 +104,13 @@ def three_q(n_circ=400, max_len=256, n_cols=4096):
     t0 = time.perf_counter(); Ha = plan.fill_hprobs(idx1=i1, idx2=i2, mode=_lib.DERIV_ANALYTIC); t_ha = time.perf_counter() - t0
     h_diff = float(np.abs(H - Ha).max() / max(np.abs(Ha).max(), 1e-300))
     flops = n_cols * 2.0 * D * D * st["applies_per_pass"]
-    return {"config": "3-qubit explicit dense model (BASELINE configs[4] shape): D=64, 10 gates, 8 outcomes, nP=%d; %d seeded random circuits, "
+    roof = {"probs": _roof_compute(2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE, t_p),
+            "dprobs_fd_block": dict(_roof_compute(flops + n_cols * 2.0 * D * nE, t_fd), compute_unit="valu_f64",
+                                    note="un-fused multiply/add (bit parity): its own ceiling is half the FMA peak"),
+            "dprobs_analytic_full": _roof_hbm(8.0 * nE * nP, t_anf),
+            "hprobs_fd_block_16x256": dict(_roof_compute(16 * 256 * (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE), t_h),
+                                           note="incl. the D2H copy of the block (host output)")}
+    return {"roofline": roof, "config": "3-qubit explicit dense model (BASELINE configs[4] shape): D=64, 10 gates, 8 outcomes, nP=%d; %d seeded random circuits, "
                       "lengths 1..%d, nE=%d" % (nP, n_circ, max_len, nE),
             "probs_ms": 1e3 * t_p, "probs_per_s": nE / t_p,
             "dprobs_fd_cols": int(n_cols), "dprobs_fd_ms": 1e3 * t_fd, "dprobs_fd_el_per_s": nE * n_cols / t_fd,
@@ -98,6 +123,30 @@ def three_q(n_circ=400, max_len=256, n_cols=4096):
             "applies_per_pass": st["applies_per_pass"], "n_tasks": st["n_tasks"],
             "note": "FD: bit-exact, register-blocked kernel (16 models per wavefront), no MFMA -- separate multiply/add is what parity "
                     "with the reference Map path requires; analytic: backward states over the suffix trie + 64x64 MFMA fp64 blocks"}
+
+
+def two_q_hessian_block(plan, nE, nP, applies_per_pass, D=16, n1=2, n2=256):
+    """One (n1 x n2) rectangle of the objective's Hessian on the bench design, Map-simulator semantics (FD of FD,
+    eps 1e-5): hprobs block + both Jacobian blocks produced and contracted with the objective's dterms / hterms on the
+    device (gst_objective_hessian_block); only n1 * n2 numbers come back."""
+    rng = np.random.default_rng(7)
+    d_c = plan.device_malloc(nE * 8); d_N = plan.device_malloc(nE * 8)
+    plan.memcpy_h2d(d_c, rng.integers(0, 1000, nE).astype(np.float64)); plan.memcpy_h2d(d_N, np.full(nE, 1000.0))
+    rows = np.arange(80, 80 + n1, dtype=np.int64); cols = np.arange(80, 80 + n2, dtype=np.int64)
+    try:
+        plan.objective_hessian_block("logl", d_c, d_N, rows, cols, 1e-5, 1e-4, 1e-4, None, _lib.DERIV_FD)
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            plan.objective_hessian_block("logl", d_c, d_N, rows, cols, 1e-5, 1e-4, 1e-4, None, _lib.DERIV_FD)
+        t = (time.perf_counter() - t0) / reps
+    finally:
+        plan.device_free(d_c); plan.device_free(d_N)
+    flops = n1 * n2 * (2.0 * D * D * applies_per_pass + 2.0 * D * nE)
+    return {"config": "2Q bench design, objective Hessian rectangle %d x %d (FD of FD, eps 1e-5; gst_objective_hessian_block)" % (n1, n2),
+            "ms": 1e3 * t, "hessian_elements_per_s": nE * n1 * n2 / t,
+            "roofline": dict(_roof_compute(flops, t), compute_unit="valu_f64",
+                             note="flops of the n1*n2 doubly perturbed passes of the reference's schedule; includes the two FD Jacobian blocks, the contraction and the blocking read-back of n1*n2 numbers")}
 
 
 if __name__ == "__main__":
