@@ -200,6 +200,8 @@ struct gst_plan {
     int64_t host_direct_min_cols = 64;  // (narrower column windows would cross PCIe in segments shorter than a wavefront's 512 bytes)
     int fd_handover = 1;                // GST_FD_HANDOVER: 0 never cut a walk, 1 cut to balance the per-SIMD queues, 2 cut every walk
     bool fd_overlap = true;             // GST_FD_OVERLAP=0: the persistent FD launch keeps the separate base pass in front of it
+    bool jtj_sparse = true;             // GST_JTJ_SPARSE=0: J^T J multiplies every panel (round-2 form)
+    DevBuf<uint32_t> d_jtj_pmask;
     bool fd_overlap_diag = false;       // GST_FD_OVERLAP=2 (measurements): the overlap kernel, but base pass in front and no chains
     bool fd_standby = true;             // GST_FD_STANDBY=0 (measurements only): no stand-by launches behind the persistent one
     bool last_overlap = false;          // the last FD fill ran its base pass inside the persistent launch
@@ -247,7 +249,7 @@ struct gst_plan {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
         d_lb_i32.release(); d_lb_i64.release(); d_lb_setparam.release(); d_lb_statics.release(); d_lb_term_re.release();
-        d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release();
+        d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release(); d_jtj_pmask.release();
         d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release();
         d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release();
         d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release();
@@ -320,6 +322,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_FD_OVERLAP")) { p->fd_overlap = std::atoi(e) != 0; p->fd_overlap_diag = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_FD_STANDBY")) p->fd_standby = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_LB_SHARE")) p->lb_share = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_JTJ_SPARSE")) p->jtj_sparse = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_TEST_SKIP_CHAINS")) p->test_skip_chains = std::atoi(e) != 0;
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
@@ -2455,12 +2458,21 @@ int gst_fill_jtj_dev(gst_plan* p, double* d_J, int64_t n_rows, int64_t n_cols, i
     int rc = ensure_device(p);
     if (rc) return rc;
     TIME_REC(p, ev0);
-    if (d_row_scale && n_rows > 0 && n_cols > 0) HIP_TRY(gst::launch_scale_rows(d_J, n_rows, n_cols, ld, d_row_scale, p->stream));
+    // Block sparsity (a row is exactly zero in the columns of gates its circuit never applies): one streaming pass marks,
+    // per 16-row panel, the 128-column tiles that hold anything -- fused with the row scaling when there is one -- and
+    // the product skips every (panel, tile pair) with an empty side.  Worth the pass from ~16 K rows x 4 tiles on.
+    const bool sparse = p->jtj_sparse && n_rows >= 16384 && gst::jtj_mask_tiles((int)n_cols) >= 4 && gst::jtj_mask_tiles((int)n_cols) <= 32;
+    const uint32_t* d_pmask = nullptr;
+    if (sparse) {
+        HIP_TRY(p->d_jtj_pmask.ensure((size_t)gst::jtj_mask_panels(n_rows)));
+        HIP_TRY(gst::launch_jtj_panel_masks(d_J, n_rows, (int)n_cols, ld, d_row_scale, p->d_jtj_pmask.p, p->stream));
+        d_pmask = p->d_jtj_pmask.p;
+    } else if (d_row_scale && n_rows > 0 && n_cols > 0) HIP_TRY(gst::launch_scale_rows(d_J, n_rows, n_cols, ld, d_row_scale, p->stream));
     if (n_cols > 0) {
         const int n_slabs = gst::jtj_num_slabs(n_rows, (int)n_cols);
         HIP_TRY(p->d_jtj_part.ensure((size_t)n_slabs * n_cols * n_cols));
         TIME_REC(p, evk0);
-        HIP_TRY(gst::launch_jtj(d_J, n_rows, (int)n_cols, ld, p->d_jtj_part.p, n_slabs, d_jtj, p->stream));
+        HIP_TRY(gst::launch_jtj(d_J, n_rows, (int)n_cols, ld, p->d_jtj_part.p, n_slabs, d_jtj, p->stream, d_pmask));
         TIME_REC(p, evk1);
     }
     TIME_REC(p, ev1);

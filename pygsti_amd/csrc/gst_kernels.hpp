@@ -178,7 +178,14 @@ hipError_t launch_scale_rows(double* J, int64_t n_rows, int64_t n_cols, int64_t 
 hipError_t launch_symmetrize(double* C, int64_t n, hipStream_t s);
 // Normal equations (gst_kernels_normal.hip): split-K MFMA fp64 J^T J and streaming J^T f
 int jtj_num_slabs(int64_t n_rows, int n_cols);
-hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs, double* C, hipStream_t s);
+// pmask (may be NULL): per 16-row panel, bit t = the panel holds a non-zero in the 128 columns of tile t
+// (launch_jtj_panel_masks; n_cols <= 32 * 128); panels whose two tiles are not both marked are skipped
+hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs, double* C, hipStream_t s,
+                      const uint32_t* pmask = nullptr);
+// one streaming pass over J: the panel masks, and with w != NULL the row scaling J <- diag(w) J as well
+hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t ld, const double* w, uint32_t* pmask, hipStream_t s);
+int jtj_mask_tiles(int n_cols);
+int64_t jtj_mask_panels(int64_t n_rows);
 hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs,
                       double* y, hipStream_t s);
 

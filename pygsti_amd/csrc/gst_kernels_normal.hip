@@ -38,9 +38,15 @@ constexpr int JTJ_LDS_STRIDE = 2 * JTJ_TILE + 8;        // doubles per staged ro
 
 constexpr int JTJ_PANEL = 16;                           // rows staged per barrier
 
+// SPARSITY (round 3): a GST Jacobian is block sparse -- row (circuit, outcome) is exactly zero in the columns of every
+// gate the circuit never applies, 30 % of all 16 x 16 blocks on the 2Q design.  `pmask[k / JTJ_PANEL]` has bit t set
+// when the 16-row panel starting at row k holds ANY non-zero in the 128 columns of tile t (jtj_panel_mask_kernel, one
+// streaming pass over J, fused into the row scaling when there is one); a panel contributes to tile pair (ti, tj) only if
+// both bits are set, and the others are skipped outright -- no fetch, no staging, no MFMAs: exact, since what is
+// skipped is a product with zeros.  On the 2Q design a third of the (panel, tile pair) products go.
 __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __restrict__ J, int64_t n_rows, int n_cols,
                                                               int64_t ld, int64_t slab_rows, int n_tiles,
-                                                              double* __restrict__ part)
+                                                              double* __restrict__ part, const uint32_t* __restrict__ pmask)
 {
     extern __shared__ __attribute__((aligned(16))) double panel_mem[];      // [2][JTJ_PANEL * JTJ_LDS_STRIDE]
     double* const panel0 = panel_mem;
@@ -95,15 +101,25 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __re
 #pragma unroll
             for (int t = 0; t < 4; t++) *(d2_t*)(pan + soff + 8 * u * JTJ_LDS_STRIDE + 2 * t) = g[u][t];
     };
-    if (k_begin < k_end) {
-        fetch(k_begin);
+    // the next panel at or after k that contributes to this tile pair (workgroup-uniform: scalar loads of the masks)
+    auto next_live = [&](int64_t k) -> int64_t {
+        if (pmask) {
+            const uint32_t need = (1u << ti) | (1u << tj);
+            while (k < k_end && (pmask[k / JTJ_PANEL] & need) != need) k += JTJ_PANEL;
+        }
+        return k;
+    };
+    int64_t k = next_live(k_begin);
+    if (k < k_end) {
+        fetch(k);
         stash(panel0);
     }
     __syncthreads();
     int cur = 0;
-    for (int64_t k = k_begin; k < k_end; k += JTJ_PANEL) {
-        const bool more = k + JTJ_PANEL < k_end;
-        if (more) fetch(k + JTJ_PANEL);                          // next panel: global -> registers, lands during the MFMAs
+    while (k < k_end) {
+        const int64_t kn = next_live(k + JTJ_PANEL);
+        const bool more = kn < k_end;
+        if (more) fetch(kn);                                     // next live panel: global -> registers, lands during the MFMAs
         const double* pc = cur ? panel1 : panel0;
 #pragma unroll
         for (int h = 0; h < JTJ_PANEL / 4; h++) {                // 4-row steps of the panel
@@ -119,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __re
         if (more) stash(cur ? panel0 : panel1);
         __syncthreads();
         cur ^= 1;
+        k = kn;
     }
     const int i0 = ti * JTJ_TILE + wi, j0 = tj * JTJ_TILE + wj;
     double* out = part + (int64_t)s * n_cols * n_cols;
@@ -131,6 +148,43 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __re
                 const int row = i0 + 16 * x + lk + 4 * r, col = j0 + 16 * y + lc;
                 if (row < n_cols && col < n_cols) out[(int64_t)row * n_cols + col] = acc[x][y][r];
             }
+}
+
+// Panel masks (and, with `w`, the row scaling J <- diag(w) J in the same pass): one wavefront per (16-row panel, 128-column
+// tile) -- 32 doubles per lane, coalesced 1 KB row segments -- sets bit `tile` of pmask[panel] when anything there is
+// non-zero (after scaling: a zero weight annihilates its row).  pmask must be zeroed before the launch.
+__global__ __launch_bounds__(256) void jtj_panel_mask_kernel(double* __restrict__ J, int64_t n_rows, int n_cols, int64_t ld,
+                                                             const double* __restrict__ w, int n_tiles, uint32_t* __restrict__ pmask)
+{
+    const int64_t n_panels = (n_rows + JTJ_PANEL - 1) / JTJ_PANEL;
+    const int lane = threadIdx.x & 63;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < n_panels * n_tiles; item += (int64_t)gridDim.x * 4) {
+        const int64_t panel = item / n_tiles;
+        const int tile = (int)(item - panel * n_tiles);
+        const int c0 = tile * JTJ_TILE + 2 * lane;
+        bool any = false;
+#pragma unroll 4
+        for (int r = 0; r < JTJ_PANEL; r++) {
+            const int64_t row = panel * JTJ_PANEL + r;
+            if (row >= n_rows) break;
+            double* p = J + row * ld + c0;
+            const double ws = w ? w[row] : 1.0;
+            if (c0 + 1 < n_cols && (((uintptr_t)p & 15) == 0)) {
+                typedef double d2_t __attribute__((ext_vector_type(2)));
+                d2_t x = *(d2_t*)p;
+                if (w) { x.x *= ws; x.y *= ws; *(d2_t*)p = x; }
+                any = any || x.x != 0.0 || x.y != 0.0;
+            } else {
+                for (int q = 0; q < 2; q++)
+                    if (c0 + q < n_cols) {
+                        double x = p[q];
+                        if (w) { x *= ws; p[q] = x; }
+                        any = any || x != 0.0;
+                    }
+            }
+        }
+        if (__ballot(any) != 0 && lane == 0) atomicOr(&pmask[panel], 1u << tile);
+    }
 }
 
 // JtJ[r][c] = sum over slabs of part[s][min][max] (the computed triangle, in units of whole tiles), mirrored
@@ -428,8 +482,24 @@ int jtj_num_slabs(int64_t n_rows, int n_cols)
     return slabs;
 }
 
+hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t ld, const double* w, uint32_t* pmask, hipStream_t s)
+{
+    const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
+    if (n_tiles > 32 || n_rows <= 0) return hipErrorInvalidValue;
+    const int64_t n_panels = (n_rows + JTJ_PANEL - 1) / JTJ_PANEL;
+    (void)hipGetLastError();
+    hipError_t e = hipMemsetAsync(pmask, 0, (size_t)n_panels * 4, s);
+    if (e != hipSuccess) return e;
+    const int64_t items = n_panels * n_tiles;
+    hipLaunchKernelGGL(jtj_panel_mask_kernel, dim3((unsigned)std::min<int64_t>((items + 3) / 4, 65536)), dim3(256), 0, s, J, n_rows, n_cols, ld, w,
+                       n_tiles, pmask);
+    return hipGetLastError();
+}
+int jtj_mask_tiles(int n_cols) { return (n_cols + JTJ_TILE - 1) / JTJ_TILE; }
+int64_t jtj_mask_panels(int64_t n_rows) { return (n_rows + JTJ_PANEL - 1) / JTJ_PANEL; }
+
 hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs, double* C,
-                      hipStream_t s)
+                      hipStream_t s, const uint32_t* pmask)
 {
     const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
@@ -442,7 +512,7 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
         if (ea != hipSuccess) return ea;
     }
     hipLaunchKernelGGL(jtj_mfma_lds_kernel, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld,
-                       slab_rows, n_tiles, part);
+                       slab_rows, n_tiles, part, pmask);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(jtj_reduce_kernel, dim3(2048), dim3(256), 0, s, part, n_slabs, n_cols, C);

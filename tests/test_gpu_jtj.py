@@ -113,3 +113,54 @@ def test_jtj_on_the_2q_design_jacobian():
     assert (np.abs(jtj - want) <= 1e-12 * scale).all(), np.abs((jtj - want) / scale).max()
     assert np.abs(jtf - J.T @ f).max() <= 1e-12 * np.abs(J.T @ f).max()
     for d in (d_J, d_jtj, d_jtf, d_f): pl.device_free(d)
+
+
+@pytest.mark.parametrize("sparse", ["1", "0"])
+def test_jtj_block_sparse_jacobian(sparse, monkeypatch):
+    """Round 3: panels (16 rows) whose 128-column tiles hold only zeros are skipped (GST_JTJ_SPARSE=1, default) -- exact,
+    what is skipped is a product with zeros.  A synthetic Jacobian with the structure of a GST one: groups of rows that are
+    zero in whole column blocks (block edges NOT aligned with the 128-column tiles or the 16-row panels), single non-zeros
+    in otherwise empty tiles, all-zero rows, zero row weights; with and without the row scale; the same bits as the dense
+    form of the kernel (GST_JTJ_SPARSE=0) and numpy to 1e-12."""
+    monkeypatch.setenv("GST_JTJ_SPARSE", sparse)
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    pl = plan_from_fixture(fx)
+    rng = np.random.default_rng(42)
+    n_rows, n_cols, ld = 20011, 730, 733
+    Jp = rng.standard_normal((n_rows, ld))
+    edges = [0, 80, 336, 592, 730]                                   # "SPAM" then three "gates"
+    r = 0
+    while r < n_rows:
+        n = int(rng.integers(3, 90))
+        for b in range(1, 4):
+            if rng.random() < 0.45:
+                Jp[r:r + n, edges[b]:edges[b + 1]] = 0.0
+        if rng.random() < 0.05:
+            Jp[r:r + n, :] = 0.0
+        r += n
+    Jp[977, 400] = 3.0; Jp[12001, 729] = -2.0                         # lone non-zeros
+    J = Jp[:, :n_cols]
+    w = rng.random(n_rows) + 0.5
+    w[rng.random(n_rows) < 0.1] = 0.0
+    d_J = pl.device_malloc(Jp.nbytes); d_jtj = pl.device_malloc(n_cols * n_cols * 8); d_w = pl.device_malloc(n_rows * 8)
+    pl.memcpy_h2d(d_J, Jp); pl.memcpy_h2d(d_w, w)
+    pl.fill_jtj_dev(d_J, n_rows, n_cols, ld, d_jtj)
+    got = pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_jtj)
+    want = J.T @ J
+    scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1e-300
+    assert (np.abs(got - want) <= 1e-12 * scale).all(), np.abs((got - want) / scale).max()
+    assert np.array_equal(got, got.T)
+    pl.fill_jtj_dev(d_J, n_rows, n_cols, ld, d_jtj, d_w)             # scales J in place, once
+    got_s = pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_jtj)
+    Js = J * w[:, None]
+    want = Js.T @ Js
+    scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1e-300
+    assert (np.abs(got_s - want) <= 1e-12 * scale).all()
+    back = pl.memcpy_d2h(np.empty((n_rows, ld)), d_J)
+    assert np.array_equal(back[:, :n_cols], Js) and np.array_equal(back[:, n_cols:], Jp[:, n_cols:])    # padding untouched
+    test_jtj_block_sparse_jacobian.results = getattr(test_jtj_block_sparse_jacobian, "results", {})
+    test_jtj_block_sparse_jacobian.results[sparse] = (got, got_s)
+    if len(test_jtj_block_sparse_jacobian.results) == 2:
+        a, b = test_jtj_block_sparse_jacobian.results["1"], test_jtj_block_sparse_jacobian.results["0"]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), "skipping zero panels must not change a bit"
+    for d in (d_J, d_jtj, d_w): pl.device_free(d)
