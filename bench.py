@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1: weak = one full design per rank (N designs in all); strong = one design dealt to N atoms")
     ap.add_argument("--no-analytic", action="store_true", help="skip the secondary analytic-derivative timing")
+    ap.add_argument("--keep-zeros", action="store_true", help="analytic legs: GST_OPT_ANALYTIC_KEEP_ZEROS (structural zeros of a re-used destination are not stored again)")
     ap.add_argument("--no-other-configs", action="store_true", help="N=1: skip the secondary legs of the other BASELINE configurations (1Q, 3Q, Hessian block)")
     ap.add_argument("--no-cptplnd", action="store_true", help="N=1: skip the secondary CPTPLND (Lindblad-parameterised) Jacobian timing")
     ap.add_argument("--emulate-ranks", type=int, default=0,
@@ -271,6 +272,8 @@ def main():
     pidx = np.arange(nP, dtype=np.int64)
 
     mode = _lib.DERIV_ANALYTIC if args.deriv == "analytic" else _lib.DERIV_FD
+    if args.keep_zeros:
+        plan.set_option(_lib.OPT_ANALYTIC_KEEP_ZEROS, 1)
     exchange = None
     if world > 1:
         exchange = {"transport": ctx.transport, "rccl_ranks": world if ctx.transport == "rccl" else 0,

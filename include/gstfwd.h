@@ -124,6 +124,17 @@ typedef struct {
 } gst_stats;
 
 int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *opt, gst_plan **out);
+
+/* Run-time options of a plan.
+ *   GST_OPT_ANALYTIC_KEEP_ZEROS (value 0 / 1): a promise about the DESTINATIONS of GST_DERIV_ANALYTIC Jacobians (D = 16).
+ *       Entry (element of circuit c, parameter of gate g) is an exact zero when c never applies g -- 30 % of a GST Jacobian.
+ *       With the option on, a fill whose destination pointer, leading dimension and column request equal the previous
+ *       analytic fill's does not store those zeros again: the caller promises that nothing but row scalings
+ *       (gst_fill_jtj_dev's d_row_scale, which keeps zeros zero) was written into that buffer in between -- what an
+ *       optimizer does that reuses one device Jacobian every iteration.  The first fill into a destination (and any fill
+ *       after the destination, the columns or the option changed) writes everything.  Off by default. */
+#define GST_OPT_ANALYTIC_KEEP_ZEROS 1
+int gst_set_option(gst_plan *plan, int32_t option, int64_t value);
 int gst_plan_create_from_circuits(const gst_circuits_desc *desc, const gst_options *opt, gst_plan **out);
 int gst_plan_destroy(gst_plan *plan);
 

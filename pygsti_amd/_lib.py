@@ -16,6 +16,7 @@ GST_OK = 0
 GST_EINVAL, GST_ENODEVICE, GST_EHIP, GST_ENOMEM, GST_ESTATE, GST_EUNSUPPORTED = -1, -2, -3, -4, -5, -6
 KIND_NONE, KIND_GATE, KIND_RHO, KIND_EFFECT = -1, 0, 1, 2
 DERIV_FD, DERIV_ANALYTIC = 0, 1
+OPT_ANALYTIC_KEEP_ZEROS = 1
 OBJ_CHI2, OBJ_POISSON_DLOGL = 0, 1
 TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1
 COMM_ID_BYTES = 128
@@ -81,7 +82,7 @@ EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_p
            "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_get_fd_queues", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
-           "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
+           "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
            "gst_comm_get_unique_id", "gst_comm_create", "gst_comm_destroy", "gst_comm_allgather_rows",
            "gst_comm_gather_rows", "gst_comm_allreduce_sum", "gst_comm_barrier", "gst_comm_sync", "gst_comm_get_info"]
 
@@ -129,6 +130,7 @@ def lib():
         L.gst_device_count.argtypes = [C.POINTER(i32)]
         L.gst_fill_dprobs_models.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp]
         L.gst_fill_dprobs_models_dev.argtypes = [vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp]
+        L.gst_set_option.argtypes = [vp, i32, i64]
         L.gst_set_lindblad.argtypes = [vp, i32, i32, C.POINTER(LindbladMemberDesc), i64, vp, vp]
         L.gst_set_lindblad_params.argtypes = [vp, vp]
         L.gst_get_model.argtypes = [vp, vp, vp, vp]
@@ -326,6 +328,10 @@ class Plan:
         der = _f64(np.concatenate([np.ascontiguousarray(o[3], np.float64).ravel() for o in objs]))
         check(lib().gst_set_derivs(self._h, int(n_params), len(objs), _ptr(kind), _ptr(obj), _ptr(ncols), _ptr(pidx), _ptr(der)))
         self.n_params = int(n_params)
+
+    def set_option(self, option, value):
+        """gst_set_option: OPT_ANALYTIC_KEEP_ZEROS, ..."""
+        check(lib().gst_set_option(self._h, int(option), int(value)))
 
     def set_lindblad(self, model):
         """Lindblad-parameterised members built on the device (gst_set_lindblad): `model` is a

@@ -128,6 +128,10 @@ struct gst_plan {
     bool ana_stream = true;             // GST_ANALYTIC_STREAM=0: two-circuit items gate by gate (tail, then the two prefixes)
     bool ana_pairs = true;              // GST_ANALYTIC_PAIRS=0: one circuit per work item in the D = 16 contraction
     bool ana_germ_order = true;         // GST_ANALYTIC_GERM_ORDER=0: pure suffix order of the work items
+    bool ana_keep_zeros = false;        // gst_set_option(GST_OPT_ANALYTIC_KEEP_ZEROS)
+    const void* ana_zero_out = nullptr; // destination of the last stream-form analytic Jacobian, its leading dimension
+    int64_t ana_zero_ld = 0;
+    bool ana_zero_valid = false;
     bool ana_group_fetch = true;        // GST_ANALYTIC_GROUP=0: every wavefront of the D = 16 contraction pulls its items alone
     DevBuf<double> d_rev_cache;
     DevBuf<uint32_t> d_work_counter, d_range_begin;
@@ -1011,7 +1015,8 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     int rc = run_probs(p, d_base, n_param > 0, will_fork && n_param > 0 ? 2 : 1);        // probabilities + every forward state
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
-    if (!p->request_cached(2, param_idx, dest_idx, n_param)) {
+    const bool request_was_cached = p->request_cached(2, param_idx, dest_idx, n_param);
+    if (!request_was_cached) {
         const int D = h.D, DD = D * D;
         std::vector<int32_t> cm_gate((size_t)std::max(h.n_gates, 1) * DD, -1), cm_rho((size_t)h.n_rhos * D, -1),
             cm_eff((size_t)h.n_effects * D, -1), col0(std::max(h.n_gates, 1), -2);
@@ -1118,6 +1123,12 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         a.pos_ptr = p->d_pos_ptr.p; a.circ_rho = p->d_circ_rho.p; a.circ_order = p->d_circ_order.p; a.work_counter = p->d_work_counter.p; a.range_begin = p->d_range_begin.p;
         a.group_fetch = p->ana_group_fetch ? 1 : 0;
         if (D == 16 && p->d_blk_ptr.p) { a.blk_f1 = p->d_blk_f1.p; a.blk_f2 = p->d_blk_f2.p; a.blk_r = p->d_blk_r.p; a.blk_ptr = p->d_blk_ptr.p; }
+        // GST_OPT_ANALYTIC_KEEP_ZEROS: the blocks of gates an item never applies are exact zeros; when THIS destination got
+        // THIS request last time (and the caller promised, by setting the option, to write nothing but row scalings into it
+        // in between) they are zero already and are not stored again -- a third of the D = 16 contraction's stores
+        const bool same_dest = p->ana_zero_out == (const void*)d_out && p->ana_zero_ld == ld && p->ana_zero_valid && request_was_cached;
+        a.zeros_resident = (p->ana_keep_zeros && same_dest && !p->derivs_set) ? 1 : 0;
+        p->ana_zero_out = d_out; p->ana_zero_ld = ld; p->ana_zero_valid = (D == 16);
         HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
         if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
         else if (D == 16) HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
@@ -2664,6 +2675,21 @@ int gst_get_program(const gst_plan* p, uint32_t* words, int64_t cap, int64_t* n_
     if (task_off && cap_tasks >= (int64_t)h.task_off.size())
         std::memcpy(task_off, h.task_off.data(), sizeof(int64_t) * h.task_off.size());
     return GST_OK;
+    });
+}
+
+int gst_set_option(gst_plan* p, int32_t option, int64_t value)
+{
+    return guarded([&]() -> int {
+    if (!p) return fail(GST_EINVAL, "plan is NULL");
+    switch (option) {
+    case GST_OPT_ANALYTIC_KEEP_ZEROS:
+        p->ana_keep_zeros = value != 0;
+        p->ana_zero_valid = false;            // the promise starts now: the next fill writes every zero
+        return GST_OK;
+    default:
+        return fail(GST_EINVAL, "unknown option " + std::to_string(option));
+    }
     });
 }
 

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                 // (written out on its own, with no accumulator array handed to `store_block` from inside a run-time loop:
                 //  that puts the arrays -- the live MFMA accumulators included -- into scratch memory)
                 auto zero_gates = [&](int g_from, int g_to) {
-                    if (a.accumulate) return;                  // (adding zeros)
+                    if (a.accumulate || a.zeros_resident) return;      // (adding zeros; or zeros the destination already holds)
                     for (int g = g_from; g < g_to; g++) {
                         const int32_t c0 = __builtin_amdgcn_readlane(c0_l, g);
                         if (c0 == -2) continue;
@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                 const int64_t p0 = as_const(a.pos_ptr)[c * nG + g], p1 = as_const(a.pos_ptr)[c * nG + g + 1];
                 const int64_t q0 = as_const(a.pos_ptr)[c2 * nG + g], q1 = as_const(a.pos_ptr)[c2 * nG + g + 1];
                 const int64_t cg = (int64_t)as_const(a.pair_common)[ci * nG + g];
+                if (a.zeros_resident && p1 == p0 && q1 == q0) continue;      // neither circuit applies g: zeros the destination already holds
                 d4_t acc[NX], acc2[NX];
 #pragma unroll
                 for (int x = 0; x < NX; x++) { acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc2[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
@@ -644,6 +645,7 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                 const int32_t c0 = as_const(a.gate_col0)[g];
                 if (c0 == -2) continue;                                // no parameter of this gate was requested
                 const int64_t p0 = as_const(a.pos_ptr)[c * nG + g], p1 = as_const(a.pos_ptr)[c * nG + g + 1];
+                if (a.zeros_resident && p1 == p0) continue;                  // g never applied: zeros the destination already holds
                 d4_t acc[NX];
 #pragma unroll
                 for (int x = 0; x < NX; x++) acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0};

@@ -191,3 +191,51 @@ def test_analytic_fill_overwrites_every_requested_entry(stream, monkeypatch):
     zero = (fx["dprobs_map"] == 0.0)
     assert np.abs(J[:, cols][zero]).max() <= 1e-8
     pl.device_free(d_J)
+
+
+def test_analytic_keep_zeros_option():
+    """GST_OPT_ANALYTIC_KEEP_ZEROS: a repeated analytic fill into the SAME destination with the SAME columns does not
+    store the structural zeros again.  First fill: everything is written (the destination is pre-filled with NaN);
+    second fill into the same device buffer: same bits; the zeros really are skipped (a sentinel planted in a
+    structural-zero entry survives the second fill, and is overwritten again as soon as the columns, the destination or
+    the option change)."""
+    from pygsti_amd import _lib
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    pl = plan_from_fixture(fx)
+    nE, nP = int(fx["nE"]), int(fx["nP"])
+    cols = np.arange(nP)
+    ref = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    pl.set_option(_lib.OPT_ANALYTIC_KEEP_ZEROS, 1)
+    d = pl.device_malloc(nE * nP * 8)
+    pl.memcpy_h2d(d, np.full(nE * nP, np.nan))
+    pl.fill_dprobs_dev(d, nP, cols, None, 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
+    J1 = pl.memcpy_d2h(np.empty((nE, nP)), d)
+    assert np.array_equal(J1, ref)
+    # a structural zero: an element whose circuit never applies some gate (a whole 256-column block of exact zeros)
+    # (a sentinel in every such block: the ones of work items none of whose circuits applies the gate are skipped; a
+    #  circuit paired with one that does apply it still gets its zeros stored with the partner's block)
+    blocks = np.abs(J1[:, 80:]).reshape(nE, -1, 256).max(2)
+    zb = np.argwhere(blocks == 0.0)
+    assert len(zb) > 100
+    poisoned = J1.copy()
+    pos = zb[:, 0] * nP + 80 + 256 * zb[:, 1] + 5
+    poisoned.ravel()[pos] = 123.456
+    pl.memcpy_h2d(d, poisoned)
+    pl.fill_dprobs_dev(d, nP, cols, None, 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
+    J2 = pl.memcpy_d2h(np.empty((nE, nP)), d)
+    kept = J2.ravel()[pos] == 123.456
+    assert kept.sum() > 0.3 * len(pos), "structural zeros of whole items must not have been stored again (%d of %d kept)" % (kept.sum(), len(pos))
+    J2.ravel()[pos[kept]] = 0.0
+    assert np.array_equal(J2, ref)
+    pos = int(pos[kept][0]); planted = np.array([123.456])
+    # another column request: everything is written again
+    pl.fill_dprobs_dev(d, nP, cols[::-1].copy(), np.arange(nP)[::-1].copy(), 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
+    assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), d), ref)
+    # option off: zeros stored every time
+    pl.memcpy_h2d(d + pos * 8, planted)
+    pl.set_option(_lib.OPT_ANALYTIC_KEEP_ZEROS, 0)
+    pl.fill_dprobs_dev(d, nP, cols[::-1].copy(), np.arange(nP)[::-1].copy(), 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
+    assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), d), ref)
+    pl.device_free(d)
+    with pytest.raises(ValueError):
+        pl.set_option(99, 1)
