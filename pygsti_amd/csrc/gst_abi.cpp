@@ -204,6 +204,7 @@ struct gst_plan {
     int64_t host_direct_min_cols = 64;  // (narrower column windows would cross PCIe in segments shorter than a wavefront's 512 bytes)
     int fd_handover = 1;                // GST_FD_HANDOVER: 0 never cut a walk, 1 cut to balance the per-SIMD queues, 2 cut every walk
     bool fd_overlap = true;             // GST_FD_OVERLAP=0: the persistent FD launch keeps the separate base pass in front of it
+    double test_cache_limit = 0;        // GST_TEST_CACHE_LIMIT (bytes; tests): stands in for the 4 GB of 32-bit cache offsets
     bool jtj_sparse = true;             // GST_JTJ_SPARSE=0: J^T J multiplies every panel (round-2 form)
     DevBuf<uint32_t> d_jtj_pmask;
     bool fd_overlap_diag = false;       // GST_FD_OVERLAP=2 (measurements): the overlap kernel, but base pass in front and no chains
@@ -327,6 +328,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_FD_STANDBY")) p->fd_standby = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_LB_SHARE")) p->lb_share = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_JTJ_SPARSE")) p->jtj_sparse = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_TEST_CACHE_LIMIT")) p->test_cache_limit = std::atof(e);
     if (const char* e = std::getenv("GST_FD_TEST_SKIP_CHAINS")) p->test_skip_chains = std::atoi(e) != 0;
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
@@ -1073,7 +1075,11 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     a.gate_col0 = p->d_gate_col0.p; a.colmap_gate = p->d_cm_gate.p; a.colmap_rho = p->d_cm_rho.p; a.colmap_eff = p->d_cm_eff.p;
     a.out = d_out; a.ld = ld;
     // (the MFMA kernel addresses both state caches with 32-bit byte offsets)
-    const bool caches_small = (double)h.n_state_ids * D * 8 < 4.0e9;
+    // Above that the plan DEGRADES instead of failing: D <= 16 Jacobians take the single backward-walking kernel (64-bit
+    // addressing, no backward cache at all); only what has no such form -- D = 64, exact Hessians -- is refused.
+    // (GST_TEST_CACHE_LIMIT: tests lower the 4 GB to exercise that path on a small plan.)
+    const double cache_limit = p->test_cache_limit > 0 ? p->test_cache_limit : 4.0e9;
+    const bool caches_small = (double)h.n_state_ids * D * 8 < cache_limit;
     if (D == 64 && !caches_small) return fail(GST_EUNSUPPORTED, "forward-state cache exceeds 4 GB");
     // the two-cache contraction: MFMA at D = 16 / 64; at D = 4 (VALU) only when a Hessian needs its tables -- a plain 1Q
     // Jacobian is launch-bound and the single backward-walking kernel below is one launch instead of three
@@ -1083,10 +1089,15 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (!chain_ok && p->want_cache_path)
         return fail(GST_EUNSUPPORTED, "exact Hessians at D <= 16 need the gate set in LDS (at most " +
                                           std::to_string(128 * 1024 / (D * D * 8)) + " gates at this D)");
+    bool rev_small = true;
     if (will_fork && caches_small && chain_ok) {
         if ((rc = ensure_reverse(p))) return rc;
-        if ((double)p->rev.n_state_ids * h.n_effects * D * 8 >= 4.0e9)
-            return fail(GST_EUNSUPPORTED, "backward-state cache exceeds 4 GB: set GST_ANALYTIC_MFMA=0 for this plan");
+        rev_small = (double)p->rev.n_state_ids * h.n_effects * D * 8 < cache_limit;
+        if (!rev_small && (D == 64 || p->want_cache_path))
+            return fail(GST_EUNSUPPORTED, "backward-state cache exceeds 4 GB: split the circuits over more atoms");
+        if (!rev_small) HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));      // (nothing runs beside the forward pass after all)
+    }
+    if (will_fork && caches_small && chain_ok && rev_small) {
         // backward states: the chain kernel over the reversed plan, transposed gates (= the row-major array), one lane
         // group per effect (64/D effects per pass)
         gst::WalkArgs w;

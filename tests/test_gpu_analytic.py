@@ -239,3 +239,24 @@ def test_analytic_keep_zeros_option():
     pl.device_free(d)
     with pytest.raises(ValueError):
         pl.set_option(99, 1)
+
+
+def test_state_caches_beyond_32bit_offsets_degrade_to_the_single_kernel(monkeypatch):
+    """The two-cache MFMA contraction addresses its state caches with 32-bit byte offsets (4 GB each).  A plan whose
+    backward-state cache is larger no longer fails: D <= 16 Jacobians take the single backward-walking kernel (64-bit
+    addressing, no backward cache).  GST_TEST_CACHE_LIMIT stands in for the 4 GB so that a small plan takes that route:
+    same Jacobian as the default path to 1e-10, as the Matrix simulator's to 1e-8; exact Hessian blocks, which have no
+    such form, are refused with GST_EUNSUPPORTED (a RuntimeError), not computed wrongly."""
+    from pygsti_amd import _lib
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    cols = fx["dprobs_cols"]
+    ref = plan_from_fixture(fx).fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    pl0 = plan_from_fixture(fx)
+    st = pl0.stats()
+    monkeypatch.setenv("GST_TEST_CACHE_LIMIT", str(st["trie_nodes"] * 16 * 8 * 2))     # forward cache fits, the 4-effect backward cache does not
+    pl = plan_from_fixture(fx)
+    J = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    assert np.abs(J - ref).max() < 1e-10
+    assert np.abs(J[fx["matrix_rows"]] - fx["dprobs_matrix"]).max() < 1e-8
+    with pytest.raises(RuntimeError):
+        pl.fill_hprobs(idx1=cols[:2], idx2=cols[:4], mode=_lib.DERIV_ANALYTIC)
