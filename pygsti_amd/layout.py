@@ -74,7 +74,8 @@ class HipLayoutAtom:
             for k, ci in enumerate(self.circuit_indices):
                 eff_label[eff_ptr[k]:eff_ptr[k + 1]] = L._out_idx[L._out_ptr[ci]:L._out_ptr[ci + 1]]
             eff_dest = np.arange(int(eff_ptr[-1]), dtype=np.int32)
-            self._plan = _lib.Plan.from_circuits(L.dim, L.num_gates, 1, nO, int(eff_ptr[-1]), np.zeros(n, np.int32), ptr,
+            self._plan = _lib.Plan.from_circuits(L.dim, L.num_gates, L.num_preps, nO, int(eff_ptr[-1]),
+                                                 L._circ_rho[self.circuit_indices].astype(np.int32), ptr,
                                                  gates, eff_ptr, eff_label, eff_dest, device=self.device,
                                                  target_tasks=L.target_tasks, max_slots=L.max_slots)
         return self._plan
@@ -90,18 +91,41 @@ class HipCOPALayout:
         self.dim = model.dim
         self.effect_labels = model.effect_labels
         self._outcomes = [tuple([lbl.split("_", 1)[1]]) for lbl in self.effect_labels]
-        self.num_outcomes = len(self._outcomes)
+        self.num_outcomes = len(self._outcomes)          # effect vectors of the plan (all POVMs)
+        # Several state preparations / POVMs (maplayout.py:101-134 handles `rho_labels` and per-circuit effect sets): a
+        # circuit then names its preparation first and its POVM last, as the reference's completed circuits do
+        # (models/model.py:1439-1631); with one of each they stay implicit.
+        self.prep_labels = list(model.preps.keys())
+        self.povm_labels = list(model.povms.keys())
+        self.num_preps = len(self.prep_labels)
+        prep_of = {l: i for i, l in enumerate(self.prep_labels)}
+        povm_of = {l: i for i, l in enumerate(self.povm_labels)}
+        povm_effects = [[k for k, lbl in enumerate(self.effect_labels) if lbl.split("_", 1)[0] == pl] for pl in self.povm_labels]
+        self._circ_rho = np.zeros(self.num_circuits, np.int64)
+        self._circ_povm = np.zeros(self.num_circuits, np.int64)
+        gate_only = []
+        for i, c in enumerate(self.circuits):
+            if c and c[0] in prep_of and c[0] not in self.model_gate_labels:
+                self._circ_rho[i] = prep_of[c[0]]; c = c[1:]
+            elif self.num_preps != 1:
+                raise ValueError("circuit %d does not name its state preparation and the model has %d" % (i, self.num_preps))
+            if c and c[-1] in povm_of and c[-1] not in self.model_gate_labels:
+                self._circ_povm[i] = povm_of[c[-1]]; c = c[:-1]
+            elif len(self.povm_labels) != 1:
+                raise ValueError("circuit %d does not name its POVM and the model has %d" % (i, len(self.povm_labels)))
+            gate_only.append(c)
+        self._gate_circuits = gate_only                    # the circuits without their SPAM labels
         self.target_tasks = target_tasks
         self.max_slots = max_slots
         self.pin_arrays = True          # allocate_local_array page-locks large element-dimension arrays
         self.last_array_pinned = False
         self._num_params = model.num_params
         lookup = {l: i for i, l in enumerate(self.model_gate_labels)}
-        self._circ_len = np.fromiter((len(c) for c in self.circuits), dtype=np.int64, count=self.num_circuits)
+        self._circ_len = np.fromiter((len(c) for c in self._gate_circuits), dtype=np.int64, count=self.num_circuits)
         self._circ_ptr = np.zeros(self.num_circuits + 1, np.int64)
         np.cumsum(self._circ_len, out=self._circ_ptr[1:])
         # (C-level iteration: 32 M labels for the 2Q L<=1024 design)
-        self._circ_gates = np.fromiter(map(lookup.__getitem__, itertools.chain.from_iterable(self.circuits)),
+        self._circ_gates = np.fromiter(map(lookup.__getitem__, itertools.chain.from_iterable(self._gate_circuits)),
                                        dtype=np.int32, count=int(self._circ_ptr[-1]))
         self._rank, self._size = rank, size
         self._mpi_comm = mpi_comm       # optional mpi4py-style communicator of the caller's ResourceAllocation
@@ -112,13 +136,18 @@ class HipCOPALayout:
         # the circuit (tuple of gate labels) that returns an object with `.outcomes` or an iterable of outcome labels
         # ('01' or ('01',)).
         nO = self.num_outcomes
-        if dataset is None:
+        if dataset is None and len(self.povm_labels) == 1:
             self._out_ptr = np.arange(self.num_circuits + 1, dtype=np.int64) * nO
             self._out_idx = np.tile(np.arange(nO, dtype=np.int32), self.num_circuits)
+        elif dataset is None:                              # every outcome of the circuit's own POVM
+            cnt = np.array([len(e) for e in povm_effects], np.int64)[self._circ_povm]
+            self._out_ptr = np.zeros(self.num_circuits + 1, np.int64)
+            np.cumsum(cnt, out=self._out_ptr[1:])
+            self._out_idx = np.concatenate([np.asarray(povm_effects[k], np.int32) for k in self._circ_povm]) if self.num_circuits else np.zeros(0, np.int32)
         else:
-            lookup_o = {o: k for k, o in enumerate(self._outcomes)}
             ptr = np.zeros(self.num_circuits + 1, np.int64); idx = []
             for i, c in enumerate(self.circuits):
+                lookup_o = {self._outcomes[k]: k for k in povm_effects[self._circ_povm[i]]}
                 row = dataset[c]
                 # the reference's Map layout takes `unique_outcomes` (maplayout.py:69, mapforwardsim.py:358): a row of
                 # time-stamped data lists an outcome once per time stamp in `.outcomes`
@@ -133,7 +162,7 @@ class HipCOPALayout:
                         idx.append(lookup_o[o])
                 ptr[i + 1] = len(idx)
             self._out_ptr, self._out_idx = ptr, np.asarray(idx, np.int32)
-        self._has_dataset = dataset is not None
+        self._has_dataset = dataset is not None or len(self.povm_labels) != 1      # (outcome sets differ per circuit)
 
         # ---- deal circuits to atoms ------------------------------------------------------------------
         num_atoms = max(1, int(num_atoms or 1))
@@ -167,13 +196,14 @@ class HipCOPALayout:
     def _partition(self, num_atoms):
         if num_atoms == 1:
             return [np.arange(self.num_circuits)]
-        order = sorted(range(self.num_circuits), key=lambda i: self.circuits[i])
+        keyed = [(int(self._circ_rho[i]),) + tuple(self._gate_circuits[i]) for i in range(self.num_circuits)]
+        order = sorted(range(self.num_circuits), key=lambda i: tuple(str(x) for x in keyed[i]))
         lcp = np.zeros(self.num_circuits, np.int64)
         cost = np.zeros(self.num_circuits, np.int64)
         for k, ci in enumerate(order):
-            c = self.circuits[ci]
+            c = keyed[ci]
             if k:
-                p = self.circuits[order[k - 1]]
+                p = keyed[order[k - 1]]
                 n = min(len(p), len(c)); j = 0
                 while j < n and p[j] == c[j]: j += 1
                 lcp[k] = j
@@ -306,7 +336,7 @@ class HipCOPALayout:
     # ---- model arrays in plan order -------------------------------------------------------------------------------
     def model_arrays(self, model):
         gates = np.array([model.operations[l] for l in self.model_gate_labels], dtype=np.float64)
-        rhos = np.array([next(iter(model.preps.values()))], dtype=np.float64)
+        rhos = np.array([model.preps[l] for l in self.prep_labels], dtype=np.float64)
         effects = np.array([model.effect_vector(l) for l in self.effect_labels], dtype=np.float64)
         return gates, rhos, effects
 
@@ -314,9 +344,9 @@ class HipCOPALayout:
         """(kind, obj, elem) of every model parameter, object indices in plan order."""
         nP = model.num_params
         kind = -np.ones(nP, np.int32); obj = np.zeros(nP, np.int32); elem = np.zeros(nP, np.int32)
-        rho_label = next(iter(model.preps.keys()))
-        s = model.gpindices(KIND_RHO, rho_label)
-        kind[s] = KIND_RHO; obj[s] = 0; elem[s] = np.arange(s.stop - s.start)
+        for i, rho_label in enumerate(self.prep_labels):
+            s = model.gpindices(KIND_RHO, rho_label)
+            kind[s] = KIND_RHO; obj[s] = i; elem[s] = np.arange(s.stop - s.start)
         for i, l in enumerate(self.effect_labels):
             s = model.gpindices(KIND_EFFECT, l)
             kind[s] = KIND_EFFECT; obj[s] = i; elem[s] = np.arange(s.stop - s.start)

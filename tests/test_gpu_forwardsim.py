@@ -207,3 +207,28 @@ def test_two_phase_fills_over_several_atoms_bitwise():
     assert_bitwise(_by_circuit(p, layout, circuits), fx["probs"], "two-phase probs")
     assert_bitwise(_by_circuit(pr, layout, circuits), fx["probs"], "two-phase pr_array_to_fill")
     assert_bitwise(_by_circuit(J, layout, circuits), fx["dprobs_map"], "two-phase dprobs")
+
+
+def test_several_preparations_and_povms_on_device():
+    """Two preparations, two POVMs (2 and 3 effects) through the host mirror's simulator: probabilities, FD Jacobian and an
+    FD-of-FD Hessian block bit-identical to the reference's vectors (tests/golden/smq1Q_multispam_L2.npz), whatever the
+    number of atoms."""
+    from test_host_mirror import _multispam_case
+    fx, model, circuits, ref = _multispam_case()
+    for natoms in (1, 2):
+        sim = HipMapForwardSimulator(model, num_atoms=natoms)
+        lay = sim.create_layout(circuits)
+        nE, nP = lay.num_elements, model.num_params
+        mine = np.empty(nE, np.int64)                      # my element -> the reference's element
+        for i in range(len(circuits)):
+            sl = lay.indices_for_index(i)
+            mine[sl] = [ref[(i, o[0])] for o in lay.outcomes_for_index(i)]
+        p = np.empty(nE); sim.bulk_fill_probs(p, lay)
+        assert_bitwise(p, fx["probs"][mine], "probs, %d atoms" % natoms)
+        J = np.empty((nE, nP)); sim.bulk_fill_dprobs(J, lay)
+        assert_bitwise(J[:, fx["dprobs_cols"]], fx["dprobs_map"][mine], "dprobs, %d atoms" % natoms)
+        if natoms == 1:
+            r, c = fx["hprobs_rows"], fx["hprobs_cols"]
+            H = np.empty((nE, len(r), len(c)))
+            sim._bulk_fill_hprobs_atom(H, None, None, lay.atoms[0], r, c)
+            assert_bitwise(H, fx["hprobs_map"][mine], "hprobs block")

@@ -217,3 +217,74 @@ def test_fill_jtj_refuses_to_return_a_partial_sum():
     lay = HipMapForwardSimulator(MP.smq1Q_XYI.target_model(), num_atoms=2).create_layout(
         MP.smq1Q_XYI.create_gst_circuits(1), resource_alloc=_RA())
     assert lay._size == 2 and isinstance(lay._mpi_comm, _FakeMPI)
+
+
+def _multispam_case():
+    """The reference's two-preparation / two-POVM model and circuits of tests/golden/smq1Q_multispam_L2.npz, rebuilt for
+    the host mirror: circuits name their preparation first and their POVM last (make_golden.py 'multispam')."""
+    from collections import OrderedDict
+    from pygsti_amd.model import ExplicitDenseModel
+    fx = load_fixture("smq1Q_multispam_L2")
+    ops = OrderedDict((str(l), fx["gates"][i]) for i, l in enumerate(fx["op_labels"]))
+    preps = OrderedDict((str(l), fx["rhos"][i]) for i, l in enumerate(fx["rho_labels"]))
+    eff = {str(l): fx["effects"][i] for i, l in enumerate(fx["eff_labels"])}
+    povms = OrderedDict([("Mdefault", OrderedDict([("0", eff["Mdefault_0"]), ("1", eff["Mdefault_1"])])),
+                         ("Mtri", OrderedDict([("a", eff["Mtri_a"]), ("b", eff["Mtri_b"]), ("c", eff["Mtri_c"])]))])
+    model = ExplicitDenseModel(ops, preps, povms)
+    # the expanded circuits from the reference's prefix table: a row starts from a preparation or from the cached state of
+    # an earlier row and appends its gates; the elements (and through their effect labels the POVM) from the effect CSR
+    R = len(fx["t_dest"])
+    of_cache, full = {}, {}
+    for k in range(R):
+        gates = tuple(str(fx["op_labels"][g]) for g in fx["gate_idx"][fx["row_ptr"][k]:fx["row_ptr"][k + 1]])
+        rho, head = (int(fx["t_rho"][k]), ()) if fx["t_start"][k] < 0 else of_cache[int(fx["t_start"][k])]
+        full[int(fx["t_dest"][k])] = (rho, head + gates)
+        if fx["t_cache"][k] >= 0:
+            of_cache[int(fx["t_cache"][k])] = (rho, head + gates)
+    circuits, ref = [], {}
+    for i in range(R):
+        rho, gates = full[i]
+        lbls = [str(fx["eff_labels"][l]) for l in fx["eff_label"][fx["eff_ptr"][i]:fx["eff_ptr"][i + 1]]]
+        povm = lbls[0].split("_", 1)[0]
+        circuits.append((str(fx["rho_labels"][rho]),) + gates + (povm,))
+        for l, e in zip(lbls, fx["eff_dest"][fx["eff_ptr"][i]:fx["eff_ptr"][i + 1]]):
+            ref[(i, l.split("_", 1)[1])] = int(e)
+    return fx, model, circuits, ref
+
+
+@pytest.mark.parametrize("natoms", [1, 3])
+def test_several_preparations_and_povms_in_the_host_mirror(natoms):
+    """maplayout.py:101-134: an atom carries `rho_labels` and per-circuit effect sets.  The host mirror's layout takes the
+    preparation from the circuit's first label and the POVM from its last; elements are the circuit's own POVM's outcomes;
+    the parameter vector and its (kind, object, element) map cover every preparation and every effect in the reference's
+    order; probabilities through the plan's programs (numpy interpreter) equal the reference's bit for bit."""
+    fx, model, circuits, ref = _multispam_case()
+    assert model.num_params == int(fx["nP"])
+    assert np.array_equal(model.to_vector(), fx["paramvec"])
+    sim = HipMapForwardSimulator(model, num_atoms=natoms)
+    lay = sim.create_layout(circuits)
+    assert lay.num_elements == int(fx["nE"]) and lay.num_preps == 2
+    kind, obj, elem = lay.param_map(model)
+    G, R, E = lay.model_arrays(model)
+    v = model.to_vector()
+    for p_ in range(model.num_params):
+        assert (G, R, E)[kind[p_]][obj[p_]].ravel()[elem[p_]] == v[p_]
+    p = np.full(lay.num_elements, np.nan)
+    for atom in lay.all_atoms:
+        pl = atom.plan()
+        w, off = pl.program()
+        ci = atom.circuit_indices
+        cnt = lay._out_ptr[ci + 1] - lay._out_ptr[ci]
+        eff_ptr = np.concatenate([[0], np.cumsum(cnt)])
+        eff_label = np.concatenate([lay._out_idx[lay._out_ptr[c]:lay._out_ptr[c + 1]] for c in ci])
+        o, written, _ = run_programs(w, off, G, R, E, eff_ptr, eff_label, np.arange(len(eff_label)), len(eff_label))
+        assert (written == 1).all()
+        p[atom.element_slice] = o
+    for i, c in enumerate(circuits):
+        sl = lay.indices_for_index(i)
+        outs = lay.outcomes_for_index(i)
+        assert len(outs) == (2 if c[-1] == "Mdefault" else 3)
+        want = np.array([fx["probs"][ref[(i, o[0])]] for o in outs])
+        assert_bitwise(p[sl], want, "circuit %d %s" % (i, c))
+    with pytest.raises(ValueError):
+        sim.create_layout([("Gxpi2:0",)])                 # two preparations: a circuit must name its own
