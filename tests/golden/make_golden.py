@@ -447,7 +447,7 @@ def main():
                         fam.append(pf + g * rep + mf)
         allset = set(allc)
         fam = [c for c in dict.fromkeys(fam) if c in allset]
-        cols = np.arange(336, 400)
+        cols = np.arange(m.num_params)       # (round 3: EVERY column at depth ~1030, where rounding is largest; round 2 pinned 64)
         dump_case('smq2Q_XYICNOT_L1024_deep', m, fam, dprobs_cols=cols, want_matrix=False)
 
     if '3q' in which:    # BASELINE configs[4] / SURVEY C5: 3-qubit explicit densitymx model, D = 64, 10 gates, nP = 41,536
