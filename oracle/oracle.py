@@ -226,6 +226,8 @@ def tp_param_map(fx):
     and the non-complement effects of a TPPOVM are one parameter <-> one dense element (a single 1.0 per derivative
     column); the complement effect (columns of -1.0, fx["comp_index"]) carries no parameter of its own."""
     nP = int(fx["nP"])
+    if "tp_kind" in fx:       # fixtures too large for the derivative tensors (D = 64) carry the map itself
+        return np.asarray(fx["tp_kind"], np.int32), np.asarray(fx["tp_obj"], np.int32), np.asarray(fx["tp_elem"], np.int32)
     pk = np.full(nP, -1, np.int32); po = np.zeros(nP, np.int32); pe = np.zeros(nP, np.int32)
     comp = int(fx["comp_index"]) if "comp_index" in fx else -1
     for k, o, pidx, dm in derivs_from_fixture(fx):

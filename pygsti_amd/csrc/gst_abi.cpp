@@ -223,6 +223,9 @@ struct gst_plan {
     bool cached_fused = false;          // the cached lane tables were packed for the fused form
     std::vector<int32_t> task_cost;     // gst::task_gate_costs, computed at the first FD request
     DevBuf<int32_t> d_wave_row, d_wave_rowidx, d_lane_colidx;
+    DevBuf<double> d_hrow;              // composed FD-of-FD Hessians: the stepped model's Jacobian over block 2
+    DevBuf<int32_t> d_hdest;            // ... and the destination columns of block 2
+    bool hess_composed = false;         // GST_HESS_COMPOSED=1: every FD-of-FD block through the composed route (tests)
     DevBuf<int32_t> d_node_parent, d_node_sym, d_node_run, d_circ_leaf, d_gate_col0, d_cm_gate, d_cm_rho, d_cm_eff;
     bool graph_uploaded = false;
     // the lane tables / column maps on the device describe this request (skip re-packing when it repeats)
@@ -273,7 +276,7 @@ struct gst_plan {
         }
         d_mm_models.release(); d_mm_raw.release(); d_mm_dest.release();
         d_task_split_pc.release(); d_ho_index.release(); d_ho_id.release(); d_ho_live.release(); d_ho_tag.release(); d_ho_flag.release(); d_ho_state.release();
-        d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release();
+        d_pbase.release(); d_base_cache.release(); d_jtj_part.release(); d_jtf_part.release(); d_out.release(); d_raw.release(); d_dcol.release(); d_probs_tmp.release(); d_hrow.release(); d_hdest.release();
         for (auto& b : d_lane) b.release();
         d_wave_row.release(); d_wave_rowidx.release(); d_lane_colidx.release();
         d_node_parent.release(); d_node_sym.release(); d_node_run.release(); d_circ_leaf.release(); d_gate_col0.release();
@@ -322,6 +325,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_FD_PERSIST")) { p->fd_persist = std::atoi(e) != 0; p->fd_persist_always = std::atoi(e) == 2; }
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_HESS_COMPOSED")) p->hess_composed = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_HOST_DIRECT")) { p->host_direct = std::atoi(e) != 0; if (std::atoi(e) == 2) p->host_direct_min_cols = 1; }
     if (const char* e = std::getenv("GST_FD_HANDOVER")) p->fd_handover = std::atoi(e);
     if (const char* e = std::getenv("GST_FD_OVERLAP")) { p->fd_overlap = std::atoi(e) != 0; p->fd_overlap_diag = std::atoi(e) == 2; }
@@ -2025,6 +2029,66 @@ int gst_fill_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, c
     });
 }
 
+// The host copy of the model with parameter `pi` stepped by eps, as `model.from_vector(vec)` leaves a model of
+// one-parameter-per-element members (mapforwardsim.py:425-428); a TP POVM's complement is re-derived from the stepped
+// effect in the reference's summation order (complementeffect.py:72-78).
+static void step_host_model(gst_plan* p, int64_t pi, double eps)
+{
+    const int D = p->hp.D;
+    const int32_t k = p->pkind[pi], o = p->pobj[pi], el = p->pelem[pi];
+    if (k == GST_KIND_GATE) {
+        const size_t at = (size_t)o * D * D + el;
+        const double v = p->h_gates[at] + eps;
+        p->h_gates[at] = v;
+        p->h_gates_t[((size_t)o * D + el % D) * D + el / D] = v;
+    } else if (k == GST_KIND_RHO) {
+        p->h_rhos[(size_t)o * D + el] = p->h_rhos[(size_t)o * D + el] + eps;
+    } else if (k == GST_KIND_EFFECT) {
+        p->h_effects[(size_t)o * D + el] = p->h_effects[(size_t)o * D + el] + eps;
+        if (p->comp_index >= 0 && std::find(p->comp_others.begin(), p->comp_others.end(), o) != p->comp_others.end()) {
+            double sum = 0.0;
+            for (int32_t q : p->comp_others) sum = sum + p->h_effects[(size_t)q * D + el];
+            p->h_effects[(size_t)p->comp_index * D + el] = p->comp_identity[el] - sum;
+        }
+    }
+    p->model_dirty = true;
+}
+
+// FD-of-FD Hessian block COMPOSED from FD Jacobians, literally as MapForwardSimulator._mapfill_hprobs_atom does it
+// (mapforwardsim.py:420-436): dprobs over block 2 at theta; for every row parameter i the model is stepped to
+// theta + eps e_i, dprobs2 = its FD Jacobian over block 2 (own base pass, `(orig + eps) + eps` where i is in block 2),
+// row i = (dprobs2 - dprobs) / eps.  Every Jacobian is bit-identical to the reference's on its model, hence so is the
+// block.  The route for plans the fused two-perturbation kernels do not cover (D = 64 with a complement effect): n1 + 2
+// Jacobian passes instead of one fused launch.  Leaves behind what run_hprobs_dev leaves behind.
+static int run_hprobs_composed(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
+                               int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2, double eps)
+{
+    int rc;
+    const int64_t nE = p->hp.n_elements;
+    HIP_TRY(p->d_dcol.ensure((size_t)nE * std::max<int64_t>(n2, 1)));
+    HIP_TRY(p->d_hrow.ensure((size_t)nE * std::max<int64_t>(n2, 1)));
+    HIP_TRY(p->d_probs_tmp.ensure((size_t)nE * std::max<int64_t>(n1, 1)));
+    if ((rc = run_dprobs_fd(p, p->d_dcol.p, n2, idx2, nullptr, n2, eps, nullptr, nullptr, 0))) return rc;
+    const int32_t* d_dest2 = nullptr;
+    if (dest2) {
+        std::vector<int32_t> d2(dest2, dest2 + n2);
+        if ((rc = upload_i32(p->d_hdest, d2, p->stream))) return rc;
+        d_dest2 = p->d_hdest.p;
+    }
+    const std::vector<double> g0 = p->h_gates, gt0 = p->h_gates_t, r0 = p->h_rhos, e0 = p->h_effects;
+    auto restore = [&]() { p->h_gates = g0; p->h_gates_t = gt0; p->h_rhos = r0; p->h_effects = e0; p->model_dirty = true; };
+    for (int64_t a = 0; a < n1; a++) {
+        step_host_model(p, idx1[a], eps);
+        if ((rc = upload_model(p)) || (rc = run_dprobs_fd(p, p->d_hrow.p, n2, idx2, nullptr, n2, eps, nullptr, nullptr, 0))) { restore(); return rc; }
+        hipError_t he = gst::launch_hess_compose(p->d_hrow.p, p->d_dcol.p, nE, (int32_t)n2, eps, d_H, ld1, ld2, dest1 ? dest1[a] : a, d_dest2, p->stream);
+        restore();
+        if (he != hipSuccess) return fail(GST_EHIP, std::string("hess_compose: ") + hipGetErrorString(he));
+    }
+    if ((rc = upload_model(p))) return rc;
+    // (the by-products the objective-Hessian rectangle reads: probabilities at theta, dprobs over block 1)
+    return run_dprobs_fd(p, p->d_probs_tmp.p, n1, idx1, nullptr, n1, eps, nullptr, nullptr, 0);
+}
+
 // FD-of-FD Hessian block into the device buffer d_H [nE][ld1][ld2] (mapforwardsim.py:394-438).  Leaves behind, on the
 // device: probabilities (d_pbase), FD dprobs over block 2 (d_dcol, [nE][n2]) and over block 1 (d_probs_tmp, [nE][n1]).
 static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, const int64_t* idx1, const int64_t* dest1,
@@ -2032,12 +2096,14 @@ static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, co
 {
     int rc;
     if (p->comp_index >= 0) {
-        if (p->hp.D == 64) return fail(GST_EUNSUPPORTED, "D = 64 Hessians are not implemented for plans with a complement effect");
         for (int64_t c = 0; c < n1 + n2; c++) {
             const int64_t pi = c < n1 ? idx1[c] : idx2[c - n1];
             if (p->pkind[pi] == GST_KIND_EFFECT && p->pobj[pi] == p->comp_index) return fail(GST_EINVAL, "a parameter maps to the complement effect");
         }
     }
+    // the fused two-perturbation kernels have no D = 64 form that re-derives a complement effect: that block is composed
+    if (p->hess_composed || (p->comp_index >= 0 && p->hp.D == 64))
+        return run_hprobs_composed(p, d_H, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2, eps);
     const int64_t nE = p->hp.n_elements;
     // (1) dprobs over block 2 at theta (mapforwardsim.py:420-421), FD step = eps
     HIP_TRY(p->d_dcol.ensure((size_t)nE * n2));

@@ -339,4 +339,9 @@ hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slo
 hipError_t launch_fd_from_models(const double* raw, int64_t raw_stride, const double* pbase, int64_t nE, int32_t n_models,
                                  const int32_t* dest, int32_t m0, double eps, double* out, int64_t ld, hipStream_t stream);
 
+// H[(e * ld1 + row) * ld2 + dest2[j]] = (Ji[e * n2 + j] - J0[e * n2 + j]) / eps: one row of an FD-of-FD Hessian block composed
+// from two FD Jacobians, as MapForwardSimulator._mapfill_hprobs_atom composes it (mapforwardsim.py:432-436)
+hipError_t launch_hess_compose(const double* Ji, const double* J0, int64_t nE, int32_t n2, double eps, double* H, int64_t ld1, int64_t ld2,
+                               int64_t row, const int32_t* dest2, hipStream_t stream);
+
 }  // namespace gst

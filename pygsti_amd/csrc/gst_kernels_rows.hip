@@ -922,6 +922,29 @@ hipError_t launch_fd_from_models(const double* raw, int64_t raw_stride, const do
     return hipGetLastError();
 }
 
+// One row of a COMPOSED FD-of-FD Hessian block (mapforwardsim.py:432-436: `(dprobs2 - dprobs) / eps` with dprobs2 the FD
+// Jacobian of the model stepped in the row's parameter): H[e][row][dest2[j]] = (J_i[e][j] - J_0[e][j]) / eps.
+__global__ __launch_bounds__(256) void hess_compose_kernel(const double* __restrict__ Ji, const double* __restrict__ J0, int64_t nE, int32_t n2,
+                                                           double eps, double* __restrict__ H, int64_t ld1, int64_t ld2, int64_t row,
+                                                           const int32_t* __restrict__ dest2)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nE * (int64_t)n2) return;
+    const int64_t e = k / n2;
+    const int32_t j = (int32_t)(k - e * n2);
+    const int64_t col = dest2 ? (int64_t)dest2[j] : (int64_t)j;
+    H[(e * ld1 + row) * ld2 + col] = (Ji[k] - J0[k]) / eps;
+}
+
+hipError_t launch_hess_compose(const double* Ji, const double* J0, int64_t nE, int32_t n2, double eps, double* H, int64_t ld1, int64_t ld2,
+                               int64_t row, const int32_t* dest2, hipStream_t stream)
+{
+    if (nE <= 0 || n2 <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(hess_compose_kernel, dim3((unsigned)((nE * n2 + 255) / 256)), dim3(256), 0, stream, Ji, J0, nE, n2, eps, H, ld1, ld2, row, dest2);
+    return hipGetLastError();
+}
+
 // FD columns of effect parameters, from the cached final states.  Perturbing an element of an effect vector changes no
 // propagated state, so the column is (E'.F_n - p)/eps on the circuits' final states -- E' being the perturbed effect for
 // outcomes of that effect, the RECOMPUTED complement for the outcome of a TP POVM's complement effect

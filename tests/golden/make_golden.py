@@ -38,7 +38,7 @@ def _label_str(lbl):
 
 def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hprobs=False,
               hprobs_blk=None, circuit_subset_for_matrix=None, extra=None, general_params=False,
-              matrix_hprobs_blocks=None, matrix_hprobs=True, model_sets=False, dump_derivs=True):
+              matrix_hprobs_blocks=None, matrix_hprobs=True, model_sets=False, dump_derivs=True, tp_map=False):
     """Build a 1-atom Map layout for `circuits`, run the reference, save everything."""
     assert model.sim.calclib.__name__.endswith('calc_densitymx'), "reference Cython path not built!"
     model = model.copy()
@@ -116,6 +116,25 @@ def dump_case(name, model, circuits, dprobs_cols=None, want_matrix=True, want_hp
         dv = dict(dv_kind=np.array(k_l, np.int32), dv_obj=np.array(o_l, np.int32), dv_ncols=np.array(n_l, np.int32),
                   dv_param_idx=np.concatenate(pi_l).astype(np.int64), dv_deriv=np.concatenate(d_l),
                   dv2_nonzero=np.array(hz_l, np.int32), dv2_hess=np.concatenate(h_l))
+    if general_params and tp_map:
+        # "full TP" models too large for the dv_* tensors (D = 64): the one-parameter-per-element map itself, read off
+        # each member's deriv_wrt_params() (a single 1.0 per column; the complement effect has no parameter of its own)
+        from pygsti.modelmembers.povms.complementeffect import ComplementPOVMEffect as _CPE
+        tk = -np.ones(nP, np.int32); to = np.zeros(nP, np.int32); te = np.zeros(nP, np.int32)
+        for kind, labels, typ in ((0, op_labels, 'op'), (1, rho_labels, 'prep'), (2, eff_labels, 'povm')):
+            for oi, lbl in enumerate(labels):
+                member = model._circuit_layer_operator(lbl, typ)
+                if isinstance(member, _CPE):
+                    continue
+                dm = np.real(member.deriv_wrt_params())
+                idx = member.gpindices_as_array()
+                rows_, cols_ = np.nonzero(dm)
+                assert len(cols_) == len(idx) and np.array_equal(np.sort(cols_), np.arange(len(idx))) and (dm[rows_, cols_] == 1.0).all()
+                assert (tk[idx] == -1).all()
+                tk[idx[cols_]] = kind; to[idx[cols_]] = oi; te[idx[cols_]] = rows_
+                del dm
+        dv.update(tp_kind=tk, tp_obj=to, tp_elem=te)
+    if general_params and (dump_derivs or tp_map):
         # TP POVMs: the complement effect = identity - sum(other effects) (modelmembers/povms/complementeffect.py:72-78)
         from pygsti.modelmembers.povms.complementeffect import ComplementPOVMEffect
         for oi, lbl in enumerate(eff_labels):
@@ -473,6 +492,34 @@ def main():
         blk = (np.array([0, 70, 576, 600, 576 + 64, 9000, 20000, nP - 1]),
                np.sort(np.unique(np.concatenate([[0, 1, 70, 576, 577, 576 + 64 + 1, 30000, nP - 2], rng.choice(nP, 40, replace=False)]))[:32]))
         dump_case('3q_explicit_L64', m, circs, dprobs_cols=cols, want_matrix=False, want_hprobs=True, hprobs_blk=blk)
+
+    if '3qtp' in which:  # the 3-qubit model as "full TP": FD Jacobian columns and an FD-of-FD Hessian block of a D = 64 plan with a complement effect
+        from pygsti.processors import QubitProcessorSpec
+        from pygsti.models import modelconstruction as mc
+        from pygsti.circuits import Circuit
+        ps = QubitProcessorSpec(3, ['Gxpi2', 'Gypi2', 'Gcnot'], geometry='line')
+        m = mc.create_explicit_model(ps, ideal_gate_type='full TP', ideal_spam_type='full TP')
+        m = m.depolarize(op_noise=0.01, spam_noise=0.01)
+        m.from_vector(m.to_vector() + 0.02 * np.random.default_rng(65).standard_normal(m.num_params))   # (kick() would turn the TP members into full ones)
+        from pygsti.modelmembers.operations import FullTPOp
+        assert all(isinstance(o, FullTPOp) for o in m.operations.values())
+        ops = list(m.operations.keys())
+        assert m.dim == 64 and len(ops) == 10
+        nP = m.num_params
+        assert nP == 63 + 7 * 64 + 10 * 64 * 63, nP
+        rng = np.random.default_rng(11)
+        lens = np.concatenate([[0, 1, 2, 40, 33], rng.integers(1, 25, 31)])
+        strs = [tuple(ops[g] for g in rng.integers(0, len(ops), L)) for L in lens]
+        for k in range(8, len(strs), 4):
+            strs[k] = strs[k - 1][:len(strs[k - 1]) // 2] + strs[k][:6]
+        circs = [Circuit(s, line_labels=(0, 1, 2)) for s in dict.fromkeys(strs)]
+        g0 = 63 + 7 * 64          # first gate parameter
+        cols = np.sort(np.unique(np.concatenate([[0, 1, 62, 63, 64, 63 + 63, 63 + 64, 63 + 6 * 64 + 5, g0 - 1, g0, g0 + 1, g0 + 4031, g0 + 4032, nP - 1],
+                                                 rng.choice(nP, 40, replace=False)]))[:48])
+        blk = (np.array([1, 63 + 2, 63 + 3 * 64 + 9, g0 + 70, g0 + 5 * 4032 + 123, nP - 1]),
+               np.sort(np.unique(np.concatenate([[0, 63, 63 + 2, 63 + 64 + 7, g0 - 1, g0, g0 + 70, g0 + 71, nP - 2], rng.choice(nP, 8, replace=False)]))[:16]))
+        dump_case('3q_explicit_TP', m, circs, dprobs_cols=cols, want_matrix=False, want_hprobs=True, hprobs_blk=blk,
+                  general_params=True, dump_derivs=False, tp_map=True)
 
     if 'designs' in which:
         # pins for the build's own circuit generator: counts and sha256 of integerised lists, plus

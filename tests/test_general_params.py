@@ -64,7 +64,7 @@ def test_gpu_general_parameterisation_dprobs(name):
 TP_CASES = ["smq1Q_XYI_L4_TP", "smq2Q_XYICNOT_L1_TP"]
 
 
-@pytest.mark.parametrize("name", TP_CASES)
+@pytest.mark.parametrize("name", TP_CASES + ["3q_explicit_TP"])
 def test_tp_fixtures_describe_the_complement(name):
     """The complement effect stored in the fixture is identity - sum(others) in the recorded order, bit for bit
     (complementeffect.py:72-78), and the TP parameter map covers every parameter exactly once."""
@@ -137,6 +137,55 @@ def test_gpu_tp_model_fd_dprobs_bitwise(name):
     assert not np.array_equal(J2, fx["dprobs_map"])
     ncomp = np.setdiff1d(np.arange(int(fx["nE"])), fx["eff_dest"][comp_rows])
     assert np.array_equal(J2[ncomp], fx["dprobs_map"][ncomp])
+
+
+@pytest.mark.gpu
+def test_gpu_3q_tp_model_fd_jacobian_and_hessian_bitwise():
+    """The 3-qubit model as "full TP" (D = 64, 40,831 parameters, a 7-effect TPPOVM + complement): probabilities, 48 FD
+    Jacobian columns and a 6 x 16 FD-of-FD Hessian block, bit for bit the reference Map simulator's
+    (tests/golden/make_golden.py, case '3qtp').  The fused D = 64 Hessian kernel has no form that re-derives a complement
+    effect; the block is composed from FD Jacobians of stepped models exactly as _mapfill_hprobs_atom composes it
+    (mapforwardsim.py:420-436) -- round 2 refused it with GST_EUNSUPPORTED."""
+    fx = load_fixture("3q_explicit_TP")
+    assert int(fx["D"]) == 64
+    pl = plan_from_fixture(fx)
+    pk, po, pe = O.tp_param_map(fx)
+    pl.set_param_map(pk, po, pe)
+    pl.set_complement_effect(int(fx["comp_index"]), fx["comp_identity"], fx["comp_others"])
+    cols = fx["dprobs_cols"]
+    pr = np.empty(int(fx["nE"]))
+    J = pl.fill_dprobs(param_idx=cols, probs_out=pr, eps=float(fx["derivative_eps"]))
+    assert np.array_equal(pr, fx["probs"])
+    assert np.array_equal(J, fx["dprobs_map"])
+    assert (pk[cols] == 2).any() and (pk[cols] == 1).any() and (pk[cols] == 0).any()
+    rows, c2 = fx["hprobs_rows"], fx["hprobs_cols"]
+    H = pl.fill_hprobs(idx1=rows, idx2=c2, eps=float(fx["hessian_eps"]))
+    assert np.array_equal(H, fx["hprobs_map"])
+    assert (pk[rows] == 2).any() and (pk[c2] == 2).any() and len(np.intersect1d(rows, c2)) > 0
+    comp_rows = fx["eff_dest"][fx["eff_label"] == int(fx["comp_index"])]
+    assert np.abs(H[comp_rows][:, pk[rows] == 2][:, :, pk[c2] == 0]).max() > 0          # effect x gate moves the complement's outcome
+    # scattered destination, and the model is left as it was
+    out = np.full((int(fx["nE"]), len(rows) + 2, len(c2) + 3), -5.0)
+    pl.fill_hprobs(out=out, idx1=rows, dest1=np.arange(len(rows))[::-1].copy() + 1, idx2=c2, dest2=np.arange(len(c2)) + 2, eps=float(fx["hessian_eps"]))
+    assert np.array_equal(out[:, 1:1 + len(rows), 2:2 + len(c2)], H[:, ::-1, :])
+    assert (out[:, 0] == -5.0).all() and (out[:, -1] == -5.0).all() and (out[:, :, :2] == -5.0).all() and (out[:, :, -1] == -5.0).all()
+    assert np.array_equal(pl.fill_probs(), fx["probs"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TP_CASES + ["smq1Q_XYI_L4_depol"])
+def test_gpu_composed_hessian_is_the_fused_one(name, monkeypatch):
+    """GST_HESS_COMPOSED=1 sends every FD-of-FD block through the composed route (n1 + 2 FD Jacobians of stepped models);
+    on plans the fused two-perturbation kernel covers, both equal the reference's block bit for bit."""
+    fx = load_fixture(name)
+    monkeypatch.setenv("GST_HESS_COMPOSED", "1")
+    pl = plan_from_fixture(fx)
+    if "comp_index" in fx:
+        pl.set_param_map(*O.tp_param_map(fx))
+        pl.set_complement_effect(int(fx["comp_index"]), fx["comp_identity"], fx["comp_others"])
+    H = pl.fill_hprobs(idx1=fx["hprobs_rows"], idx2=fx["hprobs_cols"], eps=float(fx["hessian_eps"]))
+    assert np.array_equal(H, fx["hprobs_map"])
+    assert np.array_equal(pl.fill_probs(), fx["probs"])
 
 
 def test_oracle_tp_exact_hessian_matches_matrix_simulator():
