@@ -1078,13 +1078,11 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     a.n_gates = h.n_gates; a.n_rhos = h.n_rhos; a.n_effects = h.n_effects;
     a.gate_col0 = p->d_gate_col0.p; a.colmap_gate = p->d_cm_gate.p; a.colmap_rho = p->d_cm_rho.p; a.colmap_eff = p->d_cm_eff.p;
     a.out = d_out; a.ld = ld;
-    // (the MFMA kernel addresses both state caches with 32-bit byte offsets)
-    // Above that the plan DEGRADES instead of failing: D <= 16 Jacobians take the single backward-walking kernel (64-bit
-    // addressing, no backward cache at all); only what has no such form -- D = 64, exact Hessians -- is refused.
-    // (GST_TEST_CACHE_LIMIT: tests lower the 4 GB to exercise that path on a small plan.)
+    // The MFMA kernels address both state caches with a uniform 64-bit base + 32-bit per-lane byte offsets; a cache of
+    // 4 GB or more selects their WIDE instantiation (64-bit lane offsets: two more address registers per gather in
+    // flight), nothing is refused.  (GST_TEST_CACHE_LIMIT: tests lower the 4 GB so that a small plan takes that form.)
     const double cache_limit = p->test_cache_limit > 0 ? p->test_cache_limit : 4.0e9;
     const bool caches_small = (double)h.n_state_ids * D * 8 < cache_limit;
-    if (D == 64 && !caches_small) return fail(GST_EUNSUPPORTED, "forward-state cache exceeds 4 GB");
     // the two-cache contraction: MFMA at D = 16 / 64; at D = 4 (VALU) only when a Hessian needs its tables -- a plain 1Q
     // Jacobian is launch-bound and the single backward-walking kernel below is one launch instead of three
     // D <= 16: the backward pass needs the chain kernel, whose tables (all gates, effects, emit ring) live in LDS; a gate
@@ -1094,14 +1092,12 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         return fail(GST_EUNSUPPORTED, "exact Hessians at D <= 16 need the gate set in LDS (at most " +
                                           std::to_string(128 * 1024 / (D * D * 8)) + " gates at this D)");
     bool rev_small = true;
-    if (will_fork && caches_small && chain_ok) {
+    if (will_fork && chain_ok) {
         if ((rc = ensure_reverse(p))) return rc;
         rev_small = (double)p->rev.n_state_ids * h.n_effects * D * 8 < cache_limit;
-        if (!rev_small && (D == 64 || p->want_cache_path))
-            return fail(GST_EUNSUPPORTED, "backward-state cache exceeds 4 GB: split the circuits over more atoms");
-        if (!rev_small) HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));      // (nothing runs beside the forward pass after all)
     }
-    if (will_fork && caches_small && chain_ok && rev_small) {
+    if (will_fork && chain_ok) {
+        a.wide = (caches_small && rev_small) ? 0 : 1;
         // backward states: the chain kernel over the reversed plan, transposed gates (= the row-major array), one lane
         // group per effect (64/D effects per pass)
         gst::WalkArgs w;
@@ -2211,12 +2207,13 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
     rc = run_dprobs_analytic(p, p->d_hscratch.p, ld2, idx2, dest2, n2, nullptr);
     p->want_cache_path = false;
     if (rc) return rc;
-    if (!p->last_ana_valid) return fail(GST_EUNSUPPORTED, "analytic Hessians need the MFMA path (state caches below 4 GB)");
-    const gst::AnaArgs base = p->last_ana;
+    if (!p->last_ana_valid) return fail(GST_EUNSUPPORTED, "analytic Hessians need the two-cache contraction path");
+    gst::AnaArgs base = p->last_ana;
     const std::vector<int64_t> none_cols = p->cached_none_cols;
-    // (the contraction kernels address both derivative-state caches with 32-bit byte offsets)
-    if ((double)p->rev.n_state_ids * 4 * D * nEf * 8 >= 4.0e9 || (double)h.n_state_ids * 4 * D * 8 >= 4.0e9)
-        return fail(GST_EUNSUPPORTED, "derivative-state cache exceeds 4 GB: split the circuits over more atoms");
+    {   // derivative-state caches (four row parameters per state) of 4 GB or more: the contraction's wide form
+        const double cache_limit = p->test_cache_limit > 0 ? p->test_cache_limit : 4.0e9;
+        if ((double)p->rev.n_state_ids * 4 * D * nEf * 8 >= cache_limit || (double)h.n_state_ids * 4 * D * 8 >= cache_limit) base.wide = 1;
+    }
     HIP_TRY(p->d_dF.ensure((size_t)h.n_state_ids * 4 * D));
     HIP_TRY(p->d_dB.ensure((size_t)p->rev.n_state_ids * 4 * D * nEf));
     HIP_TRY(p->d_theta.ensure(5 * 4 * (size_t)(1 + nEf)));

@@ -167,6 +167,7 @@ struct AnaArgs {
     // D = 16, two-circuit items as one stream of 4-slot blocks (NULL: gate by gate): slot = forward id of the first circuit,
     // of the second (-1: that circuit has no application here) and the backward id; blk_ptr[item * nG + g] = first block of gate g
     const int32_t *blk_f1, *blk_f2, *blk_r, *blk_ptr;
+    int32_t wide;                 // a state cache (or a derivative-state cache of a Hessian row) is 4 GB or larger: 64-bit lane offsets
     int32_t zeros_resident;       // D = 16 stream form: the blocks of gates an item never applies already hold zeros in `out`: not stored
 };
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);

@@ -227,9 +227,12 @@ constexpr int ANA_MFMA_WPS = GST_ANA_WPS;
 #endif
 constexpr int ANA_STREAM_M = GST_ANA_STREAM_M;
 
+// WIDE: a state cache of 4 GB or more -- 64-bit per-lane byte offsets instead of 32-bit ones (AnaArgs::wide)
+template <bool WIDE>
 __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const AnaArgs a)
 {
     constexpr int D = 16, NX = 4;
+    using off_t = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
     const int lane = threadIdx.x & 63;
     const int kk = lane >> 4, i = lane & 15;
     const int nE = a.n_effects, nG = a.n_gates;
@@ -306,8 +309,8 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
         auto gather = [&](const int32_t (&f)[M], const int32_t (&r)[M], double (&Fv)[M], double (&Bv)[M][NX]) {
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const uint32_t fo = (uint32_t)f[m] * fstride + lane_b;
-                const uint32_t ro = (uint32_t)r[m] * rstride + lane_r;
+                const off_t fo = (off_t)(uint32_t)f[m] * fstride + lane_b;
+                const off_t ro = (off_t)(uint32_t)r[m] * rstride + lane_r;
                 Fv[m] = *(const double*)(fb + fo);
                 if constexpr (FAST4) {
                     const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + ro, 16);
@@ -494,9 +497,9 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
 #pragma unroll
                         for (int m = 0; m < SM; m++) {
                             ok1[m] = live && f1[m] >= 0; ok2[m] = live && f2[m] >= 0;
-                            F1[m] = *(const double*)(fb + (uint32_t)(f1[m] < 0 ? 0 : f1[m]) * fstride + lane_b);
-                            F2[m] = *(const double*)(fb + (uint32_t)(f2[m] < 0 ? 0 : f2[m]) * fstride + lane_b);
-                            const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + (uint32_t)rr[m] * rstride + lane_r, 16);
+                            F1[m] = *(const double*)(fb + (off_t)(uint32_t)(f1[m] < 0 ? 0 : f1[m]) * fstride + lane_b);
+                            F2[m] = *(const double*)(fb + (off_t)(uint32_t)(f2[m] < 0 ? 0 : f2[m]) * fstride + lane_b);
+                            const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + (off_t)(uint32_t)rr[m] * rstride + lane_r, 16);
                             const d2_t t0 = q2[0], t1 = q2[1];
                             Bv[m][0] = t0.x; Bv[m][1] = t0.y; Bv[m][2] = t1.x; Bv[m][3] = t1.y;
                         }
@@ -584,9 +587,9 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                                       double (&F1)[M2], double (&F2)[M2], double (&Bv)[M2][NX]) {
 #pragma unroll
                         for (int m = 0; m < M2; m++) {
-                            F1[m] = *(const double*)(fb + (uint32_t)f1[m] * fstride + lane_b);
-                            F2[m] = *(const double*)(fb + (uint32_t)f2[m] * fstride + lane_b);
-                            const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + (uint32_t)rr[m] * rstride + lane_r, 16);
+                            F1[m] = *(const double*)(fb + (off_t)(uint32_t)f1[m] * fstride + lane_b);
+                            F2[m] = *(const double*)(fb + (off_t)(uint32_t)f2[m] * fstride + lane_b);
+                            const d2_t* q2 = (const d2_t*)__builtin_assume_aligned(rb + (off_t)(uint32_t)rr[m] * rstride + lane_r, 16);
                             const d2_t t0 = q2[0], t1 = q2[1];
                             Bv[m][0] = t0.x; Bv[m][1] = t0.y; Bv[m][2] = t1.x; Bv[m][3] = t1.y;
                         }
@@ -788,8 +791,10 @@ hipError_t launch_dwalk(int D, const DWalkArgs& a, int64_t n_tasks, int n_slots,
 // circuit outcome: for every gate it holds the 4 x 4 grid of 16 x 16 MFMA tiles of that gate's block (64 fp64
 // accumulators per lane) and, per 4 applications of the gate, gathers 4 + 4 operand registers (the four 16-row
 // slices of B_k and of F_{k-1}) for 16 v_mfma_f64_16x16x4_f64 -- two MFMAs per gathered register.
+template <bool WIDE>
 __global__ __launch_bounds__(256, 2) void analytic_mfma64_kernel(const AnaArgs a)
 {
+    using off_t = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
     constexpr int D = 64;
     const int lane = threadIdx.x & 63;
     const int kk = lane >> 4, i = lane & 15;
@@ -841,8 +846,8 @@ __global__ __launch_bounds__(256, 2) void analytic_mfma64_kernel(const AnaArgs a
                 const int64_t pi = q + kk;
                 const bool ok = pi <= last;
                 const int64_t pc = ok ? pi : last;
-                const uint32_t fo = (uint32_t)a.pair_f[pc] * fstride + lane_b;
-                const uint32_t ro = (uint32_t)a.pair_r[pc] * rstride + lane_b;
+                const off_t fo = (off_t)(uint32_t)a.pair_f[pc] * fstride + lane_b;
+                const off_t ro = (off_t)(uint32_t)a.pair_r[pc] * rstride + lane_b;
                 double Fv[4], Bv[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -890,7 +895,8 @@ hipError_t launch_analytic_mfma64(const AnaArgs& a, hipStream_t stream)
     int64_t blocks = (a.n_circuits * (int64_t)a.n_effects + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4;       // persistent wavefronts pulling (circuit, outcome) items
     (void)hipGetLastError();
-    hipLaunchKernelGGL(analytic_mfma64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    if (a.wide) hipLaunchKernelGGL(analytic_mfma64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(analytic_mfma64_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -969,7 +975,8 @@ hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream)
     if (blocks > 256 * 8) blocks = 256 * 8;       // persistent wavefronts pulling circuits from a.work_counter[0..7]
     blocks = (blocks + 7) / 8 * 8;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(analytic_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    if (a.wide) hipLaunchKernelGGL(analytic_mfma_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(analytic_mfma_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

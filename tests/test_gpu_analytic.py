@@ -133,39 +133,52 @@ def test_analytic_hprobs_1q_vs_matrix_simulator(name):
     assert np.array_equal(full[:, fx["hprobs_rows"]][:, :, fx["hprobs_cols"]], H)
 
 
-def test_exact_hessian_refuses_forward_derivative_caches_beyond_4gb():
-    """The contraction kernels address the derivative-state caches with 32-bit byte offsets: a plan whose FORWARD trie is
-    large (8.4 M states: 4 x 16 x 8 bytes each = 4.3 GB of dF) while its suffix trie is small must be refused loudly, not
-    answered with wrapped offsets (round-1 advisor finding).  8,400 circuits of depth 1,000: distinct random prefixes of
-    200 gates in front of one common suffix of 800."""
+def test_exact_hessian_with_derivative_caches_beyond_4gb():
+    """The contraction kernels address the derivative-state caches with 32-bit per-lane byte offsets; a plan whose FORWARD
+    trie is large (8.4 M states: 4 x 16 x 8 bytes each = 4.3 GB of dF) takes their 64-bit instantiation instead of being
+    refused (rounds 1-2: GST_EUNSUPPORTED) -- and must not be answered with wrapped offsets: the block's rows for the
+    lexicographically last circuits (whose states sit beyond the 4 GB mark) and for a spread of others equal what a small
+    plan holding only those circuits returns through the default instantiation.  8,400 circuits of depth 1,000: distinct
+    random prefixes of 200 gates in front of one common suffix of 800."""
     from pygsti_amd import _lib
     rng = np.random.default_rng(0)
     D, nG, nEl, nC, L = 16, 6, 4, 8400, 1000
     suffix = rng.integers(0, nG, 800)
     circs = [np.concatenate([rng.integers(0, nG, L - 800), suffix]) for _ in range(nC)]
-    ptr = np.arange(nC + 1, dtype=np.int64) * L
-    g = np.concatenate(circs).astype(np.int32)
-    nE = nC * nEl
-    pl = _lib.Plan.from_circuits(D, nG, 1, nEl, nE, np.zeros(nC, np.int32), ptr, g, np.arange(nC + 1, dtype=np.int64) * nEl,
-                                 np.tile(np.arange(nEl, dtype=np.int32), nC), np.arange(nE, dtype=np.int32))
-    st = pl.stats()
-    assert st["trie_nodes"] > 8.3e6
     gates = np.eye(D)[None] * 0.98 + 0.01 * rng.standard_normal((nG, D, D))
     rho = np.zeros((1, D)); rho[0, 0] = 0.5
     eff = 0.05 * rng.standard_normal((nEl, D)); eff[:, 0] += 0.5
-    pl.set_model(gates, rho, eff)
     nP = D + nEl * D + nG * D * D
     kind = np.concatenate([np.full(D, 1), np.full(nEl * D, 2), np.full(nG * D * D, 0)]).astype(np.int32)
     obj = np.concatenate([np.zeros(D), np.repeat(np.arange(nEl), D), np.repeat(np.arange(nG), D * D)]).astype(np.int32)
     elem = np.concatenate([np.arange(D), np.tile(np.arange(D), nEl), np.tile(np.arange(D * D), nG)]).astype(np.int32)
-    pl.set_param_map(kind, obj, elem)
-    out = np.zeros((nE, 1, 2))
-    with pytest.raises(_lib.GstError, match="4 GB"):
-        pl.fill_hprobs(out, np.array([80]), np.array([81, 82]), mode=_lib.DERIV_ANALYTIC)
-    # the Jacobian of the same plan is fine (its caches are below the limit) and probabilities still sum to ~1 per circuit
-    p = pl.fill_probs()
-    assert np.isfinite(p).all()
-    pl.close()
+
+    def make(sel):
+        n = len(sel)
+        ptr = np.arange(n + 1, dtype=np.int64) * L
+        g = np.concatenate([circs[c] for c in sel]).astype(np.int32)
+        pl = _lib.Plan.from_circuits(D, nG, 1, nEl, n * nEl, np.zeros(n, np.int32), ptr, g, np.arange(n + 1, dtype=np.int64) * nEl,
+                                     np.tile(np.arange(nEl, dtype=np.int32), n), np.arange(n * nEl, dtype=np.int32))
+        pl.set_model(gates, rho, eff)
+        pl.set_param_map(kind, obj, elem)
+        return pl
+    pl = make(np.arange(nC))
+    st = pl.stats()
+    assert st["trie_nodes"] > 8.3e6
+    rows, cols = np.array([80, 7]), np.array([81, 82, 400, 3])          # gate x gate, rho x gate, gate x rho
+    H = pl.fill_hprobs(idx1=rows, idx2=cols, mode=_lib.DERIV_ANALYTIC)
+    J = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    order = sorted(range(nC), key=lambda c: circs[c].tolist())
+    sel = np.array(order[-24:] + order[:8] + order[1000:7000:500])
+    small = make(sel)
+    Hs = small.fill_hprobs(idx1=rows, idx2=cols, mode=_lib.DERIV_ANALYTIC)
+    Js = small.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    el = (sel[:, None] * nEl + np.arange(nEl)[None, :]).ravel()
+    assert np.abs(Hs).max() > 1e-3
+    assert np.abs(H[el] - Hs).max() < 1e-11 * max(1.0, np.abs(Hs).max())
+    assert np.abs(J[el] - Js).max() < 1e-12 * max(1.0, np.abs(Js).max())
+    assert np.isfinite(H).all()
+    pl.close(); small.close()
 
 
 @pytest.mark.parametrize("stream", ["1", "0"])
@@ -241,22 +254,34 @@ def test_analytic_keep_zeros_option():
         pl.set_option(99, 1)
 
 
-def test_state_caches_beyond_32bit_offsets_degrade_to_the_single_kernel(monkeypatch):
-    """The two-cache MFMA contraction addresses its state caches with 32-bit byte offsets (4 GB each).  A plan whose
-    backward-state cache is larger no longer fails: D <= 16 Jacobians take the single backward-walking kernel (64-bit
-    addressing, no backward cache).  GST_TEST_CACHE_LIMIT stands in for the 4 GB so that a small plan takes that route:
-    same Jacobian as the default path to 1e-10, as the Matrix simulator's to 1e-8; exact Hessian blocks, which have no
-    such form, are refused with GST_EUNSUPPORTED (a RuntimeError), not computed wrongly."""
+def test_state_caches_beyond_32bit_offsets_take_the_wide_contraction(monkeypatch):
+    """The two-cache MFMA contraction addresses its state caches with 32-bit per-lane byte offsets (4 GB each).  A plan
+    whose caches are larger is no longer refused (round 2: GST_EUNSUPPORTED) or degraded: the same kernels, instantiated
+    with 64-bit lane offsets, run it -- Jacobians and exact Hessian blocks, D = 16 and D = 64.  GST_TEST_CACHE_LIMIT stands
+    in for the 4 GB so that small plans take that form: bit-identical to the default instantiation."""
     from pygsti_amd import _lib
     fx = load_fixture("smq2Q_XYICNOT_L2_depol")
     cols = fx["dprobs_cols"]
-    ref = plan_from_fixture(fx).fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
     pl0 = plan_from_fixture(fx)
+    ref = pl0.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    Href = pl0.fill_hprobs(idx1=cols[:6], idx2=cols[:40], mode=_lib.DERIV_ANALYTIC)
     st = pl0.stats()
-    monkeypatch.setenv("GST_TEST_CACHE_LIMIT", str(st["trie_nodes"] * 16 * 8 * 2))     # forward cache fits, the 4-effect backward cache does not
-    pl = plan_from_fixture(fx)
-    J = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
-    assert np.abs(J - ref).max() < 1e-10
-    assert np.abs(J[fx["matrix_rows"]] - fx["dprobs_matrix"]).max() < 1e-8
-    with pytest.raises(RuntimeError):
-        pl.fill_hprobs(idx1=cols[:2], idx2=cols[:4], mode=_lib.DERIV_ANALYTIC)
+    for limit in (st["trie_nodes"] * 16 * 8 * 2,      # forward cache fits, the 4-effect backward cache does not
+                  1024.0):                            # neither fits
+        monkeypatch.setenv("GST_TEST_CACHE_LIMIT", str(limit))
+        pl = plan_from_fixture(fx)
+        J = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+        assert np.array_equal(J, ref)
+        assert np.abs(J[fx["matrix_rows"]] - fx["dprobs_matrix"]).max() < 1e-8
+        assert np.array_equal(pl.fill_hprobs(idx1=cols[:6], idx2=cols[:40], mode=_lib.DERIV_ANALYTIC), Href)
+    # D = 64
+    monkeypatch.delenv("GST_TEST_CACHE_LIMIT")
+    fx3 = load_fixture("3q_explicit_L64")
+    c3 = fx3["dprobs_cols"][:96]
+    p3 = plan_from_fixture(fx3)
+    ref3 = p3.fill_dprobs(param_idx=c3, mode=_lib.DERIV_ANALYTIC)
+    H3 = p3.fill_hprobs(idx1=c3[:3], idx2=c3[:24], mode=_lib.DERIV_ANALYTIC)
+    monkeypatch.setenv("GST_TEST_CACHE_LIMIT", "1024")
+    p3w = plan_from_fixture(fx3)
+    assert np.array_equal(p3w.fill_dprobs(param_idx=c3, mode=_lib.DERIV_ANALYTIC), ref3)
+    assert np.array_equal(p3w.fill_hprobs(idx1=c3[:3], idx2=c3[:24], mode=_lib.DERIV_ANALYTIC), H3)
