@@ -35,13 +35,14 @@ class RankAlloc:
 
 
 def owned_row_blocks(layout, rank, size):
-    """[(start, stop)] element ranges owned by `rank` (atoms rank, rank+size, ...)."""
-    return [(at.element_slice.start, at.element_slice.stop) for a, at in enumerate(layout.all_atoms) if a % size == rank]
+    """[(start, stop)] element ranges `rank` contributes to element-dimension gathers: the atoms of its atom-processor
+    when it is that processor's first rank (atoms k, k+na, ...; every rank is one when atoms are the only axis)."""
+    return [(r0, r1) for r0, r1, _, _ in layout.owned_blocks("e", rank)]
 
 
 def row_blocks(layout, size):
     """The block list of the C ABI's row exchanges: (owner rank, first row, rows) per atom, in atom order."""
-    return [(a % size, at.element_slice.start, at.element_slice.stop - at.element_slice.start)
+    return [(layout.atom_owner_rank(a), at.element_slice.start, at.element_slice.stop - at.element_slice.start)
             for a, at in enumerate(layout.all_atoms)]
 
 
@@ -256,6 +257,60 @@ def gather_elements(local, layout, group=None, dst=None):
             out[a:b] = recv[r][off:off + (b - a)]
             off += b - a
     return out.numpy() if as_numpy else out
+
+
+def gather_blocks(local, layout, array_type, group=None, dst=None, within_atom_proc=False):
+    """Assemble a full HOST array of `array_type` ('e', 'ep', 'ep2', 'epp') from the blocks the ranks hold under the
+    layout's processor grid -- rows by atom-processor, columns by parameter-processor (`layout.owned_blocks`) -- through
+    the control group (gather_local_array, distlayout.py:1010-1156).
+
+    dst : None -> every rank receives the assembled array; int -> only that rank does (the others get None).
+    within_atom_proc : only the blocks of this rank's own atom-processor are placed (what fill_jtj needs: whole rows of
+        the rank's own atoms); rows of other atom-processors keep the local array's content."""
+    import torch
+    import torch.distributed as dist
+    loc = np.ascontiguousarray(local)
+    rank, size = dist.get_rank(group), dist.get_world_size(group)
+    if array_type in ("e",) or layout.processor_grid[1] * layout.processor_grid[2] == 1:
+        if not within_atom_proc:
+            return gather_elements(loc, layout, group, dst)
+
+    def cut(arr, blk):
+        r0, r1, c1, c2 = blk
+        v = arr[r0:r1]
+        if c1 is not None: v = v[:, c1]
+        if c2 is not None: v = v[:, :, c2]
+        return v
+    blocks = [layout.owned_blocks(array_type, r) for r in range(size)]
+    tail = loc.shape[{"e": 1, "ep": 2, "ep2": 2, "epp": 3}[array_type]:]
+    unit = int(np.prod(tail)) if tail else 1
+    counts = [sum(cut(loc, b).size for b in bl) for bl in blocks]          # (shapes only: views)
+    pad = max(max(counts), 1)
+    send = torch.zeros(pad, dtype=torch.from_numpy(loc.reshape(-1)[:1]).dtype)
+    off = 0
+    for b in blocks[rank]:
+        v = np.ascontiguousarray(cut(loc, b)).reshape(-1)
+        send[off:off + v.size] = torch.from_numpy(v)
+        off += v.size
+    if dst is None:
+        recv = [torch.empty_like(send) for _ in range(size)]
+        dist.all_gather(recv, send, group=group)
+    else:
+        recv = [torch.empty_like(send) for _ in range(size)] if rank == dst else None
+        dist.gather(send, recv, dst=dst, group=group)
+        if rank != dst:
+            return None
+    out = loc.copy() if within_atom_proc else np.empty_like(loc)
+    na, np1, np2 = layout.processor_grid
+    for r in range(size):
+        if within_atom_proc and r // (np1 * np2) != layout.atom_proc_index:
+            continue
+        buf = recv[r].numpy(); off = 0
+        for b in blocks[r]:
+            v = cut(out, b)
+            v[...] = buf[off:off + v.size].reshape(v.shape)
+            off += v.size
+    return out
 
 
 def allreduce_sum_host(arr, group=None, expect_size=1, comm=None):

@@ -108,12 +108,18 @@ class HipMapForwardSimulator:
         labels."""
         rank = getattr(resource_alloc, "comm_rank", 0) if resource_alloc is not None else 0
         size = getattr(resource_alloc, "comm_size", 1) if resource_alloc is not None else 1
-        natoms = self._num_atoms if self._num_atoms is not None else max(size, len(self.devices or [0]))
+        natoms_default = self._processor_grid[0] if self._processor_grid else max(size, len(self.devices or [0]))
+        natoms = self._num_atoms if self._num_atoms is not None else natoms_default
         blk = tuple(self._pblk_sizes) if self._pblk_sizes else (None, None)
         if len(blk) == 1:
             blk = (blk[0], None)
+        grid = self._processor_grid
+        if grid is None and size > 1 and self._num_atoms is not None and self._num_atoms < size and size % self._num_atoms == 0:
+            # fewer atoms than ranks: the ranks left over split the parameter columns (the reference's automatic grid,
+            # distforwardsim.py:469-481: na = gcd(nprocs, natoms), the rest of the processors on the first parameter dimension)
+            grid = (self._num_atoms, size // self._num_atoms)
         return HipCOPALayout(circuits, self.model, natoms, self.devices, rank, size, self.target_tasks, blk, dataset=dataset,
-                             mpi_comm=getattr(resource_alloc, "comm", None))
+                             mpi_comm=getattr(resource_alloc, "comm", None), processor_grid=grid)
 
     # -- per-atom seams (mapforwardsim.py:372-391) ---------------------------------------------------------------
     def _prepare_atom(self, layout_atom):
@@ -219,16 +225,21 @@ class HipMapForwardSimulator:
                     else:
                         pr[...] = plan.memcpy_d2h(np.empty(atom.num_elements), d_p)
             return
+        # columns of the local array this rank fills (distforwardsim.py:399-433 `host_param_slice`): all of them, or its
+        # parameter-processor's slice of a full-width array
+        hps = layout.host_param_slice
+        whole = (hps.start == 0 and array_to_fill.shape[1] == Np)
         for atom in layout.atoms:
             es = atom.element_slice
             pr = None if pr_array_to_fill is None else pr_array_to_fill[es]
             if blk is None:
-                self._bulk_fill_dprobs_atom(array_to_fill[es, :], None, atom, gps, None, pr)
+                self._bulk_fill_dprobs_atom(array_to_fill[es, :], None if whole else hps, atom, gps, None, pr)
             else:
                 nblk = int(np.ceil(Np / blk))
                 for k, block in enumerate(_slice_up_range(Np, nblk)):
                     shifted = slice(block.start + gps.start, block.stop + gps.start)
-                    self._bulk_fill_dprobs_atom(array_to_fill[es, :], block, atom, shifted, None, pr if k == 0 else None)
+                    dest = slice(block.start + hps.start, block.stop + hps.start)
+                    self._bulk_fill_dprobs_atom(array_to_fill[es, :], dest, atom, shifted, None, pr if k == 0 else None)
                 if Np == 0 and pr is not None:
                     self._bulk_fill_probs_atom(pr, atom)
 
@@ -238,26 +249,32 @@ class HipMapForwardSimulator:
         gps1, gps2 = layout.global_param_slice, layout.global_param2_slice
         nP = self.model.num_params
         Np1, Np2 = _slice_len(gps1, nP), _slice_len(gps2, nP)
+        # the rank's own slices of full-width arrays (host_param_slice / host_param2_slice); None = the whole width
+        h1, h2 = layout.host_param_slice, layout.host_param2_slice
+        d1 = None if (h1.start == 0 and array_to_fill.shape[1] == Np1) else h1
+        d2 = None if (h2.start == 0 and array_to_fill.shape[2] == Np2) else h2
         for atom in layout.atoms:
             es = atom.element_slice
             if pr_array_to_fill is not None:
                 self._bulk_fill_probs_atom(pr_array_to_fill[es], atom)
             if deriv1_array_to_fill is not None:
-                self._bulk_fill_dprobs_atom(deriv1_array_to_fill[es, :], None, atom, gps1)
+                self._bulk_fill_dprobs_atom(deriv1_array_to_fill[es, :], d1, atom, gps1)
             if deriv2_array_to_fill is not None:
                 if deriv1_array_to_fill is not None and gps1 == gps2:
-                    deriv2_array_to_fill[es, :] = deriv1_array_to_fill[es, :]
+                    deriv2_array_to_fill[es, h2] = deriv1_array_to_fill[es, h1]
                 else:
-                    self._bulk_fill_dprobs_atom(deriv2_array_to_fill[es, :], None, atom, gps2)
+                    self._bulk_fill_dprobs_atom(deriv2_array_to_fill[es, :], d2, atom, gps2)
             if b1 is None and b2 is None:
-                self._bulk_fill_hprobs_atom(array_to_fill[es, :, :], None, None, atom, gps1, gps2)
+                self._bulk_fill_hprobs_atom(array_to_fill[es, :, :], d1, d2, atom, gps1, gps2)
             else:
                 assert b1 is not None and b2 is not None, "Both (or neither) of the Hessian block sizes must be specified!"
                 for blk1 in _slice_up_range(Np1, int(np.ceil(Np1 / b1))):
                     g1 = slice(blk1.start + gps1.start, blk1.stop + gps1.start)
+                    t1 = slice(blk1.start + h1.start, blk1.stop + h1.start)
                     for blk2 in _slice_up_range(Np2, int(np.ceil(Np2 / b2))):
                         g2 = slice(blk2.start + gps2.start, blk2.stop + gps2.start)
-                        self._bulk_fill_hprobs_atom(array_to_fill[es, :, :], blk1, blk2, atom, g1, g2)
+                        t2 = slice(blk2.start + h2.start, blk2.stop + h2.start)
+                        self._bulk_fill_hprobs_atom(array_to_fill[es, :, :], t1, t2, atom, g1, g2)
 
     def iter_hprobs_by_rectangle(self, layout, wrt_slices_list, return_dprobs_12=False):
         """Yield (wrtSlice1, wrtSlice2, hprobs[, dprobs12]) per rectangle (forwardsim.py:787-878,

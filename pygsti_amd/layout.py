@@ -23,6 +23,17 @@ from . import _lib
 from .model import KIND_GATE, KIND_RHO, KIND_EFFECT
 
 
+def _slice_up_range(n, num_slices):
+    """mpitools.slice_up_range (mpitools.py:240-270): `num_slices` nearly equal contiguous slices of range(n)."""
+    base, rem = divmod(n, num_slices)
+    out, start = [], 0
+    for i in range(num_slices):
+        ln = base + (1 if i < rem else 0)
+        out.append(slice(start, start + ln))
+        start += ln
+    return out
+
+
 class _ResourceAlloc:
     """Stand-in for pygsti.baseobjs.ResourceAllocation on the serial/one-process-per-GPU path."""
 
@@ -83,7 +94,7 @@ class HipLayoutAtom:
 
 class HipCOPALayout:
     def __init__(self, circuits, model, num_atoms=1, devices=None, rank=0, size=1, target_tasks=0,
-                 param_dimension_blk_sizes=(None, None), max_slots=0, dataset=None, mpi_comm=None):
+                 param_dimension_blk_sizes=(None, None), max_slots=0, dataset=None, mpi_comm=None, processor_grid=None):
         self.circuits = [tuple(c) for c in circuits]
         self.num_circuits = len(self.circuits)
         self.model_gate_labels = list(model.operations.keys())
@@ -179,14 +190,34 @@ class HipCOPALayout:
             atoms.append(HipLayoutAtom(self, idx, slice(off, off + n_el), devices[a % len(devices)]))
             off += n_el
         self.all_atoms = atoms
-        # one process per GPU: this rank owns atoms rank, rank+size, ... (all of them when size == 1)
-        self.atoms = [at for a, at in enumerate(atoms) if a % size == rank]
+        # ---- processor grid (distforwardsim.py:445-485 `_compute_processor_distribution`, distlayout.py:424-660) ----------
+        # (na, np1[, np2]): the ranks form `na` atom-processors of np1 * np2 ranks each; the ranks of one atom-processor
+        # hold the same atoms and split the parameter columns (np1 slices; np2 slices of the second Hessian dimension)
+        # among themselves, hierarchically and in rank order as the reference's nested sub-communicators do.  Default:
+        # one rank per atom-processor -- atoms are the only axis.
+        grid = tuple(int(x) for x in processor_grid) if processor_grid else (size,)
+        na = grid[0]; np1 = grid[1] if len(grid) > 1 else 1; np2 = grid[2] if len(grid) > 2 else 1
+        if len(grid) > 3 or min(na, np1, np2) < 1 or na * np1 * np2 != size:
+            raise ValueError("processor_grid %r must be (na, np1[, np2]) with na * np1 * np2 == %d ranks" % (processor_grid, size))
+        if np1 > max(self._num_params, 1) or np2 > max(self._num_params, 1):
+            raise ValueError("more parameter-processors than parameters")
+        self.processor_grid = (na, np1, np2)
+        q = rank % (np1 * np2)
+        self.atom_proc_index, self.param_proc_index, self.param2_proc_index = rank // (np1 * np2), q // np2, q % np2
+        self.param_slices = _slice_up_range(self._num_params, np1)          # matches the param-processor indices
+        self.param2_slices = _slice_up_range(self._num_params, np2)
+        self.max_param_slice_length = max(s.stop - s.start for s in self.param_slices)
+        # one process per GPU: atom-processor k owns atoms k, k+na, ... (all of them when there is one)
+        self.atoms = [at for a, at in enumerate(atoms) if a % na == self.atom_proc_index]
         self.num_elements = self.global_num_elements   # arrays are allocated full-size; see allocate_local_array
         self.host_element_slice = slice(0, self.global_num_elements)
-        self.global_param_slice = slice(0, self._num_params)
-        self.global_param2_slice = slice(0, self._num_params)
+        self.global_param_slice = self.param_slices[self.param_proc_index]
+        self.global_param2_slice = self.param2_slices[self.param2_proc_index]
+        # full-size arrays on every rank (the reference's one-host case, distlayout.py:519-521: a host holds all
+        # parameters and every rank writes its own slice): positions in the array ARE the parameter indices
         self.host_param_slice = self.global_param_slice
         self.host_param2_slice = self.global_param2_slice
+        self.num_params = self.global_param_slice.stop - self.global_param_slice.start
         self.param_dimension_blk_sizes = tuple(param_dimension_blk_sizes)
         self.global_num_params = self._num_params
         self.host_num_elements = self.global_num_elements
@@ -272,16 +303,41 @@ class HipCOPALayout:
         if isinstance(local_array, np.ndarray):
             _lib.unpin_host_array(local_array)
 
+    # ---- who holds what (processor grid) ---------------------------------------------------------------------------
+    def rank_of(self, atom_proc, param_proc=0, param2_proc=0):
+        na, np1, np2 = self.processor_grid
+        return (atom_proc * np1 + param_proc) * np2 + param2_proc
+
+    def atom_owner_rank(self, atom_index):
+        """The first rank of the atom-processor that holds atom `atom_index` (the one that contributes its rows to
+        element-only gathers; its peers hold the same rows)."""
+        return self.rank_of(atom_index % self.processor_grid[0])
+
+    def owned_blocks(self, array_type, rank):
+        """[(row start, row stop, col slice or None, col2 slice or None)]: the blocks of a full-size local array of
+        `array_type` that `rank` is the one to contribute to a gather (every entry of the global array has exactly one
+        contributor: rows by atom-processor, columns by parameter-processor; ranks that hold copies contribute nothing)."""
+        na, np1, np2 = self.processor_grid
+        q = rank % (np1 * np2)
+        ia, ip1, ip2 = rank // (np1 * np2), q // np2, q % np2
+        dims = {"e": 0, "ep": 1, "ep2": 1, "epp": 2}[array_type]
+        if (dims < 2 and ip2 != 0 and array_type != "ep2") or (dims < 1 and ip1 != 0) or (array_type == "ep2" and ip1 != 0):
+            return []
+        c1 = None if dims == 0 else (self.param2_slices[ip2] if array_type == "ep2" else self.param_slices[ip1])
+        c2 = self.param2_slices[ip2] if dims == 2 else None
+        return [(at.element_slice.start, at.element_slice.stop, c1, c2) for a, at in enumerate(self.all_atoms) if a % na == ia]
+
     def gather_local_array(self, array_type, array_portion, extra_elements=0, all_gather=False, return_shared=False):
         """Assemble the global array from the ranks' portions (distlayout.py:1010-1156): element-dimension arrays
-        ('e', 'ep', 'ep2', 'epp') are full-size on every rank with only the rank's own atoms filled, so the row blocks
-        travel to rank 0 (Gatherv) or to every rank (`all_gather`); the other ranks get None, as in the reference.
-        Host arrays go through the control group (pygsti_amd.dist); device arrays have `dist.gather_elements_dev`."""
+        ('e', 'ep', 'ep2', 'epp') are full-size on every rank with only the rank's own atoms (rows) and parameter slices
+        (columns) filled, so the blocks travel to rank 0 (Gatherv) or to every rank (`all_gather`); the other ranks get
+        None, as in the reference.  Host arrays go through the control group (pygsti_amd.dist); device arrays have
+        `dist.gather_elements_dev`."""
         if self._size == 1 or array_type not in ("e", "ep", "ep2", "epp"):
             return array_portion
         from . import dist as _dist
         nE = self.global_num_elements
-        body = _dist.gather_elements(np.ascontiguousarray(array_portion[:nE]), self, dst=None if all_gather else 0)
+        body = _dist.gather_blocks(np.ascontiguousarray(array_portion[:nE]), self, array_type, dst=None if all_gather else 0)
         if body is None:
             return None
         if extra_elements:
@@ -300,15 +356,38 @@ class HipCOPALayout:
         plan.memcpy_h2d(d, rows)
         return plan, d
 
+    def _complete_columns(self, j):
+        """With parameter-processors (np1 > 1) a rank's 'ep' array holds only its own column slice of its atoms' rows;
+        the products below need whole rows.  The reference broadcasts every slice's transpose within the atom-processor
+        (fill_jtj, distlayout.py:1306-1346); here the column blocks are exchanged through the control group."""
+        if self.processor_grid[1] == 1:
+            return j
+        from . import dist as _dist
+        return _dist.gather_blocks(np.ascontiguousarray(j[:self.global_num_elements]), self, "ep", dst=None, within_atom_proc=True)
+
+    def _row_share(self, atom):
+        """The rows of `atom` whose products THIS rank computes: the ranks of an atom-processor hold the same rows (after
+        _complete_columns) and split them evenly, so that every GPU does 1/size of the contraction."""
+        na, np1, np2 = self.processor_grid
+        es = atom.element_slice
+        share = _slice_up_range(es.stop - es.start, np1 * np2)[self.param_proc_index * np2 + self.param2_proc_index]
+        return slice(es.start + share.start, es.start + share.stop)
+
     def fill_jtj(self, j, jtj):
         """jtj[:] = j.T @ j for a host 'ep' array: each owned atom's rows are contracted by the split-K MFMA kernel on
         that atom's GPU, the partial products are added and all-reduced over the ranks (fill_jtj, distlayout.py:1259)."""
         nP = j.shape[1]
         acc = np.zeros((nP, nP))
+        j = self._complete_columns(j)
         for atom in self.atoms:
-            plan, d_j = self._owned_rows_to_device(atom, j, "njJ")
+            rows = self._row_share(atom)
+            if rows.stop <= rows.start:
+                continue
+            plan = atom.plan()
+            blk = np.ascontiguousarray(j[rows], dtype=np.float64)
+            d_j = plan.workspace("njJ", max(blk.nbytes, 8)); plan.memcpy_h2d(d_j, blk)
             d_out = plan.workspace("njC", nP * nP * 8)
-            plan.fill_jtj_dev(d_j, atom.num_elements, nP, nP, d_out)
+            plan.fill_jtj_dev(d_j, rows.stop - rows.start, nP, nP, d_out)
             part = np.empty((nP, nP)); plan.memcpy_d2h(part, d_out); acc += part
         if self._size > 1:
             from . import dist as _dist
@@ -319,11 +398,17 @@ class HipCOPALayout:
         """jtf[:] = j.T @ f (distlayout.py:1220-1257), same arrangement as fill_jtj."""
         nP = j.shape[1]
         acc = np.zeros(nP)
+        j = self._complete_columns(j)
         for atom in self.atoms:
-            plan, d_j = self._owned_rows_to_device(atom, j, "njJ")
-            _, d_f = self._owned_rows_to_device(atom, f, "njF")
+            rows = self._row_share(atom)
+            if rows.stop <= rows.start:
+                continue
+            plan = atom.plan()
+            blk = np.ascontiguousarray(j[rows], dtype=np.float64); fv = np.ascontiguousarray(f[rows], dtype=np.float64)
+            d_j = plan.workspace("njJ", max(blk.nbytes, 8)); plan.memcpy_h2d(d_j, blk)
+            d_f = plan.workspace("njF", max(fv.nbytes, 8)); plan.memcpy_h2d(d_f, fv)
             d_out = plan.workspace("njV", nP * 8)
-            plan.fill_jtf_dev(d_j, atom.num_elements, nP, nP, d_f, d_out)
+            plan.fill_jtf_dev(d_j, rows.stop - rows.start, nP, nP, d_f, d_out)
             part = np.empty(nP); plan.memcpy_d2h(part, d_out); acc += part
         if self._size > 1:
             from . import dist as _dist

@@ -84,3 +84,64 @@ def test_two_rank_sharding_and_gather():
     owners = full0[:, 1]
     for a, at in enumerate(lay.all_atoms):
         assert (owners[at.element_slice] == a % 2).all()
+
+
+def _grid_worker(rank, size, port, q, grid, n_atoms):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size))
+    import torch.distributed as dist
+    from pygsti_amd import modelpacks as MP, dist as gdist
+    from pygsti_amd.layout import HipCOPALayout
+    ctx = gdist.init(want_comm=False)
+    pack = MP.smq1Q_XYI
+    model = pack.target_model().depolarize(0.01, 0.01)
+    lay = HipCOPALayout(pack.create_gst_circuits(2), model, num_atoms=n_atoms, rank=rank, size=size, processor_grid=grid)
+    nE, nP = lay.global_num_elements, model.num_params
+    want = {"e": np.arange(nE) * 1.0,
+            "ep": np.arange(nE)[:, None] * 1000.0 + np.arange(nP)[None, :],
+            "epp": np.arange(nE)[:, None, None] * 1e6 + np.arange(nP)[None, :, None] * 1e3 + np.arange(nP)[None, None, :]}
+    ok = True
+    for t, full in want.items():
+        # what THIS rank's fills produce: its atoms' rows, its parameter slice(s) -- everything else NaN
+        loc = np.full(full.shape, np.nan)
+        for at in lay.atoms:
+            es = at.element_slice
+            if t == "e": loc[es] = full[es]
+            elif t == "ep": loc[es, lay.host_param_slice] = full[es, lay.host_param_slice]
+            else: loc[es, lay.host_param_slice, lay.host_param2_slice] = full[es, lay.host_param_slice, lay.host_param2_slice]
+        g_all = lay.allgather_local_array(t, loc)
+        g_root = lay.gather_local_array(t, loc)
+        ok = ok and np.array_equal(g_all, full) and ((g_root is None) if rank != 0 else np.array_equal(g_root, full))
+        if t == "ep":       # whole rows of the rank's own atoms (what fill_jtj contracts), other atom-processors' rows untouched
+            comp = lay._complete_columns(loc)
+            for a, at in enumerate(lay.all_atoms):
+                mine = a % lay.processor_grid[0] == lay.atom_proc_index
+                ok = ok and (np.array_equal(comp[at.element_slice], full[at.element_slice]) if mine else np.isnan(comp[at.element_slice]).all())
+    shares = [(lay._row_share(at).start, lay._row_share(at).stop) for at in lay.atoms]
+    q.put((rank, ok, shares, [(at.element_slice.start, at.element_slice.stop) for at in lay.atoms]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid,n_atoms", [((1, 2), 2), ((2, 2), 4), ((1, 2, 2), 1)])
+def test_processor_grid_gathers_on_cpu(grid, n_atoms):
+    """Parameter-processors (distlayout.py:424-660) over gloo: every rank holds its atoms' rows x its parameter slice(s) of
+    full-size host arrays; gather / all-gather of 'e', 'ep', 'epp' arrays assemble the global array, `_complete_columns`
+    gives an atom-processor's ranks whole rows, and their row shares partition each atom for the JtJ products."""
+    import torch.multiprocessing as mp
+    size = int(np.prod(grid))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 3 + size * 31 + n_atoms) % 2000
+    procs = [ctx.Process(target=_grid_worker, args=(r, size, port, q, grid, n_atoms)) for r in range(size)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=240) for _ in range(size)], key=lambda t: t[0])
+    for p in procs: p.join(timeout=60)
+    assert all(r[1] for r in res)
+    per = size // grid[0]
+    for ap in range(grid[0]):
+        group = res[ap * per:(ap + 1) * per]
+        atoms = group[0][3]
+        assert all(g[3] == atoms for g in group)
+        for k, (a0, a1) in enumerate(atoms):      # the group's row shares tile each of its atoms
+            cuts = sorted(g[2][k] for g in group)
+            assert cuts[0][0] == a0 and cuts[-1][1] == a1 and all(cuts[i][1] == cuts[i + 1][0] for i in range(len(cuts) - 1))

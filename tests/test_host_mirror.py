@@ -288,3 +288,40 @@ def test_several_preparations_and_povms_in_the_host_mirror(natoms):
         assert_bitwise(p[sl], want, "circuit %d %s" % (i, c))
     with pytest.raises(ValueError):
         sim.create_layout([("Gxpi2:0",)])                 # two preparations: a circuit must name its own
+
+
+@pytest.mark.parametrize("grid,n_atoms", [((2, 2), 4), ((1, 2, 2), 1), ((2, 1, 2), 4), ((1, 3), 2), ((4,), 4)])
+def test_processor_grid_partitions_every_array_type(grid, n_atoms):
+    """The reference's processor grid (distforwardsim.py:445-485; distlayout.py:424-660): `na` atom-processors, each split
+    into np1 (x np2) parameter-processors in rank order.  Every entry of a global 'e' / 'ep' / 'ep2' / 'epp' array has exactly
+    one contributing rank; the ranks of an atom-processor hold the same atoms; parameter slices are mpitools.slice_up_range's."""
+    from pygsti_amd import modelpacks as MP
+    from pygsti_amd.layout import HipCOPALayout, _slice_up_range
+    pack = MP.smq1Q_XYI
+    model = pack.target_model().depolarize(0.01, 0.01)
+    circ = pack.create_gst_circuits(2)
+    size = int(np.prod(grid))
+    lays = [HipCOPALayout(circ, model, num_atoms=n_atoms, rank=r, size=size, processor_grid=grid) for r in range(size)]
+    L = lays[0]
+    nE, nP = L.global_num_elements, model.num_params
+    na, np1, np2 = (tuple(grid) + (1, 1))[:3]
+    for t, shape in (("e", (nE,)), ("ep", (nE, nP)), ("ep2", (nE, nP)), ("epp", (nE, nP, nP))):
+        cnt = np.zeros(shape, int)
+        for r in range(size):
+            for r0, r1, c1, c2 in L.owned_blocks(t, r):
+                v = cnt[r0:r1]
+                if c1 is not None: v = v[:, c1]
+                if c2 is not None: v = v[:, :, c2]
+                v += 1
+        assert (cnt == 1).all(), (grid, t)
+    for r, l in enumerate(lays):
+        q = r % (np1 * np2)
+        assert (l.atom_proc_index, l.param_proc_index, l.param2_proc_index) == (r // (np1 * np2), q // np2, q % np2)
+        assert l.global_param_slice == _slice_up_range(nP, np1)[q // np2] and l.global_param2_slice == _slice_up_range(nP, np2)[q % np2]
+        assert [a.element_slice for a in l.atoms] == [a.element_slice for a in lays[l.rank_of(l.atom_proc_index)].atoms]
+        assert l.rank_of(l.atom_proc_index, l.param_proc_index, l.param2_proc_index) == r
+    assert sorted(a.element_slice.start for r in range(0, size, np1 * np2) for a in lays[r].atoms) == [a.element_slice.start for a in L.all_atoms]
+    sizes = [s.stop - s.start for s in L.param_slices]
+    assert sum(sizes) == nP and max(sizes) - min(sizes) <= 1 and L.max_param_slice_length == max(sizes)
+    with pytest.raises(ValueError):
+        HipCOPALayout(circ, model, num_atoms=n_atoms, rank=0, size=size + 1, processor_grid=grid)
