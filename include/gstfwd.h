@@ -313,6 +313,12 @@ int gst_fill_jtj_dev(gst_plan *plan, double *d_J, int64_t n_rows, int64_t n_cols
 int gst_fill_jtf_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
                      const double *d_f, double *d_jtf);
 int gst_memcpy_h2d(gst_plan *plan, void *d_dst, const void *src, int64_t nbytes);
+/* A rows x cols block of doubles between two device arrays with their own leading dimensions (in doubles), enqueued on
+ * the plan's stream.  No counterpart in the reference, whose arrays live on the host: it is what re-assembles whole
+ * Jacobian rows from the column blocks the parameter-processors of an atom-processor hold (the reference broadcasts
+ * transposed column blocks between host arrays for the same purpose, layouts/distlayout.py:1306-1346). */
+int gst_copy_block_dev(gst_plan *plan, double *d_dst, int64_t dst_ld, const double *d_src, int64_t src_ld,
+                       int64_t n_rows, int64_t n_cols);
 
 /* Element-wise objective maps on device-resident probabilities (row f1): what the reference evaluates with numpy
  * between bulk_fill_dprobs and fill_jtj -- RawChi2Function / RawPoissonPicDeltaLogLFunction .terms/.lsvec/.dterms
@@ -395,6 +401,16 @@ int gst_comm_allgather_rows(gst_comm *comm, gst_plan *plan, double *d_full, int6
 int gst_comm_gather_rows(gst_comm *comm, gst_plan *plan, const double *d_local, double *d_full, int64_t row_doubles,
                          int32_t n_blocks, const int32_t *blk_owner, const int64_t *blk_row0, const int64_t *blk_rows,
                          int32_t root);
+/* General block exchange between device arrays (an Alltoallv): block b = blk_count[b] doubles read at d_src + blk_src_off[b]
+ * on rank blk_src_rank[b] and written at d_dst + blk_dst_off[b] on rank blk_dst_rank[b] (offsets in doubles; a block whose two
+ * ranks coincide is a local copy).  Every rank passes the same list and its OWN d_src / d_dst.  This is the exchange step of
+ * the normal equations when the Jacobian's columns are distributed over the parameter-processors of an atom-processor
+ * (layouts/distlayout.py:1306-1346: the reference broadcasts each column slice's transpose between host arrays): every
+ * rank sends its columns of the row range another rank will contract and receives that range's other columns.  Grouped
+ * ncclSend / ncclRecv under RCCL (each pair over its own xGMI link), peer copies under the IPC transport. */
+int gst_comm_exchange_blocks(gst_comm *comm, gst_plan *plan, const double *d_src, double *d_dst, int32_t n_blocks,
+                             const int32_t *blk_src_rank, const int32_t *blk_dst_rank, const int64_t *blk_src_off,
+                             const int64_t *blk_dst_off, const int64_t *blk_count);
 /* d_buf[0..n) <- sum over ranks of their d_buf, on every rank (in place). */
 int gst_comm_allreduce_sum(gst_comm *comm, gst_plan *plan, double *d_buf, int64_t n);
 int gst_comm_barrier(gst_comm *comm);                 /* all ranks have reached this call; outstanding exchanges done */

@@ -79,12 +79,12 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_get_fd_queues", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_get_fd_queues", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
            "gst_comm_get_unique_id", "gst_comm_create", "gst_comm_destroy", "gst_comm_allgather_rows",
-           "gst_comm_gather_rows", "gst_comm_allreduce_sum", "gst_comm_barrier", "gst_comm_sync", "gst_comm_get_info"]
+           "gst_comm_gather_rows", "gst_comm_exchange_blocks", "gst_comm_allreduce_sum", "gst_comm_barrier", "gst_comm_sync", "gst_comm_get_info"]
 
 _lib = None
 
@@ -119,6 +119,7 @@ def lib():
         L.gst_objective_rows_dev.argtypes = [vp, C.POINTER(ObjectiveDesc), vp, vp, vp, i64, vp, vp, vp, C.POINTER(C.c_double)]
         L.gst_objective_hessian_block.argtypes = [vp, C.POINTER(ObjectiveDesc), vp, vp, vp, i64, vp, i64, C.c_double, vp]
         L.gst_memcpy_h2d.argtypes = [vp, vp, vp, i64]
+        L.gst_copy_block_dev.argtypes = [vp, vp, i64, vp, i64, i64, i64]
         L.gst_sync.argtypes = [vp]
         L.gst_device_malloc.argtypes = [vp, i64, C.POINTER(vp)]
         L.gst_device_free.argtypes = [vp, vp]
@@ -142,6 +143,7 @@ def lib():
         L.gst_comm_destroy.argtypes = [vp]
         L.gst_comm_allgather_rows.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
         L.gst_comm_gather_rows.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, i32]
+        L.gst_comm_exchange_blocks.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.gst_comm_allreduce_sum.argtypes = [vp, vp, vp, i64]
         L.gst_comm_barrier.argtypes = [vp]
         L.gst_comm_sync.argtypes = [vp]
@@ -541,6 +543,10 @@ class Plan:
         arr = np.ascontiguousarray(arr)
         check(lib().gst_memcpy_h2d(self._h, C.c_void_p(int(d_ptr) + int(offset_bytes)), _ptr(arr), arr.nbytes))
 
+    def copy_block_dev(self, d_dst, dst_ld, d_src, src_ld, n_rows, n_cols):
+        """rows x cols doubles between device arrays with leading dimensions dst_ld / src_ld (doubles); asynchronous"""
+        check(lib().gst_copy_block_dev(self._h, C.c_void_p(int(d_dst)), int(dst_ld), C.c_void_p(int(d_src)), int(src_ld), int(n_rows), int(n_cols)))
+
     def device_malloc(self, nbytes):
         p = C.c_void_p()
         check(lib().gst_device_malloc(self._h, int(nbytes), C.byref(p)))
@@ -634,6 +640,16 @@ class Comm:
                                          None if d_local is None else C.c_void_p(int(d_local)),
                                          None if d_full is None else C.c_void_p(int(d_full)), int(row_doubles),
                                          len(owner), _ptr(owner), _ptr(row0), _ptr(rows), int(root)))
+
+    def exchange_blocks(self, d_src, d_dst, blocks, plan=None):
+        """blocks = [(src rank, dst rank, src offset, dst offset, count)] in doubles: the same list on every rank, each with
+        its own d_src / d_dst (gst_comm_exchange_blocks)"""
+        sr = _i32([b[0] for b in blocks]); dr = _i32([b[1] for b in blocks])
+        so = _i64([b[2] for b in blocks]); do = _i64([b[3] for b in blocks]); cn = _i64([b[4] for b in blocks])
+        check(lib().gst_comm_exchange_blocks(self._h, None if plan is None else plan._h,
+                                             None if d_src is None else C.c_void_p(int(d_src)),
+                                             None if d_dst is None else C.c_void_p(int(d_dst)),
+                                             len(sr), _ptr(sr), _ptr(dr), _ptr(so), _ptr(do), _ptr(cn)))
 
     def allreduce_sum(self, d_buf, n, plan=None):
         check(lib().gst_comm_allreduce_sum(self._h, None if plan is None else plan._h, C.c_void_p(int(d_buf)), int(n)))

@@ -2621,6 +2621,19 @@ int gst_memcpy_h2d(gst_plan* p, void* d_dst, const void* src, int64_t nbytes)
     });
 }
 
+int gst_copy_block_dev(gst_plan* p, double* d_dst, int64_t dst_ld, const double* d_src, int64_t src_ld, int64_t n_rows, int64_t n_cols)
+{
+    return guarded([&]() -> int {
+    if (!p || n_rows < 0 || n_cols < 0 || dst_ld < n_cols || src_ld < n_cols) return fail(GST_EINVAL, "bad argument");
+    if (n_rows == 0 || n_cols == 0) return GST_OK;
+    if (!d_dst || !d_src) return fail(GST_EINVAL, "NULL pointer");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(d_dst, (size_t)dst_ld * 8, d_src, (size_t)src_ld * 8, (size_t)n_cols * 8, (size_t)n_rows, hipMemcpyDeviceToDevice, p->stream));
+    return GST_OK;
+    });
+}
+
 int gst_device_malloc(gst_plan* p, int64_t nbytes, void** d_ptr)
 {
     return guarded([&]() -> int {

@@ -326,6 +326,61 @@ int exchange_rows(gst_comm* c, hipStream_t st, const double* d_local, double* d_
     return ipc_barrier(c);
 }
 
+// General block exchange (Alltoallv on device pointers): block k = cnt[k] doubles from rank src_rank[k]'s d_src + src_off[k]
+// to rank dst_rank[k]'s d_dst + dst_off[k].  Every rank passes the same list and its own two base pointers.
+int exchange_blocks(gst_comm* c, hipStream_t st, const double* d_src, double* d_dst, int32_t n, const int32_t* src_rank,
+                    const int32_t* dst_rank, const int64_t* src_off, const int64_t* dst_off, const int64_t* cnt)
+{
+    bool i_send = false, i_recv = false;
+    for (int32_t k = 0; k < n; k++) {
+        if (src_rank[k] < 0 || src_rank[k] >= c->size || dst_rank[k] < 0 || dst_rank[k] >= c->size || src_off[k] < 0 || dst_off[k] < 0 || cnt[k] < 0)
+            return set_error(GST_EINVAL, "block " + std::to_string(k) + ": rank, offset or count out of range");
+        if (cnt[k] == 0) continue;
+        if (src_rank[k] == c->rank) i_send = true;
+        if (dst_rank[k] == c->rank) i_recv = true;
+    }
+    if (i_send && !d_src) return set_error(GST_EINVAL, "d_src is NULL on a sending rank");
+    if (i_recv && !d_dst) return set_error(GST_EINVAL, "d_dst is NULL on a receiving rank");
+    HIP_TRYC(hipSetDevice(c->device));
+    // blocks that stay on their rank: a device-to-device copy in stream order
+    for (int32_t k = 0; k < n; k++)
+        if (cnt[k] > 0 && src_rank[k] == c->rank && dst_rank[k] == c->rank)
+            HIP_TRYC(hipMemcpyAsync(d_dst + dst_off[k], d_src + src_off[k], (size_t)cnt[k] * 8, hipMemcpyDeviceToDevice, st));
+    if (c->size == 1 && c->transport != GST_TRANSPORT_RCCL) return GST_OK;
+    if (c->transport == GST_TRANSPORT_RCCL) {
+        const RcclApi* A = c->api;
+        NCCL_TRY(A, A->GroupStart());
+        ncclResult_t bad = ncclSuccess;
+        const char* what = "";
+        for (int32_t k = 0; k < n && bad == ncclSuccess; k++) {
+            if (cnt[k] == 0 || src_rank[k] == dst_rank[k]) continue;
+            if (src_rank[k] == c->rank) { bad = A->Send(d_src + src_off[k], (size_t)cnt[k], ncclDouble, dst_rank[k], c->nccl, st); what = "ncclSend"; }
+            else if (dst_rank[k] == c->rank) { bad = A->Recv(d_dst + dst_off[k], (size_t)cnt[k], ncclDouble, src_rank[k], c->nccl, st); what = "ncclRecv"; }
+        }
+        const ncclResult_t ended = A->GroupEnd();
+        if (bad != ncclSuccess) return set_error(GST_EHIP, std::string(what) + ": " + A->GetErrorString(bad));
+        if (ended != ncclSuccess) return set_error(GST_EHIP, std::string("ncclGroupEnd: ") + A->GetErrorString(ended));
+        return GST_OK;
+    }
+    // IPC: receivers publish d_dst; after the barrier every sender copies its blocks straight into the receivers' arrays
+    HIP_TRYC(hipStreamSynchronize(st));
+    int rc;
+    if (i_recv && (rc = ipc_publish(c, d_dst))) return rc;
+    if ((rc = ipc_barrier(c))) return rc;
+    for (int r = 0; r < c->size; r++) {
+        if (r == c->rank) continue;
+        char* peer = nullptr;
+        bool have = false;
+        for (int32_t k = 0; k < n; k++) {
+            if (src_rank[k] != c->rank || dst_rank[k] != r || cnt[k] == 0) continue;
+            if (!have) { if ((rc = ipc_peer_ptr(c, r, &peer))) return rc; have = true; }
+            HIP_TRYC(hipMemcpyAsync(peer + (size_t)dst_off[k] * 8, d_src + src_off[k], (size_t)cnt[k] * 8, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    HIP_TRYC(hipStreamSynchronize(st));
+    return ipc_barrier(c);
+}
+
 hipStream_t pick_stream(gst_comm* c, gst_plan* plan, int* rc)
 {
     *rc = GST_OK;
@@ -535,6 +590,20 @@ int gst_comm_gather_rows(gst_comm* c, gst_plan* plan, const double* d_local, dou
         hipStream_t st = pick_stream(c, plan, &rc);
         if (rc) return rc;
         return exchange_rows(c, st, d_local, d_full, row_doubles, b, root);
+    });
+}
+
+int gst_comm_exchange_blocks(gst_comm* c, gst_plan* plan, const double* d_src, double* d_dst, int32_t n_blocks, const int32_t* blk_src_rank,
+                             const int32_t* blk_dst_rank, const int64_t* blk_src_off, const int64_t* blk_dst_off, const int64_t* blk_count)
+{
+    return guarded([&]() -> int {
+        if (!c) return set_error(GST_EINVAL, "comm is NULL");
+        if (n_blocks < 0 || (n_blocks > 0 && (!blk_src_rank || !blk_dst_rank || !blk_src_off || !blk_dst_off || !blk_count)))
+            return set_error(GST_EINVAL, "bad block list");
+        int rc;
+        hipStream_t st = pick_stream(c, plan, &rc);
+        if (rc) return rc;
+        return exchange_blocks(c, st, d_src, d_dst, n_blocks, blk_src_rank, blk_dst_rank, blk_src_off, blk_dst_off, blk_count);
     });
 }
 

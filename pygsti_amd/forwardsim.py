@@ -326,6 +326,8 @@ class HipMapForwardSimulator:
         if jtf is not None:
             jtf[...] = 0.0
         mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
+        if layout.processor_grid[1] * layout.processor_grid[2] > 1:
+            return self._bulk_fill_jtj_jtf_grid(jtj, jtf, layout, row_scale, f, pr_array_to_fill, mode)
         pidx = np.arange(nP, dtype=np.int64)
         for atom in layout.atoms:
             plan = self._prepare_atom(atom)
@@ -350,6 +352,84 @@ class HipMapForwardSimulator:
                 for d in (d_J, d_pr, d_jtj, d_jtf, d_w, d_f):
                     if d is not None:
                         plan.device_free(d)
+
+    def _bulk_fill_jtj_jtf_grid(self, jtj, jtf, layout, row_scale, f, pr_array_to_fill, mode):
+        """bulk_fill_jtj_jtf under a processor grid with parameter-processors: a rank fills only ITS column slice of its
+        atoms' Jacobian rows, but J^T J needs whole rows.  The ranks of an atom-processor therefore split each atom's ROWS
+        among themselves and exchange, between device buffers, the column blocks of each other's row shares
+        (gst_comm_exchange_blocks: every pair of ranks its own transfer; the reference broadcasts transposed column
+        slices between host arrays, distlayout.py:1306-1346); each then contracts its [rows/G x nP] share on its GPU.  The
+        returned jtj / jtf are this rank's partial sums, as without a grid.  Needs `layout.device_comm` (a _lib.Comm)."""
+        comm = getattr(layout, "device_comm", None)
+        if comm is None:
+            raise RuntimeError("a processor grid with parameter-processors needs the device communicator: "
+                               "set layout.device_comm = pygsti_amd.dist.init(...).comm")
+        nP = self.model.num_params
+        na, np1, np2 = layout.processor_grid
+        G = np1 * np2
+        from .layout import _slice_up_range as _sur
+        cs = layout.param_slices
+        my_cols = cs[layout.param_proc_index]
+        c_mine = my_cols.stop - my_cols.start
+        pidx = np.arange(my_cols.start, my_cols.stop, dtype=np.int64)
+        qme = layout.param_proc_index * np2 + layout.param2_proc_index
+        atoms_of = [[at for a, at in enumerate(layout.all_atoms) if a % na == g] for g in range(na)]
+        for k in range(max(len(x) for x in atoms_of)):
+            mine = atoms_of[layout.atom_proc_index][k] if k < len(atoms_of[layout.atom_proc_index]) else None
+            # the same block list on every rank: in round k every atom-processor works on its k-th atom
+            blocks = []
+            for g in range(na):
+                if k >= len(atoms_of[g]):
+                    continue
+                nE_a = atoms_of[g][k].num_elements
+                shares = _sur(nE_a, G)
+                for ip1 in range(np1):
+                    c = cs[ip1].stop - cs[ip1].start
+                    src = layout.rank_of(g, ip1, 0)
+                    for q in range(G):
+                        n = shares[q].stop - shares[q].start
+                        blocks.append((src, layout.rank_of(g) + q, shares[q].start * c, n * cs[ip1].start, n * c))
+            plan = self._prepare_atom(mine if mine is not None else layout.atoms[0])
+            bufs = []
+            try:
+                d_J = d_stage = d_T = None
+                if mine is not None:
+                    nE_a = mine.num_elements
+                    es = mine.element_slice
+                    share = _sur(nE_a, G)[qme]
+                    n_my = share.stop - share.start
+                    d_J = plan.device_malloc(max(nE_a * c_mine, 1) * 8); bufs.append(d_J)
+                    d_pr = plan.device_malloc(max(nE_a, 1) * 8); bufs.append(d_pr)
+                    d_stage = plan.device_malloc(max(n_my * nP, 1) * 8); bufs.append(d_stage)
+                    d_T = plan.device_malloc(max(n_my * nP, 1) * 8); bufs.append(d_T)
+                    plan.fill_dprobs_dev(d_J, c_mine, pidx, None, self.derivative_eps, d_pr, mode)
+                comm.exchange_blocks(d_J, d_stage, blocks, plan)          # stream-ordered behind the fill (RCCL); collective
+                if mine is None:
+                    continue
+                for ip1 in range(np1):                                    # block-column-major staging -> row-major rows
+                    c = cs[ip1].stop - cs[ip1].start
+                    plan.copy_block_dev(d_T + cs[ip1].start * 8, nP, d_stage + n_my * cs[ip1].start * 8, c, n_my, c)
+                rows = slice(es.start + share.start, es.start + share.stop)
+                d_jtj = plan.device_malloc(nP * nP * 8); bufs.append(d_jtj)
+                d_w = None
+                if row_scale is not None and n_my:
+                    d_w = plan.device_malloc(n_my * 8); bufs.append(d_w)
+                    plan.memcpy_h2d(d_w, np.asarray(row_scale, np.float64)[rows])
+                if n_my:
+                    plan.fill_jtj_dev(d_T, n_my, nP, nP, d_jtj, d_w)
+                    part = np.empty((nP, nP)); plan.memcpy_d2h(part, d_jtj); jtj += part
+                    if jtf is not None:
+                        d_f = plan.device_malloc(n_my * 8); bufs.append(d_f)
+                        d_jtf = plan.device_malloc(nP * 8); bufs.append(d_jtf)
+                        plan.memcpy_h2d(d_f, np.asarray(f, np.float64)[rows])
+                        plan.fill_jtf_dev(d_T, n_my, nP, nP, d_f, d_jtf)
+                        pv = np.empty(nP); plan.memcpy_d2h(pv, d_jtf); jtf += pv
+                if pr_array_to_fill is not None:
+                    plan.memcpy_d2h(pr_array_to_fill[es], d_pr)
+            finally:
+                plan.sync()
+                for d in bufs:
+                    plan.device_free(d)
 
     def bulk_fill_lsq_step(self, jtj, jtf, layout, counts, total_counts, objective="logl", min_prob_clip=1e-4,
                            radius=1e-4, prob_clip_interval=None, lsvec_to_fill=None, pr_array_to_fill=None):

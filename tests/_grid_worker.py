@@ -20,7 +20,8 @@ def main():
     from test_host_mirror import _model_from_fixture
     from pygsti_amd import modelpacks as MP, dist as gdist
     from pygsti_amd.forwardsim import HipMapForwardSimulator
-    ctx = gdist.init(device=0, want_comm=False)          # host arrays: the control group carries them
+    ctx = gdist.init(device=0, transport="ipc")          # host arrays travel through the control group, device blocks over IPC
+    assert ctx.comm is not None, ctx.comm_error
     rank, size = ctx.rank, ctx.size
     fx = load_fixture("smq1Q_XYI_L4_depol")
     pack = MP.smq1Q_XYI
@@ -42,7 +43,14 @@ def main():
     H = lay.allocate_local_array("epp"); H[...] = np.nan
     sim.bulk_fill_hprobs(H, lay)
     H_all = lay.allgather_local_array("epp", H)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), J_all=J_all, J_root=J_root if rank == 0 else np.zeros(0), P_all=P_all,
+    # the same products without the Jacobian leaving the GPUs: column blocks exchanged between device buffers
+    lay.device_comm = ctx.comm
+    w = 1.0 + 0.5 * np.cos(np.arange(nE) * 0.11)
+    jtj_d = np.empty((nP, nP)); jtf_d = np.empty(nP); P_d = np.full(nE, np.nan)
+    sim.bulk_fill_jtj_jtf(jtj_d, jtf_d, lay, row_scale=w, f=f, pr_array_to_fill=P_d)
+    gdist.allreduce_sum_host(jtj_d, expect_size=size); gdist.allreduce_sum_host(jtf_d, expect_size=size)
+    P_d_all = lay.allgather_local_array("e", P_d)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), jtj_d=jtj_d, jtf_d=jtf_d, P_d_all=P_d_all, J_all=J_all, J_root=J_root if rank == 0 else np.zeros(0), P_all=P_all,
              jtj=jtj, jtf=jtf, H_all=H_all, n_filled=int(filled.sum()), h_filled=int((~np.isnan(H)).sum()),
              gps=np.array([lay.global_param_slice.start, lay.global_param_slice.stop, lay.global_param2_slice.start, lay.global_param2_slice.stop]),
              owned=np.array([a.element_slice.start for a in lay.atoms]), root_none=(J_root is None))

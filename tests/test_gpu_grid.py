@@ -69,6 +69,9 @@ def test_processor_grid_assembles_the_single_process_results(tmp_path, single, n
     na, np1, np2 = (tuple(grid) + (1, 1))[:3]
     f = np.sin(np.arange(nE) * 0.37) + 0.1
     jtj, jtf = J.T @ J, J.T @ f
+    w = 1.0 + 0.5 * np.cos(np.arange(nE) * 0.11)
+    Jw = J * w[:, None]
+    jtj_w, jtf_w = Jw.T @ Jw, Jw.T @ f
     for r, d in enumerate(res):
         assert_bitwise(d["J_all"], J, "all-gathered Jacobian on rank %d" % r)
         assert_bitwise(d["P_all"], P, "all-gathered probabilities on rank %d" % r)
@@ -76,6 +79,10 @@ def test_processor_grid_assembles_the_single_process_results(tmp_path, single, n
         assert bool(d["root_none"]) == (r != 0)
         assert np.abs(d["jtj"] - jtj).max() <= 1e-12 * np.abs(jtj).max()
         assert np.abs(d["jtf"] - jtf).max() <= 1e-12 * np.abs(jtf).max()
+        # device-resident route (bulk_fill_jtj_jtf: column blocks exchanged between device buffers, gst_comm_exchange_blocks)
+        assert np.abs(d["jtj_d"] - jtj_w).max() <= 1e-12 * np.abs(jtj_w).max()
+        assert np.abs(d["jtf_d"] - jtf_w).max() <= 1e-12 * np.abs(jtf_w).max()
+        assert_bitwise(d["P_d_all"], P, "probabilities of the device-resident route on rank %d" % r)
         # the rank really computed only its block: rows of its atom-processor x its column slice(s)
         g = d["gps"]
         q = r % (np1 * np2)
