@@ -34,7 +34,7 @@ F64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (FMA = 2 flop); separate
 HBM_PEAK_GBS = 8000.0
 
 
-def build_workload(design, max_len, world, rank, device, target_tasks, max_slots=0, scaling="strong"):
+def build_workload(design, max_len, world, rank, device, target_tasks, max_slots=0, scaling="strong", grid=None):
     from pygsti_amd import modelpacks
     from pygsti_amd.layout import HipCOPALayout
     pack = modelpacks.smq2Q_XYICNOT
@@ -46,8 +46,8 @@ def build_workload(design, max_len, world, rank, device, target_tasks, max_slots
                                target_tasks=target_tasks, max_slots=max_slots)
     else:
         model = pack.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
-        layout = HipCOPALayout(circuits, model, num_atoms=world, devices=[device], rank=rank, size=world,
-                               target_tasks=target_tasks, max_slots=max_slots)
+        layout = HipCOPALayout(circuits, model, num_atoms=grid[0] if grid else world, devices=[device], rank=rank, size=world,
+                               target_tasks=target_tasks, max_slots=max_slots, processor_grid=grid)
     return pack, model, circuits, layout
 
 
@@ -216,6 +216,9 @@ def main():
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="development aid (N=1 only): time rank 0's atom of an N-atom strong-scaling layout on this one "
                          "GPU; the printed value counts only that atom's elements")
+    ap.add_argument("--grid", default="", help="processor grid NAxNP (strong scaling): NA atom-processors, each split into NP "
+                    "parameter-processors that take a column slice of the same atom (distforwardsim.py:445-485); NA*NP = --gpus")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-ranks: which rank's share to run")
     ap.add_argument("--deriv", default="fd", choices=["fd", "analytic"],
                     help="fd: finite differences, bit-identical to the reference Map path (headline); "
                          "analytic: exact derivatives (MatrixForwardSimulator semantics)")
@@ -241,9 +244,15 @@ def main():
         plan.sync()
         ctx.barrier()
 
-    lay_world, lay_rank = (args.emulate_ranks, 0) if (world == 1 and args.emulate_ranks > 1) else (world, rank)
+    lay_world, lay_rank = (args.emulate_ranks, args.emulate_rank) if (world == 1 and args.emulate_ranks > 1) else (world, rank)
+    grid = tuple(int(x) for x in args.grid.lower().split("x")) if args.grid else None
+    if grid and (len(grid) != 2 or grid[0] * grid[1] != lay_world or args.scaling != "strong"):
+        sys.exit("--grid NAxNP needs NA*NP == %d ranks and strong scaling" % lay_world)
+    col_split = bool(grid) and grid[1] > 1
+    if col_split:         # the secondary legs below assume whole rows on every rank
+        args.no_analytic = args.no_jacobian_gather = True
     pack, model, circuits, layout = build_workload(args.design, args.max_len, lay_world, lay_rank, device,
-                                                    args.target_tasks, args.max_slots, args.scaling)
+                                                    args.target_tasks, args.max_slots, args.scaling, grid)
     log("workload built: %d circuits" % len(circuits))
     atom = layout.atoms[0]
     plan = atom.plan()
@@ -266,10 +275,13 @@ def main():
         row0 = rank * nE_local
     else:
         blocks, row0 = [(0, 0, nE_local)], 0
-    d_out = plan.device_malloc(nE_local * nP * 8)          # this rank's Jacobian rows (stay distributed, as in the reference)
+    # this rank's parameter columns: all of them, or its parameter-processor's slice of the atom it shares (--grid)
+    gps = layout.global_param_slice
+    nP_local = gps.stop - gps.start
+    d_out = plan.device_malloc(nE_local * nP_local * 8)    # this rank's Jacobian block (stays distributed, as in the reference)
     d_pfull = plan.device_malloc(nE_total * 8)             # the ASSEMBLED probabilities: own rows filled in place
     d_probs = d_pfull + row0 * 8
-    pidx = np.arange(nP, dtype=np.int64)
+    pidx = np.arange(gps.start, gps.stop, dtype=np.int64)
 
     mode = _lib.DERIV_ANALYTIC if args.deriv == "analytic" else _lib.DERIV_FD
     if args.keep_zeros:
@@ -294,7 +306,7 @@ def main():
 
     def step():
         plan.set_model(gates, rhos, effects)          # from_vector -> new dense arrays -> H2D
-        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)
+        plan.fill_dprobs_dev(d_out, nP_local, pidx, None, 1e-7, d_probs, mode)
         exchange_probs()
 
     for _ in range(args.warmup):
@@ -468,7 +480,50 @@ def main():
 
     log("exchange legs done")
     jtj_info = None
-    if args.jtj:
+    if args.jtj and col_split and world > 1 and comm is not None:
+        # Normal equations with the columns distributed (distlayout.py:1306-1346): the ranks of an atom-processor split
+        # the atom's ROWS, exchange each other's column blocks between device buffers (gst_comm_exchange_blocks), and
+        # each contracts its [rows/NP x nP] share; then the usual all-reduce of nP^2 doubles.
+        from pygsti_amd.layout import _slice_up_range
+        G = grid[1]
+        share = _slice_up_range(nE_local, G)[layout.param_proc_index]
+        n_my = share.stop - share.start
+        xblocks = layout.column_exchange_blocks(0)
+        d_stage = plan.device_malloc(max(n_my * nP, 1) * 8); d_T = plan.device_malloc(max(n_my * nP, 1) * 8)
+        d_jtj = plan.device_malloc(nP * nP * 8)
+
+        def assemble():
+            comm.exchange_blocks(d_out, d_stage, xblocks, plan)
+            for cs in layout.param_slices:
+                c = cs.stop - cs.start
+                plan.copy_block_dev(d_T + cs.start * 8, nP, d_stage + n_my * cs.start * 8, c, n_my, c)
+        assemble(); plan.fill_jtj_dev(d_T, n_my, nP, nP, d_jtj); comm.allreduce_sum(d_jtj, nP * nP, plan)      # warm-up
+        barrier_sync(plan)
+        tj = time.perf_counter()
+        for _ in range(3):
+            assemble()
+        barrier_sync(plan)
+        t_x = ctx.max_over_ranks((time.perf_counter() - tj) / 3)
+        tj = time.perf_counter()
+        for _ in range(3):
+            plan.fill_jtj_dev(d_T, n_my, nP, nP, d_jtj)
+        barrier_sync(plan)
+        t_jtj = ctx.max_over_ranks((time.perf_counter() - tj) / 3)
+        tj = time.perf_counter()
+        for _ in range(3):
+            comm.allreduce_sum(d_jtj, nP * nP, plan)
+        barrier_sync(plan)
+        t_ar = ctx.max_over_ranks((time.perf_counter() - tj) / 3)
+        sent = 8.0 * nE_local * nP_local * (G - 1) / G
+        jtj_info = {"grid": "%dx%d" % grid, "column_exchange_ms": 1e3 * t_x, "column_exchange_GB_sent_per_rank": sent / 1e9,
+                    "column_exchange_GBps_per_rank": sent / t_x / 1e9, "jtj_ms": 1e3 * t_jtj, "allreduce_ms": 1e3 * t_ar,
+                    "note": "columns distributed over the parameter-processors of an atom-processor: every rank sends the other "
+                            "ranks' row shares of its column slice and receives their slices of its own share (grouped "
+                            "point-to-point under RCCL, peer copies under IPC), contracts [rows/NP x nP] with the MFMA SYRK, "
+                            "then the nP^2 all-reduce"}
+        for d in (d_stage, d_T, d_jtj):
+            plan.device_free(d)
+    elif args.jtj and not col_split:
         # One Levenberg-Marquardt iteration's worth of data reduction on the resident Jacobian (row f1):
         # probabilities -> lsvec and dlsvec row scale (Poisson-picture dlogl, synthetic counts N=1000 drawn around the
         # model's own probabilities) -> J_s^T J_s (split-K MFMA fp64) and J_s^T lsvec (streaming).
@@ -567,8 +622,8 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         # algorithmic flops of one FD Jacobian on the schedule actually executed by this rank:
         # (nP perturbed passes) x (2 D^2 per gate application + 2 D per element)
-        flops = nP * (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local)
-        jac_bytes = 8.0 * nE_local * nP
+        flops = nP_local * (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local)
+        jac_bytes = 8.0 * nE_local * nP_local
         if args.deriv == "analytic":
             roof = {"bound": "hbm", "kernel": "analytic_mfma_kernel (+ the backward chain pass that feeds it)",
                     "achieved": jac_bytes / (k_ms * 1e-3) / 1e9,
@@ -581,7 +636,7 @@ def main():
             "metric": "dprobs Jacobian-elements/sec, 2Q GST L<=1024 (bulk_fill_dprobs, %s)" % (
                 "FD eps=1e-7, bit-identical to the reference Map path" if args.deriv == "fd" else
                 "analytic derivatives, MatrixForwardSimulator semantics, <=1e-8"),
-            "value": nE_total * nP * args.steps / dt,
+            "value": nE_total * (nP if lay_world == world else nP_local) * args.steps / dt,
             "unit": "Jacobian-elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
@@ -594,8 +649,9 @@ def main():
                                                               if args.scaling == "weak" else " -- dealt to %d atoms" % world)),
                        "derivative": ("forward finite differences, eps=1e-7 (reference MapForwardSimulator semantics)"
                                       if args.deriv == "fd" else "analytic (reference MatrixForwardSimulator semantics)"),
-                       "parallelism": "atoms%d" % world if lay_world == world else
-                                      "rank 0 of atoms%d emulated on one GPU" % lay_world},
+                       "parallelism": (("atoms%d" % world) if not grid else ("grid %dx%d (atom-processors x parameter-processors)" % grid))
+                                      if lay_world == world else
+                                      "rank %d of %s emulated on one GPU" % (lay_rank, ("atoms%d" % lay_world) if not grid else "grid %dx%d" % grid)},
             "per_rank": {"ms_per_step": per_rank_ms, "dominant_kernel_ms": per_rank_kernel_ms,
                          "note": "each rank's own time for the K steps before the closing barrier; `ms_per_step` is the max over ranks after it"},
             "exchange": exchange,

@@ -373,22 +373,10 @@ class HipMapForwardSimulator:
         c_mine = my_cols.stop - my_cols.start
         pidx = np.arange(my_cols.start, my_cols.stop, dtype=np.int64)
         qme = layout.param_proc_index * np2 + layout.param2_proc_index
-        atoms_of = [[at for a, at in enumerate(layout.all_atoms) if a % na == g] for g in range(na)]
+        atoms_of = [layout.atoms_of_processor(g) for g in range(na)]
         for k in range(max(len(x) for x in atoms_of)):
             mine = atoms_of[layout.atom_proc_index][k] if k < len(atoms_of[layout.atom_proc_index]) else None
-            # the same block list on every rank: in round k every atom-processor works on its k-th atom
-            blocks = []
-            for g in range(na):
-                if k >= len(atoms_of[g]):
-                    continue
-                nE_a = atoms_of[g][k].num_elements
-                shares = _sur(nE_a, G)
-                for ip1 in range(np1):
-                    c = cs[ip1].stop - cs[ip1].start
-                    src = layout.rank_of(g, ip1, 0)
-                    for q in range(G):
-                        n = shares[q].stop - shares[q].start
-                        blocks.append((src, layout.rank_of(g) + q, shares[q].start * c, n * cs[ip1].start, n * c))
+            blocks = layout.column_exchange_blocks(k)       # the same list on every rank
             plan = self._prepare_atom(mine if mine is not None else layout.atoms[0])
             bufs = []
             try:

@@ -327,6 +327,30 @@ class HipCOPALayout:
         c2 = self.param2_slices[ip2] if dims == 2 else None
         return [(at.element_slice.start, at.element_slice.stop, c1, c2) for a, at in enumerate(self.all_atoms) if a % na == ia]
 
+    def atoms_of_processor(self, atom_proc):
+        return [at for a, at in enumerate(self.all_atoms) if a % self.processor_grid[0] == atom_proc]
+
+    def column_exchange_blocks(self, k):
+        """Block list of gst_comm_exchange_blocks for round k of the column-distributed normal equations: every
+        atom-processor works on its k-th atom; the rank holding column slice ip1 of that atom's rows ([nE_a x c] row-major)
+        sends to each rank q of the atom-processor the rows of q's share, which land block-column-major in q's staging
+        array (slice ip1's block at |share| * slice start).  [(src rank, dst rank, src offset, dst offset, count)] in
+        doubles, the same on every rank."""
+        na, np1, np2 = self.processor_grid
+        G = np1 * np2
+        blocks = []
+        for g in range(na):
+            mine = self.atoms_of_processor(g)
+            if k >= len(mine):
+                continue
+            shares = _slice_up_range(mine[k].num_elements, G)
+            for ip1, cs in enumerate(self.param_slices):
+                c = cs.stop - cs.start
+                for q in range(G):
+                    n = shares[q].stop - shares[q].start
+                    blocks.append((self.rank_of(g, ip1, 0), self.rank_of(g) + q, shares[q].start * c, n * cs.start, n * c))
+        return blocks
+
     def gather_local_array(self, array_type, array_portion, extra_elements=0, all_gather=False, return_shared=False):
         """Assemble the global array from the ranks' portions (distlayout.py:1010-1156): element-dimension arrays
         ('e', 'ep', 'ep2', 'epp') are full-size on every rank with only the rank's own atoms (rows) and parameter slices
