@@ -429,6 +429,10 @@ int gst_comm_get_info(const gst_comm *comm, gst_comm_info *out);
 int gst_device_malloc(gst_plan *plan, int64_t nbytes, void **d_ptr);
 int gst_device_free(gst_plan *plan, void *d_ptr);
 int gst_memcpy_d2h(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
+/* The same copy enqueued on the plan's stream without waiting for it (gst_sync completes it): lets one process drain
+ * the plans of several GPUs side by side -- with a page-locked destination (gst_host_register) the copies of different
+ * devices overlap; a pageable one makes the call synchronous, which is still correct. */
+int gst_memcpy_d2h_async(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
 
 /* Page-lock a caller-owned host array (hipHostRegister, portable across devices) so that the host-output fills
  * (gst_fill_probs / gst_fill_dprobs / gst_fill_hprobs*) copy into it at full PCIe rate instead of through the runtime's

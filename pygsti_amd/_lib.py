@@ -79,7 +79,7 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_get_fd_queues", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_get_fd_queues", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
@@ -124,6 +124,7 @@ def lib():
         L.gst_device_malloc.argtypes = [vp, i64, C.POINTER(vp)]
         L.gst_device_free.argtypes = [vp, vp]
         L.gst_memcpy_d2h.argtypes = [vp, vp, vp, i64]
+        L.gst_memcpy_d2h_async.argtypes = [vp, vp, vp, i64]
         L.gst_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.gst_get_program.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64]
         L.gst_get_fd_queues.argtypes = [vp, vp, i64, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
@@ -558,6 +559,12 @@ class Plan:
     def memcpy_d2h(self, out, d_ptr, offset_bytes=0):
         assert out.flags.c_contiguous
         check(lib().gst_memcpy_d2h(self._h, _ptr(out), C.c_void_p(int(d_ptr) + int(offset_bytes)), out.nbytes))
+        return out
+
+    def memcpy_d2h_async(self, out, d_ptr, offset_bytes=0):
+        """enqueue the copy behind the plan's work and return; `sync()` completes it (keep `out` alive until then)"""
+        assert out.flags.c_contiguous
+        check(lib().gst_memcpy_d2h_async(self._h, _ptr(out), C.c_void_p(int(d_ptr) + int(offset_bytes)), out.nbytes))
         return out
 
     # -- introspection -----------------------------------------------------------------------------------

@@ -71,12 +71,14 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    unsigned flags = 0;                 // hipExtMallocWithFlags flags (0: plain hipMalloc)
     hipError_t ensure(size_t count)
     {
         if (count <= n && p) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr; n = 0;
-        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        hipError_t e = flags ? hipExtMallocWithFlags((void**)&p, std::max<size_t>(count, 1) * sizeof(T), flags)
+                             : hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
         if (e == hipSuccess) n = std::max<size_t>(count, 1);
         return e;
     }
@@ -326,6 +328,11 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_HESS_COMPOSED")) p->hess_composed = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_FD_OVL_MEM")) {      // (experiment) memory type of the arrays the in-launch base pass publishes through
+        const int m = std::atoi(e);
+        const unsigned fl = m == 1 ? hipDeviceMallocUncached : m == 2 ? hipDeviceMallocFinegrained : 0u;
+        p->d_base_cache.flags = fl; p->d_pbase.flags = fl;
+    }
     if (const char* e = std::getenv("GST_HOST_DIRECT")) { p->host_direct = std::atoi(e) != 0; if (std::atoi(e) == 2) p->host_direct_min_cols = 1; }
     if (const char* e = std::getenv("GST_FD_HANDOVER")) p->fd_handover = std::atoi(e);
     if (const char* e = std::getenv("GST_FD_OVERLAP")) { p->fd_overlap = std::atoi(e) != 0; p->fd_overlap_diag = std::atoi(e) == 2; }
@@ -2664,6 +2671,17 @@ int gst_memcpy_d2h(gst_plan* p, void* dst, const void* d_src, int64_t nbytes)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy(dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost));
+    return GST_OK;
+    });
+}
+
+int gst_memcpy_d2h_async(gst_plan* p, void* dst, const void* d_src, int64_t nbytes)
+{
+    return guarded([&]() -> int {
+    if (!p || !dst || !d_src || nbytes < 0) return fail(GST_EINVAL, "bad argument");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, p->stream));
     return GST_OK;
     });
 }

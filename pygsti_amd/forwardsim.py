@@ -191,12 +191,19 @@ class HipMapForwardSimulator:
                 d = plan.workspace("bfp", atom.num_elements * 8)
                 plan.fill_probs_dev(d)                               # asynchronous, on the atom's device
                 jobs.append((atom, plan, d))
+            # drain: every device's copy is enqueued behind its own fill, then all are awaited -- the copies of different
+            # GPUs run side by side when the destination is page-locked (allocate_local_array pins large arrays)
+            later = []
             for atom, plan, d in jobs:
                 out = array_to_fill[atom.element_slice]
                 if out.flags.c_contiguous:
-                    plan.memcpy_d2h(out, d)                         # waits for that device only
+                    plan.memcpy_d2h_async(out, d)
                 else:
-                    out[...] = plan.memcpy_d2h(np.empty(atom.num_elements), d)
+                    later.append((out, plan.memcpy_d2h_async(np.empty(atom.num_elements), d)))
+            for atom, plan, d in jobs:
+                plan.sync()
+            for out, tmp in later:
+                out[...] = tmp
             return
         for atom in layout.atoms:
             self._bulk_fill_probs_atom(array_to_fill[atom.element_slice], atom)
@@ -216,14 +223,19 @@ class HipMapForwardSimulator:
                 d_p = plan.workspace("bfp", atom.num_elements * 8)
                 plan.fill_dprobs_dev(d_J, Np, pidx, None, self.derivative_eps, d_p, mode)      # asynchronous
                 jobs.append((atom, plan, d_J, d_p))
+            later = []
             for atom, plan, d_J, d_p in jobs:
-                plan.memcpy_d2h(array_to_fill[atom.element_slice, :], d_J)
+                plan.memcpy_d2h_async(array_to_fill[atom.element_slice, :], d_J)
                 if pr_array_to_fill is not None:
                     pr = pr_array_to_fill[atom.element_slice]
                     if pr.flags.c_contiguous:
-                        plan.memcpy_d2h(pr, d_p)
+                        plan.memcpy_d2h_async(pr, d_p)
                     else:
-                        pr[...] = plan.memcpy_d2h(np.empty(atom.num_elements), d_p)
+                        later.append((pr, plan.memcpy_d2h_async(np.empty(atom.num_elements), d_p)))
+            for atom, plan, d_J, d_p in jobs:
+                plan.sync()
+            for pr, tmp in later:
+                pr[...] = tmp
             return
         # columns of the local array this rank fills (distforwardsim.py:399-433 `host_param_slice`): all of them, or its
         # parameter-processor's slice of a full-width array
