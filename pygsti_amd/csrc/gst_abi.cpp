@@ -189,6 +189,10 @@ struct gst_plan {
     DevBuf<uint32_t> d_dirty_words;
     DevBuf<int64_t> d_dirty_off;
     DevBuf<int32_t> d_lb_item_pw;
+    DevBuf<int32_t> d_lbr_lane[4];          // preparation columns on the lane-per-model kernel: col | kind | obj | elem (= model set)
+    DevBuf<uint32_t> d_lbr_order;           // ... and their launch order (longest tasks first)
+    int32_t lbr_n_waves = 0;
+    bool lb_rho_lanes = true;               // GST_LB_RHO_LANES=0: preparation columns through walk_pert_kernel like the gates'
     bool lb_share = true;                   // GST_LB_SHARE=0: every (program, perturbed model) pair walked on its own (round-2 form)
     DevBuf<int32_t> d_mm_dest;
     DevBuf<double> d_obj_part;          // per-block partial sums of the objective terms
@@ -259,7 +263,7 @@ struct gst_plan {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
         d_lb_i32.release(); d_lb_i64.release(); d_lb_setparam.release(); d_lb_statics.release(); d_lb_term_re.release();
-        d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release(); d_jtj_pmask.release();
+        d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release(); d_jtj_pmask.release(); for (auto& b : d_lbr_lane) b.release(); d_lbr_order.release();
         d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release();
         d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release();
         d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release();
@@ -328,6 +332,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_HESS_COMPOSED")) p->hess_composed = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GST_LB_RHO_LANES")) p->lb_rho_lanes = std::atoi(e) != 0;
     if (const char* e = std::getenv("GST_FD_OVL_MEM")) {      // (experiment) memory type of the arrays the in-launch base pass publishes through
         const int m = std::atoi(e);
         const unsigned fl = m == 1 ? hipDeviceMallocUncached : m == 2 ? hipDeviceMallocFinegrained : 0u;
@@ -1362,10 +1367,25 @@ int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int
         }
         std::vector<int64_t> set_param;
         std::vector<int32_t> wk, wo, wn, w0, wc, cdest, zero_dest;
+        std::vector<int32_t> rl_col, rl_kind, rl_obj, rl_elem;       // preparation columns: lanes of the lane-per-model FD kernel
         p->lb_povm_cols.clear();
         for (int m = 0; m < L.n_members; m++) {
             const auto& cols = by_member[(size_t)m];
             if (cols.empty()) continue;
+            if (L.kind[(size_t)m] == GST_KIND_RHO && p->lb_rho_lanes) {
+                // A perturbed preparation changes every state of every circuit but no gate: these columns are exactly what
+                // walk_kernel's lanes are for -- 64 columns per wavefront, every gate coefficient a scalar operand -- once a
+                // lane may start from a whole perturbed vector (WalkArgs::rho_models) instead of one stepped element.
+                for (size_t k = 0; k < cols.size(); k++) {
+                    const int64_t c = cols[k];
+                    rl_col.push_back((int32_t)(dest_idx ? dest_idx[c] : c)); rl_kind.push_back(GST_KIND_RHO);
+                    rl_obj.push_back(L.obj[(size_t)m]); rl_elem.push_back((int32_t)set_param.size());
+                    set_param.push_back(param_idx[c]);
+                    cdest.push_back((int32_t)(dest_idx ? dest_idx[c] : c));
+                }
+                while (rl_col.size() % 64) { rl_col.push_back(-1); rl_kind.push_back(GST_KIND_NONE); rl_obj.push_back(0); rl_elem.push_back(0); }
+                continue;
+            }
             const bool povm = L.kind[(size_t)m] == GST_KIND_EFFECT;
             if (povm) {
                 p->lb_povm_cols.push_back(L.obj[(size_t)m]); p->lb_povm_cols.push_back(L.n_eff[(size_t)m]);
@@ -1415,6 +1435,20 @@ int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int
         HIP_TRY(p->d_block_order.ensure(iprog.size() + 1));
         if (!iprog.empty()) HIP_TRY(hipMemcpyAsync(p->d_block_order.p, iprog.data(), iprog.size() * 4, hipMemcpyHostToDevice, p->stream));
         if ((rc = upload_i32(p->d_lb_item_pw, ipw, p->stream))) return rc;
+        p->lbr_n_waves = (int32_t)(rl_col.size() / 64);
+        if (p->lbr_n_waves > 0) {
+            if ((rc = upload_i32(p->d_lbr_lane[0], rl_col, p->stream)) || (rc = upload_i32(p->d_lbr_lane[1], rl_kind, p->stream)) ||
+                (rc = upload_i32(p->d_lbr_lane[2], rl_obj, p->stream)) || (rc = upload_i32(p->d_lbr_lane[3], rl_elem, p->stream))) return rc;
+            // (task, wavefront) pairs, longest programs first: every pair walks its whole task
+            std::vector<int64_t> order((size_t)nT);
+            for (int64_t t = 0; t < nT; t++) order[(size_t)t] = t;
+            std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return h.task_off[(size_t)x + 1] - h.task_off[(size_t)x] > h.task_off[(size_t)y + 1] - h.task_off[(size_t)y]; });
+            std::vector<uint32_t> bo;
+            bo.reserve((size_t)nT * p->lbr_n_waves);
+            for (int64_t t : order) for (int32_t w = 0; w < p->lbr_n_waves; w++) bo.push_back((uint32_t)(t * p->lbr_n_waves + w));
+            HIP_TRY(p->d_lbr_order.ensure(bo.size() + 1));
+            HIP_TRY(hipMemcpyAsync(p->d_lbr_order.p, bo.data(), bo.size() * 4, hipMemcpyHostToDevice, p->stream));
+        }
         HIP_TRY(hipStreamSynchronize(p->stream));          // the host vectors go out of scope
         p->lb_n_pwaves = n_pw;
         p->lb_n_items = (int64_t)items.size();
@@ -1443,6 +1477,18 @@ int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int
     TIME_REC(p, evk0);
     HIP_TRY(gst::launch_zero_columns(d_out, ld, h.n_elements, a.col_dest + n_param, p->lb_n_zero, -1, p->stream));
     HIP_TRY(gst::launch_walk_pert(D, a, p->lb_n_items, h.max_slots, p->stream));
+    if (p->lbr_n_waves > 0) {          // preparation columns: the lane-per-model FD kernel, each lane starting from its own vector
+        gst::WalkArgs w;
+        base_args(p, w);
+        w.mode = gst::EMIT_FD;
+        w.out = d_out; w.ld = ld; w.eps = eps; w.pbase = d_base; w.base_cache = p->d_base_cache.p;
+        w.lanes.col = p->d_lbr_lane[0].p; w.lanes.kind[0] = p->d_lbr_lane[1].p; w.lanes.obj[0] = p->d_lbr_lane[2].p; w.lanes.elem[0] = p->d_lbr_lane[3].p;
+        w.n_pwaves = p->lbr_n_waves;
+        w.block_order = p->d_lbr_order.p;
+        w.rho_models = p->d_lb_pert.p; w.rho_model_stride = (int64_t)D * D;
+        HIP_TRY(gst::launch_walk(D, 1, w, nT, h.max_slots, p->stream, 1));
+        p->last_launches++;
+    }
     for (size_t k = 0; k + 3 < p->lb_povm_cols.size(); k += 4)
         HIP_TRY(gst::launch_effect_columns(D, a, p->d_circ_leaf.p, h.n_circuits, p->lb_povm_cols[k], p->lb_povm_cols[k + 1],
                                            p->lb_povm_cols[k + 2], p->lb_povm_cols[k + 3], p->stream));

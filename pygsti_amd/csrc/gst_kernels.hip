@@ -361,7 +361,10 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
             const double* base = a.gates;
             int b = -1;
             if (kind[s] == GST_KIND_GATE) { row[s] = el[s] / D; b = el[s] % D; base = a.gates + ((int64_t)obj[s] * D + row[s]) * D; }
-            else if (kind[s] == GST_KIND_RHO) { row[s] = 0; b = el[s]; base = a.rhos + (int64_t)obj[s] * D; }
+            else if (kind[s] == GST_KIND_RHO) {
+                row[s] = 0; b = el[s]; base = a.rhos + (int64_t)obj[s] * D;
+                if (a.rho_models) { base = a.rho_models + (int64_t)el[s] * a.rho_model_stride; b = -1; }     // a whole perturbed vector
+            }
             else if (kind[s] == GST_KIND_EFFECT) { row[s] = 0; b = el[s]; base = a.effects + (int64_t)obj[s] * D; }
 #pragma unroll
             for (int j = 0; j < D; j++) {

@@ -120,6 +120,11 @@ struct WalkArgs {
     int32_t* ho_tag;
     int32_t ho_blocks;
     int32_t ovl_test_skip;       // tests: walk no chain (every consumer's wait then runs out and the stand-by launches take over)
+    // Whole-vector preparation perturbations (Lindblad-parameterised preparations, gst_set_lindblad): a GST_KIND_RHO lane's
+    // perturbed preparation is rho_models[elem * rho_model_stride ...] (D doubles) instead of rhos[obj] with element `elem`
+    // stepped.  NULL: the one-element form.
+    const double* rho_models;
+    int64_t rho_model_stride;
 };
 
 // Launch the walk over all tasks x parameter wavefronts.  S = number of specials per lane (0,1,2);
