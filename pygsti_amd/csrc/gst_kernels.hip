@@ -201,59 +201,6 @@ constexpr int XPAD = 2;      // exchange-buffer lane stride D + 2 doubles: 16-by
 // value.  On a 1/8 atom of the 2Q design the base pass was 0.45 ms of a 4.4 ms step that nothing overlapped.
 constexpr unsigned long long WAIT_LIMIT_TICKS = 10000000ull;     // bounded waits: 0.1 s of the 100 MHz wall clock
 
-// The chains of the base pass inside the persistent launch (OVL; see WalkArgs::ovl_n_tasks): runs once per wavefront,
-// before anything of the interpreter is live.  Inlined: `lds` must stay an LDS (address-space 3) pointer for the chain
-// walk's DS instructions -- through a real call it would decay to a generic pointer.
-template <int D>
-__device__ __forceinline__ void ovl_chain_prologue(double* lds, const int lane)
-{
-    // ---- the chains of the base pass, inside this launch (see WalkArgs::ovl_n_tasks) -------------------------------
-    const GST_CONST WalkArgs* c = (const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    const int n_waves = (int)(blockDim.x >> 6);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // chain k of the workgroup on wavefront k: the FIRST wavefronts.  The SIMD's arbiter serves its oldest wavefront
-    // first, so a chain on the youngest wavefront of its SIMD starves behind two finite-difference walks (measured:
-    // the step got 0.25 ms LONGER); raised priority on top, for the chain's duration only -- a chain is a latency
-    // chain of dependent instructions, it leaves most issue slots to the walks anyway
-    const int k = wave;
-    const int64_t t = (int64_t)blockIdx.x + (int64_t)k * gridDim.x;
-    if (t < (int64_t)c->ovl_n_tasks && !c->ovl_test_skip) {
-        const int nG = c->n_gates, nE = c->n_effects;
-        const int n_slots = c->lds_wave_doubles / (D * 64);
-        double* const region = lds + (size_t)n_waves * c->lds_wave_doubles + (size_t)k * c->ovl_chain_doubles;
-        double* const ldsE = region;
-        double* const ldsG = ldsE + nE * D;
-        double* const wlds = region + base_shared_doubles(D, nG, nE);
-        uint32_t* const ldsP = (uint32_t*)((int32_t*)(wlds + (n_slots > 0 ? n_slots : 1) * 64 + BASE_ER * (D + 1)) + BASE_ER);
-        const int64_t pc0 = as_const(c->task_off)[t];
-        const int32_t n_words = (int32_t)(as_const(c->task_off)[t + 1] - pc0);
-        const uint32_t* gprog = c->prog + pc0;
-        const double* gt = c->gates_t;
-        const double* ef = c->effects;
-        stage_lds(ldsP, BASE_PW, lane, [&](int i) { return (i < n_words) ? gprog[i] : 0u; });
-        stage_lds(ldsG, nG * D * D, lane, [&](int i) { return gt[i]; });
-        stage_lds(ldsE, nE * D, lane, [&](int i) { return ef[i]; });
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        ChainArgs ca;
-        ca.gprog = gprog; ca.n_words = n_words;
-        ca.eff_ptr = c->eff_ptr; ca.eff_label = c->eff_label; ca.eff_dest = c->eff_dest;
-        ca.rhos = c->rhos; ca.out = c->pbase_w; ca.cache = (double*)c->base_cache;
-        ca.multi_start = 0; ca.start0 = 0;
-        const unsigned long long tc0 = c->trace ? wall_clock64() : 0ull;
-        __builtin_amdgcn_s_setprio(3);
-        base_chain_walk<D, true>(ca, n_slots, ldsE, ldsG, wlds, lane);
-        __builtin_amdgcn_s_setprio(0);
-        if (c->trace && lane == 0) {           // development aid (GST_FD_TRACE): chains are records with bit 30 set
-            unsigned long long* tr = c->trace;
-            const unsigned long long kk = atomicAdd(tr, 1ull);
-            tr[1 + 4 * kk] = 0x40000000ull | (unsigned long long)t; tr[2 + 4 * kk] = tc0; tr[3 + 4 * kk] = wall_clock64();
-            tr[4 + 4 * kk] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4)) |
-                             ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);
-        }
-    }
-}
-
 template <int D, int S, int WPS, int NW = 1, bool PERSIST = false, bool COMP = false, bool OVL = false>
 __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS) void walk_kernel(const WalkArgs a)
 {
@@ -274,7 +221,53 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
         // stand-by launch behind an optimistic persistent one (WalkArgs::guard): nothing to do unless that one gave up
         if (a.guard && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
     }
-    if constexpr (OVL) ovl_chain_prologue<D>(lds, lane);
+    if constexpr (OVL) {
+        // ---- the chains of the base pass, inside this launch (see WalkArgs::ovl_n_tasks) -------------------------------
+        const GST_CONST WalkArgs* c = (const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        const int n_waves = (int)(blockDim.x >> 6);
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        // chain k of the workgroup on wavefront k: the FIRST wavefronts.  The SIMD's arbiter serves its oldest wavefront
+        // first, so a chain on the youngest wavefront of its SIMD starves behind two finite-difference walks (measured:
+        // the step got 0.25 ms LONGER); raised priority on top, for the chain's duration only -- a chain is a latency
+        // chain of dependent instructions, it leaves most issue slots to the walks anyway
+        const int k = wave;
+        const int64_t t = (int64_t)blockIdx.x + (int64_t)k * gridDim.x;
+        if (t < (int64_t)c->ovl_n_tasks && !c->ovl_test_skip) {
+            const int nG = c->n_gates, nE = c->n_effects;
+            const int n_slots = c->lds_wave_doubles / (D * 64);
+            double* const region = lds + (size_t)n_waves * c->lds_wave_doubles + (size_t)k * c->ovl_chain_doubles;
+            double* const ldsE = region;
+            double* const ldsG = ldsE + nE * D;
+            double* const wlds = region + base_shared_doubles(D, nG, nE);
+            uint32_t* const ldsP = (uint32_t*)((int32_t*)(wlds + (n_slots > 0 ? n_slots : 1) * 64 + BASE_ER * (D + 1)) + BASE_ER);
+            const int64_t pc0 = as_const(c->task_off)[t];
+            const int32_t n_words = (int32_t)(as_const(c->task_off)[t + 1] - pc0);
+            const uint32_t* gprog = c->prog + pc0;
+            const double* gt = c->gates_t;
+            const double* ef = c->effects;
+            stage_lds(ldsP, BASE_PW, lane, [&](int i) { return (i < n_words) ? gprog[i] : 0u; });
+            stage_lds(ldsG, nG * D * D, lane, [&](int i) { return gt[i]; });
+            stage_lds(ldsE, nE * D, lane, [&](int i) { return ef[i]; });
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            ChainArgs ca;
+            ca.gprog = gprog; ca.n_words = n_words;
+            ca.eff_ptr = c->eff_ptr; ca.eff_label = c->eff_label; ca.eff_dest = c->eff_dest;
+            ca.rhos = c->rhos; ca.out = c->pbase_w; ca.cache = (double*)c->base_cache;
+            ca.multi_start = 0; ca.start0 = 0;
+            const unsigned long long tc0 = c->trace ? wall_clock64() : 0ull;
+            __builtin_amdgcn_s_setprio(3);
+            base_chain_walk<D, true>(ca, n_slots, ldsE, ldsG, wlds, lane);
+            __builtin_amdgcn_s_setprio(0);
+            if (c->trace && lane == 0) {           // development aid (GST_FD_TRACE): chains are records with bit 30 set
+                unsigned long long* tr = c->trace;
+                const unsigned long long kk = atomicAdd(tr, 1ull);
+                tr[1 + 4 * kk] = 0x40000000ull | (unsigned long long)t; tr[2 + 4 * kk] = tc0; tr[3 + 4 * kk] = wall_clock64();
+                tr[4 + 4 * kk] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4)) |
+                                 ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);
+            }
+        }
+    }
   for (;;) {                                 // PERSIST: one iteration per popped pair; otherwise exactly one
     int64_t bid;
     int32_t part = 0;                        // PERSIST: 0 whole pair, 1 first half (up to the split), 2 second half
@@ -363,7 +356,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
             if (kind[s] == GST_KIND_GATE) { row[s] = el[s] / D; b = el[s] % D; base = a.gates + ((int64_t)obj[s] * D + row[s]) * D; }
             else if (kind[s] == GST_KIND_RHO) {
                 row[s] = 0; b = el[s]; base = a.rhos + (int64_t)obj[s] * D;
-                if (a.rho_models) { base = a.rho_models + (int64_t)el[s] * a.rho_model_stride; b = -1; }     // a whole perturbed vector
+                if (a.rho_models) { base = a.rho_models + (int64_t)el[s] * a.rho_model_stride; b = -1; }
             }
             else if (kind[s] == GST_KIND_EFFECT) { row[s] = 0; b = el[s]; base = a.effects + (int64_t)obj[s] * D; }
 #pragma unroll
@@ -473,23 +466,14 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
     // scalar cache): poll it with system-scope loads, which bypass the non-coherent caches.  Returns false when the wait
     // ran out (the abort flag is then raised).
     bool ovl_dead = false;
-#ifdef GST_OVL_STATS
-    uint32_t st_polls = 0, st_ticks = 0;     // (development build: slow-path entries and their waiting time go into the trace record)
-#endif
-    // ONE polling loop per site, for up to 64 consecutive doubles at once: lane l < n reads g[l] (a single vector load per
-    // round) until no lane sees the sentinel; the caller broadcasts what it needs out of the returned register.  (The first
-    // version polled component by component -- 16 inlined loops per state fetch, 33 in the kernel -- and that code alone
-    // cost the interpreter 130 more spilled SGPRs and 15 % more scalar instructions on EVERY walk.)
-    auto ovl_poll = [&](const double* g, const int n) -> double {
+    auto ovl_poll = [&](const double* g) -> double {
         const unsigned long long t_wait = wall_clock64();
-#ifdef GST_OVL_STATS
-        st_polls++;
-#endif
-        double x = 0.0;
         for (;;) {
-            const bool on = lane < n;
-            x = __hip_atomic_load(g + (on ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (__ballot(on && (unsigned long long)__double_as_longlong(x) == OVL_SENTINEL64) == 0ull) break;
+            // (every lane reads the same address; the value is made wave-uniform explicitly so that control flow stays scalar)
+            const long long xb = __double_as_longlong(__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+            const int xlo = __builtin_amdgcn_readfirstlane((int)(xb & 0xffffffffLL)), xhi = __builtin_amdgcn_readfirstlane((int)(xb >> 32));
+            const double x = __longlong_as_double(((long long)xhi << 32) | (unsigned int)xlo);
+            if ((unsigned long long)__double_as_longlong(x) != OVL_SENTINEL64) return x;
             __builtin_amdgcn_s_sleep(16);
             if (wall_clock64() - t_wait > WAIT_LIMIT_TICKS) {
                 const GST_CONST WalkArgs* c = (const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -497,18 +481,9 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
                 //  keep the interpreter's scalar state across -- "illegal VGPR to SGPR copy")
                 if (c->abort_flag) __hip_atomic_store(c->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 ovl_dead = true;
-                break;
+                return x;
             }
         }
-#ifdef GST_OVL_STATS
-        st_ticks += (uint32_t)(wall_clock64() - t_wait);
-#endif
-        return x;
-    };
-    auto lane_bcast = [&](const double x, const int l) -> double {      // wave-uniform copy of lane l's value
-        const long long xb = __double_as_longlong(x);
-        const int lo = __builtin_amdgcn_readlane((int)(xb & 0xffffffffLL), l), hi = __builtin_amdgcn_readlane((int)(xb >> 32), l);
-        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
     };
     // (a macro, not a lambda: an array captured by reference from inside the interpreter loop ends up in scratch memory)
 #define GST_FETCH_STATE(id_)                                                                              \
@@ -523,9 +498,9 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
         if constexpr (OVL) {                                                                              \
             if (__builtin_expect(late_ != 0, 0)) {                                                        \
                 const double* g_ = ((const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr())->base_cache + (int64_t)(id_) * D; \
-                const double xv_ = ovl_poll(g_, D);                                                       \
+                _Pragma("unroll") for (int j = 0; j < D; j++)                                             \
+                    if (!ovl_dead && ((late_ >> j) & 1u)) v[j] = ovl_poll(g_ + j);                        \
                 if (ovl_dead) return;                                                                     \
-                _Pragma("unroll") for (int j = 0; j < D; j++) v[j] = lane_bcast(xv_, j);                  \
             }                                                                                             \
         }                                                                                                 \
     } while (0)
@@ -796,9 +771,8 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
                         double pb = as_const(c->pbase)[dest];
                         if constexpr (OVL) {
                             if (__builtin_expect((unsigned long long)__double_as_longlong(pb) == OVL_SENTINEL64, 0)) {
-                                const double pv = ovl_poll(c->pbase + dest, 1);      // the chain has not flushed this circuit yet
+                                pb = ovl_poll(c->pbase + dest);      // the chain has not flushed this circuit yet
                                 if (ovl_dead) return;
-                                pb = lane_bcast(pv, 0);
                             }
                         }
                         if (col >= 0) c->out[dest * c->ld + col] = (p - pb) / c->eps;
@@ -860,11 +834,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
         unsigned long long* tr = ((const GST_CONST WalkArgs*)__builtin_amdgcn_kernarg_segment_ptr())->trace;
         if (tr && lane == 0) {
             const unsigned long long k = atomicAdd(tr, 1ull);
-            unsigned long long w0 = (unsigned long long)bid;
-#ifdef GST_OVL_STATS
-            w0 |= ((unsigned long long)(st_polls > 0xffffu ? 0xffffu : st_polls) << 32) | ((unsigned long long)(st_ticks / 100u > 0xffffu ? 0xffffu : st_ticks / 100u) << 48);
-#endif
-            tr[1 + 4 * k] = w0; tr[2 + 4 * k] = t_begin; tr[3 + 4 * k] = wall_clock64();
+            tr[1 + 4 * k] = (unsigned long long)bid; tr[2 + 4 * k] = t_begin; tr[3 + 4 * k] = wall_clock64();
             tr[4 + 4 * k] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4)) |
                             ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);
         }

@@ -60,7 +60,7 @@ for lo, hi in ((0, 50), (50, 600), (600, 1500), (1500, 2500), (2500, 9999)):
     m = big & (r[:, 2] >= lo) & (r[:, 2] < hi)
     if m.sum() > 5:
         print(" segments starting in [%4d, %4d) us of A: n=%4d ratio A/B %.3f" % (lo, hi, m.sum(), r[m, 0].sum() / r[m, 1].sum()))
-# slow-path statistics (a -DGST_OVL_STATS build packs them into the record's first word)
+# slow-path statistics (an instrumented build may pack poll counts into the upper half of the record's first word; zeros otherwise)
 rawA = np.fromfile(sys.argv[1], dtype=np.uint64)
 nA = int(rawA[0]); w0 = rawA[1:1 + 4 * nA].reshape(nA, 4)[:, 0]
 w0 = w0[(w0 & np.uint64(0x40000000)) == 0]
