@@ -199,6 +199,10 @@ constexpr int XPAD = 2;      // exchange-buffer lane stride D + 2 doubles: 16-by
 // chain first (gst_chain.hpp, publishing states and probabilities with write-through stores) while the others already
 // run finite-difference walks; a walk that reads the sentinel the destinations were pre-filled with waits for the
 // value.  On a 1/8 atom of the 2Q design the base pass was 0.45 ms of a 4.4 ms step that nothing overlapped.
+#ifndef GST_OVL_PRIO
+#define GST_OVL_PRIO 0       // wavefront priority of a chain of the in-launch base pass: as the oldest wavefront of its SIMD it
+                             // is served first anyway -- 0 / 1 / 2 / 3 measured 4.15 / 4.17 / 4.15 / 4.18 ms on a 1/8 atom
+#endif
 constexpr unsigned long long WAIT_LIMIT_TICKS = 10000000ull;     // bounded waits: 0.1 s of the 100 MHz wall clock
 
 template <int D, int S, int WPS, int NW = 1, bool PERSIST = false, bool COMP = false, bool OVL = false>
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(PERSIST ? 64 * WPS * 4 : 64 * NW, PERSIST ? 1 : WPS
             ca.rhos = c->rhos; ca.out = c->pbase_w; ca.cache = (double*)c->base_cache;
             ca.multi_start = 0; ca.start0 = 0;
             const unsigned long long tc0 = c->trace ? wall_clock64() : 0ull;
-            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(GST_OVL_PRIO);
             base_chain_walk<D, true>(ca, n_slots, ldsE, ldsG, wlds, lane);
             __builtin_amdgcn_s_setprio(0);
             if (c->trace && lane == 0) {           // development aid (GST_FD_TRACE): chains are records with bit 30 set
