@@ -113,11 +113,7 @@ class HipMapForwardSimulator:
         blk = tuple(self._pblk_sizes) if self._pblk_sizes else (None, None)
         if len(blk) == 1:
             blk = (blk[0], None)
-        grid = self._processor_grid
-        if grid is None and size > 1 and self._num_atoms is not None and self._num_atoms < size and size % self._num_atoms == 0:
-            # fewer atoms than ranks: the ranks left over split the parameter columns (the reference's automatic grid,
-            # distforwardsim.py:469-481: na = gcd(nprocs, natoms), the rest of the processors on the first parameter dimension)
-            grid = (self._num_atoms, size // self._num_atoms)
+        grid = self._processor_grid      # (None: the layout picks the reference's automatic grid when atoms < ranks)
         return HipCOPALayout(circuits, self.model, natoms, self.devices, rank, size, self.target_tasks, blk, dataset=dataset,
                              mpi_comm=getattr(resource_alloc, "comm", None), processor_grid=grid)
 

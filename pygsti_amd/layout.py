@@ -175,8 +175,14 @@ class HipCOPALayout:
             self._out_ptr, self._out_idx = ptr, np.asarray(idx, np.int32)
         self._has_dataset = dataset is not None or len(self.povm_labels) != 1      # (outcome sets differ per circuit)
 
-        # ---- deal circuits to atoms ------------------------------------------------------------------
+        # ---- processor grid, then deal circuits to atoms --------------------------------------------
         num_atoms = max(1, int(num_atoms or 1))
+        if not processor_grid and size > 1 and num_atoms < size and size % num_atoms == 0:
+            # fewer atoms than ranks: the ranks left over split the parameter columns (the reference's automatic grid,
+            # distforwardsim.py:469-481: na = gcd(nprocs, natoms), the rest of the processors on the first parameter dimension)
+            processor_grid = (num_atoms, size // num_atoms)
+        na_req = int(processor_grid[0]) if processor_grid else size
+        num_atoms = min(max(num_atoms, na_req), max(self.num_circuits, 1))      # natoms = max(na, num_atoms), distforwardsim.py:461
         groups = self._partition(num_atoms)
         self.global_num_elements = int(self._out_ptr[-1])
         self._circuit_offset = np.empty(self.num_circuits, np.int64)   # first element of each circuit
@@ -201,6 +207,8 @@ class HipCOPALayout:
             raise ValueError("processor_grid %r must be (na, np1[, np2]) with na * np1 * np2 == %d ranks" % (processor_grid, size))
         if np1 > max(self._num_params, 1) or np2 > max(self._num_params, 1):
             raise ValueError("more parameter-processors than parameters")
+        if na > len(atoms):
+            raise ValueError("%d atom-processors but only %d atoms (%d circuits)" % (na, len(atoms), self.num_circuits))
         self.processor_grid = (na, np1, np2)
         q = rank % (np1 * np2)
         self.atom_proc_index, self.param_proc_index, self.param2_proc_index = rank // (np1 * np2), q // np2, q % np2
