@@ -94,7 +94,7 @@ class HipLayoutAtom:
 
 class HipCOPALayout:
     def __init__(self, circuits, model, num_atoms=1, devices=None, rank=0, size=1, target_tasks=0,
-                 param_dimension_blk_sizes=(None, None), max_slots=0, dataset=None, mpi_comm=None, processor_grid=None):
+                 param_dimension_blk_sizes=(None, None), max_slots=0, dataset=None, mpi_comm=None, processor_grid=None, partition_cost="fd"):
         self.circuits = [tuple(c) for c in circuits]
         self.num_circuits = len(self.circuits)
         self.model_gate_labels = list(model.operations.keys())
@@ -139,6 +139,7 @@ class HipCOPALayout:
         self._circ_gates = np.fromiter(map(lookup.__getitem__, itertools.chain.from_iterable(self._gate_circuits)),
                                        dtype=np.int32, count=int(self._circ_ptr[-1]))
         self._rank, self._size = rank, size
+        self.partition_cost = partition_cost     # what atoms are balanced on: "fd" (finite-difference work) or "trie" (new states)
         self._mpi_comm = mpi_comm       # optional mpi4py-style communicator of the caller's ResourceAllocation
         # ---- outcomes laid out per circuit (copalayout.py:155-168) ---------------------------------------------------
         # dataset None: every outcome of the POVM; otherwise only the outcomes the data set holds for the circuit, in
@@ -247,13 +248,16 @@ class HipCOPALayout:
                 while j < n and p[j] == c[j]: j += 1
                 lcp[k] = j
             cost[k] = len(c) - lcp[k] + 1
+        if self.partition_cost == "fd":
+            cost = self._fd_cost(np.asarray(order, np.int64), lcp)
         cum = np.cumsum(cost)
         total = int(cum[-1])
         cuts = [0]
         for a in range(1, num_atoms):
             target = total * a // num_atoms
             k0 = int(np.searchsorted(cum, target))
-            lo, hi = max(cuts[-1] + 1, k0 - 200), min(self.num_circuits - 1, k0 + 200)
+            win = max(8, min(200, self.num_circuits // (50 * num_atoms)))     # (2 % of an atom: the cheapest restart near the balanced cut)
+            lo, hi = max(cuts[-1] + 1, k0 - win), min(self.num_circuits - 1, k0 + win)
             if lo > hi:
                 k = min(max(cuts[-1] + 1, k0), self.num_circuits - 1)
             else:
@@ -262,6 +266,34 @@ class HipCOPALayout:
         cuts.append(self.num_circuits)
         order = np.asarray(order, np.int64)
         return [np.sort(order[cuts[a]:cuts[a + 1]]) for a in range(num_atoms) if cuts[a + 1] > cuts[a]]
+
+    def _fd_cost(self, order, lcp):
+        """What the new states of each circuit (in prefix-sorted order) cost a FINITE-DIFFERENCE Jacobian: a state is
+        re-propagated by the parameter wavefronts of every gate that occurs on its path (the others find it in the base
+        pass's cache) and by the preparation's wavefront.  Atoms of equal trie work differ by up to 17 % in this measure --
+        germs made of several distinct gates dirty more wavefronts -- and so did the measured steps of the eight ranks of
+        the 2Q design (4.11 ... 4.62 ms); the N-GPU step is the slowest rank's.  Vectorised: first occurrence of every gate
+        in every circuit, then, per gate, the number of new states behind it."""
+        n, nG = self.num_circuits, self.num_gates
+        ptr, g = self._circ_ptr, self._circ_gates
+        ln = ptr[1:] - ptr[:-1]
+        first = np.full((n, max(nG, 1)), np.iinfo(np.int64).max // 4, np.int64)
+        if len(g):
+            circ_of = np.repeat(np.arange(n, dtype=np.int32), ln)
+            for gg in range(nG):
+                at = np.flatnonzero(g == gg)
+                if not len(at):
+                    continue
+                c = circ_of[at]
+                head = np.r_[0, np.flatnonzero(np.diff(c)) + 1]          # first occurrence in each circuit that has one
+                first[c[head], gg] = at[head] - ptr[c[head]]
+        waves = max(1, (self.dim * self.dim) // 64)                      # wavefronts of 64 parameters per gate
+        Lk = ln[order] + 1                                                # path length in states (the preparation first)
+        fo = first[order] + 1                                             # state index behind the first occurrence
+        cost = (Lk - lcp).astype(np.int64)                                # the preparation's wavefront: every new state
+        for gg in range(nG):
+            cost += waves * np.maximum(0, Lk - np.maximum(lcp, fo[:, gg]))
+        return np.maximum(cost, 1)
 
     # ---- element index (copalayout.py:683-763) ----------------------------------------------------------------
     def __len__(self):

@@ -325,3 +325,41 @@ def test_processor_grid_partitions_every_array_type(grid, n_atoms):
     assert sum(sizes) == nP and max(sizes) - min(sizes) <= 1 and L.max_param_slice_length == max(sizes)
     with pytest.raises(ValueError):
         HipCOPALayout(circ, model, num_atoms=n_atoms, rank=0, size=size + 1, processor_grid=grid)
+
+
+def test_atoms_are_balanced_on_finite_difference_work():
+    """The N-GPU step is the slowest rank's, and a rank's finite-difference Jacobian costs what its atoms' new states cost
+    ALL the parameter wavefronts that re-propagate them -- those of every gate on a state's path, plus the preparation's --
+    not the number of new states: atoms cut for equal trie work differed by 17 % in that measure on the 2Q design and their
+    measured steps by 12 % (profiles/r03_emulate_all_ranks.json).  The default partition balances the FD measure."""
+    from pygsti_amd import modelpacks as MP
+    from pygsti_amd.layout import HipCOPALayout
+    pack = MP.smq2Q_XYICNOT
+    model = pack.target_model().depolarize(0.01, 0.01)
+    circ = pack.create_gst_circuits(64, lite=True)
+
+    def spread(lay):
+        keyed = [(int(lay._circ_rho[i]),) + tuple(lay._gate_circuits[i]) for i in range(lay.num_circuits)]
+        order = np.array(sorted(range(lay.num_circuits), key=lambda i: tuple(str(x) for x in keyed[i])))
+        lcp = np.zeros(len(order), np.int64)
+        for k in range(1, len(order)):
+            p, c = keyed[order[k - 1]], keyed[order[k]]
+            j = 0
+            while j < min(len(p), len(c)) and p[j] == c[j]: j += 1
+            lcp[k] = j
+        cost = lay._fd_cost(order, lcp)
+        inv = np.empty(len(order), np.int64); inv[order] = np.arange(len(order))
+        per = np.array([cost[inv[at.circuit_indices]].sum() for at in lay.all_atoms], float)
+        return per.max() / per.mean()
+    fd = HipCOPALayout(circ, model, num_atoms=8)
+    trie = HipCOPALayout(circ, model, num_atoms=8, partition_cost="trie")
+    assert fd.partition_cost == "fd" and len(fd.all_atoms) == len(trie.all_atoms) == 8
+    for lay in (fd, trie):      # a partition either way: every circuit in exactly one atom, element slices tile the array
+        assert sorted(np.concatenate([at.circuit_indices for at in lay.all_atoms]).tolist()) == list(range(lay.num_circuits))
+        assert [at.element_slice.start for at in lay.all_atoms][1:] == [at.element_slice.stop for at in lay.all_atoms][:-1]
+    assert spread(fd) < 1.03
+    assert spread(trie) > spread(fd) + 0.02
+    # the cost itself: a circuit's new states behind the first occurrence of a gate count once per wavefront of that gate
+    one = HipCOPALayout([("Gxpi2:0", "Gxpi2:0", "Gypi2:1")], model, num_atoms=1)
+    c = one._fd_cost(np.array([0]), np.array([0]))
+    assert c[0] == 4 + 4 * (3 + 1)      # 4 states for the preparation's wavefront; Gxpi2:0 dirties 3 states, Gypi2:1 one; 4 wavefronts each
