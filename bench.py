@@ -34,7 +34,7 @@ F64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (FMA = 2 flop); separate
 HBM_PEAK_GBS = 8000.0
 
 
-def build_workload(design, max_len, world, rank, device, target_tasks, max_slots=0, scaling="strong", grid=None):
+def build_workload(design, max_len, world, rank, device, target_tasks, max_slots=0, scaling="strong", grid=None, deriv="fd"):
     from pygsti_amd import modelpacks
     from pygsti_amd.layout import HipCOPALayout
     pack = modelpacks.smq2Q_XYICNOT
@@ -47,7 +47,8 @@ def build_workload(design, max_len, world, rank, device, target_tasks, max_slots
     else:
         model = pack.target_model().depolarize(op_noise=0.01, spam_noise=0.01)
         layout = HipCOPALayout(circuits, model, num_atoms=grid[0] if grid else world, devices=[device], rank=rank, size=world,
-                               target_tasks=target_tasks, max_slots=max_slots, processor_grid=grid)
+                               target_tasks=target_tasks, max_slots=max_slots, processor_grid=grid,
+                               partition_cost="depth" if deriv == "analytic" else "fd")
     return pack, model, circuits, layout
 
 
@@ -268,7 +269,7 @@ def main():
     if col_split:         # the secondary legs below assume whole rows on every rank
         args.no_analytic = args.no_jacobian_gather = True
     pack, model, circuits, layout = build_workload(args.design, args.max_len, lay_world, lay_rank, device,
-                                                    args.target_tasks, args.max_slots, args.scaling, grid)
+                                                    args.target_tasks, args.max_slots, args.scaling, grid, args.deriv)
     log("workload built: %d circuits" % len(circuits))
     atom = layout.atoms[0]
     plan = atom.plan()

@@ -115,7 +115,8 @@ class HipMapForwardSimulator:
             blk = (blk[0], None)
         grid = self._processor_grid      # (None: the layout picks the reference's automatic grid when atoms < ranks)
         return HipCOPALayout(circuits, self.model, natoms, self.devices, rank, size, self.target_tasks, blk, dataset=dataset,
-                             mpi_comm=getattr(resource_alloc, "comm", None), processor_grid=grid)
+                             mpi_comm=getattr(resource_alloc, "comm", None), processor_grid=grid,
+                             partition_cost="depth" if self.derivative_mode == "analytic" else "fd")
 
     # -- per-atom seams (mapforwardsim.py:372-391) ---------------------------------------------------------------
     def _prepare_atom(self, layout_atom):

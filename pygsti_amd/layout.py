@@ -139,7 +139,7 @@ class HipCOPALayout:
         self._circ_gates = np.fromiter(map(lookup.__getitem__, itertools.chain.from_iterable(self._gate_circuits)),
                                        dtype=np.int32, count=int(self._circ_ptr[-1]))
         self._rank, self._size = rank, size
-        self.partition_cost = partition_cost     # what atoms are balanced on: "fd" (finite-difference work) or "trie" (new states)
+        self.partition_cost = partition_cost     # what atoms are balanced on: "fd" (finite-difference work), "depth" (gate applications: analytic mode) or "trie" (new states)
         self._mpi_comm = mpi_comm       # optional mpi4py-style communicator of the caller's ResourceAllocation
         # ---- outcomes laid out per circuit (copalayout.py:155-168) ---------------------------------------------------
         # dataset None: every outcome of the POVM; otherwise only the outcomes the data set holds for the circuit, in
@@ -250,6 +250,8 @@ class HipCOPALayout:
             cost[k] = len(c) - lcp[k] + 1
         if self.partition_cost == "fd":
             cost = self._fd_cost(np.asarray(order, np.int64), lcp)
+        elif self.partition_cost == "depth":      # analytic derivatives: one block product per gate application of every circuit
+            cost = (self._circ_len[np.asarray(order, np.int64)] + 1).astype(np.int64)
         cum = np.cumsum(cost)
         total = int(cum[-1])
         cuts = [0]
