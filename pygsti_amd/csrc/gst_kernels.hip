@@ -50,6 +50,9 @@ __device__ __forceinline__ const GST_CONST T* as_const(const T* p)
 #ifndef GST_FD_WPS
 #define GST_FD_WPS 4
 #endif
+#ifndef GST_HESS_WPS
+#define GST_HESS_WPS 3        // wavefronts per SIMD the two-perturbation (Hessian) pass is compiled for
+#endif
 #ifndef GST_FD_WPS_PERSIST
 #define GST_FD_WPS_PERSIST 3
 #endif
@@ -934,7 +937,7 @@ hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_s
 {
     if (complement) {
         if (S == 2 && D == 4) return launch_one<4, 2, 4, 1, true>(a, n_tasks, n_slots, stream);
-        if (S == 2 && D == 16) return launch_one<16, 2, 3, 1, true>(a, n_tasks, n_slots, stream);
+        if (S == 2 && D == 16) return launch_one<16, 2, GST_HESS_WPS, 1, true>(a, n_tasks, n_slots, stream);
         return hipErrorInvalidValue;
     }
     if (D == 16 && S == 1 && split == 4) return launch_one<16, 1, 4, 4>(a, n_tasks, n_slots, stream);
@@ -946,7 +949,7 @@ hipError_t launch_walk(int D, int S, const WalkArgs& a, int64_t n_tasks, int n_s
     } else if (D == 16) {
         if (S == 0) return launch_one<16, 0, 4>(a, n_tasks, n_slots, stream);
         if (S == 1) return launch_one<16, 1, GST_FD_WPS>(a, n_tasks, n_slots, stream);
-        if (S == 2) return launch_one<16, 2, 3>(a, n_tasks, n_slots, stream);
+        if (S == 2) return launch_one<16, 2, GST_HESS_WPS>(a, n_tasks, n_slots, stream);
     }
     return hipErrorInvalidValue;
 }
