@@ -1609,7 +1609,7 @@ int plan_device(const gst_plan* plan) { return plan->device; }
 extern "C" {
 
 const char* gst_last_error(void) { return g_err.c_str(); }
-const char* gst_version(void) { return "gstfwd 0.2 (gfx950)"; }
+const char* gst_version(void) { return "gstfwd 0.3 (gfx950)"; }
 
 int gst_device_count(int32_t* n)
 {
