@@ -424,7 +424,7 @@ def main():
                          "set_params_ms": 1e3 * t_set,
                          "note": "bulk_fill_dprobs of the CPTPLND-parameterised model (FD eps=1e-7, Map-simulator semantics, <=1e-8 vs the "
                                  "reference): every column's changed member assembled and exponentiated on the device (no host to_dense per "
-                                 "column), walks share the base pass's states (dirty programs, 4 columns per wavefront), POVM columns from "
+                                 "column), walks share the base pass's states (gates: dirty programs, 4 columns per wavefront; the preparation: 64 per wavefront on the lane-per-model kernel), POVM columns from "
                                  "the cached final states; round 2's form of the same Jacobian (host-stepped dense model sets, one "
                                  "independent walk per (program, model)) took 580 ms; secondary figure, not `value`"}
         finally:
