@@ -452,6 +452,21 @@ int gst_get_stats(const gst_plan *plan, gst_stats *out);
 int gst_get_program(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words,
                     int64_t *task_off, int64_t cap_tasks);
 
+/* Host-side utility of layout construction (no device, no plan): the circuits in prefix order.  Circuit c's key is
+ * (circ_head[c], circ_syms[circ_ptr[c]] ... circ_syms[circ_ptr[c+1] - 1]) -- the state preparation, then the gate symbols,
+ * as integers whose order the caller chooses -- compared element by element, a proper prefix first (Python's tuple order).
+ * order_out[k] = the k-th circuit in that order (stable), lcp_out[k] = the number of leading key elements it shares with its
+ * predecessor (0 for k = 0).  What `PrefixTable` / the distributed layouts' circuit partition compute with Python tuple
+ * compares (layouts/prefixtable.py:26-101, 154-288: 16 s at 2Q L<=1024): the atoms of a multi-GPU layout are contiguous runs
+ * of this order, cut where lcp is small.  circ_head may be NULL (one preparation). */
+int gst_sort_circuits(int64_t n_circuits, const int64_t *circ_ptr, const int32_t *circ_syms, const int32_t *circ_head,
+                      int64_t *order_out, int64_t *lcp_out);
+/* first_out[c * n_syms + g] = position of the first occurrence of symbol g in circuit c, -1 if it never occurs (host-only):
+ * what decides which parameter wavefronts of a finite-difference Jacobian re-propagate a state (those of the gates on its
+ * path) -- the measure the atoms of a multi-GPU layout are balanced on. */
+int gst_circuit_first_use(int64_t n_circuits, const int64_t *circ_ptr, const int32_t *circ_syms, int32_t n_syms,
+                          int64_t *first_out);
+
 /* The per-SIMD queues the persistent finite-difference launch of a small atom would use for these columns (host-side
  * only, no device needed): estimated work of each of n_queues queues after longest-first packing and hand-overs
  * (handover: 0 none, 1 balance, 2 cut every walk).  Needs gst_set_param_map.  D <= 16. */

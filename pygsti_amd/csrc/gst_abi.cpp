@@ -2988,6 +2988,58 @@ int gst_get_lindblad_model_sets(gst_plan* p, const int64_t* param_idx, int64_t n
     });
 }
 
+int gst_sort_circuits(int64_t n_circuits, const int64_t* circ_ptr, const int32_t* circ_syms, const int32_t* circ_head,
+                      int64_t* order_out, int64_t* lcp_out)
+{
+    return guarded([&]() -> int {
+    if (n_circuits < 0 || (n_circuits > 0 && (!circ_ptr || !order_out || !lcp_out))) return fail(GST_EINVAL, "bad argument");
+    for (int64_t c = 0; c < n_circuits; c++)
+        if (circ_ptr[c + 1] < circ_ptr[c]) return fail(GST_EINVAL, "circ_ptr must be non-decreasing");
+    if (n_circuits > 0 && circ_ptr[n_circuits] > circ_ptr[0] && !circ_syms) return fail(GST_EINVAL, "circ_syms is NULL");
+    // key of circuit c: (head[c], syms[ptr[c]] ... syms[ptr[c+1]-1]) compared element by element, a proper prefix first
+    auto common = [&](int64_t x, int64_t y) -> int64_t {          // equal leading key elements
+        if (circ_head && circ_head[x] != circ_head[y]) return 0;
+        const int32_t* a = circ_syms + circ_ptr[x];
+        const int32_t* b = circ_syms + circ_ptr[y];
+        const int64_t la = circ_ptr[x + 1] - circ_ptr[x], lb = circ_ptr[y + 1] - circ_ptr[y], m = std::min(la, lb);
+        int64_t j = 0;
+        while (j < m && a[j] == b[j]) j++;
+        return 1 + j;
+    };
+    auto less = [&](int64_t x, int64_t y) -> bool {
+        if (circ_head && circ_head[x] != circ_head[y]) return circ_head[x] < circ_head[y];
+        const int32_t* a = circ_syms + circ_ptr[x];
+        const int32_t* b = circ_syms + circ_ptr[y];
+        const int64_t la = circ_ptr[x + 1] - circ_ptr[x], lb = circ_ptr[y + 1] - circ_ptr[y], m = std::min(la, lb);
+        for (int64_t j = 0; j < m; j++)
+            if (a[j] != b[j]) return a[j] < b[j];
+        return la < lb;
+    };
+    for (int64_t c = 0; c < n_circuits; c++) order_out[c] = c;
+    std::stable_sort(order_out, order_out + n_circuits, less);
+    for (int64_t k = 0; k < n_circuits; k++) lcp_out[k] = k ? common(order_out[k - 1], order_out[k]) : 0;
+    return GST_OK;
+    });
+}
+
+int gst_circuit_first_use(int64_t n_circuits, const int64_t* circ_ptr, const int32_t* circ_syms, int32_t n_syms, int64_t* first_out)
+{
+    return guarded([&]() -> int {
+    if (n_circuits < 0 || n_syms < 0 || (n_circuits > 0 && (!circ_ptr || (n_syms > 0 && !first_out)))) return fail(GST_EINVAL, "bad argument");
+    for (int64_t c = 0; c < n_circuits; c++) {
+        int64_t* f = first_out + c * n_syms;
+        for (int32_t g = 0; g < n_syms; g++) f[g] = -1;
+        int32_t found = 0;
+        for (int64_t k = circ_ptr[c]; k < circ_ptr[c + 1] && found < n_syms; k++) {
+            const int32_t g = circ_syms[k];
+            if (g < 0 || g >= n_syms) return fail(GST_EINVAL, "symbol out of range in circuit " + std::to_string(c));
+            if (f[g] < 0) { f[g] = k - circ_ptr[c]; found++; }
+        }
+    }
+    return GST_OK;
+    });
+}
+
 int gst_get_fd_queues(gst_plan* p, const int64_t* param_idx, int64_t n_param, int32_t n_queues, int32_t handover,
                       int64_t* load_out, int32_t* n_pairs, int32_t* n_handovers)
 {

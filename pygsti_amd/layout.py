@@ -236,22 +236,19 @@ class HipCOPALayout:
     def _partition(self, num_atoms):
         if num_atoms == 1:
             return [np.arange(self.num_circuits)]
-        keyed = [(int(self._circ_rho[i]),) + tuple(self._gate_circuits[i]) for i in range(self.num_circuits)]
-        order = sorted(range(self.num_circuits), key=lambda i: tuple(str(x) for x in keyed[i]))
-        lcp = np.zeros(self.num_circuits, np.int64)
-        cost = np.zeros(self.num_circuits, np.int64)
-        for k, ci in enumerate(order):
-            c = keyed[ci]
-            if k:
-                p = keyed[order[k - 1]]
-                n = min(len(p), len(c)); j = 0
-                while j < n and p[j] == c[j]: j += 1
-                lcp[k] = j
-            cost[k] = len(c) - lcp[k] + 1
+        # prefix order of (preparation, gate labels ...), labels compared as strings, and each circuit's common prefix with
+        # its predecessor: gst_sort_circuits on integer ranks of the labels (0.6 s for the 2Q L<=1024 design; the Python
+        # tuple sort and compare loop this replaces took 8.5 s of a 13 s layout)
+        rank = np.empty(max(self.num_gates, 1), np.int32)
+        rank[np.argsort(np.array([str(l) for l in self.model_gate_labels], dtype=object), kind="stable")] = np.arange(self.num_gates, dtype=np.int32)
+        rho_strs = sorted({str(int(r)) for r in range(max(self.num_preps, 1))})
+        head = np.array([rho_strs.index(str(int(r))) for r in self._circ_rho], np.int32)
+        order, lcp = _lib.sort_circuits(self._circ_ptr, rank[self._circ_gates] if len(self._circ_gates) else np.zeros(0, np.int32), head)
+        cost = (self._circ_len[order] + 1 - lcp + 1).astype(np.int64)          # new trie states (+1)
         if self.partition_cost == "fd":
-            cost = self._fd_cost(np.asarray(order, np.int64), lcp)
+            cost = self._fd_cost(order, lcp)
         elif self.partition_cost == "depth":      # analytic derivatives: one block product per gate application of every circuit
-            cost = (self._circ_len[np.asarray(order, np.int64)] + 1).astype(np.int64)
+            cost = (self._circ_len[order] + 1).astype(np.int64)
         cum = np.cumsum(cost)
         total = int(cum[-1])
         cuts = [0]
@@ -274,21 +271,13 @@ class HipCOPALayout:
         re-propagated by the parameter wavefronts of every gate that occurs on its path (the others find it in the base
         pass's cache) and by the preparation's wavefront.  Atoms of equal trie work differ by up to 17 % in this measure --
         germs made of several distinct gates dirty more wavefronts -- and so did the measured steps of the eight ranks of
-        the 2Q design (4.11 ... 4.62 ms); the N-GPU step is the slowest rank's.  Vectorised: first occurrence of every gate
-        in every circuit, then, per gate, the number of new states behind it."""
+        the 2Q design (4.11 ... 4.62 ms); the N-GPU step is the slowest rank's.  First occurrence of every gate in every
+        circuit (gst_circuit_first_use), then, per gate, the number of new states behind it."""
         n, nG = self.num_circuits, self.num_gates
         ptr, g = self._circ_ptr, self._circ_gates
         ln = ptr[1:] - ptr[:-1]
-        first = np.full((n, max(nG, 1)), np.iinfo(np.int64).max // 4, np.int64)
-        if len(g):
-            circ_of = np.repeat(np.arange(n, dtype=np.int32), ln)
-            for gg in range(nG):
-                at = np.flatnonzero(g == gg)
-                if not len(at):
-                    continue
-                c = circ_of[at]
-                head = np.r_[0, np.flatnonzero(np.diff(c)) + 1]          # first occurrence in each circuit that has one
-                first[c[head], gg] = at[head] - ptr[c[head]]
+        first = _lib.circuit_first_use(ptr, g, nG)
+        first[first < 0] = np.iinfo(np.int64).max // 4                    # never applied: behind every state
         waves = max(1, (self.dim * self.dim) // 64)                      # wavefronts of 64 parameters per gate
         Lk = ln[order] + 1                                                # path length in states (the preparation first)
         fo = first[order] + 1                                             # state index behind the first occurrence

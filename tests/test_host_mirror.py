@@ -363,3 +363,39 @@ def test_atoms_are_balanced_on_finite_difference_work():
     one = HipCOPALayout([("Gxpi2:0", "Gxpi2:0", "Gypi2:1")], model, num_atoms=1)
     c = one._fd_cost(np.array([0]), np.array([0]))
     assert c[0] == 4 + 4 * (3 + 1)      # 4 states for the preparation's wavefront; Gxpi2:0 dirties 3 states, Gypi2:1 one; 4 wavefronts each
+
+
+def test_sort_circuits_and_first_use_match_python():
+    """gst_sort_circuits / gst_circuit_first_use (host-only utilities of layout construction) against the Python they replace:
+    tuple order of (preparation, symbols...) with a proper prefix first, stable for equal keys, common-prefix lengths
+    counted in key elements; first occurrence of every symbol per circuit."""
+    from pygsti_amd import _lib
+    rng = np.random.default_rng(5)
+    n, n_syms = 400, 5
+    lens = rng.integers(0, 9, n)
+    seqs = [rng.integers(0, n_syms, L).tolist() for L in lens]
+    seqs[7] = seqs[3][:]                    # a duplicate key: stable order
+    seqs[11] = seqs[3][:2]                  # a proper prefix
+    head = rng.integers(0, 2, n).astype(np.int32); head[7] = head[3]; head[11] = head[3]
+    ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(s) for s in seqs])
+    syms = np.array([x for s in seqs for x in s], np.int32)
+    order, lcp = _lib.sort_circuits(ptr, syms, head)
+    keys = [(int(head[i]),) + tuple(seqs[i]) for i in range(n)]
+    want = sorted(range(n), key=lambda i: keys[i])
+    assert order.tolist() == want
+    for k in range(1, n):
+        a, b = keys[order[k - 1]], keys[order[k]]
+        j = 0
+        while j < min(len(a), len(b)) and a[j] == b[j]: j += 1
+        assert lcp[k] == j
+    assert lcp[0] == 0
+    order2, lcp2 = _lib.sort_circuits(ptr, syms, None)          # one preparation: the key is (0, symbols...)
+    assert order2.tolist() == sorted(range(n), key=lambda i: tuple(seqs[i])) and lcp2[1:].min() >= 1
+    first = _lib.circuit_first_use(ptr, syms, n_syms)
+    for i in (0, 3, 7, 11, 50, n - 1):
+        for g in range(n_syms):
+            assert first[i, g] == (seqs[i].index(g) if g in seqs[i] else -1)
+    with pytest.raises(Exception):
+        _lib.circuit_first_use(ptr, syms, 2)                    # a symbol out of range
+    o0, l0 = _lib.sort_circuits(np.zeros(1, np.int64), np.zeros(0, np.int32), None)
+    assert len(o0) == 0 and len(l0) == 0
