@@ -2,6 +2,7 @@
 // gst_plan_create_* + gst_get_program (tests/test_plan_compiler.py interprets the programs in numpy).
 #include "gst_plan.hpp"
 
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -267,6 +268,10 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
         seen[d] = 1;
     }
 
+    const bool tm_ = std::getenv("GST_PLAN_TIMING") != nullptr;      // development aid: seconds per stage on stderr
+    auto t0_ = std::chrono::steady_clock::now();
+    auto lap_ = [&](const char* w) { if (tm_) { auto t1 = std::chrono::steady_clock::now(); std::fprintf(stderr, "[plan] %s %.3f s\n", w, std::chrono::duration<double>(t1 - t0_).count()); t0_ = t1; } };
+    lap_("validate");
     // --- sort circuits lexicographically on (rho, gates...) --------------------------------------
     std::vector<int32_t> order(nC);
     std::iota(order.begin(), order.end(), 0);
@@ -282,6 +287,7 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
         return a < b;
     };
     std::sort(order.begin(), order.end(), less);
+    lap_("sort");
     std::vector<int64_t> lcp(nC, 0);   // common symbols (rho counts as one) with the previous circuit
     P.sum_depth = 0; P.trie_nodes = 0; P.max_depth = 0;
     for (int64_t k = 0; k < nC; k++) {
@@ -325,6 +331,7 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
     }
     cuts.push_back(nC);
 
+    lap_("lcp+cuts");
     // --- compile each task ----------------------------------------------------------------------------
     struct Built { std::vector<uint32_t> words; int64_t applies; };
     std::vector<Built> built;
@@ -359,6 +366,7 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
         P.applies_per_pass += b.applies;
         built.push_back(std::move(b));
     }
+    lap_("tasks");
     // heaviest first: the device takes tasks in launch order, long ones should not start last
     std::stable_sort(built.begin(), built.end(), [](const Built& a, const Built& b) { return a.applies > b.applies; });
     P.prog.clear(); P.task_off.assign(1, 0); P.task_applies.clear();

@@ -34,6 +34,19 @@ def _slice_up_range(n, num_slices):
     return out
 
 
+def _ragged_take(values, ptr, rows, out_ptr):
+    """Concatenation of values[ptr[r]:ptr[r+1]] for r in rows (out_ptr: the running lengths, out_ptr[-1] in all)."""
+    total = int(out_ptr[-1])
+    if total == 0:
+        return values[:0].copy()
+    rows = np.asarray(rows, np.int64)
+    if len(rows) and rows[0] == 0 and len(rows) == len(ptr) - 1 and np.array_equal(rows, np.arange(len(rows))):
+        return np.ascontiguousarray(values[:total])              # every row in order: the array itself
+    lens = out_ptr[1:] - out_ptr[:-1]
+    src = np.repeat(np.asarray(ptr, np.int64)[rows] - out_ptr[:-1], lens) + np.arange(total, dtype=np.int64)
+    return values[src]
+
+
 class _ResourceAlloc:
     """Stand-in for pygsti.baseobjs.ResourceAllocation on the serial/one-process-per-GPU path."""
 
@@ -74,16 +87,13 @@ class HipLayoutAtom:
             lens = L._circ_len[self.circuit_indices]
             ptr = np.zeros(n + 1, np.int64)
             np.cumsum(lens, out=ptr[1:])
-            gates = np.empty(int(ptr[-1]), np.int32)
-            for k, ci in enumerate(self.circuit_indices):
-                gates[ptr[k]:ptr[k + 1]] = L._circ_gates[L._circ_ptr[ci]:L._circ_ptr[ci + 1]]
+            # (one gather instead of a Python loop over the circuits: 1.4 s of a 1.9 s call for the 2Q L<=1024 design)
+            gates = _ragged_take(L._circ_gates, L._circ_ptr, self.circuit_indices, ptr).astype(np.int32, copy=False)
             # effect CSR of this atom's circuits: all outcomes, or only those the data set observed (maplayout.py:69)
             cnt = L._out_ptr[self.circuit_indices + 1] - L._out_ptr[self.circuit_indices]
             eff_ptr = np.zeros(n + 1, np.int64)
             np.cumsum(cnt, out=eff_ptr[1:])
-            eff_label = np.empty(int(eff_ptr[-1]), np.int32)
-            for k, ci in enumerate(self.circuit_indices):
-                eff_label[eff_ptr[k]:eff_ptr[k + 1]] = L._out_idx[L._out_ptr[ci]:L._out_ptr[ci + 1]]
+            eff_label = _ragged_take(L._out_idx, L._out_ptr, self.circuit_indices, eff_ptr).astype(np.int32, copy=False)
             eff_dest = np.arange(int(eff_ptr[-1]), dtype=np.int32)
             self._plan = _lib.Plan.from_circuits(L.dim, L.num_gates, L.num_preps, nO, int(eff_ptr[-1]),
                                                  L._circ_rho[self.circuit_indices].astype(np.int32), ptr,
