@@ -207,7 +207,8 @@ struct gst_plan {
     bool fd_persist_always = false;     // GST_FD_PERSIST=2: per-SIMD queues whatever the number of pairs
     bool fd_fused = true;               // GST_FD_FUSED=0: launch-bound plans keep the separate base pass
     bool host_direct = true;            // GST_HOST_DIRECT=0: page-locked destinations are filled by a copy, not by the kernel
-    int64_t host_direct_min_cols = 64;  // (narrower column windows would cross PCIe in segments shorter than a wavefront's 512 bytes)
+    int64_t host_direct_min_cols = 32;  // (narrower column windows would cross PCIe in segments of less than 256 bytes; 64 until round 3 --
+                                        //  the 1Q model's 60 columns were just below it: blocking fill 103 -> 81 us with the kernel's direct stores)
     int fd_handover = 1;                // GST_FD_HANDOVER: 0 never cut a walk, 1 cut to balance the per-SIMD queues, 2 cut every walk
     bool fd_overlap = true;             // GST_FD_OVERLAP=0: the persistent FD launch keeps the separate base pass in front of it
     double test_cache_limit = 0;        // GST_TEST_CACHE_LIMIT (bytes; tests): stands in for the 4 GB of 32-bit cache offsets

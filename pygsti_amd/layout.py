@@ -336,7 +336,7 @@ class HipCOPALayout:
         # element-dimension arrays are what the fills copy into: page-lock the large ones once, here, so that every
         # later bulk_fill_* runs at PCIe rate (the reference allocates these once per objective and reuses them)
         self.last_array_pinned = False
-        if array_type in ("e", "ep", "ep2", "epp") and arr.nbytes >= (1 << 22) and self.pin_arrays:
+        if array_type in ("e", "ep", "ep2", "epp") and arr.nbytes >= (1 << 18) and self.pin_arrays:      # (256 KB: the 1Q Jacobian is 1 MB)
             self.last_array_pinned = _lib.pin_host_array(arr)
         return arr
 

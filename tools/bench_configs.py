@@ -76,7 +76,7 @@ def one_q():
     t_an = timed(lambda: plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_ANALYTIC), plan, 200)
     st = plan.stats()
     # one blocking fill at a time (what a caller that needs the result sees), host arrays included
-    J = np.empty((nE, nP)); pr = np.empty(nE)
+    J = layout.allocate_local_array("ep"); pr = layout.allocate_local_array("e")     # (what bulk_fill_dprobs(array, layout) is handed: page-locked from 256 KB)
     def lat(fn, reps=200):
         fn()
         t0 = time.perf_counter()
@@ -86,6 +86,7 @@ def one_q():
     l_p = lat(lambda: plan.fill_probs(pr))
     l_fd = lat(lambda: plan.fill_dprobs(J, pidx, None, 1e-7, pr, _lib.DERIV_FD))
     l_an = lat(lambda: plan.fill_dprobs(J, pidx, None, 1e-7, pr, _lib.DERIV_ANALYTIC))
+    layout.free_local_array(J); layout.free_local_array(pr)
     D = 4
     fl_pass = 2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE           # flops of one probability pass
     roof = {"probs": _roof_compute(fl_pass, t_p), "dprobs_fd": _roof_compute(nP * fl_pass, t_fd),
