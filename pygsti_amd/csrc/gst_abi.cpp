@@ -2030,11 +2030,20 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     // A page-locked destination (gst_host_register): the FD kernel writes the Jacobian straight into it -- 512-byte row
     // segments over PCIe while the walk is still computing -- instead of filling 7 GB of HBM first and copying afterwards
     // (kernel and transfer overlap completely; the (ld, dest_idx) window is honoured by the kernel itself).
-    if (!p->derivs_set && mode == GST_DERIV_FD && n_param >= p->host_direct_min_cols && nE > 0 && p->hp.D <= 16 && p->comp_index < 0 && p->host_direct) {
+    // (the analytic contraction writes every requested entry exactly once as well -- streaming stores -- and takes the same route)
+    if (!p->derivs_set && (mode == GST_DERIV_FD || mode == GST_DERIV_ANALYTIC) && n_param >= p->host_direct_min_cols && nE > 0 && p->hp.D <= 16 &&
+        p->comp_index < 0 && p->host_direct && !(mode == GST_DERIV_ANALYTIC && p->ana_keep_zeros)) {
         int64_t max_col = 0;
-        for (int64_t c = 0; c < n_param; c++) max_col = std::max<int64_t>(max_col, dest_idx ? dest_idx[c] : c);
-        if (void* d_host = mapped_device_pointer(out, (size_t)((nE - 1) * ld + max_col + 1) * 8)) {
-            if ((rc = run_dprobs_fd(p, (double*)d_host, ld, param_idx, dest_idx, n_param, eps, nullptr, nullptr, 0))) return rc;
+        bool plain = true;          // (analytic: columns of parameters the atom never uses are zero-filled by a 2-D memset -- staged route)
+        for (int64_t c = 0; c < n_param; c++) {
+            max_col = std::max<int64_t>(max_col, dest_idx ? dest_idx[c] : c);
+            if (mode == GST_DERIV_ANALYTIC && p->pkind[(size_t)param_idx[c]] == GST_KIND_NONE) plain = false;
+        }
+        void* d_host = plain ? mapped_device_pointer(out, (size_t)((nE - 1) * ld + max_col + 1) * 8) : nullptr;
+        if (d_host) {
+            if (mode == GST_DERIV_ANALYTIC) rc = run_dprobs_analytic(p, (double*)d_host, ld, param_idx, dest_idx, n_param, nullptr);
+            else rc = run_dprobs_fd(p, (double*)d_host, ld, param_idx, dest_idx, n_param, eps, nullptr, nullptr, 0);
+            if (rc) return rc;
             if (probs_out) HIP_TRY(hipMemcpyAsync(probs_out, p->d_pbase.p, nE * 8, hipMemcpyDeviceToHost, p->stream));
             return end_call(p, true);
         }

@@ -201,6 +201,36 @@ def test_dprobs_into_page_locked_array_bitwise(name, direct, monkeypatch):
     assert_bitwise(pl.fill_dprobs(param_idx=cols, eps=1e-7), fx["dprobs_map"], "pageable destination afterwards")
 
 
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq2Q_XYICNOT_L2_depol"])
+def test_analytic_dprobs_into_page_locked_array(name, monkeypatch):
+    """The analytic contraction writes a page-locked destination itself as well (round 3): bit for bit what the staged route
+    (GST_HOST_DIRECT=0: HBM, then a copy) returns, window honoured, NaN pre-fill fully overwritten, nothing outside touched;
+    with GST_OPT_ANALYTIC_KEEP_ZEROS set the staged route is taken (the kernel then skips stores the host array never got)."""
+    from pygsti_amd import _lib
+    fx = load_fixture(name)
+    cols = fx["dprobs_cols"]; nE, n = int(fx["nE"]), len(cols)
+    monkeypatch.setenv("GST_HOST_DIRECT", "0")
+    ref = plan_from_fixture(fx).fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    monkeypatch.setenv("GST_HOST_DIRECT", "2")
+    pl = plan_from_fixture(fx)
+    full = np.full((nE, n + 7), np.nan)
+    assert _lib.pin_host_array(full)
+    pr = np.empty(nE)
+    try:
+        full[:, :3] = -7.0; full[:, 3 + n:] = -7.0
+        pl.fill_dprobs(out=full, param_idx=cols, dest_idx=np.arange(n) + 3, probs_out=pr, mode=_lib.DERIV_ANALYTIC)
+        assert_bitwise(full[:, 3:3 + n], ref, "page-locked destination, analytic")
+        assert (full[:, :3] == -7.0).all() and (full[:, 3 + n:] == -7.0).all()
+        assert np.abs(pr - fx["probs"]).max() < 1e-13
+        pl.set_option(_lib.OPT_ANALYTIC_KEEP_ZEROS, 1)
+        full[:, 3:3 + n] = np.nan
+        for _ in range(2):      # same destination, same request, twice: every entry must still be there
+            pl.fill_dprobs(out=full, param_idx=cols, dest_idx=np.arange(n) + 3, mode=_lib.DERIV_ANALYTIC)
+            assert_bitwise(full[:, 3:3 + n], ref, "page-locked destination with the keep-zeros option")
+    finally:
+        _lib.unpin_host_array(full)
+
+
 @pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2", "smq2Q_XYICNOT_L2_depol", "3q_explicit_L64"])
 @pytest.mark.parametrize("mode", ["fd", "analytic"])
 def test_device_fills_overwrite_every_requested_entry(name, mode):
