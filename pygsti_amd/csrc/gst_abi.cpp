@@ -79,8 +79,12 @@ struct DevBuf {
         p = nullptr; n = 0;
         hipError_t e = flags ? hipExtMallocWithFlags((void**)&p, std::max<size_t>(count, 1) * sizeof(T), flags)
                              : hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
-        if (e == hipSuccess) n = std::max<size_t>(count, 1);
-        return e;
+        if (e != hipSuccess) { p = nullptr; return e; }
+        n = std::max<size_t>(count, 1);
+        // A (re)grown buffer starts from zeros, not from whatever an earlier allocation of this process left there: a table
+        // entry or padding word that some path does not write is then the same harmless value in every run (once per
+        // growth, at memory speed).
+        return hipMemset(p, 0, n * sizeof(T));
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
