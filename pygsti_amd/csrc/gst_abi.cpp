@@ -84,7 +84,9 @@ struct DevBuf {
         // A (re)grown buffer starts from zeros, not from whatever an earlier allocation of this process left there: a table
         // entry or padding word that some path does not write is then the same harmless value in every run (once per
         // growth, at memory speed).
-        return hipMemset(p, 0, n * sizeof(T));
+        e = hipMemset(p, 0, n * sizeof(T));
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);      // (done before any of the plan's own, non-blocking streams touches it)
+        return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
