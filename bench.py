@@ -420,8 +420,24 @@ def main():
             dtc = (time.perf_counter() - tc0) / n_c
             chk = plan.memcpy_d2h(np.empty(nPl), d_outl + ((nE_local - 1) * nPl) * 8)
             assert np.isfinite(chk).all()
+            # the same Jacobian with exact derivatives: element Jacobian (analytic contraction) x the members' derivative
+            # matrices, both computed on the device (MatrixForwardSimulator semantics for this parameterisation)
+            dta = None
+            try:
+                plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
+                barrier_sync(plan)
+                ta0 = time.perf_counter()
+                for _ in range(n_c):
+                    plan.set_lindblad_params(theta)
+                    plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
+                barrier_sync(plan)
+                dta = (time.perf_counter() - ta0) / n_c
+            except Exception as e:
+                log("CPTPLND analytic leg failed: %s" % e)
             cptp_info = {"value": nE_local * nPl / dtc, "unit": "Jacobian-elements/s", "ms_per_step": 1e3 * dtc, "n_params": nPl,
                          "set_params_ms": 1e3 * t_set,
+                         "analytic_ms_per_step": None if dta is None else 1e3 * dta,
+                         "analytic_elements_per_s": None if dta is None else nE_local * nPl / dta,
                          "note": "bulk_fill_dprobs of the CPTPLND-parameterised model (FD eps=1e-7, Map-simulator semantics, <=1e-8 vs the "
                                  "reference): every column's changed member assembled and exponentiated on the device (no host to_dense per "
                                  "column), walks share the base pass's states (gates: dirty programs, 4 columns per wavefront; the preparation: 64 per wavefront on the lane-per-model kernel), POVM columns from "
