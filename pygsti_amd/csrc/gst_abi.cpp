@@ -1874,10 +1874,33 @@ int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* pa
     int rc = run_element_jacobian(p, d_probs_out);
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
-    // zero the requested columns, then accumulate object by object
+    // Object by object: the first object that maps onto a destination column STORES its product there, later ones (shared
+    // parameters: the effects of a POVM) add to it.  Only when some requested column is reached by no object at all are
+    // the columns zeroed first (8.4 GB of memset and as much read-modify-write traffic for the 2Q CPTPLND Jacobian otherwise).
+    std::vector<uint8_t> first_writer(p->dv_kind.size(), 0);
+    bool all_covered = true;
+    {
+        std::vector<uint8_t> seen((size_t)p->dv_n_params, 0);
+        for (size_t o = 0; o < p->dv_kind.size(); o++) {
+            bool any_seen = false, any_new = false;
+            for (int64_t c = p->dv_off_cols[o]; c < p->dv_off_cols[o + 1]; c++) {
+                const int64_t gp = p->dv_param_idx[(size_t)c];
+                if (dest_of[(size_t)gp] < 0) continue;
+                if (seen[(size_t)gp]) any_seen = true; else any_new = true;
+            }
+            first_writer[o] = (any_new && !any_seen) ? 1 : 0;
+            // an object that is neither purely first nor purely later (it shares SOME columns) must add: those columns need zeros
+            if (any_new && any_seen) all_covered = false;
+            for (int64_t c = p->dv_off_cols[o]; c < p->dv_off_cols[o + 1]; c++) seen[(size_t)p->dv_param_idx[(size_t)c]] = 1;
+        }
+        for (int64_t c = 0; c < n_param; c++) all_covered = all_covered && seen[(size_t)param_idx[c]];
+        if (!all_covered) std::fill(first_writer.begin(), first_writer.end(), (uint8_t)0);
+    }
     bool window = true;
     for (int64_t c = 1; dest_idx && c < n_param; c++) window = window && dest_idx[c] == dest_idx[0] + c;
-    if (window) {
+    if (all_covered) {
+        // (every requested column gets its first value by a store)
+    } else if (window) {
         const int64_t d0 = dest_idx ? dest_idx[0] : 0;
         HIP_TRY(hipMemset2DAsync(d_out + d0, (size_t)ld * 8, 0, (size_t)n_param * 8, (size_t)nE, p->stream));
     } else {
@@ -1894,7 +1917,7 @@ int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* pa
         const int K = k == GST_KIND_GATE ? D * D : D;
         const int64_t a0 = (k == GST_KIND_GATE ? base_gate : k == GST_KIND_RHO ? base_rho : base_eff) + (int64_t)p->dv_obj[o] * K;
         HIP_TRY(gst::launch_chain_rule_gemm(p->d_jelem.p, n_el, a0, K, p->d_dv_deriv.p + p->dv_off_deriv[o], p->dv_ncols[o],
-                                            p->d_dv_colmap.p + p->dv_off_cols[o], d_out, ld, nE, p->stream));
+                                            p->d_dv_colmap.p + p->dv_off_cols[o], d_out, ld, nE, p->stream, first_writer[o] != 0));
         p->last_launches++;
     }
     return GST_OK;

@@ -421,27 +421,50 @@ hipError_t launch_hessian_block(const double* H, const double* d1, const double*
 __global__ __launch_bounds__(256) void chain_rule_gemm_kernel(const double* __restrict__ A, int64_t ldA, int64_t a_col0, int K,
                                                               const double* __restrict__ B, int n,
                                                               const int32_t* __restrict__ colmap, double* __restrict__ C,
-                                                              int64_t ldC, int64_t n_rows)
+                                                              int64_t ldC, int64_t n_rows, const int overwrite)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the four wavefronts of a workgroup take four consecutive 16-row tiles of the SAME 64-column tile: they stream the same
+    // K x 64 slice of B (131 KB at K = 256) through the CU's L1 together.  (Until round 3 they took the four column tiles
+    // of one row tile, so every 16 rows re-read all of B from L2: 16.7 GB per gate of the 2Q CPTPLND model.)
     const int tiles_n = (n + 63) / 64;
-    const int64_t r0 = (wave / tiles_n) * 16;
-    const int c0 = (int)(wave % tiles_n) * 64;
+    const int64_t r0 = (((int64_t)blockIdx.x / tiles_n) * 4 + (threadIdx.x >> 6)) * 16;
+    const int c0 = (int)((int64_t)blockIdx.x % tiles_n) * 64;
     if (r0 >= n_rows) return;
     const int i = lane & 15, kk = lane >> 4;
     d4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    const bool row_ok = r0 + i < n_rows;
-    const double* arow = A + (row_ok ? r0 + i : 0) * ldA + a_col0;
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + kk;
-        const double a = (row_ok && k < K) ? arow[k] : 0.0;
+    // Rows / columns beyond the matrix are CLAMPED to valid ones instead of predicated (their products are never stored), and
+    // B is addressed by a 32-bit element offset behind its uniform base: the loop is 5 loads, 4 address adds and 4 MFMAs per
+    // k-step.  (With a select on every operand and 64-bit index arithmetic per load the kernel issued ~10 vector
+    // instructions per MFMA and kept the matrix pipes 28 % busy.)
+    const int64_t arow_i = (r0 + i < n_rows) ? r0 + i : n_rows - 1;
+    const double* ap = A + arow_i * ldA + a_col0 + kk;
+    uint32_t bo[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int col = c0 + 16 * t + i;
+        bo[t] = (uint32_t)(kk * n + (col < n ? col : n - 1));
+    }
+    const int K4 = K & ~3;
+    const uint32_t step = 4u * (uint32_t)n;
+#pragma unroll 8
+    for (int k0 = 0; k0 < K4; k0 += 4) {
+        const double a = ap[k0];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int col = c0 + 16 * t + i;
-            const double b = (k < K && col < n) ? B[(int64_t)k * n + col] : 0.0;
+            const double b = B[bo[t]];
+            bo[t] += step;
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    if (K4 < K) {                                  // the last, partial k-step: operands beyond K are zeros
+        const bool k_ok = K4 + kk < K;
+        const double a = k_ok ? ap[K4] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const double b = k_ok ? B[bo[t]] : 0.0;
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
         }
     }
@@ -453,20 +476,22 @@ __global__ __launch_bounds__(256) void chain_rule_gemm_kernel(const double* __re
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int64_t row = r0 + kk + 4 * r;
-            if (row < n_rows) C[row * ldC + cc] += acc[t][r];
+            if (row < n_rows) {                     // (the first object that owns these columns stores, later ones add)
+                double* c = C + row * ldC + cc;
+                *c = overwrite ? acc[t][r] : *c + acc[t][r];
+            }
         }
     }
 }
 
 hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, int K, const double* B, int n, const int32_t* colmap,
-                                  double* C, int64_t ldC, int64_t n_rows, hipStream_t s)
+                                  double* C, int64_t ldC, int64_t n_rows, hipStream_t s, bool overwrite)
 {
     if (n <= 0 || n_rows <= 0 || K <= 0) return hipSuccess;
-    const int64_t waves = ((n_rows + 15) / 16) * ((n + 63) / 64);
-    const int64_t blocks = (waves + 3) / 4;
+    const int64_t blocks = ((n_rows + 63) / 64) * ((n + 63) / 64);       // workgroup = 64 rows x 64 columns
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(chain_rule_gemm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, A, ldA, a_col0, K, B, n, colmap, C, ldC, n_rows);
+    hipLaunchKernelGGL(chain_rule_gemm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, A, ldA, a_col0, K, B, n, colmap, C, ldC, n_rows, overwrite ? 1 : 0);
     return hipGetLastError();
 }
 
