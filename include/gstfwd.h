@@ -451,6 +451,14 @@ int gst_get_stats(const gst_plan *plan, gst_stats *out);
  * *n_words.  task_off (may be NULL) receives n_tasks+1 offsets when cap_tasks suffices. */
 int gst_get_program(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words,
                     int64_t *task_off, int64_t cap_tasks);
+/* The "dirty programs" of finite differences over whole-object perturbations (gst_set_lindblad): for task t and object
+ * class c (gate c for c < n_gates, preparation c - n_gates behind them; *n_classes = n_gates + n_rhos) the part of the
+ * task's walk that a perturbation of that object changes -- program (t, c) = words[prog_off[t * n_classes + c] ...
+ * prog_off[t * n_classes + c + 1]), empty when no outcome of the task sees the object.  GST_OP_CACHE id starts from state
+ * `id` of the base pass; the rest are the ordinary opcodes.  Copies up to `cap` words, the total in *n_words; prog_off
+ * (may be NULL) receives n_tasks * n_classes + 1 offsets when cap_progs suffices. */
+int gst_get_dirty_programs(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words, int64_t *prog_off,
+                           int64_t cap_progs, int32_t *n_classes);
 
 /* Host-side utility of layout construction (no device, no plan): the circuits in prefix order.  Circuit c's key is
  * (circ_head[c], circ_syms[circ_ptr[c]] ... circ_syms[circ_ptr[c+1] - 1]) -- the state preparation, then the gate symbols,

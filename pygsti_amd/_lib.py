@@ -79,7 +79,7 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_state_graph", "gst_get_fd_queues", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
@@ -127,6 +127,7 @@ def lib():
         L.gst_memcpy_d2h_async.argtypes = [vp, vp, vp, i64]
         L.gst_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.gst_get_program.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64]
+        L.gst_get_dirty_programs.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i32)]
         L.gst_get_fd_queues.argtypes = [vp, vp, i64, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
         L.gst_sort_circuits.argtypes = [i64, vp, vp, vp, vp, vp]
         L.gst_circuit_first_use.argtypes = [i64, vp, vp, i32, vp]
@@ -601,6 +602,20 @@ class Plan:
         off = np.empty(nt + 1, np.int64)
         check(lib().gst_get_program(self._h, _ptr(words), n.value, C.byref(n), _ptr(off), nt + 1))
         return words[:n.value], off
+
+
+def _dirty_programs(self):
+    """(words, prog_off, n_classes) of gst_get_dirty_programs: program (task t, class c) = words[off[t * n_classes + c] : off[... + 1]]"""
+    n = C.c_int64(0); nc = C.c_int32(0)
+    check(lib().gst_get_dirty_programs(self._h, None, 0, C.byref(n), None, 0, C.byref(nc)))
+    words = np.empty(max(n.value, 1), np.uint32)
+    n_prog = self.stats()["n_tasks"] * nc.value
+    off = np.empty(n_prog + 1, np.int64)
+    check(lib().gst_get_dirty_programs(self._h, _ptr(words), n.value, C.byref(n), _ptr(off), n_prog + 1, C.byref(nc)))
+    return words[:n.value], off, nc.value
+
+
+Plan.dirty_programs = _dirty_programs
 
 
 def sort_circuits(circ_ptr, circ_syms, circ_head=None):

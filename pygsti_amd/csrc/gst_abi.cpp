@@ -2868,6 +2868,23 @@ int gst_get_program(const gst_plan* p, uint32_t* words, int64_t cap, int64_t* n_
     });
 }
 
+int gst_get_dirty_programs(const gst_plan* p, uint32_t* words, int64_t cap, int64_t* n_words, int64_t* prog_off, int64_t cap_progs,
+                           int32_t* n_classes)
+{
+    return guarded([&]() -> int {
+    if (!p || !n_words || !n_classes) return fail(GST_EINVAL, "NULL argument");
+    if (p->hp.n_gates > 64) return fail(GST_EUNSUPPORTED, "dirty programs exist for at most 64 gates");
+    gst::DirtyPrograms local;
+    const gst::DirtyPrograms* d = &p->dirty;
+    if (!p->dirty_ready) { gst::build_dirty_programs(p->hp, local); d = &local; }     // (a const plan: built for this call only)
+    *n_words = (int64_t)d->words.size();
+    *n_classes = d->n_classes;
+    if (words && cap > 0) std::memcpy(words, d->words.data(), sizeof(uint32_t) * std::min<int64_t>(cap, *n_words));
+    if (prog_off && cap_progs >= (int64_t)d->off.size()) std::memcpy(prog_off, d->off.data(), sizeof(int64_t) * d->off.size());
+    return GST_OK;
+    });
+}
+
 int gst_set_option(gst_plan* p, int32_t option, int64_t value)
 {
     return guarded([&]() -> int {

@@ -57,3 +57,35 @@ def run_programs(words, task_off, gates, rhos, effects, eff_ptr, eff_label, eff_
                 raise AssertionError("bad opcode %d" % op)
         assert pc == task_off[t + 1]
     return out, written, stats
+
+
+OP_CACHE = 7
+
+
+def run_dirty_program(words, gates, rhos, effects, eff_ptr, eff_label, eff_dest, cache, out):
+    """One "dirty program" (gst_get_dirty_programs): the part of a task's walk that a perturbation of one object changes.
+    `gates` / `rhos` are the PERTURBED model's arrays, `cache` the base pass's states by id (OP_CACHE starts from one of
+    them); probabilities of the emitted circuits go into `out`.  Returns the list of emitted circuits."""
+    v, slots, emitted = None, {}, []
+    for w in words:
+        w = int(w)
+        op, arg = w >> 28, w & 0x0FFFFFFF
+        if op == OP_END:
+            break
+        if op == OP_RHO:
+            v = rhos[arg].copy()
+        elif op == OP_CACHE:
+            v = cache[arg].copy()
+        elif op == OP_APPLY:
+            v = matvec(gates[arg], v)
+        elif op == OP_SAVE:
+            slots[arg] = v.copy()
+        elif op == OP_LOAD:
+            v = slots[arg].copy()
+        elif op == OP_EMIT:
+            emitted.append(arg)
+            for x in range(eff_ptr[arg], eff_ptr[arg + 1]):
+                out[eff_dest[x]] = dot(effects[eff_label[x]], v)
+        else:
+            raise AssertionError("opcode %d does not belong in a dirty program" % op)
+    return emitted

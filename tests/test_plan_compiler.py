@@ -126,3 +126,45 @@ def test_fd_queue_packing_and_handovers():
     assert l1.max() <= l0.max() and (l1.max() - l1.min()) <= (l0.max() - l0.min())
     assert h2 >= h1 >= 0
     assert l1.sum() >= l0.sum()                       # every hand-over adds its bookkeeping cost to the estimate
+
+
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq1Q_multispam_L2", "smq2Q_XYICNOT_L2_depol"])
+def test_dirty_programs_reproduce_the_perturbed_walk(name):
+    """gst_get_dirty_programs (finite differences over whole-object perturbations, gst_set_lindblad): for every task and
+    object class the compiled fragment -- entered from the base pass's cached state at the object's first application, or
+    from the perturbed preparation -- must give, for the circuits it emits, BIT FOR BIT the probabilities of the full walk
+    with the perturbed object, and every circuit it does not emit must be untouched by the perturbation.  Numpy
+    interpreter on the CPU; the device kernel that runs these programs is tests/test_gpu_lindblad.py's subject."""
+    from _interp import run_programs, run_dirty_program
+    fx = load_fixture(name)
+    pl = make(fx)
+    words, off = pl.program()
+    dwords, doff, nC = pl.dirty_programs()
+    G, R, E = fx["gates"], fx["rhos"], fx["effects"]
+    nG, nR = len(G), len(R)
+    assert nC == nG + nR and len(doff) == (len(off) - 1) * nC + 1
+    nE = int(fx["nE"])
+    base, _, st = run_programs(words, off, G, R, E, fx["eff_ptr"], fx["eff_label"], fx["eff_dest"], nE)
+    cache = st["node_states"]
+    rng = np.random.default_rng(3)
+    n_tasks = len(off) - 1
+    checked_gate = checked_rho = 0
+    for cls in range(nC):
+        Gp, Rp = G.copy(), R.copy()
+        if cls < nG:
+            Gp[cls] = G[cls] + 1e-3 * rng.standard_normal(G[cls].shape)          # the WHOLE object moves
+        else:
+            Rp[cls - nG] = R[cls - nG] + 1e-3 * rng.standard_normal(R[cls - nG].shape)
+        full, _, _ = run_programs(words, off, Gp, Rp, E, fx["eff_ptr"], fx["eff_label"], fx["eff_dest"], nE)
+        got = base.copy()
+        for t in range(n_tasks):
+            a, b = int(doff[t * nC + cls]), int(doff[t * nC + cls + 1])
+            if b == a:
+                continue
+            emitted = run_dirty_program(dwords[a:b], Gp, Rp, E, fx["eff_ptr"], fx["eff_label"], fx["eff_dest"], cache, got)
+            assert len(emitted) > 0 and len(set(emitted)) == len(emitted)
+            if cls < nG: checked_gate += 1
+            else: checked_rho += 1
+        assert np.array_equal(got.view(np.uint64), full.view(np.uint64)), "class %d" % cls
+        assert (full != base).any()
+    assert checked_gate > 0 and checked_rho > 0
