@@ -399,3 +399,55 @@ def test_sort_circuits_and_first_use_match_python():
         _lib.circuit_first_use(ptr, syms, 2)                    # a symbol out of range
     o0, l0 = _lib.sort_circuits(np.zeros(1, np.int64), np.zeros(0, np.int32), None)
     assert len(o0) == 0 and len(l0) == 0
+
+
+@pytest.mark.parametrize("grid,n_atoms", [((1, 2), 2), ((2, 2), 4), ((1, 3), 1), ((2, 1, 2), 3)])
+def test_column_exchange_blocks_assemble_whole_rows(grid, n_atoms):
+    """The block list of the device-side normal equations under a processor grid (layout.column_exchange_blocks →
+    gst_comm_exchange_blocks), executed here in numpy: every rank holds its atoms' rows x its own column slice, packed
+    row-major; after the exchange and the block-column → row-major copy each rank of an atom-processor must hold ITS row
+    share of the atom with ALL columns, and the shares must tile the atom."""
+    from pygsti_amd import modelpacks as MP
+    from pygsti_amd.layout import HipCOPALayout, _slice_up_range
+    pack = MP.smq1Q_XYI
+    model = pack.target_model().depolarize(0.01, 0.01)
+    circ = pack.create_gst_circuits(2)
+    size = int(np.prod(grid))
+    lays = [HipCOPALayout(circ, model, num_atoms=n_atoms, rank=r, size=size, processor_grid=grid) for r in range(size)]
+    L = lays[0]
+    na, np1, np2 = L.processor_grid
+    nP, G = model.num_params, np1 * np2
+    full = np.arange(L.global_num_elements)[:, None] * 1000.0 + np.arange(nP)[None, :]
+    n_rounds = max(len(L.atoms_of_processor(g)) for g in range(na))
+    for k in range(n_rounds):
+        blocks = L.column_exchange_blocks(k)
+        # what every rank holds before: its k-th atom's rows x its column slice, packed (None: no k-th atom)
+        src, dst, atom_of = {}, {}, {}
+        for r, l in enumerate(lays):
+            mine = l.atoms_of_processor(l.atom_proc_index)
+            if k >= len(mine):
+                continue
+            at = mine[k]; atom_of[r] = at
+            src[r] = np.ascontiguousarray(full[at.element_slice, l.global_param_slice]).ravel()
+            share = _slice_up_range(at.num_elements, G)[l.param_proc_index * np2 + l.param2_proc_index]
+            dst[r] = np.full((share.stop - share.start) * nP, np.nan)
+        for s_rank, d_rank, s_off, d_off, cnt in blocks:              # gst_comm_exchange_blocks' semantics
+            assert s_rank in src and d_rank in dst
+            dst[d_rank][d_off:d_off + cnt] = src[s_rank][s_off:s_off + cnt]
+        covered = {}
+        for r, l in enumerate(lays):
+            if r not in dst:
+                continue
+            at = atom_of[r]
+            share = _slice_up_range(at.num_elements, G)[l.param_proc_index * np2 + l.param2_proc_index]
+            n_my = share.stop - share.start
+            T = np.empty((n_my, nP))
+            for cs in l.param_slices:                                    # gst_copy_block_dev: block-column staging -> row-major
+                c = cs.stop - cs.start
+                T[:, cs] = dst[r][n_my * cs.start:n_my * cs.start + n_my * c].reshape(n_my, c)
+            rows = slice(at.element_slice.start + share.start, at.element_slice.start + share.stop)
+            assert np.array_equal(T, full[rows]), (grid, k, r)
+            covered.setdefault(at.element_slice.start, []).append((rows.start, rows.stop))
+        for a0, spans in covered.items():
+            spans.sort()
+            assert spans[0][0] == a0 and all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
