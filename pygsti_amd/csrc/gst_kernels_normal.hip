@@ -415,59 +415,68 @@ hipError_t launch_hessian_block(const double* H, const double* d1, const double*
     return hipGetLastError();
 }
 
-// Chain rule of general parameterisations (gst_set_derivs): C[:, colmap[j]] += A[:, a_col0 : a_col0 + K] . B[:, j]
-// with A the element Jacobian (row-major, ldA), B = d(element)/d(parameter) of one object (row-major [K][n]).  One
-// wavefront = 16 rows x 64 columns, v_mfma_f64_16x16x4_f64; operands straight from memory in the MFMA layouts.
+// Chain rule of general parameterisations (gst_set_derivs): C[:, colmap[j]] (+)= A[:, a_col0 : a_col0 + K] . B[:, j]
+// with A the element Jacobian (row-major, ldA), B = d(element)/d(parameter) of one object (row-major [K][n]).
+// Workgroup = 64 rows x 64 columns (wavefront w: rows 16 w ... 16 w + 15, 4 column tiles of v_mfma_f64_16x16x4_f64); A and B
+// go through LDS in chunks of 32 k, loaded with coalesced rows and read back in the MFMA operand layouts from padded,
+// conflict-free arrays.  (Round 3.  The first form took every operand straight from memory: 5 loads of 8 bytes per lane and
+// k-step, the A one touching 16 cache lines -- timing ablations: 13.3 of the kernel's 16 ms were the operand loads, the
+// matrix pipes 28 % busy.  Through LDS a workgroup moves 32 KB per chunk instead of 80.)
+// Rows / columns beyond the matrix are CLAMPED to valid ones (their products are never stored); k beyond K reads zeros.
+constexpr int CR_BK = 32;              // k per chunk
+constexpr int CR_AS = CR_BK + 2;       // row stride of the A chunk in LDS: 16 rows x {kk, kk + 1} hit 64 distinct banks
+constexpr int CR_BS = 64 + 16;         // row stride of the B chunk: consecutive k rows start 32 banks apart
 __global__ __launch_bounds__(256) void chain_rule_gemm_kernel(const double* __restrict__ A, int64_t ldA, int64_t a_col0, int K,
                                                               const double* __restrict__ B, int n,
                                                               const int32_t* __restrict__ colmap, double* __restrict__ C,
                                                               int64_t ldC, int64_t n_rows, const int overwrite)
 {
-    const int lane = threadIdx.x & 63;
-    // the four wavefronts of a workgroup take four consecutive 16-row tiles of the SAME 64-column tile: they stream the same
-    // K x 64 slice of B (131 KB at K = 256) through the CU's L1 together.  (Until round 3 they took the four column tiles
-    // of one row tile, so every 16 rows re-read all of B from L2: 16.7 GB per gate of the 2Q CPTPLND model.)
+    __shared__ double As[64 * CR_AS];
+    __shared__ double Bs[CR_BK * CR_BS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tiles_n = (n + 63) / 64;
-    const int64_t r0 = (((int64_t)blockIdx.x / tiles_n) * 4 + (threadIdx.x >> 6)) * 16;
+    const int64_t R0 = ((int64_t)blockIdx.x / tiles_n) * 64;
     const int c0 = (int)((int64_t)blockIdx.x % tiles_n) * 64;
-    if (r0 >= n_rows) return;
     const int i = lane & 15, kk = lane >> 4;
     d4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    // Rows / columns beyond the matrix are CLAMPED to valid ones instead of predicated (their products are never stored), and
-    // B is addressed by a 32-bit element offset behind its uniform base: the loop is 5 loads, 4 address adds and 4 MFMAs per
-    // k-step.  (With a select on every operand and 64-bit index arithmetic per load the kernel issued ~10 vector
-    // instructions per MFMA and kept the matrix pipes 28 % busy.)
-    const int64_t arow_i = (r0 + i < n_rows) ? r0 + i : n_rows - 1;
-    const double* ap = A + arow_i * ldA + a_col0 + kk;
-    uint32_t bo[4];
+    // loaders: A chunk 64 rows x 32 k -- thread (row tid >> 5 (+ 8 e), k tid & 31); B chunk 32 k x 64 columns -- thread
+    // (k tid >> 6 (+ 4 e), column tid & 63): every load instruction reads whole 256- / 512-byte row pieces
+    const int a_r = tid >> 5, a_k = tid & 31;
+    const int b_k = tid >> 6, b_c = tid & 63;
+    const int b_col = (c0 + b_c < n) ? c0 + b_c : n - 1;
+    const double* a_src[8];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int col = c0 + 16 * t + i;
-        bo[t] = (uint32_t)(kk * n + (col < n ? col : n - 1));
+    for (int e = 0; e < 8; e++) {
+        const int64_t row = R0 + a_r + 8 * e;
+        a_src[e] = A + (row < n_rows ? row : n_rows - 1) * ldA + a_col0 + a_k;
     }
-    const int K4 = K & ~3;
-    const uint32_t step = 4u * (uint32_t)n;
-#pragma unroll 8
-    for (int k0 = 0; k0 < K4; k0 += 4) {
-        const double a = ap[k0];
+    for (int k0 = 0; k0 < K; k0 += CR_BK) {
+        double av[8], bv[8];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const double b = B[bo[t]];
-            bo[t] += step;
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        for (int e = 0; e < 8; e++) av[e] = (k0 + a_k < K) ? a_src[e][k0] : 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int k = k0 + b_k + 4 * e;
+            bv[e] = (k < K) ? B[(int64_t)k * n + b_col] : 0.0;
+        }
+        __syncthreads();                         // (the previous chunk has been consumed)
+#pragma unroll
+        for (int e = 0; e < 8; e++) As[(a_r + 8 * e) * CR_AS + a_k] = av[e];
+#pragma unroll
+        for (int e = 0; e < 8; e++) Bs[(b_k + 4 * e) * CR_BS + b_c] = bv[e];
+        __syncthreads();
+        const double* as = As + (16 * wv + i) * CR_AS + kk;
+        const double* bs = Bs + kk * CR_BS + i;
+#pragma unroll
+        for (int s = 0; s < CR_BK / 4; s++) {
+            const double a = as[4 * s];
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bs[4 * s * CR_BS + 16 * t], acc[t], 0, 0, 0);
         }
     }
-    if (K4 < K) {                                  // the last, partial k-step: operands beyond K are zeros
-        const bool k_ok = K4 + kk < K;
-        const double a = k_ok ? ap[K4] : 0.0;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const double b = k_ok ? B[bo[t]] : 0.0;
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-        }
-    }
+    const int64_t r0 = R0 + 16 * wv;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int col = c0 + 16 * t + i;
