@@ -452,8 +452,8 @@ __global__ __launch_bounds__(256) void chain_rule_gemm_kernel(const double* __re
         const int64_t row = R0 + a_r + 8 * e;
         a_src[e] = A + (row < n_rows ? row : n_rows - 1) * ldA + a_col0 + a_k;
     }
-    for (int k0 = 0; k0 < K; k0 += CR_BK) {
-        double av[8], bv[8];
+    double av[8], bv[8];
+    auto fetch = [&](const int k0) {             // the chunk's 16 global loads per thread, into registers
 #pragma unroll
         for (int e = 0; e < 8; e++) av[e] = (k0 + a_k < K) ? a_src[e][k0] : 0.0;
 #pragma unroll
@@ -461,12 +461,16 @@ __global__ __launch_bounds__(256) void chain_rule_gemm_kernel(const double* __re
             const int k = k0 + b_k + 4 * e;
             bv[e] = (k < K) ? B[(int64_t)k * n + b_col] : 0.0;
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += CR_BK) {
         __syncthreads();                         // (the previous chunk has been consumed)
 #pragma unroll
         for (int e = 0; e < 8; e++) As[(a_r + 8 * e) * CR_AS + a_k] = av[e];
 #pragma unroll
         for (int e = 0; e < 8; e++) Bs[(b_k + 4 * e) * CR_BS + b_c] = bv[e];
         __syncthreads();
+        if (k0 + CR_BK < K) fetch(k0 + CR_BK);   // the next chunk is in flight while this one is multiplied
         const double* as = As + (16 * wv + i) * CR_AS + kk;
         const double* bs = Bs + kk * CR_BS + i;
 #pragma unroll
