@@ -2906,7 +2906,9 @@ int gst_set_lindblad(gst_plan* p, int32_t n_params, int32_t n_members, const gst
     return guarded([&]() -> int {
     if (!p) return fail(GST_EINVAL, "plan is NULL");
     gst_plan::Lindblad& L = p->lb;
-    if (n_members == 0) { L = gst_plan::Lindblad(); return GST_OK; }
+    // (the request tables of the last fill -- wave tables, set_param order, POVM columns, dirty items -- are derived from
+    //  the members' kinds, objects and parameter ranges: a new description, or none, invalidates them)
+    if (n_members == 0) { L = gst_plan::Lindblad(); p->cached_kind = 0; return GST_OK; }
     const int D = p->hp.D;
     if (D != 4 && D != 16) return fail(GST_EUNSUPPORTED, "Lindblad members are built on the device for D = 4 and 16");
     if (n_members < 0 || n_params < 0 || !members || n_terms <= 0 || !term_re || !term_im) return fail(GST_EINVAL, "bad argument");
@@ -2937,6 +2939,8 @@ int gst_set_lindblad(gst_plan* p, int32_t n_params, int32_t n_members, const gst
             n_static = (size_t)D;
         } else if (M.kind == GST_KIND_EFFECT) {
             if (M.n_eff < 1 || M.obj < 0 || M.obj + M.n_eff > p->hp.n_effects) return fail(GST_EINVAL, who + "bad effect range");
+            // (a perturbed member occupies one D*D slot of the per-column member sets: n_eff * D doubles must fit)
+            if (M.n_eff > D) return fail(GST_EUNSUPPORTED, who + "a POVM member with more than D effects (over-complete POVM) is not built on the device");
             for (int e = M.obj; e < M.obj + M.n_eff; e++) if (eff_seen[(size_t)e]++) return fail(GST_EINVAL, who + "effect listed twice");
             n_static = (size_t)M.n_eff * D;
         } else return fail(GST_EINVAL, who + "unknown kind");
@@ -2944,6 +2948,18 @@ int gst_set_lindblad(gst_plan* p, int32_t n_params, int32_t n_members, const gst
         N.n_par.push_back((int32_t)np); N.n_blocks.push_back(M.n_blocks);
         N.param0.push_back(M.param0); N.term_off.push_back(M.term_offset); N.static_off.push_back((int64_t)N.statics.size());
         N.statics.insert(N.statics.end(), M.static_part, M.static_part + n_static);
+    }
+    // a parameter belongs to exactly ONE member: the build / derivative kernels and the column tables step the member whose
+    // range holds the column's parameter, so members that share an error generator (same gpindices for two gates) would
+    // have only one of them stepped, where the reference's set_parameter_value moves both -- refuse, the caller then
+    // takes the host-stepped dense-model route (gst_fill_dprobs_models)
+    {
+        std::vector<std::pair<int64_t, int64_t>> rng;
+        for (int32_t m = 0; m < n_members; m++) if (N.n_par[(size_t)m] > 0) rng.emplace_back(N.param0[(size_t)m], N.param0[(size_t)m] + N.n_par[(size_t)m]);
+        std::sort(rng.begin(), rng.end());
+        for (size_t k = 1; k < rng.size(); k++)
+            if (rng[k].first < rng[k - 1].second)
+                return fail(GST_EUNSUPPORTED, "two Lindblad members share parameters (overlapping parameter ranges): not built on the device");
     }
     // every object of the plan must belong to a member: the device builds the WHOLE model
     for (uint8_t v : gate_seen) if (!v) return fail(GST_EINVAL, "a gate of the plan belongs to no Lindblad member");
@@ -2960,6 +2976,7 @@ int gst_set_lindblad(gst_plan* p, int32_t n_params, int32_t n_members, const gst
     N.term_im.assign(term_im, term_im + (size_t)n_terms * D * D);
     N.set = true;
     L = std::move(N);
+    p->cached_kind = 0;
     return GST_OK;
     });
 }

@@ -336,7 +336,16 @@ class HipMapForwardSimulator:
             jtf[...] = 0.0
         mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
         if layout.processor_grid[1] * layout.processor_grid[2] > 1:
-            return self._bulk_fill_jtj_jtf_grid(jtj, jtf, layout, row_scale, f, pr_array_to_fill, mode)
+            if getattr(layout, "device_comm", None) is not None:
+                return self._bulk_fill_jtj_jtf_grid(jtj, jtf, layout, row_scale, f, pr_array_to_fill, mode)
+            # no device communicator attached (dist.init(...).comm -> layout.device_comm): the ranks of an atom-processor
+            # hold the SAME atoms, so exactly one of them -- parameter-processor (0, 0) -- contributes the full-width
+            # products and the others contribute zeros; the caller's all-reduce over ranks is then right
+            if not self._first_param_proc(layout):
+                if pr_array_to_fill is not None:
+                    for atom in layout.atoms:
+                        self._bulk_fill_probs_atom(pr_array_to_fill[atom.element_slice], atom)
+                return
         pidx = np.arange(nP, dtype=np.int64)
         for atom in layout.atoms:
             plan = self._prepare_atom(atom)
@@ -361,6 +370,13 @@ class HipMapForwardSimulator:
                 for d in (d_J, d_pr, d_jtj, d_jtf, d_w, d_f):
                     if d is not None:
                         plan.device_free(d)
+
+    @staticmethod
+    def _first_param_proc(layout):
+        """True on the one rank of each atom-processor that contributes whole-atom reductions (sums over elements of
+        full-width quantities): under a processor grid with parameter-processors every rank of an atom-processor holds the
+        same atoms, and a sum over ranks must count each atom once."""
+        return getattr(layout, "param_proc_index", 0) == 0 and getattr(layout, "param2_proc_index", 0) == 0
 
     def _bulk_fill_jtj_jtf_grid(self, jtj, jtf, layout, row_scale, f, pr_array_to_fill, mode):
         """bulk_fill_jtj_jtf under a processor grid with parameter-processors: a rank fills only ITS column slice of its
@@ -435,10 +451,14 @@ class HipMapForwardSimulator:
         TimeIndependentMDCObjectiveFunction, pygsti/objectivefns/objectivefns.py:4573-4665, for `objective` = 'chi2'
         or 'logl'), then J_s^T J_s and J_s^T lsvec (optimize/simplerlm.py:677-678).  `counts` / `total_counts` are
         per-element host arrays in layout order.  Returns the objective value sum(terms) of this process's atoms;
-        jtj (nP, nP) and jtf (nP,) are summed over them (ranks all-reduce, as layout.fill_jtj does)."""
+        jtj (nP, nP) and jtf (nP,) are summed over them (ranks all-reduce, as layout.fill_jtj does).  Under a processor
+        grid with parameter-processors the ranks of an atom-processor hold the same atoms: parameter-processor (0, 0)
+        contributes them, its peers contribute zeros (and fill only `pr_array_to_fill` / `lsvec_to_fill` rows), so the
+        all-reduce counts every atom once."""
         nP = self.model.num_params
         jtj[...] = 0.0
         jtf[...] = 0.0
+        contributes = self._first_param_proc(layout)
         mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
         pidx = np.arange(nP, dtype=np.int64)
         counts = np.asarray(counts, np.float64)
@@ -453,6 +473,14 @@ class HipMapForwardSimulator:
             bufs = [plan.workspace("lsq%d" % k, nb) for k, nb in enumerate(sizes)]
             d_J, d_pr, d_c, d_N, d_ls, d_w, d_jtj, d_jtf = bufs
             plan.memcpy_h2d(d_c, counts[es]); plan.memcpy_h2d(d_N, total_counts[es])
+            if not contributes:                 # (kept for the rows the caller asked for; no share in the sums)
+                plan.fill_probs_dev(d_pr)
+                plan.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius, prob_clip_interval)
+                if lsvec_to_fill is not None:
+                    plan.memcpy_d2h(lsvec_to_fill[es], d_ls)
+                if pr_array_to_fill is not None:
+                    plan.memcpy_d2h(pr_array_to_fill[es], d_pr)
+                continue
             plan.fill_dprobs_dev(d_J, nP, pidx, None, self.derivative_eps, d_pr, mode)
             total += plan.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius,
                                              prob_clip_interval)
@@ -474,9 +502,12 @@ class HipMapForwardSimulator:
         (gst_objective_hessian_block); only the block's row_block x num_params numbers come back.  `hessian` is summed
         over this process's atoms (ranks all-reduce it, as `_gather_hessian` does).  Map-path semantics: both
         derivative levels are finite differences with `hessian_eps` -- or, with derivative_mode="analytic", exact
-        derivatives at both levels (Matrix-path semantics)."""
+        derivatives at both levels (Matrix-path semantics).  Under a processor grid with parameter-processors only
+        parameter-processor (0, 0) of each atom-processor contributes (its peers hold the same atoms)."""
         nP = self.model.num_params
         hessian[...] = 0.0
+        if not self._first_param_proc(layout):
+            return hessian
         counts = np.asarray(counts, np.float64)
         total_counts = np.asarray(total_counts, np.float64)
         cols = np.arange(nP, dtype=np.int64)

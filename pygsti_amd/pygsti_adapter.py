@@ -230,6 +230,13 @@ def atom_lindblad(model, atom):
         raise NotImplementedError("the POVM is not a ComposedPOVM")
     base = np.array([static_dense(povm.base_povm[str(l).split("_", 1)[1]], (D,)) for l in eff_labels])
     members.append(member_of(LBM.KIND_POVM, 0, povm, base, povm.error_map))
+    if len(eff_labels) > D:
+        raise NotImplementedError("a POVM with more than dim effects")
+    # members that share an error generator (same gpindices for two gates) are stepped TOGETHER by the reference's
+    # set_parameter_value; the device tables give a parameter to exactly one member
+    spans = sorted((m.param0, m.param0 + m.n_params) for m in members if m.n_params > 0)
+    if any(b[0] < a[1] for a, b in zip(spans, spans[1:])):
+        raise NotImplementedError("two members share parameters")
     return LBM.LindbladModel(members, model.num_params, len(atom.op_labels), len(atom.rho_labels), len(eff_labels))
 
 
@@ -351,6 +358,12 @@ class AtomFillLogic:
 
     def _prepare(self, layout_atom, derivatives=False, hessian=False):
         plan = atom_plan(self.model, layout_atom, self._hip_device)
+        # an atom already resolved to the device-built Lindblad route keeps it for this model: the host to_dense() of
+        # every member (what set_model would upload, only to be overwritten by set_lindblad_params) is skipped
+        if (getattr(plan, "_hip_mode", None) == "lindblad" and getattr(layout_atom, "_hip_lb_model", None) is self.model
+                and layout_atom._hip_lb is not None and self.lindblad_on_device and not hessian):
+            plan.set_lindblad_params(self.model.to_vector())
+            return plan
         plan.set_model(*atom_arrays(self.model, layout_atom))
         if not derivatives:
             return plan
@@ -362,6 +375,7 @@ class AtomFillLogic:
             layout_atom._hip_pmap_model = self.model
         if layout_atom._hip_pmap is not None:
             if plan.n_params != self.model.num_params or getattr(plan, "_hip_mode", None) != "elements":
+                self._leave_lindblad(plan, layout_atom)
                 plan.set_derivs(self.model.num_params, [])
                 plan.set_complement_effect(-1)
                 plan.set_param_map(*layout_atom._hip_pmap)
@@ -393,12 +407,12 @@ class AtomFillLogic:
                         plan._hip_mode = "lindblad"
                     plan.set_lindblad_params(self.model.to_vector())      # (replaces the host-densified set_model above)
                     return plan
-                if getattr(plan, "_hip_mode", None) == "lindblad":
-                    plan.set_lindblad(None)
+                self._leave_lindblad(plan, layout_atom)
                 plan._hip_mode = "models"
                 return plan
             k, o, e, comp = layout_atom._hip_tpmap
             if plan.n_params != self.model.num_params or getattr(plan, "_hip_mode", None) != "tp-elements":
+                self._leave_lindblad(plan, layout_atom)
                 plan.set_derivs(self.model.num_params, [])
                 plan.set_param_map(k, o, e)
                 if comp is not None:
@@ -423,12 +437,19 @@ class AtomFillLogic:
                         plan._hip_mode = "lindblad"
                     plan.set_lindblad_params(self.model.to_vector())
                     return plan
-            if getattr(plan, "_hip_mode", None) == "lindblad":
-                plan.set_lindblad(None)
-                plan.set_model(*atom_arrays(self.model, layout_atom))
+            self._leave_lindblad(plan, layout_atom)
             plan.set_derivs(self.model.num_params, atom_derivs(self.model, layout_atom))
             plan._hip_mode = "derivs"
         return plan
+
+    def _leave_lindblad(self, plan, layout_atom):
+        """A plan that was in the device-built Lindblad mode and now serves another mode: drop the description (later
+        GST_DERIV_FD fills would still take the Lindblad route, with a stale theta) and re-install the host's dense model
+        (set_lindblad_params had replaced it)."""
+        if getattr(plan, "_hip_mode", None) == "lindblad":
+            plan.set_lindblad(None)
+            plan.set_model(*atom_arrays(self.model, layout_atom))
+            plan._hip_mode = None
 
     def _bulk_fill_probs_atom(self, array_to_fill, layout_atom, resource_alloc):
         plan = self._prepare(layout_atom)

@@ -50,7 +50,23 @@ def main():
     sim.bulk_fill_jtj_jtf(jtj_d, jtf_d, lay, row_scale=w, f=f, pr_array_to_fill=P_d)
     gdist.allreduce_sum_host(jtj_d, expect_size=size); gdist.allreduce_sum_host(jtf_d, expect_size=size)
     P_d_all = lay.allgather_local_array("e", P_d)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), jtj_d=jtj_d, jtf_d=jtf_d, P_d_all=P_d_all, J_all=J_all, J_root=J_root if rank == 0 else np.zeros(0), P_all=P_all,
+    # ... and without a device communicator attached: one rank per atom-processor contributes, the sums stay right
+    lay.device_comm = None
+    jtj_n = np.empty((nP, nP)); jtf_n = np.empty(nP)
+    sim.bulk_fill_jtj_jtf(jtj_n, jtf_n, lay, row_scale=w, f=f)
+    gdist.allreduce_sum_host(jtj_n, expect_size=size); gdist.allreduce_sum_host(jtf_n, expect_size=size)
+    # one Levenberg-Marquardt step's data reduction and the objective Hessian under the grid (every atom counted once)
+    counts = np.round(1000.0 * (0.5 + 0.4 * np.sin(np.arange(nE) * 0.77)))
+    Ntot = np.full(nE, 1000.0)
+    jtj_l = np.empty((nP, nP)); jtf_l = np.empty(nP); ls = np.full(nE, np.nan)
+    obj = np.array([sim.bulk_fill_lsq_step(jtj_l, jtf_l, lay, counts, Ntot, objective="chi2", lsvec_to_fill=ls)])
+    gdist.allreduce_sum_host(jtj_l, expect_size=size); gdist.allreduce_sum_host(jtf_l, expect_size=size)
+    gdist.allreduce_sum_host(obj, expect_size=size)
+    ls_all = lay.allgather_local_array("e", ls)
+    hess = np.empty((nP, nP))
+    sim.bulk_fill_objective_hessian(hess, lay, counts, Ntot, objective="chi2", row_block=30)
+    gdist.allreduce_sum_host(hess, expect_size=size)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), jtj_n=jtj_n, jtf_n=jtf_n, jtj_l=jtj_l, jtf_l=jtf_l, obj=obj, ls_all=ls_all, hess=hess, jtj_d=jtj_d, jtf_d=jtf_d, P_d_all=P_d_all, J_all=J_all, J_root=J_root if rank == 0 else np.zeros(0), P_all=P_all,
              jtj=jtj, jtf=jtf, H_all=H_all, n_filled=int(filled.sum()), h_filled=int((~np.isnan(H)).sum()),
              gps=np.array([lay.global_param_slice.start, lay.global_param_slice.stop, lay.global_param2_slice.start, lay.global_param2_slice.stop]),
              owned=np.array([a.element_slice.start for a in lay.atoms]), root_none=(J_root is None))

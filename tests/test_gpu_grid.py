@@ -54,7 +54,11 @@ def single():
         nE, nP = lay.global_num_elements, model.num_params
         J = np.empty((nE, nP)); P = np.empty(nE); H = np.empty((nE, nP, nP))
         sim.bulk_fill_dprobs(J, lay, P); sim.bulk_fill_hprobs(H, lay)
-        out[n_atoms] = (J, P, H)
+        counts = np.round(1000.0 * (0.5 + 0.4 * np.sin(np.arange(nE) * 0.77)))
+        jtj_l = np.empty((nP, nP)); jtf_l = np.empty(nP); ls = np.empty(nE); hess = np.empty((nP, nP))
+        obj = sim.bulk_fill_lsq_step(jtj_l, jtf_l, lay, counts, np.full(nE, 1000.0), objective="chi2", lsvec_to_fill=ls)
+        sim.bulk_fill_objective_hessian(hess, lay, counts, np.full(nE, 1000.0), objective="chi2", row_block=30)
+        out[n_atoms] = (J, P, H, (jtj_l, jtf_l, obj, ls, hess))
     # the element order depends on the atoms; the values, circuit by circuit, are the fixture's
     idx = np.concatenate([np.arange(*lay.indices_for_index(i).indices(nE)) for i in range(lay.num_circuits)])
     assert_bitwise(out[4][0][idx], fx["dprobs_map"], "single-process Jacobian vs the reference")
@@ -64,7 +68,7 @@ def single():
 @pytest.mark.parametrize("n_atoms,grid", [(1, (1, 2)), (2, (2, 2)), (4, (2, 1, 2)), (1, (1, 2, 2)), (2, (1, 3))])
 def test_processor_grid_assembles_the_single_process_results(tmp_path, single, n_atoms, grid):
     res = _run(tmp_path, n_atoms, grid)
-    J, P, H = single[n_atoms]
+    J, P, H, (jtj_l, jtf_l, obj_l, ls_l, hess_l) = single[n_atoms]
     nE, nP = J.shape
     na, np1, np2 = (tuple(grid) + (1, 1))[:3]
     f = np.sin(np.arange(nE) * 0.37) + 0.1
@@ -83,6 +87,15 @@ def test_processor_grid_assembles_the_single_process_results(tmp_path, single, n
         assert np.abs(d["jtj_d"] - jtj_w).max() <= 1e-12 * np.abs(jtj_w).max()
         assert np.abs(d["jtf_d"] - jtf_w).max() <= 1e-12 * np.abs(jtf_w).max()
         assert_bitwise(d["P_d_all"], P, "probabilities of the device-resident route on rank %d" % r)
+        # no device communicator attached: parameter-processor (0, 0) alone contributes; and the fused LM step /
+        # objective Hessian count every atom once whatever the grid (they over-counted by np1*np2 before round 4)
+        assert np.abs(d["jtj_n"] - jtj_w).max() <= 1e-12 * np.abs(jtj_w).max()
+        assert np.abs(d["jtf_n"] - jtf_w).max() <= 1e-12 * np.abs(jtf_w).max()
+        assert np.abs(d["jtj_l"] - jtj_l).max() <= 1e-12 * np.abs(jtj_l).max()
+        assert np.abs(d["jtf_l"] - jtf_l).max() <= 1e-12 * np.abs(jtf_l).max()
+        assert abs(float(d["obj"][0]) - obj_l) <= 1e-12 * abs(obj_l)
+        assert_bitwise(d["ls_all"], ls_l, "lsvec rows under the grid on rank %d" % r)
+        assert np.abs(d["hess"] - hess_l).max() <= 1e-11 * np.abs(hess_l).max()
         # the rank really computed only its block: rows of its atom-processor x its column slice(s)
         g = d["gps"]
         q = r % (np1 * np2)
