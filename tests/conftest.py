@@ -50,3 +50,17 @@ def plan_from_fixture(fx, **kw):
     pl.set_model(fx['gates'], fx['rhos'], fx['effects'])
     pl.set_param_map(fx['pkind'], fx['pobj'], fx['pelem'])
     return pl
+
+
+def matrix_rows_by_circuit(fx):
+    """Round-4 fixtures store the Matrix simulator's vectors ordered [circuit][outcome name sorted]
+    (`matrix_by_circuit_*`, `matrix_outcome_names`): index array that brings them into the Map layout's element order."""
+    names = [str(n) for n in fx["outcome_names"]]
+    mn = [str(n) for n in fx["matrix_outcome_names"]]
+    return np.array([int(fx["el_circuit"][k]) * len(mn) + mn.index(names[int(fx["el_outcome"][k])])
+                     for k in range(int(fx["nE"]))], np.int64)
+
+
+def element_depth(fx):
+    """Gate count of the circuit every element belongs to."""
+    return np.diff(fx["circ_ptr"])[fx["el_circuit"]]

@@ -12,7 +12,7 @@ DESIGN_FIXTURES = ["smq1Q_XYI_L4_depol", "smq1Q_XYI_L4_kick", "smq1Q_XYI_L128_de
                    "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep"]
 # + two preparations, two POVMs (2 and 3 effects), explicit SPAM labels in the circuits, an empty gate string
 # + the 3-qubit explicit model (D = 64, 10 gates, 41,536 parameters; BASELINE configs[4]): 207 seeded random circuits
-FIXTURES = DESIGN_FIXTURES + ["smq1Q_multispam_L2", "3q_explicit_L64"]
+FIXTURES = DESIGN_FIXTURES + ["smq1Q_multispam_L2", "3q_explicit_L64", "3q_explicit_matrix"]
 HAVE_REF = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgst_ref.so")) or \
     os.path.isdir("/root/reference/pygsti/evotypes/densitymx")
 KINDS = ["port"] + (["reference"] if HAVE_REF else [])
@@ -126,3 +126,55 @@ def test_two_level_model_sets_reproduce_the_map_fd_of_fd_hessian(oracle_built):
     cols = [list(fx["hprobs_cols"]).index(c) for c in fx["mm2_cols"]]
     ref = fx["hprobs_map"][:, rows][:, :, cols]
     assert np.abs(H - ref).max() <= 2e-5, np.abs(H - ref).max()       # observed 6.7e-6 (max|H| = 2.0)
+
+
+def test_numpy_analytic_oracle_vs_matrix_simulator_at_d64():
+    """The direct analytic reference at D = 64 (round 4): two 16-column Jacobian blocks and two Hessian blocks taken
+    straight from MatrixForwardSimulator's per-atom seams on the 3-qubit model (tests/golden/make_golden_r4.py,
+    matrixforwardsim.py:1047-1287) pin the numpy forward/backward restatement there as well (it was pinned at D = 4 and
+    16 only, and the device's D = 64 analytic kernels were compared with it alone)."""
+    from conftest import matrix_rows_by_circuit
+    from oracle import oracle as O
+    fx = load_fixture("3q_explicit_matrix")
+    rows = matrix_rows_by_circuit(fx)
+    J, P = O.analytic_dprobs(fx, fx["matrix_cols"])
+    assert np.abs(P - fx["matrix_by_circuit_probs"][rows]).max() < 1e-13
+    assert np.abs(J - fx["matrix_by_circuit_dprobs"][rows]).max() < 1e-11
+    assert np.abs(fx["matrix_by_circuit_dprobs"]).max() > 0.1
+    for b in (0, 1):
+        H = O.analytic_hprobs(fx, fx["mh%d_idx1" % b], fx["mh%d_idx2" % b])
+        ref = fx["mh%d_by_circuit_hprobs" % b][rows]
+        assert np.abs(H - ref).max() < 1e-11, (b, np.abs(H - ref).max())
+        assert np.abs(ref).max() > 1e-3
+
+
+@pytest.mark.parametrize("name,jtol", [("smq1Q_XYI_L128_CPTPLND", 1e-10), ("smq2Q_XYICNOT_L1024_CPTPLND_deep", None)])
+def test_deep_cptplnd_fixtures(oracle_built, name, jtol):
+    """CPTPLND models at depth (round 4): (i) the numpy analytic Jacobian x the members' reference derivative matrices
+    equals the Matrix simulator's columns (1Q L<=128, every column); (ii) the reference's own two simulators differ by
+    the FD truncation error, which grows with depth (9e-3 at depth 1,030 here) -- parity is per mode; (iii) the dense
+    model sets of the 2Q fixture walked by the oracle reproduce the Map simulator's FD columns to 1e-8 at EVERY depth
+    (dense products vs factor-by-factor composed reps: 4.4e-9 observed, flat in depth)."""
+    from conftest import matrix_rows_by_circuit, element_depth
+    from oracle import oracle as O
+    fx = load_fixture(name)
+    rows = matrix_rows_by_circuit(fx)
+    Jm = fx["matrix_by_circuit_dprobs"][rows]
+    assert np.abs(fx["matrix_by_circuit_probs"][rows] - fx["probs"]).max() < 1e-12
+    d = np.abs(Jm - fx["dprobs_map"])
+    depth = element_depth(fx)
+    assert d[depth <= 4].max() < 1e-4 and d.max() > 1e-4          # FD truncation: small when shallow, not at depth
+    if jtol is not None:
+        J, P = O.analytic_dprobs_general(fx)
+        assert np.abs(J - Jm).max() < jtol, np.abs(J - Jm).max()
+    else:
+        eps = float(fx["derivative_eps"])
+        orc = oracle_built.from_fixture({k: np.array(v) for k, v in fx.items()})
+        base = orc.probs()
+        J = np.empty_like(fx["dprobs_map"])
+        for c, (g, r, e) in enumerate(zip(fx["mm_gates"], fx["mm_rhos"], fx["mm_effects"])):
+            orc.set_model(g, r, e)
+            J[:, c] = (orc.probs() - base) / eps
+        err = np.abs(J - fx["dprobs_map"])
+        assert err.max() <= 1e-8, err.max()
+        assert depth.max() >= 1030
