@@ -73,7 +73,50 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(pack, model, max_len, design):
+def parity_columns(model_dim, n_gates, n_effects, n_params):
+    """The finite-difference columns of the parity leg: spread over the preparation, the effects and every gate (`full`
+    parameterisation: rho | effects | gates in the parameter vector, one parameter per dense element)."""
+    D = model_dim
+    cols = [0, D // 2 + 1, D, D + (n_effects * D) // 2 - 1, D + n_effects * D - 1]
+    g0 = D + n_effects * D
+    for g in range(n_gates):
+        cols += [g0 + g * D * D + (3 * g + 1) * D % (D * D) + (5 * g + 2) % D, g0 + g * D * D + D * D - 1 - 7 * g]
+    cols = sorted(set(c for c in cols if 0 <= c < n_params))
+    return np.array(cols, np.int64)
+
+
+def reference_parity(orc, parity_ctx):
+    """The benchmarked workload itself against the CPU checker (the reference's own C++ reps when oracle/_ref is built):
+    ALL probabilities of the design and K full finite-difference columns of the HBM-resident Jacobian (one more step,
+    identical to the timed ones), compared bit for bit."""
+    plan, nE, nP = parity_ctx["plan"], parity_ctx["nE"], parity_ctx["nP"]
+    cols = parity_ctx["cols"]
+    t0 = time.perf_counter()
+    Jo, po = orc.dprobs(cols, eps=1e-7, return_probs=True)
+    t_cpu = time.perf_counter() - t0
+    pd = plan.memcpy_d2h(np.empty(nE), parity_ctx["d_probs"])
+    Jd = np.empty((nE, len(cols)))
+    d_col = plan.device_malloc(nE * 8)
+    tmp = np.empty(nE)
+    try:
+        for j, c in enumerate(cols):            # column c of the resident [nE][nP] Jacobian -> a contiguous device vector
+            plan.copy_block_dev(d_col, 1, parity_ctx["d_out"] + int(c) * 8, nP, nE, 1)
+            plan.memcpy_d2h(tmp, d_col)
+            Jd[:, j] = tmp
+    finally:
+        plan.device_free(d_col)
+    same_p = np.array_equal(pd.view(np.uint64), po.view(np.uint64))
+    same_j = np.array_equal(Jd.view(np.uint64), np.ascontiguousarray(Jo).view(np.uint64))
+    return {"bitwise": bool(same_p and same_j), "bitwise_probs": bool(same_p), "bitwise_dprobs": bool(same_j),
+            "max_abs_probs": float(np.abs(pd - po).max()), "max_abs_dprobs": float(np.abs(Jd - Jo).max()),
+            "n_rows": int(nE), "n_cols": int(len(cols)), "cols": [int(c) for c in cols], "checker": orc.kind,
+            "checker_seconds": t_cpu, "max_abs_J_checked": float(np.abs(Jo).max()),
+            "what": "every probability of the benchmarked design and %d whole columns (preparation, effects, all gates) of the "
+                    "HBM-resident Jacobian of one more step identical to the timed ones vs the CPU checker's bulk_fill_dprobs on the reference-format prefix "
+                    "table of the same design (checker = %s)" % (len(cols), "the reference's own C++ reps, oracle/_ref" if orc.kind == "reference" else "the C restatement, oracle/liboracle.so")}
+
+
+def cpu_baseline(pack, model, max_len, design, parity_ctx=None):
     """Time the CPU checker on a bounded sample of THE SAME workload: the reference-format prefix table of the
     benchmarked design (restated PrefixTable, oracle/prefix_table.py) walked for a fixed number of passes -- one pass =
     one finite-difference column = one `dm_mapfill_probs` (mapforwardsim_calc_densitymx.pyx:194-287).  Returns the
@@ -94,12 +137,20 @@ def cpu_baseline(pack, model, max_len, design):
     R = np.array([next(iter(model.preps.values()))])
     E = np.array([model.effect_vector(l) for l in model.effect_labels])
     nP = model.num_params
-    mdl = dict(gates=G, rhos=R, effects=E, pkind=-np.ones(nP, np.int32), pobj=np.zeros(nP, np.int32),
-               pelem=np.zeros(nP, np.int32))
+    if parity_ctx is not None:
+        pk, po_, pe = parity_ctx["param_map"]
+    else:
+        pk, po_, pe = -np.ones(nP, np.int32), np.zeros(nP, np.int32), np.zeros(nP, np.int32)
+    mdl = dict(gates=G, rhos=R, effects=E, pkind=pk, pobj=po_, pelem=pe)
     have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgst_ref.so"))
     kind = "reference" if have_ref else "port"
     orc = O.Oracle(tbl, mdl, kind)
     nE = tbl["nE"]
+    parity = None
+    if parity_ctx is not None:
+        assert nE == parity_ctx["nE"]
+        parity = reference_parity(orc, parity_ctx)
+        log("parity leg done: bitwise=%s" % parity["bitwise"])
     t1 = orc.time_passes(2)                      # calibrate
     n_pass = int(max(4, min(400, 10.0 / max(t1 / 2, 1e-6))))
     t = orc.time_passes(n_pass)
@@ -138,7 +189,7 @@ def cpu_baseline(pack, model, max_len, design):
             "cpu_model": cpu_model, "nproc": os.cpu_count(), "cgroup_limited": cores < (os.cpu_count() or 1),
             "sample": "%d threads x %d FD columns each over the %s, %.1f s" % (cores, per, what, ta),
             "speedup_over_1_core": (nE * per * cores / ta) / (nE * n_pass / t)}
-    return one, allc
+    return one, allc, parity
 
 
 def self_launch(n):
@@ -213,6 +264,7 @@ def main():
     ap.add_argument("--no-analytic", action="store_true", help="skip the secondary analytic-derivative timing")
     ap.add_argument("--keep-zeros", action="store_true", help="analytic legs: GST_OPT_ANALYTIC_KEEP_ZEROS (structural zeros of a re-used destination are not stored again)")
     ap.add_argument("--no-other-configs", action="store_true", help="N=1: skip the secondary legs of the other BASELINE configurations (1Q, 3Q, Hessian block)")
+    ap.add_argument("--no-lm-step", action="store_true", help="skip the secondary LM-iteration timing (fill + objective maps + J^T J + J^T f [+ all-reduce])")
     ap.add_argument("--no-cptplnd", action="store_true", help="N=1: skip the secondary CPTPLND (Lindblad-parameterised) Jacobian timing")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="development aid (N=1 only): time rank 0's atom of an N-atom strong-scaling layout on this one "
@@ -506,6 +558,51 @@ def main():
         barrier_sync(plan)
 
     log("exchange legs done")
+    # secondary (every N): one Levenberg-Marquardt iteration's device work end to end -- model upload, Jacobian fill,
+    # objective maps (lsvec, dlsvec row scale), J_s^T J_s and J_s^T lsvec on the resident Jacobian, and for N > 1 the
+    # all-reduce of the nP^2 + nP partial sums between device buffers (the path's one real exchange step, SURVEY 8(e) /
+    # row f1).  This is the figure multi-GPU scaling of a FIT hinges on: no Jacobian ever leaves its GPU.
+    lm_info = None
+    if not col_split and not args.no_lm_step:
+        bufs = [plan.device_malloc(n) for n in (nP * nP * 8, nP * 8, nE_local * 8, nE_local * 8, nE_local * 8, nE_local * 8)]
+        d_jtj, d_jtf, d_ls, d_w, d_c, d_N = bufs
+        try:
+            pb = plan.memcpy_d2h(np.empty(nE_local), d_probs)
+            plan.memcpy_h2d(d_c, np.random.default_rng(1234 + rank).binomial(1000, np.clip(pb, 0.0, 1.0)).astype(np.float64))
+            plan.memcpy_h2d(d_N, np.full(nE_local, 1000.0))
+
+            def lm_step():
+                plan.set_model(gates, rhos, effects)
+                plan.fill_dprobs_dev(d_out, nP_local, pidx, None, 1e-7, d_probs, mode)
+                plan.objective_rows_dev("logl", d_probs, d_c, d_N, nE_local, d_ls, d_w, want_sum=False)
+                plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj, d_w)          # (scales the rows of J in place first)
+                plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_ls, d_jtf)
+                if world > 1 and comm is not None:
+                    comm.allreduce_sum(d_jtj, nP * nP, plan)
+                    comm.allreduce_sum(d_jtf, nP, plan)
+            lm_step()
+            barrier_sync(plan)
+            n_lm = max(3, min(args.steps, 5))
+            tl = time.perf_counter()
+            for _ in range(n_lm):
+                lm_step()
+            barrier_sync(plan)
+            t_lm = ctx.max_over_ranks(time.perf_counter() - tl) / n_lm
+            chk = plan.memcpy_d2h(np.empty(nP), d_jtf)
+            assert np.isfinite(chk).all()
+            lm_info = {"ms_per_step": 1e3 * t_lm, "elements_per_s": nE_total * nP / t_lm, "unit": "Jacobian-elements/s",
+                       "allreduce_MB": (nP * nP + nP) * 8 / 1e6 if world > 1 else 0.0,
+                       "allreduce_transport": ctx.transport if world > 1 else None,
+                       "note": "fill + Poisson-picture dlogl maps + J^T J (block-sparse split-K MFMA fp64 SYRK) + J^T f"
+                               + (" + all-reduce of nP^2 + nP doubles between device buffers" if world > 1 else "")
+                               + "; the Jacobian never leaves HBM; secondary figure, not `value`"}
+        finally:
+            for d in bufs:
+                plan.device_free(d)
+        plan.set_model(gates, rhos, effects)
+        plan.fill_dprobs_dev(d_out, nP_local, pidx, None, 1e-7, d_probs, mode)      # leave the headline Jacobian resident (unscaled)
+        barrier_sync(plan)
+        log("LM-step leg done: %.2f ms" % (1e3 * t_lm))
     jtj_info = None
     if args.jtj and col_split and world > 1 and comm is not None:
         # Normal equations with the columns distributed (distlayout.py:1306-1346): the ranks of an atom-processor split
@@ -674,6 +771,7 @@ def main():
                                        args.max_len, args.design, len(circuits), layout.global_num_elements, nP, D,
                                        "" if world == 1 else (" -- x%d designs, one per rank (%d circuits in all)" % (world, n_circ_total)
                                                               if args.scaling == "weak" else " -- dealt to %d atoms" % world)),
+                       "destination": "device (HBM-resident Jacobian, gst_fill_dprobs_dev); the reference API's host-array fill is the `host_fill` leg (PCIe-bound)",
                        "derivative": ("forward finite differences, eps=1e-7 (reference MapForwardSimulator semantics)"
                                       if args.deriv == "fd" else "analytic (reference MatrixForwardSimulator semantics)"),
                        "parallelism": (("atoms%d" % world) if not grid else ("grid %dx%d (atom-processors x parameter-processors)" % grid))
@@ -682,6 +780,7 @@ def main():
             "per_rank": {"ms_per_step": per_rank_ms, "dominant_kernel_ms": per_rank_kernel_ms,
                          "note": "each rank's own time for the K steps before the closing barrier; `ms_per_step` is the max over ranks after it"},
             "exchange": exchange,
+            "lm_step": lm_info,
             "normal_equations": jtj_info,
             "analytic_dprobs": ana_info,
             "cptplnd_dprobs": cptp_info,
@@ -706,7 +805,16 @@ def main():
                                         "n_tasks", "prog_words", "max_slots")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["cpu_baseline_allcores"] = cpu_baseline(pack, model, args.max_len, args.design)
+            pctx = None
+            if lay_world == 1 and args.deriv == "fd":
+                # parity where the number is quoted: the headline Jacobian is (re)filled, then checked against the checker
+                plan.set_model(gates, rhos, effects)
+                plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)
+                plan.sync()
+                pctx = {"plan": plan, "nE": nE_local, "nP": nP, "d_probs": d_probs, "d_out": d_out,
+                        "param_map": layout.param_map(model),
+                        "cols": parity_columns(D, len(gates), len(effects), nP)}
+            out["cpu_baseline"], out["cpu_baseline_allcores"], out["parity"] = cpu_baseline(pack, model, args.max_len, args.design, pctx)
             log("cpu baseline done")
         print(json.dumps(out))
     plan.device_free(d_out)

@@ -530,6 +530,31 @@ class Plan:
                                            C.byref(s) if want_sum else None))
         return s.value if want_sum else None
 
+    def lsq_step(self, n_params, counts, total_counts, objective="logl", eps=1e-7, mode=DERIV_FD, min_prob_clip=1e-4,
+                 radius=1e-4, prob_clip_interval=None, lsvec_out=None, probs_out=None):
+        """Everything one Levenberg-Marquardt iteration needs from this plan's rows without the Jacobian leaving HBM:
+        probabilities and Jacobian (gst_fill_dprobs_dev, FD or analytic; the model / parameter map / derivative state of
+        the plan must be set), the objective's element-wise maps (lsvec and the dlsvec row scale of
+        TimeIndependentMDCObjectiveFunction, objectivefns.py:4573-4665), then J_s^T J_s and J_s^T lsvec
+        (optimize/simplerlm.py:677-678).  counts / total_counts: host arrays in the plan's element order.
+        Returns (sum(terms), jtj [nP, nP], jtf [nP]); buffers are plan-lifetime workspaces (an optimizer calls this every
+        iteration)."""
+        nE, nP = self.n_elements, int(n_params)
+        sizes = (nE * nP * 8, nE * 8, nE * 8, nE * 8, nE * 8, nE * 8, nP * nP * 8, nP * 8)
+        d_J, d_pr, d_c, d_N, d_ls, d_w, d_jtj, d_jtf = [self.workspace("lsq%d" % k, nb) for k, nb in enumerate(sizes)]
+        self.memcpy_h2d(d_c, np.ascontiguousarray(counts, np.float64)); self.memcpy_h2d(d_N, np.ascontiguousarray(total_counts, np.float64))
+        self.fill_dprobs_dev(d_J, nP, np.arange(nP, dtype=np.int64), None, eps, d_pr, mode)
+        total = self.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius, prob_clip_interval)
+        self.fill_jtj_dev(d_J, nE, nP, nP, d_jtj, d_w)          # scales the rows of J in place first
+        self.fill_jtf_dev(d_J, nE, nP, nP, d_ls, d_jtf)
+        jtj = np.empty((nP, nP)); self.memcpy_d2h(jtj, d_jtj)
+        jtf = np.empty(nP); self.memcpy_d2h(jtf, d_jtf)
+        if lsvec_out is not None:
+            self.memcpy_d2h(lsvec_out, d_ls)
+        if probs_out is not None:
+            self.memcpy_d2h(probs_out, d_pr)
+        return total, jtj, jtf
+
     def objective_hessian_block(self, kind, d_counts, d_totals, idx1, idx2, eps=1e-5, min_prob_clip=1e-4, radius=1e-4,
                                 prob_clip_interval=None, mode=DERIV_FD):
         """(len(idx1), len(idx2)) block of the objective's Hessian, contracted over this plan's elements on the device

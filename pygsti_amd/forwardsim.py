@@ -460,7 +460,6 @@ class HipMapForwardSimulator:
         jtf[...] = 0.0
         contributes = self._first_param_proc(layout)
         mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
-        pidx = np.arange(nP, dtype=np.int64)
         counts = np.asarray(counts, np.float64)
         total_counts = np.asarray(total_counts, np.float64)
         total = 0.0
@@ -468,12 +467,9 @@ class HipMapForwardSimulator:
             plan = self._prepare_atom(atom)
             nE = atom.num_elements
             es = atom.element_slice
-            # (plan-lifetime workspaces: an optimizer calls this every iteration)
-            sizes = (nE * nP * 8, nE * 8, nE * 8, nE * 8, nE * 8, nE * 8, nP * nP * 8, nP * 8)
-            bufs = [plan.workspace("lsq%d" % k, nb) for k, nb in enumerate(sizes)]
-            d_J, d_pr, d_c, d_N, d_ls, d_w, d_jtj, d_jtf = bufs
-            plan.memcpy_h2d(d_c, counts[es]); plan.memcpy_h2d(d_N, total_counts[es])
             if not contributes:                 # (kept for the rows the caller asked for; no share in the sums)
+                d_pr, d_c, d_N, d_ls, d_w = [plan.workspace("lsq%d" % k, nE * 8) for k in (1, 2, 3, 4, 5)]
+                plan.memcpy_h2d(d_c, counts[es]); plan.memcpy_h2d(d_N, total_counts[es])
                 plan.fill_probs_dev(d_pr)
                 plan.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius, prob_clip_interval)
                 if lsvec_to_fill is not None:
@@ -481,17 +477,11 @@ class HipMapForwardSimulator:
                 if pr_array_to_fill is not None:
                     plan.memcpy_d2h(pr_array_to_fill[es], d_pr)
                 continue
-            plan.fill_dprobs_dev(d_J, nP, pidx, None, self.derivative_eps, d_pr, mode)
-            total += plan.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius,
-                                             prob_clip_interval)
-            plan.fill_jtj_dev(d_J, nE, nP, nP, d_jtj, d_w)          # scales the rows of J in place first
-            plan.fill_jtf_dev(d_J, nE, nP, nP, d_ls, d_jtf)
-            part = np.empty((nP, nP)); plan.memcpy_d2h(part, d_jtj); jtj += part
-            pv = np.empty(nP); plan.memcpy_d2h(pv, d_jtf); jtf += pv
-            if lsvec_to_fill is not None:
-                plan.memcpy_d2h(lsvec_to_fill[es], d_ls)
-            if pr_array_to_fill is not None:
-                plan.memcpy_d2h(pr_array_to_fill[es], d_pr)
+            t, part, pv = plan.lsq_step(nP, counts[es], total_counts[es], objective, self.derivative_eps, mode, min_prob_clip,
+                                        radius, prob_clip_interval,
+                                        None if lsvec_to_fill is None else lsvec_to_fill[es],
+                                        None if pr_array_to_fill is None else pr_array_to_fill[es])
+            total += t; jtj += part; jtf += pv
         return total
 
     def bulk_fill_objective_hessian(self, hessian, layout, counts, total_counts, objective="logl", min_prob_clip=1e-4,

@@ -356,8 +356,44 @@ class AtomFillLogic:
     # (expects on `self`: model, derivative_eps, hessian_eps, derivative_mode, lindblad_on_device, _hip_device -- no
     #  defaults here: class attributes of a mixin would shadow pyGSTi's `model` property)
 
+    def _lindblad_description(self, layout_atom):
+        """The atom's Lindblad member description (None when the model is not of that family), cached per model."""
+        if getattr(layout_atom, "_hip_lb_model", None) is not self.model:
+            try:
+                layout_atom._hip_lb = atom_lindblad(self.model, layout_atom)
+            except NotImplementedError:
+                layout_atom._hip_lb = None
+            layout_atom._hip_lb_model = self.model
+        return layout_atom._hip_lb
+
+    def _effective_mode(self, layout_atom):
+        """'fd' or 'analytic' for this atom.  derivative_mode='auto' (the adapter's default): finite differences -- the
+        Map simulator's own values, bit for bit -- wherever parameters are dense elements (`full`, full TP) or the model is
+        stepped on the host; EXACT derivatives for Lindblad-parameterised models (CPTPLND, GLND, H+S) whose members the
+        device builds itself: there the device's exponential (scaled Taylor) and the reference's (scipy's Pade approximant)
+        differ in the last bit of the perturbed member, which a finite-difference quotient amplifies by (occurrences of
+        the member in the circuit) / eps -- <= 1e-8 against the Map simulator for shallow circuits only (1e-6 at depth
+        1,000; tests/test_gpu_lindblad.py::test_cptplnd_models_at_depth_error_profile) -- while the exact route agrees
+        with the Matrix simulator to <= 1e-8 at every depth (observed 1e-12).  'fd' and 'analytic' force one mode."""
+        if self.derivative_mode != "auto":
+            return self.derivative_mode
+        key = getattr(layout_atom, "_hip_auto_key", (None, None))
+        if key[0] is not self.model or key[1] != bool(self.lindblad_on_device):
+            mode = "fd"
+            try:
+                atom_param_map(self.model, layout_atom)
+            except NotImplementedError:
+                try:
+                    atom_tp_map(self.model, layout_atom)
+                except NotImplementedError:
+                    if self.lindblad_on_device and self._lindblad_description(layout_atom) is not None:
+                        mode = "analytic"
+            layout_atom._hip_auto_mode, layout_atom._hip_auto_key = mode, (self.model, bool(self.lindblad_on_device))
+        return layout_atom._hip_auto_mode
+
     def _prepare(self, layout_atom, derivatives=False, hessian=False):
         plan = atom_plan(self.model, layout_atom, self._hip_device)
+        dmode = self._effective_mode(layout_atom) if derivatives else None
         # an atom already resolved to the device-built Lindblad route keeps it for this model: the host to_dense() of
         # every member (what set_model would upload, only to be overwritten by set_lindblad_params) is skipped
         if (getattr(plan, "_hip_mode", None) == "lindblad" and getattr(layout_atom, "_hip_lb_model", None) is self.model
@@ -380,7 +416,7 @@ class AtomFillLogic:
                 plan.set_complement_effect(-1)
                 plan.set_param_map(*layout_atom._hip_pmap)
                 plan._hip_mode = "elements"
-        elif self.derivative_mode != "analytic":
+        elif dmode != "analytic":
             # TP-style models: element-subset members + a complement effect, bit-identical finite differences
             if getattr(layout_atom, "_hip_tpmap_model", None) is not self.model:
                 try:
@@ -393,13 +429,7 @@ class AtomFillLogic:
             if layout_atom._hip_tpmap is None:
                 # Lindblad-parameterised members (CPTPLND, GLND, H+S): the device builds them from the parameter vector,
                 # for the base model and for every FD step
-                if getattr(layout_atom, "_hip_lb_model", None) is not self.model:
-                    try:
-                        layout_atom._hip_lb = atom_lindblad(self.model, layout_atom)
-                    except NotImplementedError:
-                        layout_atom._hip_lb = None
-                    layout_atom._hip_lb_model = self.model
-                if layout_atom._hip_lb is not None and self.lindblad_on_device:
+                if self._lindblad_description(layout_atom) is not None and self.lindblad_on_device:
                     if getattr(plan, "_hip_mode", None) != "lindblad":
                         plan.set_derivs(self.model.num_params, [])
                         plan.set_complement_effect(-1)
@@ -423,13 +453,7 @@ class AtomFillLogic:
             # members' d(dense)/d(parameter) itself (Frechet derivative of the exponential); anything else: the members'
             # deriv_wrt_params() from the host, re-sent every call (they move with the parameters)
             if self.lindblad_on_device and not hessian:
-                if getattr(layout_atom, "_hip_lb_model", None) is not self.model:
-                    try:
-                        layout_atom._hip_lb = atom_lindblad(self.model, layout_atom)
-                    except NotImplementedError:
-                        layout_atom._hip_lb = None
-                    layout_atom._hip_lb_model = self.model
-                if layout_atom._hip_lb is not None:
+                if self._lindblad_description(layout_atom) is not None:
                     if getattr(plan, "_hip_mode", None) != "lindblad":
                         plan.set_derivs(self.model.num_params, [])
                         plan.set_complement_effect(-1)
@@ -468,7 +492,7 @@ class AtomFillLogic:
             plan.set_model(*atom_arrays(self.model, layout_atom))
             plan.fill_dprobs_models(G, R, E, array_to_fill, didx, self.derivative_eps)
             return
-        mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
+        mode = _lib.DERIV_ANALYTIC if self._effective_mode(layout_atom) == "analytic" else _lib.DERIV_FD
         plan.fill_dprobs(array_to_fill, pidx, didx, self.derivative_eps, mode=mode)
 
     def _bulk_fill_hprobs_atom(self, array_to_fill, dest_param_slice1, dest_param_slice2, layout_atom,
@@ -523,7 +547,7 @@ class AtomFillLogic:
             finally:
                 plan.set_lindblad_params(orig)
             return
-        elif hmode != "elements" and not (hmode == "tp-elements" and self.derivative_mode == "fd"):
+        elif hmode != "elements" and not (hmode == "tp-elements" and self._effective_mode(layout_atom) == "fd"):
             raise NotImplementedError("Hessians on the device: fully parameterised models (FD or exact), full-TP models "
                                       "(FD of FD as the Map simulator computes them, or exact), any parameterisation "
                                       "with derivative_mode='analytic' (exact)")
@@ -534,7 +558,7 @@ class AtomFillLogic:
         d2 = None if dest_param_slice2 is None else _to_array(dest_param_slice2)
         # derivative_mode="analytic": exact second derivatives (MatrixForwardSimulator's values) 
         # (D = 4, 16, 64); otherwise the Map simulator's FD-of-FD, bit for bit
-        mode = _lib.DERIV_ANALYTIC if (self.derivative_mode == "analytic") else _lib.DERIV_FD
+        mode = _lib.DERIV_ANALYTIC if (self._effective_mode(layout_atom) == "analytic") else _lib.DERIV_FD
         if array_to_fill.flags.c_contiguous:
             plan.fill_hprobs(array_to_fill, i1, i2, d1, d2, self.hessian_eps, mode)
         else:
@@ -543,17 +567,47 @@ class AtomFillLogic:
             array_to_fill[...] = tmp
 
 
+    def bulk_fill_lsq_step(self, jtj, jtf, layout, counts, total_counts, objective="logl", min_prob_clip=1e-4, radius=1e-4,
+                           prob_clip_interval=None, lsvec_to_fill=None, pr_array_to_fill=None):
+        """What one Levenberg-Marquardt iteration of a GST fit needs from the data, computed without the Jacobian leaving
+        the GPU: for every atom of `layout` the probabilities and the Jacobian (this simulator's
+        derivative mode for the model's parameterisation), the objective's element-wise maps -- lsvec and the dlsvec row
+        scale of TimeIndependentMDCObjectiveFunction (objectivefns.py:4573-4665; `objective` = 'chi2' | 'logl') -- then
+        J_s^T J_s and J_s^T lsvec (optimize/simplerlm.py:677-678).  `counts` / `total_counts`: per-element arrays in
+        layout order (the objective's `.counts` / `.total_counts`).  jtj (nP, nP) and jtf (nP,) are summed over this
+        process's atoms (ranks all-reduce, as `layout.fill_jtj` does); returns sum(terms) of them.  Not available for
+        models that must be stepped on the host ("models" mode: no device-resident Jacobian)."""
+        nP = self.model.num_params
+        jtj[...] = 0.0
+        jtf[...] = 0.0
+        total = 0.0
+        counts = np.asarray(counts, np.float64); total_counts = np.asarray(total_counts, np.float64)
+        for atom in layout.atoms:
+            plan = self._prepare(atom, derivatives=True)
+            if getattr(plan, "_hip_mode", None) == "models":
+                raise NotImplementedError("the fused LM step needs a device-resident Jacobian; this model is stepped on the host")
+            es = getattr(atom, "element_slice", slice(0, atom.num_elements))
+            mode = _lib.DERIV_ANALYTIC if self._effective_mode(atom) == "analytic" else _lib.DERIV_FD
+            t, part, pv = plan.lsq_step(nP, counts[es], total_counts[es], objective, self.derivative_eps, mode, min_prob_clip,
+                                        radius, prob_clip_interval,
+                                        None if lsvec_to_fill is None else lsvec_to_fill[es],
+                                        None if pr_array_to_fill is None else pr_array_to_fill[es])
+            total += t; jtj += part; jtf += pv
+        return total
+
+
 class HipMapForwardSimulator(AtomFillLogic, _MapForwardSimulator):
-    """MapForwardSimulator whose atom fills run on the GPU.  `derivative_mode="fd"` (default): bit-identical to the
-    Map simulator's finite differences; `"analytic"`: exact first derivatives (what MatrixForwardSimulator returns,
-    to <= 1e-8), several times faster, and exact Hessian blocks."""
+    """MapForwardSimulator whose atom fills run on the GPU.  `derivative_mode="auto"` (default): the Map simulator's
+    finite differences, bit for bit, for `full` / full-TP models and exact derivatives for Lindblad-parameterised models
+    (see AtomFillLogic._effective_mode); `"fd"`: finite differences for every model; `"analytic"`: exact first
+    derivatives (what MatrixForwardSimulator returns, to <= 1e-8), several times faster, and exact Hessian blocks."""
 
     def __init__(self, model=None, max_cache_size=None, num_atoms=None, processor_grid=None, param_blk_sizes=None,
-                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1, derivative_mode="fd", lindblad_on_device=True):
+                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1, derivative_mode="auto", lindblad_on_device=True):
         if not HAVE_PYGSTI:
             raise ImportError("pygsti is not importable; use pygsti_amd.forwardsim.HipMapForwardSimulator instead")
-        if derivative_mode not in ("fd", "analytic"):
-            raise ValueError("derivative_mode must be 'fd' or 'analytic'")
+        if derivative_mode not in ("auto", "fd", "analytic"):
+            raise ValueError("derivative_mode must be 'auto', 'fd' or 'analytic'")
         super().__init__(model, max_cache_size, num_atoms, processor_grid, param_blk_sizes, derivative_eps, hessian_eps)
         self._hip_device = device
         self.derivative_mode = derivative_mode

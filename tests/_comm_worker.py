@@ -15,18 +15,20 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     out_dir, transport, n_atoms = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    distinct = len(sys.argv) > 4 and sys.argv[4] == "distinct"      # one GPU per rank (a multi-GPU node): device = LOCAL_RANK
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if distinct else 0
     from conftest import load_fixture
     from test_host_mirror import _model_from_fixture
     from pygsti_amd import modelpacks as MP, dist as gdist, _lib
     from pygsti_amd.layout import HipCOPALayout
-    ctx = gdist.init(device=0, transport=transport)
+    ctx = gdist.init(device=dev, transport=transport)
     assert ctx.comm is not None, ctx.comm_error
     rank, size = ctx.rank, ctx.size
     fx = load_fixture("smq2Q_XYICNOT_L2_depol")
     pack = MP.smq2Q_XYICNOT
     model = _model_from_fixture(fx, pack)
     circuits = pack.create_gst_circuits(2)
-    lay = HipCOPALayout(circuits, model, num_atoms=n_atoms, devices=[0], rank=rank, size=size)
+    lay = HipCOPALayout(circuits, model, num_atoms=n_atoms, devices=[dev], rank=rank, size=size)
     cols = np.asarray(fx["dprobs_cols"], np.int64)
     nE, nC = lay.global_num_elements, len(cols)
     plans = [at.plan() for at in lay.atoms]

@@ -64,3 +64,23 @@ def matrix_rows_by_circuit(fx):
 def element_depth(fx):
     """Gate count of the circuit every element belongs to."""
     return np.diff(fx["circ_ptr"])[fx["el_circuit"]]
+
+
+def design_checker(oracle_module, pack, model, circuits, layout, kind=None):
+    """The CPU checker for a WHOLE design of the host mirror (bench.py's workload): the reference-format prefix table of
+    `circuits` (oracle/prefix_table.py, array-equal to the reference's own table on every design fixture) with the model's
+    arrays and the `full` parameter map, walked by the reference's own C++ reps when oracle/_ref is built.  Element order =
+    the 1-atom layout's (circuit-major, outcomes in model.effect_labels order)."""
+    from oracle import prefix_table as PT
+    lookup = {l: i for i, l in enumerate(model.operations.keys())}
+    ptr = np.zeros(len(circuits) + 1, np.int64)
+    ptr[1:] = np.cumsum([len(c) for c in circuits])
+    gates = np.fromiter((lookup[g] for c in circuits for g in c), np.int32, count=int(ptr[-1]))
+    tbl = PT.build_table(ptr, gates, len(model.effect_labels))
+    tbl["D"] = model.dim
+    G, R, E = layout.model_arrays(model)
+    pk, po, pe = layout.param_map(model)
+    mdl = dict(gates=G, rhos=R, effects=E, pkind=pk, pobj=po, pelem=pe)
+    if kind is None:
+        kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgst_ref.so")) else "port"
+    return oracle_module.Oracle(tbl, mdl, kind)

@@ -1,0 +1,152 @@
+"""End-to-end fit check (the reference pins this path with whole GST runs: test/unit/protocols/test_gst.py:243-292,
+test/unit/objects/test_forwardsim.py:351-378).
+
+pyGSTi cannot travel to the GPU box, so the run was RECORDED in the build container (tests/golden/make_golden_fit.py:
+`GateSetTomography(smq1Q_XYI.target_model("full TP"), 'stdgaugeopt').run(data, simulator=<recording MapForwardSimulator>)`,
+L <= 8, 1,000 sampled shots per circuit) and is REPLAYED here: the optimizer's whole sequence of parameter vectors -- 21
+Jacobian requests over the four stages L = 1, 2, 4, 8 (chi^2 iterations, then the final Poisson-picture logL ones) --
+goes through the drop-in's per-atom logic (`AtomFillLogic`, "tp-elements" mode) and its fused LM step on the device.
+
+  * every iterate's probabilities and FULL finite-difference Jacobian equal the reference's bit for bit;
+  * every iteration's J_s^T J_s, J_s^T lsvec and objective value equal numpy products of the reference's own dlsvec /
+    lsvec arrays to 1e-12 (chi^2) / 1e-10 (logL: log() rounding);
+  * 2*delta-logL of the final estimate equals `two_delta_logl(model, dataset)` to 1e-9.
+
+The CPU half checks the same record against the oracle (so the fixture's meaning is pinned without a GPU)."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture, assert_bitwise
+
+NAME = "fit_smq1Q_XYI_L8_TP"
+
+
+def _stage_fixture(fx, s, it=None):
+    """The table-format dict of stage `s` (what plan_from_fixture / the oracle take), with iterate `it`'s dense model."""
+    d = {k: fx["s%d_%s" % (s, k)] for k in ("t_dest", "t_start", "t_cache", "t_rho", "row_ptr", "gate_idx", "eff_ptr", "eff_label",
+                                            "eff_dest", "nE", "cache_size", "op_labels", "rho_labels", "eff_labels")}
+    d["D"] = fx["D"]; d["nP"] = fx["nP"]
+    d["pkind"], d["pobj"], d["pelem"] = fx["tp_kind"], fx["tp_obj"], fx["tp_elem"]
+    if it is not None:
+        d["gates"], d["rhos"], d["effects"] = fx["it%d_gates" % it], fx["it%d_rhos" % it], fx["it%d_effects" % it]
+        d["paramvec"] = fx["it%d_vec" % it]
+    return d
+
+
+def test_fit_record_replays_on_the_oracle(oracle_built):
+    """CPU: the oracle (the reference's own C++ reps when built) walks every recorded iterate -- probabilities and the
+    preparation / gate columns bit for bit through the TP element map, the effect columns by stepping the effect and
+    re-deriving the complement as complementeffect.py:72-78 does -- and the objective record is what the numpy
+    restatement of the objective maps gives."""
+    from oracle import objective_oracle as OO
+    fx = load_fixture(NAME)
+    n_it = int(fx["n_iterates"])
+    assert n_it == 21 and int(fx["n_stages"]) == 4
+    comp, others, ident = int(fx["comp_index"]), fx["comp_others"], fx["comp_identity"]
+    eps = float(fx["derivative_eps"])
+    kinds = ["port"] + (["reference"] if __import__("os").path.exists(__import__("os").path.join(__import__("conftest").ROOT, "oracle", "_ref", "libgst_ref.so")) else [])
+    for it in range(0, n_it, 4):
+        s = int(fx["it%d_stage" % it])
+        d = _stage_fixture(fx, s, it)
+        for kind in kinds:
+            orc = oracle_built.from_fixture({k: np.array(v) for k, v in d.items() if k not in ("op_labels", "rho_labels", "eff_labels", "nP", "paramvec")}, kind)
+            J, pr = orc.dprobs(np.arange(int(fx["nP"])), eps=eps, return_probs=True)
+            assert_bitwise(pr, fx["it%d_probs" % it], "iterate %d probs (%s)" % (it, kind))
+            not_eff = fx["tp_kind"] != 2
+            assert_bitwise(J[:, not_eff], fx["it%d_dprobs" % it][:, not_eff], "iterate %d rho/gate columns (%s)" % (it, kind))
+            for p in np.nonzero(fx["tp_kind"] == 2)[0]:
+                E = d["effects"].copy()
+                E[fx["tp_obj"][p], fx["tp_elem"][p]] += eps
+                E[comp] = ident - sum([E[o] for o in others])
+                orc.set_model(d["gates"], d["rhos"], E)
+                assert_bitwise((orc.probs() - pr) / eps, fx["it%d_dprobs" % it][:, p], "iterate %d effect column %d" % (it, p))
+                orc.set_model(d["gates"], d["rhos"], d["effects"])
+    for k in range(int(fx["n_obj"])):
+        it, s, kind = int(fx["ob%d_iterate" % k]), int(fx["ob%d_stage" % k]), int(fx["ob%d_kind" % k])
+        mpc = float(fx["ob%d_min_prob_clip_for_weighting" % k]) if kind == 0 else float(fx["ob%d_min_p" % k])
+        rad = 1e-4 if kind == 0 else float(fx["ob%d_radius" % k])
+        p = np.clip(fx["it%d_probs" % it], float(fx["ob%d_clip_lo" % k]), float(fx["ob%d_clip_hi" % k]))
+        t, ls, dt, rs = OO.objective_rows(OO.CHI2 if kind == 0 else OO.DLOGL, p, fx["s%d_counts" % s], fx["s%d_totals" % s], mpc, rad)
+        Js = fx["it%d_dprobs" % it] * rs[:, None]
+        ref = fx["ob%d_jtj" % k]
+        assert np.abs(Js.T @ Js - ref).max() <= 1e-11 * np.abs(ref).max(), (k, np.abs(Js.T @ Js - ref).max() / np.abs(ref).max())
+        assert abs(t.sum() - float(fx["ob%d_fsum" % k])) <= 1e-11 * abs(float(fx["ob%d_fsum" % k]))
+    assert abs(2.0 * float(fx["ob%d_fsum" % (int(fx["n_obj"]) - 1)]) - float(fx["two_delta_logl"])) < 1.0    # (the last iterate is next to the estimate)
+
+
+@pytest.mark.gpu
+def test_gpu_fit_replay_through_the_adapter_logic():
+    from pygsti_amd import _lib
+    import test_gpu_adapter_modes as M
+    fx = load_fixture(NAME)
+    nP, D = int(fx["nP"]), int(fx["D"])
+    n_stages = int(fx["n_stages"])
+    atoms = [M._Atom(_stage_fixture(fx, s)) for s in range(n_stages)]
+
+    def model_for(gates, rhos, effects, vec):
+        """A full-TP stand-in model (members answer to_dense / gpindices_as_array / deriv_wrt_params as pyGSTi's do)."""
+        d = _stage_fixture(fx, n_stages - 1)
+        members = {}
+        comp = int(fx["comp_index"])
+        for kind, typ, labels, arr, cls in ((0, "op", d["op_labels"], gates, M.FullTPOp), (1, "prep", d["rho_labels"], rhos, M.TPState),
+                                            (2, "povm", d["eff_labels"], effects, M.FullPOVMEffect)):
+            n_el = D * D if kind == 0 else D
+            for oi, l in enumerate(labels):
+                if kind == 2 and oi == comp:
+                    continue
+                sel = np.nonzero((fx["tp_kind"] == kind) & (fx["tp_obj"] == oi))[0]
+                dm = np.zeros((n_el, len(sel)))
+                dm[fx["tp_elem"][sel], np.arange(len(sel))] = 1.0
+                members[(typ, str(l))] = cls(arr[oi], sel, dm)
+        c = M.ComplementPOVMEffect(effects[comp], np.nonzero(fx["tp_kind"] == 2)[0])
+        c.other_effects = [members[("povm", str(d["eff_labels"][o]))] for o in fx["comp_others"]]
+        c.identity = M._Member(fx["comp_identity"], [])
+        members[("povm", str(d["eff_labels"][comp]))] = c
+        return M._StaticModel(dict(D=D, nP=nP, paramvec=vec), members)
+
+    obj_of = {int(fx["ob%d_iterate" % k]): [] for k in range(int(fx["n_obj"]))}
+    for k in range(int(fx["n_obj"])):
+        obj_of[int(fx["ob%d_iterate" % k])].append(k)
+    sim = M._Sim(None, "auto")
+    for it in range(int(fx["n_iterates"])):
+        s = int(fx["it%d_stage" % it])
+        atom = atoms[s]
+        sim.model = model_for(fx["it%d_gates" % it], fx["it%d_rhos" % it], fx["it%d_effects" % it], fx["it%d_vec" % it])
+        nE = atom.num_elements
+        p = np.empty(nE); sim._bulk_fill_probs_atom(p, atom, None)
+        assert_bitwise(p, fx["it%d_probs" % it], "iterate %d probabilities" % it)
+        J = np.empty((nE, nP)); sim._bulk_fill_dprobs_atom(J, None, atom, None, None)
+        assert atom._hip_plan._hip_mode == "tp-elements"
+        assert_bitwise(J, fx["it%d_dprobs" % it], "iterate %d Jacobian (stage %d)" % (it, s))
+        for k in obj_of.get(it, []):
+            kind = int(fx["ob%d_kind" % k])
+            mpc = float(fx["ob%d_min_prob_clip_for_weighting" % k]) if kind == 0 else float(fx["ob%d_min_p" % k])
+            rad = 1e-4 if kind == 0 else float(fx["ob%d_radius" % k])
+            lay = type("L", (), {"atoms": [atom]})()
+            jtj = np.empty((nP, nP)); jtf = np.empty(nP); ls = np.empty(nE)
+            total = sim.bulk_fill_lsq_step(jtj, jtf, lay, fx["s%d_counts" % s], fx["s%d_totals" % s], "chi2" if kind == 0 else "logl",
+                                           mpc, rad, (float(fx["ob%d_clip_lo" % k]), float(fx["ob%d_clip_hi" % k])), lsvec_to_fill=ls)
+            tol = 1e-12 if kind == 0 else 1e-10
+            rj, rf = fx["ob%d_jtj" % k], fx["ob%d_jtf" % k]
+            assert np.abs(jtj - rj).max() <= tol * np.abs(rj).max(), (k, np.abs(jtj - rj).max() / np.abs(rj).max())
+            assert np.abs(jtf - rf).max() <= tol * max(np.abs(rf).max(), 1e-6 * np.sqrt(np.abs(rj).max() * float(fx["ob%d_fsum" % k]))), k
+            assert abs(total - float(fx["ob%d_fsum" % k])) <= tol * abs(float(fx["ob%d_fsum" % k])), k
+            if kind == 0:
+                assert_bitwise(ls, fx["ob%d_lsvec" % k], "lsvec of dlsvec call %d" % k)
+    # the final estimate: 2 * delta logL over the whole data set (= the last stage's layout)
+    s = n_stages - 1
+    atom = atoms[s]
+    sim.model = model_for(fx["final_gates"], fx["final_rhos"], fx["final_effects"], fx["final_vec"])
+    plan = sim._prepare(atom)
+    nE = atom.num_elements
+    bufs = [plan.device_malloc(nE * 8) for _ in range(5)]
+    d_p, d_c, d_N, d_ls, d_w = bufs
+    try:
+        plan.fill_probs_dev(d_p)
+        plan.memcpy_h2d(d_c, fx["s%d_counts" % s]); plan.memcpy_h2d(d_N, fx["s%d_totals" % s])
+        dlogl = plan.objective_rows_dev("logl", d_p, d_c, d_N, nE, d_ls, d_w, None, float(fx["tdl_min_prob_clip"]), float(fx["tdl_radius"]),
+                                        (float(fx["tdl_clip_lo"]), float(fx["tdl_clip_hi"])))
+    finally:
+        for b in bufs:
+            plan.device_free(b)
+    assert abs(2.0 * dlogl - float(fx["two_delta_logl"])) <= 1e-9 * float(fx["two_delta_logl"]), (2.0 * dlogl, float(fx["two_delta_logl"]))

@@ -100,35 +100,41 @@ def test_device_resident_fill_matches_host_fill():
     pl.device_free(d_out); pl.device_free(d_pr)
 
 
-def test_full_size_properties():
-    """BASELINE-size run (2Q L<=1024 lite, 24,394 circuits) through size-independent properties:
-    probabilities of each circuit sum to 1 (trace preservation of the depolarized target), the FD
-    columns of the idle gate's first row are exactly zero (TP: that row never changes the output...
-    only checked as finite), results are independent of the task granularity, and a spot sample of
-    circuits equals the CPU oracle bit for bit."""
+def test_full_size_properties(oracle_built):
+    """BASELINE-size run (2Q L<=1024 lite, 24,394 circuits): EVERY probability and 17 whole finite-difference columns
+    (preparation, effects, all six gates) equal the CPU checker -- the reference's own C++ reps walking the
+    reference-format prefix table of the same design -- bit for bit; results are independent of the task granularity;
+    probabilities of each circuit sum to 1 (trace preservation of the depolarized target)."""
+    from conftest import design_checker
+    import bench
     pack = MP.smq2Q_XYICNOT
     model = pack.target_model().depolarize(0.01, 0.01)
     circuits = pack.create_gst_circuits(1024, lite=True)
+    cols = bench.parity_columns(model.dim, 6, 4, model.num_params)
     sims = [HipMapForwardSimulator(target_tasks=t) for t in (0, 97)]
     outs = []
     for sim in sims:
         model.sim = sim
         lay = sim.create_layout(circuits)
         p = np.empty(lay.num_elements); sim.bulk_fill_probs(p, lay)
-        cols = np.array([0, 17, 80, 81, 335, 336, 700, 1615])
         J = np.empty((lay.num_elements, len(cols)))
         sim._bulk_fill_dprobs_atom(J, None, lay.atoms[0], cols)
         outs.append((p, J))
     assert_bitwise(outs[0][0], outs[1][0], "probs vs task granularity")
     assert_bitwise(outs[0][1], outs[1][1], "dprobs vs task granularity")
+    orc = design_checker(oracle_built, pack, model, circuits, lay)
+    Jo, po = orc.dprobs(cols, eps=1e-7, return_probs=True)
+    assert_bitwise(outs[0][0], po, "all %d probabilities of the lite design vs the %s checker" % (len(po), orc.kind))
+    assert_bitwise(outs[0][1], Jo, "%d whole FD columns of the lite design vs the %s checker" % (len(cols), orc.kind))
     p = outs[0][0].reshape(-1, 4)
     assert np.abs(p.sum(axis=1) - 1.0).max() < 1e-12 and p.min() > -1e-12
-    assert np.isfinite(outs[0][1]).all()
 
 
-def test_baseline_size_checksums():
+def test_baseline_size_checksums(oracle_built):
     """The bench workload itself (2Q L<=1024 FULL design: 136,275 circuits x 1,616 parameters, a 7 GB Jacobian that
-    stays in HBM) through size-independent properties: probabilities of every circuit sum to 1; J^T f -- a checksum of
+    stays in HBM): ALL 545,100 probabilities and 17 whole columns of the resident Jacobian equal the CPU checker (the
+    reference's own C++ reps on the reference-format prefix table of the design) bit for bit -- the comparison bench.py
+    repeats in its `parity` object -- and, for the other 1,599 columns, size-independent properties: J^T f -- a checksum of
     every Jacobian element, reduced on the device in a fixed order -- is BITWISE the same for two different task
     decompositions (any prefix-sharing schedule gives the same states); it is linear in f; and the
     analytic Jacobian's checksum agrees with the finite-difference one to the FD truncation error."""
@@ -163,6 +169,17 @@ def test_baseline_size_checksums():
             sums[tt] = (probs, y1)
             if tt == 0:
                 assert np.abs(probs.reshape(-1, 4).sum(axis=1) - 1.0).max() < 1e-12 and probs.min() > -1e-12
+                import bench
+                from conftest import design_checker
+                cols = bench.parity_columns(model.dim, 6, 4, nP)
+                orc = design_checker(oracle_built, pack, model, circuits, layout)
+                Jo, po = orc.dprobs(cols, eps=1e-7, return_probs=True)
+                assert_bitwise(probs, po, "all 545,100 probabilities of the bench workload vs the %s checker" % orc.kind)
+                d_col = plan.device_malloc(nE * 8)
+                for j, c in enumerate(cols):
+                    plan.copy_block_dev(d_col, 1, d_J + int(c) * 8, nP, nE, 1)
+                    assert_bitwise(plan.memcpy_d2h(np.empty(nE), d_col), Jo[:, j], "column %d of the resident Jacobian vs the checker" % c)
+                plan.device_free(d_col)
                 assert np.abs(y12 - (y1 + y2)).max() <= 1e-9 * np.abs(y1).max()          # linearity of the checksum
                 plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_ANALYTIC)
                 ya = jtf(f1)

@@ -119,7 +119,7 @@ def test_adapter_general_parameterisation_fd_model_sets():
     m = smq1Q_XYI.target_model("CPTPLND")
     m.from_vector(m.to_vector() + 0.01 * np.random.default_rng(3).standard_normal(m.num_params))
     assert np.array_equal(m.to_vector(), fx["paramvec"])
-    m.sim = A.HipMapForwardSimulator()                       # defaults: derivative_mode="fd"
+    m.sim = A.HipMapForwardSimulator()                       # defaults: derivative_mode="auto" (exact derivatives for Lindblad members)
     lay = m.sim.create_layout(list(smq1Q_XYI.create_gst_experiment_design(4).all_circuits_needing_data), array_types=("ep",))
     atom = lay.atoms[0]
     A.atom_plan(m, atom)
