@@ -9,7 +9,7 @@ goes through the drop-in's per-atom logic (`AtomFillLogic`, "tp-elements" mode) 
 
   * every iterate's probabilities and FULL finite-difference Jacobian equal the reference's bit for bit;
   * every iteration's J_s^T J_s, J_s^T lsvec and objective value equal numpy products of the reference's own dlsvec /
-    lsvec arrays to 1e-12 (chi^2) / 1e-10 (logL: log() rounding);
+    lsvec arrays to 1e-12 (chi^2) / 1e-10 (logL: log() rounding) of their summands' scale;
   * 2*delta-logL of the final estimate equals `two_delta_logl(model, dataset)` to 1e-9.
 
 The CPU half checks the same record against the oracle (so the fixture's meaning is pinned without a GPU)."""
@@ -129,7 +129,8 @@ def test_gpu_fit_replay_through_the_adapter_logic():
             tol = 1e-12 if kind == 0 else 1e-10
             rj, rf = fx["ob%d_jtj" % k], fx["ob%d_jtf" % k]
             assert np.abs(jtj - rj).max() <= tol * np.abs(rj).max(), (k, np.abs(jtj - rj).max() / np.abs(rj).max())
-            assert np.abs(jtf - rf).max() <= tol * max(np.abs(rf).max(), 1e-6 * np.sqrt(np.abs(rj).max() * float(fx["ob%d_fsum" % k]))), k
+            # (J_s^T lsvec -> 0 at the optimum: the error scale is that of its cancelling summands, |J_s| |lsvec|)
+            assert np.abs(jtf - rf).max() <= 1e-2 * tol * np.sqrt(np.abs(rj).max() * float(fx["ob%d_fsum" % k])), k
             assert abs(total - float(fx["ob%d_fsum" % k])) <= tol * abs(float(fx["ob%d_fsum" % k])), k
             if kind == 0:
                 assert_bitwise(ls, fx["ob%d_lsvec" % k], "lsvec of dlsvec call %d" % k)
