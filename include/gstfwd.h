@@ -121,6 +121,9 @@ typedef struct {
                                   per-SIMD queues; 2 = persistent with the base pass walked inside the same launch */
     int32_t last_fd_aborted;   /* 1: a bounded wait of that persistent launch ran out (producer workgroup not resident, e.g. a
                                   shared device) and the stand-by launches behind it produced the result instead */
+    int32_t last_levels;       /* 1: the last fill took its forward states from the log-depth level pass (GST_OPT_FAST_CHAINS /
+                                  GST_OPT_FAST_PROBS), 0: from the sequential walk */
+    int32_t reserved0;
 } gst_stats;
 
 int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *opt, gst_plan **out);
@@ -134,6 +137,20 @@ int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *op
  *       optimizer does that reuses one device Jacobian every iteration.  The first fill into a destination (and any fill
  *       after the destination, the columns or the option changed) writes everything.  Off by default. */
 #define GST_OPT_ANALYTIC_KEEP_ZEROS 1
+/*   GST_OPT_FAST_CHAINS (value 0 / 1 / 2; D = 16): how the modes WITHOUT an ordering contract -- GST_DERIV_ANALYTIC, and
+ *       gst_fill_probs* under GST_OPT_FAST_PROBS -- obtain the states of the circuit tries.  The sequential walk applies a
+ *       GST family's ~1,150 gates one after another (0.5 ms of latency on any hardware; it IS the finite-difference mode's
+ *       bit-parity contract and stays there).  The level pass finds the periodic (germ-power) paths of the tries, forms the
+ *       germ's matrix and its squarings on the matrix cores and evaluates every path in ~2 m + 15 dependent stages (the
+ *       reference's Matrix simulator multiplies sub-products over an eval tree for the same reason, matrixforwardsim.py:
+ *       675-727, evaltree.py:31-189).  Results differ from the walk's by re-association only (<= 1e-13 observed at depth
+ *       1,030; the mode's bars are 1e-10 for probabilities, 1e-8 for derivatives).  1 (default): where the stages are few
+ *       against the chains; 0: never; 2: whenever a level program exists (tests).
+ *   GST_OPT_FAST_PROBS (value 0 / 1; default 0): gst_fill_probs / gst_fill_probs_dev through the level pass: probabilities
+ *       within 1e-10 of the reference's, NOT bit-identical -- for callers (line searches of an optimizer) that do not
+ *       difference them.  Finite-difference fills never use it. */
+#define GST_OPT_FAST_CHAINS 2
+#define GST_OPT_FAST_PROBS 3
 int gst_set_option(gst_plan *plan, int32_t option, int64_t value);
 int gst_plan_create_from_circuits(const gst_circuits_desc *desc, const gst_options *opt, gst_plan **out);
 int gst_plan_destroy(gst_plan *plan);
@@ -457,6 +474,15 @@ int gst_get_program(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t 
  * prog_off[t * n_classes + c + 1]), empty when no outcome of the task sees the object.  GST_OP_CACHE id starts from state
  * `id` of the base pass; the rest are the ordinary opcodes.  Copies up to `cap` words, the total in *n_words; prog_off
  * (may be NULL) receives n_tasks * n_classes + 1 offsets when cap_progs suffices. */
+/* The level program of the forward plan (which = 0) or of the plan of the reversed circuits (which = 1; nv = n_effects
+ * vectors per state), built on the host for this call (no device needed) -- what GST_OPT_FAST_CHAINS executes; format in
+ * csrc/gst_levels.hpp.  Two-call pattern: sizes come back in *n_words / *n_ids; arrays are filled when their capacities
+ * suffice.  node_parent / node_sym (may be NULL): the state graph the ids refer to (for which = 1 the reversed plan's).
+ * info[12] = usable, worthwhile, nv, scratch matrices per task, most stages of a task, stages, tiles, chains, nodes on
+ * chains, sum over tasks of the deepest node, states, tasks. */
+int gst_get_level_program(const gst_plan *plan, int32_t which, int32_t *words, int64_t cap_words, int64_t *n_words, int32_t *ids,
+                          int64_t cap_ids, int64_t *n_ids, int64_t *task_off, int64_t cap_tasks, int32_t *node_parent,
+                          int32_t *node_sym, int64_t cap_nodes, int64_t *info);
 int gst_get_dirty_programs(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words, int64_t *prog_off,
                            int64_t cap_progs, int32_t *n_classes);
 

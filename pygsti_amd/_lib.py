@@ -17,6 +17,8 @@ GST_EINVAL, GST_ENODEVICE, GST_EHIP, GST_ENOMEM, GST_ESTATE, GST_EUNSUPPORTED = 
 KIND_NONE, KIND_GATE, KIND_RHO, KIND_EFFECT = -1, 0, 1, 2
 DERIV_FD, DERIV_ANALYTIC = 0, 1
 OPT_ANALYTIC_KEEP_ZEROS = 1
+OPT_FAST_CHAINS = 2       # 0 never / 1 where it pays (default) / 2 always: log-depth level pass for the modes without an ordering contract
+OPT_FAST_PROBS = 3        # fill_probs through the level pass (<= 1e-10, not bit-identical)
 OBJ_CHI2, OBJ_POISSON_DLOGL = 0, 1
 TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1
 COMM_ID_BYTES = 128
@@ -73,13 +75,13 @@ class Stats(C.Structure):
                 ("trie_nodes", C.c_int64), ("applies_per_pass", C.c_int64), ("n_tasks", C.c_int64),
                 ("prog_words", C.c_int64), ("max_slots", C.c_int32), ("max_depth", C.c_int32),
                 ("last_kernel_ms", C.c_double), ("last_total_ms", C.c_double), ("last_launches", C.c_int64),
-                ("last_fd_form", C.c_int32), ("last_fd_aborted", C.c_int32)]
+                ("last_fd_form", C.c_int32), ("last_fd_aborted", C.c_int32), ("last_levels", C.c_int32), ("reserved0", C.c_int32)]
 
 
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
@@ -627,6 +629,30 @@ class Plan:
         off = np.empty(nt + 1, np.int64)
         check(lib().gst_get_program(self._h, _ptr(words), n.value, C.byref(n), _ptr(off), nt + 1))
         return words[:n.value], off
+
+
+def _level_program(self, which=0):
+    """gst_get_level_program: the log-depth level program of the forward plan (which = 0) or of the reversed plan (1), built
+    on the host.  Returns dict(usable, worthwhile, nv, max_mats, max_stages, n_stages, n_tiles, n_chains, chain_nodes,
+    sum_task_depth, n_states, n_tasks, words, ids, task_off, node_parent, node_sym)."""
+    nw, ni = C.c_int64(0), C.c_int64(0)
+    info = np.zeros(12, np.int64)
+    check(lib().gst_get_level_program(self._h, int(which), None, 0, C.byref(nw), None, 0, C.byref(ni), None, 0, None, None, 0, _ptr(info)))
+    keys = ("usable", "worthwhile", "nv", "max_mats", "max_stages", "n_stages", "n_tiles", "n_chains", "chain_nodes", "sum_task_depth",
+            "n_states", "n_tasks")
+    out = {k: int(v) for k, v in zip(keys, info)}
+    if not out["usable"]:
+        return out
+    words = np.empty(max(nw.value, 1), np.int32); ids = np.empty(max(ni.value, 1), np.int32)
+    off = np.empty(out["n_tasks"] + 1, np.int64)
+    par = np.empty(max(out["n_states"], 1), np.int32); sym = np.empty(max(out["n_states"], 1), np.int32)
+    check(lib().gst_get_level_program(self._h, int(which), _ptr(words), len(words), C.byref(nw), _ptr(ids), len(ids), C.byref(ni),
+                                      _ptr(off), len(off), _ptr(par), _ptr(sym), len(par), _ptr(info)))
+    out.update(words=words[:nw.value], ids=ids[:ni.value], task_off=off, node_parent=par[:out["n_states"]], node_sym=sym[:out["n_states"]])
+    return out
+
+
+Plan.level_program = _level_program
 
 
 def _dirty_programs(self):

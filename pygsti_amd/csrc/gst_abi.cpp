@@ -22,6 +22,7 @@
 #include "gst_internal.hpp"
 #include "gst_kernels.hpp"
 #include "gst_plan.hpp"
+#include "gst_levels.hpp"
 
 namespace {
 
@@ -172,6 +173,18 @@ struct gst_plan {
     DevBuf<double> d_obj_dt, d_obj_ht, d_obj_pc, d_obj_tmp, d_hess_part, d_hess_out;   // objective Hessian blocks
     DevBuf<int32_t> d_dv_colmap;
     bool ana_mfma = true;               // D = 16 analytic mode on the MFMA path (GST_ANALYTIC_MFMA=0: the VALU kernel)
+    // log-depth chain passes (gst_levels.hpp): level programs of the forward and of the reversed plan
+    struct Levels {
+        gst::LevelProgram prog;
+        bool built = false, usable = false, uploaded = false;
+        std::string why;                // why the plan has no level program (diagnostics)
+        DevBuf<int32_t> d_words, d_ids;
+        DevBuf<int64_t> d_task_off;
+        DevBuf<double> d_mats;
+    } lv_fwd, lv_rev;
+    int fast_chains = 1;                // GST_OPT_FAST_CHAINS: 0 never, 1 where the stages are few against the chains (default), 2 always (tests)
+    bool fast_probs = false;            // GST_OPT_FAST_PROBS: gst_fill_probs* through the level pass (<= 1e-10, not bit-exact)
+    bool last_levels = false;           // the last fill took its states from the level pass
     int fd_split = 0;                   // gst_options.fd_split: 0 auto, 1 / 2 / 4 wavefronts per (task, 64 columns) pair
     int n_cus = 256;
     DevBuf<double> d_mm_models, d_mm_raw;   // gst_fill_dprobs_models: perturbed model sets, their probability vectors
@@ -456,6 +469,83 @@ int run_probs(gst_plan* p, double* d_dst, bool fill_cache, int chain_share = 1, 
     HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     p->last_launches++;
     return GST_OK;
+}
+
+// ---- log-depth chain passes (gst_levels.hpp / gst_kernels_levels.hip) -------------------------------------------------------
+int upload_i32(DevBuf<int32_t>& b, const std::vector<int32_t>& v, hipStream_t s);
+
+// The level program of the forward plan (`rev` false) or of the reversed plan, built once on the host (the reversed
+// plan's while its state graph still exists: ensure_reverse).
+void build_levels_host(gst_plan* p, bool rev)
+{
+    gst_plan::Levels& L = rev ? p->lv_rev : p->lv_fwd;
+    if (L.built) return;
+    L.built = true;
+    const gst::HostPlan& h = rev ? p->rev : p->hp;
+    L.why = gst::build_level_program(h, rev ? p->hp.n_effects : 1, L.prog);
+    L.usable = L.why.empty();
+}
+
+int ensure_levels(gst_plan* p, bool rev)
+{
+    gst_plan::Levels& L = rev ? p->lv_rev : p->lv_fwd;
+    const gst::HostPlan& h = rev ? p->rev : p->hp;
+    build_levels_host(p, rev);
+    if (!L.usable || L.uploaded) return GST_OK;
+    int rc;
+    if ((rc = upload_i32(L.d_words, L.prog.words, p->stream))) return rc;
+    if ((rc = upload_i32(L.d_ids, L.prog.ids, p->stream))) return rc;
+    HIP_TRY(L.d_task_off.ensure(L.prog.task_off.size()));
+    HIP_TRY(hipMemcpyAsync(L.d_task_off.p, L.prog.task_off.data(), L.prog.task_off.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(L.d_mats.ensure(std::max<size_t>((size_t)h.n_tasks() * (size_t)std::max(L.prog.max_mats, 1) * 256, 1)));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    L.uploaded = true;
+    return GST_OK;
+}
+
+bool levels_wanted(const gst_plan* p, const gst_plan::Levels& L)
+{
+    return L.usable && (p->fast_chains == 2 || (p->fast_chains == 1 && L.prog.worthwhile));
+}
+
+// Every state of the forward trie into the base-state cache by the level pass, then (d_dst != NULL) the probabilities from
+// the circuits' final states.  The caller has checked levels_wanted(p, p->lv_fwd).
+int run_levels_forward(gst_plan* p, double* d_dst)
+{
+    const gst::HostPlan& h = p->hp;
+    int rc;
+    HIP_TRY(p->d_base_cache.ensure((size_t)h.n_state_ids * h.D));
+    gst::LevelArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.words = p->lv_fwd.d_words.p; a.task_off = p->lv_fwd.d_task_off.p; a.ids = p->lv_fwd.d_ids.p;
+    a.bmats = p->d_gates_t.p; a.starts = p->d_rhos.p; a.cache = p->d_base_cache.p; a.mats = p->lv_fwd.d_mats.p;
+    a.nv = 1; a.max_mats = std::max(p->lv_fwd.prog.max_mats, 1);
+    HIP_TRY(gst::launch_level_pass(a, h.n_tasks(), p->stream));
+    p->last_launches++;
+    if (d_dst) {
+        if (!p->leaf_uploaded) {
+            if ((rc = upload_i32(p->d_circ_leaf, h.circ_leaf, p->stream))) return rc;
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            p->leaf_uploaded = true;
+        }
+        HIP_TRY(gst::launch_probs_from_cache(p->d_base_cache.p, p->d_circ_leaf.p, p->d_eff_ptr.p, p->d_eff_label.p, p->d_eff_dest.p,
+                                             p->d_effects.p, h.n_circuits, h.D, d_dst, p->stream));
+        p->last_launches++;
+    }
+    p->last_levels = true;
+    return GST_OK;
+}
+
+// gst_fill_probs*: the sequential walk (bit-identical to the reference), or with GST_OPT_FAST_PROBS the level pass
+int run_probs_any(gst_plan* p, double* d_dst)
+{
+    p->last_levels = false;
+    if (p->fast_probs && p->hp.D == 16 && p->fast_chains) {
+        int rc = ensure_levels(p, false);
+        if (rc) return rc;
+        if (levels_wanted(p, p->lv_fwd)) return run_levels_forward(p, d_dst);
+    }
+    return run_probs(p, d_dst, false);
 }
 
 struct LaneLayout {
@@ -1015,6 +1105,7 @@ int ensure_reverse(gst_plan* p)
         if ((rc = upload_i32(p->d_blk_ptr, bptr, p->stream))) return rc;
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
+    if (h.D == 16 && p->fast_chains) build_levels_host(p, true);      // (needs the reversed plan's state graph, dropped below)
     // (the host copies of the reversed programs are not needed any more)
     p->rev.prog.clear(); p->rev.prog.shrink_to_fit();
     p->rev.node_parent.clear(); p->rev.node_parent.shrink_to_fit();
@@ -1037,7 +1128,17 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     //  only where the two-cache contraction will run: a plain 1Q Jacobian is launch-bound and takes the single kernel)
     const bool will_fork = p->ana_mfma && (h.D != 4 || p->want_cache_path);
     if (will_fork) HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
-    int rc = run_probs(p, d_base, n_param > 0, will_fork && n_param > 0 ? 2 : 1);        // probabilities + every forward state
+    // Forward states: the sequential walk (bit-identical probabilities), or -- this mode has no ordering contract -- the
+    // log-depth level pass where the plan's germ-power paths make it pay (GST_OPT_FAST_CHAINS; probabilities <= 1e-10)
+    int rc;
+    bool lv_f = false;
+    p->last_levels = false;
+    if (h.D == 16 && will_fork && n_param > 0 && p->fast_chains) {
+        if ((rc = ensure_levels(p, false))) return rc;
+        lv_f = levels_wanted(p, p->lv_fwd);
+    }
+    rc = lv_f ? run_levels_forward(p, d_base)
+              : run_probs(p, d_base, n_param > 0, will_fork && n_param > 0 ? 2 : 1);        // probabilities + every forward state
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
     const bool request_was_cached = p->request_cached(2, param_idx, dest_idx, n_param);
@@ -1135,7 +1236,20 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         // Both chain passes are latency-bound (one wavefront per task, a fraction of the SIMDs): the backward one runs
         // on the second stream beside the forward pass launched above, and the contraction waits for both.
         HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
-        if (D == 64) {                                         // one wavefront per (task, effect), a single launch
+        bool lv_r = false;
+        if (D == 16 && p->fast_chains) {
+            if ((rc = ensure_levels(p, true))) return rc;
+            lv_r = levels_wanted(p, p->lv_rev);
+        }
+        if (lv_r) {                                            // backward states by the level pass: one launch, all effects
+            gst::LevelArgs ra;
+            std::memset(&ra, 0, sizeof(ra));
+            ra.words = p->lv_rev.d_words.p; ra.task_off = p->lv_rev.d_task_off.p; ra.ids = p->lv_rev.d_ids.p;
+            ra.bmats = p->d_gates.p; ra.starts = p->d_effects.p; ra.cache = p->d_rev_cache.p; ra.mats = p->lv_rev.d_mats.p;
+            ra.nv = h.n_effects; ra.max_mats = std::max(p->lv_rev.prog.max_mats, 1);
+            HIP_TRY(gst::launch_level_pass(ra, p->rev.n_tasks(), p->stream2));
+            p->last_launches++;
+        } else if (D == 64) {                                  // one wavefront per (task, effect), a single launch
             w.start0 = 0; w.n_pwaves = h.n_effects;
             HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));
             p->last_launches++;
@@ -1979,7 +2093,7 @@ int gst_fill_probs_dev(gst_plan* p, double* d_out)
     if (rc) return rc;
     if (!d_out) return fail(GST_EINVAL, "d_out is NULL");
     TIME_REC(p, evk0);
-    if ((rc = run_probs(p, d_out, false))) return rc;
+    if ((rc = run_probs_any(p, d_out))) return rc;
     TIME_REC(p, evk1);
     return end_call(p, false);
     });
@@ -1992,7 +2106,7 @@ int gst_fill_probs(gst_plan* p, double* out)
     if (rc) return rc;
     if (!out) return fail(GST_EINVAL, "out is NULL");
     TIME_REC(p, evk0);
-    if ((rc = run_probs(p, p->d_pbase.p, false))) return rc;
+    if ((rc = run_probs_any(p, p->d_pbase.p))) return rc;
     TIME_REC(p, evk1);
     HIP_TRY(hipMemcpyAsync(out, p->d_pbase.p, p->hp.n_elements * 8, hipMemcpyDeviceToHost, p->stream));
     return end_call(p, true);
@@ -2828,6 +2942,7 @@ int gst_get_stats(const gst_plan* p, gst_stats* s)
     s->prog_words = (int64_t)h.prog.size(); s->max_slots = h.max_slots; s->max_depth = h.max_depth;
     s->last_kernel_ms = p->last_kernel_ms; s->last_total_ms = p->last_total_ms; s->last_launches = p->last_launches;
     s->last_fd_form = p->last_fd_form; s->last_fd_aborted = 0;
+    s->last_levels = p->last_levels ? 1 : 0; s->reserved0 = 0;
     if (p->last_fd_form >= 1 && p->d_bin_head.p && p->n_bins > 0 && p->dev_ready) {
         uint32_t flag = 0;                  // the abort flag sits behind the queue heads
         HIP_TRY(hipSetDevice(p->device));
@@ -2868,6 +2983,39 @@ int gst_get_program(const gst_plan* p, uint32_t* words, int64_t cap, int64_t* n_
     });
 }
 
+int gst_get_level_program(const gst_plan* p, int32_t which, int32_t* words, int64_t cap_words, int64_t* n_words, int32_t* ids,
+                          int64_t cap_ids, int64_t* n_ids, int64_t* task_off, int64_t cap_tasks, int32_t* node_parent, int32_t* node_sym,
+                          int64_t cap_nodes, int64_t* info)
+{
+    return guarded([&]() -> int {
+    if (!p || !n_words || !n_ids || !info) return fail(GST_EINVAL, "NULL argument");
+    if (which != 0 && which != 1) return fail(GST_EINVAL, "which: 0 = forward plan, 1 = reversed plan");
+    // (a const plan, possibly without a device: built for this call only, exactly as ensure_levels / ensure_reverse build them)
+    gst::HostPlan R;
+    const gst::HostPlan* h = &p->hp;
+    if (which == 1) {
+        std::string err = gst::build_reverse_plan(p->hp, R, 0, p->hp.D == 16 ? 1 : (p->hp.D == 64 ? 8 : 4));
+        if (!err.empty()) return fail(GST_EINVAL, "reversed plan: " + err);
+        h = &R;
+    }
+    gst::LevelProgram L;
+    const std::string why = gst::build_level_program(*h, which == 1 ? p->hp.n_effects : 1, L);
+    info[0] = why.empty() ? 1 : 0; info[1] = L.worthwhile ? 1 : 0; info[2] = L.nv; info[3] = L.max_mats; info[4] = L.max_stages;
+    info[5] = L.n_stages; info[6] = L.n_tiles; info[7] = L.n_chains; info[8] = L.chain_nodes; info[9] = L.sum_task_depth;
+    info[10] = h->n_state_ids; info[11] = h->n_tasks();
+    *n_words = (int64_t)L.words.size(); *n_ids = (int64_t)L.ids.size();
+    if (!why.empty()) return GST_OK;
+    if (words && cap_words >= *n_words) std::memcpy(words, L.words.data(), sizeof(int32_t) * L.words.size());
+    if (ids && cap_ids >= *n_ids) std::memcpy(ids, L.ids.data(), sizeof(int32_t) * L.ids.size());
+    if (task_off && cap_tasks >= (int64_t)L.task_off.size()) std::memcpy(task_off, L.task_off.data(), sizeof(int64_t) * L.task_off.size());
+    if (node_parent && node_sym && cap_nodes >= h->n_state_ids) {
+        std::memcpy(node_parent, h->node_parent.data(), sizeof(int32_t) * (size_t)h->n_state_ids);
+        std::memcpy(node_sym, h->node_sym.data(), sizeof(int32_t) * (size_t)h->n_state_ids);
+    }
+    return GST_OK;
+    });
+}
+
 int gst_get_dirty_programs(const gst_plan* p, uint32_t* words, int64_t cap, int64_t* n_words, int64_t* prog_off, int64_t cap_progs,
                            int32_t* n_classes)
 {
@@ -2893,6 +3041,13 @@ int gst_set_option(gst_plan* p, int32_t option, int64_t value)
     case GST_OPT_ANALYTIC_KEEP_ZEROS:
         p->ana_keep_zeros = value != 0;
         p->ana_zero_valid = false;            // the promise starts now: the next fill writes every zero
+        return GST_OK;
+    case GST_OPT_FAST_CHAINS:
+        if (value < 0 || value > 2) return fail(GST_EINVAL, "GST_OPT_FAST_CHAINS takes 0, 1 or 2");
+        p->fast_chains = (int)value;
+        return GST_OK;
+    case GST_OPT_FAST_PROBS:
+        p->fast_probs = value != 0;
         return GST_OK;
     default:
         return fail(GST_EINVAL, "unknown option " + std::to_string(option));

@@ -350,4 +350,21 @@ hipError_t launch_fd_from_models(const double* raw, int64_t raw_stride, const do
 hipError_t launch_hess_compose(const double* Ji, const double* J0, int64_t nE, int32_t n2, double eps, double* H, int64_t ld1, int64_t ld2,
                                int64_t row, const int32_t* dest2, hipStream_t stream);
 
+
+// ---- log-depth evaluation of the state tries (gst_levels.hpp, gst_kernels_levels.hip) ---------------------------------
+constexpr int32_t LV_KIND_ROWS_ = 0, LV_KIND_MAT_ = 1, LV_BMAT_IDENT_ = -1;       // (= gst_levels.hpp's LV_KIND_* / LV_BMAT_IDENT)
+struct LevelArgs {
+    const int32_t* words;      // level programs of all tasks (LevelProgram::words)
+    const int64_t* task_off;   // [n_tasks + 1]
+    const int32_t* ids;        // pool of source / destination state ids
+    const double* bmats;       // [n_gates][16][16]: the gates in ROW form (forward: transposed table; backward: row-major table)
+    const double* starts;      // start vectors [start][vector][16] (forward: the state preparations; backward: the effects)
+    double* cache;             // [n_states][16][nv]
+    double* mats;              // [n_tasks][max_mats][16][16] scratch (germ products and their squarings)
+    int32_t nv, max_mats;
+};
+hipError_t launch_level_pass(const LevelArgs& a, int64_t n_tasks, hipStream_t stream);
+hipError_t launch_probs_from_cache(const double* cache, const int32_t* circ_leaf, const int32_t* eff_ptr, const int32_t* eff_label,
+                                   const int32_t* eff_dest, const double* effects, int64_t n_circuits, int D, double* out, hipStream_t stream);
+
 }  // namespace gst

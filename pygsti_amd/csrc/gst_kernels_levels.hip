@@ -1,0 +1,134 @@
+// gst_kernels_levels.hip -- log-depth evaluation of the state tries on the matrix cores (gst_levels.hpp).
+//
+// level_pass_kernel: one workgroup (4 wavefronts) per task.  The task's level program is a sequence of stages; a stage is
+// a list of independent TILES, each  OUT[16 rows] = IN[16 rows] x M  with M a 16 x 16 matrix in "row form" (gate table,
+// identity, or one of the task's scratch matrices: the germ's product and its squarings).  A tile is four
+// v_mfma_f64_16x16x4_f64 (k = 0..15 in steps of 4):
+//     A operand  lane l <- IN[row l & 15][k = 4 s + (l >> 4)]        (a row = `nv`-strided components of a cached state)
+//     B operand  lane l <- M[k = 4 s + (l >> 4)][col l & 15]         (row-major M: one coalesced 512-byte read per s)
+//     D          lane l -> OUT[row (l >> 4) + 4 r][col l & 15], r = 0..3: sixteen lanes store one whole 128-byte state
+// Wavefront w of the workgroup takes tiles w, w + 4, ... of a stage; a barrier (and a device-scope fence) ends it.
+// Every location -- trie state, scratch matrix -- is written exactly ONCE per launch and read only in later stages, so
+// no cache can hold a stale copy of anything.
+//
+// Only the modes without an ordering contract use this (exact derivatives, the opt-in fast probabilities): the sums
+// here are fused and re-associated (matrix powers), <= 1e-13 from the sequential walk on the deepest GST circuits.
+#include "gst_kernels.hpp"
+#include "../../include/gstfwd.h"
+
+namespace gst {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+template <int NV>
+__global__ __launch_bounds__(256) void level_pass_kernel(const LevelArgs a)
+{
+    constexpr int D = 16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int64_t task = blockIdx.x;
+    const int32_t* __restrict__ w = a.words + a.task_off[task];
+    double* __restrict__ mats = a.mats + task * (int64_t)a.max_mats * (D * D);
+    const int n_stages = w[0];
+    w += 1;
+    for (int s = 0; s < n_stages; s++) {
+        const int nt = w[0];
+        const int32_t* tw = w + 1;
+        for (int t = wv; t < nt; t += 4) {
+            const int32_t w0 = tw[4 * t], mref = tw[4 * t + 1], wa = tw[4 * t + 2], wb = tw[4 * t + 3];
+            const int kind = w0 & 255, n_nodes = w0 >> 8;
+            // ---- A operand: row i of the input, components 4 s4 + kk ----
+            const double* sp;
+            int64_t cs = 1;
+            bool valid = true;
+            if (kind == LV_KIND_MAT_) {
+                sp = (wa >= 0 ? a.bmats + (int64_t)wa * (D * D) : mats + (int64_t)(-(wa + 2)) * (D * D)) + i * D;
+            } else {
+                const int node = i / NV, v = i % NV;
+                valid = node < n_nodes;
+                const int32_t id = valid ? a.ids[wa + node] : 0;
+                if (id >= 0) { sp = a.cache + (int64_t)id * (D * NV) + v; cs = NV; }
+                else sp = a.starts + ((int64_t)(-(id + 1)) * NV + v) * D;
+            }
+            double av[4], bv[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) av[s4] = valid ? sp[(int64_t)(4 * s4 + kk) * cs] : 0.0;
+            // ---- B operand: M[4 s4 + kk][i] ----
+            if (mref == LV_BMAT_IDENT_) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) bv[s4] = (4 * s4 + kk == i) ? 1.0 : 0.0;
+            } else {
+                const double* bp = mref >= 0 ? a.bmats + (int64_t)mref * (D * D) : mats + (int64_t)(-(mref + 2)) * (D * D);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) bv[s4] = bp[(4 * s4 + kk) * D + i];
+            }
+            d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+            // ---- D: out[row kk + 4 r][component i] ----
+            if (kind == LV_KIND_MAT_) {
+                double* dp = mats + (int64_t)wb * (D * D);
+#pragma unroll
+                for (int r = 0; r < 4; r++) dp[(kk + 4 * r) * D + i] = acc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = kk + 4 * r, node = row / NV, v = row % NV;
+                    if (node < n_nodes) {
+                        const int32_t id = a.ids[wb + node];
+                        a.cache[(int64_t)id * (D * NV) + (int64_t)i * NV + v] = acc[r];
+                    }
+                }
+            }
+        }
+        w = tw + 4 * nt;
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+hipError_t launch_level_pass(const LevelArgs& a, int64_t n_tasks, hipStream_t stream)
+{
+    if (n_tasks <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)n_tasks), block(256);
+    switch (a.nv) {
+    case 1: hipLaunchKernelGGL(level_pass_kernel<1>, grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(level_pass_kernel<2>, grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(level_pass_kernel<4>, grid, block, 0, stream, a); break;
+    case 8: hipLaunchKernelGGL(level_pass_kernel<8>, grid, block, 0, stream, a); break;
+    case 16: hipLaunchKernelGGL(level_pass_kernel<16>, grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// Probabilities of every circuit from its cached final state: out[eff_dest[x]] = effects[eff_label[x]] . cache[leaf(c)]
+// (one thread per circuit; the level pass emits nothing itself).
+__global__ __launch_bounds__(256) void probs_from_cache_kernel(const double* __restrict__ cache, const int32_t* __restrict__ circ_leaf,
+                                                               const int32_t* __restrict__ eff_ptr, const int32_t* __restrict__ eff_label,
+                                                               const int32_t* __restrict__ eff_dest, const double* __restrict__ effects,
+                                                               int64_t n_circuits, int D, double* __restrict__ out)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_circuits) return;
+    const double* f = cache + (int64_t)circ_leaf[c] * D;
+    for (int32_t x = eff_ptr[c]; x < eff_ptr[c + 1]; x++) {
+        const double* e = effects + (int64_t)eff_label[x] * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; k++) acc = __builtin_fma(e[k], f[k], acc);
+        out[eff_dest[x]] = acc;
+    }
+}
+
+hipError_t launch_probs_from_cache(const double* cache, const int32_t* circ_leaf, const int32_t* eff_ptr, const int32_t* eff_label,
+                                   const int32_t* eff_dest, const double* effects, int64_t n_circuits, int D, double* out, hipStream_t stream)
+{
+    if (n_circuits <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(probs_from_cache_kernel, dim3((unsigned)((n_circuits + 255) / 256)), dim3(256), 0, stream, cache, circ_leaf, eff_ptr,
+                       eff_label, eff_dest, effects, n_circuits, D, out);
+    return hipGetLastError();
+}
+
+}  // namespace gst

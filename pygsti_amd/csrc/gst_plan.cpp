@@ -333,7 +333,7 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
 
     lap_("lcp+cuts");
     // --- compile each task ----------------------------------------------------------------------------
-    struct Built { std::vector<uint32_t> words; int64_t applies; };
+    struct Built { std::vector<uint32_t> words; int64_t applies; int64_t node0; int32_t nodes; };
     std::vector<Built> built;
     built.reserve(cuts.size());
     P.max_slots = 0;
@@ -348,6 +348,7 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
         if (max_slots > 0) tc.slot_limit = max_slots;
         tc.node_base = P.n_state_ids;
         tc.build(order, lcp, cuts[t], cuts[t + 1]);
+        b.node0 = tc.node_base; b.nodes = (int32_t)tc.nodes.size();
         P.n_state_ids += (int64_t)tc.nodes.size();
         // state-id graph for the analytic (backward) sweeps: parent id and symbol of every state
         P.node_parent.resize(P.n_state_ids, -1);
@@ -370,10 +371,12 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots)
     // heaviest first: the device takes tasks in launch order, long ones should not start last
     std::stable_sort(built.begin(), built.end(), [](const Built& a, const Built& b) { return a.applies > b.applies; });
     P.prog.clear(); P.task_off.assign(1, 0); P.task_applies.clear();
+    P.task_node0.clear(); P.task_nodes.clear();
     for (auto& b : built) {
         P.prog.insert(P.prog.end(), b.words.begin(), b.words.end());
         P.task_off.push_back((int64_t)P.prog.size());
         P.task_applies.push_back(b.applies);
+        P.task_node0.push_back(b.node0); P.task_nodes.push_back(b.nodes);
     }
     return "";
 }

@@ -39,6 +39,8 @@ struct HostPlan {
     int64_t n_state_ids = 0;   // NODE marker ids: one per task-trie node (size of the base-state cache)
     std::vector<int32_t> node_parent, node_sym;   // [n_state_ids]: parent state id (-1: a rho state) and gate/rho index
     std::vector<int32_t> circ_leaf;               // [n_circuits]: state id of each circuit's final state
+    std::vector<int64_t> task_node0;              // [n_tasks + 1]: the state ids of task t are task_node0[t] ... + task_nodes[t] - 1
+    std::vector<int32_t> task_nodes;              //   (its first id is the task's virtual root: no state of its own)
 
     int64_t n_tasks() const { return (int64_t)task_off.size() - 1; }
 };
