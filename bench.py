@@ -490,8 +490,14 @@ def main():
                          "set_params_ms": 1e3 * t_set,
                          "analytic_ms_per_step": None if dta is None else 1e3 * dta,
                          "analytic_elements_per_s": None if dta is None else nE_local * nPl / dta,
-                         "note": "bulk_fill_dprobs of the CPTPLND-parameterised model (FD eps=1e-7, Map-simulator semantics, <=1e-8 vs the "
-                                 "reference): every column's changed member assembled and exponentiated on the device (no host to_dense per "
+                         "parity": "FD columns vs the reference's Map simulator: <= 1e-8 only for circuits of depth <= 16 (6.9e-9); 5e-8 at depth "
+                                   "41-80 and 7e-8 at depth 1,030 (2Q germ-power families), 1.2e-7 at depth 81-160 (1Q L<=128 design) -- the "
+                                   "perturbed member's exponential (scaled Taylor here, scipy's Pade there) differs in the last bit and the "
+                                   "quotient amplifies it by occurrences/eps; the EXACT route (`analytic_ms_per_step`, the adapter's default "
+                                   "for these models) agrees with the Matrix simulator to 1.2e-11 at depth 1,030 "
+                                   "(profiles/r04_cptplnd_depth_profile_*.json, tests/test_gpu_lindblad.py)",
+                         "note": "bulk_fill_dprobs of the CPTPLND-parameterised model (FD eps=1e-7, Map-simulator semantics): every column's "
+                                 "changed member assembled and exponentiated on the device (no host to_dense per "
                                  "column), walks share the base pass's states (gates: dirty programs, 4 columns per wavefront; the preparation: 64 per wavefront on the lane-per-model kernel), POVM columns from "
                                  "the cached final states; round 2's form of the same Jacobian (host-stepped dense model sets, one "
                                  "independent walk per (program, model)) took 580 ms; secondary figure, not `value`"}

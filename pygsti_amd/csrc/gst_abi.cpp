@@ -179,7 +179,7 @@ struct gst_plan {
         bool built = false, usable = false, uploaded = false;
         std::string why;                // why the plan has no level program (diagnostics)
         DevBuf<int32_t> d_words, d_ids;
-        DevBuf<int64_t> d_task_off;
+        DevBuf<int64_t> d_task_off, d_ids_off;
         DevBuf<double> d_mats;
     } lv_fwd, lv_rev;
     int fast_chains = 1;                // GST_OPT_FAST_CHAINS: 0 never, 1 where the stages are few against the chains (default), 2 always (tests)
@@ -201,6 +201,7 @@ struct gst_plan {
     DevBuf<double> d_lb_statics, d_lb_term_re, d_lb_term_im, d_lb_theta, d_lb_base, d_lb_gates_rm, d_lb_pert;
     DevBuf<int32_t> d_lb_waves;             // walk_pert_kernel's wave tables: kind | obj | n_eff | col0 | ncols | col_dest
     int32_t lb_n_pwaves = 0, lb_n_zero = 0;
+    int64_t lb_n_sets = 0;                  // perturbed member sets of the cached request (columns of parameters that belong to a member)
     int64_t lb_n_items = 0;
     std::vector<int32_t> lb_povm_cols;      // per POVM member with requested columns: obj, n_eff, col0, ncols
     gst::DirtyPrograms dirty;               // gst::build_dirty_programs, once per plan
@@ -497,10 +498,21 @@ int ensure_levels(gst_plan* p, bool rev)
     if ((rc = upload_i32(L.d_ids, L.prog.ids, p->stream))) return rc;
     HIP_TRY(L.d_task_off.ensure(L.prog.task_off.size()));
     HIP_TRY(hipMemcpyAsync(L.d_task_off.p, L.prog.task_off.data(), L.prog.task_off.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(L.d_ids_off.ensure(L.prog.task_ids_off.size()));
+    HIP_TRY(hipMemcpyAsync(L.d_ids_off.p, L.prog.task_ids_off.data(), L.prog.task_ids_off.size() * 8, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(L.d_mats.ensure(std::max<size_t>((size_t)h.n_tasks() * (size_t)std::max(L.prog.max_mats, 1) * 256, 1)));
     HIP_TRY(hipStreamSynchronize(p->stream));
     L.uploaded = true;
     return GST_OK;
+}
+
+void level_args(const gst_plan::Levels& L, gst::LevelArgs& a)
+{
+    std::memset(&a, 0, sizeof(a));
+    a.words = L.d_words.p; a.task_off = L.d_task_off.p; a.ids = L.d_ids.p; a.task_ids_off = L.d_ids_off.p; a.mats = L.d_mats.p;
+    a.nv = L.prog.nv; a.max_mats = std::max(L.prog.max_mats, 1);
+    a.stage_lds = L.prog.max_task_ints * 4 <= 60 * 1024 ? 1 : 0;       // (a plan with huger tasks reads its program from memory)
+    a.lds_ints = (int32_t)std::min<int64_t>(L.prog.max_task_ints, 15 * 1024);
 }
 
 bool levels_wanted(const gst_plan* p, const gst_plan::Levels& L)
@@ -516,10 +528,8 @@ int run_levels_forward(gst_plan* p, double* d_dst)
     int rc;
     HIP_TRY(p->d_base_cache.ensure((size_t)h.n_state_ids * h.D));
     gst::LevelArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.words = p->lv_fwd.d_words.p; a.task_off = p->lv_fwd.d_task_off.p; a.ids = p->lv_fwd.d_ids.p;
-    a.bmats = p->d_gates_t.p; a.starts = p->d_rhos.p; a.cache = p->d_base_cache.p; a.mats = p->lv_fwd.d_mats.p;
-    a.nv = 1; a.max_mats = std::max(p->lv_fwd.prog.max_mats, 1);
+    level_args(p->lv_fwd, a);
+    a.bmats = p->d_gates_t.p; a.starts = p->d_rhos.p; a.cache = p->d_base_cache.p;
     HIP_TRY(gst::launch_level_pass(a, h.n_tasks(), p->stream));
     p->last_launches++;
     if (d_dst) {
@@ -1105,7 +1115,7 @@ int ensure_reverse(gst_plan* p)
         if ((rc = upload_i32(p->d_blk_ptr, bptr, p->stream))) return rc;
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
-    if (h.D == 16 && p->fast_chains) build_levels_host(p, true);      // (needs the reversed plan's state graph, dropped below)
+    if (h.D == 16) build_levels_host(p, true);      // (needs the reversed plan's state graph, dropped below; whatever GST_OPT_FAST_CHAINS says NOW)
     // (the host copies of the reversed programs are not needed any more)
     p->rev.prog.clear(); p->rev.prog.shrink_to_fit();
     p->rev.node_parent.clear(); p->rev.node_parent.shrink_to_fit();
@@ -1243,10 +1253,8 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         }
         if (lv_r) {                                            // backward states by the level pass: one launch, all effects
             gst::LevelArgs ra;
-            std::memset(&ra, 0, sizeof(ra));
-            ra.words = p->lv_rev.d_words.p; ra.task_off = p->lv_rev.d_task_off.p; ra.ids = p->lv_rev.d_ids.p;
-            ra.bmats = p->d_gates.p; ra.starts = p->d_effects.p; ra.cache = p->d_rev_cache.p; ra.mats = p->lv_rev.d_mats.p;
-            ra.nv = h.n_effects; ra.max_mats = std::max(p->lv_rev.prog.max_mats, 1);
+            level_args(p->lv_rev, ra);
+            ra.bmats = p->d_gates.p; ra.starts = p->d_effects.p; ra.cache = p->d_rev_cache.p;
             HIP_TRY(gst::launch_level_pass(ra, p->rev.n_tasks(), p->stream2));
             p->last_launches++;
         } else if (D == 64) {                                  // one wavefront per (task, effect), a single launch
@@ -1476,15 +1484,18 @@ int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int
         p->cached_kind = 0;
         // columns grouped by member, G per wavefront
         std::vector<std::vector<int64_t>> by_member((size_t)L.n_members);
+        std::vector<int64_t> no_member;
         for (int64_t c = 0; c < n_param; c++) {
             const int64_t gp = param_idx[c];
             int m = -1;
             for (int mm = 0; mm < L.n_members; mm++)
                 if (gp >= L.param0[(size_t)mm] && gp < L.param0[(size_t)mm] + L.n_par[(size_t)mm]) m = mm;
-            if (m < 0) return fail(GST_EINVAL, "parameter " + std::to_string(gp) + " belongs to no Lindblad member");
             const int64_t dst = dest_idx ? dest_idx[c] : c;
             if (dst < 0 || dst >= ld) return fail(GST_EINVAL, "destination column out of range");
-            by_member[(size_t)m].push_back(c);
+            // a parameter of no member of THIS plan (an object the atom never applies, cf. GST_KIND_NONE): the reference's
+            // step changes no probability of the atom -- the column is an exact zero, written by the zero-fill pass
+            if (m < 0) no_member.push_back(c);
+            else by_member[(size_t)m].push_back(c);
         }
         std::vector<int64_t> set_param;
         std::vector<int32_t> wk, wo, wn, w0, wc, cdest, zero_dest;
@@ -1526,6 +1537,11 @@ int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int
                     if (!povm) zero_dest.push_back(dst);
                 }
             }
+        }
+        p->lb_n_sets = (int64_t)set_param.size();          // (member-less columns come last: no perturbed set is built for them)
+        for (int64_t c : no_member) {
+            const int32_t dst = (int32_t)(dest_idx ? dest_idx[c] : c);
+            cdest.push_back(dst); zero_dest.push_back(dst);
         }
         std::sort(zero_dest.begin(), zero_dest.end());
         const int32_t n_pw = (int32_t)wk.size();
@@ -1579,7 +1595,7 @@ int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int
     gst::LbArgs b;
     lb_args(p, b);
     b.set_param = p->d_lb_setparam.p; b.sets = p->d_lb_pert.p; b.set_stride = (int64_t)D * D; b.member_only = 1; b.eps = eps;
-    HIP_TRY(gst::launch_lindblad_build(D, b, n_param, p->stream));
+    HIP_TRY(gst::launch_lindblad_build(D, b, p->lb_n_sets, p->stream));
     gst::PertArgs a;
     std::memset(&a, 0, sizeof(a));
     a.prog = p->d_dirty_words.p; a.prog_off = p->d_dirty_off.p;

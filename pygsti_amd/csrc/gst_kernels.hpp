@@ -362,6 +362,8 @@ struct LevelArgs {
     double* cache;             // [n_states][16][nv]
     double* mats;              // [n_tasks][max_mats][16][16] scratch (germ products and their squarings)
     int32_t nv, max_mats;
+    const int64_t* task_ids_off;   // [n_tasks + 1] (LevelProgram::task_ids_off)
+    int32_t stage_lds, lds_ints;   // 1: a task's words + ids (at most lds_ints of them) are staged in LDS
 };
 hipError_t launch_level_pass(const LevelArgs& a, int64_t n_tasks, hipStream_t stream);
 hipError_t launch_probs_from_cache(const double* cache, const int32_t* circ_leaf, const int32_t* eff_ptr, const int32_t* eff_label,

@@ -7,7 +7,7 @@
 //     A operand  lane l <- IN[row l & 15][k = 4 s + (l >> 4)]        (a row = `nv`-strided components of a cached state)
 //     B operand  lane l <- M[k = 4 s + (l >> 4)][col l & 15]         (row-major M: one coalesced 512-byte read per s)
 //     D          lane l -> OUT[row (l >> 4) + 4 r][col l & 15], r = 0..3: sixteen lanes store one whole 128-byte state
-// Wavefront w of the workgroup takes tiles w, w + 4, ... of a stage; a barrier (and a device-scope fence) ends it.
+// Wavefront w of the workgroup takes tiles w, w + 4, ... of a stage; a workgroup-scope fence and a barrier end it.
 // Every location -- trie state, scratch matrix -- is written exactly ONCE per launch and read only in later stages, so
 // no cache can hold a stale copy of anything.
 //
@@ -28,7 +28,21 @@ __global__ __launch_bounds__(256) void level_pass_kernel(const LevelArgs a)
     const int i = lane & 15, kk = lane >> 4;
     const int64_t task = blockIdx.x;
     const int32_t* __restrict__ w = a.words + a.task_off[task];
+    const int32_t* __restrict__ ids = a.ids;
     double* __restrict__ mats = a.mats + task * (int64_t)a.max_mats * (D * D);
+    if (a.stage_lds) {
+        // the task's program and its id lists into LDS, once: every stage otherwise starts with two dependent trips to
+        // memory (tile words, then ids) before the first operand can be requested
+        extern __shared__ int32_t lds[];
+        const int nw = (int)(a.task_off[task + 1] - a.task_off[task]);
+        const int64_t i0 = a.task_ids_off[task];
+        const int ni = (int)(a.task_ids_off[task + 1] - i0);
+        for (int k = tid; k < nw; k += 256) lds[k] = w[k];
+        for (int k = tid; k < ni; k += 256) lds[nw + k] = a.ids[i0 + k];
+        __syncthreads();
+        w = lds;
+        ids = lds + nw - i0;              // (tile words hold GLOBAL offsets into the id pool)
+    }
     const int n_stages = w[0];
     w += 1;
     for (int s = 0; s < n_stages; s++) {
@@ -46,7 +60,7 @@ __global__ __launch_bounds__(256) void level_pass_kernel(const LevelArgs a)
             } else {
                 const int node = i / NV, v = i % NV;
                 valid = node < n_nodes;
-                const int32_t id = valid ? a.ids[wa + node] : 0;
+                const int32_t id = valid ? ids[wa + node] : 0;
                 if (id >= 0) { sp = a.cache + (int64_t)id * (D * NV) + v; cs = NV; }
                 else sp = a.starts + ((int64_t)(-(id + 1)) * NV + v) * D;
             }
@@ -75,15 +89,19 @@ __global__ __launch_bounds__(256) void level_pass_kernel(const LevelArgs a)
                 for (int r = 0; r < 4; r++) {
                     const int row = kk + 4 * r, node = row / NV, v = row % NV;
                     if (node < n_nodes) {
-                        const int32_t id = a.ids[wb + node];
+                        const int32_t id = ids[wb + node];
                         a.cache[(int64_t)id * (D * NV) + (int64_t)i * NV + v] = acc[r];
                     }
                 }
             }
         }
         w = tw + 4 * nt;
-        __threadfence();
+        // A workgroup lives on one CU of one XCD: workgroup scope is all the ordering the next stage needs (s_waitcnt
+        // vmcnt(0) + s_barrier).  A device-scope fence here writes back the XCD's whole L2 (the XCDs' L2s are not coherent
+        // with each other): measured, the two passes took 8.7 ms instead of well under one.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
 
@@ -92,12 +110,13 @@ hipError_t launch_level_pass(const LevelArgs& a, int64_t n_tasks, hipStream_t st
     if (n_tasks <= 0) return hipSuccess;
     (void)hipGetLastError();
     const dim3 grid((unsigned)n_tasks), block(256);
+    const size_t lds = a.stage_lds ? (size_t)a.lds_ints * 4 : 0;
     switch (a.nv) {
-    case 1: hipLaunchKernelGGL(level_pass_kernel<1>, grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(level_pass_kernel<2>, grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(level_pass_kernel<4>, grid, block, 0, stream, a); break;
-    case 8: hipLaunchKernelGGL(level_pass_kernel<8>, grid, block, 0, stream, a); break;
-    case 16: hipLaunchKernelGGL(level_pass_kernel<16>, grid, block, 0, stream, a); break;
+    case 1: hipLaunchKernelGGL(level_pass_kernel<1>, grid, block, lds, stream, a); break;
+    case 2: hipLaunchKernelGGL(level_pass_kernel<2>, grid, block, lds, stream, a); break;
+    case 4: hipLaunchKernelGGL(level_pass_kernel<4>, grid, block, lds, stream, a); break;
+    case 8: hipLaunchKernelGGL(level_pass_kernel<8>, grid, block, lds, stream, a); break;
+    case 16: hipLaunchKernelGGL(level_pass_kernel<16>, grid, block, lds, stream, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -9,7 +9,7 @@ namespace gst {
 namespace {
 
 constexpr int MAX_PERIOD = 16;     // longest germ recognised (gates)
-constexpr int MIN_CHAIN = 32;      // shortest periodic path worth a doubling schedule (gates)
+constexpr int MIN_CHAIN = 12;      // shortest periodic path given a doubling schedule (gates; at least three periods)
 
 struct Tile { int32_t kind, n_nodes, mref, a, b; };
 
@@ -33,6 +33,7 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
     const int per_tile = 16 / nv;
     const int64_t nT = P.n_tasks();
     out.task_off.assign(1, 0);
+    out.task_ids_off.assign(1, 0);
     std::vector<int32_t> par, sym, depth, ready, chain_of, pos_in, run, anc, best_len, best_m;
     std::vector<uint32_t> cont;
     std::vector<uint8_t> covered;
@@ -93,7 +94,7 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
                     // some child matches period m: the run continues only if that child's run is rm + 1 (always true when it matches)
                     goes_on = true;
                 }
-                if (!goes_on && len >= MIN_CHAIN && len >= 2 * m) cands.push_back(Cand{len, m, i});
+                if (!goes_on && len >= MIN_CHAIN && len >= 3 * m) cands.push_back(Cand{len, m, i});
             }
         }
         std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) {
@@ -108,7 +109,7 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
             // the uncovered tail of the run (walking up from its end)
             int32_t T = 0, v = c.end;
             while (T < c.len && !covered[(size_t)v]) { T++; v = par[(size_t)v]; }
-            if (T < MIN_CHAIN || T < 2 * c.m) continue;
+            if (T < MIN_CHAIN || T < 3 * c.m) continue;
             Chain ch;
             ch.m = c.m;
             ch.nodes.resize((size_t)T);
@@ -153,6 +154,8 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
             while ((1 << K) < q + 1) K++;
             // matrices: pow[k] = (M(g0) ... M(g_{m-1}))^(2^k)
             std::vector<int32_t> pow_ref((size_t)K), t_pow((size_t)K);
+            std::vector<int32_t> prefix_ref((size_t)m + 1, LV_BMAT_IDENT);       // prefix_ref[s] = M(g0) ... M(g_{s-1})
+            prefix_ref[1] = g[0];
             if (m == 1) { pow_ref[0] = g[0]; t_pow[0] = -1; }
             else {
                 int32_t prev = g[0];
@@ -160,6 +163,7 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
                     const int32_t slot = n_slots++;
                     stage_ref(s - 1).push_back(Tile{LV_KIND_MAT, 16, g[(size_t)s], prev, slot});
                     prev = lv_slot_ref(slot);
+                    prefix_ref[(size_t)s + 1] = prev;
                 }
                 pow_ref[0] = prev; t_pow[0] = m - 2;
             }
@@ -176,15 +180,24 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
                 if (cnt <= 0) break;
                 st = std::max(st, t_pow[(size_t)k]) + 1;
                 src.clear(); dst.clear();
-                for (int32_t j = 0; j < cnt; j++) { src.push_back(pos_id(j * m)); dst.push_back(pos_id((have + j) * m)); }
+                for (int32_t j = 0; j < cnt; j++) {
+                    src.push_back(pos_id(j * m)); dst.push_back(pos_id((have + j) * m));
+                    ready[(size_t)ch.nodes[(size_t)((have + j) * m) - 1]] = st;       // (what hangs off an early node need not wait for the whole chain)
+                }
                 rows_tile(st, pow_ref[(size_t)k], src, dst);
             }
-            // the positions inside a period, all periods at once
-            for (int32_t s = 1; s < m; s++) {
-                st++;
-                src.clear(); dst.clear();
-                for (int32_t r = 0; r * m + s <= T; r++) { src.push_back(pos_id(r * m + s - 1)); dst.push_back(pos_id(r * m + s)); }
-                rows_tile(st, g[(size_t)s - 1], src, dst);
+            // the positions inside a period: F[r m + s] = X_r x (M(g0) ... M(g_{s-1})), every r and every s in ONE stage (the
+            // prefix products are the intermediates of the germ's product chain, ready since stage m - 2 <= st)
+            if (m > 1) {
+                st = std::max(st, m - 2) + 1;
+                for (int32_t s = 1; s < m; s++) {
+                    src.clear(); dst.clear();
+                    for (int32_t r = 0; r * m + s <= T; r++) {
+                        src.push_back(pos_id(r * m)); dst.push_back(pos_id(r * m + s));
+                        ready[(size_t)ch.nodes[(size_t)(r * m + s) - 1]] = st;
+                    }
+                    rows_tile(st, prefix_ref[(size_t)s], src, dst);
+                }
             }
             ch.done = st;
         };
@@ -198,8 +211,7 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
             const int32_t ci = chain_of[(size_t)i];
             if (ci >= 0) {
                 Chain& ch = chains[(size_t)ci];
-                if (ch.done < 0) schedule_chain(ch);
-                ready[(size_t)i] = ch.done;
+                if (ch.done < 0) schedule_chain(ch);      // (sets `ready` of every node of the chain)
                 continue;
             }
             const int32_t st = ready[(size_t)par[(size_t)i]] + 1;
@@ -229,6 +241,8 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
         out.max_stages = std::max(out.max_stages, ns);
         out.max_mats = std::max(out.max_mats, n_slots);
         out.task_off.push_back((int64_t)out.words.size());
+        out.task_ids_off.push_back((int64_t)out.ids.size());
+        out.max_task_ints = std::max<int64_t>(out.max_task_ints, (int64_t)(out.words.size() - w0) + (out.task_ids_off.back() - out.task_ids_off[out.task_ids_off.size() - 2]));
         if (out.words.size() > 0x7fff0000u || out.ids.size() > 0x7fff0000u) return "level program too large";
     }
     out.worthwhile = out.n_stages * 4 <= out.sum_task_depth;

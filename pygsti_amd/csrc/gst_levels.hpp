@@ -47,6 +47,8 @@ struct LevelProgram {
     std::vector<int64_t> task_off;
     std::vector<int32_t> words;
     std::vector<int32_t> ids;
+    std::vector<int64_t> task_ids_off;   // [n_tasks + 1]: task t's ids are ids[task_ids_off[t] .. task_ids_off[t + 1]) (tile offsets stay global)
+    int64_t max_task_ints = 0;           // most words + ids of one task (what the kernel stages in LDS)
     int32_t max_mats = 0;          // scratch matrices a task needs at most (every slot is written ONCE per pass)
     int32_t max_stages = 0;
     int64_t n_stages = 0, n_tiles = 0, n_chains = 0, chain_nodes = 0, n_nodes = 0;

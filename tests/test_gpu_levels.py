@@ -61,6 +61,12 @@ def test_analytic_jacobian_through_level_passes_deep_families(oracle_built):
     assert seq.stats()["last_levels"] == 0
     assert_bitwise(pr2, fx["probs"], "sequential analytic fill: the base pass's probabilities")
     assert np.abs(J - J2).max() < 1e-10, np.abs(J - J2).max()
+    # switching the option on a plan whose reversed plan already exists (its level program is built with it, whatever the
+    # option said at that moment: a late switch once read a state graph that had been dropped)
+    seq.set_option(_lib.OPT_FAST_CHAINS, 1)
+    J3 = seq.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    assert seq.stats()["last_levels"] == 1
+    assert np.array_equal(J3, J)
 
 
 def test_forced_level_passes_on_a_design_fixture_jacobian_and_hessian():
