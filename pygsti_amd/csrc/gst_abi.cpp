@@ -134,14 +134,14 @@ struct gst_plan {
     DevBuf<int64_t> d_rtask_off, d_pos_ptr;
     DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order, d_circ_partner, d_pair_common;
     DevBuf<int32_t> d_blk_f1, d_blk_f2, d_blk_r, d_blk_ptr;   // two-circuit items as one stream of 4-application blocks (ensure_reverse)
-    bool ana_stream = true;             // GST_ANALYTIC_STREAM=0: two-circuit items gate by gate (tail, then the two prefixes)
-    bool ana_pairs = true;              // GST_ANALYTIC_PAIRS=0: one circuit per work item in the D = 16 contraction
-    bool ana_germ_order = true;         // GST_ANALYTIC_GERM_ORDER=0: pure suffix order of the work items
+    static constexpr bool ana_stream = true;       // two-circuit items as one block stream (the gate-by-gate form remains for > 63 gates)
+    static constexpr bool ana_pairs = true;        // two-circuit work items in the D = 16 contraction
+    static constexpr bool ana_germ_order = true;   // germ-major order of the work items
     bool ana_keep_zeros = false;        // gst_set_option(GST_OPT_ANALYTIC_KEEP_ZEROS)
     const void* ana_zero_out = nullptr; // destination of the last stream-form analytic Jacobian, its leading dimension
     int64_t ana_zero_ld = 0;
     bool ana_zero_valid = false;
-    bool ana_group_fetch = true;        // GST_ANALYTIC_GROUP=0: every wavefront of the D = 16 contraction pulls its items alone
+    static constexpr bool ana_group_fetch = true;  // the four wavefronts of a workgroup take four consecutive items together
     DevBuf<double> d_rev_cache;
     DevBuf<uint32_t> d_work_counter, d_range_begin;
     bool want_cache_path = false;       // set by the Hessian driver around its set-up Jacobian call
@@ -172,7 +172,7 @@ struct gst_plan {
     DevBuf<double> d_dv_deriv, d_jelem;
     DevBuf<double> d_obj_dt, d_obj_ht, d_obj_pc, d_obj_tmp, d_hess_part, d_hess_out;   // objective Hessian blocks
     DevBuf<int32_t> d_dv_colmap;
-    bool ana_mfma = true;               // D = 16 analytic mode on the MFMA path (GST_ANALYTIC_MFMA=0: the VALU kernel)
+    static constexpr bool ana_mfma = true;         // D = 16 / 64 analytic mode on the MFMA path (the one-kernel VALU form serves D = 4 and gate sets beyond LDS)
     // log-depth chain passes (gst_levels.hpp): level programs of the forward and of the reversed plan
     struct Levels {
         gst::LevelProgram prog;
@@ -212,8 +212,8 @@ struct gst_plan {
     DevBuf<int32_t> d_lbr_lane[4];          // preparation columns on the lane-per-model kernel: col | kind | obj | elem (= model set)
     DevBuf<uint32_t> d_lbr_order;           // ... and their launch order (longest tasks first)
     int32_t lbr_n_waves = 0;
-    bool lb_rho_lanes = true;               // GST_LB_RHO_LANES=0: preparation columns through walk_pert_kernel like the gates'
-    bool lb_share = true;                   // GST_LB_SHARE=0: every (program, perturbed model) pair walked on its own (round-2 form)
+    static constexpr bool lb_rho_lanes = true;               // preparation columns of a Lindblad FD Jacobian on the lane-per-model kernel
+    static constexpr bool lb_share = true;                   // Lindblad FD walks share the base pass's states (independent walks remain the fall-back for plans the shared kernel does not fit)
     DevBuf<int32_t> d_mm_dest;
     DevBuf<double> d_obj_part;          // per-block partial sums of the objective terms
     DevBuf<uint32_t> d_block_order;     // FD launch order of the cached request (expensive (task, wavefront) pairs first)
@@ -223,22 +223,22 @@ struct gst_plan {
     DevBuf<uint64_t> d_trace;           // GST_FD_TRACE records
     int32_t n_bins = 0;
     bool have_bins = false;
-    bool fd_persist = true;             // GST_FD_PERSIST=0: one workgroup per pair, placed by the dispatcher
-    bool fd_persist_always = false;     // GST_FD_PERSIST=2: per-SIMD queues whatever the number of pairs
-    bool fd_fused = true;               // GST_FD_FUSED=0: launch-bound plans keep the separate base pass
-    bool host_direct = true;            // GST_HOST_DIRECT=0: page-locked destinations are filled by a copy, not by the kernel
+    bool fd_persist = true;             // GST_TEST_FORCE persist=0: one workgroup per pair, placed by the dispatcher
+    bool fd_persist_always = false;     // persist=2: per-SIMD queues whatever the number of pairs
+    bool fd_fused = true;               // fused=0: launch-bound plans keep the separate base pass
+    bool host_direct = true;            // host_direct=0: page-locked destinations are filled by a copy, not by the kernel
     int64_t host_direct_min_cols = 32;  // (narrower column windows would cross PCIe in segments of less than 256 bytes; 64 until round 3 --
                                         //  the 1Q model's 60 columns were just below it: blocking fill 103 -> 81 us with the kernel's direct stores)
-    int fd_handover = 1;                // GST_FD_HANDOVER: 0 never cut a walk, 1 cut to balance the per-SIMD queues, 2 cut every walk
-    bool fd_overlap = true;             // GST_FD_OVERLAP=0: the persistent FD launch keeps the separate base pass in front of it
-    double test_cache_limit = 0;        // GST_TEST_CACHE_LIMIT (bytes; tests): stands in for the 4 GB of 32-bit cache offsets
-    bool jtj_sparse = true;             // GST_JTJ_SPARSE=0: J^T J multiplies every panel (round-2 form)
+    int fd_handover = 1;                // (GST_TEST_FORCE handover=) 0 never cut a walk, 1 cut to balance the per-SIMD queues, 2 cut every walk
+    bool fd_overlap = true;             // overlap=0: the persistent FD launch keeps the separate base pass in front of it
+    double test_cache_limit = 0;        // (GST_TEST_FORCE cache_limit=, bytes; tests) stands in for the 4 GB of 32-bit cache offsets
+    static constexpr bool jtj_sparse = true;             // J^T J skips all-zero panels
     DevBuf<uint32_t> d_jtj_pmask;
-    bool fd_overlap_diag = false;       // GST_FD_OVERLAP=2 (measurements): the overlap kernel, but base pass in front and no chains
-    bool fd_standby = true;             // GST_FD_STANDBY=0 (measurements only): no stand-by launches behind the persistent one
+    static constexpr bool fd_overlap_diag = false;       // (measurement form of round 3, retired)
+    static constexpr bool fd_standby = true;             // stand-by launches behind the persistent one
     bool last_overlap = false;          // the last FD fill ran its base pass inside the persistent launch
     int last_fd_form = 0;               // gst_stats.last_fd_form
-    bool test_skip_chains = false;      // GST_FD_TEST_SKIP_CHAINS=1 (tests): the overlap launch walks no chain, so every wait runs out
+    bool test_skip_chains = false;      // skip_chains=1 (tests): the overlap launch walks no chain, so every wait runs out
     bool split_ready = false;
     std::vector<int32_t> cand_ptr, cand_pc;      // gst::task_split_candidates: where a walk may be handed over
     std::vector<float> cand_frac;
@@ -252,7 +252,7 @@ struct gst_plan {
     DevBuf<int32_t> d_wave_row, d_wave_rowidx, d_lane_colidx;
     DevBuf<double> d_hrow;              // composed FD-of-FD Hessians: the stepped model's Jacobian over block 2
     DevBuf<int32_t> d_hdest;            // ... and the destination columns of block 2
-    bool hess_composed = false;         // GST_HESS_COMPOSED=1: every FD-of-FD block through the composed route (tests)
+    bool hess_composed = false;         // hess_composed=1: every FD-of-FD block through the composed route (tests)
     DevBuf<int32_t> d_node_parent, d_node_sym, d_node_run, d_circ_leaf, d_gate_col0, d_cm_gate, d_cm_rho, d_cm_eff;
     bool graph_uploaded = false;
     // the lane tables / column maps on the device describe this request (skip re-packing when it repeats)
@@ -344,29 +344,41 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
         p->timing = t == 1 || (t != 2 && p->hp.n_state_ids > 65536);
         if (const char* e = std::getenv("GST_TIMING")) p->timing = std::atoi(e) != 0;
     }
-    if (const char* e = std::getenv("GST_FD_SPLIT")) p->fd_split = std::atoi(e);     // development override
-    if (const char* e = std::getenv("GST_ANALYTIC_PAIRS")) p->ana_pairs = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_ANALYTIC_GERM_ORDER")) p->ana_germ_order = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_ANALYTIC_GROUP")) p->ana_group_fetch = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_ANALYTIC_STREAM")) p->ana_stream = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_FD_PERSIST")) { p->fd_persist = std::atoi(e) != 0; p->fd_persist_always = std::atoi(e) == 2; }
-    if (const char* e = std::getenv("GST_ANALYTIC_MFMA")) p->ana_mfma = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_FD_FUSED")) p->fd_fused = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_HESS_COMPOSED")) p->hess_composed = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_LB_RHO_LANES")) p->lb_rho_lanes = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_FD_OVL_MEM")) {      // (experiment) memory type of the arrays the in-launch base pass publishes through
-        const int m = std::atoi(e);
-        const unsigned fl = m == 1 ? hipDeviceMallocUncached : m == 2 ? hipDeviceMallocFinegrained : 0u;
-        p->d_base_cache.flags = fl; p->d_pbase.flags = fl;
+    // GST_TEST_FORCE="key=value,key=value,...": the ONE test hook of the library.  On the small fixtures that carry reference
+    // vectors it selects the launch forms that big plans take on their own (and the fall-backs they take under pressure),
+    // so that every production form is compared bit for bit with the reference; nothing here is a tuning knob.
+    //   persist=0|1|2     FD walk: 0 dispatcher-placed workgroups, 2 per-SIMD queues whatever the number of pairs
+    //   fused=0           launch-bound plans keep the separate base pass (instead of the fused base lane)
+    //   overlap=0|1       base pass outside / inside the persistent FD launch
+    //   handover=0|1|2    never cut a walk / cut to balance the queues (default) / cut every walk that can be cut
+    //   skip_chains=1     the overlap launch walks no chain: every bounded wait runs out, the stand-by launches take over
+    //   host_direct=0|2   page-locked destinations filled by a copy / by the kernel's own stores at any column count
+    //   hess_composed=1   every FD-of-FD Hessian block through the composed route
+    //   cache_limit=BYTES stands in for the 4 GB of 32-bit cache offsets (the WIDE contraction kernels)
+    if (const char* spec = std::getenv("GST_TEST_FORCE")) {
+        std::string str(spec);
+        size_t pos = 0;
+        while (pos < str.size()) {
+            size_t end = str.find(',', pos);
+            if (end == std::string::npos) end = str.size();
+            const std::string item = str.substr(pos, end - pos);
+            pos = end + 1;
+            const size_t eq = item.find('=');
+            if (eq == std::string::npos) continue;
+            const std::string key = item.substr(0, eq);
+            const double val = std::atof(item.c_str() + eq + 1);
+            const int iv = (int)val;
+            if (key == "persist") { p->fd_persist = iv != 0; p->fd_persist_always = iv == 2; }
+            else if (key == "fused") p->fd_fused = iv != 0;
+            else if (key == "overlap") p->fd_overlap = iv != 0;
+            else if (key == "handover") p->fd_handover = iv;
+            else if (key == "skip_chains") p->test_skip_chains = iv != 0;
+            else if (key == "host_direct") { p->host_direct = iv != 0; if (iv == 2) p->host_direct_min_cols = 1; }
+            else if (key == "hess_composed") p->hess_composed = iv != 0;
+            else if (key == "cache_limit") p->test_cache_limit = val;
+            else { delete p; return fail(GST_EINVAL, "GST_TEST_FORCE: unknown key '" + key + "'"); }
+        }
     }
-    if (const char* e = std::getenv("GST_HOST_DIRECT")) { p->host_direct = std::atoi(e) != 0; if (std::atoi(e) == 2) p->host_direct_min_cols = 1; }
-    if (const char* e = std::getenv("GST_FD_HANDOVER")) p->fd_handover = std::atoi(e);
-    if (const char* e = std::getenv("GST_FD_OVERLAP")) { p->fd_overlap = std::atoi(e) != 0; p->fd_overlap_diag = std::atoi(e) == 2; }
-    if (const char* e = std::getenv("GST_FD_STANDBY")) p->fd_standby = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_LB_SHARE")) p->lb_share = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_JTJ_SPARSE")) p->jtj_sparse = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GST_TEST_CACHE_LIMIT")) p->test_cache_limit = std::atof(e);
-    if (const char* e = std::getenv("GST_FD_TEST_SKIP_CHAINS")) p->test_skip_chains = std::atoi(e) != 0;
     if (p->fd_split != 0 && p->fd_split != 1 && p->fd_split != 2 && p->fd_split != 4) p->fd_split = 0;
     *out = p;
     return GST_OK;
@@ -751,16 +763,12 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
                 (size_t)16 * std::max(p->hp.max_slots, 1) * p->hp.D * 64 * 8 <= 160 * 1024) {
                 const int n_bins = 4 * p->n_cus;
                 if (p->fd_handover != 0 && !p->split_ready) {
-                    // Default: cuts only where no save slot is live and the interpreter's outer loop stands (an EMIT, the word
-                    // after a LOAD), the one nearest a walk's middle.  GST_FD_CUT_RICH=1 (development): any position, in
-                    // front of any APPLY as well, live slots travelling along -- with it the packer (GST_FD_CUT=1/2) gets
-                    // the estimated loads within 2 % of the mean (2,924-3,035 against 2,553-3,114 on a 1/8 atom of the 2Q
-                    // design), and the kernel gets SLOWER (4.45 against 4.05 ms): a second part that is popped before its
-                    // first part is done occupies a wavefront, one that is popped late ends late, and neither shows in a
-                    // load estimate.  Measured, kept switchable, not the default.
-                    const bool rich = std::getenv("GST_FD_CUT_RICH") && std::atoi(std::getenv("GST_FD_CUT_RICH")) != 0;
-                    gst::task_split_candidates(p->hp, p->cand_ptr, p->cand_pc, p->cand_frac, rich ? 128 : (1 << 20), rich ? &p->cand_live : nullptr);
-                    if (!rich) p->cand_live.clear();
+                    // cuts only where no save slot is live and the interpreter's outer loop stands (an EMIT, the word after a
+                    // LOAD), the one nearest a walk's middle.  (Cuts at any position with live slots travelling along balance the
+                    // ESTIMATED loads to 2 % and make the kernel slower -- 4.45 against 4.05 ms on a 1/8 atom: a second part
+                    // popped before its first part is done occupies a wavefront.  Measured in round 3, removed in round 4.)
+                    gst::task_split_candidates(p->hp, p->cand_ptr, p->cand_pc, p->cand_frac, 1 << 20, nullptr);
+                    p->cand_live.clear();
                     p->split_ready = true;
                 }
                 gst::FdQueues Q;
@@ -771,18 +779,11 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
                 const std::vector<int32_t>& ho_index = Q.ho_index;
                 const std::vector<int32_t>& ho_pc = Q.ho_pc;
                 std::vector<int32_t> ho_live(Q.ho_live.begin(), Q.ho_live.end());
-                const std::vector<int64_t>& load = Q.load;
                 if ((rc = upload_i32(p->d_bin_ptr, bptr, p->stream))) return rc;
                 HIP_TRY(p->d_bin_items.ensure(bitems.size()));
                 HIP_TRY(hipMemcpyAsync(p->d_bin_items.p, bitems.data(), bitems.size() * 4, hipMemcpyHostToDevice, p->stream));
                 HIP_TRY(p->d_bin_head.ensure((size_t)n_bins + 1));            // (+ the abort flag)
                 p->n_split = n_split;
-                if (std::getenv("GST_FD_DEBUG")) {
-                    int64_t lo = load[0], hi = load[0];
-                    for (int64_t l : load) { lo = std::min(lo, l); hi = std::max(hi, l); }
-                    std::fprintf(stderr, "[gstfwd] per-SIMD queues: %zu pairs, %d hand-overs, estimated load min %lld max %lld\n",
-                                 items.size(), n_split, (long long)lo, (long long)hi);
-                }
                 if (n_split > 0) {
                     if ((rc = upload_i32(p->d_ho_index, ho_index, p->stream))) return rc;
                     if ((rc = upload_i32(p->d_task_split_pc, ho_pc, p->stream))) return rc;
@@ -942,8 +943,7 @@ int ensure_reverse(gst_plan* p)
 {
     if (p->rev_ready) return GST_OK;
     const gst::HostPlan& h = p->hp;
-    int32_t rev_tasks = 0;
-    if (const char* e = std::getenv("GST_ANALYTIC_REV_TASKS")) rev_tasks = std::atoi(e);       // development aid
+    const int32_t rev_tasks = 0;
     std::string err = gst::build_reverse_plan(h, p->rev, rev_tasks, h.D == 16 ? 1 : (h.D == 64 ? 8 : 4));
     if (!err.empty()) return fail(GST_EINVAL, "reversed plan: " + err);
     if (p->rev.max_slots > (h.D == 64 ? 32 : 4)) return fail(GST_EUNSUPPORTED, "reversed plan needs too many save slots");
@@ -1210,7 +1210,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     a.out = d_out; a.ld = ld;
     // The MFMA kernels address both state caches with a uniform 64-bit base + 32-bit per-lane byte offsets; a cache of
     // 4 GB or more selects their WIDE instantiation (64-bit lane offsets: two more address registers per gather in
-    // flight), nothing is refused.  (GST_TEST_CACHE_LIMIT: tests lower the 4 GB so that a small plan takes that form.)
+    // flight), nothing is refused.  (GST_TEST_FORCE cache_limit=: tests lower the 4 GB so that a small plan takes that form.)
     const double cache_limit = p->test_cache_limit > 0 ? p->test_cache_limit : 4.0e9;
     const bool caches_small = (double)h.n_state_ids * D * 8 < cache_limit;
     // the two-cache contraction: MFMA at D = 16 / 64; at D = 4 (VALU) only when a Hessian needs its tables -- a plain 1Q
@@ -2418,7 +2418,7 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
                                int64_t n1, const int64_t* idx2, const int64_t* dest2, int64_t n2)
 {
     const gst::HostPlan& h = p->hp;
-    if (!p->ana_mfma) return fail(GST_EUNSUPPORTED, "analytic Hessians need the two-cache contraction path (GST_ANALYTIC_MFMA=0 is set)");
+    if (!p->ana_mfma) return fail(GST_EUNSUPPORTED, "analytic Hessians need the two-cache contraction path");
     const int D = h.D, nEf = h.n_effects;
     const int64_t nE = h.n_elements;
     int rc;

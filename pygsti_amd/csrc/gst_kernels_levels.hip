@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void level_pass_kernel(const LevelArgs a)
     const int64_t task = blockIdx.x;
     const int32_t* __restrict__ w = a.words + a.task_off[task];
     const int32_t* __restrict__ ids = a.ids;
+    int64_t ids_bias = 0;                  // subtracted from the tile words' GLOBAL id-pool offsets
     double* __restrict__ mats = a.mats + task * (int64_t)a.max_mats * (D * D);
     if (a.stage_lds) {
         // the task's program and its id lists into LDS, once: every stage otherwise starts with two dependent trips to
@@ -41,7 +42,8 @@ __global__ __launch_bounds__(256) void level_pass_kernel(const LevelArgs a)
         for (int k = tid; k < ni; k += 256) lds[nw + k] = a.ids[i0 + k];
         __syncthreads();
         w = lds;
-        ids = lds + nw - i0;              // (tile words hold GLOBAL offsets into the id pool)
+        ids = lds + nw;                    // (an LDS pointer must not be biased out of its aperture: the offsets are rebased instead)
+        ids_bias = i0;
     }
     const int n_stages = w[0];
     w += 1;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void level_pass_kernel(const LevelArgs a)
             } else {
                 const int node = i / NV, v = i % NV;
                 valid = node < n_nodes;
-                const int32_t id = valid ? ids[wa + node] : 0;
+                const int32_t id = valid ? ids[wa - ids_bias + node] : 0;
                 if (id >= 0) { sp = a.cache + (int64_t)id * (D * NV) + v; cs = NV; }
                 else sp = a.starts + ((int64_t)(-(id + 1)) * NV + v) * D;
             }
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void level_pass_kernel(const LevelArgs a)
                 for (int r = 0; r < 4; r++) {
                     const int row = kk + 4 * r, node = row / NV, v = row % NV;
                     if (node < n_nodes) {
-                        const int32_t id = ids[wb + node];
+                        const int32_t id = ids[wb - ids_bias + node];
                         a.cache[(int64_t)id * (D * NV) + (int64_t)i * NV + v] = acc[r];
                     }
                 }
@@ -122,21 +124,37 @@ hipError_t launch_level_pass(const LevelArgs& a, int64_t n_tasks, hipStream_t st
     return hipGetLastError();
 }
 
-// Probabilities of every circuit from its cached final state: out[eff_dest[x]] = effects[eff_label[x]] . cache[leaf(c)]
-// (one thread per circuit; the level pass emits nothing itself).
+// Probabilities of every circuit from its cached final state: out[eff_dest[x]] = effects[eff_label[x]] . cache[leaf(c)].
+// Sixteen lanes per circuit (lane = state component: the 128-byte state is ONE coalesced read; a thread per circuit made
+// every load instruction touch 64 different lines -- 90 us for the bench design instead of ~15), the dot product summed
+// over the lane group by four butterfly steps.  (The level pass emits nothing itself.)
+template <int D>
 __global__ __launch_bounds__(256) void probs_from_cache_kernel(const double* __restrict__ cache, const int32_t* __restrict__ circ_leaf,
                                                                const int32_t* __restrict__ eff_ptr, const int32_t* __restrict__ eff_label,
                                                                const int32_t* __restrict__ eff_dest, const double* __restrict__ effects,
-                                                               int64_t n_circuits, int D, double* __restrict__ out)
+                                                               int64_t n_circuits, double* __restrict__ out)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_circuits) return;
-    const double* f = cache + (int64_t)circ_leaf[c] * D;
-    for (int32_t x = eff_ptr[c]; x < eff_ptr[c + 1]; x++) {
-        const double* e = effects + (int64_t)eff_label[x] * D;
-        double acc = 0.0;
-        for (int k = 0; k < D; k++) acc = __builtin_fma(e[k], f[k], acc);
-        out[eff_dest[x]] = acc;
+    constexpr int PER = 64 / D;                                    // circuits per wavefront
+    const int lane = threadIdx.x & 63, k = lane % D;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t c = wave * PER + lane / D;
+    const bool on = c < n_circuits;
+    const int64_t cc = on ? c : n_circuits - 1;
+    const double f = cache[(int64_t)circ_leaf[cc] * D + k];
+    const int32_t x0 = eff_ptr[cc], x1 = eff_ptr[cc + 1];
+    int32_t nx = x1 - x0;
+    // (every lane group of the wavefront runs the longest group's trip count: the shuffles below need all lanes)
+    int32_t nmax = nx;
+#pragma unroll
+    for (int o = D; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    for (int32_t j = 0; j < nmax; j++) {
+        const bool live = j < nx;
+        const int32_t x = x0 + j;
+        double part = 0.0;
+        if (live) part = effects[(int64_t)eff_label[x] * D + k] * f;
+#pragma unroll
+        for (int o = D / 2; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (on && live && k == 0) out[eff_dest[x]] = part;
     }
 }
 
@@ -145,8 +163,11 @@ hipError_t launch_probs_from_cache(const double* cache, const int32_t* circ_leaf
 {
     if (n_circuits <= 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(probs_from_cache_kernel, dim3((unsigned)((n_circuits + 255) / 256)), dim3(256), 0, stream, cache, circ_leaf, eff_ptr,
-                       eff_label, eff_dest, effects, n_circuits, D, out);
+    if (D != 16 && D != 4) return hipErrorInvalidValue;
+    const int64_t per_block = 4 * (64 / D);
+    const dim3 grid((unsigned)((n_circuits + per_block - 1) / per_block)), block(256);
+    if (D == 16) hipLaunchKernelGGL(probs_from_cache_kernel<16>, grid, block, 0, stream, cache, circ_leaf, eff_ptr, eff_label, eff_dest, effects, n_circuits, out);
+    else hipLaunchKernelGGL(probs_from_cache_kernel<4>, grid, block, 0, stream, cache, circ_leaf, eff_ptr, eff_label, eff_dest, effects, n_circuits, out);
     return hipGetLastError();
 }
 

@@ -579,12 +579,9 @@ void pack_fd_queues(const std::vector<std::pair<int32_t, uint32_t>>& items, int3
         // where a walk is cut: 0 = in its middle (the second part is then long enough to be worth a wavefront's wait and
         // short enough to end with its queue); 1 = where the donor's load becomes the mean; 2 = where donor and receiver
         // become equal.  (development switch; the default is what measured best on a 1/8 atom of the 2Q design)
-        int cut_policy = 0;
-        if (const char* e = std::getenv("GST_FD_CUT")) cut_policy = std::atoi(e);
-        double cut_frac = 0.5;
-        if (const char* e = std::getenv("GST_FD_CUT_FRAC")) cut_frac = std::atof(e);
-        int64_t min_gain = 16;
-        if (const char* e = std::getenv("GST_FD_CUT_GAIN")) min_gain = std::atoll(e);
+        const int cut_policy = 0;
+        const double cut_frac = 0.5;
+        const int64_t min_gain = 16;
         // donors: queues above the mean, fullest first; receivers: all queues, emptiest first.  A donor that has nothing
         // (more) to give leaves the donor set only -- it may still receive.
         std::set<LB> donors, recv;
@@ -601,7 +598,7 @@ void pack_fd_queues(const std::vector<std::pair<int32_t, uint32_t>>& items, int3
                 if (!force && bi.cost < std::max<int64_t>(64, mean / 4)) continue;
                 if (best < 0 || bi.cost > bins[(size_t)bmax][(size_t)best].cost) best = (int)k;
             }
-            if (best < 0) { if (std::getenv("GST_FD_DEBUG")) std::fprintf(stderr, "[pack] queue %d load %lld: nothing to cut (%zu items)\n", bmax, (long long)load[(size_t)bmax], bins[(size_t)bmax].size()); donors.erase(top); continue; }  // nothing to cut in the fullest queue: look at the next
+            if (best < 0) { donors.erase(top); continue; }  // nothing to cut in the fullest queue: look at the next
             LB low = *recv.begin();
             if (low.second == bmax) { if (recv.size() < 2) break; low = *std::next(recv.begin()); }
             const int bmin = low.second;
@@ -618,7 +615,7 @@ void pack_fd_queues(const std::vector<std::pair<int32_t, uint32_t>>& items, int3
             const double frac = cand_frac[(size_t)ci];
             const int64_t c1 = (int64_t)((double)whole.cost * frac) + 24, c2 = whole.cost - (int64_t)((double)whole.cost * frac) + 24;
             const int64_t new_hi = std::max(load[(size_t)bmax] - whole.cost + c1, load[(size_t)bmin] + c2);
-            if (!force && new_hi + min_gain >= load[(size_t)bmax]) { if (std::getenv("GST_FD_DEBUG")) std::fprintf(stderr, "[pack] queue %d load %lld -> %d load %lld: no gain (cost %lld frac %.3f want %.3f)\n", bmax, (long long)load[(size_t)bmax], bmin, (long long)load[(size_t)bmin], (long long)whole.cost, frac, want); donors.erase(top); continue; }   // no gain here: next queue
+            if (!force && new_hi + min_gain >= load[(size_t)bmax]) { donors.erase(top); continue; }   // no gain here: next queue
             donors.erase(top); donors.erase(LB(load[(size_t)bmin], bmin));
             recv.erase(LB(load[(size_t)bmax], bmax)); recv.erase(low);
             bins[(size_t)bmax].erase(bins[(size_t)bmax].begin() + best);

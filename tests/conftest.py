@@ -84,3 +84,18 @@ def design_checker(oracle_module, pack, model, circuits, layout, kind=None):
     if kind is None:
         kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgst_ref.so")) else "port"
     return oracle_module.Oracle(tbl, mdl, kind)
+
+
+def force(monkeypatch, **kw):
+    """Set keys of GST_TEST_FORCE (the library's one test hook: launch-form selectors read when a plan is created;
+    include/gstfwd.h); value None removes a key."""
+    cur = dict(item.split("=", 1) for item in os.environ.get("GST_TEST_FORCE", "").split(",") if item)
+    for k, v in kw.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    if cur:
+        monkeypatch.setenv("GST_TEST_FORCE", ",".join("%s=%s" % kv for kv in cur.items()))
+    else:
+        monkeypatch.delenv("GST_TEST_FORCE", raising=False)

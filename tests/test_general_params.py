@@ -5,7 +5,7 @@ on `full TP` / `CPTPLND` models, with the members' deriv_wrt_params() and gpindi
 import numpy as np
 import pytest
 
-from conftest import load_fixture, plan_from_fixture
+from conftest import force, load_fixture, plan_from_fixture
 from oracle import oracle as O
 
 CASES = ["smq1Q_XYI_L4_TP", "smq1Q_XYI_L4_CPTPLND", "smq2Q_XYICNOT_L1_TP"]
@@ -175,10 +175,10 @@ def test_gpu_3q_tp_model_fd_jacobian_and_hessian_bitwise():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", TP_CASES + ["smq1Q_XYI_L4_depol"])
 def test_gpu_composed_hessian_is_the_fused_one(name, monkeypatch):
-    """GST_HESS_COMPOSED=1 sends every FD-of-FD block through the composed route (n1 + 2 FD Jacobians of stepped models);
+    """GST_TEST_FORCE hess_composed=1 sends every FD-of-FD block through the composed route (n1 + 2 FD Jacobians of stepped models);
     on plans the fused two-perturbation kernel covers, both equal the reference's block bit for bit."""
     fx = load_fixture(name)
-    monkeypatch.setenv("GST_HESS_COMPOSED", "1")
+    force(monkeypatch, hess_composed=1)
     pl = plan_from_fixture(fx)
     if "comp_index" in fx:
         pl.set_param_map(*O.tp_param_map(fx))

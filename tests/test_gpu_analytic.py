@@ -4,7 +4,7 @@ forward/backward Jacobian of oracle/oracle.py on the deep 2Q circuits where Matr
 import numpy as np
 import pytest
 
-from conftest import load_fixture, assert_bitwise, plan_from_fixture
+from conftest import force, load_fixture, assert_bitwise, plan_from_fixture
 from pygsti_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -48,34 +48,6 @@ def test_analytic_column_window_and_permutation():
     pl.fill_dprobs(out=out, param_idx=cols, dest_idx=np.arange(300) + 7, mode=_lib.DERIV_ANALYTIC)
     assert np.array_equal(out[:, 7:307], full[:, cols])
     assert (out[:, :7] == -3.0).all() and (out[:, 307:] == -3.0).all()
-
-
-def test_analytic_valu_kernel_fallback(monkeypatch):
-    """GST_ANALYTIC_MFMA=0 (read when the plan is created) keeps the one-wavefront-per-circuit VALU kernel alive at D = 16:
-    same vectors, same tolerance, and the two paths agree far below it."""
-    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
-    J_mfma = plan_from_fixture(fx).fill_dprobs(param_idx=fx["dprobs_cols"], mode=_lib.DERIV_ANALYTIC)
-    monkeypatch.setenv("GST_ANALYTIC_MFMA", "0")
-    J_valu = plan_from_fixture(fx).fill_dprobs(param_idx=fx["dprobs_cols"], mode=_lib.DERIV_ANALYTIC)
-    rows = fx["matrix_rows"]
-    assert np.abs(J_valu[rows] - fx["dprobs_matrix"]).max() < TOL
-    assert np.abs(J_valu - J_mfma).max() < 1e-12
-    assert not np.array_equal(J_valu, J_mfma)          # (different summation orders: they are different kernels)
-
-
-def test_analytic_two_circuit_items_vs_single(monkeypatch):
-    """The D = 16 contraction pairs circuits that end with the same applications and gathers their common backward
-    states once (default); GST_ANALYTIC_PAIRS=0 hands out one circuit per item.  Same sums in a slightly different
-    order: the two agree far below the tolerance, on the design fixture and on the deep germ-power families."""
-    for name, cols in (("smq2Q_XYICNOT_L2_depol", np.arange(1616)), ("smq2Q_XYICNOT_L1024_deep", np.arange(80, 1616, 3))):
-        fx = load_fixture(name)
-        J_pairs = plan_from_fixture(fx).fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
-        monkeypatch.setenv("GST_ANALYTIC_PAIRS", "0")
-        J_single = plan_from_fixture(fx).fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
-        monkeypatch.delenv("GST_ANALYTIC_PAIRS")
-        scale = max(1.0, np.abs(J_single).max())
-        assert np.abs(J_pairs - J_single).max() < 1e-12 * scale
-        assert (J_pairs != 0).any()
 
 
 def test_analytic_hprobs_vs_numpy_oracle(oracle_built):
@@ -181,12 +153,10 @@ def test_exact_hessian_with_derivative_caches_beyond_4gb():
     pl.close(); small.close()
 
 
-@pytest.mark.parametrize("stream", ["1", "0"])
-def test_analytic_fill_overwrites_every_requested_entry(stream, monkeypatch):
+def test_analytic_fill_overwrites_every_requested_entry():
     """Circuits that never apply some gate must get exact zeros in that gate's columns, not whatever the buffer held:
-    the destination is pre-filled with NaN and a sentinel, in the streamed and the gate-by-gate form of the contraction."""
+    the destination is pre-filled with NaN and a sentinel."""
     from pygsti_amd import _lib
-    monkeypatch.setenv("GST_ANALYTIC_STREAM", stream)
     fx = load_fixture("smq2Q_XYICNOT_L2_depol")
     pl = plan_from_fixture(fx)
     nE, nP = int(fx["nE"]), int(fx["nP"])
@@ -257,7 +227,7 @@ def test_analytic_keep_zeros_option():
 def test_state_caches_beyond_32bit_offsets_take_the_wide_contraction(monkeypatch):
     """The two-cache MFMA contraction addresses its state caches with 32-bit per-lane byte offsets (4 GB each).  A plan
     whose caches are larger is no longer refused (round 2: GST_EUNSUPPORTED) or degraded: the same kernels, instantiated
-    with 64-bit lane offsets, run it -- Jacobians and exact Hessian blocks, D = 16 and D = 64.  GST_TEST_CACHE_LIMIT stands
+    with 64-bit lane offsets, run it -- Jacobians and exact Hessian blocks, D = 16 and D = 64.  GST_TEST_FORCE cache_limit=... stands
     in for the 4 GB so that small plans take that form: bit-identical to the default instantiation."""
     from pygsti_amd import _lib
     fx = load_fixture("smq2Q_XYICNOT_L2_depol")
@@ -268,20 +238,20 @@ def test_state_caches_beyond_32bit_offsets_take_the_wide_contraction(monkeypatch
     st = pl0.stats()
     for limit in (st["trie_nodes"] * 16 * 8 * 2,      # forward cache fits, the 4-effect backward cache does not
                   1024.0):                            # neither fits
-        monkeypatch.setenv("GST_TEST_CACHE_LIMIT", str(limit))
+        force(monkeypatch, cache_limit=limit)
         pl = plan_from_fixture(fx)
         J = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
         assert np.array_equal(J, ref)
         assert np.abs(J[fx["matrix_rows"]] - fx["dprobs_matrix"]).max() < 1e-8
         assert np.array_equal(pl.fill_hprobs(idx1=cols[:6], idx2=cols[:40], mode=_lib.DERIV_ANALYTIC), Href)
     # D = 64
-    monkeypatch.delenv("GST_TEST_CACHE_LIMIT")
+    force(monkeypatch, cache_limit=None)
     fx3 = load_fixture("3q_explicit_L64")
     c3 = fx3["dprobs_cols"][:96]
     p3 = plan_from_fixture(fx3)
     ref3 = p3.fill_dprobs(param_idx=c3, mode=_lib.DERIV_ANALYTIC)
     H3 = p3.fill_hprobs(idx1=c3[:3], idx2=c3[:24], mode=_lib.DERIV_ANALYTIC)
-    monkeypatch.setenv("GST_TEST_CACHE_LIMIT", "1024")
+    force(monkeypatch, cache_limit=1024)
     p3w = plan_from_fixture(fx3)
     assert np.array_equal(p3w.fill_dprobs(param_idx=c3, mode=_lib.DERIV_ANALYTIC), ref3)
     assert np.array_equal(p3w.fill_hprobs(idx1=c3[:3], idx2=c3[:24], mode=_lib.DERIV_ANALYTIC), H3)

@@ -115,14 +115,12 @@ def test_jtj_on_the_2q_design_jacobian():
     for d in (d_J, d_jtj, d_jtf, d_f): pl.device_free(d)
 
 
-@pytest.mark.parametrize("sparse", ["1", "0"])
-def test_jtj_block_sparse_jacobian(sparse, monkeypatch):
-    """Round 3: panels (16 rows) whose 128-column tiles hold only zeros are skipped (GST_JTJ_SPARSE=1, default) -- exact,
+def test_jtj_block_sparse_jacobian():
+    """Round 3: panels (16 rows) whose 128-column tiles hold only zeros are skipped -- exact,
     what is skipped is a product with zeros.  A synthetic Jacobian with the structure of a GST one: groups of rows that are
     zero in whole column blocks (block edges NOT aligned with the 128-column tiles or the 16-row panels), single non-zeros
-    in otherwise empty tiles, all-zero rows, zero row weights; with and without the row scale; the same bits as the dense
-    form of the kernel (GST_JTJ_SPARSE=0) and numpy to 1e-12."""
-    monkeypatch.setenv("GST_JTJ_SPARSE", sparse)
+    in otherwise empty tiles, all-zero rows, zero row weights; with and without the row scale; numpy to 1e-12 (the dense
+    form of the kernel, bit-identical on this input in round 3, has been removed)."""
     fx = load_fixture("smq1Q_XYI_L4_depol")
     pl = plan_from_fixture(fx)
     rng = np.random.default_rng(42)
@@ -158,9 +156,4 @@ def test_jtj_block_sparse_jacobian(sparse, monkeypatch):
     assert (np.abs(got_s - want) <= 1e-12 * scale).all()
     back = pl.memcpy_d2h(np.empty((n_rows, ld)), d_J)
     assert np.array_equal(back[:, :n_cols], Js) and np.array_equal(back[:, n_cols:], Jp[:, n_cols:])    # padding untouched
-    test_jtj_block_sparse_jacobian.results = getattr(test_jtj_block_sparse_jacobian, "results", {})
-    test_jtj_block_sparse_jacobian.results[sparse] = (got, got_s)
-    if len(test_jtj_block_sparse_jacobian.results) == 2:
-        a, b = test_jtj_block_sparse_jacobian.results["1"], test_jtj_block_sparse_jacobian.results["0"]
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), "skipping zero panels must not change a bit"
     for d in (d_J, d_jtj, d_w): pl.device_free(d)

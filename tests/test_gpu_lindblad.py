@@ -67,11 +67,12 @@ def test_probs_and_fd_dprobs_of_cptplnd_models(name, nq):
 
 
 @pytest.mark.parametrize("name,nq", CASES)
-def test_state_sharing_walk_agrees_with_independent_walks(name, nq, monkeypatch):
-    """The two device forms of a Lindblad model's FD Jacobian -- walk_pert_kernel (clean/dirty sharing with the base
-    pass, 64/D columns per wavefront; default) and one independent walk per (program, perturbed model) (GST_LB_SHARE=0)
-    -- use the same perturbed members and the same operation order: they agree to the rounding of (p' - p) / eps, for
-    ragged column subsets, repeated and shuffled columns, a destination window, small and large task counts."""
+def test_state_sharing_walk_agrees_with_independent_walks(name, nq):
+    """The state-sharing form of a Lindblad model's FD Jacobian -- walk_pert_kernel (clean/dirty sharing with the base pass,
+    64/D columns per wavefront) -- against one independent walk per (program, perturbed model) over the SAME device-built
+    member sets (gst_fill_dprobs_models on gst_get_lindblad_model_sets): same perturbed members, same operation order, so
+    they agree to the rounding of (p' - p) / eps -- for ragged column subsets, repeated and shuffled columns, a
+    destination window, small and large task counts."""
     fx, lb = load_fixture(name), load_fixture("lindblad_" + name)
     model = LB.LindbladModel.from_fixture(lb, nq)
     nP, nE = model.num_params, int(fx["nE"])
@@ -79,27 +80,26 @@ def test_state_sharing_walk_agrees_with_independent_walks(name, nq, monkeypatch)
     cols = np.concatenate([np.arange(nP) if nP <= 64 else np.sort(rng.choice(nP, 150, replace=False)), [3, 3, 0]])
     dest = rng.permutation(len(cols) + 5)[:len(cols)]
     outs = {}
-    for share in ("1", "0"):
-        monkeypatch.setenv("GST_LB_SHARE", share)
-        for tt in (0, 5):
-            pl = plan_from_fixture(fx, target_tasks=tt)
-            pl.set_lindblad(model); pl.set_lindblad_params(lb["paramvec"])
-            J = np.full((nE, len(cols) + 5), np.nan)
-            pr = np.empty(nE)
-            pl.fill_dprobs(out=J, param_idx=cols, dest_idx=dest, eps=1e-7, probs_out=pr)
-            untouched = np.setdiff1d(np.arange(len(cols) + 5), dest)
-            assert np.isnan(J[:, untouched]).all() and not np.isnan(J[:, dest]).any()
-            assert np.abs(pr - fx["probs"]).max() < 1e-10
-            outs[(share, tt)] = J[:, dest]
-            J_again = np.full_like(J, np.nan)
-            pl.fill_dprobs(out=J_again, param_idx=cols, dest_idx=dest, eps=1e-7)
-            assert np.array_equal(J_again[:, dest], J[:, dest])
-    ref = outs[("0", 0)]
+    for tt in (0, 5):
+        pl = plan_from_fixture(fx, target_tasks=tt)
+        pl.set_lindblad(model); pl.set_lindblad_params(lb["paramvec"])
+        J = np.full((nE, len(cols) + 5), np.nan)
+        pr = np.empty(nE)
+        pl.fill_dprobs(out=J, param_idx=cols, dest_idx=dest, eps=1e-7, probs_out=pr)
+        untouched = np.setdiff1d(np.arange(len(cols) + 5), dest)
+        assert np.isnan(J[:, untouched]).all() and not np.isnan(J[:, dest]).any()
+        assert np.abs(pr - fx["probs"]).max() < 1e-10
+        outs[tt] = J[:, dest]
+        J_again = np.full_like(J, np.nan)
+        pl.fill_dprobs(out=J_again, param_idx=cols, dest_idx=dest, eps=1e-7)
+        assert np.array_equal(J_again[:, dest], J[:, dest])
+    Gs, Rs, Es = pl.lindblad_model_sets(cols, 1e-7)
+    ref = pl.fill_dprobs_models(Gs, Rs, Es, eps=1e-7)
     for k, v in outs.items():
         assert np.abs(v - ref).max() < 2e-8, (k, np.abs(v - ref).max())
     known = np.isin(cols, fx["dprobs_cols"])
     pos = [int(np.nonzero(fx["dprobs_cols"] == c)[0][0]) for c in cols[known]]
-    assert np.abs(outs[("1", 0)][:, known] - fx["dprobs_map"][:, pos]).max() < 1e-8
+    assert np.abs(outs[0][:, known] - fx["dprobs_map"][:, pos]).max() < 1e-8
 
 
 def test_lindblad_description_is_validated():

@@ -4,7 +4,7 @@ FD dprobs and FD-of-FD hprobs (the device computes in the reference's arithmetic
 import numpy as np
 import pytest
 
-from conftest import load_fixture, assert_bitwise, plan_from_fixture
+from conftest import force, load_fixture, assert_bitwise, plan_from_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -45,14 +45,11 @@ def test_dprobs_fd_row_split_variants_bitwise(fd_split):
 
 @pytest.mark.parametrize("overlap,handover", [("1", "1"), ("1", "2"), ("1", "0"), ("0", "1")])
 def test_dprobs_fd_base_pass_inside_persistent_launch_bitwise(overlap, handover, monkeypatch):
-    """Persistent launch with the base pass walked INSIDE it (GST_FD_OVERLAP=1, the default for D = 16): designated
+    """Persistent launch with the base pass walked INSIDE it (GST_TEST_FORCE overlap=1, the default for D = 16): designated
     wavefronts publish states and probabilities with write-through stores, the finite-difference walks wait on the
     sentinel the buffers were pre-filled with.  Same arithmetic, same bits -- including probs_out, which the chains fill
     -- whatever the hand-over setting; destinations pre-filled with NaN; repeated fills (stale cache contents)."""
-    monkeypatch.setenv("GST_FD_PERSIST", "2")
-    monkeypatch.setenv("GST_FD_FUSED", "0")            # (plans this small would otherwise take the one-launch fused-lane form)
-    monkeypatch.setenv("GST_FD_OVERLAP", overlap)
-    monkeypatch.setenv("GST_FD_HANDOVER", handover)
+    force(monkeypatch, persist=2, fused=0, overlap=overlap, handover=handover)   # (fused=0: plans this small would otherwise take the one-launch fused-lane form)
     forms = set()
     for name in ("smq2Q_XYICNOT_L1024_deep", "smq2Q_XYICNOT_L2_depol"):
         fx = load_fixture(name)
@@ -71,23 +68,21 @@ def test_dprobs_fd_base_pass_inside_persistent_launch_bitwise(overlap, handover,
             g2 = np.array(fx['gates']) * 0.999
             pl.set_model(g2, fx['rhos'], fx['effects'])
             J2 = pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']))
-            monkeypatch.setenv("GST_FD_PERSIST", "0")
+            force(monkeypatch, persist=0)
             pl0 = plan_from_fixture(fx, target_tasks=tt)
             pl0.set_model(g2, fx['rhos'], fx['effects'])
             assert_bitwise(J2, pl0.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps'])), "second model " + name)
-            monkeypatch.setenv("GST_FD_PERSIST", "2")
+            force(monkeypatch, persist=2)
     assert (2 in forms) == (overlap == "1"), forms
 
 
 def test_dprobs_fd_bounded_waits_fall_back_to_the_standby_launches(monkeypatch):
-    """A wait that cannot end -- here: the overlap launch is told to walk no chain at all (GST_FD_TEST_SKIP_CHAINS), as
+    """A wait that cannot end -- here: the overlap launch is told to walk no chain at all (GST_TEST_FORCE skip_chains=1), as
     when the producing workgroup is not resident on a shared device -- runs out after ~0.1 s, raises the abort flag, and
     the stand-by launches enqueued behind the persistent one (separate base pass, one workgroup per pair, guarded by that
     flag) produce the reference's Jacobian bit for bit.  Nothing hangs; the next fill is unaffected."""
     import time
-    monkeypatch.setenv("GST_FD_PERSIST", "2")
-    monkeypatch.setenv("GST_FD_FUSED", "0")
-    monkeypatch.setenv("GST_FD_TEST_SKIP_CHAINS", "1")
+    force(monkeypatch, persist=2, fused=0, skip_chains=1)
     fx = load_fixture("smq2Q_XYICNOT_L1024_deep")
     pl = plan_from_fixture(fx)
     pr = np.full(int(fx['nE']), np.nan)
@@ -99,63 +94,40 @@ def test_dprobs_fd_bounded_waits_fall_back_to_the_standby_launches(monkeypatch):
     assert dt < 20.0, "bounded waits must end within a fraction of a second each (took %.1f s)" % dt
     assert_bitwise(pr, fx['probs'], "probs after the fall-back")
     assert_bitwise(J, fx['dprobs_map'], "dprobs after the fall-back")
-    monkeypatch.delenv("GST_FD_TEST_SKIP_CHAINS")
+    force(monkeypatch, skip_chains=None)
     pl2 = plan_from_fixture(fx)
     J2 = pl2.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']))
     assert pl2.stats()["last_fd_aborted"] == 0
     assert_bitwise(J2, fx['dprobs_map'], "dprobs, next plan")
 
 
-@pytest.mark.parametrize("cut", ["1", "2"])
-def test_dprobs_fd_handover_inside_chains_with_live_slots_bitwise(cut, monkeypatch):
-    """GST_FD_CUT_RICH=1: a walk may be cut in front of ANY gate application, also where save slots are live -- the slots
-    (a clean state's id, or the 64 lanes' data) travel with the lane states -- and the packer places the cut where it
-    balances the queues (GST_FD_CUT=1: donor down to the mean, 2: donor and receiver equal).  Same program words, same
-    arithmetic: same bits.  (Not the default: better balanced on paper, slower on the device; see gst_abi.cpp.)"""
-    monkeypatch.setenv("GST_FD_PERSIST", "2")
-    monkeypatch.setenv("GST_FD_FUSED", "0")
-    monkeypatch.setenv("GST_FD_CUT_RICH", "1")
-    monkeypatch.setenv("GST_FD_CUT", cut)
-    for name in ("smq2Q_XYICNOT_L1024_deep", "smq2Q_XYICNOT_L2_depol"):
-        fx = load_fixture(name)
-        for tt, slots in ((0, 0), (3, 2), (5, 1)):
-            for ho in ("1", "2"):
-                monkeypatch.setenv("GST_FD_HANDOVER", ho)
-                pl = plan_from_fixture(fx, target_tasks=tt, max_slots=slots)
-                J = np.full((int(fx['nE']), len(fx['dprobs_cols'])), np.nan)
-                pl.fill_dprobs(out=J, param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']))
-                assert pl.stats()["last_fd_aborted"] == 0
-                assert_bitwise(J, fx['dprobs_map'], "dprobs rich cuts policy %s handover %s %s tasks=%d slots=%d" % (cut, ho, name, tt, slots))
-
-
 @pytest.mark.parametrize("handover", ["0", "1", "2"])
 def test_dprobs_fd_walk_handover_bitwise(handover, monkeypatch):
     """Persistent launch with walks cut at their task's slot-free middle and handed from one SIMD to another
-    (GST_FD_HANDOVER=2: every walk that can be cut; 1: only to balance the queues; 0: never): the second half picks up
+    (GST_TEST_FORCE handover=2: every walk that can be cut; 1: only to balance the queues; 0: never): the second half picks up
     the 64 lane states the first half stored -- same program words, same arithmetic, same bits."""
-    monkeypatch.setenv("GST_FD_PERSIST", "2")
-    monkeypatch.setenv("GST_FD_HANDOVER", handover)
+    force(monkeypatch, persist=2, handover=handover)
     for name in ("smq2Q_XYICNOT_L1024_deep", "smq2Q_XYICNOT_L2_depol", "smq1Q_XYI_L128_depol"):
         fx = load_fixture(name)
         for tt in (0, 3):
             pl = plan_from_fixture(fx, target_tasks=tt)
             pr = np.empty(int(fx['nE']))
             J = pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']), probs_out=pr)
-            assert_bitwise(J, fx['dprobs_map'], "dprobs GST_FD_HANDOVER=%s %s tasks=%d" % (handover, name, tt))
+            assert_bitwise(J, fx['dprobs_map'], "dprobs handover=%s %s tasks=%d" % (handover, name, tt))
             assert_bitwise(pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps'])), J, "repeat " + name)
 
 
 @pytest.mark.parametrize("mode", ["0", "2"])
 def test_dprobs_fd_launch_forms_bitwise(mode, monkeypatch):
     """The two forms of the FD launch -- one workgroup per (task, wavefront) pair placed by the dispatcher
-    (GST_FD_PERSIST=0), and persistent workgroups popping pairs from per-SIMD queues (=2: always) -- run the same
+    (GST_TEST_FORCE persist=0), and persistent workgroups popping pairs from per-SIMD queues (=2: always) -- run the same
     arithmetic: same bits.  (The default picks by the number of pairs per SIMD.)"""
-    monkeypatch.setenv("GST_FD_PERSIST", mode)
+    force(monkeypatch, persist=mode)
     for name in ("smq1Q_XYI_L128_depol", "smq2Q_XYICNOT_L2_depol", "smq2Q_XYICNOT_L1024_deep"):
         fx = load_fixture(name)
         pl = plan_from_fixture(fx)
         J = pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps']))
-        assert_bitwise(J, fx['dprobs_map'], "dprobs GST_FD_PERSIST=%s %s" % (mode, name))
+        assert_bitwise(J, fx['dprobs_map'], "dprobs persist=%s %s" % (mode, name))
         assert_bitwise(pl.fill_dprobs(param_idx=fx['dprobs_cols'], eps=float(fx['derivative_eps'])), J, "repeat " + name)
 
 
@@ -177,11 +149,11 @@ def test_dprobs_column_window_and_dest_indices():
 @pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq2Q_XYICNOT_L2_depol"])
 @pytest.mark.parametrize("direct", ["2", "1", "0"])      # 2: kernel-written whatever the window's width
 def test_dprobs_into_page_locked_array_bitwise(name, direct, monkeypatch):
-    """A destination registered with gst_host_register is written by the FD kernel itself (GST_HOST_DIRECT=1, default) or
+    """A destination registered with gst_host_register is written by the FD kernel itself (default; GST_TEST_FORCE host_direct=0 selects the copy) or
     by a copy from HBM (=0): same bits as the reference either way, (ld, dest_idx) window honoured, nothing outside it
     touched, and a later pageable destination still works."""
     from pygsti_amd import _lib
-    monkeypatch.setenv("GST_HOST_DIRECT", direct)
+    force(monkeypatch, host_direct=direct)
     fx = load_fixture(name)
     pl = plan_from_fixture(fx)
     cols = fx["dprobs_cols"]; nE, n = int(fx["nE"]), len(cols)
@@ -204,14 +176,14 @@ def test_dprobs_into_page_locked_array_bitwise(name, direct, monkeypatch):
 @pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq2Q_XYICNOT_L2_depol"])
 def test_analytic_dprobs_into_page_locked_array(name, monkeypatch):
     """The analytic contraction writes a page-locked destination itself as well (round 3): bit for bit what the staged route
-    (GST_HOST_DIRECT=0: HBM, then a copy) returns, window honoured, NaN pre-fill fully overwritten, nothing outside touched;
+    (host_direct=0: HBM, then a copy) returns, window honoured, NaN pre-fill fully overwritten, nothing outside touched;
     with GST_OPT_ANALYTIC_KEEP_ZEROS set the staged route is taken (the kernel then skips stores the host array never got)."""
     from pygsti_amd import _lib
     fx = load_fixture(name)
     cols = fx["dprobs_cols"]; nE, n = int(fx["nE"]), len(cols)
-    monkeypatch.setenv("GST_HOST_DIRECT", "0")
+    force(monkeypatch, host_direct=0)
     ref = plan_from_fixture(fx).fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
-    monkeypatch.setenv("GST_HOST_DIRECT", "2")
+    force(monkeypatch, host_direct=2)
     pl = plan_from_fixture(fx)
     full = np.full((nE, n + 7), np.nan)
     assert _lib.pin_host_array(full)

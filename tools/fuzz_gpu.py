@@ -31,9 +31,9 @@ for k in range(n_cases):
         max_len = int(rng.choice([4, 20, 60])); max_slots = int(rng.choice([0, 1, 2, 3, 6, 12]))
     persist = str(rng.choice(["0", "2"]))
     if persist:
-        os.environ["GST_FD_PERSIST"] = persist
+        os.environ["GST_TEST_FORCE"] = "persist=%s" % persist
     else:
-        os.environ.pop("GST_FD_PERSIST", None)
+        os.environ.pop("GST_TEST_FORCE", None)
     a, tbl, mdl, nP = _random_case(D, seed0 + k, n_circ=n_circ, nG=nG, nR=nR, nEl=nEl, max_len=max_len)
     tag = "case %d: D=%d circuits=%d nG=%d nR=%d nEl=%d max_len=%d slots=%d tasks=%d persist=%s" % (
         k, D, n_circ, nG, nR, nEl, max_len, max_slots, target_tasks, persist)

@@ -1,5 +1,5 @@
 """Development aid: where the CPTPLND finite-difference Jacobian's time goes -- columns of one gate, of the preparation,
-of the POVM, all; GST_LB_SHARE=0/1."""
+of the POVM, all."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,7 +1,7 @@
 #!/bin/bash
-# development aid: one traced FD run (GST_FD_TRACE) on a 1/RANKS atom; env: RANKS, GST_FD_PERSIST, GST_FD_HANDOVER
+# development aid: one traced FD run (GST_FD_TRACE) on a 1/RANKS atom; env: RANKS, GST_TEST_FORCE
 mkdir -p gpurun_out
-GST_FD_DEBUG=1 GST_FD_TRACE=gpurun_out/trace_one.bin timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-analytic --no-host-fill --emulate-ranks ${RANKS:-8} > gpurun_out/tr_one.json 2> gpurun_out/tr_one.err
+GST_FD_TRACE=gpurun_out/trace_one.bin timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-analytic --no-host-fill --emulate-ranks ${RANKS:-8} > gpurun_out/tr_one.json 2> gpurun_out/tr_one.err
 grep gstfwd gpurun_out/tr_one.err | tail -2
 python tools/trace_stats.py gpurun_out/trace_one.bin
 python - <<'PY'
