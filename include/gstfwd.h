@@ -474,12 +474,12 @@ int gst_get_program(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t 
  * prog_off[t * n_classes + c + 1]), empty when no outcome of the task sees the object.  GST_OP_CACHE id starts from state
  * `id` of the base pass; the rest are the ordinary opcodes.  Copies up to `cap` words, the total in *n_words; prog_off
  * (may be NULL) receives n_tasks * n_classes + 1 offsets when cap_progs suffices. */
-/* The level program of the forward plan (which = 0) or of the plan of the reversed circuits (which = 1; nv = n_effects
- * vectors per state), built on the host for this call (no device needed) -- what GST_OPT_FAST_CHAINS executes; format in
+/* The level program of the forward plan (which = 0; which = 2: its probability-only form, the circuits' final states and
+ * their sources) or of the plan of the reversed circuits (which = 1; nv = n_effects vectors per state), built on the host for this call (no device needed) -- what GST_OPT_FAST_CHAINS executes; format in
  * csrc/gst_levels.hpp.  Two-call pattern: sizes come back in *n_words / *n_ids; arrays are filled when their capacities
  * suffice.  node_parent / node_sym (may be NULL): the state graph the ids refer to (for which = 1 the reversed plan's).
- * info[12] = usable, worthwhile, nv, scratch matrices per task, most stages of a task, stages, tiles, chains, nodes on
- * chains, sum over tasks of the deepest node, states, tasks. */
+ * info[13] = usable, worthwhile, nv, scratch matrices per task, most stages of a task, stages, tiles, chains, nodes on
+ * chains, sum over tasks of the deepest node, states, tasks, states produced. */
 int gst_get_level_program(const gst_plan *plan, int32_t which, int32_t *words, int64_t cap_words, int64_t *n_words, int32_t *ids,
                           int64_t cap_ids, int64_t *n_ids, int64_t *task_off, int64_t cap_tasks, int32_t *node_parent,
                           int32_t *node_sym, int64_t cap_nodes, int64_t *info);

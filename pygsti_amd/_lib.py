@@ -636,10 +636,10 @@ def _level_program(self, which=0):
     on the host.  Returns dict(usable, worthwhile, nv, max_mats, max_stages, n_stages, n_tiles, n_chains, chain_nodes,
     sum_task_depth, n_states, n_tasks, words, ids, task_off, node_parent, node_sym)."""
     nw, ni = C.c_int64(0), C.c_int64(0)
-    info = np.zeros(12, np.int64)
+    info = np.zeros(13, np.int64)
     check(lib().gst_get_level_program(self._h, int(which), None, 0, C.byref(nw), None, 0, C.byref(ni), None, 0, None, None, 0, _ptr(info)))
     keys = ("usable", "worthwhile", "nv", "max_mats", "max_stages", "n_stages", "n_tiles", "n_chains", "chain_nodes", "sum_task_depth",
-            "n_states", "n_tasks")
+            "n_states", "n_tasks", "n_produced")
     out = {k: int(v) for k, v in zip(keys, info)}
     if not out["usable"]:
         return out

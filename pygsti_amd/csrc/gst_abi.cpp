@@ -181,7 +181,7 @@ struct gst_plan {
         DevBuf<int32_t> d_words, d_ids;
         DevBuf<int64_t> d_task_off, d_ids_off;
         DevBuf<double> d_mats;
-    } lv_fwd, lv_rev;
+    } lv_fwd, lv_rev, lv_probs;      // lv_probs: the forward plan's probability-only program (only the circuits' final states and their sources)
     int fast_chains = 1;                // GST_OPT_FAST_CHAINS: 0 never, 1 where the stages are few against the chains (default), 2 always (tests)
     bool fast_probs = false;            // GST_OPT_FAST_PROBS: gst_fill_probs* through the level pass (<= 1e-10, not bit-exact)
     bool last_levels = false;           // the last fill took its states from the level pass
@@ -489,21 +489,21 @@ int upload_i32(DevBuf<int32_t>& b, const std::vector<int32_t>& v, hipStream_t s)
 
 // The level program of the forward plan (`rev` false) or of the reversed plan, built once on the host (the reversed
 // plan's while its state graph still exists: ensure_reverse).
-void build_levels_host(gst_plan* p, bool rev)
+void build_levels_host(gst_plan* p, bool rev, bool probs_only = false)
 {
-    gst_plan::Levels& L = rev ? p->lv_rev : p->lv_fwd;
+    gst_plan::Levels& L = rev ? p->lv_rev : (probs_only ? p->lv_probs : p->lv_fwd);
     if (L.built) return;
     L.built = true;
     const gst::HostPlan& h = rev ? p->rev : p->hp;
-    L.why = gst::build_level_program(h, rev ? p->hp.n_effects : 1, L.prog);
+    L.why = gst::build_level_program(h, rev ? p->hp.n_effects : 1, L.prog, probs_only ? &p->hp.circ_leaf : nullptr);
     L.usable = L.why.empty();
 }
 
-int ensure_levels(gst_plan* p, bool rev)
+int ensure_levels(gst_plan* p, bool rev, bool probs_only = false)
 {
-    gst_plan::Levels& L = rev ? p->lv_rev : p->lv_fwd;
+    gst_plan::Levels& L = rev ? p->lv_rev : (probs_only ? p->lv_probs : p->lv_fwd);
     const gst::HostPlan& h = rev ? p->rev : p->hp;
-    build_levels_host(p, rev);
+    build_levels_host(p, rev, probs_only);
     if (!L.usable || L.uploaded) return GST_OK;
     int rc;
     if ((rc = upload_i32(L.d_words, L.prog.words, p->stream))) return rc;
@@ -534,13 +534,13 @@ bool levels_wanted(const gst_plan* p, const gst_plan::Levels& L)
 
 // Every state of the forward trie into the base-state cache by the level pass, then (d_dst != NULL) the probabilities from
 // the circuits' final states.  The caller has checked levels_wanted(p, p->lv_fwd).
-int run_levels_forward(gst_plan* p, double* d_dst)
+int run_levels_forward(gst_plan* p, double* d_dst, bool probs_only = false)
 {
     const gst::HostPlan& h = p->hp;
     int rc;
     HIP_TRY(p->d_base_cache.ensure((size_t)h.n_state_ids * h.D));
     gst::LevelArgs a;
-    level_args(p->lv_fwd, a);
+    level_args(probs_only ? p->lv_probs : p->lv_fwd, a);
     a.bmats = p->d_gates_t.p; a.starts = p->d_rhos.p; a.cache = p->d_base_cache.p;
     HIP_TRY(gst::launch_level_pass(a, h.n_tasks(), p->stream));
     p->last_launches++;
@@ -563,9 +563,9 @@ int run_probs_any(gst_plan* p, double* d_dst)
 {
     p->last_levels = false;
     if (p->fast_probs && p->hp.D == 16 && p->fast_chains) {
-        int rc = ensure_levels(p, false);
+        int rc = ensure_levels(p, false, true);
         if (rc) return rc;
-        if (levels_wanted(p, p->lv_fwd)) return run_levels_forward(p, d_dst);
+        if (levels_wanted(p, p->lv_probs)) return run_levels_forward(p, d_dst, true);
     }
     return run_probs(p, d_dst, false);
 }
@@ -3005,7 +3005,7 @@ int gst_get_level_program(const gst_plan* p, int32_t which, int32_t* words, int6
 {
     return guarded([&]() -> int {
     if (!p || !n_words || !n_ids || !info) return fail(GST_EINVAL, "NULL argument");
-    if (which != 0 && which != 1) return fail(GST_EINVAL, "which: 0 = forward plan, 1 = reversed plan");
+    if (which < 0 || which > 2) return fail(GST_EINVAL, "which: 0 = forward plan, 1 = reversed plan, 2 = forward plan, probability-only");
     // (a const plan, possibly without a device: built for this call only, exactly as ensure_levels / ensure_reverse build them)
     gst::HostPlan R;
     const gst::HostPlan* h = &p->hp;
@@ -3015,9 +3015,9 @@ int gst_get_level_program(const gst_plan* p, int32_t which, int32_t* words, int6
         h = &R;
     }
     gst::LevelProgram L;
-    const std::string why = gst::build_level_program(*h, which == 1 ? p->hp.n_effects : 1, L);
+    const std::string why = gst::build_level_program(*h, which == 1 ? p->hp.n_effects : 1, L, which == 2 ? &p->hp.circ_leaf : nullptr);
     info[0] = why.empty() ? 1 : 0; info[1] = L.worthwhile ? 1 : 0; info[2] = L.nv; info[3] = L.max_mats; info[4] = L.max_stages;
-    info[5] = L.n_stages; info[6] = L.n_tiles; info[7] = L.n_chains; info[8] = L.chain_nodes; info[9] = L.sum_task_depth;
+    info[5] = L.n_stages; info[6] = L.n_tiles; info[7] = L.n_chains; info[8] = L.chain_nodes; info[9] = L.sum_task_depth; info[12] = L.n_produced;
     info[10] = h->n_state_ids; info[11] = h->n_tasks();
     *n_words = (int64_t)L.words.size(); *n_ids = (int64_t)L.ids.size();
     if (!why.empty()) return GST_OK;

@@ -22,7 +22,7 @@ struct Chain {
 
 }  // namespace
 
-std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out)
+std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out, const std::vector<int32_t>* keep_ids)
 {
     out = LevelProgram();
     out.D = P.D; out.nv = nv;
@@ -32,6 +32,13 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
     if (P.n_gates >= (1 << 20)) return "too many gates";
     const int per_tile = 16 / nv;
     const int64_t nT = P.n_tasks();
+    // keep_ids: only these states (and what they are computed from) are produced -- the probability-only program
+    std::vector<uint8_t> keep_mark;
+    if (keep_ids) {
+        keep_mark.assign((size_t)P.n_state_ids, 0);
+        for (int32_t id : *keep_ids) if (id >= 0 && id < P.n_state_ids) keep_mark[(size_t)id] = 1;
+    }
+    std::vector<uint8_t> need;
     out.task_off.assign(1, 0);
     out.task_ids_off.assign(1, 0);
     std::vector<int32_t> par, sym, depth, ready, chain_of, pos_in, run, anc, best_len, best_m;
@@ -123,6 +130,22 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
             chains.push_back(std::move(ch));
         }
         out.n_chains += (int64_t)chains.size();
+        // ---- which states are produced: all of them, or the kept ones and their sources (children before parents) ----
+        need.assign((size_t)n, keep_ids ? 0 : 1);
+        if (keep_ids) {
+            for (int32_t i = 1; i < n; i++) need[(size_t)i] = keep_mark[(size_t)(base + i)];
+            for (int32_t i = n - 1; i >= 1; i--) {
+                if (!need[(size_t)i]) continue;
+                const int32_t ci = chain_of[(size_t)i];
+                if (ci < 0) { need[(size_t)par[(size_t)i]] = 1; continue; }
+                const Chain& ch = chains[(size_t)ci];
+                const int32_t pos = pos_in[(size_t)i], r = pos / ch.m;
+                int32_t src_pos;                                    // the position this node is computed from (see schedule_chain)
+                if (pos % ch.m) src_pos = r * ch.m;                 // inside a period: from its period's boundary X_r
+                else { int32_t k = 0; while ((2 << k) <= r) k++; src_pos = (r - (1 << k)) * ch.m; }     // X_r from X_{r - 2^k}
+                need[(size_t)(src_pos == 0 ? ch.start : ch.nodes[(size_t)src_pos - 1])] = 1;
+            }
+        }
         // ---- stages ----
         std::vector<std::vector<Tile>> stages;
         auto stage_ref = [&](int32_t s) -> std::vector<Tile>& {
@@ -138,6 +161,7 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
                 const int32_t b = (int32_t)out.ids.size();
                 out.ids.insert(out.ids.end(), dst.begin() + (long)k0, dst.begin() + (long)k0 + cnt);
                 stage_ref(stage).push_back(Tile{LV_KIND_ROWS, cnt, mref, a, b});
+                out.n_produced += cnt;
             }
         };
         int32_t n_slots = 0;
@@ -181,8 +205,10 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
                 st = std::max(st, t_pow[(size_t)k]) + 1;
                 src.clear(); dst.clear();
                 for (int32_t j = 0; j < cnt; j++) {
+                    const int32_t dn = ch.nodes[(size_t)((have + j) * m) - 1];
+                    ready[(size_t)dn] = st;       // (what hangs off an early node need not wait for the whole chain)
+                    if (!need[(size_t)dn]) continue;
                     src.push_back(pos_id(j * m)); dst.push_back(pos_id((have + j) * m));
-                    ready[(size_t)ch.nodes[(size_t)((have + j) * m) - 1]] = st;       // (what hangs off an early node need not wait for the whole chain)
                 }
                 rows_tile(st, pow_ref[(size_t)k], src, dst);
             }
@@ -193,8 +219,10 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
                 for (int32_t s = 1; s < m; s++) {
                     src.clear(); dst.clear();
                     for (int32_t r = 0; r * m + s <= T; r++) {
+                        const int32_t dn = ch.nodes[(size_t)(r * m + s) - 1];
+                        ready[(size_t)dn] = st;
+                        if (!need[(size_t)dn]) continue;
                         src.push_back(pos_id(r * m)); dst.push_back(pos_id(r * m + s));
-                        ready[(size_t)ch.nodes[(size_t)(r * m + s) - 1]] = st;
                     }
                     rows_tile(st, prefix_ref[(size_t)s], src, dst);
                 }
@@ -204,6 +232,7 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
         for (int32_t i = 1; i < n; i++) {
             if (depth[(size_t)i] == 1) {                                // a start vector: copied into its node at stage 0
                 ready[(size_t)i] = 0;
+                if (!need[(size_t)i]) continue;
                 auto& b = buckets[{0, LV_BMAT_IDENT}];
                 b.first.push_back(-(sym[(size_t)i] + 1)); b.second.push_back(gid(i));
                 continue;
@@ -216,6 +245,7 @@ std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out
             }
             const int32_t st = ready[(size_t)par[(size_t)i]] + 1;
             ready[(size_t)i] = st;
+            if (!need[(size_t)i]) continue;
             auto& b = buckets[{st, sym[(size_t)i]}];
             b.first.push_back(gid(par[(size_t)i])); b.second.push_back(gid(i));
         }

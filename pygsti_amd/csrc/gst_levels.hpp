@@ -51,13 +51,15 @@ struct LevelProgram {
     int64_t max_task_ints = 0;           // most words + ids of one task (what the kernel stages in LDS)
     int32_t max_mats = 0;          // scratch matrices a task needs at most (every slot is written ONCE per pass)
     int32_t max_stages = 0;
-    int64_t n_stages = 0, n_tiles = 0, n_chains = 0, chain_nodes = 0, n_nodes = 0;
+    int64_t n_stages = 0, n_tiles = 0, n_chains = 0, chain_nodes = 0, n_nodes = 0, n_produced = 0;
     int64_t sum_task_depth = 0;    // sum over tasks of the deepest node: the dependent steps of the sequential walk
     bool worthwhile = false;       // the stages are few against those steps
 };
 
 // Schedules every task of P (P.task_node0 / task_nodes / node_parent / node_sym).  nv * k == 16 for some k is required.
 // Returns "" or why the plan has no level program (the caller then keeps the sequential walk).
-std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out);
+// keep_ids (may be NULL = every state): produce only these states and the ones they are computed from -- with the circuits'
+// final states this is the probability-only program (most positions inside a germ period are then never formed).
+std::string build_level_program(const HostPlan& P, int32_t nv, LevelProgram& out, const std::vector<int32_t>* keep_ids = nullptr);
 
 }  // namespace gst

@@ -115,6 +115,48 @@ def test_level_program_of_the_bench_design_is_shallow():
         print("which=%d: %.2f s; %s" % (which, dt, {k: v for k, v in lp.items() if not hasattr(v, "shape")}))
 
 
+@pytest.mark.parametrize("name", ["smq2Q_XYICNOT_L1024_deep", "smq2Q_XYICNOT_L2_depol"])
+def test_probability_only_program_produces_the_final_states(name):
+    """which = 2: only the circuits' final states and what they are computed from (doubling sources, period boundaries,
+    the paths to them) -- every final state equals the sequential walk's, far fewer states are formed on deep families."""
+    fx = load_fixture(name)
+    pl = make(fx)
+    full, lp = pl.level_program(0), pl.level_program(2)
+    assert lp["usable"]
+    G, R = fx["gates"], fx["rhos"]
+    bmats, starts = np.transpose(G, (0, 2, 1)), R[:, None, :]
+    cache, n_stages = interpret(lp, bmats, starts, 1)
+    assert len(cache) == lp["n_produced"] <= full["n_produced"]
+    par, sym = lp["node_parent"], lp["node_sym"]
+    # the final state of every circuit: the state graph's leaves of the fixture's circuits, walked sequentially
+    _, _, leaf = pl_state_graph(pl)
+    assert set(int(x) for x in leaf) <= set(cache.keys())
+    for c in range(0, len(leaf), max(1, len(leaf) // 60)):
+        path, i = [], int(leaf[c])
+        while i >= 0:
+            path.append(i); i = int(par[i])
+        X = None
+        for i in reversed(path):
+            X = starts[int(sym[i])] if par[i] < 0 else X @ bmats[int(sym[i])]
+        assert np.abs(cache[int(leaf[c])].T - X).max() < 1e-12
+    if "L1024" in name:
+        assert lp["n_produced"] < 0.5 * full["n_produced"], (lp["n_produced"], full["n_produced"])
+        assert lp["max_stages"] <= full["max_stages"]
+
+
+def pl_state_graph(pl):
+    import ctypes as C
+    from pygsti_amd import _lib
+    n = C.c_int64(0)
+    _lib.check(_lib.lib().gst_get_state_graph(pl._h, None, None, 0, None, 0, C.byref(n)))
+    par = np.empty(n.value, np.int32); sym = np.empty(n.value, np.int32)
+    nc = pl.stats()["n_circuits"]
+    leaf = np.empty(nc, np.int32)
+    _lib.check(_lib.lib().gst_get_state_graph(pl._h, par.ctypes.data_as(C.c_void_p), sym.ctypes.data_as(C.c_void_p), n.value,
+                                              leaf.ctypes.data_as(C.c_void_p), nc, C.byref(n)))
+    return par, sym, leaf
+
+
 def test_non_periodic_and_small_plans_have_no_level_program_or_decline():
     fx = load_fixture("smq1Q_XYI_L128_depol")           # D = 4
     assert not make(fx).level_program(0)["usable"]
