@@ -134,13 +134,6 @@ struct gst_plan {
     DevBuf<int64_t> d_rtask_off, d_pos_ptr;
     DevBuf<int32_t> d_reff_ptr, d_rev_leaf, d_pair_f, d_pair_r, d_circ_rho, d_circ_order, d_circ_partner, d_pair_common;
     DevBuf<int32_t> d_blk_f1, d_blk_f2, d_blk_r, d_blk_ptr;   // two-circuit items as one stream of 4-application blocks (ensure_reverse)
-    // wide items of the D = 16 contraction (analytic_wide_kernel): up to 16 circuits with a common tail per workgroup
-    DevBuf<int32_t> d_w_circ, d_w_ptr, d_w_cg, d_w_r, d_w_f;
-    DevBuf<uint32_t> d_w_range, d_w_counter, d_range_rest;   // XCD ranges of the wide items; of the old kernel's items that are NOT in a wide item
-    int32_t n_witems = 0;
-    int64_t wide_slots = 0;
-    int64_t n_items_rest = 0;           // the old kernel's item list is [items of circuits outside wide items | items of wide circuits]
-    bool ana_wide = true;               // GST_TEST_FORCE wide=0: every circuit through analytic_mfma_kernel
     static constexpr bool ana_stream = true;       // two-circuit items as one block stream (the gate-by-gate form remains for > 63 gates)
     static constexpr bool ana_pairs = true;        // two-circuit work items in the D = 16 contraction
     static constexpr bool ana_germ_order = true;   // germ-major order of the work items
@@ -268,7 +261,6 @@ struct gst_plan {
     bool cached_has_didx = false;
     int32_t cached_n_waves = 0;
     std::vector<int64_t> cached_none_cols;
-    std::vector<int32_t> cached_gate_col0;      // analytic request: per gate, first of D*D consecutive columns / -1 column map / -2 none
 
     bool request_cached(int kind, const int64_t* pidx, const int64_t* didx, int64_t n) const
     {
@@ -363,7 +355,6 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     //   host_direct=0|2   page-locked destinations filled by a copy / by the kernel's own stores at any column count
     //   hess_composed=1   every FD-of-FD Hessian block through the composed route
     //   cache_limit=BYTES stands in for the 4 GB of 32-bit cache offsets (the WIDE contraction kernels)
-    //   wide=0            D = 16 analytic contraction: no wide (16-circuit, LDS-staged) items, every circuit through the per-wavefront kernel
     if (const char* spec = std::getenv("GST_TEST_FORCE")) {
         std::string str(spec);
         size_t pos = 0;
@@ -385,7 +376,6 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
             else if (key == "host_direct") { p->host_direct = iv != 0; if (iv == 2) p->host_direct_min_cols = 1; }
             else if (key == "hess_composed") p->hess_composed = iv != 0;
             else if (key == "cache_limit") p->test_cache_limit = val;
-            else if (key == "wide") p->ana_wide = iv != 0;
             else { delete p; return fail(GST_EINVAL, "GST_TEST_FORCE: unknown key '" + key + "'"); }
         }
     }
@@ -1038,168 +1028,10 @@ int ensure_reverse(gst_plan* p)
         for (int x = 0; x < 4; x++) if (h.eff_label[(size_t)h.eff_ptr[c] + x] != x) return false;
         return true;
     };
-    // WIDE items (analytic_wide_kernel): runs of 3 .. 16 consecutive circuits of the item order that all end like the run's
-    // first circuit -- in a GST design all the preparation fiducials in front of one germ power and measurement fiducial.
-    // One workgroup contracts a run from LDS-staged operands: the common backward vectors are fetched once for all
-    // members.  Per (item, gate): the common tail as a stream of slots (backward id, the members' forward ids), padded
-    // to whole slabs of 8; what a member applies in front of the tail stays in the pair tables (w_cg tells where it ends).
-    std::vector<uint8_t> in_wide((size_t)h.n_circuits, 0);
-    p->n_witems = 0;
-    if (pairing && p->ana_wide && nG <= 63 && h.n_rhos >= 1) {
-        constexpr int WM = 16, SLAB = 8, WMIN = 3, OWN_MAX = 12;
-        // Grouping key of a circuit: the backward state reached after dropping its first `own` gates (own <= OWN_MAX) that the
-        // MOST circuits share -- for prep . germ^q . meas that is the state of germ^q . meas, shared by all the preparation
-        // fiducials.  Members of a group have exactly the same backward states from there on (one suffix-trie node).
-        const std::vector<int32_t>& rpar = p->rev.node_parent;
-        std::vector<int32_t> cnt((size_t)p->rev.n_state_ids, 0);
-        for (int64_t c = 0; c < h.n_circuits; c++) {
-            if (!plain4((int32_t)c)) continue;
-            int32_t id = p->rev.circ_leaf[(size_t)c];
-            const int64_t n = h.circ_ptr[c + 1] - h.circ_ptr[c];
-            for (int64_t own = 0; own <= std::min<int64_t>(OWN_MAX, n) && id >= 0; own++) { cnt[(size_t)id]++; id = rpar[(size_t)id]; }
-        }
-        std::vector<int32_t> key((size_t)h.n_circuits, -1), own_of((size_t)h.n_circuits, 0);
-        for (int64_t c = 0; c < h.n_circuits; c++) {
-            if (!plain4((int32_t)c)) continue;
-            int32_t id = p->rev.circ_leaf[(size_t)c];
-            const int64_t n = h.circ_ptr[c + 1] - h.circ_ptr[c];
-            int32_t best = 0;
-            for (int64_t own = 0; own <= std::min<int64_t>(OWN_MAX, n) && id >= 0; own++) {
-                if (n - own >= 8 && cnt[(size_t)id] >= WMIN && cnt[(size_t)id] > best) { best = cnt[(size_t)id]; key[(size_t)c] = id; own_of[(size_t)c] = (int32_t)own; }
-                id = rpar[(size_t)id];
-            }
-        }
-        // groups in the order of their first member (the item order keeps a germ's chains together in an XCD's L2)
-        std::vector<int32_t> group_of_key((size_t)p->rev.n_state_ids, -1);
-        std::vector<std::vector<int32_t>> groups;
-        for (int64_t k = 0; k < h.n_circuits; k++) {
-            const int32_t c = order[(size_t)k];
-            if (key[(size_t)c] < 0) continue;
-            int32_t& gi = group_of_key[(size_t)key[(size_t)c]];
-            if (gi < 0) { gi = (int32_t)groups.size(); groups.emplace_back(); }
-            groups[(size_t)gi].push_back(c);
-        }
-        std::vector<int32_t> w_circ, w_ptr, w_cg, w_r, w_f;
-        std::vector<double> w_work;
-        std::vector<int32_t> own_g((size_t)WM * nG);
-        for (const auto& grp : groups) {
-            if ((int)grp.size() < WMIN) continue;
-            for (size_t m0 = 0; m0 < grp.size(); m0 += WM) {
-                const int64_t n_mem = (int64_t)std::min<size_t>(WM, grp.size() - m0);
-                if (n_mem < WMIN && m0 > 0) break;                    // (a short remainder stays with the per-wavefront kernel)
-                const int32_t c0 = grp[m0];
-                double work = 0;
-                for (int64_t q = 0; q < WM; q++) w_circ.push_back(q < n_mem ? grp[m0 + (size_t)q] : -1);
-                std::fill(own_g.begin(), own_g.end(), 0);
-                for (int64_t q = 0; q < n_mem; q++) {
-                    const int32_t c = grp[m0 + (size_t)q];
-                    in_wide[(size_t)c] = 1;
-                    work += (double)(h.circ_ptr[c + 1] - h.circ_ptr[c]) + 24.0;
-                    for (int32_t t = 0; t < own_of[(size_t)c]; t++) own_g[(size_t)q * nG + h.circ_gates[(size_t)(h.circ_ptr[c] + t)]]++;
-                }
-                for (int g = 0; g < nG; g++) {
-                    w_ptr.push_back((int32_t)w_r.size());
-                    const int32_t cg = (int32_t)(pos_ptr[(size_t)c0 * nG + g + 1] - pos_ptr[(size_t)c0 * nG + g]) - own_g[(size_t)g];    // gate g in the common tail
-                    w_cg.push_back(cg);
-                    for (int32_t t = 0; t < cg; t++) {
-                        w_r.push_back(pr[(size_t)(pos_ptr[(size_t)c0 * nG + g] + own_g[(size_t)g] + t)]);
-                        for (int64_t q = 0; q < WM; q++) {
-                            if (q >= n_mem) { w_f.push_back(-1); continue; }
-                            const int32_t c = grp[m0 + (size_t)q];
-                            w_f.push_back(pf[(size_t)(pos_ptr[(size_t)c * nG + g] + own_g[(size_t)q * nG + g] + t)]);
-                        }
-                    }
-                    // what a member applies in front of the common tail (at most OWN_MAX gates): slots of its own -- its
-                    // backward state, its forward state, nobody else's -- in the same stream: fifteen sixteenths of their
-                    // products are with zeros, but they ride the pipeline instead of stalling it
-                    for (int64_t q = 0; q < n_mem; q++) {
-                        const int32_t c = grp[m0 + (size_t)q];
-                        for (int32_t t = 0; t < own_g[(size_t)q * nG + g]; t++) {
-                            const int64_t at = pos_ptr[(size_t)c * nG + g] + t;
-                            w_r.push_back(pr[(size_t)at]);
-                            for (int64_t q2 = 0; q2 < WM; q2++) w_f.push_back(q2 == q ? pf[(size_t)at] : -1);
-                        }
-                    }
-                    while (w_r.size() % SLAB) { w_r.push_back(w_r.empty() ? 0 : w_r.back()); for (int q = 0; q < WM; q++) w_f.push_back(-1); }
-                }
-                w_ptr.push_back((int32_t)w_r.size());
-                w_work.push_back(work);
-                if (w_r.size() > 0x7ff00000u / WM) return fail(GST_EUNSUPPORTED, "wide item stream too long");
-            }
-        }
-        p->n_witems = (int32_t)w_work.size();
-        if (p->n_witems > 0) {
-            // two queues: deep items first in the arrays, then shallow ones (both keep the germ-major order); each queue cut
-            // into 8 XCD ranges of equal work.  wr[0..8]: deep, wr[9..17]: shallow.
-            const size_t nI = w_work.size();
-            constexpr int32_t DEEP_SLOTS = 160;
-            std::vector<int32_t> perm;
-            perm.reserve(nI);
-            auto slots_of = [&](size_t q) { return w_ptr[q * (nG + 1) + nG] - w_ptr[q * (nG + 1)]; };
-            for (size_t q = 0; q < nI; q++) if (slots_of(q) >= DEEP_SLOTS) perm.push_back((int32_t)q);
-            const size_t n_deep = perm.size();
-            for (size_t q = 0; q < nI; q++) if (slots_of(q) < DEEP_SLOTS) perm.push_back((int32_t)q);
-            {
-                std::vector<int32_t> c2(w_circ.size()), p2(w_ptr.size()), g2(w_cg.size());
-                std::vector<double> k2(nI);
-                for (size_t q = 0; q < nI; q++) {
-                    const size_t o = (size_t)perm[q];
-                    std::copy(w_circ.begin() + (long)(o * WM), w_circ.begin() + (long)((o + 1) * WM), c2.begin() + (long)(q * WM));
-                    std::copy(w_ptr.begin() + (long)(o * (nG + 1)), w_ptr.begin() + (long)((o + 1) * (nG + 1)), p2.begin() + (long)(q * (nG + 1)));
-                    std::copy(w_cg.begin() + (long)(o * nG), w_cg.begin() + (long)((o + 1) * nG), g2.begin() + (long)(q * nG));
-                    k2[q] = w_work[o];
-                }
-                w_circ.swap(c2); w_ptr.swap(p2); w_cg.swap(g2); w_work.swap(k2);
-            }
-            std::vector<uint32_t> wr(18, 0);
-            auto cut = [&](size_t a0, size_t a1, uint32_t* out9, bool by_slots) {
-                double total = 0, accw = 0;
-                for (size_t q = a0; q < a1; q++) total += by_slots ? (double)slots_of(q) + 16.0 : w_work[q];
-                int r = 1;
-                out9[0] = (uint32_t)a0;
-                for (size_t q = a0; q < a1 && r < 8; q++) {
-                    accw += by_slots ? (double)slots_of(q) + 16.0 : w_work[q];
-                    while (r < 8 && accw >= total * r / 8.0) out9[r++] = (uint32_t)(q + 1);
-                }
-                for (; r < 8; r++) out9[r] = (uint32_t)a1;
-                out9[8] = (uint32_t)a1;
-            };
-            cut(0, n_deep, wr.data(), true);
-            cut(n_deep, nI, wr.data() + 9, false);
-            if (w_r.empty()) { w_r.assign(SLAB, 0); w_f.assign((size_t)SLAB * WM, -1); }
-            if ((rc = upload_i32(p->d_w_circ, w_circ, p->stream))) return rc;
-            if ((rc = upload_i32(p->d_w_ptr, w_ptr, p->stream))) return rc;
-            if ((rc = upload_i32(p->d_w_cg, w_cg, p->stream))) return rc;
-            if ((rc = upload_i32(p->d_w_r, w_r, p->stream))) return rc;
-            if ((rc = upload_i32(p->d_w_f, w_f, p->stream))) return rc;
-            HIP_TRY(p->d_w_range.ensure(18));
-            HIP_TRY(hipMemcpyAsync(p->d_w_range.p, wr.data(), 18 * 4, hipMemcpyHostToDevice, p->stream));
-            HIP_TRY(p->d_w_counter.ensure(16));
-            HIP_TRY(hipStreamSynchronize(p->stream));
-            p->wide_slots = (int64_t)w_r.size();
-            if (std::getenv("GST_PLAN_TIMING")) {
-                int64_t n_in = 0, common = 0;
-                for (uint8_t v : in_wide) n_in += v;
-                for (int32_t v : w_cg) common += v;
-                std::fprintf(stderr, "[plan] wide items %d (%lld of %lld circuits), slots %lld (common %lld, own + padding %lld)\n", p->n_witems,
-                             (long long)n_in, (long long)h.n_circuits, (long long)w_r.size(), (long long)common, (long long)((int64_t)w_r.size() - common));
-            }
-        }
-    }
-    // The per-wavefront kernel's item list: first the circuits outside wide items, then the wide circuits (the Hessian rows
-    // and the forms the wide kernel does not cover run every circuit through it).  Pairs never mix the two parts.
-    std::vector<int32_t> order2;
-    order2.reserve((size_t)h.n_circuits);
-    for (int64_t k = 0; k < h.n_circuits; k++) if (!in_wide[(size_t)order[(size_t)k]]) order2.push_back(order[(size_t)k]);
-    const int64_t n_circ_rest = (int64_t)order2.size();
-    for (int64_t k = 0; k < h.n_circuits; k++) if (in_wide[(size_t)order[(size_t)k]]) order2.push_back(order[(size_t)k]);
-    order.swap(order2);
-    p->n_items_rest = -1;
     for (int64_t k = 0; k < h.n_circuits; k++) {
-        if (k == n_circ_rest) p->n_items_rest = (int64_t)item_first.size();
         const int32_t c = order[(size_t)k];
         bool paired = false;
-        if (pairing && k + 1 < h.n_circuits && k + 1 != n_circ_rest) {
+        if (pairing && k + 1 < h.n_circuits) {
             const int32_t c2 = order[(size_t)k + 1];
             if (plain4(c) && plain4(c2)) {
                 std::vector<int32_t> cg((size_t)nG, 0);
@@ -1218,7 +1050,6 @@ int ensure_reverse(gst_plan* p)
         }
     }
     const int64_t n_items = (int64_t)item_first.size();
-    if (p->n_items_rest < 0) p->n_items_rest = n_items;
     if (h.D == 16) {
         if ((rc = upload_i32(p->d_circ_order, item_first, p->stream))) return rc;
         if ((rc = upload_i32(p->d_circ_partner, item_partner, p->stream))) return rc;
@@ -1250,27 +1081,6 @@ int ensure_reverse(gst_plan* p)
     }
     HIP_TRY(p->d_range_begin.ensure(9));
     HIP_TRY(hipMemcpyAsync(p->d_range_begin.p, range_begin.data(), 9 * 4, hipMemcpyHostToDevice, p->stream));
-    {   // ... and the ranges over the first part of the list only (what runs beside the wide kernel)
-        std::vector<uint32_t> rr(9, 0);
-        if (h.D == 16 && p->n_witems > 0) {
-            auto work1 = [&](int64_t k) {
-                double w = (double)(h.circ_ptr[item_first[(size_t)k] + 1] - h.circ_ptr[item_first[(size_t)k]]) + 24.0;
-                if (item_partner[(size_t)k] >= 0) w += (double)(h.circ_ptr[item_partner[(size_t)k] + 1] - h.circ_ptr[item_partner[(size_t)k]]) + 24.0;
-                return w;
-            };
-            double total = 0, accw = 0;
-            for (int64_t k = 0; k < p->n_items_rest; k++) total += work1(k);
-            int r = 1;
-            for (int64_t k = 0; k < p->n_items_rest && r < 8; k++) {
-                accw += work1(k);
-                while (r < 8 && accw >= total * r / 8.0) rr[(size_t)r++] = (uint32_t)(k + 1);
-            }
-            for (; r < 8; r++) rr[(size_t)r] = (uint32_t)p->n_items_rest;
-            rr[8] = (uint32_t)p->n_items_rest;
-        }
-        HIP_TRY(p->d_range_rest.ensure(9));
-        HIP_TRY(hipMemcpyAsync(p->d_range_rest.p, rr.data(), 9 * 4, hipMemcpyHostToDevice, p->stream));
-    }
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(p->d_work_counter.ensure(8));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1377,7 +1187,6 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
             p->graph_uploaded = true;
         }
         p->cached_kind = 0;
-        p->cached_gate_col0 = col0;
         if ((rc = upload_i32(p->d_gate_col0, col0, p->stream))) return rc;
         if ((rc = upload_i32(p->d_cm_gate, cm_gate, p->stream))) return rc;
         if ((rc = upload_i32(p->d_cm_rho, cm_rho, p->stream))) return rc;
@@ -1473,31 +1282,12 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         a.zeros_resident = (p->ana_keep_zeros && same_dest && !p->derivs_set) ? 1 : 0;
         p->ana_zero_out = d_out; p->ana_zero_ld = ld; p->ana_zero_valid = (D == 16);
         HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
-        p->last_ana = a; p->last_ana_valid = true;     // (the Hessian rows re-launch the per-wavefront contraction, over every circuit, with other caches)
-        // Wide items: a plain Jacobian whose requested gate blocks are contiguous column runs, narrow caches -- the
-        // workgroup-per-run kernel takes the runs, the per-wavefront kernel the circuits outside them (disjoint rows)
-        bool use_wide = D == 16 && p->n_witems > 0 && p->ana_wide && !a.wide && !p->want_cache_path;
-        if (use_wide)
-            for (int g = 0; g < h.n_gates; g++) use_wide = use_wide && p->cached_gate_col0[(size_t)g] != -1;
-        if (use_wide) {
-            a.w_circ = p->d_w_circ.p; a.w_ptr = p->d_w_ptr.p; a.w_cg = p->d_w_cg.p; a.w_r = p->d_w_r.p; a.w_f = p->d_w_f.p;
-            a.w_range_begin = p->d_w_range.p; a.w_counter = p->d_w_counter.p; a.n_witems = p->n_witems;
-            HIP_TRY(hipMemsetAsync(p->d_w_counter.p, 0, 16 * sizeof(uint32_t), p->stream));
-            p->last_launches++;
-            if (const char* e = std::getenv("GST_WIDE_DEBUG")) a.zeros_resident = std::atoi(e);     // (TEMPORARY ablation switch)
-            HIP_TRY(gst::launch_analytic_wide(a, p->n_cus, p->stream));
-            a.range_begin = p->d_range_rest.p;
-            a.zeros_resident = 0;
-            if (p->n_items_rest > 0) { HIP_TRY(gst::launch_analytic_mfma(a, p->stream)); p->last_launches++; }
-            p->ana_zero_valid = false;
-            TIME_REC(p, evk1);
-            return GST_OK;
-        }
         if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
         else if (D == 16) HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
         else HIP_TRY(gst::launch_analytic_small(a, p->stream));
         TIME_REC(p, evk1);
         p->last_launches++;
+        p->last_ana = a; p->last_ana_valid = true;     // (the Hessian rows re-launch the contraction with other caches)
         return GST_OK;
     }
     if (D == 64) return fail(GST_EUNSUPPORTED, "D = 64 analytic derivatives exist on the MFMA path only");

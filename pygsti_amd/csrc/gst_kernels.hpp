@@ -174,18 +174,7 @@ struct AnaArgs {
     const int32_t *blk_f1, *blk_f2, *blk_r, *blk_ptr;
     int32_t wide;                 // a state cache (or a derivative-state cache of a Hessian row) is 4 GB or larger: 64-bit lane offsets
     int32_t zeros_resident;       // D = 16 stream form: the blocks of gates an item never applies already hold zeros in `out`: not stored
-    // D = 16 WIDE items (analytic_wide_kernel): up to 16 circuits that end with the same applications (one germ power and
-    // measurement fiducial behind all the preparation fiducials) contracted by ONE workgroup from LDS-staged operands
-    const int32_t* w_circ;        // [n_witems][16] member circuits (-1: none)
-    const int32_t* w_ptr;         // [n_witems][nG + 1] first slot of gate g's common stream (slots padded to whole slabs of 8)
-    const int32_t* w_cg;          // [n_witems][nG] applications of gate g in the common tail (the rest of a member's are its own)
-    const int32_t* w_r;           // [n_wslots] backward state id of the slot
-    const int32_t* w_f;           // [n_wslots][16] forward state id of each member (-1: no application in this slot)
-    const uint32_t* w_range_begin;   // [2][9] the deep and the shallow wide items, each cut into 8 ranges of equal work
-    uint32_t* w_counter;          // [2][8]
-    int32_t n_witems;
 };
-hipError_t launch_analytic_wide(const AnaArgs& a, int n_cus, hipStream_t stream);   // D = 16, four plain effects, contiguous gate columns
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
 hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream);   // D = 16
 int analytic_stream_chunks();        // chunks of 4 slots per block of the D = 16 stream (the host pads every gate's slots to whole blocks)

@@ -661,205 +661,6 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// analytic_wide_kernel (D = 16, four plain effects): the contraction of a WIDE item -- up to 16 circuits that end with the
-// same applications (in a GST design: one germ power and measurement fiducial behind all the preparation fiducials) --
-// by one workgroup, as a blocked matrix product with LDS-staged operands:
-//     rows    (outcome o, component a)      <- the item's COMMON backward vectors B_t[a][o]   (64 doubles per application)
-//     columns (member circuit c, comp. b)   <- every member's own forward vector F_t^c[b]     (16 x 16 doubles)
-//     k       the applications t of one gate in the common tail, in slabs of 8
-// A slab is fetched once per workgroup (global -> registers -> LDS, the next slab's loads in flight during the current
-// slab's MFMAs) and read back in the MFMA operand layouts, conflict-free: wavefront w owns members 4w .. 4w+3 and issues
-// 4 x 4 x 2 = 32 MFMAs per slab from 16 LDS reads.  The per-wavefront items of analytic_mfma_kernel request three cache
-// lines per MFMA from the L1 (whose miss queue is what bounds that kernel, profiles/r02_analytic_mix.json); here it is
-// 0.3, and the index arithmetic is per slab, not per MFMA.  Applications in front of the common tail (the preparation
-// fiducials' own gates: a handful per member) are added by the owning wavefront with direct gathers; then the
-// wavefront stores its 16 tiles.
-constexpr int WD_SLAB = 8;             // applications per slab
-constexpr int WD_MEM = 16;             // circuits per wide item
-constexpr int WD_BDBL = WD_SLAB * 64;  // doubles of a slab's backward part [o][slot][a]
-constexpr int WD_BUF = WD_BDBL + WD_MEM * WD_SLAB * 16;
-__global__ __launch_bounds__(256, 2) void analytic_wide_kernel(const AnaArgs a)
-{
-    constexpr int D = 16, NX = 4;
-    __shared__ double lds[2][WD_BUF];
-    __shared__ uint32_t s_item;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int kk = lane >> 4, i = lane & 15;
-    const int nG = a.n_gates, nE = a.n_effects;
-    const char* const fb = (const char*)a.base_cache;
-    const char* const rb = (const char*)a.rev_cache;
-    const int xcd = blockIdx.x & 7;
-    int probe = 0;                                   // (used by thread 0 only)
-    const int first_q = (blockIdx.x >= gridDim.x / 2) ? 1 : 0;
-    for (;;) {
-        __syncthreads();                             // (everybody has read the previous s_item and left the LDS buffers)
-        if (tid == 0) {
-            // Two queues, each cut into 8 XCD ranges: DEEP items (long matrix work between their stores) and SHALLOW ones
-            // (hardly anything but stores).  The two workgroups of a CU start on different queues, so that one's store
-            // drain runs beside the other's MFMAs; a workgroup whose queue is empty helps with the other.
-            uint32_t it = 0xffffffffu;
-            for (; probe < 16; probe++) {
-                const int q = ((probe >> 3) ^ first_q) & 1, rg = (xcd + (probe & 7)) & 7;
-                const uint32_t r0 = a.w_range_begin[9 * q + rg], r1 = a.w_range_begin[9 * q + rg + 1];
-                const uint32_t cu = atomicAdd(a.w_counter + 8 * q + rg, 1u);
-                if ((uint64_t)r0 + cu < (uint64_t)r1) { it = r0 + cu; break; }
-            }
-            s_item = it;
-        }
-        __syncthreads();
-        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
-        if (item == 0xffffffffu) break;
-        // this wavefront's four members, their outcome rows
-        int32_t cm[4];
-        int64_t dest[4][NX];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            cm[j] = __builtin_amdgcn_readfirstlane(as_const(a.w_circ)[(int64_t)item * WD_MEM + 4 * wv + j]);
-            const int32_t x0 = cm[j] >= 0 ? as_const(a.eff_ptr)[cm[j]] : 0;
-#pragma unroll
-            for (int x = 0; x < NX; x++) dest[j][x] = cm[j] >= 0 ? (int64_t)as_const(a.eff_dest)[x0 + x] : 0;
-        }
-        // SPAM columns: lane group kk looks after outcome kk (dp/dE[a] = F_n[a] for the outcome's own effect, dp/drho[b] = B_0[b])
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (cm[j] < 0) continue;
-            const int64_t c = cm[j];
-            const int64_t dest_l = dest[j][0] * (kk == 0) + dest[j][1] * (kk == 1) + dest[j][2] * (kk == 2) + dest[j][3] * (kk == 3);
-            const int32_t fleaf = as_const(a.circ_leaf)[c], rleaf = as_const(a.rev_leaf)[c], rsym = as_const(a.circ_rho)[c];
-            const double FL = *(const double*)(fb + (int64_t)fleaf * (D * 8) + i * 8);
-            for (int e2 = 0; e2 < nE; e2++) {
-                const int32_t ce = a.colmap_eff[e2 * D + i];
-                if (ce >= 0) a.out[dest_l * a.ld + ce] = (e2 == kk) ? FL : 0.0;
-            }
-            const double B0 = *(const double*)(rb + (int64_t)rleaf * (nE * D * 8) + ((int64_t)i * nE + kk) * 8);
-            for (int r2 = 0; r2 < a.n_rhos; r2++) {
-                const int32_t cr = a.colmap_rho[r2 * D + i];
-                if (cr >= 0) a.out[dest_l * a.ld + cr] = (r2 == rsym) ? B0 : 0.0;
-            }
-        }
-        // The item's slots of ALL gates are one contiguous stream (w_ptr[item][0] .. w_ptr[item][nG]; every gate padded to
-        // whole slabs): the fetch -> stage -> multiply pipeline runs through the whole item, and a gate's tiles are stored
-        // when its last slab has been multiplied -- AFTER the next slab's loads have been issued (loads and stores share
-        // one in-order counter on this architecture: a load behind a store cannot be consumed before the store is done).
-        const int32_t* const wp = a.w_ptr + (int64_t)item * (nG + 1);
-        const int32_t S0 = as_const(wp)[0];
-        const int32_t n_slab = (as_const(wp)[nG] - S0) / WD_SLAB;
-        d4_t acc[4][NX];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int x = 0; x < NX; x++) acc[j][x] = (d4_t){0.0, 0.0, 0.0, 0.0};
-        auto flush = [&](const int g) {                      // the wavefront's 16 tiles of gate g -> Jacobian rows, accumulators cleared
-            const int32_t c0 = as_const(a.gate_col0)[g];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (cm[j] >= 0 && c0 >= 0 && !(a.zeros_resident & 4)) {
-#pragma unroll
-                    for (int x = 0; x < NX; x++) {
-                        double* o = a.out + dest[j][x] * a.ld + c0 + kk * D + i;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) __builtin_nontemporal_store(acc[j][x][r], &o[4 * r * D]);
-                    }
-                }
-#pragma unroll
-                for (int x = 0; x < NX; x++) acc[j][x] = (d4_t){0.0, 0.0, 0.0, 0.0};
-            }
-        };
-        // Staging, per thread: 2 doubles of the backward part (slot (tid >> 6) + 4 e, element tid & 63 of its [a][o] block) and 8
-        // of the forward part (slot (tid >> 4) & 7, component tid & 15, members 8 (tid >> 7) + e) -- the eight member ids
-        // are two 16-byte loads of a slot's id row.  Depth of the pipeline: the MFMAs of slab n run while the data of slabs
-        // n + 1 and n + 2 are in flight (two register sets) and the ids of slab n + 3 are being read; with one slab of
-        // look-ahead the loads cost as much again as the MFMAs (ablation: 0.8 ms of 2.6), a slab's 0.85 us of matrix work
-        // being shorter than a trip to L2 under load.
-        double rB[2][2], rF[2][8];
-        int32_t rI[2];
-        typedef int32_t i4_t __attribute__((ext_vector_type(4)));
-        i4_t fI[2];
-        const int f_slot = (tid >> 4) & 7, f_m0 = 8 * (tid >> 7), f_b = tid & 15;
-        auto load_ids = [&](const int32_t s) {
-#pragma unroll
-            for (int e = 0; e < 2; e++) rI[e] = a.w_r[s + (tid >> 6) + 4 * e];
-            const i4_t* row = (const i4_t*)__builtin_assume_aligned(a.w_f + (int64_t)(s + f_slot) * WD_MEM + f_m0, 16);
-            fI[0] = row[0]; fI[1] = row[1];
-        };
-        auto fetch_data = [&](auto set_tag) {                // one slab: global -> register set, addresses from the ids loaded earlier
-            constexpr int S = decltype(set_tag)::value;
-#pragma unroll
-            for (int e = 0; e < 2; e++) rB[S][e] = *(const double*)(rb + (int64_t)(uint32_t)rI[e] * (nE * D * 8) + (tid & 63) * 8);
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int32_t f = fI[e >> 2][e & 3];
-                const double v = *(const double*)(fb + (int64_t)(uint32_t)(f < 0 ? 0 : f) * (D * 8) + f_b * 8);
-                rF[S][e] = f < 0 ? 0.0 : v;
-            }
-        };
-        auto stage = [&](auto set_tag) {                     // register set S -> LDS buffer S, in the operand layouts
-            constexpr int S = decltype(set_tag)::value;
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const int slot = (tid >> 6) + 4 * e, within = tid & 63;                  // within = component * 4 + outcome
-                lds[S][(within & 3) * (WD_SLAB * 16) + slot * 16 + (within >> 2)] = rB[S][e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; e++) lds[S][WD_BDBL + (f_m0 + e) * (WD_SLAB * 16) + (tid & 127)] = rF[S][e];      // [member][slot][b]
-        };
-        int g = 0;
-        int32_t g_end = (as_const(wp)[1] - S0) / WD_SLAB;    // first slab BEHIND gate g's
-        // gates in front of the first slab that have no slots at all: their tiles are zeros
-        while (g < nG && g_end == 0) { flush(g); g++; g_end = g < nG ? (as_const(wp)[g + 1] - S0) / WD_SLAB : 0; }
-        using T0 = std::integral_constant<int, 0>;
-        using T1 = std::integral_constant<int, 1>;
-        // Iteration n (parity P): LDS buffer P holds slab n; register set 1 - P holds slab n + 1 (requested an iteration ago);
-        // set P -- staged at the end of the previous iteration -- takes slab n + 2.
-        auto body = [&](auto p_tag, const int32_t n) {
-            constexpr int P = decltype(p_tag)::value;
-            if (n + 2 < n_slab) fetch_data(std::integral_constant<int, P>{});
-            if (n + 3 < n_slab) load_ids(S0 + WD_SLAB * (n + 3));
-            const double* const Bs = lds[P];
-            const double* const Fs = lds[P] + WD_BDBL + (4 * wv) * (WD_SLAB * 16);
-#pragma unroll
-            for (int ks = 0; ks < WD_SLAB / 4; ks++) {
-                double A[NX], Fv[4];
-#pragma unroll
-                for (int x = 0; x < NX; x++) A[x] = Bs[x * (WD_SLAB * 16) + ks * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < 4; j++) Fv[j] = Fs[j * (WD_SLAB * 16) + ks * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-#pragma unroll
-                    for (int x = 0; x < NX; x++) acc[j][x] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[x], Fv[j], acc[j][x], 0, 0, 0);
-            }
-            while (g < nG && n + 1 == g_end) { flush(g); g++; g_end = g < nG ? (as_const(wp)[g + 1] - S0) / WD_SLAB : -1; }
-            if (n + 1 < n_slab) stage(std::integral_constant<int, 1 - P>{});      // buffer 1 - P: slab n - 1's MFMAs ended before the last barrier
-            __syncthreads();
-        };
-        if (n_slab > 0) {
-            load_ids(S0);
-            fetch_data(T0{});
-            if (n_slab > 1) { load_ids(S0 + WD_SLAB); fetch_data(T1{}); }
-            if (n_slab > 2) load_ids(S0 + 2 * WD_SLAB);
-            stage(T0{});
-            __syncthreads();
-            for (int32_t n = 0; n < n_slab; n += 2) {
-                body(T0{}, n);
-                if (n + 1 < n_slab) body(T1{}, n + 1);
-            }
-        }
-        while (g < nG) { flush(g); g++; }
-    }
-}
-
-hipError_t launch_analytic_wide(const AnaArgs& a, int n_cus, hipStream_t stream)
-{
-    if (a.n_witems <= 0) return hipSuccess;
-    (void)hipGetLastError();
-    const int64_t blocks = std::min<int64_t>((int64_t)a.n_witems, (int64_t)2 * (n_cus > 0 ? n_cus : 256));
-    hipLaunchKernelGGL(analytic_wide_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // dwalk_kernel (D = 16): derivative states for the analytic Hessian, four parameters per wavefront (lane group q <->
 // theta_q; see DWalkArgs).  A plain interpreter of the walk programs: the passes are short next to the contractions
 // they feed, so nothing is pipelined here -- the base-state element of an injection is simply read from the cache.

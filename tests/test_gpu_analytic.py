@@ -280,30 +280,3 @@ def test_d64_analytic_jacobian_and_hessian_vs_matrix_simulator_directly():
         assert np.abs(H - href).max() < TOL, (b, np.abs(H - href).max())
         assert np.abs(href).max() > 1e-3
     assert_bitwise(pl.fill_dprobs(param_idx=fx["dprobs_cols"], eps=float(fx["derivative_eps"])), fx["dprobs_map"], "D = 64 FD columns")
-
-
-def test_wide_items_agree_with_the_per_wavefront_contraction(monkeypatch, oracle_built):
-    """analytic_wide_kernel (runs of 3 .. 16 circuits with a common tail, one workgroup per run, LDS-staged operands)
-    against analytic_mfma_kernel over every circuit (GST_TEST_FORCE wide=0) and against the numpy analytic oracle, on
-    the depth-1,030 germ-power families: same products summed in another order (<= 1e-10 at |J| = 65; oracle <= 1e-8);
-    destinations pre-filled with NaN (every requested entry is written, by exactly one of the two kernels); a column
-    window with a leading dimension; and the exact-derivative route of a general parameterisation on top of it."""
-    fx = load_fixture("smq2Q_XYICNOT_L1024_deep")
-    nE, nP = int(fx["nE"]), int(fx["nP"])
-    cols = np.arange(nP)
-    out = {}
-    for wide in (1, 0):
-        force(monkeypatch, wide=wide)
-        pl = plan_from_fixture(fx)
-        J = np.full((nE, nP + 5), np.nan)
-        pl.fill_dprobs(out=J, param_idx=cols, dest_idx=cols + 2, mode=_lib.DERIV_ANALYTIC)
-        assert np.isnan(J[:, :2]).all() and np.isnan(J[:, nP + 2:]).all() and np.isfinite(J[:, 2:nP + 2]).all()
-        out[wide] = J[:, 2:nP + 2]
-        assert pl.stats()["last_launches"] >= (4 if wide else 3)
-    force(monkeypatch, wide=None)
-    assert np.abs(out[1] - out[0]).max() < 1e-10, np.abs(out[1] - out[0]).max()
-    sub = np.concatenate([np.arange(0, 100), np.arange(336, 400), np.arange(1360, 1616)])
-    Jo, _ = oracle_built.analytic_dprobs(fx, sub)
-    assert np.abs(out[1][:, sub] - Jo).max() < TOL
-    none = fx["pkind"] == -1
-    assert none.any() and (out[1][:, none] == 0).all()

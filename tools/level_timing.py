@@ -34,4 +34,5 @@ for fc in (0, 1):
     plan.set_option(_lib.OPT_FAST_CHAINS, fc)
     ms = timed(lambda: (plan.set_model(G, R, E), plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_ANALYTIC)), 5)
     print("analytic fast_chains=%d: %.3f ms  (last_levels=%d kernel_ms=%.3f)" % (fc, ms, plan.stats()["last_levels"], plan.stats()["last_kernel_ms"]))
-print("GST_TEST_FORCE =", os.environ.get("GST_TEST_FORCE"), " launches of the last fill:", plan.stats()["last_launches"])
+lp = plan.level_program(0)
+print({k: v for k, v in lp.items() if not hasattr(v, "shape")})
