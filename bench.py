@@ -416,6 +416,33 @@ def main():
         exchange_probs()
     barrier_sync(plan)
     dtp = ctx.max_over_ranks(time.perf_counter() - tp0)
+    # secondary: the same fill through the log-depth level pass (GST_OPT_FAST_PROBS: germ-power paths by matrix squaring and
+    # doubling on the MFMA cores, <= 1e-10 against the bit-exact probabilities -- what a line search of the optimizer may use)
+    fast_info = None
+    try:
+        exact = plan.memcpy_d2h(np.empty(nE_local), d_probs)
+        plan.set_option(_lib.OPT_FAST_PROBS, 1)
+        for _ in range(2):
+            plan.fill_probs_dev(d_probs)
+        barrier_sync(plan)
+        used = plan.stats()["last_levels"]
+        tf0 = time.perf_counter()
+        for _ in range(n_pr):
+            plan.set_model(gates, rhos, effects)
+            plan.fill_probs_dev(d_probs)
+            exchange_probs()
+        barrier_sync(plan)
+        dtf = ctx.max_over_ranks(time.perf_counter() - tf0)
+        fast = plan.memcpy_d2h(np.empty(nE_local), d_probs)
+        fast_info = {"ms": 1e3 * dtf / n_pr, "probs_per_s": nE_total * n_pr / dtf, "level_pass_used": bool(used),
+                     "max_abs_vs_bit_exact_probs": float(np.abs(fast - exact).max()),
+                     "note": "gst_fill_probs_dev under GST_OPT_FAST_PROBS; bar 1e-10; the default fill stays bit-identical to the reference"}
+    except Exception as e:
+        fast_info = {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        plan.set_option(_lib.OPT_FAST_PROBS, 0)
+        plan.fill_probs_dev(d_probs)
+        barrier_sync(plan)
 
     # secondary: the same Jacobian by analytic derivatives (MatrixForwardSimulator semantics, <= 1e-8 vs that simulator)
     ana_info = None
@@ -441,6 +468,7 @@ def main():
                                  "whole_step_frac": ana_bytes / (dta / n_an) / 1e9 / HBM_PEAK_GBS,
                                  "bytes_per_launch": ana_bytes,
                                  "note": "algorithmic bytes = the Jacobian write 8*nE*nP; `frac` over the contraction kernel, `whole_step_frac` over the step (chain passes included)"},
+                    "chain_passes": "log-depth level passes" if plan.stats()["last_levels"] else "sequential walks",
                     "note": "analytic derivatives (reference MatrixForwardSimulator semantics); secondary figure, not `value`"}
         plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the FD Jacobian resident
         barrier_sync(plan)
@@ -794,6 +822,7 @@ def main():
             "host_fill": host_fill,
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,
+            "fast_probs": fast_info,
             "probs_roofline": {"bound": "mfma", "compute_unit": "valu_f64", "unit": "TFLOP/s", "peak": F64_VALU_PEAK_TFLOPS,
                                "achieved": (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local) / (dtp / n_pr) / 1e12,
                                "frac": (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local) / (dtp / n_pr) / 1e12 / F64_VALU_PEAK_TFLOPS,

@@ -372,9 +372,13 @@ class AtomFillLogic:
         stepped on the host; EXACT derivatives for Lindblad-parameterised models (CPTPLND, GLND, H+S) whose members the
         device builds itself: there the device's exponential (scaled Taylor) and the reference's (scipy's Pade approximant)
         differ in the last bit of the perturbed member, which a finite-difference quotient amplifies by (occurrences of
-        the member in the circuit) / eps -- <= 1e-8 against the Map simulator for shallow circuits only (1e-6 at depth
-        1,000; tests/test_gpu_lindblad.py::test_cptplnd_models_at_depth_error_profile) -- while the exact route agrees
-        with the Matrix simulator to <= 1e-8 at every depth (observed 1e-12).  'fd' and 'analytic' force one mode."""
+        the member in the circuit) / eps -- <= 1e-8 against the Map simulator for circuits of depth <= 16 only (7e-8 at depth
+        1,030, 1.2e-7 on the 1Q L<=128 design; tests/test_gpu_lindblad.py::test_cptplnd_models_at_depth_error_profile) -- while the exact route agrees
+        with the Matrix simulator to <= 1e-8 at every depth (observed 1e-12).  Models of any OTHER parameterisation
+        (implicit models: embedded / composed layer operations sharing their factors' parameters, ...) also take the
+        exact route: the chain rule over the members' deriv_wrt_params runs on the device, while their finite differences
+        would have the host re-densify the model for every column ("models" mode, still there under 'fd').  'fd' and
+        'analytic' force one mode."""
         if self.derivative_mode != "auto":
             return self.derivative_mode
         key = getattr(layout_atom, "_hip_auto_key", (None, None))
@@ -386,8 +390,9 @@ class AtomFillLogic:
                 try:
                     atom_tp_map(self.model, layout_atom)
                 except NotImplementedError:
-                    if self.lindblad_on_device and self._lindblad_description(layout_atom) is not None:
-                        mode = "analytic"
+                    # neither element maps nor TP element subsets: Lindblad members (built on the device) and every other
+                    # parameterisation whose members give deriv_wrt_params take exact derivatives
+                    mode = "analytic"
             layout_atom._hip_auto_mode, layout_atom._hip_auto_key = mode, (self.model, bool(self.lindblad_on_device))
         return layout_atom._hip_auto_mode
 

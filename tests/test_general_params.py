@@ -273,3 +273,54 @@ def test_gpu_cptplnd_exact_hessian_block():
     pl.set_second_derivs([])
     H_lin = pl.fill_hprobs(idx1=r, idx2=c, mode=_lib.DERIV_ANALYTIC)
     assert np.abs(H_lin[fx["matrix_rows"]] - ref).max() > 1e-3
+
+
+# ---- implicit models: embedded / composed layer operations (opcreps.cpp:93-158, 242-276) -----------------------------------------
+def test_oracle_chain_rule_on_the_implicit_3q_model():
+    """`3q_crosstalk_free` (a LocalNoiseModel generated by the reference: every circuit layer an EmbeddedOp of a 1Q / 2Q
+    dense factor, or a ComposedOp of several, layers SHARING the factors' parameters): the numpy chain rule over the
+    layers' deriv_wrt_params equals the Matrix simulator's columns; the Map simulator's FD columns differ from them by the
+    FD truncation error only; the dense layer operations reproduce the probabilities the reference got by acting factor
+    by factor."""
+    from conftest import matrix_rows_by_circuit
+    fx = load_fixture("3q_crosstalk_free")
+    rows = matrix_rows_by_circuit(fx)
+    J, P = O.analytic_dprobs_general(fx, fx["dprobs_cols"])
+    assert np.abs(J - fx["matrix_by_circuit_dprobs"][rows]).max() < 1e-12
+    assert np.abs(P - fx["probs"]).max() < 1e-14 and np.abs(P - fx["matrix_by_circuit_probs"][rows]).max() < 1e-14
+    d = np.abs(fx["dprobs_map"] - fx["matrix_by_circuit_dprobs"][rows]).max()
+    assert 1e-9 < d < 1e-4
+    off, spans = 0, []
+    for n in fx["dv_ncols"]:
+        spans.append(set(fx["dv_param_idx"][off:off + n].tolist())); off += n
+    assert sum(1 for a in range(len(spans)) for b in range(a) if spans[a] & spans[b]) >= 10      # layers share parameters
+    assert any(str(l).startswith("[") for l in fx["op_labels"])                                    # composed layers
+
+
+@pytest.mark.gpu
+def test_gpu_implicit_3q_model_exact_jacobian():
+    """The same model on the device (D = 64): the layers' dense operations + their derivative matrices through
+    gst_set_derivs -- nothing is re-densified per column on the host -- exact Jacobian <= 1e-8 against the Matrix
+    simulator, probabilities <= 1e-10 against the Map simulator (which propagates through the embedded / composed reps);
+    then through the drop-in's per-atom logic with stand-in members, whose `auto` derivative mode takes this route."""
+    from conftest import matrix_rows_by_circuit
+    from pygsti_amd import _lib
+    import test_gpu_adapter_modes as M
+    fx = load_fixture("3q_crosstalk_free")
+    rows = matrix_rows_by_circuit(fx)
+    cols = fx["dprobs_cols"]
+    nE, nP = int(fx["nE"]), int(fx["nP"])
+    pl = plan_from_fixture(fx)
+    pl.set_derivs(nP, O.derivs_from_fixture(fx))
+    pr = np.empty(nE)
+    J = pl.fill_dprobs(param_idx=cols, probs_out=pr, mode=_lib.DERIV_ANALYTIC)
+    assert np.abs(J - fx["matrix_by_circuit_dprobs"][rows]).max() < 1e-8
+    assert np.abs(pr - fx["probs"]).max() < 1e-10
+    atom, model = M._Atom(fx), M._dv_model(fx, None)
+    sim = M._Sim(model, "auto")
+    Ja = np.full((nE, len(cols)), np.nan)
+    sim._bulk_fill_dprobs_atom(Ja, None, atom, cols, None)
+    assert atom._hip_plan._hip_mode == "derivs"
+    assert np.abs(Ja - fx["matrix_by_circuit_dprobs"][rows]).max() < 1e-8
+    p = np.empty(nE); sim._bulk_fill_probs_atom(p, atom, None)
+    assert np.abs(p - fx["probs"]).max() < 1e-10

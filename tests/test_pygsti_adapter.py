@@ -135,8 +135,9 @@ def test_adapter_general_parameterisation_fd_model_sets():
         with pytest.raises(_lib.GstDeviceError):
             m.sim._prepare(atom, derivatives=True)
         assert atom._hip_plan._hip_mode == "lindblad"
-    # ... and the host-stepped validation path on request
+    # ... and the host-stepped validation path on request (finite differences forced: `auto` would take exact derivatives)
     m.sim.lindblad_on_device = False
+    m.sim.derivative_mode = "fd"
     plan = m.sim._prepare(atom, derivatives=True)
     assert plan._hip_mode == "models"
     if _lib.device_count() == 0:
@@ -236,3 +237,39 @@ def test_atom_plan_from_raw_circuits_is_cheap_and_equivalent():
                                eff_ptr, np.array(el, np.int32), np.array(ed, np.int32))
     w1, o1 = plan.program(); w2, o2 = ref.program()
     assert np.array_equal(w1, w2) and np.array_equal(o1, o2)
+
+
+def test_adapter_takes_exact_derivatives_for_implicit_models():
+    """An implicit model of the reference (`create_crosstalk_free_model`: EmbeddedOp / ComposedOp layer operations sharing
+    their factors' parameters) under the default simulator: no element map, no TP map, no Lindblad description -- the
+    `auto` derivative mode resolves to the chain rule over the layers' deriv_wrt_params ("derivs" mode: no host
+    re-densification per column); the matrices handed to gst_set_derivs are the reference's own, and the dense layer
+    operations are the ones the committed fixture holds (tests/golden/3q_crosstalk_free.npz)."""
+    from pygsti.processors import QubitProcessorSpec
+    from pygsti.models import modelconstruction as mc
+    from pygsti.circuits import Circuit
+    from conftest import load_fixture
+    fx = load_fixture("3q_crosstalk_free")
+    ps = QubitProcessorSpec(3, ['Gxpi2', 'Gypi2', 'Gcnot'], geometry='line')
+    m = mc.create_crosstalk_free_model(ps, ideal_gate_type='full', ideal_spam_type='full')
+    m.from_vector(m.to_vector() + 0.02 * np.random.default_rng(77).standard_normal(m.num_params))
+    assert np.array_equal(m.to_vector(), fx["paramvec"])
+    m.sim = A.HipMapForwardSimulator()
+    circs = [Circuit([[('Gxpi2', 0), ('Gcnot', 1, 2)], ('Gypi2', 1), [('Gypi2', 1), ('Gxpi2', 2)]], line_labels=(0, 1, 2)),
+             Circuit([('Gcnot', 0, 1), ('Gxpi2', 2)], line_labels=(0, 1, 2))]
+    lay = m.sim.create_layout(circs, array_types=("ep",))
+    atom = lay.atoms[0]
+    A.atom_plan(m, atom)
+    assert m.sim._effective_mode(atom) == "analytic"
+    G, R, E = A.atom_arrays(m, atom)
+    mine = [str(l) for l in atom.op_labels]
+    ref = [str(l) for l in fx["op_labels"]]
+    for k, l in enumerate(mine):
+        assert np.array_equal(G[k], fx["gates"][ref.index(l)]), l
+    dv = A.atom_derivs(m, atom)
+    assert len(dv) == len(mine) + 1 + len(atom._hip_eff_labels)
+    shared = sum(1 for a in range(len(dv)) for b in range(a) if set(dv[a][2].tolist()) & set(dv[b][2].tolist()))
+    assert shared >= 1                                    # Gypi2:1 alone and inside the composed layer
+    if _lib.device_count() == 0:
+        with pytest.raises(_lib.GstDeviceError):
+            m.sim._prepare(atom, derivatives=True)
