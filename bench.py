@@ -262,7 +262,8 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1: weak = one full design per rank (N designs in all); strong = one design dealt to N atoms")
     ap.add_argument("--no-analytic", action="store_true", help="skip the secondary analytic-derivative timing")
-    ap.add_argument("--keep-zeros", action="store_true", help="analytic legs: GST_OPT_ANALYTIC_KEEP_ZEROS (structural zeros of a re-used destination are not stored again)")
+    ap.add_argument("--keep-zeros", action="store_true", help="analytic legs: GST_OPT_ANALYTIC_KEEP_ZEROS = 1 (the caller's promise for ANY destination; the default, 2, already covers the tracked device memory this bench fills)")
+    ap.add_argument("--store-zeros", action="store_true", help="analytic legs: GST_OPT_ANALYTIC_KEEP_ZEROS = 0 (every fill stores the structural zeros again: the round-3 default)")
     ap.add_argument("--no-other-configs", action="store_true", help="N=1: skip the secondary legs of the other BASELINE configurations (1Q, 3Q, Hessian block)")
     ap.add_argument("--no-lm-step", action="store_true", help="skip the secondary LM-iteration timing (fill + objective maps + J^T J + J^T f [+ all-reduce])")
     ap.add_argument("--no-cptplnd", action="store_true", help="N=1: skip the secondary CPTPLND (Lindblad-parameterised) Jacobian timing")
@@ -353,8 +354,8 @@ def main():
     pidx = np.arange(gps.start, gps.stop, dtype=np.int64)
 
     mode = _lib.DERIV_ANALYTIC if args.deriv == "analytic" else _lib.DERIV_FD
-    if args.keep_zeros:
-        plan.set_option(_lib.OPT_ANALYTIC_KEEP_ZEROS, 1)
+    if args.keep_zeros or args.store_zeros:
+        plan.set_option(_lib.OPT_ANALYTIC_KEEP_ZEROS, 0 if args.store_zeros else 1)
     exchange = None
     if world > 1:
         exchange = {"transport": ctx.transport, "rccl_ranks": world if ctx.transport == "rccl" else 0,
@@ -469,6 +470,9 @@ def main():
                                  "bytes_per_launch": ana_bytes,
                                  "note": "algorithmic bytes = the Jacobian write 8*nE*nP; `frac` over the contraction kernel, `whole_step_frac` over the step (chain passes included)"},
                     "chain_passes": "log-depth level passes" if plan.stats()["last_levels"] else "sequential walks",
+                    "structural_zeros": ("resident (the destination is tracked device memory whose previous contents were this fill's: "
+                                         "the zero blocks of gates a circuit never applies are not stored again)"
+                                         if plan.stats()["last_zeros_resident"] else "stored by every fill"),
                     "note": "analytic derivatives (reference MatrixForwardSimulator semantics); secondary figure, not `value`"}
         plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the FD Jacobian resident
         barrier_sync(plan)

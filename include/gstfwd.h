@@ -123,19 +123,27 @@ typedef struct {
                                   shared device) and the stand-by launches behind it produced the result instead */
     int32_t last_levels;       /* 1: the last fill took its forward states from the log-depth level pass (GST_OPT_FAST_CHAINS /
                                   GST_OPT_FAST_PROBS), 0: from the sequential walk */
-    int32_t reserved0;
+    int32_t last_zeros_resident;   /* 1: the last exact Jacobian fill did not re-store the destination's structural zeros */
 } gst_stats;
 
 int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *opt, gst_plan **out);
 
 /* Run-time options of a plan.
- *   GST_OPT_ANALYTIC_KEEP_ZEROS (value 0 / 1): a promise about the DESTINATIONS of GST_DERIV_ANALYTIC Jacobians (D = 16).
+ *   GST_OPT_ANALYTIC_KEEP_ZEROS (value 0 / 1 / 2): the structural zeros of GST_DERIV_ANALYTIC Jacobians (D = 16).
  *       Entry (element of circuit c, parameter of gate g) is an exact zero when c never applies g -- 30 % of a GST Jacobian.
- *       With the option on, a fill whose destination pointer, leading dimension and column request equal the previous
- *       analytic fill's does not store those zeros again: the caller promises that nothing but row scalings
- *       (gst_fill_jtj_dev's d_row_scale, which keeps zeros zero) was written into that buffer in between -- what an
- *       optimizer does that reuses one device Jacobian every iteration.  The first fill into a destination (and any fill
- *       after the destination, the columns or the option changed) writes everything.  Off by default. */
+ *       A fill whose destination, leading dimension and column request equal an earlier exact fill's need not store those
+ *       zeros again (a third of the contraction's stores) if nothing else was written there in between.
+ *       2 (default): only for destinations the library can vouch for -- memory from gst_device_malloc and the plan's own
+ *          staging buffer behind host destinations.  Every entry point that writes device memory (fills, gst_memcpy_h2d,
+ *          gst_copy_block_dev, the objective maps, the gst_comm_* collectives) invalidates what it overwrites;
+ *          gst_fill_jtj_dev's in-place row scaling keeps zeros zero and is checked for non-finite factors on the stream.
+ *          A caller that writes gst_device_malloc memory with ITS OWN kernels announces it with gst_device_touch.
+ *          (gst_stats.last_zeros_resident reports the decision of the last fill.)
+ *       1: additionally for ANY destination pointer: the caller promises that nothing but row scalings was written into
+ *          the buffer since the previous exact fill of this plan -- what an optimizer does that reuses one device Jacobian
+ *          every iteration.  The first fill into a destination (and any fill after the destination, the columns or the
+ *          option changed) writes everything.
+ *       0: every fill stores every entry. */
 #define GST_OPT_ANALYTIC_KEEP_ZEROS 1
 /*   GST_OPT_FAST_CHAINS (value 0 / 1 / 2; D = 16): how the modes WITHOUT an ordering contract -- GST_DERIV_ANALYTIC, and
  *       gst_fill_probs* under GST_OPT_FAST_PROBS -- obtain the states of the circuit tries.  The sequential walk applies a
@@ -445,6 +453,9 @@ int gst_comm_get_info(const gst_comm *comm, gst_comm_info *out);
  * keep results resident (bench.py, tests).  Buffers from any other allocator work equally. */
 int gst_device_malloc(gst_plan *plan, int64_t nbytes, void **d_ptr);
 int gst_device_free(gst_plan *plan, void *d_ptr);
+/* The caller wrote [d_ptr, d_ptr + nbytes) of gst_device_malloc memory by means other than this library (its own kernel,
+ * a peer copy): whatever the library remembered about the contents (GST_OPT_ANALYTIC_KEEP_ZEROS = 2) is forgotten. */
+int gst_device_touch(gst_plan *plan, void *d_ptr, int64_t nbytes);
 int gst_memcpy_d2h(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
 /* The same copy enqueued on the plan's stream without waiting for it (gst_sync completes it): lets one process drain
  * the plans of several GPUs side by side -- with a page-locked destination (gst_host_register) the copies of different

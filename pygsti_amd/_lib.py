@@ -75,13 +75,13 @@ class Stats(C.Structure):
                 ("trie_nodes", C.c_int64), ("applies_per_pass", C.c_int64), ("n_tasks", C.c_int64),
                 ("prog_words", C.c_int64), ("max_slots", C.c_int32), ("max_depth", C.c_int32),
                 ("last_kernel_ms", C.c_double), ("last_total_ms", C.c_double), ("last_launches", C.c_int64),
-                ("last_fd_form", C.c_int32), ("last_fd_aborted", C.c_int32), ("last_levels", C.c_int32), ("reserved0", C.c_int32)]
+                ("last_fd_form", C.c_int32), ("last_fd_aborted", C.c_int32), ("last_levels", C.c_int32), ("last_zeros_resident", C.c_int32)]
 
 
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
@@ -125,6 +125,7 @@ def lib():
         L.gst_sync.argtypes = [vp]
         L.gst_device_malloc.argtypes = [vp, i64, C.POINTER(vp)]
         L.gst_device_free.argtypes = [vp, vp]
+        L.gst_device_touch.argtypes = [vp, vp, C.c_int64]
         L.gst_memcpy_d2h.argtypes = [vp, vp, vp, i64]
         L.gst_memcpy_d2h_async.argtypes = [vp, vp, vp, i64]
         L.gst_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -585,6 +586,10 @@ class Plan:
 
     def device_free(self, d_ptr):
         check(lib().gst_device_free(self._h, C.c_void_p(int(d_ptr))))
+
+    def device_touch(self, d_ptr, nbytes):
+        """the caller wrote device_malloc memory by its own means: what the library remembered about it is forgotten"""
+        check(lib().gst_device_touch(self._h, C.c_void_p(int(d_ptr)), int(nbytes)))
 
     def memcpy_d2h(self, out, d_ptr, offset_bytes=0):
         assert out.flags.c_contiguous

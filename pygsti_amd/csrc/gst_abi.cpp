@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <queue>
 #include <set>
 #include <cstdio>
@@ -137,7 +138,11 @@ struct gst_plan {
     static constexpr bool ana_stream = true;       // two-circuit items as one block stream (the gate-by-gate form remains for > 63 gates)
     static constexpr bool ana_pairs = true;        // two-circuit work items in the D = 16 contraction
     static constexpr bool ana_germ_order = true;   // germ-major order of the work items
-    bool ana_keep_zeros = false;        // gst_set_option(GST_OPT_ANALYTIC_KEEP_ZEROS)
+    int ana_keep_zeros = 2;             // gst_set_option(GST_OPT_ANALYTIC_KEEP_ZEROS): 0 never, 1 any destination (the caller's
+                                        // promise), 2 destinations the library tracks (gst_track.cpp) -- the default
+    uint64_t uid = 0;                   // process-unique plan number, request_serial: bumped when the analytic column tables are
+    uint64_t request_serial = 0;        // rebuilt -- (uid, serial, ld) is the signature of a Jacobian's zero pattern
+    bool last_zeros_resident = false;
     const void* ana_zero_out = nullptr; // destination of the last stream-form analytic Jacobian, its leading dimension
     int64_t ana_zero_ld = 0;
     bool ana_zero_valid = false;
@@ -283,6 +288,7 @@ struct gst_plan {
     {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
+        if (d_out.p) gst::track_touch(d_out.p, d_out.n * 8);
         d_lb_i32.release(); d_lb_i64.release(); d_lb_setparam.release(); d_lb_statics.release(); d_lb_term_re.release();
         d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release(); d_jtj_pmask.release(); for (auto& b : d_lbr_lane) b.release(); d_lbr_order.release();
         d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release();
@@ -323,6 +329,8 @@ namespace {
 
 int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
 {
+    static std::atomic<uint64_t> next_uid{1};
+    p->uid = next_uid.fetch_add(1);
     // default slot budget: what fits in LDS at 4 wavefronts per SIMD (16 per CU): one 8 KB slot at D=16
     int32_t max_slots = opt ? opt->max_slots : 0;
     if (p->hp.D != 4 && p->hp.D != 16 && p->hp.D != 64) {
@@ -626,6 +634,25 @@ int upload_i32(DevBuf<int32_t>& b, const std::vector<int32_t>& v, hipStream_t s)
 {
     HIP_TRY(b.ensure(v.size()));
     if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice, s));
+    return GST_OK;
+}
+
+// bytes from a Jacobian destination's first entry to one past its last: rows of `ld` doubles, columns dest_idx (or 0 .. n - 1)
+size_t jac_extent(int64_t n_rows, int64_t ld, const int64_t* dest_idx, int64_t n_param)
+{
+    if (n_rows <= 0 || n_param <= 0) return 0;
+    int64_t max_col = n_param - 1;
+    if (dest_idx) { max_col = 0; for (int64_t c = 0; c < n_param; c++) max_col = std::max(max_col, dest_idx[c]); }
+    return (size_t)((n_rows - 1) * ld + max_col + 1) * 8;
+}
+int64_t nE_total(const gst_plan* p) { return p->hp.n_elements; }
+
+// The plan's staging buffer for host destinations.  Every use but an exact Jacobian overwrites the zeros a previous one
+// may have left there (gst_track.cpp); so does growing it.
+int stage_out(gst_plan* p, size_t count, bool keeps_claims = false)
+{
+    if (p->d_out.p && (!keeps_claims || count > p->d_out.n)) gst::track_touch(p->d_out.p, p->d_out.n * 8);
+    HIP_TRY(p->d_out.ensure(count));
     return GST_OK;
 }
 
@@ -1153,6 +1180,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (n_param == 0) return GST_OK;
     const bool request_was_cached = p->request_cached(2, param_idx, dest_idx, n_param);
     if (!request_was_cached) {
+        p->request_serial++;
         const int D = h.D, DD = D * D;
         std::vector<int32_t> cm_gate((size_t)std::max(h.n_gates, 1) * DD, -1), cm_rho((size_t)h.n_rhos * D, -1),
             cm_eff((size_t)h.n_effects * D, -1), col0(std::max(h.n_gates, 1), -2);
@@ -1278,8 +1306,21 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         // GST_OPT_ANALYTIC_KEEP_ZEROS: the blocks of gates an item never applies are exact zeros; when THIS destination got
         // THIS request last time (and the caller promised, by setting the option, to write nothing but row scalings into it
         // in between) they are zero already and are not stored again -- a third of the D = 16 contraction's stores
+        // Without the option (value 2, the default) the same holds for destinations the library can vouch for: memory from
+        // gst_device_malloc and the plan's own staging buffer, whose every other writer reports to gst_track.cpp.
         const bool same_dest = p->ana_zero_out == (const void*)d_out && p->ana_zero_ld == ld && p->ana_zero_valid && request_was_cached;
-        a.zeros_resident = (p->ana_keep_zeros && same_dest && !p->derivs_set) ? 1 : 0;
+        const bool zero_form = D == 16 && !p->derivs_set && !p->want_cache_path;
+        const size_t extent = jac_extent(nE_total(p), ld, dest_idx, n_param);
+        const uint64_t sig = (p->uid * 0x9E3779B97F4A7C15ull) ^ (p->request_serial * 0xC2B2AE3D27D4EB4Full) ^ (uint64_t)ld;
+        bool claim = false;
+        a.zeros_resident = 0; a.zeros_ok = nullptr;
+        if (zero_form && p->ana_keep_zeros == 1) a.zeros_resident = same_dest ? 1 : 0;
+        else if (zero_form && p->ana_keep_zeros == 2 && (d_out == p->d_out.p || gst::track_owned(d_out, extent))) {
+            claim = true;
+            if (const uint32_t* w = gst::track_claim_find(d_out, extent, sig)) { a.zeros_resident = 1; a.zeros_ok = w; }
+        }
+        if (!claim) gst::track_touch(d_out, extent);
+        p->last_zeros_resident = a.zeros_resident != 0;
         p->ana_zero_out = d_out; p->ana_zero_ld = ld; p->ana_zero_valid = (D == 16);
         HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
         if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
@@ -1287,10 +1328,16 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         else HIP_TRY(gst::launch_analytic_small(a, p->stream));
         TIME_REC(p, evk1);
         p->last_launches++;
+        if (claim) {         // what this fill leaves behind; the word reads 1 again whatever a row scaling did to it before
+            if (uint32_t* w = gst::track_claim_set(d_out, extent, sig, p->device)) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)w, 1, 1, p->stream));
+        }
         p->last_ana = a; p->last_ana_valid = true;     // (the Hessian rows re-launch the contraction with other caches)
+        p->last_ana.zeros_resident = 0; p->last_ana.zeros_ok = nullptr;
         return GST_OK;
     }
     if (D == 64) return fail(GST_EUNSUPPORTED, "D = 64 analytic derivatives exist on the MFMA path only");
+    gst::track_touch(d_out, jac_extent(h.n_elements, ld, dest_idx, n_param));
+    p->last_zeros_resident = false;
     TIME_REC(p, evk0);
     HIP_TRY(gst::launch_analytic(D, a, p->stream));
     TIME_REC(p, evk1);
@@ -2108,6 +2155,7 @@ int gst_fill_probs_dev(gst_plan* p, double* d_out)
     int rc = begin_call(p);
     if (rc) return rc;
     if (!d_out) return fail(GST_EINVAL, "d_out is NULL");
+    gst::track_touch(d_out, (size_t)p->hp.n_elements * 8);
     TIME_REC(p, evk0);
     if ((rc = run_probs_any(p, d_out))) return rc;
     TIME_REC(p, evk1);
@@ -2137,6 +2185,9 @@ int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (rc) return rc;
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!d_out && n_param > 0) return fail(GST_EINVAL, "d_out is NULL");
+    // what this call overwrites no longer holds an earlier exact Jacobian's zeros (the plain exact fill keeps its own books)
+    if (d_probs_out) gst::track_touch(d_probs_out, (size_t)p->hp.n_elements * 8);
+    if (n_param > 0 && (mode == GST_DERIV_FD || p->lb.set || p->derivs_set)) gst::track_touch(d_out, jac_extent(p->hp.n_elements, ld, dest_idx, n_param));
     if (p->lb.set && !p->derivs_set) {
         if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
         if (mode == GST_DERIV_FD) rc = run_dprobs_lindblad(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out);
@@ -2174,7 +2225,7 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     if (!out && n_param > 0) return fail(GST_EINVAL, "out is NULL");
     if (p->lb.set && (mode == GST_DERIV_FD || !p->derivs_set)) {
         if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
-        HIP_TRY(p->d_out.ensure((size_t)p->hp.n_elements * std::max<int64_t>(n_param, 1)));
+        if ((rc = stage_out(p, (size_t)p->hp.n_elements * std::max<int64_t>(n_param, 1)))) return rc;
         if (mode == GST_DERIV_FD) rc = run_dprobs_lindblad(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr);
         else rc = run_dprobs_lindblad_analytic(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
         if (rc) return rc;
@@ -2191,7 +2242,7 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     // (kernel and transfer overlap completely; the (ld, dest_idx) window is honoured by the kernel itself).
     // (the analytic contraction writes every requested entry exactly once as well -- streaming stores -- and takes the same route)
     if (!p->derivs_set && (mode == GST_DERIV_FD || mode == GST_DERIV_ANALYTIC) && n_param >= p->host_direct_min_cols && nE > 0 && p->hp.D <= 16 &&
-        p->comp_index < 0 && p->host_direct && !(mode == GST_DERIV_ANALYTIC && p->ana_keep_zeros)) {
+        p->comp_index < 0 && p->host_direct && !(mode == GST_DERIV_ANALYTIC && p->ana_keep_zeros == 1)) {
         int64_t max_col = 0;
         bool plain = true;          // (analytic: columns of parameters the atom never uses are zero-filled by a 2-D memset -- staged route)
         for (int64_t c = 0; c < n_param; c++) {
@@ -2208,7 +2259,7 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
         }
     }
     // device staging is dense [nE][n_param]; scattered into the caller's (ld, dest_idx) window on the host
-    HIP_TRY(p->d_out.ensure((size_t)nE * std::max<int64_t>(n_param, 1)));
+    if ((rc = stage_out(p, (size_t)nE * std::max<int64_t>(n_param, 1), !p->derivs_set && mode == GST_DERIV_ANALYTIC))) return rc;
     if (p->derivs_set) rc = run_dprobs_general(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
     else if (mode == GST_DERIV_ANALYTIC) rc = run_dprobs_analytic(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
     else rc = run_dprobs_fd(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr, nullptr, 0);
@@ -2226,6 +2277,8 @@ int gst_fill_dprobs_models_dev(gst_plan* p, int64_t n_models, const double* gate
         if (n_models < 0 || (n_models > 0 && (!rhos || !effects || (p->hp.n_gates > 0 && !gates) || !d_out)))
             return fail(GST_EINVAL, "bad argument");
         if (!(eps != 0.0)) return fail(GST_EINVAL, "eps must be non-zero");
+        if (d_probs_out) gst::track_touch(d_probs_out, (size_t)p->hp.n_elements * 8);
+        gst::track_touch(d_out, jac_extent(p->hp.n_elements, ld, dest_idx, n_models));
         if ((rc = run_dprobs_models(p, n_models, gates, rhos, effects, d_out, ld, dest_idx, eps, d_probs_out))) return rc;
         return end_call(p, false);
     });
@@ -2241,7 +2294,7 @@ int gst_fill_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, c
             return fail(GST_EINVAL, "bad argument");
         if (!(eps != 0.0)) return fail(GST_EINVAL, "eps must be non-zero");
         const int64_t nE = p->hp.n_elements;
-        HIP_TRY(p->d_out.ensure((size_t)nE * std::max<int64_t>(n_models, 1)));
+        if ((rc = stage_out(p, (size_t)nE * std::max<int64_t>(n_models, 1)))) return rc;
         if ((rc = run_dprobs_models(p, n_models, gates, rhos, effects, p->d_out.p, n_models, nullptr, eps, nullptr))) return rc;
         return copy_out_dprobs(p, out, ld, dest_idx, n_models, probs_out);
     });
@@ -2658,7 +2711,7 @@ int gst_fill_hprobs_analytic(gst_plan* p, double* out, int64_t ld1, int64_t ld2,
     if (!p->derivs_set && ((rc = check_params(p, idx1, n1)) || (rc = check_params(p, idx2, n2)))) return rc;
     const int64_t nE = p->hp.n_elements;
     if (n1 == 0 || n2 == 0) return end_call(p, true);
-    HIP_TRY(p->d_out.ensure((size_t)nE * ld1 * ld2));
+    if ((rc = stage_out(p, (size_t)nE * ld1 * ld2))) return rc;
     const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
     if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
     if (p->derivs_set) rc = run_hprobs_general(p, p->d_out.p, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2);
@@ -2682,7 +2735,7 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     const int64_t nE = p->hp.n_elements;
     if (n1 == 0 || n2 == 0) return end_call(p, true);
     // dense device output [nE][n1'][n2'] in the caller's leading dimensions
-    HIP_TRY(p->d_out.ensure((size_t)nE * ld1 * ld2));
+    if ((rc = stage_out(p, (size_t)nE * ld1 * ld2))) return rc;
     // rows/columns of the caller's block that this call does not own must survive: start from the caller's data
     const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
     if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
@@ -2711,7 +2764,7 @@ int gst_objective_hessian_block(gst_plan* p, const gst_objective_desc* d, const 
     if (n1 > 0x7fffffff || n2 > 0x7fffffff) return fail(GST_EINVAL, "block too large");
     const int64_t nE = p->hp.n_elements;
     if (n1 == 0 || n2 == 0) return end_call(p, true);
-    HIP_TRY(p->d_out.ensure((size_t)nE * n1 * n2));
+    if ((rc = stage_out(p, (size_t)nE * n1 * n2))) return rc;
     const double* d_d1 = nullptr;
     const double* d_d2 = nullptr;
     if (d->hessian_mode == GST_DERIV_ANALYTIC && p->derivs_set) {
@@ -2764,6 +2817,16 @@ int gst_fill_jtj_dev(gst_plan* p, double* d_J, int64_t n_rows, int64_t n_cols, i
     if (!p || !d_J || !d_jtj || n_rows < 0 || n_cols < 0 || ld < n_cols || n_cols > 0x7fffffff) return fail(GST_EINVAL, "bad argument");
     int rc = ensure_device(p);
     if (rc) return rc;
+    gst::track_touch(d_jtj, (size_t)n_cols * n_cols * 8);
+    if (d_row_scale && n_rows > 0 && n_cols > 0) {
+        // the in-place row scaling keeps an exact Jacobian's zeros zero -- unless a factor is not finite (0 * inf): the
+        // claim's device word is cleared on the stream then, and the next exact fill stores everything (gst_track.cpp)
+        bool several = false;
+        const size_t bytes = (size_t)((n_rows - 1) * ld + n_cols) * 8;
+        uint32_t* w = gst::track_claim_overlapping(d_J, bytes, &several);
+        if (several) gst::track_touch(d_J, bytes);
+        else if (w) HIP_TRY(gst::launch_check_finite(d_row_scale, n_rows, w, p->stream));
+    }
     TIME_REC(p, ev0);
     // Block sparsity (a row is exactly zero in the columns of gates its circuit never applies): one streaming pass marks,
     // per 16-row panel, the 128-column tiles that hold anything -- fused with the row scaling when there is one -- and
@@ -2796,6 +2859,7 @@ int gst_fill_jtf_dev(gst_plan* p, const double* d_J, int64_t n_rows, int64_t n_c
     if (rc) return rc;
     if (n_cols == 0) return GST_OK;
     const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n_rows + 255) / 256));
+    gst::track_touch(d_jtf, (size_t)n_cols * 8);
     HIP_TRY(p->d_jtf_part.ensure((size_t)n_slabs * n_cols));
     HIP_TRY(gst::launch_jtf(d_J, d_f, n_rows, (int)n_cols, ld, p->d_jtf_part.p, n_slabs, d_jtf, p->stream));
     return GST_OK;
@@ -2815,6 +2879,7 @@ int gst_objective_rows_dev(gst_plan* p, const gst_objective_desc* d, double* d_p
     if (rc) return rc;
     if (sum_terms) *sum_terms = 0.0;
     if (n == 0) return GST_OK;
+    for (double* w : {d_probs, d_lsvec, d_rowscale, d_terms}) gst::track_touch(w, (size_t)n * 8);
     const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + 255) / 256));
     HIP_TRY(p->d_obj_part.ensure((size_t)n_blocks));
     HIP_TRY(gst::launch_objective_rows(d->kind, d_probs, d_counts, d_totals, n, d->min_prob_clip, d->radius, d->prob_clip_lo,
@@ -2837,6 +2902,7 @@ int gst_memcpy_h2d(gst_plan* p, void* d_dst, const void* src, int64_t nbytes)
     if (!p || !d_dst || !src || nbytes < 0) return fail(GST_EINVAL, "bad argument");
     int rc = ensure_device(p);
     if (rc) return rc;
+    gst::track_touch(d_dst, (size_t)nbytes);
     HIP_TRY(hipMemcpyAsync(d_dst, src, (size_t)nbytes, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return GST_OK;
@@ -2851,6 +2917,7 @@ int gst_copy_block_dev(gst_plan* p, double* d_dst, int64_t dst_ld, const double*
     if (!d_dst || !d_src) return fail(GST_EINVAL, "NULL pointer");
     int rc = ensure_device(p);
     if (rc) return rc;
+    gst::track_touch(d_dst, (size_t)((n_rows - 1) * dst_ld + n_cols) * 8);
     HIP_TRY(hipMemcpy2DAsync(d_dst, (size_t)dst_ld * 8, d_src, (size_t)src_ld * 8, (size_t)n_cols * 8, (size_t)n_rows, hipMemcpyDeviceToDevice, p->stream));
     return GST_OK;
     });
@@ -2863,6 +2930,7 @@ int gst_device_malloc(gst_plan* p, int64_t nbytes, void** d_ptr)
     int rc = ensure_device(p);
     if (rc) return rc;
     HIP_TRY(hipMalloc(d_ptr, (size_t)std::max<int64_t>(nbytes, 1)));
+    gst::track_alloc(*d_ptr, (size_t)std::max<int64_t>(nbytes, 1));
     return GST_OK;
     });
 }
@@ -2873,7 +2941,17 @@ int gst_device_free(gst_plan* p, void* d_ptr)
     if (!p) return fail(GST_EINVAL, "plan is NULL");
     int rc = ensure_device(p);
     if (rc) return rc;
+    gst::track_free(d_ptr);
     HIP_TRY(hipFree(d_ptr));
+    return GST_OK;
+    });
+}
+
+int gst_device_touch(gst_plan* p, void* d_ptr, int64_t nbytes)
+{
+    return guarded([&]() -> int {
+    if (!p || nbytes < 0 || (nbytes > 0 && !d_ptr)) return fail(GST_EINVAL, "bad argument");
+    gst::track_touch(d_ptr, (size_t)nbytes);
     return GST_OK;
     });
 }
@@ -2958,7 +3036,7 @@ int gst_get_stats(const gst_plan* p, gst_stats* s)
     s->prog_words = (int64_t)h.prog.size(); s->max_slots = h.max_slots; s->max_depth = h.max_depth;
     s->last_kernel_ms = p->last_kernel_ms; s->last_total_ms = p->last_total_ms; s->last_launches = p->last_launches;
     s->last_fd_form = p->last_fd_form; s->last_fd_aborted = 0;
-    s->last_levels = p->last_levels ? 1 : 0; s->reserved0 = 0;
+    s->last_levels = p->last_levels ? 1 : 0; s->last_zeros_resident = p->last_zeros_resident ? 1 : 0;
     if (p->last_fd_form >= 1 && p->d_bin_head.p && p->n_bins > 0 && p->dev_ready) {
         uint32_t flag = 0;                  // the abort flag sits behind the queue heads
         HIP_TRY(hipSetDevice(p->device));
@@ -3055,8 +3133,9 @@ int gst_set_option(gst_plan* p, int32_t option, int64_t value)
     if (!p) return fail(GST_EINVAL, "plan is NULL");
     switch (option) {
     case GST_OPT_ANALYTIC_KEEP_ZEROS:
-        p->ana_keep_zeros = value != 0;
-        p->ana_zero_valid = false;            // the promise starts now: the next fill writes every zero
+        if (value < 0 || value > 2) return fail(GST_EINVAL, "GST_OPT_ANALYTIC_KEEP_ZEROS takes 0, 1 or 2");
+        p->ana_keep_zeros = (int)value;
+        p->ana_zero_valid = false;            // a promise starts now: the next fill writes every zero
         return GST_OK;
     case GST_OPT_FAST_CHAINS:
         if (value < 0 || value > 2) return fail(GST_EINVAL, "GST_OPT_FAST_CHAINS takes 0, 1 or 2");

@@ -192,6 +192,7 @@ int ipc_publish(gst_comm* c, const void* ptr)
     HIP_TRYC(hipMemGetAddressRange((hipDeviceptr_t*)&base, &bytes, (hipDeviceptr_t)ptr));
     // (a freed and re-allocated buffer may come back at the same address: the handle, not the address, identifies it)
     hipIpcMemHandle_t h;
+    std::memset(&h, 0, sizeof(h));        // (the runtime fills only part of the 64 bytes; the handles are compared bytewise below)
     HIP_TRYC(hipIpcGetMemHandle(&h, base));
     if (s.alloc_id == 0 || s.bytes != bytes || std::memcmp(&h, &s.handle, sizeof(h)) != 0) {
         gst_comm::Published* hit = nullptr;
@@ -247,6 +248,15 @@ struct Blocks {
     const int64_t* row0;
     const int64_t* rows;
 };
+
+// the row blocks a collective writes into d_full no longer hold an exact Jacobian's zeros (gst_track.cpp); an in-place
+// all-gather leaves the caller's own blocks alone
+void touch_rows(double* d_full, const Blocks& b, int64_t row_doubles, int skip_owner)
+{
+    if (!d_full) return;
+    for (int32_t k = 0; k < b.n; k++)
+        if (b.owner[k] != skip_owner && b.rows[k] > 0) gst::track_touch(d_full + b.row0[k] * row_doubles, (size_t)(b.rows[k] * row_doubles) * 8);
+}
 
 int check_blocks(const gst_comm* c, const Blocks& b, int64_t row_doubles)
 {
@@ -572,6 +582,7 @@ int gst_comm_allgather_rows(gst_comm* c, gst_plan* plan, double* d_full, int64_t
         Blocks b{n_blocks, blk_owner, blk_row0, blk_rows};
         int rc = check_blocks(c, b, row_doubles);
         if (rc) return rc;
+        touch_rows(d_full, b, row_doubles, c->rank);
         hipStream_t st = pick_stream(c, plan, &rc);
         if (rc) return rc;
         return exchange_rows(c, st, nullptr, d_full, row_doubles, b, -1);
@@ -587,6 +598,7 @@ int gst_comm_gather_rows(gst_comm* c, gst_plan* plan, const double* d_local, dou
         Blocks b{n_blocks, blk_owner, blk_row0, blk_rows};
         int rc = check_blocks(c, b, row_doubles);
         if (rc) return rc;
+        if (c->rank == root) touch_rows(d_full, b, row_doubles, -1);
         hipStream_t st = pick_stream(c, plan, &rc);
         if (rc) return rc;
         return exchange_rows(c, st, d_local, d_full, row_doubles, b, root);
@@ -600,6 +612,8 @@ int gst_comm_exchange_blocks(gst_comm* c, gst_plan* plan, const double* d_src, d
         if (!c) return set_error(GST_EINVAL, "comm is NULL");
         if (n_blocks < 0 || (n_blocks > 0 && (!blk_src_rank || !blk_dst_rank || !blk_src_off || !blk_dst_off || !blk_count)))
             return set_error(GST_EINVAL, "bad block list");
+        for (int32_t k = 0; k < n_blocks; k++)      // (received blocks overwrite what an exact Jacobian left in the destination)
+            if (blk_dst_rank[k] == c->rank && blk_count[k] > 0 && d_dst) gst::track_touch(d_dst + blk_dst_off[k], (size_t)blk_count[k] * 8);
         int rc;
         hipStream_t st = pick_stream(c, plan, &rc);
         if (rc) return rc;
@@ -611,6 +625,7 @@ int gst_comm_allreduce_sum(gst_comm* c, gst_plan* plan, double* d_buf, int64_t n
 {
     return guarded([&]() -> int {
         if (!c || n < 0 || (n > 0 && !d_buf)) return set_error(GST_EINVAL, "bad argument");
+        gst::track_touch(d_buf, (size_t)n * 8);
         int rc;
         hipStream_t st = pick_stream(c, plan, &rc);
         if (rc) return rc;

@@ -18,4 +18,16 @@ int plan_device(const gst_plan* plan);
 // out[i] = sum_{r < n_slots} slots[r * stride + i] in ascending r (deterministic), i < n   (gst_kernels_normal.hip)
 hipError_t launch_sum_slots(const double* slots, int n_slots, int64_t stride, int64_t n, double* out, hipStream_t s);
 
+// clears *flag when any w[i], i < n, is not finite   (gst_kernels_normal.hip)
+hipError_t launch_check_finite(const double* w, int64_t n, uint32_t* flag, hipStream_t s);
+
+// Destination tracking (gst_track.cpp): device ranges that still hold the structural zeros of an analytic Jacobian.
+void track_alloc(const void* p, size_t bytes);           // memory the library handed out or owns
+void track_free(const void* p);                          // ... released (drops the claims inside it)
+bool track_owned(const void* p, size_t bytes);           // [p, p + bytes) lies inside one tracked allocation
+void track_touch(const void* p, size_t bytes);           // the library writes there (anything but a row scaling): claims dropped
+uint32_t* track_claim_find(const void* base, size_t bytes, uint64_t sig);       // the claim's device word (1 = holds), or NULL
+uint32_t* track_claim_set(const void* base, size_t bytes, uint64_t sig, int device);
+uint32_t* track_claim_overlapping(const void* p, size_t bytes, bool* several);  // the one claim a row scaling of this range meets
+
 }  // namespace gst

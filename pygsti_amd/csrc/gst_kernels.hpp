@@ -174,6 +174,7 @@ struct AnaArgs {
     const int32_t *blk_f1, *blk_f2, *blk_r, *blk_ptr;
     int32_t wide;                 // a state cache (or a derivative-state cache of a Hessian row) is 4 GB or larger: 64-bit lane offsets
     int32_t zeros_resident;       // D = 16 stream form: the blocks of gates an item never applies already hold zeros in `out`: not stored
+    const uint32_t* zeros_ok;     // ... unless this device word (NULL: none) reads 0: a row scaling met a non-finite factor since
 };
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
 hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream);   // D = 16

@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
     const int lane = threadIdx.x & 63;
     const int kk = lane >> 4, i = lane & 15;
     const int nE = a.n_effects, nG = a.n_gates;
+    // structural zeros the destination still holds are not stored again; a tracked destination's claim carries a device
+    // word that a row scaling with a non-finite factor (0 * inf) has cleared (gst_track.cpp)
+    const bool zeros_resident = a.zeros_resident && (!a.zeros_ok || *(const volatile uint32_t*)a.zeros_ok != 0u);
     const uint32_t fstride = a.fwd_stride ? a.fwd_stride : (uint32_t)(D * 8);
     const uint32_t rstride = a.rev_stride ? a.rev_stride : (uint32_t)nE * (D * 8);
     // uniform 64-bit bases + 32-bit per-lane byte offsets (both caches are < 4 GB, checked on the host): one offset
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                 // (written out on its own, with no accumulator array handed to `store_block` from inside a run-time loop:
                 //  that puts the arrays -- the live MFMA accumulators included -- into scratch memory)
                 auto zero_gates = [&](int g_from, int g_to) {
-                    if (a.accumulate || a.zeros_resident) return;      // (adding zeros; or zeros the destination already holds)
+                    if (a.accumulate || zeros_resident) return;      // (adding zeros; or zeros the destination already holds)
                     for (int g = g_from; g < g_to; g++) {
                         const int32_t c0 = __builtin_amdgcn_readlane(c0_l, g);
                         if (c0 == -2) continue;
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                 const int64_t p0 = as_const(a.pos_ptr)[c * nG + g], p1 = as_const(a.pos_ptr)[c * nG + g + 1];
                 const int64_t q0 = as_const(a.pos_ptr)[c2 * nG + g], q1 = as_const(a.pos_ptr)[c2 * nG + g + 1];
                 const int64_t cg = (int64_t)as_const(a.pair_common)[ci * nG + g];
-                if (a.zeros_resident && p1 == p0 && q1 == q0) continue;      // neither circuit applies g: zeros the destination already holds
+                if (zeros_resident && p1 == p0 && q1 == q0) continue;      // neither circuit applies g: zeros the destination already holds
                 d4_t acc[NX], acc2[NX];
 #pragma unroll
                 for (int x = 0; x < NX; x++) { acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc2[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                 const int32_t c0 = as_const(a.gate_col0)[g];
                 if (c0 == -2) continue;                                // no parameter of this gate was requested
                 const int64_t p0 = as_const(a.pos_ptr)[c * nG + g], p1 = as_const(a.pos_ptr)[c * nG + g + 1];
-                if (a.zeros_resident && p1 == p0) continue;                  // g never applied: zeros the destination already holds
+                if (zeros_resident && p1 == p0) continue;                  // g never applied: zeros the destination already holds
                 d4_t acc[NX];
 #pragma unroll
                 for (int x = 0; x < NX; x++) acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0};

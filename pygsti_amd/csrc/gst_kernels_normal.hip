@@ -620,6 +620,24 @@ __global__ void sum_slots_kernel(const double* __restrict__ slots, int n_slots, 
     }
 }
 
+__global__ __launch_bounds__(256) void check_finite_kernel(const double* __restrict__ w, int64_t n, uint32_t* __restrict__ flag)
+{
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double x = w[i];
+        bad = bad || !(x - x == 0.0);                  // inf - inf and nan - nan are nan
+    }
+    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) *flag = 0u;
+}
+
+hipError_t launch_check_finite(const double* w, int64_t n, uint32_t* flag, hipStream_t s)
+{
+    if (n <= 0 || !flag) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(check_finite_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, s, w, n, flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_sum_slots(const double* slots, int n_slots, int64_t stride, int64_t n, double* out, hipStream_t s)
 {
     if (n <= 0 || n_slots <= 0) return hipSuccess;

@@ -224,6 +224,94 @@ def test_analytic_keep_zeros_option():
         pl.set_option(99, 1)
 
 
+def test_resident_zeros_by_default_on_tracked_destinations():
+    """Default (GST_OPT_ANALYTIC_KEEP_ZEROS = 2): memory the library handed out is tracked, so a repeated exact fill into it
+    skips the structural zeros WITHOUT a promise -- and every library write in between (h2d copy, an FD fill, an objective
+    map, the caller's gst_device_touch, a row scaling with a non-finite factor) makes the next fill store everything again.
+    Sentinels cannot be planted through the library here (that is a tracked write): the decision is read from
+    gst_stats.last_zeros_resident and the results are compared with a fresh host fill every time."""
+    from pygsti_amd import _lib
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    pl = plan_from_fixture(fx)
+    nE, nP = int(fx["nE"]), int(fx["nP"])
+    cols = np.arange(nP)
+    ref = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    d = pl.device_malloc(nE * nP * 8)
+
+    def fill(dst=d, ld=nP, c=cols, dest=None):
+        pl.fill_dprobs_dev(dst, ld, c, dest, 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
+        return bool(pl.stats()["last_zeros_resident"])
+
+    def check():
+        assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), d), ref)
+
+    pl.memcpy_h2d(d, np.full(nE * nP, np.nan))
+    assert not fill(); check()                      # first fill of the destination: everything stored over the NaNs
+    assert fill(); check()                          # second: zeros resident
+    assert fill(); check()
+    pl.memcpy_h2d(d, np.full(nE * nP, np.nan))      # a library write in between
+    assert not fill(); check()
+    assert fill()
+    pl.memcpy_h2d(d + 8 * (nE * nP - 1), np.array([np.nan]))      # ... of a single entry
+    assert not fill(); check()
+    assert fill()
+    pl.fill_dprobs_dev(d, nP, cols, None, 1e-7, None, _lib.DERIV_FD); pl.sync()       # an FD Jacobian over it (no exact zeros in general)
+    assert not fill(); check()
+    assert fill()
+    pl.device_touch(d + 800, 16)                   # the caller's own kernel wrote there
+    assert not fill(); check()
+    assert fill()
+    # another column request / leading dimension: nothing is assumed
+    assert not fill(c=cols[::-1].copy(), dest=np.arange(nP)[::-1].copy()); check()
+    assert fill(c=cols[::-1].copy(), dest=np.arange(nP)[::-1].copy()); check()
+    assert not fill(); check()
+    # row scalings keep zeros zero ...
+    w = pl.device_malloc(nE * 8); jtj = pl.device_malloc(nP * nP * 8)
+    scale = np.linspace(0.5, 2.0, nE)
+    pl.memcpy_h2d(w, scale)
+    assert fill()
+    pl.fill_jtj_dev(d, nE, nP, nP, jtj, w); pl.sync()
+    assert np.allclose(pl.memcpy_d2h(np.empty((nE, nP)), d), ref * scale[:, None], rtol=1e-15, atol=0)
+    assert fill(); check()
+    # ... unless a factor is not finite: 0 * inf = NaN in a structural zero, which the next fill must overwrite.  The host
+    # cannot know (the factors live on the device): the claim's device word is cleared on the stream and the kernel reads it
+    scale[3] = np.inf
+    pl.memcpy_h2d(w, scale)
+    pl.fill_jtj_dev(d, nE, nP, nP, jtj, w); pl.sync()
+    assert np.isnan(pl.memcpy_d2h(np.empty((nE, nP)), d)[3]).any()
+    fill(); check()                                # (stats say "resident": the host's view; the kernel stored everything)
+    assert fill(); check()
+    # foreign memory (a pointer straight from the HIP runtime: its owner may write it with kernels the library never sees)
+    # is never trusted
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    raw = C.c_void_p()
+    assert hip.hipMalloc(C.byref(raw), C.c_size_t(nE * nP * 8)) == 0
+    assert not fill(dst=raw.value)
+    assert not fill(dst=raw.value)
+    assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), raw.value), ref)
+    hip.hipFree(raw)
+    # freed and re-allocated tracked memory starts untrusted
+    pl.device_free(d)
+    d2 = pl.device_malloc(nE * nP * 8)
+    pl.memcpy_h2d(d2, np.full(nE * nP, np.nan))
+    assert not fill(dst=d2)
+    assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), d2), ref)
+    # host destinations go through the plan's staging buffer, which only the library writes: resident from the second fill
+    # on, and an FD fill (same staging buffer) in between resets it
+    pl2 = plan_from_fixture(fx)
+    a1 = pl2.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC); r1 = pl2.stats()["last_zeros_resident"]
+    a2 = pl2.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC); r2 = pl2.stats()["last_zeros_resident"]
+    pl2.fill_dprobs(param_idx=cols, mode=_lib.DERIV_FD)
+    a3 = pl2.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC); r3 = pl2.stats()["last_zeros_resident"]
+    assert (r1, r2, r3) == (0, 1, 0) and np.array_equal(a1, ref) and np.array_equal(a2, ref) and np.array_equal(a3, ref)
+    # option 0: never
+    pl.set_option(_lib.OPT_ANALYTIC_KEEP_ZEROS, 0)
+    assert not fill(dst=d2) and not fill(dst=d2)
+    for p_ in (w, jtj, d2):
+        pl.device_free(p_)
+
+
 def test_state_caches_beyond_32bit_offsets_take_the_wide_contraction(monkeypatch):
     """The two-cache MFMA contraction addresses its state caches with 32-bit per-lane byte offsets (4 GB each).  A plan
     whose caches are larger is no longer refused (round 2: GST_EUNSUPPORTED) or degraded: the same kernels, instantiated
