@@ -69,6 +69,11 @@ int guarded(F&& body)
         if ((p)->timing) HIP_TRY(hipEventRecord((p)->ev, (p)->stream));      \
     } while (0)
 
+// GST_TEST_FORCE poison=1 (tests): a (re)grown device buffer starts from 0xFF bytes -- NaNs, index -1, counters at their
+// maximum -- instead of zeros, so that any path that READS a word nothing wrote fails loudly instead of quietly (the
+// diagnosis tool for "works because fresh memory happens to be zero")
+int g_poison_fill = 0;
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -86,7 +91,7 @@ struct DevBuf {
         // A (re)grown buffer starts from zeros, not from whatever an earlier allocation of this process left there: a table
         // entry or padding word that some path does not write is then the same harmless value in every run (once per
         // growth, at memory speed).
-        e = hipMemset(p, 0, n * sizeof(T));
+        e = hipMemset(p, g_poison_fill, n * sizeof(T));
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);      // (done before any of the plan's own, non-blocking streams touches it)
         return e;
     }
@@ -363,6 +368,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     //   host_direct=0|2   page-locked destinations filled by a copy / by the kernel's own stores at any column count
     //   hess_composed=1   every FD-of-FD Hessian block through the composed route
     //   cache_limit=BYTES stands in for the 4 GB of 32-bit cache offsets (the WIDE contraction kernels)
+    //   poison=1          grown device buffers start from 0xFF bytes instead of zeros (reads of unwritten words show)
     if (const char* spec = std::getenv("GST_TEST_FORCE")) {
         std::string str(spec);
         size_t pos = 0;
@@ -384,6 +390,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
             else if (key == "host_direct") { p->host_direct = iv != 0; if (iv == 2) p->host_direct_min_cols = 1; }
             else if (key == "hess_composed") p->hess_composed = iv != 0;
             else if (key == "cache_limit") p->test_cache_limit = val;
+            else if (key == "poison") g_poison_fill = iv ? 0xFF : 0;
             else { delete p; return fail(GST_EINVAL, "GST_TEST_FORCE: unknown key '" + key + "'"); }
         }
     }
@@ -474,7 +481,9 @@ void base_args(gst_plan* p, gst::WalkArgs& a)
 
 // Base probabilities into d_dst (device), S = 0 walk: one wavefront per task.  With `fill_cache` the
 // pass also stores every state it produces (the derivative passes start from them).
-int run_probs(gst_plan* p, double* d_dst, bool fill_cache, int chain_share = 1, const uint32_t* guard = nullptr)
+// `reassoc`: the caller has no ordering contract (exact derivatives, GST_OPT_FAST_PROBS) -- a D = 64 plan then walks on
+// the matrix cores (gst_kernels_chain64.hip), 5x faster per dependent step, results equal up to re-association.
+int run_probs(gst_plan* p, double* d_dst, bool fill_cache, int chain_share = 1, const uint32_t* guard = nullptr, bool reassoc = false)
 {
     gst::WalkArgs a;
     base_args(p, a);
@@ -487,7 +496,10 @@ int run_probs(gst_plan* p, double* d_dst, bool fill_cache, int chain_share = 1, 
         a.base_cache_w = p->d_base_cache.p;
     }
     a.rows_S = 0;
-    HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
+    if (reassoc && p->hp.D == 64 && p->fast_chains && !guard) {
+        HIP_TRY(gst::launch_chain64(a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
+        p->last_levels = true;
+    } else HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
     p->last_launches++;
     return GST_OK;
 }
@@ -575,7 +587,7 @@ int run_probs_any(gst_plan* p, double* d_dst)
         if (rc) return rc;
         if (levels_wanted(p, p->lv_probs)) return run_levels_forward(p, d_dst, true);
     }
-    return run_probs(p, d_dst, false);
+    return run_probs(p, d_dst, false, 1, nullptr, p->fast_probs);
 }
 
 struct LaneLayout {
@@ -1175,7 +1187,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         lv_f = levels_wanted(p, p->lv_fwd);
     }
     rc = lv_f ? run_levels_forward(p, d_base)
-              : run_probs(p, d_base, n_param > 0, will_fork && n_param > 0 ? 2 : 1);        // probabilities + every forward state
+              : run_probs(p, d_base, n_param > 0, will_fork && n_param > 0 ? 2 : 1, nullptr, will_fork && n_param > 0);   // probabilities + every forward state
     if (rc) return rc;
     if (n_param == 0) return GST_OK;
     const bool request_was_cached = p->request_cached(2, param_idx, dest_idx, n_param);
@@ -1285,6 +1297,12 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
             ra.bmats = p->d_gates.p; ra.starts = p->d_effects.p; ra.cache = p->d_rev_cache.p;
             HIP_TRY(gst::launch_level_pass(ra, p->rev.n_tasks(), p->stream2));
             p->last_launches++;
+        } else if (D == 64 && p->fast_chains) {                // all effects of a task as one row block on the matrix cores
+            for (int e0 = 0; e0 < h.n_effects; e0 += 16) {
+                w.start0 = e0;
+                HIP_TRY(gst::launch_chain64(w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));
+                p->last_launches++;
+            }
         } else if (D == 64) {                                  // one wavefront per (task, effect), a single launch
             w.start0 = 0; w.n_pwaves = h.n_effects;
             HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));

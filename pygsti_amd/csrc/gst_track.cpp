@@ -21,10 +21,11 @@ namespace {
 
 struct Claim { const char* base; size_t bytes; uint64_t sig; uint32_t* d_ok; int device; };
 
-std::mutex g_mu;
-std::map<const char*, size_t> g_allocs;              // tracked allocations: base -> bytes
-std::vector<Claim> g_claims;
-std::vector<std::pair<int, uint32_t*>> g_free_flags;  // (device, word) of dropped claims, reused
+// (never destroyed: a plan released during process teardown may still report here)
+std::mutex& g_mu = *new std::mutex;
+std::map<const char*, size_t>& g_allocs = *new std::map<const char*, size_t>;              // tracked allocations: base -> bytes
+std::vector<Claim>& g_claims = *new std::vector<Claim>;
+std::vector<std::pair<int, uint32_t*>>& g_free_flags = *new std::vector<std::pair<int, uint32_t*>>;  // (device, word) of dropped claims, reused
 
 bool overlaps(const char* a, size_t na, const char* b, size_t nb) { return a < b + nb && b < a + na; }
 

@@ -123,3 +123,46 @@ def test_level_passes_on_the_bench_design():
     finally:
         for b in bufs:
             plan.device_free(b)
+
+
+def test_three_qubit_walk_on_the_matrix_cores():
+    """D = 64 (gst_kernels_chain64.hip): the modes without an ordering contract walk a task as one [start vectors][64] row
+    block on the matrix cores instead of a wavefront per (task, start vector).  GST_OPT_FAST_PROBS probabilities <= 1e-10 from
+    the reference's (the default fill stays bit-identical); exact Jacobians within re-association of the SAME plan's exact
+    Jacobian through the sequential row kernel (GST_OPT_FAST_CHAINS = 0), which the Matrix fixtures pin
+    (test_gpu_analytic.py); tasks with save slots and depth-256 circuits included (3q_explicit_L64)."""
+    fx = load_fixture("3q_explicit_L64")
+    pl = plan_from_fixture(fx)
+    nE = int(fx["nE"])
+    exact = pl.fill_probs()
+    assert_bitwise(exact, fx["probs"], "default 3Q probabilities stay bit-identical")
+    assert pl.stats()["last_levels"] == 0
+    pl.set_option(_lib.OPT_FAST_PROBS, 1)
+    fast = pl.fill_probs()
+    assert pl.stats()["last_levels"] == 1
+    err = np.abs(fast - fx["probs"]).max()
+    assert 0 < err < 1e-10 or err == 0.0, err
+    assert err < 1e-13, err
+    pl.set_option(_lib.OPT_FAST_PROBS, 0)
+    # exact Jacobian columns spread over the state preparation, the effects and every gate
+    rng = np.random.default_rng(5)
+    cols = np.sort(rng.choice(int(fx["nP"]), 300, replace=False))
+    pr1 = np.empty(nE); pr0 = np.empty(nE)
+    J1 = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC, probs_out=pr1)
+    assert pl.stats()["last_levels"] == 1
+    pl.set_option(_lib.OPT_FAST_CHAINS, 0)
+    J0 = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC, probs_out=pr0)
+    assert pl.stats()["last_levels"] == 0
+    assert_bitwise(pr0, fx["probs"], "sequential chain passes: probabilities of an exact fill are the reference's bits")
+    assert np.abs(pr1 - pr0).max() < 1e-13
+    scale = max(1.0, np.abs(J0).max())
+    assert np.abs(J1 - J0).max() < 1e-11 * scale, np.abs(J1 - J0).max()
+    assert np.abs(J0).max() > 1e-3
+    # ... and against the finite-difference columns of the reference at the usual FD accuracy
+    fd_cols = fx["dprobs_cols"][:64]
+    pl.set_option(_lib.OPT_FAST_CHAINS, 1)
+    Ja = pl.fill_dprobs(param_idx=fd_cols, mode=_lib.DERIV_ANALYTIC)
+    assert np.abs(Ja - fx["dprobs_map"][:, :64]).max() < 5e-5
+    # FD mode untouched
+    J = pl.fill_dprobs(param_idx=fd_cols, eps=float(fx["derivative_eps"]))
+    assert_bitwise(J, fx["dprobs_map"][:, :64], "3Q FD columns with the matrix-core walk available")
