@@ -1,0 +1,562 @@
+// gst_fill_analytic.cpp -- exact derivatives behind the C ABI (matrixforwardsim.py:1047-1287): the reversed plan and its
+// pair / block tables, the two state caches and the MFMA contraction, and the chain rule for general parameterisations
+// (gst_set_derivs / gst_set_second_derivs).
+#include "gst_state.hpp"
+
+using namespace gst_impl;
+
+namespace gst_impl {
+
+// Analytic mode, D = 16: reversed plan + pair tables, built and uploaded once per plan.
+int ensure_reverse(gst_plan* p)
+{
+    if (p->rev_ready) return GST_OK;
+    const gst::HostPlan& h = p->hp;
+    const int32_t rev_tasks = 0;
+    std::string err = gst::build_reverse_plan(h, p->rev, rev_tasks, h.D == 16 ? 1 : (h.D == 64 ? 8 : 4));
+    if (!err.empty()) return fail(GST_EINVAL, "reversed plan: " + err);
+    if (p->rev.max_slots > (h.D == 64 ? 32 : 4)) return fail(GST_EUNSUPPORTED, "reversed plan needs too many save slots");
+    std::vector<int32_t> pf, pr;
+    std::vector<int64_t> pos_ptr;
+    gst::build_pair_tables(h, p->rev, pf, pr, pos_ptr);
+    HIP_TRY(p->d_rprog.ensure(p->rev.prog.size() + 64));
+    HIP_TRY(hipMemsetAsync(p->d_rprog.p, 0, (p->rev.prog.size() + 64) * 4, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_rprog.p, p->rev.prog.data(), p->rev.prog.size() * 4, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p->d_rtask_off.ensure(p->rev.task_off.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_rtask_off.p, p->rev.task_off.data(), p->rev.task_off.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(p->d_pos_ptr.ensure(pos_ptr.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_pos_ptr.p, pos_ptr.data(), pos_ptr.size() * 8, hipMemcpyHostToDevice, p->stream));
+    int rc;
+    std::vector<int32_t> zeros((size_t)h.n_circuits + 1, 0);
+    if ((rc = upload_i32(p->d_reff_ptr, zeros, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_rev_leaf, p->rev.circ_leaf, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_pair_f, pf, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_pair_r, pr, p->stream))) return rc;
+    if ((rc = upload_i32(p->d_circ_rho, h.circ_rho, p->stream))) return rc;
+    std::vector<int32_t> order((size_t)h.n_circuits);
+    for (int64_t c = 0; c < h.n_circuits; c++) order[(size_t)c] = (int32_t)c;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->rev.circ_leaf[x] < p->rev.circ_leaf[y]; });
+    const int nG = h.n_gates;
+    // applications of every gate that two circuits have in common at their ends (equal backward-state ids)
+    auto common_tail = [&](int32_t c, int32_t c2, int32_t* per_gate) {
+        int64_t common = 0;
+        for (int g = 0; g < nG; g++) {
+            const int64_t a0 = pos_ptr[(size_t)c * nG + g], a1 = pos_ptr[(size_t)c * nG + g + 1];
+            const int64_t b0 = pos_ptr[(size_t)c2 * nG + g], b1 = pos_ptr[(size_t)c2 * nG + g + 1];
+            int64_t n = 0;
+            while (n < a1 - a0 && n < b1 - b0 && pr[(size_t)(a1 - 1 - n)] == pr[(size_t)(b1 - 1 - n)]) n++;
+            if (per_gate) per_gate[g] = (int32_t)n;
+            common += n;
+        }
+        return common;
+    };
+    auto similar = [&](int32_t c, int32_t c2, int64_t common) {
+        const int64_t longer = std::max(h.circ_ptr[c + 1] - h.circ_ptr[c], h.circ_ptr[c2 + 1] - h.circ_ptr[c2]);
+        return common >= 8 && 2 * common >= longer;
+    };
+    if (h.D == 16 && p->ana_germ_order && h.n_circuits > 1) {
+        // Locality of the FORWARD states.  Pure suffix order keeps the backward chains of neighbours together but walks
+        // through every prefix family (preparation fiducial x germ) for each measurement fiducial and germ power, so the
+        // forward chains -- 128 bytes per application of every item -- never stay in an XCD's 4 MB L2.  Runs of
+        // neighbours that end alike (one germ power and measurement fiducial behind all the preparation fiducials)
+        // are kept whole, and the runs are ordered by the forward-trie family their first member belongs to (the root
+        // of its state's parent chain = the task of the forward plan): all the runs of one germ become consecutive, their
+        // 16 forward chains (2 MB) stay in L2 while the germ's backward chains stream through once.
+        std::vector<int32_t> root((size_t)h.n_state_ids, -2);
+        auto root_of = [&](int32_t id) {
+            int32_t r = id;
+            while (root[(size_t)r] == -2 && h.node_parent[(size_t)r] >= 0) r = h.node_parent[(size_t)r];
+            const int32_t top = root[(size_t)r] == -2 ? r : root[(size_t)r];
+            for (int32_t q = id; q != r; q = h.node_parent[(size_t)q]) root[(size_t)q] = top;
+            root[(size_t)r] = top;
+            return top;
+        };
+        std::vector<int32_t> run_of((size_t)h.n_circuits, 0), run_key;
+        int32_t run = 0;
+        run_key.push_back(root_of(h.circ_leaf[(size_t)order[0]]));
+        for (int64_t k = 1; k < h.n_circuits; k++) {
+            const int32_t c = order[(size_t)k - 1], c2 = order[(size_t)k];
+            if (!similar(c, c2, common_tail(c, c2, nullptr))) { run++; run_key.push_back(0x7fffffff); }
+            run_of[(size_t)k] = run;
+            run_key[(size_t)run] = std::min(run_key[(size_t)run], root_of(h.circ_leaf[(size_t)c2]));
+        }
+        std::vector<int32_t> posn((size_t)h.n_circuits);
+        for (int64_t k = 0; k < h.n_circuits; k++) posn[(size_t)k] = (int32_t)k;
+        std::stable_sort(posn.begin(), posn.end(), [&](int32_t x, int32_t y) { return run_key[(size_t)run_of[(size_t)x]] < run_key[(size_t)run_of[(size_t)y]]; });
+        std::vector<int32_t> reordered((size_t)h.n_circuits);
+        for (int64_t k = 0; k < h.n_circuits; k++) reordered[(size_t)k] = order[(size_t)posn[(size_t)k]];
+        order.swap(reordered);
+    }
+    // Work items of the D = 16 contraction: a circuit, or TWO neighbours of the suffix order whose last applications
+    // coincide (same germ power and measurement fiducial behind different preparation fiducials): over the common
+    // tail their backward states are the same vectors and the kernel gathers them once for both.
+    std::vector<int32_t> item_first, item_partner, item_common;
+    const bool pairing = h.D == 16 && h.n_effects == 4 && p->ana_pairs;
+    auto plain4 = [&](int32_t c) {
+        if (h.eff_ptr[c + 1] - h.eff_ptr[c] != 4) return false;
+        for (int x = 0; x < 4; x++) if (h.eff_label[(size_t)h.eff_ptr[c] + x] != x) return false;
+        return true;
+    };
+    for (int64_t k = 0; k < h.n_circuits; k++) {
+        const int32_t c = order[(size_t)k];
+        bool paired = false;
+        if (pairing && k + 1 < h.n_circuits) {
+            const int32_t c2 = order[(size_t)k + 1];
+            if (plain4(c) && plain4(c2)) {
+                std::vector<int32_t> cg((size_t)nG, 0);
+                const int64_t common = common_tail(c, c2, cg.data());
+                if (similar(c, c2, common)) {
+                    item_first.push_back(c); item_partner.push_back(c2);
+                    item_common.insert(item_common.end(), cg.begin(), cg.end());
+                    paired = true;
+                    k++;
+                }
+            }
+        }
+        if (!paired) {
+            item_first.push_back(c); item_partner.push_back(-1);
+            item_common.insert(item_common.end(), (size_t)nG, 0);
+        }
+    }
+    const int64_t n_items = (int64_t)item_first.size();
+    if (h.D == 16) {
+        if ((rc = upload_i32(p->d_circ_order, item_first, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_circ_partner, item_partner, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_pair_common, item_common, p->stream))) return rc;
+    } else {
+        if ((rc = upload_i32(p->d_circ_order, order, p->stream))) return rc;
+    }
+    // 8 contiguous ranges of the item list with equal numbers of gate applications (+ a constant per circuit)
+    std::vector<uint32_t> range_begin(9, 0);
+    {
+        auto work = [&](int64_t k) {
+            double w = (double)(h.circ_ptr[item_first[(size_t)k] + 1] - h.circ_ptr[item_first[(size_t)k]]) + 24.0;
+            if (item_partner[(size_t)k] >= 0) w += (double)(h.circ_ptr[item_partner[(size_t)k] + 1] - h.circ_ptr[item_partner[(size_t)k]]) + 24.0;
+            return w;
+        };
+        double total = 0;
+        for (int64_t k = 0; k < n_items; k++) total += work(k);
+        double acc = 0;
+        int r = 1;
+        for (int64_t k = 0; k < n_items && r < 8; k++) {
+            acc += work(k);
+            while (r < 8 && acc >= total * r / 8.0) range_begin[r++] = (uint32_t)(k + 1);
+        }
+        for (; r < 8; r++) range_begin[r] = (uint32_t)n_items;
+        range_begin[8] = (uint32_t)n_items;
+    }
+    if (h.D != 16) {            // (the other contraction kernels index the plain permutation; their ranges are unused)
+        for (int r = 0; r <= 8; r++) range_begin[r] = (uint32_t)(h.n_circuits * r / 8);
+    }
+    HIP_TRY(p->d_range_begin.ensure(9));
+    HIP_TRY(hipMemcpyAsync(p->d_range_begin.p, range_begin.data(), 9 * 4, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(p->d_work_counter.ensure(8));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (h.D == 16 && pairing && p->ana_stream && nG <= 63) {
+        // Two-circuit items as ONE stream of blocks of 4 "slots": per gate the common tail (slot = one application of
+        // both circuits: their two forward ids and the shared backward id), then what each circuit has before the tail
+        // (the other circuit's forward id = -1: its operand is zeroed), padded to a multiple of 4 with dead slots.  The
+        // contraction's gather pipeline then runs through a whole item without draining at every gate and segment.
+        const size_t blk_slots = 4 * (size_t)gst::analytic_stream_chunks();
+        std::vector<int32_t> bf1, bf2, br, bptr((size_t)n_items * (size_t)nG + 1, 0);
+        bf1.reserve(pf.size()); bf2.reserve(pf.size()); br.reserve(pf.size());
+        for (int64_t k = 0; k < n_items; k++) {
+            const int32_t c = item_first[(size_t)k], c2 = item_partner[(size_t)k];
+            for (int g = 0; g < nG; g++) {
+                bptr[(size_t)k * nG + g] = (int32_t)(bf1.size() / blk_slots);
+                if (c2 < 0) continue;
+                const int64_t p0 = pos_ptr[(size_t)c * nG + g], p1 = pos_ptr[(size_t)c * nG + g + 1];
+                const int64_t q0 = pos_ptr[(size_t)c2 * nG + g], q1 = pos_ptr[(size_t)c2 * nG + g + 1];
+                const int64_t cg = item_common[(size_t)k * nG + g];
+                for (int64_t t = 0; t < cg; t++) { bf1.push_back(pf[(size_t)(p1 - cg + t)]); bf2.push_back(pf[(size_t)(q1 - cg + t)]); br.push_back(pr[(size_t)(p1 - cg + t)]); }
+                for (int64_t j = p0; j < p1 - cg; j++) { bf1.push_back(pf[(size_t)j]); bf2.push_back(-1); br.push_back(pr[(size_t)j]); }
+                for (int64_t j = q0; j < q1 - cg; j++) { bf1.push_back(-1); bf2.push_back(pf[(size_t)j]); br.push_back(pr[(size_t)j]); }
+                while (bf1.size() % blk_slots) { bf1.push_back(-1); bf2.push_back(-1); br.push_back(br.empty() ? 0 : br.back()); }
+            }
+            if (bf1.size() / 4 > 0x1ffffff0u) return fail(GST_EUNSUPPORTED, "analytic block stream too long");
+        }
+        bptr[(size_t)n_items * nG] = (int32_t)(bf1.size() / blk_slots);
+        if (bf1.empty()) { bf1.assign(blk_slots, -1); bf2.assign(blk_slots, -1); br.assign(blk_slots, 0); }
+        if ((rc = upload_i32(p->d_blk_f1, bf1, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_blk_f2, bf2, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_blk_r, br, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_blk_ptr, bptr, p->stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    if (h.D == 16) build_levels_host(p, true);      // (needs the reversed plan's state graph, dropped below; whatever GST_OPT_FAST_CHAINS says NOW)
+    // (the host copies of the reversed programs are not needed any more)
+    p->rev.prog.clear(); p->rev.prog.shrink_to_fit();
+    p->rev.node_parent.clear(); p->rev.node_parent.shrink_to_fit();
+    p->rev.node_sym.clear(); p->rev.node_sym.shrink_to_fit();
+    p->rev_ready = true;
+    return GST_OK;
+}
+
+// Exact Jacobian columns (GST_DERIV_ANALYTIC) into device memory.
+int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
+                        int64_t n_param, double* d_probs_out)
+{
+    const gst::HostPlan& h = p->hp;
+    if (p->comp_index >= 0 && !p->derivs_set)
+        return fail(GST_EUNSUPPORTED, "a complement effect is declared: exact derivatives of TP POVMs need gst_set_derivs");
+    if (h.D != 4 && h.D != 16 && h.D != 64) return fail(GST_EUNSUPPORTED, "the analytic mode supports D = 4, 16 and 64");
+    if (h.D == 64 && !p->ana_mfma) return fail(GST_EUNSUPPORTED, "D = 64 analytic derivatives exist on the MFMA path only");
+    double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
+    // (the backward chain pass needs only the model arrays already on their way: it forks here, onto the second stream --
+    //  only where the two-cache contraction will run: a plain 1Q Jacobian is launch-bound and takes the single kernel)
+    const bool will_fork = p->ana_mfma && (h.D != 4 || p->want_cache_path);
+    if (will_fork) HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
+    // Forward states: the sequential walk (bit-identical probabilities), or -- this mode has no ordering contract -- the
+    // log-depth level pass where the plan's germ-power paths make it pay (GST_OPT_FAST_CHAINS; probabilities <= 1e-10)
+    int rc;
+    bool lv_f = false;
+    p->last_levels = false;
+    if (h.D == 16 && will_fork && n_param > 0 && p->fast_chains) {
+        if ((rc = ensure_levels(p, false))) return rc;
+        lv_f = levels_wanted(p, p->lv_fwd);
+    }
+    rc = lv_f ? run_levels_forward(p, d_base)
+              : run_probs(p, d_base, n_param > 0, will_fork && n_param > 0 ? 2 : 1, nullptr, will_fork && n_param > 0);   // probabilities + every forward state
+    if (rc) return rc;
+    if (n_param == 0) return GST_OK;
+    const bool request_was_cached = p->request_cached(2, param_idx, dest_idx, n_param);
+    if (!request_was_cached) {
+        p->request_serial++;
+        const int D = h.D, DD = D * D;
+        std::vector<int32_t> cm_gate((size_t)std::max(h.n_gates, 1) * DD, -1), cm_rho((size_t)h.n_rhos * D, -1),
+            cm_eff((size_t)h.n_effects * D, -1), col0(std::max(h.n_gates, 1), -2);
+        std::vector<int64_t> none_cols;
+        for (int64_t c = 0; c < n_param; c++) {
+            const int64_t pi = param_idx[c];
+            const int32_t col = (int32_t)(dest_idx ? dest_idx[c] : c);
+            switch (p->pkind[pi]) {
+            case GST_KIND_GATE: cm_gate[(size_t)p->pobj[pi] * DD + p->pelem[pi]] = col; break;
+            case GST_KIND_RHO: cm_rho[(size_t)p->pobj[pi] * D + p->pelem[pi]] = col; break;
+            case GST_KIND_EFFECT: cm_eff[(size_t)p->pobj[pi] * D + p->pelem[pi]] = col; break;
+            default: none_cols.push_back(col);
+            }
+        }
+        for (int g = 0; g < h.n_gates; g++) {
+            const int32_t* m = cm_gate.data() + (size_t)g * DD;
+            bool any = false, contiguous = m[0] >= 0;
+            for (int k = 0; k < DD; k++) { any = any || m[k] >= 0; contiguous = contiguous && m[k] == m[0] + k; }
+            col0[g] = contiguous ? m[0] : (any ? -1 : -2);
+        }
+        if (!p->graph_uploaded) {
+            if ((rc = upload_i32(p->d_node_parent, h.node_parent, p->stream))) return rc;
+            if ((rc = upload_i32(p->d_node_sym, h.node_sym, p->stream))) return rc;
+            {   // run[id] = 1 + run[id-1] while parent(id) == id-1 is a gate state reached by a consecutive id
+                std::vector<int32_t> run(h.n_state_ids, 0);
+                for (int64_t i = 1; i < h.n_state_ids; i++)
+                    if (h.node_parent[i] == i - 1) run[i] = 1 + ((h.node_parent[i - 1] >= 0 && h.node_parent[i - 1] == i - 2) ? run[i - 1] : 0);
+                if ((rc = upload_i32(p->d_node_run, run, p->stream))) return rc;
+                HIP_TRY(hipStreamSynchronize(p->stream));
+            }
+            if ((rc = upload_i32(p->d_circ_leaf, h.circ_leaf, p->stream))) return rc;
+            p->graph_uploaded = true;
+        }
+        p->cached_kind = 0;
+        if ((rc = upload_i32(p->d_gate_col0, col0, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_cm_gate, cm_gate, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_cm_rho, cm_rho, p->stream))) return rc;
+        if ((rc = upload_i32(p->d_cm_eff, cm_eff, p->stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(p->stream));          // host vectors above go out of scope
+        p->remember_request(2, param_idx, dest_idx, n_param);
+        p->cached_none_cols = none_cols;
+    }
+    const int D = h.D;
+    const std::vector<int64_t>& none_cols = p->cached_none_cols;
+    for (int64_t col : none_cols)                      // parameters of objects this atom never applies: exact zeros
+        HIP_TRY(hipMemset2DAsync(d_out + col, (size_t)ld * 8, 0, 8, (size_t)h.n_elements, p->stream));
+    gst::AnaArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_circuits = h.n_circuits;
+    a.circ_leaf = p->d_circ_leaf.p; a.node_parent = p->d_node_parent.p; a.node_sym = p->d_node_sym.p; a.node_run = p->d_node_run.p;
+    a.eff_ptr = p->d_eff_ptr.p; a.eff_label = p->d_eff_label.p; a.eff_dest = p->d_eff_dest.p;
+    a.gates_t = p->d_gates_t.p; a.effects = p->d_effects.p; a.base_cache = p->d_base_cache.p;
+    a.n_gates = h.n_gates; a.n_rhos = h.n_rhos; a.n_effects = h.n_effects;
+    a.gate_col0 = p->d_gate_col0.p; a.colmap_gate = p->d_cm_gate.p; a.colmap_rho = p->d_cm_rho.p; a.colmap_eff = p->d_cm_eff.p;
+    a.out = d_out; a.ld = ld;
+    // The MFMA kernels address both state caches with a uniform 64-bit base + 32-bit per-lane byte offsets; a cache of
+    // 4 GB or more selects their WIDE instantiation (64-bit lane offsets: two more address registers per gather in
+    // flight), nothing is refused.  (GST_TEST_FORCE cache_limit=: tests lower the 4 GB so that a small plan takes that form.)
+    const double cache_limit = p->test_cache_limit > 0 ? p->test_cache_limit : 4.0e9;
+    const bool caches_small = (double)h.n_state_ids * D * 8 < cache_limit;
+    // the two-cache contraction: MFMA at D = 16 / 64; at D = 4 (VALU) only when a Hessian needs its tables -- a plain 1Q
+    // Jacobian is launch-bound and the single backward-walking kernel below is one launch instead of three
+    // D <= 16: the backward pass needs the chain kernel, whose tables (all gates, effects, emit ring) live in LDS; a gate
+    // set too large for it takes the single-kernel path below (Jacobians) or is refused (Hessians need the caches)
+    const bool chain_ok = D == 64 || gst::chain_kernel_fits(D, h.n_gates, h.n_effects, 4);
+    if (!chain_ok && p->want_cache_path)
+        return fail(GST_EUNSUPPORTED, "exact Hessians at D <= 16 need the gate set in LDS (at most " +
+                                          std::to_string(128 * 1024 / (D * D * 8)) + " gates at this D)");
+    bool rev_small = true;
+    if (will_fork && chain_ok) {
+        if ((rc = ensure_reverse(p))) return rc;
+        rev_small = (double)p->rev.n_state_ids * h.n_effects * D * 8 < cache_limit;
+    }
+    if (will_fork && chain_ok) {
+        a.wide = (caches_small && rev_small) ? 0 : 1;
+        // backward states: the chain kernel over the reversed plan, transposed gates (= the row-major array), one lane
+        // group per effect (64/D effects per pass)
+        gst::WalkArgs w;
+        std::memset(&w, 0, sizeof(w));
+        w.prog = p->d_rprog.p; w.task_off = p->d_rtask_off.p;
+        w.eff_ptr = p->d_reff_ptr.p; w.eff_label = p->d_reff_ptr.p; w.eff_dest = p->d_reff_ptr.p;
+        w.gates = p->d_gates_t.p; w.gates_t = p->d_gates.p;          // (G^T)^T = G: the roles of the two layouts swap
+        w.rhos = p->d_effects.p; w.effects = p->d_effects.p;
+        w.n_gates = h.n_gates; w.n_effects = 0;
+        w.n_pwaves = 1; w.rows_S = 0; w.mode = gst::EMIT_PROBS; w.out = p->d_pbase.p;
+        HIP_TRY(p->d_rev_cache.ensure((size_t)p->rev.n_state_ids * h.n_effects * D));
+        w.base_cache_w = p->d_rev_cache.p;
+        w.multi_start = h.n_effects;
+        w.chain_share = 2;                      // (the forward pass runs beside this one)
+        TIME_REC(p, evk0);
+        // Both chain passes are latency-bound (one wavefront per task, a fraction of the SIMDs): the backward one runs
+        // on the second stream beside the forward pass launched above, and the contraction waits for both.
+        HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
+        bool lv_r = false;
+        if (D == 16 && p->fast_chains) {
+            if ((rc = ensure_levels(p, true))) return rc;
+            lv_r = levels_wanted(p, p->lv_rev);
+        }
+        if (lv_r) {                                            // backward states by the level pass: one launch, all effects
+            gst::LevelArgs ra;
+            level_args(p->lv_rev, ra);
+            ra.bmats = p->d_gates.p; ra.starts = p->d_effects.p; ra.cache = p->d_rev_cache.p;
+            HIP_TRY(gst::launch_level_pass(ra, p->rev.n_tasks(), p->stream2));
+            p->last_launches++;
+        } else if (D == 64 && p->fast_chains) {                // all effects of a task as one row block on the matrix cores
+            for (int e0 = 0; e0 < h.n_effects; e0 += 16) {
+                w.start0 = e0;
+                HIP_TRY(gst::launch_chain64(w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));
+                p->last_launches++;
+            }
+        } else if (D == 64) {                                  // one wavefront per (task, effect), a single launch
+            w.start0 = 0; w.n_pwaves = h.n_effects;
+            HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));
+            p->last_launches++;
+        } else {
+            for (int e0 = 0; e0 < h.n_effects; e0 += 64 / D) {  // four effects (lane groups) per pass of the chain kernel
+                w.start0 = e0;
+                HIP_TRY(gst::launch_walk_rows(D, w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));
+                p->last_launches++;
+            }
+        }
+        HIP_TRY(hipEventRecord(p->ev_join, p->stream2));
+        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+        a.rev_cache = p->d_rev_cache.p; a.rev_leaf = p->d_rev_leaf.p; a.pair_f = p->d_pair_f.p; a.pair_r = p->d_pair_r.p;
+        a.circ_partner = D == 16 ? p->d_circ_partner.p : nullptr; a.pair_common = D == 16 ? p->d_pair_common.p : nullptr;
+        a.pos_ptr = p->d_pos_ptr.p; a.circ_rho = p->d_circ_rho.p; a.circ_order = p->d_circ_order.p; a.work_counter = p->d_work_counter.p; a.range_begin = p->d_range_begin.p;
+        a.group_fetch = p->ana_group_fetch ? 1 : 0;
+        if (D == 16 && p->d_blk_ptr.p) { a.blk_f1 = p->d_blk_f1.p; a.blk_f2 = p->d_blk_f2.p; a.blk_r = p->d_blk_r.p; a.blk_ptr = p->d_blk_ptr.p; }
+        // GST_OPT_ANALYTIC_KEEP_ZEROS: the blocks of gates an item never applies are exact zeros; when THIS destination got
+        // THIS request last time (and the caller promised, by setting the option, to write nothing but row scalings into it
+        // in between) they are zero already and are not stored again -- a third of the D = 16 contraction's stores
+        // Without the option (value 2, the default) the same holds for destinations the library can vouch for: memory from
+        // gst_device_malloc and the plan's own staging buffer, whose every other writer reports to gst_track.cpp.
+        const bool same_dest = p->ana_zero_out == (const void*)d_out && p->ana_zero_ld == ld && p->ana_zero_valid && request_was_cached;
+        const bool zero_form = D == 16 && !p->derivs_set && !p->want_cache_path;
+        const size_t extent = jac_extent(nE_total(p), ld, dest_idx, n_param);
+        const uint64_t sig = (p->uid * 0x9E3779B97F4A7C15ull) ^ (p->request_serial * 0xC2B2AE3D27D4EB4Full) ^ (uint64_t)ld;
+        bool claim = false;
+        a.zeros_resident = 0; a.zeros_ok = nullptr;
+        if (zero_form && p->ana_keep_zeros == 1) a.zeros_resident = same_dest ? 1 : 0;
+        else if (zero_form && p->ana_keep_zeros == 2 && (d_out == p->d_out.p || gst::track_owned(d_out, extent))) {
+            claim = true;
+            if (const uint32_t* w = gst::track_claim_find(d_out, extent, sig)) { a.zeros_resident = 1; a.zeros_ok = w; }
+        }
+        if (!claim) gst::track_touch(d_out, extent);
+        p->last_zeros_resident = a.zeros_resident != 0;
+        p->ana_zero_out = d_out; p->ana_zero_ld = ld; p->ana_zero_valid = (D == 16);
+        HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
+        if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
+        else if (D == 16) HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
+        else HIP_TRY(gst::launch_analytic_small(a, p->stream));
+        TIME_REC(p, evk1);
+        p->last_launches++;
+        if (claim) {         // what this fill leaves behind; the word reads 1 again whatever a row scaling did to it before
+            if (uint32_t* w = gst::track_claim_set(d_out, extent, sig, p->device)) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)w, 1, 1, p->stream));
+        }
+        p->last_ana = a; p->last_ana_valid = true;     // (the Hessian rows re-launch the contraction with other caches)
+        p->last_ana.zeros_resident = 0; p->last_ana.zeros_ok = nullptr;
+        return GST_OK;
+    }
+    if (D == 64) return fail(GST_EUNSUPPORTED, "D = 64 analytic derivatives exist on the MFMA path only");
+    gst::track_touch(d_out, jac_extent(h.n_elements, ld, dest_idx, n_param));
+    p->last_zeros_resident = false;
+    TIME_REC(p, evk0);
+    HIP_TRY(gst::launch_analytic(D, a, p->stream));
+    TIME_REC(p, evk1);
+    p->last_launches++;
+    return GST_OK;
+}
+
+
+// The element Jacobian [nE][n_el] ([rhos | effects | gates] of the `full` layout) of the current model into d_jelem,
+// through the ordinary analytic path with the identity element map.
+int run_element_jacobian(gst_plan* p, double* d_probs_out)
+{
+    const gst::HostPlan& h = p->hp;
+    const int D = h.D;
+    const int64_t nE = h.n_elements;
+    const int64_t n_el = (int64_t)h.n_rhos * D + (int64_t)h.n_effects * D + (int64_t)h.n_gates * D * D;
+    std::vector<int32_t> ek((size_t)n_el), eo((size_t)n_el), ee((size_t)n_el);
+    {
+        int64_t q = 0;
+        for (int r = 0; r < h.n_rhos; r++) for (int j = 0; j < D; j++, q++) { ek[q] = GST_KIND_RHO; eo[q] = r; ee[q] = j; }
+        for (int e = 0; e < h.n_effects; e++) for (int j = 0; j < D; j++, q++) { ek[q] = GST_KIND_EFFECT; eo[q] = e; ee[q] = j; }
+        for (int g = 0; g < h.n_gates; g++) for (int j = 0; j < D * D; j++, q++) { ek[q] = GST_KIND_GATE; eo[q] = g; ee[q] = j; }
+    }
+    std::vector<int64_t> all((size_t)n_el);
+    for (int64_t q = 0; q < n_el; q++) all[(size_t)q] = q;
+    HIP_TRY(p->d_jelem.ensure((size_t)std::max<int64_t>(nE * n_el, 1)));
+    p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
+    p->cached_kind = 0;
+    int rc = run_dprobs_analytic(p, p->d_jelem.p, n_el, all.data(), nullptr, n_el, d_probs_out);
+    p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
+    p->cached_kind = 0;
+    return rc;
+}
+
+// GST_DERIV_ANALYTIC with gst_set_derivs: element Jacobian (the `full` layout [rhos | effects | gates]) into scratch,
+// then one MFMA chain-rule product per object, accumulated into the requested parameter columns.
+int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
+                       int64_t n_param, double* d_probs_out)
+{
+    const gst::HostPlan& h = p->hp;
+    const int D = h.D;
+    const int64_t nE = h.n_elements;
+    const int64_t n_el = (int64_t)h.n_rhos * D + (int64_t)h.n_effects * D + (int64_t)h.n_gates * D * D;
+    for (int64_t c = 0; c < n_param; c++)
+        if (param_idx[c] < 0 || param_idx[c] >= p->dv_n_params) return fail(GST_EINVAL, "parameter index out of range");
+    std::vector<int32_t> dest_of((size_t)p->dv_n_params, -1);
+    for (int64_t c = 0; c < n_param; c++) {
+        if (dest_of[(size_t)param_idx[c]] >= 0) return fail(GST_EINVAL, "a parameter is requested twice (not supported with gst_set_derivs)");
+        dest_of[(size_t)param_idx[c]] = (int32_t)(dest_idx ? dest_idx[c] : c);
+    }
+    int rc = run_element_jacobian(p, d_probs_out);
+    if (rc) return rc;
+    if (n_param == 0) return GST_OK;
+    // Object by object: the first object that maps onto a destination column STORES its product there, later ones (shared
+    // parameters: the effects of a POVM) add to it.  Only when some requested column is reached by no object at all are
+    // the columns zeroed first (8.4 GB of memset and as much read-modify-write traffic for the 2Q CPTPLND Jacobian otherwise).
+    std::vector<uint8_t> first_writer(p->dv_kind.size(), 0);
+    bool all_covered = true;
+    {
+        std::vector<uint8_t> seen((size_t)p->dv_n_params, 0);
+        for (size_t o = 0; o < p->dv_kind.size(); o++) {
+            bool any_seen = false, any_new = false;
+            for (int64_t c = p->dv_off_cols[o]; c < p->dv_off_cols[o + 1]; c++) {
+                const int64_t gp = p->dv_param_idx[(size_t)c];
+                if (dest_of[(size_t)gp] < 0) continue;
+                if (seen[(size_t)gp]) any_seen = true; else any_new = true;
+            }
+            first_writer[o] = (any_new && !any_seen) ? 1 : 0;
+            // an object that is neither purely first nor purely later (it shares SOME columns) must add: those columns need zeros
+            if (any_new && any_seen) all_covered = false;
+            for (int64_t c = p->dv_off_cols[o]; c < p->dv_off_cols[o + 1]; c++) seen[(size_t)p->dv_param_idx[(size_t)c]] = 1;
+        }
+        for (int64_t c = 0; c < n_param; c++) all_covered = all_covered && seen[(size_t)param_idx[c]];
+        if (!all_covered) std::fill(first_writer.begin(), first_writer.end(), (uint8_t)0);
+    }
+    bool window = true;
+    for (int64_t c = 1; dest_idx && c < n_param; c++) window = window && dest_idx[c] == dest_idx[0] + c;
+    if (all_covered) {
+        // (every requested column gets its first value by a store)
+    } else if (window) {
+        const int64_t d0 = dest_idx ? dest_idx[0] : 0;
+        HIP_TRY(hipMemset2DAsync(d_out + d0, (size_t)ld * 8, 0, (size_t)n_param * 8, (size_t)nE, p->stream));
+    } else {
+        for (int64_t c = 0; c < n_param; c++) HIP_TRY(hipMemset2DAsync(d_out + dest_idx[c], (size_t)ld * 8, 0, 8, (size_t)nE, p->stream));
+    }
+    const int64_t base_rho = 0, base_eff = (int64_t)h.n_rhos * D, base_gate = base_eff + (int64_t)h.n_effects * D;
+    HIP_TRY(p->d_dv_colmap.ensure((size_t)std::max<int64_t>(p->dv_off_cols.back(), 1)));
+    std::vector<int32_t> colmap((size_t)p->dv_off_cols.back());
+    for (size_t c = 0; c < colmap.size(); c++) colmap[c] = dest_of[(size_t)p->dv_param_idx[c]];
+    if (!colmap.empty()) HIP_TRY(hipMemcpyAsync(p->d_dv_colmap.p, colmap.data(), colmap.size() * 4, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));          // `colmap` goes out of scope
+    for (size_t o = 0; o < p->dv_kind.size(); o++) {
+        const int k = p->dv_kind[o];
+        const int K = k == GST_KIND_GATE ? D * D : D;
+        const int64_t a0 = (k == GST_KIND_GATE ? base_gate : k == GST_KIND_RHO ? base_rho : base_eff) + (int64_t)p->dv_obj[o] * K;
+        HIP_TRY(gst::launch_chain_rule_gemm(p->d_jelem.p, n_el, a0, K, p->d_dv_deriv.p + p->dv_off_deriv[o], p->dv_ncols[o],
+                                            p->d_dv_colmap.p + p->dv_off_cols[o], d_out, ld, nE, p->stream, first_writer[o] != 0));
+        p->last_launches++;
+    }
+    return GST_OK;
+}
+
+}  // namespace gst_impl
+
+extern "C" {
+
+int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t* kind, const int32_t* obj,
+                   const int32_t* n_cols, const int64_t* param_idx, const double* deriv)
+{
+    return guarded([&]() -> int {
+    if (!p || n_params < 0 || n_objs < 0) return fail(GST_EINVAL, "bad argument");
+    p->cached_kind = 0;
+    if (n_objs == 0) { p->derivs_set = false; p->dv2_set = false; p->dv2_off.clear(); return GST_OK; }
+    if (!kind || !obj || !n_cols || !param_idx || !deriv) return fail(GST_EINVAL, "bad argument");
+    const int D = p->hp.D;
+    std::vector<int64_t> off_c((size_t)n_objs + 1, 0), off_d((size_t)n_objs + 1, 0);
+    for (int32_t o = 0; o < n_objs; o++) {
+        const int k = kind[o];
+        const int nobj = k == GST_KIND_GATE ? p->hp.n_gates : k == GST_KIND_RHO ? p->hp.n_rhos : k == GST_KIND_EFFECT ? p->hp.n_effects : -1;
+        if (nobj < 0 || obj[o] < 0 || obj[o] >= nobj || n_cols[o] < 0) return fail(GST_EINVAL, "derivative object " + std::to_string(o) + " out of range");
+        off_c[o + 1] = off_c[o] + n_cols[o];
+        off_d[o + 1] = off_d[o] + (int64_t)(k == GST_KIND_GATE ? D * D : D) * n_cols[o];
+    }
+    for (int64_t c = 0; c < off_c[n_objs]; c++)
+        if (param_idx[c] < 0 || param_idx[c] >= n_params) return fail(GST_EINVAL, "derivative parameter index out of range");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    p->dv_kind.assign(kind, kind + n_objs); p->dv_obj.assign(obj, obj + n_objs); p->dv_ncols.assign(n_cols, n_cols + n_objs);
+    p->dv_param_idx.assign(param_idx, param_idx + off_c[n_objs]);
+    p->dv_off_cols = off_c; p->dv_off_deriv = off_d;
+    p->dv_n_params = n_params;
+    p->dv_deriv_h.assign(deriv, deriv + off_d[n_objs]);
+    p->dv2_set = false; p->dv2_off.clear();
+    HIP_TRY(p->d_dv_deriv.ensure((size_t)std::max<int64_t>(off_d[n_objs], 1)));
+    if (off_d[n_objs] > 0) {
+        HIP_TRY(hipMemcpyAsync(p->d_dv_deriv.p, deriv, (size_t)off_d[n_objs] * 8, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    p->derivs_set = true;
+    return GST_OK;
+    });
+}
+
+int gst_set_second_derivs(gst_plan* p, int32_t n_objs, const int32_t* nonzero, const double* hess)
+{
+    return guarded([&]() -> int {
+    if (!p || n_objs < 0) return fail(GST_EINVAL, "bad argument");
+    if (n_objs == 0) { p->dv2_set = false; p->dv2_off.clear(); return GST_OK; }
+    if (!p->derivs_set || (size_t)n_objs != p->dv_kind.size()) return fail(GST_ESTATE, "gst_set_second_derivs follows gst_set_derivs, object for object");
+    if (!nonzero) return fail(GST_EINVAL, "bad argument");
+    const int D = p->hp.D;
+    std::vector<int64_t> off((size_t)n_objs, -1);
+    int64_t total = 0;
+    for (int32_t o = 0; o < n_objs; o++) {
+        if (!nonzero[o]) continue;
+        const int64_t K = p->dv_kind[o] == GST_KIND_GATE ? D * D : D;
+        off[(size_t)o] = total;
+        total += K * p->dv_ncols[o] * (int64_t)p->dv_ncols[o];
+    }
+    if (total > 0 && !hess) return fail(GST_EINVAL, "hess is NULL");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    HIP_TRY(p->d_dv2.ensure((size_t)std::max<int64_t>(total, 1)));
+    if (total > 0) {
+        HIP_TRY(hipMemcpyAsync(p->d_dv2.p, hess, (size_t)total * 8, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    p->dv2_off = off;
+    p->dv2_set = total > 0;
+    return GST_OK;
+    });
+}
+
+}  // extern "C"
