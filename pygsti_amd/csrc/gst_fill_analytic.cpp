@@ -479,11 +479,22 @@ int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* pa
     HIP_TRY(hipStreamSynchronize(p->stream));          // `colmap` goes out of scope
     for (size_t o = 0; o < p->dv_kind.size(); o++) {
         const int k = p->dv_kind[o];
-        const int K = k == GST_KIND_GATE ? D * D : D;
+        int K = k == GST_KIND_GATE ? D * D : D;
         const int64_t a0 = (k == GST_KIND_GATE ? base_gate : k == GST_KIND_RHO ? base_rho : base_eff) + (int64_t)p->dv_obj[o] * K;
+        // The effects of one POVM share their parameters: as separate objects each of them would read-modify-write the same
+        // nE x n columns (1 GB apiece at 2Q).  Consecutive objects of one kind whose element columns, derivative matrices
+        // and destination columns line up are ONE product with the K's stacked.
+        size_t last = o;
+        while (last + 1 < p->dv_kind.size() && p->dv_kind[last + 1] == k && p->dv_obj[last + 1] == p->dv_obj[last] + 1 &&
+               p->dv_ncols[last + 1] == p->dv_ncols[o] && !first_writer[last + 1] &&
+               p->dv_off_deriv[last + 1] == p->dv_off_deriv[last] + (int64_t)(k == GST_KIND_GATE ? D * D : D) * p->dv_ncols[o] &&
+               std::equal(colmap.begin() + p->dv_off_cols[o], colmap.begin() + p->dv_off_cols[o + 1], colmap.begin() + p->dv_off_cols[last + 1]))
+            last++;
+        K *= (int)(last - o + 1);
         HIP_TRY(gst::launch_chain_rule_gemm(p->d_jelem.p, n_el, a0, K, p->d_dv_deriv.p + p->dv_off_deriv[o], p->dv_ncols[o],
                                             p->d_dv_colmap.p + p->dv_off_cols[o], d_out, ld, nE, p->stream, first_writer[o] != 0));
         p->last_launches++;
+        o = last;
     }
     return GST_OK;
 }

@@ -497,10 +497,116 @@ __global__ __launch_bounds__(256) void chain_rule_gemm_kernel(const double* __re
     }
 }
 
+// The same product for the big objects (a gate's K = D^2 element columns x its parameters; round 4).  Workgroup = 128 rows
+// x 80 columns (the 240 parameters of a two-qubit CPTPLND gate are three such tiles exactly), wavefront w = rows 32 w ..
+// 32 w + 31 as 2 x 5 accumulator tiles: 10 MFMAs per 7 LDS operand reads instead of 4 per 5.  k in chunks of 16 (28 KB of
+// LDS: five workgroups per CU).  Every wavefront stages ITS OWN 32 rows of A, so it knows whether the chunk is all zero
+// -- the element Jacobian's block of a gate none of its 8 circuits applies -- and skips the chunk's MFMAs (a fifth of
+// them on a GST design); the B chunk is shared.  Column tiles are the fastest grid index: the workgroups that re-read an
+// A tile run side by side and find it in L2.
+constexpr int C2_BK = 16;
+constexpr int C2_AS = C2_BK + 2;       // 36 dwords: 16 rows land on 16 distinct multiples of 4 banks, {kk, kk + 1} interleave
+constexpr int C2_BN = 80;
+__global__ __launch_bounds__(256, 3) void chain_rule_gemm2_kernel(const double* __restrict__ A, int64_t ldA, int64_t a_col0, int K,
+                                                               const double* __restrict__ B, int n,
+                                                               const int32_t* __restrict__ colmap, double* __restrict__ C,
+                                                               int64_t ldC, int64_t n_rows, const int overwrite)
+{
+    __shared__ double As[4 * 32 * C2_AS];
+    __shared__ double Bs[C2_BK * C2_BN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (n + C2_BN - 1) / C2_BN;
+    const int64_t R0 = ((int64_t)blockIdx.x / tiles_n) * 128;
+    const int c0 = (int)((int64_t)blockIdx.x % tiles_n) * C2_BN;
+    const int i = lane & 15, kk = lane >> 4;
+    d4_t acc[2][5];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int t = 0; t < 5; t++) acc[m][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    // loaders: A -- this wavefront's rows 32 wv + (lane >> 4) + 4 e, k = lane & 15 (four 128-byte row pieces per load);
+    // B -- element tid + 256 e of the 16 x 80 chunk
+    const double* a_src[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int64_t row = R0 + 32 * wv + kk + 4 * e;
+        a_src[e] = A + (row < n_rows ? row : n_rows - 1) * ldA + a_col0 + i;
+    }
+    int b_k[5], b_off[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) {
+        const int idx = tid + 256 * e;
+        b_k[e] = idx / C2_BN;
+        const int bc = idx - b_k[e] * C2_BN;
+        b_off[e] = (c0 + bc < n) ? c0 + bc : n - 1;
+    }
+    double av[8], bv[5];
+    auto fetch = [&](const int k0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) av[e] = (k0 + i < K) ? a_src[e][k0] : 0.0;
+#pragma unroll
+        for (int e = 0; e < 5; e++) bv[e] = (k0 + b_k[e] < K) ? B[(int64_t)(k0 + b_k[e]) * n + b_off[e]] : 0.0;
+    };
+    double* const my_as = As + wv * 32 * C2_AS;
+    bool any = false;
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += C2_BK) {
+        __syncthreads();                         // (the previous chunk has been consumed)
+        bool nzl = false;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { my_as[(kk + 4 * e) * C2_AS + i] = av[e]; nzl = nzl || av[e] != 0.0; }
+#pragma unroll
+        for (int e = 0; e < 5; e++) Bs[tid + 256 * e] = bv[e];
+        const bool nz = __ballot(nzl) != 0;      // wave-uniform: do this wavefront's 32 rows hold anything in this chunk?
+        __syncthreads();
+        if (k0 + C2_BK < K) fetch(k0 + C2_BK);   // the next chunk is in flight while this one is multiplied
+        if (nz) {
+            any = true;
+            const double* as = my_as + i * C2_AS + kk;
+            const double* bs = Bs + kk * C2_BN + i;
+#pragma unroll 1
+            for (int s = 0; s < C2_BK / 4; s++) {
+                const double a0 = as[4 * s], a1 = as[16 * C2_AS + 4 * s];
+#pragma unroll
+                for (int t = 0; t < 5; t++) {
+                    const double b = bs[4 * s * C2_BN + 16 * t];
+                    acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!any && !overwrite) return;              // (adding zeros)
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const int col = c0 + 16 * t + i;
+        const int32_t cc = col < n ? colmap[col] : -1;
+        if (cc < 0) continue;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t row = R0 + 32 * wv + 16 * m + kk + 4 * r;
+                if (row < n_rows) {
+                    double* c = C + row * ldC + cc;
+                    *c = overwrite ? acc[m][t][r] : *c + acc[m][t][r];
+                }
+            }
+    }
+}
+
 hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, int K, const double* B, int n, const int32_t* colmap,
                                   double* C, int64_t ldC, int64_t n_rows, hipStream_t s, bool overwrite)
 {
     if (n <= 0 || n_rows <= 0 || K <= 0) return hipSuccess;
+    if (K >= 64 && n >= 40 && n_rows >= 128) {
+        const int64_t blocks2 = ((n_rows + 127) / 128) * ((n + C2_BN - 1) / C2_BN);
+        if (blocks2 > 0x7fffffffLL) return hipErrorInvalidValue;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(chain_rule_gemm2_kernel, dim3((unsigned)blocks2), dim3(256), 0, s, A, ldA, a_col0, K, B, n, colmap, C, ldC, n_rows, overwrite ? 1 : 0);
+        return hipGetLastError();
+    }
     const int64_t blocks = ((n_rows + 63) / 64) * ((n + 63) / 64);       // workgroup = 64 rows x 64 columns
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     (void)hipGetLastError();
