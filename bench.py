@@ -609,9 +609,11 @@ def main():
             plan.memcpy_h2d(d_c, np.random.default_rng(1234 + rank).binomial(1000, np.clip(pb, 0.0, 1.0)).astype(np.float64))
             plan.memcpy_h2d(d_N, np.full(nE_local, 1000.0))
 
+            lm_mode = [mode]
+
             def lm_step():
                 plan.set_model(gates, rhos, effects)
-                plan.fill_dprobs_dev(d_out, nP_local, pidx, None, 1e-7, d_probs, mode)
+                plan.fill_dprobs_dev(d_out, nP_local, pidx, None, 1e-7, d_probs, lm_mode[0])
                 plan.objective_rows_dev("logl", d_probs, d_c, d_N, nE_local, d_ls, d_w, want_sum=False)
                 plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj, d_w)          # (scales the rows of J in place first)
                 plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_ls, d_jtf)
@@ -634,6 +636,21 @@ def main():
                        "note": "fill + Poisson-picture dlogl maps + J^T J (block-sparse split-K MFMA fp64 SYRK) + J^T f"
                                + (" + all-reduce of nP^2 + nP doubles between device buffers" if world > 1 else "")
                                + "; the Jacobian never leaves HBM; secondary figure, not `value`"}
+            if mode == _lib.DERIV_FD and not args.no_analytic:
+                # the same iteration with the exact Jacobian (what an optimizer that does not insist on the Map simulator's
+                # finite differences would run; the structural zeros of the re-used Jacobian stay resident under the scaling)
+                lm_mode[0] = _lib.DERIV_ANALYTIC
+                lm_step(); lm_step()
+                barrier_sync(plan)
+                tl = time.perf_counter()
+                for _ in range(n_lm):
+                    lm_step()
+                barrier_sync(plan)
+                t_lma = ctx.max_over_ranks(time.perf_counter() - tl) / n_lm
+                assert np.isfinite(plan.memcpy_d2h(np.empty(nP), d_jtf)).all()
+                lm_info["exact_jacobian_ms_per_step"] = 1e3 * t_lma
+                lm_info["exact_jacobian_zeros_resident"] = bool(plan.stats()["last_zeros_resident"])
+                lm_mode[0] = mode
         finally:
             for d in bufs:
                 plan.device_free(d)

@@ -357,13 +357,13 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         // Without the option (value 2, the default) the same holds for destinations the library can vouch for: memory from
         // gst_device_malloc and the plan's own staging buffer, whose every other writer reports to gst_track.cpp.
         const bool same_dest = p->ana_zero_out == (const void*)d_out && p->ana_zero_ld == ld && p->ana_zero_valid && request_was_cached;
-        const bool zero_form = D == 16 && !p->derivs_set && !p->want_cache_path;
+        const bool zero_form = D == 16 && (!p->derivs_set || p->jelem_call) && !p->want_cache_path;
         const size_t extent = jac_extent(nE_total(p), ld, dest_idx, n_param);
-        const uint64_t sig = (p->uid * 0x9E3779B97F4A7C15ull) ^ (p->request_serial * 0xC2B2AE3D27D4EB4Full) ^ (uint64_t)ld;
+        const uint64_t sig = (p->uid * 0x9E3779B97F4A7C15ull) ^ ((p->jelem_call ? ~0ull : p->request_serial) * 0xC2B2AE3D27D4EB4Full) ^ (uint64_t)ld;
         bool claim = false;
         a.zeros_resident = 0; a.zeros_ok = nullptr;
         if (zero_form && p->ana_keep_zeros == 1) a.zeros_resident = same_dest ? 1 : 0;
-        else if (zero_form && p->ana_keep_zeros == 2 && (d_out == p->d_out.p || gst::track_owned(d_out, extent))) {
+        else if (zero_form && p->ana_keep_zeros == 2 && (d_out == p->d_out.p || d_out == p->d_jelem.p || gst::track_owned(d_out, extent))) {
             claim = true;
             if (const uint32_t* w = gst::track_claim_find(d_out, extent, sig)) { a.zeros_resident = 1; a.zeros_ok = w; }
         }
@@ -411,10 +411,14 @@ int run_element_jacobian(gst_plan* p, double* d_probs_out)
     }
     std::vector<int64_t> all((size_t)n_el);
     for (int64_t q = 0; q < n_el; q++) all[(size_t)q] = q;
+    if (p->d_jelem.p && (size_t)(nE * n_el) > p->d_jelem.n) gst::track_touch(p->d_jelem.p, p->d_jelem.n * 8);      // (about to be re-allocated)
     HIP_TRY(p->d_jelem.ensure((size_t)std::max<int64_t>(nE * n_el, 1)));
     p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
     p->cached_kind = 0;
+    // (the scratch is written by this call only and always with the same column map: its structural zeros stay resident)
+    p->jelem_call = true;
     int rc = run_dprobs_analytic(p, p->d_jelem.p, n_el, all.data(), nullptr, n_el, d_probs_out);
+    p->jelem_call = false;
     p->pkind.swap(ek); p->pobj.swap(eo); p->pelem.swap(ee);
     p->cached_kind = 0;
     return rc;

@@ -149,6 +149,7 @@ struct gst_plan {
     uint64_t uid = 0;                   // process-unique plan number, request_serial: bumped when the analytic column tables are
     uint64_t request_serial = 0;        // rebuilt -- (uid, serial, ld) is the signature of a Jacobian's zero pattern
     bool last_zeros_resident = false;
+    bool jelem_call = false;            // run_element_jacobian is filling its scratch (general parameterisations)
     const void* ana_zero_out = nullptr; // destination of the last stream-form analytic Jacobian, its leading dimension
     int64_t ana_zero_ld = 0;
     bool ana_zero_valid = false;
@@ -295,6 +296,7 @@ struct gst_plan {
         if (!dev_ready) return;
         (void)hipSetDevice(device);
         if (d_out.p) gst::track_touch(d_out.p, d_out.n * 8);
+        if (d_jelem.p) gst::track_touch(d_jelem.p, d_jelem.n * 8);
         d_lb_i32.release(); d_lb_i64.release(); d_lb_setparam.release(); d_lb_statics.release(); d_lb_term_re.release();
         d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release(); d_jtj_pmask.release(); for (auto& b : d_lbr_lane) b.release(); d_lbr_order.release();
         d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release();

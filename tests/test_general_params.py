@@ -324,3 +324,54 @@ def test_gpu_implicit_3q_model_exact_jacobian():
     assert np.abs(Ja - fx["matrix_by_circuit_dprobs"][rows]).max() < 1e-8
     p = np.empty(nE); sim._bulk_fill_probs_atom(p, atom, None)
     assert np.abs(p - fx["probs"]).max() < 1e-10
+
+
+@pytest.mark.gpu
+def test_gpu_chain_rule_with_ragged_objects():
+    """The chain-rule products (gst_kernels_normal.hip: 128 x 80 tiles for the big objects, 64 x 64 for the small ones) at
+    shapes no reference parameterisation has: parameter counts that are no multiple of a tile (97, 41, 240 + 1), a row
+    count that is no multiple of 128, four effects sharing their parameters (stacked into one product), a gate with no
+    parameters at all, and a shared parameter between two gates (the second object ADDS).  Expected: the same plan's
+    element Jacobian (pinned against the Matrix simulator elsewhere) times the derivative matrices, in numpy."""
+    from pygsti_amd import _lib
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    pl = plan_from_fixture(fx)
+    nE, D = int(fx["nE"]), 16
+    nG, nEf = fx["gates"].shape[0], fx["effects"].shape[0]
+    Jp = pl.fill_dprobs(param_idx=np.arange(int(fx["nP"])), mode=_lib.DERIV_ANALYTIC)
+    # ... re-ordered into the element layout [rho | effects | gates] whatever the fixture's parameter order is
+    pk, po, pe = (np.asarray(fx[k]) for k in ("pkind", "pobj", "pelem"))
+    col = np.where(pk == 1, pe, np.where(pk == 2, D + po * D + pe, D + nEf * D + po * D * D + pe))
+    Jel = np.zeros((nE, D + nEf * D + nG * D * D))
+    Jel[:, col[pk >= 0]] = Jp[:, pk >= 0]
+    rng = np.random.default_rng(11)
+    sizes = {"g0": 97, "g1": 41, "g2": 241, "rho": 5, "povm": 23}
+    off, p = {}, 0
+    for k, n in sizes.items():
+        off[k] = p; p += n
+    nP = p
+    objs, expected = [], np.zeros((nE, nP))
+    base_rho, base_eff, base_gate = 0, D, D + nEf * D
+
+    def add(kind, obj, pidx, W, a0):
+        objs.append((kind, obj, np.asarray(pidx, np.int64), W))
+        expected[:, pidx] += Jel[:, a0:a0 + W.shape[0]] @ W
+    for gi, key in enumerate(("g0", "g1", "g2")):
+        W = rng.standard_normal((D * D, sizes[key]))
+        W[rng.random(W.shape) < 0.5] = 0.0
+        add(0, gi, off[key] + np.arange(sizes[key]), W, base_gate + gi * D * D)
+    # gate 4 shares the first 30 parameters of g0 (later object: adds); gate 3 has no parameters
+    add(0, 4, off["g0"] + np.arange(30), rng.standard_normal((D * D, 30)), base_gate + 4 * D * D)
+    add(1, 0, off["rho"] + np.arange(sizes["rho"]), rng.standard_normal((D, sizes["rho"])), base_rho)
+    for e in range(nEf):
+        add(2, e, off["povm"] + np.arange(sizes["povm"]), rng.standard_normal((D, sizes["povm"])), base_eff + e * D)
+    pl.set_derivs(nP, objs)
+    J = pl.fill_dprobs(param_idx=np.arange(nP), mode=_lib.DERIV_ANALYTIC)
+    scale = np.abs(expected).max()
+    assert scale > 1.0 and np.abs(J - expected).max() < 1e-12 * scale, np.abs(J - expected).max()
+    # a scattered column request into a wider destination
+    sub = np.array([off["g2"] + 240, off["g0"] + 3, off["povm"] + 22, off["g1"] + 40, off["g0"] + 96])
+    out = np.full((nE, 9), -3.0)
+    pl.fill_dprobs(out=out, param_idx=sub, dest_idx=np.array([7, 0, 3, 5, 2]), mode=_lib.DERIV_ANALYTIC)
+    assert np.abs(out[:, [7, 0, 3, 5, 2]] - expected[:, sub]).max() < 1e-12 * scale
+    assert (out[:, [1, 4, 6, 8]] == -3.0).all()
