@@ -424,6 +424,28 @@ int run_element_jacobian(gst_plan* p, double* d_probs_out)
     return rc;
 }
 
+// Which rows of the element Jacobian can be non-zero in which gate's columns: bit g of word r <=> some circuit with an
+// outcome among rows 32 r .. 32 r + 31 applies gate g (the chain-rule product skips the rest: launch_chain_rule_gemm).
+// Built once per plan from the expanded circuits; padded to whole 128-row workgroup tiles.
+int ensure_rowmask(gst_plan* p)
+{
+    if (p->rowmask_built) return GST_OK;
+    p->rowmask_built = true;
+    const gst::HostPlan& h = p->hp;
+    if (h.n_gates > 64 || h.circ_ptr.size() != (size_t)h.n_circuits + 1 || h.eff_ptr.size() != (size_t)h.n_circuits + 1) return GST_OK;
+    std::vector<uint64_t> mask((size_t)((h.n_elements + 127) / 128) * 4, 0);
+    for (int64_t c = 0; c < h.n_circuits; c++) {
+        uint64_t gs = 0;
+        for (int64_t k = h.circ_ptr[(size_t)c]; k < h.circ_ptr[(size_t)c + 1]; k++) gs |= 1ull << h.circ_gates[(size_t)k];
+        for (int32_t x = h.eff_ptr[(size_t)c]; x < h.eff_ptr[(size_t)c + 1]; x++) mask[(size_t)(h.eff_dest[(size_t)x] >> 5)] |= gs;
+    }
+    HIP_TRY(p->d_rowmask.ensure(mask.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_rowmask.p, mask.data(), mask.size() * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->rowmask_ok = true;
+    return GST_OK;
+}
+
 // GST_DERIV_ANALYTIC with gst_set_derivs: element Jacobian (the `full` layout [rhos | effects | gates]) into scratch,
 // then one MFMA chain-rule product per object, accumulated into the requested parameter columns.
 int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
@@ -481,6 +503,7 @@ int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* pa
     for (size_t c = 0; c < colmap.size(); c++) colmap[c] = dest_of[(size_t)p->dv_param_idx[c]];
     if (!colmap.empty()) HIP_TRY(hipMemcpyAsync(p->d_dv_colmap.p, colmap.data(), colmap.size() * 4, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));          // `colmap` goes out of scope
+    if ((rc = ensure_rowmask(p))) return rc;
     for (size_t o = 0; o < p->dv_kind.size(); o++) {
         const int k = p->dv_kind[o];
         int K = k == GST_KIND_GATE ? D * D : D;
@@ -496,7 +519,8 @@ int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* pa
             last++;
         K *= (int)(last - o + 1);
         HIP_TRY(gst::launch_chain_rule_gemm(p->d_jelem.p, n_el, a0, K, p->d_dv_deriv.p + p->dv_off_deriv[o], p->dv_ncols[o],
-                                            p->d_dv_colmap.p + p->dv_off_cols[o], d_out, ld, nE, p->stream, first_writer[o] != 0));
+                                            p->d_dv_colmap.p + p->dv_off_cols[o], d_out, ld, nE, p->stream, first_writer[o] != 0,
+                                            (k == GST_KIND_GATE && last == o && p->rowmask_ok) ? p->d_rowmask.p : nullptr, p->dv_obj[o]));
         p->last_launches++;
         o = last;
     }

@@ -199,7 +199,8 @@ hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_co
 
 // C[:, colmap[j]] += A[:, a_col0 : a_col0 + K] . B[:, j]  (B row-major [K][n]; colmap[j] < 0: skip) -- MFMA fp64
 hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, int K, const double* B, int n, const int32_t* colmap,
-                                  double* C, int64_t ldC, int64_t n_rows, hipStream_t s, bool overwrite = false);
+                                  double* C, int64_t ldC, int64_t n_rows, hipStream_t s, bool overwrite = false,
+                                  const uint64_t* rowmask = nullptr, int mask_bit = 0);      // rowmask: [ceil(n_rows / 128) * 4] words, see the kernel
 
 // Derivative states for the analytic Hessian (gst_kernels_analytic.hip): lane group q of a wavefront carries
 //   dS^{theta_q}: dS_0 = start (a unit vector or 0);  dS_k = G_k dS_{k-1} + [g_k = inj_gate[q]] e_{inj_dst[q]} * S_{k-1}[inj_src[q]]

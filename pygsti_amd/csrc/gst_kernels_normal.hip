@@ -510,7 +510,8 @@ constexpr int C2_BN = 80;
 __global__ __launch_bounds__(256, 3) void chain_rule_gemm2_kernel(const double* __restrict__ A, int64_t ldA, int64_t a_col0, int K,
                                                                const double* __restrict__ B, int n,
                                                                const int32_t* __restrict__ colmap, double* __restrict__ C,
-                                                               int64_t ldC, int64_t n_rows, const int overwrite)
+                                                               int64_t ldC, int64_t n_rows, const int overwrite,
+                                                               const uint64_t* __restrict__ rowmask, const int mask_bit)
 {
     __shared__ double As[4 * 32 * C2_AS];
     __shared__ double Bs[C2_BK * C2_BN];
@@ -520,6 +521,29 @@ __global__ __launch_bounds__(256, 3) void chain_rule_gemm2_kernel(const double* 
     const int64_t R0 = ((int64_t)blockIdx.x / tiles_n) * 128;
     const int c0 = (int)((int64_t)blockIdx.x % tiles_n) * C2_BN;
     const int i = lane & 15, kk = lane >> 4;
+    // rowmask (optional, from the plan's structure): bit g of word r says whether any of rows 32 r .. 32 r + 31 can be
+    // non-zero in gate g's element columns (some circuit of those rows applies g).  A wavefront whose 32 rows cannot
+    // does not even load them; a workgroup none of whose wavefronts can stores its zeros and leaves.
+    bool live = true;
+    if (rowmask) {
+        const uint64_t* m = rowmask + (R0 >> 5);
+        live = ((m[wv] >> mask_bit) & 1ull) != 0;
+        if ((((m[0] | m[1] | m[2] | m[3]) >> mask_bit) & 1ull) == 0) {
+            if (!overwrite) return;
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const int col = c0 + 16 * t + i;
+                const int32_t cc = col < n ? colmap[col] : -1;
+                if (cc < 0) continue;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int64_t row = R0 + 32 * wv + kk + 4 * r;
+                    if (row < n_rows) C[row * ldC + cc] = 0.0;
+                }
+            }
+            return;
+        }
+    }
     d4_t acc[2][5];
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -544,7 +568,7 @@ __global__ __launch_bounds__(256, 3) void chain_rule_gemm2_kernel(const double* 
     double av[8], bv[5];
     auto fetch = [&](const int k0) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) av[e] = (k0 + i < K) ? a_src[e][k0] : 0.0;
+        for (int e = 0; e < 8; e++) av[e] = (live && k0 + i < K) ? a_src[e][k0] : 0.0;
 #pragma unroll
         for (int e = 0; e < 5; e++) bv[e] = (k0 + b_k[e] < K) ? B[(int64_t)(k0 + b_k[e]) * n + b_off[e]] : 0.0;
     };
@@ -597,14 +621,15 @@ __global__ __launch_bounds__(256, 3) void chain_rule_gemm2_kernel(const double* 
 }
 
 hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, int K, const double* B, int n, const int32_t* colmap,
-                                  double* C, int64_t ldC, int64_t n_rows, hipStream_t s, bool overwrite)
+                                  double* C, int64_t ldC, int64_t n_rows, hipStream_t s, bool overwrite, const uint64_t* rowmask, int mask_bit)
 {
     if (n <= 0 || n_rows <= 0 || K <= 0) return hipSuccess;
     if (K >= 64 && n >= 40 && n_rows >= 128) {
         const int64_t blocks2 = ((n_rows + 127) / 128) * ((n + C2_BN - 1) / C2_BN);
         if (blocks2 > 0x7fffffffLL) return hipErrorInvalidValue;
         (void)hipGetLastError();
-        hipLaunchKernelGGL(chain_rule_gemm2_kernel, dim3((unsigned)blocks2), dim3(256), 0, s, A, ldA, a_col0, K, B, n, colmap, C, ldC, n_rows, overwrite ? 1 : 0);
+        hipLaunchKernelGGL(chain_rule_gemm2_kernel, dim3((unsigned)blocks2), dim3(256), 0, s, A, ldA, a_col0, K, B, n, colmap, C, ldC, n_rows, overwrite ? 1 : 0,
+                           rowmask, mask_bit);
         return hipGetLastError();
     }
     const int64_t blocks = ((n_rows + 63) / 64) * ((n + 63) / 64);       // workgroup = 64 rows x 64 columns

@@ -149,6 +149,8 @@ struct gst_plan {
     uint64_t uid = 0;                   // process-unique plan number, request_serial: bumped when the analytic column tables are
     uint64_t request_serial = 0;        // rebuilt -- (uid, serial, ld) is the signature of a Jacobian's zero pattern
     bool last_zeros_resident = false;
+    DevBuf<uint64_t> d_rowmask;         // ensure_rowmask: rows x gates that can be non-zero in the element Jacobian
+    bool rowmask_built = false, rowmask_ok = false;
     bool jelem_call = false;            // run_element_jacobian is filling its scratch (general parameterisations)
     const void* ana_zero_out = nullptr; // destination of the last stream-form analytic Jacobian, its leading dimension
     int64_t ana_zero_ld = 0;
@@ -306,7 +308,7 @@ struct gst_plan {
         d_pair_common.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release();
         d_blk_f1.release(); d_blk_f2.release(); d_blk_r.release(); d_blk_ptr.release();
         d_dv_deriv.release(); d_dv2.release(); d_helem.release(); d_hw.release(); d_hcsc.release();
-        d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release();
+        d_rowmask.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release();
         d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release();
         d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release();
         d_eff_label.release(); d_eff_dest.release();
