@@ -145,7 +145,7 @@ int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *op
  *          option changed) writes everything.
  *       0: every fill stores every entry. */
 #define GST_OPT_ANALYTIC_KEEP_ZEROS 1
-/*   GST_OPT_FAST_CHAINS (value 0 / 1 / 2; D = 16): how the modes WITHOUT an ordering contract -- GST_DERIV_ANALYTIC, and
+/*   GST_OPT_FAST_CHAINS (value 0 / 1 / 2; D = 16 and 64): how the modes WITHOUT an ordering contract -- GST_DERIV_ANALYTIC, and
  *       gst_fill_probs* under GST_OPT_FAST_PROBS -- obtain the states of the circuit tries.  The sequential walk applies a
  *       GST family's ~1,150 gates one after another (0.5 ms of latency on any hardware; it IS the finite-difference mode's
  *       bit-parity contract and stays there).  The level pass finds the periodic (germ-power) paths of the tries, forms the
@@ -153,8 +153,11 @@ int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *op
  *       reference's Matrix simulator multiplies sub-products over an eval tree for the same reason, matrixforwardsim.py:
  *       675-727, evaltree.py:31-189).  Results differ from the walk's by re-association only (<= 1e-13 observed at depth
  *       1,030; the mode's bars are 1e-10 for probabilities, 1e-8 for derivatives).  1 (default): where the stages are few
- *       against the chains; 0: never; 2: whenever a level program exists (tests).
- *   GST_OPT_FAST_PROBS (value 0 / 1; default 0): gst_fill_probs / gst_fill_probs_dev through the level pass: probabilities
+ *       against the chains; 0: never; 2: whenever a level program exists (tests).  D = 64 has no level programs: any
+ *       non-zero value sends these modes' walks to the matrix cores instead (one workgroup per task, the state a
+ *       [start vectors][64] row block, gst_kernels_chain64.hip), again equal up to re-association; 0 keeps the row kernel.
+ *   GST_OPT_FAST_PROBS (value 0 / 1; default 0): gst_fill_probs / gst_fill_probs_dev through the level pass (D = 16) or the
+ *       matrix-core walk (D = 64): probabilities
  *       within 1e-10 of the reference's, NOT bit-identical -- for callers (line searches of an optimizer) that do not
  *       difference them.  Finite-difference fills never use it. */
 #define GST_OPT_FAST_CHAINS 2

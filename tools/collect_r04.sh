@@ -9,7 +9,7 @@ timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 Q="--no-cpu-baseline --no-host-fill --no-other-configs --no-cptplnd"
 timeout 200 python bench.py $Q --jtj > $OUT/bench_jtj.json 2> $OUT/bench_jtj.err
 timeout 200 python bench.py $Q --deriv analytic --steps 10 --warmup 3 > $OUT/bench_analytic.json 2>/dev/null
-timeout 200 python bench.py $Q --deriv analytic --keep-zeros --steps 10 --warmup 3 > $OUT/bench_analytic_keepzeros.json 2>/dev/null
+timeout 200 python bench.py $Q --deriv analytic --store-zeros --steps 10 --warmup 3 > $OUT/bench_analytic_storezeros.json 2>/dev/null
 N=8 bash tools/emulate_all_ranks.sh > $OUT/emulate_all_ranks.txt 2>&1
 timeout 300 python bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/two_ranks_one_gpu.json 2> $OUT/two_ranks_one_gpu.err
 timeout 200 python tools/level_timing.py > $OUT/level_timing.txt 2>&1
@@ -19,6 +19,7 @@ timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/fd_stats -o s -- $B 
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/an_stats -o s -- $B --steps 5 --warmup 2 --deriv analytic > $OUT/an_stats.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/lv_stats -o s -- python $R/tools/level_timing.py > $OUT/lv_stats.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/cfg_stats -o s -- python $R/tools/bench_configs.py > $OUT/cfg_stats.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/lb_stats -o s -- python $R/tools/lb_analytic_profile.py > $OUT/lb_stats.log 2>&1
 for mode in fd analytic; do
   X="--no-analytic"; [ $mode = analytic ] && X=""
   for c in FETCH_SIZE WRITE_SIZE; do

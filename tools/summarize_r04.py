@@ -34,7 +34,7 @@ def dst(name):
     return os.path.join(DST, TAG + "_" + name)
 
 
-for d, name in (("fd_stats", "bench_fd"), ("an_stats", "bench_analytic"), ("lv_stats", "level_passes"), ("cfg_stats", "other_configs")):
+for d, name in (("fd_stats", "bench_fd"), ("an_stats", "bench_analytic"), ("lv_stats", "level_passes"), ("cfg_stats", "other_configs"), ("lb_stats", "cptplnd_exact")):
     g = glob.glob(os.path.join(SRC, d, "**", "*kernel_stats.csv"), recursive=True)
     if g:
         shutil.copy(g[0], dst(name + "_kernel_stats.csv"))
@@ -56,7 +56,7 @@ sq = {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in counters("pmc_fd_s
 json.dump({"fd": sq}, open(dst("bench_pmc_sq_current.json"), "w"), indent=1)
 
 for f, name in (("bench.json", "bench.json"), ("bench_jtj.json", "bench_jtj.json"), ("bench_analytic.json", "bench_analytic.json"),
-                ("bench_analytic_keepzeros.json", "bench_analytic_keepzeros.json"), ("two_ranks_one_gpu.json", "two_ranks_one_gpu.json")):
+                ("bench_analytic_storezeros.json", "bench_analytic_storezeros.json"), ("two_ranks_one_gpu.json", "two_ranks_one_gpu.json")):
     b = last_json(os.path.join(SRC, f))
     if b:
         json.dump(b, open(dst(name), "w"), indent=1)
@@ -77,7 +77,7 @@ if ranks and head:
                "projected_speedup_at_%d_gpus" % ranks[0]["of"]: head["ms_per_step"] / slow,
                "note": "one GPU runs each rank's 1/N atom in turn (bench.py --emulate-ranks N --emulate-rank r); the N-GPU fill step is the "
                        "slowest rank's; NOT a multi-GPU measurement"}, open(dst("emulate_all_ranks.json"), "w"), indent=1)
-for f in ("level_timing.txt",):
+for f in ("level_timing.txt", "lb_stats.log", "pytest_final.txt"):
     try:
         shutil.copy(os.path.join(SRC, f), dst(f))
     except OSError:
