@@ -327,7 +327,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
             ra.bmats = p->d_gates.p; ra.starts = p->d_effects.p; ra.cache = p->d_rev_cache.p;
             HIP_TRY(gst::launch_level_pass(ra, p->rev.n_tasks(), p->stream2));
             p->last_launches++;
-        } else if (D == 64 && p->fast_chains) {                // all effects of a task as one row block on the matrix cores
+        } else if (D == 64 && p->fast_chains && gst::chain64_fits(std::min(16, h.n_effects), p->rev.max_slots)) {      // all effects of a task as one row block on the matrix cores
             for (int e0 = 0; e0 < h.n_effects; e0 += 16) {
                 w.start0 = e0;
                 HIP_TRY(gst::launch_chain64(w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));

@@ -35,7 +35,7 @@ int run_probs(gst_plan* p, double* d_dst, bool fill_cache, int chain_share, cons
         a.base_cache_w = p->d_base_cache.p;
     }
     a.rows_S = 0;
-    if (reassoc && p->hp.D == 64 && p->fast_chains && !guard) {
+    if (reassoc && p->hp.D == 64 && p->fast_chains && !guard && gst::chain64_fits(1, p->hp.max_slots)) {
         HIP_TRY(gst::launch_chain64(a, p->hp.n_tasks(), p->hp.max_slots, p->stream));
         p->last_levels = true;
     } else HIP_TRY(gst::launch_walk_rows(p->hp.D, a, p->hp.n_tasks(), p->hp.max_slots, p->stream));

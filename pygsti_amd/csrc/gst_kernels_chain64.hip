@@ -155,6 +155,12 @@ __global__ __launch_bounds__(256) void chain64_mfma_kernel(const WalkArgs a, con
 
 }  // namespace
 
+// LDS the walk needs for `nv` start vectors and `n_slots` save slots; plans beyond a CU's LDS keep the row kernel.
+bool chain64_fits(int nv, int n_slots)
+{
+    return ((size_t)2 * 16 * C64_XS + (size_t)(n_slots > 0 ? n_slots : 1) * nv * C64_D) * sizeof(double) <= 156 * 1024;
+}
+
 // The S = 0 walk of a D = 64 plan on the matrix cores: same arguments as launch_walk_rows (rows_S = 0, EMIT_PROBS); with
 // a.multi_start > 0 one launch covers start vectors a.start0 .. min(a.start0 + 16, a.multi_start) - 1.
 hipError_t launch_chain64(const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream)
