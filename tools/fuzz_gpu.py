@@ -60,6 +60,67 @@ for k in range(n_cases):
             Ha = pl.fill_hprobs(idx1=i1[:3], idx2=i2[:12], mode=_lib.DERIV_ANALYTIC)
             Ho = O.analytic_hprobs(fx, i1[:3], i2[:12])
             assert np.abs(Ha - Ho).max() <= 1e-8 * max(1.0, np.abs(Ho).max()), "analytic hprobs"
+        # --- round 4: the modes without an ordering contract and the bookkeeping around them ---------------------------
+        if a["nE"] > 0:
+            nE = a["nE"]
+            allc = np.arange(nP)
+            exact = pl.fill_probs()
+            # fast probabilities (level passes forced at D = 16, the matrix-core walk at D = 64): <= 1e-10
+            pl.set_option(_lib.OPT_FAST_PROBS, 1); pl.set_option(_lib.OPT_FAST_CHAINS, 2)
+            fast = pl.fill_probs()
+            # (the random models are not contractive: values grow with depth, so the bars are relative to the largest one)
+            pscale = max(1.0, np.abs(exact).max())
+            assert np.abs(fast - exact).max() <= 1e-10 * pscale, "fast probs %g (scale %g)" % (np.abs(fast - exact).max(), pscale)
+            Jl = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+            assert np.abs(Jl - Jo).max() <= 1e-8 * max(1.0, np.abs(Jo).max()), "analytic dprobs through the level / matrix-core passes"
+            pl.set_option(_lib.OPT_FAST_PROBS, 0); pl.set_option(_lib.OPT_FAST_CHAINS, 1)
+            # resident zeros on tracked memory: repeated exact fills, a finite-difference fill and a new model in between
+            if nP * nE <= 4_000_000:
+                Jfull = pl.fill_dprobs(param_idx=allc, mode=_lib.DERIV_ANALYTIC)
+                d = pl.device_malloc(nE * nP * 8)
+                pl.memcpy_h2d(d, np.full(nE * nP, np.nan))
+                for rep in range(3):
+                    pl.fill_dprobs_dev(d, nP, allc, None, 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
+                    assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), d), Jfull), "repeated exact fill %d" % rep
+                pl.fill_dprobs_dev(d, nP, allc, None, 1e-7, None, _lib.DERIV_FD); pl.sync()
+                pl.fill_dprobs_dev(d, nP, allc, None, 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
+                assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), d), Jfull), "exact fill after an FD fill into the same memory"
+                g2 = mdl["gates"] + 1e-3 * rng.standard_normal(mdl["gates"].shape)
+                pl.set_model(g2, mdl["rhos"], mdl["effects"])
+                J2 = pl.fill_dprobs(param_idx=allc, mode=_lib.DERIV_ANALYTIC)
+                pl.fill_dprobs_dev(d, nP, allc, None, 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
+                assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), d), J2), "exact fill (resident zeros) after a model change"
+                pl.set_model(mdl["gates"], mdl["rhos"], mdl["effects"])
+                pl.device_free(d)
+                # a random general parameterisation over the element Jacobian (chain-rule products of both tilings)
+                if D <= 16:
+                    # the whole element Jacobian [rhos | effects | gates] through an identity parameter map
+                    nR_, nEl_, nG_ = mdl["rhos"].shape[0], mdl["effects"].shape[0], mdl["gates"].shape[0]
+                    fk = np.concatenate([np.full(nR_ * D, 1), np.full(nEl_ * D, 2), np.full(nG_ * D * D, 0)]).astype(np.int32)
+                    fo = np.concatenate([np.repeat(np.arange(nR_), D), np.repeat(np.arange(nEl_), D), np.repeat(np.arange(nG_), D * D)]).astype(np.int32)
+                    fe = np.concatenate([np.tile(np.arange(D), nR_), np.tile(np.arange(D), nEl_), np.tile(np.arange(D * D), nG_)]).astype(np.int32)
+                    pl.set_param_map(fk, fo, fe)
+                    Jall = pl.fill_dprobs(param_idx=np.arange(len(fk)), mode=_lib.DERIV_ANALYTIC)
+                    objs, nQ, exp_cols, exp_abs = [], 0, [], []
+                    for kind, n_obj in ((0, nG_), (1, nR_), (2, nEl_)):
+                        for o in range(n_obj):
+                            if rng.random() < 0.2:
+                                continue                        # an object without parameters
+                            Jel = Jall[:, (fk == kind) & (fo == o)]
+                            nq = int(rng.choice([1, 7, 45, 97]))
+                            W = rng.standard_normal((Jel.shape[1], nq))
+                            objs.append((kind, int(o), nQ + np.arange(nq), W)); exp_cols.append(Jel @ W); exp_abs.append(np.abs(Jel) @ np.abs(W)); nQ += nq
+                    if not objs:
+                        objs.append((1, 0, np.arange(3), np.zeros((D, 3)))); exp_cols.append(np.zeros((nE, 3))); exp_abs.append(np.zeros((nE, 3))); nQ = 3
+                    pl.set_derivs(nQ, objs)
+                    Jg = pl.fill_dprobs(param_idx=np.arange(nQ), mode=_lib.DERIV_ANALYTIC)
+                    Je = np.concatenate(exp_cols, axis=1)
+                    cscale = max(1.0, np.concatenate(exp_abs, axis=1).max())
+                    assert np.abs(Jg - Je).max() <= 1e-12 * cscale, "chain rule %g (scale %g)" % (np.abs(Jg - Je).max(), cscale)
+                    Jg2 = pl.fill_dprobs(param_idx=np.arange(nQ), mode=_lib.DERIV_ANALYTIC)
+                    assert np.array_equal(Jg, Jg2), "chain rule (repeat)"
+                    pl.set_derivs(nP, [])
+                    pl.set_param_map(mdl["pkind"], mdl["pobj"], mdl["pelem"])
         pl.close()
     except Exception as e:           # noqa
         bad += 1
