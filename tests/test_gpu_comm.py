@@ -66,7 +66,7 @@ def _run_job(tmp_path, n_ranks, transport, n_atoms, distinct=False):
     return [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(n_ranks)]
 
 
-@pytest.mark.parametrize("n_ranks,n_atoms,transport", [(2, 2, "ipc"), (2, 4, "ipc"), (3, 5, "ipc"), (2, 2, "auto")])
+@pytest.mark.parametrize("n_ranks,n_atoms,transport", [(2, 2, "ipc"), (2, 4, "ipc"), (3, 5, "ipc"), (8, 8, "ipc"), (2, 2, "auto")])
 def test_ranks_sharing_one_gpu_assemble_the_reference_jacobian_bitwise(tmp_path, n_ranks, n_atoms, transport):
     fx = load_fixture("smq2Q_XYICNOT_L2_depol")
     res = _run_job(tmp_path, n_ranks, transport, n_atoms)
