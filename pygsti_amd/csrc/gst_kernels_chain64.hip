@@ -42,6 +42,14 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
+// VEC: a single start vector (the forward pass).  A 16-row MFMA tile would carry one live row -- and MI355X runs fp64 MFMA at
+// the VALU's rate, so the padding is not free (1,024 matrix-pipe cycles per step and wavefront).  Instead thread
+// (column 16 w + (l & 15), k-quarter l >> 4) sums its 16 products and the four quarters meet in two shuffles: 32 VALU
+// instructions per step, the same coalesced 128-byte row segments of M.  (Measured: 0.48 -> 0.29 ms for depth-256 circuits.
+// What a step costs now is its own dependent chain -- LDS read, 16 ordered adds, two cross-lane steps, LDS write, barrier:
+// ~0.5 us -- plus what of the next gate's trip to L2 the step does not cover; operands two gates ahead in rotating
+// register sets changed nothing.)
+template <bool VEC>
 __global__ __launch_bounds__(256) void chain64_mfma_kernel(const WalkArgs a, const int n_slots)
 {
     constexpr int D = C64_D, XS = C64_XS;
@@ -79,10 +87,11 @@ __global__ __launch_bounds__(256) void chain64_mfma_kernel(const WalkArgs a, con
         op = GST_OP(w_); arg = GST_ARG(w_); pc++;                                                     \
     } while (0)
     // B operand of gate g for this wavefront's 16 columns: b[s] = M[4 s + lk][16 w + lr]
+    // (VEC: b[s] = M[16 lk + s][16 w + lr])
 #define C64_LOADB(dst, g_)                                                                            \
     do {                                                                                              \
-        const double* M_ = a.gates_t + (int64_t)(g_) * D * D + lk * D + 16 * w + lr;                  \
-        _Pragma("unroll") for (int s = 0; s < 16; s++) dst[s] = M_[s * 4 * D];                        \
+        const double* M_ = a.gates_t + (int64_t)(g_) * D * D + (VEC ? 16 * lk : lk) * D + 16 * w + lr; \
+        _Pragma("unroll") for (int s = 0; s < 16; s++) dst[s] = M_[s * (VEC ? 1 : 4) * D];           \
     } while (0)
 
     C64_FETCH();
@@ -97,6 +106,25 @@ __global__ __launch_bounds__(256) void chain64_mfma_kernel(const WalkArgs a, con
                 C64_FETCH();                                           // what follows
                 const bool more = (op == GST_OP_APPLY);
                 if (more) C64_LOADB(bn, arg);
+                if constexpr (VEC) {
+                    const double* xq = X + 16 * lk;                    // (row 0; the same address in all 16 lanes of a quarter)
+                    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;     // four independent partial sums: shorter dependent chain
+#pragma unroll
+                    for (int s = 0; s < 16; s += 4) { p0 += xq[s] * b[s]; p1 += xq[s + 1] * b[s + 1]; p2 += xq[s + 2] * b[s + 2]; p3 += xq[s + 3] * b[s + 3]; }
+                    double part = (p0 + p1) + (p2 + p3);
+                    part += __shfl_xor(part, 16, 64);
+                    part += __shfl_xor(part, 32, 64);
+                    if (lk == 0) {
+                        Y[16 * w + lr] = part;
+                        if (a.base_cache_w) a.base_cache_w[(int64_t)node_id * cstride + coff + 16 * w + lr] = part;
+                    }
+                    lds_barrier();
+                    { double* t = X; X = Y; Y = t; }
+                    if (!more) break;
+#pragma unroll
+                    for (int s = 0; s < 16; s++) b[s] = bn[s];
+                    continue;
+                }
                 d4_t acc = {0.0, 0.0, 0.0, 0.0};
                 const double* xa = X + lr * XS + lk;
                 double xr[16];                                         // all 16 LDS reads in flight before the first MFMA
@@ -172,10 +200,12 @@ hipError_t launch_chain64(const WalkArgs& a, int64_t n_tasks, int n_slots, hipSt
     (void)hipGetLastError();
     if (lds_bytes > 64 * 1024) {
         if (lds_bytes > 156 * 1024) return hipErrorInvalidValue;
-        hipError_t e = hipFuncSetAttribute((const void*)chain64_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = nv == 1 ? hipFuncSetAttribute((const void*)chain64_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+                               : hipFuncSetAttribute((const void*)chain64_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(chain64_mfma_kernel, dim3((unsigned)n_tasks), dim3(256), lds_bytes, stream, a, n_slots);
+    if (nv == 1) hipLaunchKernelGGL(chain64_mfma_kernel<true>, dim3((unsigned)n_tasks), dim3(256), lds_bytes, stream, a, n_slots);
+    else hipLaunchKernelGGL(chain64_mfma_kernel<false>, dim3((unsigned)n_tasks), dim3(256), lds_bytes, stream, a, n_slots);
     return hipGetLastError();
 }
 

@@ -121,6 +121,12 @@ def three_q(n_circ=400, max_len=256, n_cols=4096):
     plan.set_model(gates, rhos, effects); plan.set_param_map(kind, obj, elem)
     d_p = plan.device_malloc(nE * 8)
     t_p = timed(lambda: plan.fill_probs_dev(d_p), plan, 20)
+    exact_p = plan.memcpy_d2h(np.empty(nE), d_p)
+    plan.set_option(_lib.OPT_FAST_PROBS, 1)                       # (the walk on the matrix cores: <= 1e-10, not bit-identical)
+    t_pf = timed(lambda: plan.fill_probs_dev(d_p), plan, 20)
+    fast_err = float(np.abs(plan.memcpy_d2h(np.empty(nE), d_p) - exact_p).max() / max(1.0, np.abs(exact_p).max()))
+    plan.set_option(_lib.OPT_FAST_PROBS, 0)
+    plan.fill_probs_dev(d_p); plan.sync()
     cols = np.arange(576, 576 + n_cols, dtype=np.int64)          # one whole gate's parameters (64 x 64)
     d_J = plan.device_malloc(nE * n_cols * 8)
     t_fd = timed(lambda: plan.fill_dprobs_dev(d_J, n_cols, cols, None, 1e-7, d_p, _lib.DERIV_FD), plan, 2)
@@ -146,6 +152,7 @@ def three_q(n_circ=400, max_len=256, n_cols=4096):
     return {"roofline": roof, "config": "3-qubit explicit dense model (BASELINE configs[4] shape): D=64, 10 gates, 8 outcomes, nP=%d; %d seeded random circuits, "
                       "lengths 1..%d, nE=%d" % (nP, n_circ, max_len, nE),
             "probs_ms": 1e3 * t_p, "probs_per_s": nE / t_p,
+            "fast_probs_ms": 1e3 * t_pf, "fast_probs_max_diff_rel_to_largest": fast_err, "largest_abs_prob": float(np.abs(exact_p).max()),
             "dprobs_fd_cols": int(n_cols), "dprobs_fd_ms": 1e3 * t_fd, "dprobs_fd_el_per_s": nE * n_cols / t_fd,
             "dprobs_fd_TFLOPs_algorithmic": flops / t_fd / 1e12,
             "dprobs_analytic_same_block_ms": 1e3 * t_an, "dprobs_analytic_same_block_el_per_s": nE * n_cols / t_an,
