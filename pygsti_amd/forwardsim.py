@@ -85,14 +85,19 @@ class HipMapForwardSimulator:
         return s
 
     def _to_nice_serialization(self):
+        # (mapforwardsim.py:174-181 plus this class's own options: a simulator restored from a checkpoint must not
+        #  silently change its derivative mode)
         return {"module": type(self).__module__, "class": type(self).__name__,
                 "max_cache_size": self._max_cache_size, "derivative_epsilon": self.derivative_eps,
-                "hessian_epsilon": self.hessian_eps}
+                "hessian_epsilon": self.hessian_eps, "hip_derivative_mode": self.derivative_mode,
+                "hip_devices": None if self.devices is None else [int(d) for d in self.devices],
+                "hip_target_tasks": int(self.target_tasks)}
 
     @classmethod
     def _from_nice_serialization(cls, state):
         return cls(None, state.get("max_cache_size"), derivative_eps=state.get("derivative_epsilon", 1e-7),
-                   hessian_eps=state.get("hessian_epsilon", 1e-5))
+                   hessian_eps=state.get("hessian_epsilon", 1e-5), devices=state.get("hip_devices"),
+                   target_tasks=state.get("hip_target_tasks", 0), derivative_mode=state.get("hip_derivative_mode", "fd"))
 
     def __getstate__(self):
         st = self.__dict__.copy()

@@ -28,13 +28,18 @@ model-set Jacobians exactly as `_mapfill_hprobs_atom` composes them.  There is n
 import numpy as np
 
 from . import _lib
+from . import lmstep as _lm
 
 try:   # pyGSTi is optional: this module is importable (and useless) without it
     from pygsti.forwardsims.mapforwardsim import MapForwardSimulator as _MapForwardSimulator
+    from pygsti.layouts.maplayout import MapCOPALayout as _MapCOPALayout
+    from pygsti.objectivefns import objectivefns as _objfns
     from pygsti.tools import slicetools as _slct
     HAVE_PYGSTI = True
 except Exception:   # pragma: no cover - exercised only where pyGSTi is absent
     _MapForwardSimulator = object
+    _MapCOPALayout = object
+    _objfns = None
     _slct = None
     HAVE_PYGSTI = False
 
@@ -489,6 +494,7 @@ class AtomFillLogic:
 
     def _bulk_fill_dprobs_atom(self, array_to_fill, dest_param_slice, layout_atom, param_slice, resource_alloc):
         plan = self._prepare(layout_atom, derivatives=True)
+        _lm.pin_destination(array_to_fill)        # pyGSTi's own 'ep' array: page-locked on its first real fill
         nP = self.model.num_params
         pidx = np.arange(nP) if param_slice is None else _to_array(param_slice)
         didx = None if dest_param_slice is None else _to_array(dest_param_slice)
@@ -572,33 +578,72 @@ class AtomFillLogic:
             array_to_fill[...] = tmp
 
 
-    def bulk_fill_lsq_step(self, jtj, jtf, layout, counts, total_counts, objective="logl", min_prob_clip=1e-4, radius=1e-4,
-                           prob_clip_interval=None, lsvec_to_fill=None, pr_array_to_fill=None):
-        """What one Levenberg-Marquardt iteration of a GST fit needs from the data, computed without the Jacobian leaving
-        the GPU: for every atom of `layout` the probabilities and the Jacobian (this simulator's
-        derivative mode for the model's parameterisation), the objective's element-wise maps -- lsvec and the dlsvec row
-        scale of TimeIndependentMDCObjectiveFunction (objectivefns.py:4573-4665; `objective` = 'chi2' | 'logl') -- then
-        J_s^T J_s and J_s^T lsvec (optimize/simplerlm.py:677-678).  `counts` / `total_counts`: per-element arrays in
-        layout order (the objective's `.counts` / `.total_counts`).  jtj (nP, nP) and jtf (nP,) are summed over this
-        process's atoms (ranks all-reduce, as `layout.fill_jtj` does); returns sum(terms) of them.  Not available for
-        models that must be stepped on the host ("models" mode: no device-resident Jacobian)."""
+    def device_scaled_jacobian(self, layout, counts, total_counts, objective="logl", min_prob_clip=1e-4, radius=1e-4,
+                               prob_clip_interval=None, lsvec_to_fill=None, pr_array_to_fill=None):
+        """The device half of `TimeIndependentMDCObjectiveFunction.dlsvec` (objectivefns.py:4595-4665) for every atom of
+        `layout`: probabilities and Jacobian (this simulator's derivative mode for the model's parameterisation), the
+        objective's element-wise maps (lsvec; the dlsvec row factor (0.5 / lsvec) * dterms), the rows of the Jacobian
+        scaled IN PLACE, and J_s^T J_s -- nothing of size (nE, nP) leaves HBM.  `counts` / `total_counts`: per-element
+        arrays in layout order (the objective's `.counts` / `.total_counts`); objective = 'chi2' | 'logl'.
+        Returns (parts, jtj): parts = [(plan, device pointer of the atom's scaled [nE_atom][nP] block, element slice)]
+        (what lmstep.DeviceJacobian wraps), jtj = the (nP, nP) sum over this process's atoms.  The optional host vectors
+        receive lsvec and the (clipped) probabilities, as the reference's dlsvec leaves them in `objective.obj` /
+        `objective.probs`; `self.last_objective_sum` holds sum(terms).  Not available for models that must be stepped on
+        the host ("models" mode: no device-resident Jacobian)."""
         nP = self.model.num_params
-        jtj[...] = 0.0
-        jtf[...] = 0.0
-        total = 0.0
         counts = np.asarray(counts, np.float64); total_counts = np.asarray(total_counts, np.float64)
+        jtj = np.zeros((nP, nP)); part = np.empty((nP, nP))
+        parts = []
+        total = 0.0
+        pidx = np.arange(nP, dtype=np.int64)
         for atom in layout.atoms:
             plan = self._prepare(atom, derivatives=True)
             if getattr(plan, "_hip_mode", None) == "models":
                 raise NotImplementedError("the fused LM step needs a device-resident Jacobian; this model is stepped on the host")
             es = getattr(atom, "element_slice", slice(0, atom.num_elements))
+            nE = atom.num_elements
             mode = _lib.DERIV_ANALYTIC if self._effective_mode(atom) == "analytic" else _lib.DERIV_FD
-            t, part, pv = plan.lsq_step(nP, counts[es], total_counts[es], objective, self.derivative_eps, mode, min_prob_clip,
-                                        radius, prob_clip_interval,
-                                        None if lsvec_to_fill is None else lsvec_to_fill[es],
-                                        None if pr_array_to_fill is None else pr_array_to_fill[es])
-            total += t; jtj += part; jtf += pv
-        return total
+            sizes = (nE * nP * 8, nE * 8, nE * 8, nE * 8, nE * 8, nE * 8, nP * nP * 8)
+            d_J, d_pr, d_c, d_N, d_ls, d_w, d_jtj = [plan.workspace("lsq%d" % k, nb) for k, nb in enumerate(sizes)]
+            plan.memcpy_h2d(d_c, np.ascontiguousarray(counts[es])); plan.memcpy_h2d(d_N, np.ascontiguousarray(total_counts[es]))
+            plan.fill_dprobs_dev(d_J, nP, pidx, None, self.derivative_eps, d_pr, mode)
+            total += plan.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius,
+                                             prob_clip_interval)
+            plan.fill_jtj_dev(d_J, nE, nP, nP, d_jtj, d_w)          # scales the rows of J in place first
+            plan.memcpy_d2h(part, d_jtj)
+            jtj += part
+            if lsvec_to_fill is not None:
+                self._d2h_rows(plan, lsvec_to_fill, es, d_ls)
+            if pr_array_to_fill is not None:
+                self._d2h_rows(plan, pr_array_to_fill, es, d_pr)
+            parts.append((plan, d_J, es))
+        self.last_objective_sum = total
+        return parts, jtj
+
+    @staticmethod
+    def _d2h_rows(plan, host_vec, es, d_ptr):
+        view = host_vec[es]
+        if isinstance(view, np.ndarray) and view.flags.c_contiguous:
+            plan.memcpy_d2h(view, d_ptr)
+        else:
+            tmp = np.empty(es.stop - es.start); plan.memcpy_d2h(tmp, d_ptr); host_vec[es] = tmp
+
+    def bulk_fill_lsq_step(self, jtj, jtf, layout, counts, total_counts, objective="logl", min_prob_clip=1e-4, radius=1e-4,
+                           prob_clip_interval=None, lsvec_to_fill=None, pr_array_to_fill=None):
+        """What one Levenberg-Marquardt iteration of a GST fit needs from the data, computed without the Jacobian leaving
+        the GPU: `device_scaled_jacobian`, then J_s^T lsvec (optimize/simplerlm.py:677-678).
+        jtj (nP, nP) and jtf (nP,) are summed over this process's atoms (ranks all-reduce, as `layout.fill_jtj` does);
+        returns sum(terms) of them.  This is the direct call; from the reference's own optimizer the same step is reached
+        through `hip_objfn_builders()` (objective.dlsvec -> lmstep.DeviceJacobian -> layout.fill_jtj / fill_jtf)."""
+        nP = self.model.num_params
+        n_el = sum(a.num_elements for a in layout.atoms)
+        ls = np.empty(n_el) if lsvec_to_fill is None else lsvec_to_fill
+        parts, part_jtj = self.device_scaled_jacobian(layout, counts, total_counts, objective, min_prob_clip, radius,
+                                                      prob_clip_interval, ls, pr_array_to_fill)
+        dj = _lm.DeviceJacobian(parts, part_jtj, n_el, nP)
+        jtj[...] = dj.jtj()
+        jtf[...] = dj.jtf(ls)
+        return self.last_objective_sum
 
 
 class HipMapForwardSimulator(AtomFillLogic, _MapForwardSimulator):
@@ -627,6 +672,23 @@ class HipMapForwardSimulator(AtomFillLogic, _MapForwardSimulator):
                                      self._hip_device, self.derivative_mode, self.lindblad_on_device)
         return out
 
+    def _to_nice_serialization(self):
+        """MapForwardSimulator's state (max_cache_size and the two step sizes, mapforwardsim.py:174-181) plus this class's
+        own options: pyGSTi writes the simulator into every GST checkpoint and results directory
+        (protocols/gst.py:1497-1504), and a run resumed from one must not silently change its derivative mode."""
+        state = super()._to_nice_serialization()
+        state.update({"hip_derivative_mode": self.derivative_mode, "hip_device": int(self._hip_device),
+                      "hip_lindblad_on_device": bool(self.lindblad_on_device)})
+        return state
+
+    @classmethod
+    def _from_nice_serialization(cls, state):
+        # (like the base class, mapforwardsim.py:183-188: the parent model and the processor distribution are not stored)
+        return cls(None, state["max_cache_size"], derivative_eps=state.get("derivative_epsilon", 1e-7),
+                   hessian_eps=state.get("hessian_epsilon", 1e-5), device=state.get("hip_device", -1),
+                   derivative_mode=state.get("hip_derivative_mode", "auto"),
+                   lindblad_on_device=state.get("hip_lindblad_on_device", True))
+
     def create_layout(self, circuits, dataset=None, resource_alloc=None, array_types=('E',), derivative_dimensions=None,
                       verbosity=0, layout_creation_circuit_cache=None, **kwargs):
         """pyGSTi's own MapCOPALayout (element indexing, atoms, parameter blocks, MPI grid -- everything upstream relies
@@ -636,11 +698,55 @@ class HipMapForwardSimulator(AtomFillLogic, _MapForwardSimulator):
         tuple-comparison pass that is half of layout creation (2Q L<=1024 lite: 14.6 -> 7.7 s; what remains is pyGSTi's
         per-circuit completion / POVM separation, models/model.py:1600-1775, which callers amortise with
         `layout_creation_circuit_cache`).  Results are unchanged: every state is still rho followed by the circuit's
-        gates applied left to right."""
+        gates applied left to right.
+
+        The layout comes back as `HipMapCOPALayout`: the same object with three methods of the LM path overridden
+        (lmstep.LayoutNormalEquations: `fill_jtj` / `fill_jtf` accept a device-resident Jacobian, `allocate_local_array`
+        marks pyGSTi's 'ep' arrays for page-locking on their first real fill)."""
         keep = self._max_cache_size
         self._max_cache_size = 0
         try:
-            return super().create_layout(circuits, dataset, resource_alloc, array_types, derivative_dimensions, verbosity,
-                                         layout_creation_circuit_cache, **kwargs)
+            layout = super().create_layout(circuits, dataset, resource_alloc, array_types, derivative_dimensions, verbosity,
+                                           layout_creation_circuit_cache, **kwargs)
         finally:
             self._max_cache_size = keep
+        if type(layout) is _MapCOPALayout:
+            layout.__class__ = HipMapCOPALayout      # (no new state: a method-only subclass)
+        return layout
+
+
+class HipMapCOPALayout(_lm.LayoutNormalEquations, _MapCOPALayout):
+    """pyGSTi's MapCOPALayout whose normal-equation products accept the device-resident Jacobian of `dlsvec`
+    (layouts/distlayout.py:1220-1359 otherwise) -- see lmstep.LayoutNormalEquations."""
+
+
+if HAVE_PYGSTI:
+    class HipChi2Function(_lm.DeviceLMStepLogic, _objfns.Chi2Function):
+        """`Chi2Function` (objectivefns.py:4972-4983) whose `dlsvec` leaves the scaled Jacobian on the device."""
+
+    class HipPoissonPicDeltaLogLFunction(_lm.DeviceLMStepLogic, _objfns.PoissonPicDeltaLogLFunction):
+        """`PoissonPicDeltaLogLFunction` (objectivefns.py:5056-5068) whose `dlsvec` leaves the scaled Jacobian on the device."""
+
+
+def hip_objfn_builders(objective="logl", always_perform_mle=False, only_perform_mle=False):
+    """`GSTObjFnBuilders.create_from(objective)` (protocols/gst.py:790-834) with the two objective classes above in place
+    of the stock ones -- same names, descriptions, regularisation and penalties, so estimates and reports read the same:
+
+        proto = pygsti.protocols.GateSetTomography(model, objfn_builders=hip_objfn_builders(), ...)
+        results = proto.run(data, simulator=HipMapForwardSimulator())
+
+    Every LM iteration of that run then goes objective.dlsvec -> device (fill + maps + J^T J) -> layout.fill_jtj /
+    fill_jtf, and no (nE, nP) host array is ever filled.  The builders serialize by class path
+    (objectivefns.py:287-307), so checkpoints and results round-trip wherever pygsti_amd is importable."""
+    if not HAVE_PYGSTI:
+        raise ImportError("pygsti is not importable")
+    from pygsti.protocols.gst import GSTObjFnBuilders
+    stock = GSTObjFnBuilders.create_from(objective, always_perform_mle=always_perform_mle, only_perform_mle=only_perform_mle)
+    swap = {_objfns.Chi2Function: HipChi2Function, _objfns.PoissonPicDeltaLogLFunction: HipPoissonPicDeltaLogLFunction}
+
+    def convert(b):
+        cls = swap.get(b.cls_to_build)
+        if cls is None:
+            return b
+        return _objfns.ObjectiveFunctionBuilder(cls, b.name, b.description, b.regularization, b.penalties, **b.additional_args)
+    return GSTObjFnBuilders([convert(b) for b in stock.iteration_builders], [convert(b) for b in stock.final_builders])

@@ -150,7 +150,8 @@ def main():
     ds = simulate_data(datagen, design.all_circuits_needing_data, 1000, sample_error='binomial', seed=2026)
     data = ProtocolData(design, ds)
     proto = gst.GateSetTomography(smq1Q_XYI.target_model("full TP"), 'stdgaugeopt', name="fit", verbosity=0)
-    results = proto.run(data, simulator=RecordingMapForwardSimulator)
+    # (pyGSTi would otherwise drop gst_checkpoints/*.json into the working directory: protocols/gst.py:1497-1504)
+    results = proto.run(data, simulator=RecordingMapForwardSimulator, disable_checkpointing=True)
     final = results.estimates["fit"].models['final iteration estimate']
     n_fit_calls = len(CALLS)
     tdl = two_delta_logl(final, ds)                   # (further simulator calls: not part of the replayed sequence)

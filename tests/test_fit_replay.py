@@ -74,10 +74,69 @@ def test_fit_record_replays_on_the_oracle(oracle_built):
     assert abs(2.0 * float(fx["ob%d_fsum" % (int(fx["n_obj"]) - 1)]) - float(fx["two_delta_logl"])) < 1.0    # (the last iterate is next to the estimate)
 
 
+from pygsti_amd import lmstep           # noqa: E402  (pyGSTi-free: the logic mixed into pyGSTi's classes by the adapter)
+
+
+class _HostLayout:
+    """what is to the right of lmstep.LayoutNormalEquations in the adapter's layout class (pyGSTi's MapCOPALayout there)"""
+    def __init__(self, atoms):
+        self.atoms = atoms
+
+    def fill_jtj(self, j, jtj, shared_mem_buf=None):
+        raise AssertionError("host product requested")
+
+    def fill_jtf(self, j, f, jtf):
+        raise AssertionError("host product requested")
+
+
+class _StandInLayout(lmstep.LayoutNormalEquations, _HostLayout):
+    pass
+
+
+class _RawChi2:
+    def __init__(self, mpc):
+        self.min_prob_clip_for_weighting = mpc
+_RawChi2.__name__ = "RawChi2Function"
+
+
+class _RawLogl:
+    regtype = "minp"
+    def __init__(self, mpc, radius):
+        self.min_p, self.radius = mpc, radius
+_RawLogl.__name__ = "RawPoissonPicDeltaLogLFunction"
+
+
+class _Resources:
+    comm = None
+
+
+class _HostObjective:
+    """the attributes of TimeIndependentMDCObjectiveFunction the device step reads (objectivefns.py:4406-4431)"""
+    def __init__(self, sim, layout, counts, totals, kind, mpc, radius, clip):
+        class _M:            # model: the stand-in model plus the `.sim` back-reference and from_vector of pyGSTi's
+            pass
+        m = _M(); m.sim = sim; m.num_params = sim.model.num_params
+        m.to_vector = sim.model.to_vector; m.from_vector = lambda v: None       # (the replayed iterate IS sim.model)
+        self.model, self.layout = m, layout
+        self.counts, self.total_counts = np.asarray(counts, float), np.asarray(totals, float)
+        self.raw_objfn = _RawChi2(mpc) if kind == 0 else _RawLogl(mpc, radius)
+        self.nelements = len(self.counts); self.ex = self.local_ex = 0
+        self.probs = np.empty(self.nelements); self.obj = np.empty(self.nelements)
+        self.firsts = None; self.prob_clip_interval = clip; self.resource_alloc = _Resources()
+
+    def dlsvec(self, paramvec=None):
+        raise AssertionError("host dlsvec requested")
+
+
+class _StandInObjective(lmstep.DeviceLMStepLogic, _HostObjective):
+    pass
+
+
 @pytest.mark.gpu
 def test_gpu_fit_replay_through_the_adapter_logic():
     from pygsti_amd import _lib
     import test_gpu_adapter_modes as M
+    lmstep.DeviceJacobian.materialisations = 0
     fx = load_fixture(NAME)
     nP, D = int(fx["nP"]), int(fx["D"])
     n_stages = int(fx["n_stages"])
@@ -134,6 +193,22 @@ def test_gpu_fit_replay_through_the_adapter_logic():
             assert abs(total - float(fx["ob%d_fsum" % k])) <= tol * abs(float(fx["ob%d_fsum" % k])), k
             if kind == 0:
                 assert_bitwise(ls, fx["ob%d_lsvec" % k], "lsvec of dlsvec call %d" % k)
+            # the SAME step the way the reference's optimizer reaches it (simplerlm.py:663-678): objective.dlsvec returns
+            # a device-resident Jacobian, np.linalg.norm / layout.fill_jtj / layout.fill_jtf take it -- the logic classes
+            # pygsti_adapter.py mixes into pyGSTi's objective and layout, here over stand-ins
+            obj = _StandInObjective(sim, _StandInLayout([atom]), fx["s%d_counts" % s], fx["s%d_totals" % s], kind, mpc, rad,
+                                    (float(fx["ob%d_clip_lo" % k]), float(fx["ob%d_clip_hi" % k])))
+            dj = obj.dlsvec(fx["it%d_vec" % it])
+            assert obj.last_dlsvec_route == "device" and isinstance(dj, lmstep.DeviceJacobian) and dj.shape == (nE, nP)
+            jtj2 = np.empty((nP, nP)); jtf2 = np.empty(nP)
+            obj.layout.fill_jtj(dj, jtj2); obj.layout.fill_jtf(dj, obj.obj, jtf2)
+            assert np.array_equal(jtj2, jtj) and np.array_equal(jtf2, jtf)
+            assert abs(np.linalg.norm(dj) ** 2 - np.trace(rj)) <= tol * np.trace(rj)
+            assert np.array_equal(obj.obj, ls) and lmstep.DeviceJacobian.materialisations == 0
+    # one materialisation on request: the scaled Jacobian the reference's dlsvec would have returned
+    Js = np.asarray(dj)
+    assert lmstep.DeviceJacobian.materialisations == 1 and Js.shape == (nE, nP)
+    assert np.abs(Js.T @ Js - jtj).max() <= 1e-12 * np.abs(jtj).max()
     # the final estimate: 2 * delta logL over the whole data set (= the last stage's layout)
     s = n_stages - 1
     atom = atoms[s]

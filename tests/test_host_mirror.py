@@ -108,6 +108,9 @@ def test_simulator_surface_and_helpers():
     st = sim._to_nice_serialization()
     s2 = HipMapForwardSimulator._from_nice_serialization(st)
     assert (s2.derivative_eps, s2.hessian_eps) == (1e-7, 1e-5)
+    sa = HipMapForwardSimulator(derivative_mode="analytic", devices=[0, 1], target_tasks=7)
+    sb = HipMapForwardSimulator._from_nice_serialization(sa._to_nice_serialization())     # the options survive a checkpoint
+    assert (sb.derivative_mode, sb.devices, sb.target_tasks) == ("analytic", [0, 1], 7)
     import pickle
     s3 = pickle.loads(pickle.dumps(sim))
     assert s3.model is None                      # live handles are dropped, the parent model re-attaches
