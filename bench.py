@@ -348,7 +348,7 @@ def main():
     # this rank's parameter columns: all of them, or its parameter-processor's slice of the atom it shares (--grid)
     gps = layout.global_param_slice
     nP_local = gps.stop - gps.start
-    d_out = plan.device_malloc(nE_local * nP_local * 8)    # this rank's Jacobian block (stays distributed, as in the reference)
+    d_out = plan.device_malloc(nE_local * nP_local * 8, tracked=True)    # this rank's Jacobian block (stays distributed, as in the reference); TRACKED: only the library writes it
     d_pfull = plan.device_malloc(nE_total * 8)             # the ASSEMBLED probabilities: own rows filled in place
     d_probs = d_pfull + row0 * 8
     pidx = np.arange(gps.start, gps.stop, dtype=np.int64)
@@ -487,7 +487,7 @@ def main():
         theta = 0.003 * np.random.default_rng(9).standard_normal(lmodel.num_params)
         nPl = lmodel.num_params
         plan.set_lindblad(lmodel)
-        d_outl = plan.device_malloc(nE_local * nPl * 8)
+        d_outl = plan.device_malloc(nE_local * nPl * 8, tracked=True)
         pidx_l = np.arange(nPl, dtype=np.int64)
         try:
             t_set0 = time.perf_counter()

@@ -133,11 +133,13 @@ int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *op
  *       Entry (element of circuit c, parameter of gate g) is an exact zero when c never applies g -- 30 % of a GST Jacobian.
  *       A fill whose destination, leading dimension and column request equal an earlier exact fill's need not store those
  *       zeros again (a third of the contraction's stores) if nothing else was written there in between.
- *       2 (default): only for destinations the library can vouch for -- memory from gst_device_malloc and the plan's own
- *          staging buffer behind host destinations.  Every entry point that writes device memory (fills, gst_memcpy_h2d,
+ *       2 (default): only for destinations the library can vouch for -- memory the caller allocated as TRACKED
+ *          (gst_device_malloc_tracked: an explicit statement per allocation) and the plan's own staging buffer behind
+ *          host destinations; plain gst_device_malloc memory and foreign pointers are NOT eligible.  Every entry point that writes device memory (fills, gst_memcpy_h2d,
  *          gst_copy_block_dev, the objective maps, the gst_comm_* collectives) invalidates what it overwrites;
  *          gst_fill_jtj_dev's in-place row scaling keeps zeros zero and is checked for non-finite factors on the stream.
- *          A caller that writes gst_device_malloc memory with ITS OWN kernels announces it with gst_device_touch.
+ *          A caller that writes tracked memory with ITS OWN kernels announces it with gst_device_touch; a row scaling
+ *          issued through ANOTHER plan than the one that filled the Jacobian ends the claim (different streams).
  *          (gst_stats.last_zeros_resident reports the decision of the last fill.)
  *       1: additionally for ANY destination pointer: the caller promises that nothing but row scalings was written into
  *          the buffer since the previous exact fill of this plan -- what an optimizer does that reuses one device Jacobian
@@ -231,7 +233,14 @@ int gst_set_derivs(gst_plan *plan, int32_t n_params, int32_t n_objs, const int32
  * device builds the dense model after every step itself -- no host densification and no PCIe traffic per column
  * (gst_fill_dprobs_models is the host-stepped form of the same walk).  Accuracy: the reference propagates through the
  * composed member factor by factor and exponentiates with a Pade approximant; dense members agree to ~1e-16, probabilities
- * to ~1e-15, FD quotients to ~1e-8.
+ * to ~1e-15.  THE FD QUOTIENTS OF THIS ROUTE ARE OUTSIDE THE 1e-8 BAR AT DEPTH: a last-bit difference of the perturbed member
+ * is amplified by (occurrences of the member in the circuit) / eps -- measured against the Map simulator <= 1e-8 for
+ * circuits of depth <= 8, 1.5e-8 to depth 16, 7e-8 at depth 41-80, 1.2e-7 at depth 81-160 (1Q) and 7e-8 at depth 1,030 (2Q)
+ * (tests/test_gpu_lindblad.py asserts that envelope with < 3x head-room).  No implementation can do better against that
+ * oracle short of reproducing scipy's Pade solve bit for bit: the reference's own quotients carry the same amplified
+ * rounding (dense-vs-composed evaluation of IDENTICAL members already moves them by 4e-9).  Use it for speed studies; for
+ * fits use GST_DERIV_ANALYTIC (below; 1e-11 at depth 1,030 -- what the adapter's derivative_mode="auto" selects), or the
+ * host-stepped gst_fill_dprobs_models, which walks the REFERENCE's perturbed dense members (4e-9, flat in depth).
  * GST_DERIV_ANALYTIC columns are exact: the device computes every member's d(dense)/d(parameter) itself -- the Frechet
  * derivative of the exponential in the direction dL/dtheta_p, composed with the static factor: what the reference's
  * ExpErrorgenOp.deriv_wrt_params() (experrorgenop.py:213-260) hands to MatrixForwardSimulator._doperation -- and applies the
@@ -455,9 +464,16 @@ int gst_comm_get_info(const gst_comm *comm, gst_comm_info *out);
 /* Plain device-buffer helpers on the plan's device, so that callers without any GPU framework can
  * keep results resident (bench.py, tests).  Buffers from any other allocator work equally. */
 int gst_device_malloc(gst_plan *plan, int64_t nbytes, void **d_ptr);
+/* The same allocation, declared TRACKED: the caller states that every write to this memory goes through this library
+ * (fills, gst_memcpy_h2d, gst_copy_block_dev, the objective maps, gst_comm_*; each reports what it overwrites) or is
+ * announced with gst_device_touch.  Only such memory -- and the plans' private staging buffers -- is eligible for the
+ * default of GST_OPT_ANALYTIC_KEEP_ZEROS (2): a repeated exact fill skips the structural zeros it left there itself.
+ * Memory from gst_device_malloc or from any other allocator is never trusted without the explicit promise (value 1).
+ * Released with gst_device_free. */
+int gst_device_malloc_tracked(gst_plan *plan, int64_t nbytes, void **d_ptr);
 int gst_device_free(gst_plan *plan, void *d_ptr);
-/* The caller wrote [d_ptr, d_ptr + nbytes) of gst_device_malloc memory by means other than this library (its own kernel,
- * a peer copy): whatever the library remembered about the contents (GST_OPT_ANALYTIC_KEEP_ZEROS = 2) is forgotten. */
+/* The caller wrote [d_ptr, d_ptr + nbytes) of gst_device_malloc_tracked memory by means other than this library (its own
+ * kernel, a peer copy): whatever the library remembered about the contents is forgotten. */
 int gst_device_touch(gst_plan *plan, void *d_ptr, int64_t nbytes);
 int gst_memcpy_d2h(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
 /* The same copy enqueued on the plan's stream without waiting for it (gst_sync completes it): lets one process drain

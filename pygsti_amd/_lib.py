@@ -81,7 +81,7 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
@@ -124,6 +124,7 @@ def lib():
         L.gst_copy_block_dev.argtypes = [vp, vp, i64, vp, i64, i64, i64]
         L.gst_sync.argtypes = [vp]
         L.gst_device_malloc.argtypes = [vp, i64, C.POINTER(vp)]
+        L.gst_device_malloc_tracked.argtypes = [vp, i64, C.POINTER(vp)]
         L.gst_device_free.argtypes = [vp, vp]
         L.gst_device_touch.argtypes = [vp, vp, C.c_int64]
         L.gst_memcpy_d2h.argtypes = [vp, vp, vp, i64]
@@ -287,7 +288,7 @@ class Plan:
         if have is not None:
             self.device_free(have[0])
             del ws[name]
-        ptr = self.device_malloc(max(int(nbytes), 8))
+        ptr = self.device_malloc(max(int(nbytes), 8), tracked=True)      # (only this wrapper writes its workspaces)
         ws[name] = (ptr, int(nbytes))
         return ptr
 
@@ -579,9 +580,12 @@ class Plan:
         """rows x cols doubles between device arrays with leading dimensions dst_ld / src_ld (doubles); asynchronous"""
         check(lib().gst_copy_block_dev(self._h, C.c_void_p(int(d_dst)), int(dst_ld), C.c_void_p(int(d_src)), int(src_ld), int(n_rows), int(n_cols)))
 
-    def device_malloc(self, nbytes):
+    def device_malloc(self, nbytes, tracked=False):
+        """tracked=True: gst_device_malloc_tracked -- memory written only through this library (or announced with
+        `device_touch`), eligible for the resident structural zeros of exact Jacobians (OPT_ANALYTIC_KEEP_ZEROS = 2)."""
         p = C.c_void_p()
-        check(lib().gst_device_malloc(self._h, int(nbytes), C.byref(p)))
+        fn = lib().gst_device_malloc_tracked if tracked else lib().gst_device_malloc
+        check(fn(self._h, int(nbytes), C.byref(p)))
         return p.value
 
     def device_free(self, d_ptr):

@@ -612,6 +612,17 @@ int gst_device_malloc(gst_plan* p, int64_t nbytes, void** d_ptr)
     int rc = ensure_device(p);
     if (rc) return rc;
     HIP_TRY(hipMalloc(d_ptr, (size_t)std::max<int64_t>(nbytes, 1)));
+    return GST_OK;
+    });
+}
+
+int gst_device_malloc_tracked(gst_plan* p, int64_t nbytes, void** d_ptr)
+{
+    return guarded([&]() -> int {
+    if (!p || !d_ptr || nbytes < 0) return fail(GST_EINVAL, "bad argument");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(d_ptr, (size_t)std::max<int64_t>(nbytes, 1)));
     gst::track_alloc(*d_ptr, (size_t)std::max<int64_t>(nbytes, 1));
     return GST_OK;
     });

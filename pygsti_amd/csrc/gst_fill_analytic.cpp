@@ -355,7 +355,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         // THIS request last time (and the caller promised, by setting the option, to write nothing but row scalings into it
         // in between) they are zero already and are not stored again -- a third of the D = 16 contraction's stores
         // Without the option (value 2, the default) the same holds for destinations the library can vouch for: memory from
-        // gst_device_malloc and the plan's own staging buffer, whose every other writer reports to gst_track.cpp.
+        // gst_device_malloc_tracked and the plan's own staging buffer, whose every other writer reports to gst_track.cpp.
         const bool same_dest = p->ana_zero_out == (const void*)d_out && p->ana_zero_ld == ld && p->ana_zero_valid && request_was_cached;
         const bool zero_form = D == 16 && (!p->derivs_set || p->jelem_call) && !p->want_cache_path;
         const size_t extent = jac_extent(nE_total(p), ld, dest_idx, n_param);
@@ -377,7 +377,7 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         TIME_REC(p, evk1);
         p->last_launches++;
         if (claim) {         // what this fill leaves behind; the word reads 1 again whatever a row scaling did to it before
-            if (uint32_t* w = gst::track_claim_set(d_out, extent, sig, p->device)) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)w, 1, 1, p->stream));
+            if (uint32_t* w = gst::track_claim_set(d_out, extent, sig, p->device, p->uid)) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)w, 1, 1, p->stream));
         }
         p->last_ana = a; p->last_ana_valid = true;     // (the Hessian rows re-launch the contraction with other caches)
         p->last_ana.zeros_resident = 0; p->last_ana.zeros_ok = nullptr;

@@ -27,7 +27,7 @@ void track_free(const void* p);                          // ... released (drops 
 bool track_owned(const void* p, size_t bytes);           // [p, p + bytes) lies inside one tracked allocation
 void track_touch(const void* p, size_t bytes);           // the library writes there (anything but a row scaling): claims dropped
 uint32_t* track_claim_find(const void* base, size_t bytes, uint64_t sig);       // the claim's device word (1 = holds), or NULL
-uint32_t* track_claim_set(const void* base, size_t bytes, uint64_t sig, int device);
-uint32_t* track_claim_overlapping(const void* p, size_t bytes, bool* several);  // the one claim a row scaling of this range meets
+uint32_t* track_claim_set(const void* base, size_t bytes, uint64_t sig, int device, uint64_t owner);   // owner = the claiming plan's uid
+uint32_t* track_claim_overlapping(const void* p, size_t bytes, bool* several, uint64_t* owner);  // the one claim a row scaling of this range meets
 
 }  // namespace gst

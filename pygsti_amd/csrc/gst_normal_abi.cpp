@@ -17,10 +17,13 @@ int gst_fill_jtj_dev(gst_plan* p, double* d_J, int64_t n_rows, int64_t n_cols, i
     if (d_row_scale && n_rows > 0 && n_cols > 0) {
         // the in-place row scaling keeps an exact Jacobian's zeros zero -- unless a factor is not finite (0 * inf): the
         // claim's device word is cleared on the stream then, and the next exact fill stores everything (gst_track.cpp)
+        // (the claim's word lives on its OWNER's stream: a scaling issued through another plan is not ordered against the
+        //  owner's next contraction, so it simply ends the claim)
         bool several = false;
+        uint64_t owner = 0;
         const size_t bytes = (size_t)((n_rows - 1) * ld + n_cols) * 8;
-        uint32_t* w = gst::track_claim_overlapping(d_J, bytes, &several);
-        if (several) gst::track_touch(d_J, bytes);
+        uint32_t* w = gst::track_claim_overlapping(d_J, bytes, &several, &owner);
+        if (several || (w && owner != p->uid)) gst::track_touch(d_J, bytes);
         else if (w) HIP_TRY(gst::launch_check_finite(d_row_scale, n_rows, w, p->stream));
     }
     TIME_REC(p, ev0);

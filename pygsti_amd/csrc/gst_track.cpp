@@ -1,9 +1,14 @@
 // gst_track.cpp -- which device ranges still hold the exact zeros of an analytic Jacobian.
 //
+// Tracked memory is OPT-IN per allocation: gst_device_malloc_tracked (the caller states that every write to it goes through
+// this library or is announced with gst_device_touch); plain gst_device_malloc memory is the caller's and is never claimed.
+// A claim remembers the plan that made it: its device word is only ever read and written on THAT plan's stream, so a row
+// scaling issued through another plan (another stream: no ordering against the owner's next fill) drops the claim instead.
+//
 // Entry (element of circuit c, parameter of gate g) of an exact Jacobian is zero when c never applies g: 30 % of a GST
 // Jacobian.  A repeated fill into the same destination need not store those zeros again (a third of the D = 16
-// contraction's stores) -- provided nothing else was written there in between.  For memory the LIBRARY handed out
-// (gst_device_malloc) or owns (a plan's staging buffer) that is knowable: every entry point that writes device memory
+// contraction's stores) -- provided nothing else was written there in between.  For memory the library handed out as TRACKED
+// (gst_device_malloc_tracked) or owns (a plan's staging buffer) that is knowable: every entry point that writes device memory
 // reports the range here (track_touch), a fill records what it left behind (track_claim_set), and the next fill with the
 // same signature (plan, column request, leading dimension) finds the claim and skips the zeros.  Row scalings
 // (gst_fill_jtj_dev) keep zeros zero unless a factor is not finite: the claim carries a device word that a check of the
@@ -19,7 +24,7 @@
 namespace gst {
 namespace {
 
-struct Claim { const char* base; size_t bytes; uint64_t sig; uint32_t* d_ok; int device; };
+struct Claim { const char* base; size_t bytes; uint64_t sig; uint32_t* d_ok; int device; uint64_t owner; };
 
 // (never destroyed: a plan released during process teardown may still report here)
 std::mutex& g_mu = *new std::mutex;
@@ -85,7 +90,7 @@ uint32_t* track_claim_find(const void* base, size_t bytes, uint64_t sig)
     return nullptr;
 }
 
-uint32_t* track_claim_set(const void* base, size_t bytes, uint64_t sig, int device)
+uint32_t* track_claim_set(const void* base, size_t bytes, uint64_t sig, int device, uint64_t owner)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     for (const Claim& c : g_claims)
@@ -95,17 +100,17 @@ uint32_t* track_claim_set(const void* base, size_t bytes, uint64_t sig, int devi
     for (size_t i = 0; i < g_free_flags.size(); i++)
         if (g_free_flags[i].first == device) { w = g_free_flags[i].second; g_free_flags[i] = g_free_flags.back(); g_free_flags.pop_back(); break; }
     if (!w && hipMalloc((void**)&w, sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    g_claims.push_back({(const char*)base, bytes, sig, w, device});
+    g_claims.push_back({(const char*)base, bytes, sig, w, device, owner});
     return w;
 }
 
-uint32_t* track_claim_overlapping(const void* p, size_t bytes, bool* several)
+uint32_t* track_claim_overlapping(const void* p, size_t bytes, bool* several, uint64_t* owner)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     uint32_t* w = nullptr;
     int n = 0;
     for (const Claim& c : g_claims)
-        if (overlaps(c.base, c.bytes, (const char*)p, bytes)) { w = c.d_ok; n++; }
+        if (overlaps(c.base, c.bytes, (const char*)p, bytes)) { w = c.d_ok; n++; if (owner) *owner = c.owner; }
     if (several) *several = n > 1;
     return n == 1 ? w : nullptr;
 }

@@ -396,18 +396,33 @@ class AtomFillLogic:
                     atom_tp_map(self.model, layout_atom)
                 except NotImplementedError:
                     # neither element maps nor TP element subsets: Lindblad members (built on the device) and every other
-                    # parameterisation whose members give deriv_wrt_params take exact derivatives
+                    # parameterisation whose members give deriv_wrt_params take exact derivatives; a member that cannot
+                    # give them (deriv_wrt_params unimplemented) sends the atom back to finite differences over
+                    # host-stepped dense model sets -- what 'fd' did for every such model before 'auto' existed
                     mode = "analytic"
+                    if not (self.lindblad_on_device and self._lindblad_description(layout_atom) is not None):
+                        try:
+                            atom_derivs(self.model, layout_atom)
+                        except (NotImplementedError, AttributeError):
+                            mode = "fd"
             layout_atom._hip_auto_mode, layout_atom._hip_auto_key = mode, (self.model, bool(self.lindblad_on_device))
         return layout_atom._hip_auto_mode
 
     def _prepare(self, layout_atom, derivatives=False, hessian=False):
         plan = atom_plan(self.model, layout_atom, self._hip_device)
         dmode = self._effective_mode(layout_atom) if derivatives else None
-        # an atom already resolved to the device-built Lindblad route keeps it for this model: the host to_dense() of
-        # every member (what set_model would upload, only to be overwritten by set_lindblad_params) is skipped
-        if (getattr(plan, "_hip_mode", None) == "lindblad" and getattr(layout_atom, "_hip_lb_model", None) is self.model
-                and layout_atom._hip_lb is not None and self.lindblad_on_device and not hessian):
+        # Lindblad-parameterised atoms with `lindblad_on_device`: the DEVICE builds the dense members from the parameter
+        # vector for EVERY fill of this model -- probabilities included, from the first call on -- so that what
+        # bulk_fill_probs returns never depends on whether a derivative was requested before (the device's scaled-Taylor
+        # exponential and the host's Pade approximant differ in the last bit, which a line search would see).  Skips the
+        # host to_dense() of every member as well.  Only exact HESSIAN requests leave this route (they need the host's
+        # deriv / hessian matrices, `derivs` mode below); the next fill re-enters it.
+        if self.lindblad_on_device and not hessian and self._lindblad_description(layout_atom) is not None:
+            if getattr(plan, "_hip_mode", None) != "lindblad":
+                plan.set_derivs(self.model.num_params, [])
+                plan.set_complement_effect(-1)
+                plan.set_lindblad(layout_atom._hip_lb)
+                plan._hip_mode = "lindblad"
             plan.set_lindblad_params(self.model.to_vector())
             return plan
         plan.set_model(*atom_arrays(self.model, layout_atom))
@@ -437,8 +452,8 @@ class AtomFillLogic:
                     layout_atom._hip_tpmap = None
                 layout_atom._hip_tpmap_model = self.model
             if layout_atom._hip_tpmap is None:
-                # Lindblad-parameterised members (CPTPLND, GLND, H+S): the device builds them from the parameter vector,
-                # for the base model and for every FD step
+                # Lindblad-parameterised members (CPTPLND, GLND, H+S) under an FD-of-FD Hessian request (everything else
+                # returned at the top): the device builds them from the parameter vector, for the base model and every step
                 if self._lindblad_description(layout_atom) is not None and self.lindblad_on_device:
                     if getattr(plan, "_hip_mode", None) != "lindblad":
                         plan.set_derivs(self.model.num_params, [])
@@ -459,18 +474,9 @@ class AtomFillLogic:
                     plan.set_complement_effect(comp[0], comp[1], comp[2])
                 plan._hip_mode = "tp-elements"
         else:
-            # exact derivatives of a general parameterisation.  Lindblad-parameterised models: the device computes the
-            # members' d(dense)/d(parameter) itself (Frechet derivative of the exponential); anything else: the members'
-            # deriv_wrt_params() from the host, re-sent every call (they move with the parameters)
-            if self.lindblad_on_device and not hessian:
-                if self._lindblad_description(layout_atom) is not None:
-                    if getattr(plan, "_hip_mode", None) != "lindblad":
-                        plan.set_derivs(self.model.num_params, [])
-                        plan.set_complement_effect(-1)
-                        plan.set_lindblad(layout_atom._hip_lb)
-                        plan._hip_mode = "lindblad"
-                    plan.set_lindblad_params(self.model.to_vector())
-                    return plan
+            # exact derivatives of a general parameterisation (Lindblad-parameterised models whose member derivatives the
+            # device computes itself -- Frechet derivative of the exponential -- returned at the top; their exact Hessians
+            # come here): the members' deriv_wrt_params() from the host, re-sent every call (they move with the parameters)
             self._leave_lindblad(plan, layout_atom)
             plan.set_derivs(self.model.num_params, atom_derivs(self.model, layout_atom))
             plan._hip_mode = "derivs"

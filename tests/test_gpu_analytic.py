@@ -225,8 +225,9 @@ def test_analytic_keep_zeros_option():
 
 
 def test_resident_zeros_by_default_on_tracked_destinations():
-    """Default (GST_OPT_ANALYTIC_KEEP_ZEROS = 2): memory the library handed out is tracked, so a repeated exact fill into it
-    skips the structural zeros WITHOUT a promise -- and every library write in between (h2d copy, an FD fill, an objective
+    """Default (GST_OPT_ANALYTIC_KEEP_ZEROS = 2): memory the caller allocated as TRACKED (gst_device_malloc_tracked: an
+    explicit statement per allocation; plain gst_device_malloc memory is never claimed) lets a repeated exact fill into it
+    skip the structural zeros WITHOUT a per-fill promise -- and every library write in between (h2d copy, an FD fill, an objective
     map, the caller's gst_device_touch, a row scaling with a non-finite factor) makes the next fill store everything again.
     Sentinels cannot be planted through the library here (that is a tracked write): the decision is read from
     gst_stats.last_zeros_resident and the results are compared with a fresh host fill every time."""
@@ -236,7 +237,7 @@ def test_resident_zeros_by_default_on_tracked_destinations():
     nE, nP = int(fx["nE"]), int(fx["nP"])
     cols = np.arange(nP)
     ref = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
-    d = pl.device_malloc(nE * nP * 8)
+    d = pl.device_malloc(nE * nP * 8, tracked=True)
 
     def fill(dst=d, ld=nP, c=cols, dest=None):
         pl.fill_dprobs_dev(dst, ld, c, dest, 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
@@ -291,9 +292,22 @@ def test_resident_zeros_by_default_on_tracked_destinations():
     assert not fill(dst=raw.value)
     assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), raw.value), ref)
     hip.hipFree(raw)
+    # ... and neither is the library's own PLAIN allocation: its caller never said that only the library writes it
+    plain = pl.device_malloc(nE * nP * 8)
+    assert not fill(dst=plain) and not fill(dst=plain)
+    assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), plain), ref)
+    pl.device_free(plain)
+    # a row scaling issued through ANOTHER plan (another stream) ends the claim instead of racing with its device word
+    other = plan_from_fixture(fx)
+    scale[3] = 1.0
+    pl.memcpy_h2d(w, scale)
+    assert fill()
+    other.fill_jtj_dev(d, nE, nP, nP, jtj, w); other.sync()
+    assert not fill(); check()
+    assert fill()
     # freed and re-allocated tracked memory starts untrusted
     pl.device_free(d)
-    d2 = pl.device_malloc(nE * nP * 8)
+    d2 = pl.device_malloc(nE * nP * 8, tracked=True)
     pl.memcpy_h2d(d2, np.full(nE * nP, np.nan))
     assert not fill(dst=d2)
     assert np.array_equal(pl.memcpy_d2h(np.empty((nE, nP)), d2), ref)

@@ -188,6 +188,9 @@ def test_analytic_jacobian_of_a_cptplnd_model_with_device_computed_member_deriva
 
 
 DEEP = [("smq1Q_XYI_L128_CPTPLND", 1), ("smq2Q_XYICNOT_L1024_CPTPLND_deep", 2)]
+# measured round 4 (1Q / 2Q): 8.9e-9 / 6.9e-9, 1.5e-8 / 4.4e-9, 3.6e-8 / -, 6.8e-8 / 5.2e-8, 1.2e-7 / -, - / -, - / 7.0e-8
+FD_VS_MAP_ENVELOPE = {(0, 8): 1e-8, (9, 16): 4e-8, (17, 40): 1e-7, (41, 80): 2e-7, (81, 160): 3.5e-7, (161, 600): 3.5e-7,
+                      (601, 2000): 2e-7}
 
 
 @pytest.mark.parametrize("name,nq", DEEP)
@@ -223,8 +226,14 @@ def test_cptplnd_models_at_depth_error_profile(name, nq):
         if m.any():
             prof["%d-%d" % (lo, hi)] = {"fd_vs_map": float(e_fd[m].max()), "analytic_vs_matrix": float(e_an[m].max()), "elements": int(m.sum())}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r04_cptplnd_depth_profile_%s.json" % name), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r05_cptplnd_depth_profile_%s.json" % name), "w") as f:
         json.dump({"fixture": name, "max_abs_J": float(np.abs(fx["dprobs_map"]).max()), "by_depth": prof}, f, indent=1)
     assert e_an.max() < 1e-8, ("analytic vs Matrix", e_an.max(), prof)
-    assert e_fd[depth <= 8].max() < 1e-8, ("FD vs Map, shallow", prof)
-    assert e_fd.max() < 2e-5, ("FD vs Map at depth", prof)
+    # FD vs Map: the measured envelope per depth bin (profiles/r04_cptplnd_depth_profile_*.json, maximum over the 1Q and 2Q
+    # fixtures) with less than 3x head-room -- a 3x regression of the device's exponential or of the FD route fails here.
+    # Beyond depth 8 this route is OUTSIDE the 1e-8 bar by construction (see the docstring); `derivative_mode="auto"` never
+    # selects it.
+    for (lo, hi), bound in FD_VS_MAP_ENVELOPE.items():
+        m = (depth >= lo) & (depth <= hi)
+        if m.any():
+            assert e_fd[m].max() < bound, ("FD vs Map, depth %d-%d" % (lo, hi), float(e_fd[m].max()), bound, prof)

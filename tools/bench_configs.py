@@ -37,8 +37,8 @@ def _releasing(fn):
         made = []
         orig = _lib.Plan.device_malloc
 
-        def rec(self, nbytes):
-            ptr = orig(self, nbytes)
+        def rec(self, nbytes, tracked=False):
+            ptr = orig(self, nbytes, tracked)
             made.append((self, ptr))
             return ptr
         _lib.Plan.device_malloc = rec

@@ -77,7 +77,7 @@ for k in range(n_cases):
             # resident zeros on tracked memory: repeated exact fills, a finite-difference fill and a new model in between
             if nP * nE <= 4_000_000:
                 Jfull = pl.fill_dprobs(param_idx=allc, mode=_lib.DERIV_ANALYTIC)
-                d = pl.device_malloc(nE * nP * 8)
+                d = pl.device_malloc(nE * nP * 8, tracked=True)
                 pl.memcpy_h2d(d, np.full(nE * nP, np.nan))
                 for rep in range(3):
                     pl.fill_dprobs_dev(d, nP, allc, None, 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
