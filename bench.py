@@ -784,13 +784,29 @@ def main():
         FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md).  None when no profile matches."""
         if world != 1 or lay_world != 1 or args.design != "full" or args.max_len != 1024:
             return None
-        for name in ("r04_hbm_counters.json", "r03_hbm_counters.json", "r02_hbm_counters.json", "r01_hbm_counters.json"):
+        for name in ("r05_hbm_counters.json", "r04_hbm_counters.json", "r03_hbm_counters.json", "r02_hbm_counters.json", "r01_hbm_counters.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     prof = json.load(f)[args.deriv]
                 for k, v in prof.items():
                     if kernel_prefix in k:
                         return (2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0
+            except Exception:
+                pass
+        return None
+
+    def measured_valu_instructions(kernel_prefix):
+        """SQ_INSTS_VALU per launch of the dominant kernel from the newest committed PMC pass of this same workload
+        (profiles/r*_bench_pmc_sq_current.json), with its file name -- the cross-check of `executed`."""
+        if world != 1 or lay_world != 1 or args.design != "full" or args.max_len != 1024:
+            return None
+        for name in ("r05_bench_pmc_sq_current.json", "r04_bench_pmc_sq_current.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    prof = json.load(f)[args.deriv]
+                for k, v in prof.items():
+                    if kernel_prefix in k:
+                        return float(v["SQ_INSTS_VALU"]), "profiles/" + name
             except Exception:
                 pass
         return None
@@ -811,6 +827,24 @@ def main():
                     "kernel_ms": k_ms, "bytes_per_launch": jac_bytes, "traffic": measured_traffic("analytic_mfma_kernel")}
         else:
             roof = None
+        fd_exec = None
+        if roof is None and D <= 16:
+            # what the kernel really executes (gst_get_fd_work: the plan's programs walked with the kernel's own clean/dirty
+            # rule), so that the fraction of the roof can be read for the schedule AND for the arithmetic actually issued
+            w = plan.fd_work(pidx)
+            issued = 64.0 * (2.0 * D * D * w["wave_applies_executed"] + 2.0 * D * w["wave_dots_executed"])
+            fd_exec = {"executed_applications": w["col_applies_executed"], "schedule_applications": w["col_applies_schedule"],
+                       "executed_over_schedule": w["col_applies_executed"] / max(w["col_applies_schedule"], 1),
+                       "wavefront_applications_executed": w["wave_applies_executed"], "wavefront_dots_executed": w["wave_dots_executed"],
+                       "wavefronts": w["n_waves"], "issued_flops_per_launch": issued,
+                       "frac_executed": issued / (k_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
+                       "frac_of_unfused_ceiling": issued / (k_ms * 1e-3) / 1e12 / (0.5 * F64_VALU_PEAK_TFLOPS),
+                       "mul_add_wave_instructions": w["wave_applies_executed"] * 2 * D * D + w["wave_dots_executed"] * 2 * D}
+            pmc = measured_valu_instructions("walk_kernel<16, 1")
+            if pmc:
+                fd_exec["pmc_SQ_INSTS_VALU_per_launch"] = pmc[0]
+                fd_exec["pmc_source"] = pmc[1]
+                fd_exec["mul_add_share_of_pmc_valu"] = fd_exec["mul_add_wave_instructions"] / pmc[0]
         out = {
             "metric": "dprobs Jacobian-elements/sec, 2Q GST L<=1024 (bulk_fill_dprobs, %s)" % (
                 "FD eps=1e-7, bit-identical to the reference Map path" if args.deriv == "fd" else
@@ -853,7 +887,8 @@ def main():
                          "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
                          "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (k_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
-                         "note": "flops = the reference schedule's nP*(2*D^2*A + 2*D*nE); the kernel executes ~0.56 of them (the rest is provably bit-identical to the base pass) as separate v_mul_f64+v_add_f64 (no FMA: bitwise parity), whose own ceiling is 0.5 of the FMA peak",
+                         "note": "flops = the reference schedule's nP*(2*D^2*A + 2*D*nE) (SURVEY 8(d)); `executed` = what the kernel issues after skipping every state that is provably bit-identical to the base pass (measured from the plan's programs by gst_get_fd_work, not assumed), as separate v_mul_f64 + v_add_f64 (no FMA: bitwise parity), whose own ceiling is 0.5 of the FMA peak: `frac_of_unfused_ceiling`",
+                         "executed": fd_exec,
                          "kernel_ms": k_ms, "flops_per_launch": flops,
                          "hbm_write_GBps": jac_bytes / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
                          "traffic": measured_traffic("walk_kernel<16, 1")},

@@ -537,6 +537,18 @@ int gst_circuit_first_use(int64_t n_circuits, const int64_t *circ_ptr, const int
 int gst_get_fd_queues(gst_plan *plan, const int64_t *param_idx, int64_t n_param, int32_t n_queues, int32_t handover,
                       int64_t *load_out, int32_t *n_pairs, int32_t *n_handovers);
 
+/* EXACT arithmetic of one GST_DERIV_FD fill of these columns by the lane-per-model walk (D <= 16; host-side only, no device
+ * needed; needs gst_set_param_map) -- what bench.py's roofline line divides by the kernel time.  The kernel skips every
+ * state no lane of a wavefront has perturbed (bit-identical to the base pass by construction); this walks the plan's
+ * programs with that same rule.  out[8] =
+ *   [0] wavefront-applications executed      [1] column-applications executed (live lanes only)
+ *   [2] wavefront-dots executed (EMIT outcomes with real arithmetic)      [3] column-dots executed
+ *   [4] wavefront-applications of the full schedule (wavefronts x applications per pass)   [5] column-applications of it
+ *   [6] wavefronts the columns are packed into   [7] tasks
+ * Executed flops of the fill = 2 D^2 * 64 * out[0] + 2 D * 64 * out[2] (every lane of a wavefront issues); the reference
+ * schedule's flops = n_param * (2 D^2 A + 2 D nE). */
+int gst_get_fd_work(gst_plan *plan, const int64_t *param_idx, int64_t n_param, int64_t *out);
+
 /* The state-id graph behind the NODE markers: parent state id (-1 for a state preparation) and gate / rho index of
  * every state, and the id of each expanded circuit's final state (what the analytic mode walks backwards). */
 int gst_get_state_graph(const gst_plan *plan, int32_t *node_parent, int32_t *node_sym, int64_t cap_nodes,

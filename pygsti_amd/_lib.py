@@ -81,7 +81,7 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_get_fd_work", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
@@ -133,6 +133,7 @@ def lib():
         L.gst_get_program.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64]
         L.gst_get_dirty_programs.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i32)]
         L.gst_get_fd_queues.argtypes = [vp, vp, i64, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
+        L.gst_get_fd_work.argtypes = [vp, vp, i64, vp]
         L.gst_sort_circuits.argtypes = [i64, vp, vp, vp, vp, vp]
         L.gst_circuit_first_use.argtypes = [i64, vp, vp, i32, vp]
         L.gst_get_state_graph.argtypes = [vp, vp, vp, i64, vp, i64, C.POINTER(i64)]
@@ -620,6 +621,15 @@ class Plan:
         check(lib().gst_get_fd_queues(self._h, _ptr(pidx), len(pidx), int(n_queues), int(handover), _ptr(load),
                                       C.byref(n_pairs), C.byref(n_ho)))
         return load, n_pairs.value, n_ho.value
+
+    def fd_work(self, param_idx):
+        """gst_get_fd_work: the exact arithmetic of one FD fill of these columns under the kernel's clean/dirty rule."""
+        pidx = _i64(param_idx)
+        out = np.zeros(8, np.int64)
+        check(lib().gst_get_fd_work(self._h, _ptr(pidx), len(pidx), _ptr(out)))
+        keys = ("wave_applies_executed", "col_applies_executed", "wave_dots_executed", "col_dots_executed",
+                "wave_applies_schedule", "col_applies_schedule", "n_waves", "n_tasks")
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def state_graph(self):
         n = C.c_int64(0)

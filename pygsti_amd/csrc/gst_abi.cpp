@@ -935,4 +935,34 @@ int gst_get_fd_queues(gst_plan* p, const int64_t* param_idx, int64_t n_param, in
     });
 }
 
+int gst_get_fd_work(gst_plan* p, const int64_t* param_idx, int64_t n_param, int64_t* out)
+{
+    return guarded([&]() -> int {
+    if (!p || !out || n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad argument");
+    if (p->hp.D == 64) return fail(GST_EUNSUPPORTED, "the lane-per-model walk exists for D <= 16");
+    if (p->hp.n_gates > 64) return fail(GST_EUNSUPPORTED, "more than 64 gates");
+    int rc = check_params(p, param_idx, n_param);
+    if (rc) return rc;
+    LaneLayout L;
+    pack_lanes(p, param_idx, nullptr, n_param, L, false);
+    std::vector<uint64_t> wg((size_t)L.n_waves, 0);
+    std::vector<uint8_t> wr((size_t)L.n_waves, 0), we((size_t)L.n_waves, 0);
+    std::vector<int32_t> wc((size_t)L.n_waves, 0);
+    for (size_t q = 0; q < L.col.size(); q++) {
+        if (L.col[q] < 0) continue;
+        const size_t w = q / 64;
+        wc[w]++;
+        if (L.kind[0][q] == GST_KIND_GATE) wg[w] |= 1ull << L.obj[0][q];
+        else if (L.kind[0][q] == GST_KIND_RHO) wr[w] = 1;
+        else if (L.kind[0][q] == GST_KIND_EFFECT) we[w] = 1;
+    }
+    int64_t work[6];
+    gst::fd_executed_work(p->hp, wg, wr, we, wc, work);
+    for (int i = 0; i < 6; i++) out[i] = work[i];
+    out[6] = L.n_waves;
+    out[7] = p->hp.n_tasks();
+    return GST_OK;
+    });
+}
+
 }  // extern "C"

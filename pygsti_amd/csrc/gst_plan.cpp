@@ -407,6 +407,48 @@ void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost)
     }
 }
 
+void fd_executed_work(const HostPlan& P, const std::vector<uint64_t>& wave_gates, const std::vector<uint8_t>& wave_rho,
+                      const std::vector<uint8_t>& wave_eff, const std::vector<int32_t>& wave_cols, int64_t out[6])
+{
+    for (int i = 0; i < 6; i++) out[i] = 0;
+    const int64_t nT = P.n_tasks();
+    const size_t nW = wave_gates.size();
+    std::vector<uint64_t> slot(64, 0);
+    for (size_t w0 = 0; w0 < nW; w0 += 64) {                  // 64 wavefronts at a time: one bit each
+        const size_t nb = std::min<size_t>(64, nW - w0);
+        std::vector<uint64_t> gate_waves((size_t)std::max(P.n_gates, 1), 0);
+        uint64_t rho_waves = 0, eff_waves = 0;
+        int64_t cols_all = 0;
+        for (size_t b = 0; b < nb; b++) {
+            for (uint64_t m = wave_gates[w0 + b]; m; m &= m - 1) gate_waves[(size_t)__builtin_ctzll(m)] |= 1ull << b;
+            if (wave_rho[w0 + b]) rho_waves |= 1ull << b;
+            if (wave_eff[w0 + b]) eff_waves |= 1ull << b;
+            cols_all += wave_cols[w0 + b];
+        }
+        auto cols_of = [&](uint64_t mask) { int64_t c = 0; for (uint64_t m = mask; m; m &= m - 1) c += wave_cols[w0 + (size_t)__builtin_ctzll(m)]; return c; };
+        for (int64_t t = 0; t < nT; t++) {
+            uint64_t dirty = 0;
+            uint64_t last_mask = ~0ull; int64_t last_cols = 0;          // (the mask changes rarely along a chain)
+            for (int64_t k = P.task_off[t]; k < P.task_off[t + 1]; k++) {
+                const uint32_t w = P.prog[k], op = GST_OP(w), arg = GST_ARG(w);
+                if (op == GST_OP_APPLY) {
+                    dirty |= gate_waves[arg];
+                    if (dirty != last_mask) { last_mask = dirty; last_cols = cols_of(dirty); }
+                    out[0] += __builtin_popcountll(dirty); out[1] += last_cols;
+                    out[4] += (int64_t)nb; out[5] += cols_all;
+                } else if (op == GST_OP_SAVE) { if (arg < 64) slot[arg] = dirty; }
+                else if (op == GST_OP_LOAD) { if (arg < 64) dirty = slot[arg]; }
+                else if (op == GST_OP_RHO) dirty = rho_waves;
+                else if (op == GST_OP_EMIT) {
+                    const int64_t n_out = P.eff_ptr[arg + 1] - P.eff_ptr[arg];
+                    const uint64_t real = dirty | eff_waves;
+                    out[2] += n_out * __builtin_popcountll(real); out[3] += n_out * cols_of(real);
+                }
+            }
+        }
+    }
+}
+
 void build_dirty_programs(const HostPlan& P, DirtyPrograms& out)
 {
     const int nG = P.n_gates, nR = P.n_rhos, nC = nG + nR;

@@ -61,6 +61,17 @@ std::string compile_plan(HostPlan& P, int32_t target_tasks, int32_t max_slots);
 // (task, wavefront) pairs first.  Empty result when n_gates > 64.
 void task_gate_costs(const HostPlan& P, std::vector<int32_t>& cost);
 
+// EXACT work of one finite-difference pass of the lane-per-model walk (gst_kernels.hip) for a given set of wavefronts, by
+// the kernel's own clean/dirty rule: wavefront w computes a gate application only once a gate one of its lanes perturbs
+// (wave_gates[w], bit per gate) has been applied on the path -- or from the start when a lane perturbs a preparation
+// (wave_rho[w]); SAVE / LOAD carry the flag; an EMIT costs real dot products when the state is dirty or a lane perturbs an
+// effect (wave_eff[w]), otherwise it stores exact zeros.  wave_cols[w] = live lanes of w (<= 64).
+// out[0] = wavefront-applications executed, out[1] = column-applications executed (live lanes only),
+// out[2] = wavefront-dots executed, out[3] = column-dots executed, out[4] = wavefront-applications of the whole schedule
+// (n_waves * applies_per_pass: what a kernel without the rule would execute), out[5] = column-applications of the schedule.
+void fd_executed_work(const HostPlan& P, const std::vector<uint64_t>& wave_gates, const std::vector<uint8_t>& wave_rho,
+                      const std::vector<uint8_t>& wave_eff, const std::vector<int32_t>& wave_cols, int64_t out[6]);
+
 // Hand-over points of the derivative walks (persistent launch of small atoms): for every task a program position
 // (word index relative to the task's first word, or -1) at which NO save slot is live, so that a walk can be cut there
 // into two halves that run on different SIMDs -- the first stores its 64 lane states, the second picks them up -- and

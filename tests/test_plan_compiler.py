@@ -4,7 +4,7 @@ probabilities bit for bit, for every slot budget / task granularity."""
 import numpy as np
 import pytest
 
-from conftest import load_fixture, assert_bitwise
+from conftest import load_fixture, assert_bitwise, plan_from_fixture
 from _interp import run_programs
 from pygsti_amd import _lib
 
@@ -168,3 +168,51 @@ def test_dirty_programs_reproduce_the_perturbed_walk(name):
         assert np.array_equal(got.view(np.uint64), full.view(np.uint64)), "class %d" % cls
         assert (full != base).any()
     assert checked_gate > 0 and checked_rho > 0
+
+
+@pytest.mark.parametrize("name", ["smq1Q_XYI_L4_depol", "smq2Q_XYICNOT_L2_depol"])
+def test_fd_work_counts_what_the_kernel_executes(name):
+    """gst_get_fd_work (bench.py's `roofline.executed`): the plan's programs walked with the FD kernel's clean/dirty rule --
+    checked here against a direct per-wavefront Python walk of the same programs (one wavefront = 64 consecutive lanes of
+    the packed columns: preparation / effect parameters first, then each gate's on wavefronts of its own)."""
+    from pygsti_amd import _lib
+    fx = load_fixture(name)
+    pl = plan_from_fixture(fx)
+    nP, D = int(fx["nP"]), int(fx["D"])
+    got = pl.fd_work(np.arange(nP))
+    words, off = pl.program()
+    # the lane packing of gst_fill_fd.cpp::pack_lanes for the `full` element map
+    spam = [p for p in range(nP) if fx["pkind"][p] != 0]
+    waves = [spam[i:i + 64] for i in range(0, len(spam), 64)]
+    for g in range(len(fx["gates"])):
+        mine = [p for p in range(nP) if fx["pkind"][p] == 0 and fx["pobj"][p] == g]
+        if len(mine) >= 32 or not waves or len(waves[-1]) == 64:
+            waves += [mine[i:i + 64] for i in range(0, len(mine), 64)]
+        else:
+            room = 64 - len(waves[-1]); waves[-1] = waves[-1] + mine[:room]
+            waves += [mine[i:i + 64] for i in range(room, len(mine), 64)]
+    assert got["n_waves"] == len(waves) and got["n_tasks"] == len(off) - 1
+    ex_w = ex_c = dots_w = dots_c = sched = 0
+    n_out = np.diff(fx["eff_ptr"])
+    for cols in waves:
+        gates = {int(fx["pobj"][p]) for p in cols if fx["pkind"][p] == 0}
+        rho = any(fx["pkind"][p] == 1 for p in cols); eff = any(fx["pkind"][p] == 2 for p in cols)
+        for t in range(len(off) - 1):
+            dirty = False; slot = {}
+            for w in words[off[t]:off[t + 1]]:
+                op, arg = int(w) >> 28, int(w) & 0x0FFFFFFF
+                if op == _lib.OP_RHO: dirty = rho
+                elif op == _lib.OP_APPLY:
+                    dirty = dirty or arg in gates
+                    sched += 1
+                    if dirty: ex_w += 1; ex_c += len(cols)
+                elif op == _lib.OP_SAVE: slot[arg] = dirty
+                elif op == _lib.OP_LOAD: dirty = slot[arg]
+                elif op == _lib.OP_EMIT and (dirty or eff):
+                    dots_w += int(n_out[arg]); dots_c += int(n_out[arg]) * len(cols)
+    assert (got["wave_applies_executed"], got["col_applies_executed"]) == (ex_w, ex_c)
+    assert (got["wave_dots_executed"], got["col_dots_executed"]) == (dots_w, dots_c)
+    assert got["wave_applies_schedule"] == sched == len(waves) * pl.stats()["applies_per_pass"]
+    # (1Q: all 60 parameters share ONE wavefront that perturbs the preparation -- nothing is clean; 2Q: 26 wavefronts)
+    assert 0 < got["col_applies_executed"] <= got["col_applies_schedule"]
+    assert (got["col_applies_executed"] < got["col_applies_schedule"]) == (len(waves) > 1)
