@@ -258,6 +258,50 @@ int gst_set_lindblad(gst_plan *plan, int32_t n_params, int32_t n_members, const 
 int gst_set_lindblad_params(gst_plan *plan, const double *theta);
 /* The plan's current dense model (row-major, the layout of gst_set_model); any pointer may be NULL. */
 int gst_get_model(gst_plan *plan, double *gates, double *rhos, double *effects);
+
+/* Implicit models (pyGSTi's LocalNoiseModel / CloudNoiseModel, e.g. create_crosstalk_free_model): a circuit layer is not a
+ * stored dense superoperator but a ComposedOp of EmbeddedOps -- small one- and two-qubit operations embedded into the
+ * register (pygsti/modelmembers/operations/embeddedop.py, composedop.py; reps: evotypes/densitymx/opcreps.cpp:93-158
+ * `OpCRep_Embedded::acton`, :242-276 `OpCRep_Composed::acton`), and one small operation usually stands behind several
+ * layers (`independent_gates=False`), so its parameters are SHARED between the plan's gates.  The reference's Map path
+ * steps such a parameter with set_parameter_value (models/model.py:1198-1310: every member that holds it moves) and walks the
+ * circuits through the reps factor by factor.  gst_set_composite describes that structure once; afterwards the DEVICE builds
+ * the dense layers, the complete perturbed model of every finite-difference column, and the layers' exact derivative
+ * matrices -- no host to_dense() / deriv_wrt_params() per model update or per column.
+ *   leaves:   n_leaves dense operations of dimension leaf_dim[l] (4 / 16 / 64 = one / two / three qubits); their elements
+ *             (row-major) concatenated; leaf_param[e] = the model parameter that IS element e (FullArbitraryOp, the rows of
+ *             a FullTPOp ...), -1 for elements that are no parameter (static leaves, a TP operation's first row).
+ *   factors:  factor f = leaf factor_leaf[f] embedded on the qubits factor_targets[3 f .. 3 f + 2] (as many as the leaf has
+ *             qubits, in the order of the leaf's own tensor factors; the rest -1).  Qubit 0 is the most significant base-4
+ *             digit of the state index (the register's Pauli-product basis is the Kronecker product in qubit order).
+ *   layers:   gate g of the plan = Emb(f_{n-1}) ... Emb(f_1) Emb(f_0) over factors gate_factor_ptr[g] .. gate_factor_ptr[g+1]
+ *             (f_0 acts first, as ComposedOp applies its factorops in order); an empty list is the identity.
+ * Preparations and effects stay dense vectors; parameters that are elements of those are declared as usual with
+ * gst_set_param_map (GST_KIND_NONE for every parameter that belongs to a leaf).
+ *   gst_set_composite          copies the description (NULL or n_leaves = 0 clears).  D = 4, 16, 64.
+ *   gst_set_composite_values   takes the leaves' current elements (same concatenation) and the dense preparations / effects
+ *       -- call it where gst_set_model would be called, after every model.from_vector(); the device builds every layer and the
+ *       result is the plan's model for ALL fills (gst_get_model reads it back).
+ * While set, GST_DERIV_FD columns of gst_fill_dprobs(_dev) are mapfill_dprobs_atom's for such a model
+ * (mapforwardsim_calc_densitymx.pyx:349-381): per column the device moves every leaf element that is the parameter by eps,
+ * rebuilds the layers that contain the leaf, and walks the circuits with that complete dense model (the whole-model walk of
+ * gst_fill_dprobs_models, fed from device memory).  Accuracy as gst_fill_dprobs_models: the reference propagates factor by
+ * factor, this path through the dense product -- probabilities to ~1e-15, quotients to ~1e-8, not bit for bit.
+ * GST_DERIV_ANALYTIC columns are exact: the device forms every layer's d(dense)/d(parameter) by the product rule over its
+ * factors (what ComposedOp / EmbeddedOp.deriv_wrt_params() hand to MatrixForwardSimulator._doperation) and applies the chain
+ * rule to the element Jacobian (<= 1e-8 against the Matrix simulator).  Exact HESSIAN blocks of such models are not built
+ * here (a layer is bilinear in two leaves): use gst_set_derivs + gst_set_second_derivs for those.  An explicit
+ * gst_set_derivs takes precedence in the analytic mode. */
+typedef struct gst_composite_desc {
+    int32_t n_leaves;
+    const int32_t *leaf_dim;          /* [n_leaves] */
+    const int64_t *leaf_param;        /* [sum leaf_dim^2] */
+    const int32_t *gate_factor_ptr;   /* [n_gates + 1] */
+    const int32_t *factor_leaf;       /* [n_factors] */
+    const int32_t *factor_targets;    /* [n_factors][3] */
+} gst_composite_desc;
+int gst_set_composite(gst_plan *plan, int32_t n_params, const gst_composite_desc *desc);
+int gst_set_composite_values(gst_plan *plan, const double *leaf_values, const double *rhos, const double *effects);
 /* The dense models the device builds for the finite-difference steps of parameters param_idx (theta_p + eps each):
  * gates[n][n_gates][D][D], rhos[n][n_rhos][D], effects[n][n_effects][D] (host; tests compare them with the reference's). */
 int gst_get_lindblad_model_sets(gst_plan *plan, const int64_t *param_idx, int64_t n_param, double eps, double *gates,

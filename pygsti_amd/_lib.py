@@ -65,6 +65,11 @@ class LindbladMemberDesc(C.Structure):
                 ("param0", C.c_int64), ("term_offset", C.c_int64), ("static_part", C.c_void_p)]
 
 
+class CompositeDesc(C.Structure):
+    _fields_ = [("n_leaves", C.c_int32), ("leaf_dim", C.c_void_p), ("leaf_param", C.c_void_p), ("gate_factor_ptr", C.c_void_p),
+                ("factor_leaf", C.c_void_p), ("factor_targets", C.c_void_p)]
+
+
 class CommInfo(C.Structure):
     _fields_ = [("transport", C.c_int32), ("rank", C.c_int32), ("size", C.c_int32), ("device", C.c_int32),
                 ("rccl_version", C.c_int32), ("ipc_opens", C.c_int32), ("reserved", C.c_int32 * 2)]
@@ -84,7 +89,7 @@ EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_p
            "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_get_fd_work", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
-           "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_get_model", "gst_get_lindblad_model_sets",
+           "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_set_composite", "gst_set_composite_values", "gst_get_model", "gst_get_lindblad_model_sets",
            "gst_comm_get_unique_id", "gst_comm_create", "gst_comm_destroy", "gst_comm_allgather_rows",
            "gst_comm_gather_rows", "gst_comm_exchange_blocks", "gst_comm_allreduce_sum", "gst_comm_barrier", "gst_comm_sync", "gst_comm_get_info"]
 
@@ -123,6 +128,8 @@ def lib():
         L.gst_memcpy_h2d.argtypes = [vp, vp, vp, i64]
         L.gst_copy_block_dev.argtypes = [vp, vp, i64, vp, i64, i64, i64]
         L.gst_sync.argtypes = [vp]
+        L.gst_set_composite.argtypes = [vp, i32, C.POINTER(CompositeDesc)]
+        L.gst_set_composite_values.argtypes = [vp, vp, vp, vp]
         L.gst_device_malloc.argtypes = [vp, i64, C.POINTER(vp)]
         L.gst_device_malloc_tracked.argtypes = [vp, i64, C.POINTER(vp)]
         L.gst_device_free.argtypes = [vp, vp]
@@ -377,6 +384,27 @@ class Plan:
             d.param0 = m.param0; d.term_offset = offsets[k]; d.static_part = st.ctypes.data
         check(lib().gst_set_lindblad(self._h, int(model.num_params), len(members), arr, int(n_terms), _ptr(term_re), _ptr(term_im)))
         self.n_params = int(model.num_params)
+
+    def set_composite(self, model):
+        """gst_set_composite: the layer structure of an implicit model (a composite.CompositeModel; None clears)."""
+        if model is None:
+            check(lib().gst_set_composite(self._h, 0, None))
+            self._composite = None
+            return
+        assert len(model.gate_factors) == self.n_gates and model.D == self.D
+        leaf_dim, leaf_param, fptr, fl, ft = model.arrays()
+        keep = [_i32(leaf_dim), _i64(leaf_param), _i32(fptr), _i32(fl) if len(fl) else np.zeros(1, np.int32),
+                _i32(ft) if len(ft) else np.full((1, 3), -1, np.int32)]
+        d = CompositeDesc(len(leaf_dim), *[a.ctypes.data for a in keep])
+        check(lib().gst_set_composite(self._h, int(model.num_params), C.byref(d)))
+        self._composite = model
+        self.n_params = int(model.num_params)
+
+    def set_composite_values(self, leaf_values, rhos, effects):
+        """gst_set_composite_values: the leaves' current elements + the dense SPAM vectors; the device builds every layer."""
+        v = _f64(leaf_values)
+        r = _f64(rhos).reshape(self.n_rhos, self.D); e = _f64(effects).reshape(self.n_effects, self.D)
+        check(lib().gst_set_composite_values(self._h, _ptr(v), _ptr(r), _ptr(e)))
 
     def set_lindblad_params(self, theta):
         """The model's parameter vector: the device builds every dense member from it (gst_set_lindblad_params)."""

@@ -465,7 +465,14 @@ int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (!d_out && n_param > 0) return fail(GST_EINVAL, "d_out is NULL");
     // what this call overwrites no longer holds an earlier exact Jacobian's zeros (the plain exact fill keeps its own books)
     if (d_probs_out) gst::track_touch(d_probs_out, (size_t)p->hp.n_elements * 8);
-    if (n_param > 0 && (mode == GST_DERIV_FD || p->lb.set || p->derivs_set)) gst::track_touch(d_out, jac_extent(p->hp.n_elements, ld, dest_idx, n_param));
+    if (n_param > 0 && (mode == GST_DERIV_FD || p->lb.set || p->cmp.set || p->derivs_set)) gst::track_touch(d_out, jac_extent(p->hp.n_elements, ld, dest_idx, n_param));
+    if (p->cmp.set && (mode == GST_DERIV_FD || !p->derivs_set)) {        // implicit models: device-built layers (gst_set_composite)
+        if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
+        if (mode == GST_DERIV_FD) rc = run_dprobs_composite(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out);
+        else rc = run_dprobs_composite_analytic(p, d_out, ld, param_idx, dest_idx, n_param, d_probs_out);
+        if (rc) return rc;
+        return end_call(p, false);
+    }
     if (p->lb.set && !p->derivs_set) {
         if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
         if (mode == GST_DERIV_FD) rc = run_dprobs_lindblad(p, d_out, ld, param_idx, dest_idx, n_param, eps, d_probs_out);
@@ -501,6 +508,14 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     if (rc) return rc;
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!out && n_param > 0) return fail(GST_EINVAL, "out is NULL");
+    if (p->cmp.set && (mode == GST_DERIV_FD || !p->derivs_set)) {
+        if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
+        if ((rc = stage_out(p, (size_t)p->hp.n_elements * std::max<int64_t>(n_param, 1)))) return rc;
+        if (mode == GST_DERIV_FD) rc = run_dprobs_composite(p, p->d_out.p, n_param, param_idx, nullptr, n_param, eps, nullptr);
+        else rc = run_dprobs_composite_analytic(p, p->d_out.p, n_param, param_idx, nullptr, n_param, nullptr);
+        if (rc) return rc;
+        return copy_out_dprobs(p, out, ld, dest_idx, n_param, probs_out);
+    }
     if (p->lb.set && (mode == GST_DERIV_FD || !p->derivs_set)) {
         if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
         if ((rc = stage_out(p, (size_t)p->hp.n_elements * std::max<int64_t>(n_param, 1)))) return rc;

@@ -306,6 +306,34 @@ hipError_t launch_lindblad_build(int D, const LbArgs& a, int64_t n_sets, hipStre
 // [n_elem][n_params[m]] matrix at deriv_out + deriv_off[m] (a POVM: n_eff matrices [D][n_params] one after another)
 hipError_t launch_lindblad_derivs(int D, const LbArgs& a, int64_t n_params_total, hipStream_t stream);
 
+// Layer operations of implicit models (gst_kernels_composite.hip): layer g = Emb(f_{n-1}) ... Emb(f_0) over its factors
+// gate_fptr[g] .. gate_fptr[g + 1]; factor f embeds leaf factor_leaf[f] (leaf_dim x leaf_dim, row-major values at
+// leaf_values + leaf_off, the model parameter of each element in leaf_param, -1 = none) on the qubits factor_targets[f][0..2]
+// (-1 = unused; qubit 0 = most significant base-4 digit of the state index).
+struct CompositeArgs {
+    int32_t D, nq, n_gates, n_rhos, n_effects, n_leaves, max_leaf_dim;
+    const int32_t *leaf_dim;
+    const int64_t *leaf_off, *leaf_param;
+    const double* leaf_values;
+    const int32_t *gate_fptr, *factor_leaf, *factor_targets;
+    const double *rhos, *effects;            // the base SPAM vectors
+    const int32_t *pkind, *pobj, *pelem;     // the plan's parameter map (SPAM columns of the model sets), or NULL
+    const int64_t* set_param;                // [n_sets]: the parameter stepped in each set, or NULL (base build)
+    const double* base_set;                  // the base model in set layout (layers a step does not move are copied), or NULL
+    double eps;
+    double* sets;                            // [n_sets][set_stride]: [gates_t | rhos | effects]
+    int64_t set_stride;
+    double* gates_rowmajor;                  // base build only (may be NULL)
+    // launch_composite_derivs: work item = one column of one layer's derivative matrix
+    const int32_t *item_gate, *item_col;
+    const int64_t *item_param;
+    const int32_t* gate_ncols;               // [n_gates]
+    const int64_t* gate_doff;                // [n_gates]: offset of layer g's [D*D][ncols] matrix in deriv_out
+    double* deriv_out;
+};
+hipError_t launch_composite_build(const CompositeArgs& a, int64_t n_sets, hipStream_t stream);
+hipError_t launch_composite_derivs(const CompositeArgs& a, int64_t n_items, hipStream_t stream);
+
 // Finite-difference walks for columns that change a whole object (gst_kernels_pert.hip): a work item is a task's dirty
 // program for the member's class walked for the 64/D columns col0 .. col0 + ncols of ONE member (kind / obj / n_eff of
 // parameter wavefront pw); column c's changed member sits at pert + c * pert_stride (layout as LbArgs::member_only), its

@@ -210,6 +210,17 @@ struct gst_plan {
         std::vector<int64_t> param0, term_off, static_off;
         std::vector<double> statics, term_re, term_im, theta;
     } lb;
+    // gst_set_composite: layer operations of implicit models = products of embedded leaves, built on the device
+    struct Composite {
+        bool set = false, have_values = false, uploaded = false;
+        int32_t n_params = 0, n_leaves = 0, max_leaf_dim = 0;
+        std::vector<int32_t> leaf_dim, gate_fptr, factor_leaf, factor_targets;
+        std::vector<int64_t> leaf_off, leaf_param;
+        std::vector<std::vector<int64_t>> gate_params;      // per layer: the distinct parameters of its factors' leaves, ascending
+    } cmp;
+    DevBuf<int32_t> d_cmp_i32, d_cmp_pmap, d_cmp_items32;   // leaf_dim | gate_fptr | factor_leaf | factor_targets; the parameter map; deriv items
+    DevBuf<int64_t> d_cmp_i64, d_cmp_setparam;              // leaf_off | leaf_param; the stepped parameter of each set / deriv item tables
+    DevBuf<double> d_cmp_values, d_cmp_spam, d_cmp_base, d_cmp_gates_rm;
     DevBuf<int32_t> d_lb_i32;               // kind | obj | n_eff | n_par | n_blocks | blk_type | blk_mode | blk_n
     DevBuf<int64_t> d_lb_i64, d_lb_setparam;   // param0 | term_off | static_off; the stepped parameter of each set
     DevBuf<double> d_lb_statics, d_lb_term_re, d_lb_term_im, d_lb_theta, d_lb_base, d_lb_gates_rm, d_lb_pert;
@@ -299,6 +310,8 @@ struct gst_plan {
         (void)hipSetDevice(device);
         if (d_out.p) gst::track_touch(d_out.p, d_out.n * 8);
         if (d_jelem.p) gst::track_touch(d_jelem.p, d_jelem.n * 8);
+        d_cmp_i32.release(); d_cmp_pmap.release(); d_cmp_items32.release(); d_cmp_i64.release(); d_cmp_setparam.release();
+        d_cmp_values.release(); d_cmp_spam.release(); d_cmp_base.release(); d_cmp_gates_rm.release();
         d_lb_i32.release(); d_lb_i64.release(); d_lb_setparam.release(); d_lb_statics.release(); d_lb_term_re.release();
         d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release(); d_jtj_pmask.release(); for (auto& b : d_lbr_lane) b.release(); d_lbr_order.release();
         d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release();
@@ -377,6 +390,8 @@ int begin_call(gst_plan* p);
 int end_call(gst_plan* p, bool sync);
 int run_element_jacobian(gst_plan* p, double* d_probs_out);
 int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx, int64_t n_param, double* d_probs_out);
+int run_dprobs_composite(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx, int64_t n_param, double eps, double* d_probs_out);
+int run_dprobs_composite_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx, int64_t n_param, double* d_probs_out);
 int run_dprobs_lindblad_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx, int64_t n_param, double* d_probs_out);
 
 // device address of a host pointer inside a region registered with gst_host_register, or NULL (gst_abi.cpp)

@@ -282,6 +282,98 @@ def atom_second_derivs(model, atom):
     return out
 
 
+def _element_selection(member, n_el):
+    """int64 [n_el]: the model parameter that IS each dense element of `member` (-1: not a parameter), for members whose
+    deriv_wrt_params is a 0/1 selection with at most one parameter per element and one element per parameter (FullArbitraryOp,
+    FullTPOp, FullState, TPState, FullPOVMEffect, static members ...); NotImplementedError otherwise."""
+    idx = np.asarray(member.gpindices_as_array(), np.int64)
+    sel = -np.ones(n_el, np.int64)
+    if len(idx) == 0:
+        return sel
+    dm = np.asarray(member.deriv_wrt_params())
+    if np.iscomplexobj(dm):
+        dm = np.real(dm)
+    dm = dm.reshape(n_el, len(idx))
+    rows, cols = np.nonzero(dm)
+    if len(rows) != len(idx) or len(set(cols.tolist())) != len(idx) or len(set(rows.tolist())) != len(rows) or not np.all(dm[rows, cols] == 1.0):
+        raise NotImplementedError("member %s is not one-parameter-per-dense-element" % type(member).__name__)
+    sel[rows] = idx[cols]
+    return sel
+
+
+def atom_composite(model, atom):
+    """The layer structure of an implicit model for gst_set_composite: every operation label of the atom resolved into an
+    ordered product of EMBEDDED LEAVES -- `ComposedOp.factorops` in order of application, `EmbeddedOp.embedded_op` on
+    `target_labels` (modelmembers/operations/composedop.py, embeddedop.py), nested as deep as they come -- with leaves
+    identified by object identity (so a leaf that stands behind several layers, `independent_gates=False`, is ONE leaf and
+    its parameters are shared, exactly as set_parameter_value moves them, models/model.py:1198-1310).  Leaves must be
+    one-parameter-per-element or static (FullArbitraryOp, FullTPOp, StaticArbitraryOp ...).
+    Returns (composite.CompositeModel, (kind, obj, elem) parameter map of the SPAM elements); NotImplementedError for
+    anything else (Lindblad leaves, leaves on more than three qubits, non-qubit registers ...)."""
+    from .composite import CompositeModel
+    D, nP = model.dim, model.num_params
+    if D not in (4, 16, 64):
+        raise NotImplementedError("composite layers are built on the device for one to three qubits")
+    nq = {4: 1, 16: 2, 64: 3}[D]
+    leaves, leaf_dims, leaf_params, leaf_static = {}, [], [], []
+
+    def leaf_of(op):
+        key = id(op)
+        if key not in leaves:
+            d = int(op.dim)
+            if d not in (4, 16, 64) or d > D:
+                raise NotImplementedError("a leaf operation of dimension %d" % d)
+            leaf_params.append(_element_selection(op, d * d))
+            leaf_static.append(np.ascontiguousarray(np.real(op.to_dense("HilbertSchmidt")), dtype=np.float64).ravel())
+            leaf_dims.append(d)
+            leaves[key] = (len(leaf_dims) - 1, op)         # (the op is kept alive: ids are only unique among live objects)
+        return leaves[key][0]
+
+    def expand(op, qubits):
+        """-> [(leaf, target positions)] in order of application; `qubits`: register position of each qubit of op's space"""
+        name = type(op).__name__
+        if name == "ComposedOp":
+            out = []
+            for f in op.factorops:
+                out.extend(expand(f, qubits))
+            return out
+        if name == "EmbeddedOp":
+            lbls = list(op.state_space.sole_tensor_product_block_labels)
+            if len(lbls) != len(qubits):
+                raise NotImplementedError("an embedded operation over a non-qubit space")
+            inner = tuple(qubits[lbls.index(t)] for t in op.target_labels)
+            return expand(op.embedded_op, inner)
+        if getattr(op, "factorops", None) is not None or hasattr(op, "embedded_op") or hasattr(op, "errorgen"):
+            raise NotImplementedError("layer member %s" % name)
+        if int(op.dim) != 4 ** len(qubits):
+            raise NotImplementedError("a leaf that does not fill its target qubits")
+        return [(leaf_of(op), tuple(qubits))]
+
+    gate_factors = []
+    for lbl in atom.op_labels:
+        op = model._circuit_layer_operator(lbl, "op")
+        lbls = list(op.state_space.sole_tensor_product_block_labels)
+        if len(lbls) != nq:
+            raise NotImplementedError("a register that is not %d qubits" % nq)
+        gate_factors.append(expand(op, tuple(range(nq))))
+    if not any(len(f) > 1 or (len(f) == 1 and leaf_dims[f[0][0]] < D) for f in gate_factors):
+        raise NotImplementedError("every layer is one dense operation: not an implicit model")
+    kind = -np.ones(nP, np.int32); obj = np.zeros(nP, np.int32); elem = np.zeros(nP, np.int32)
+    for k, labels, typ in ((_lib.KIND_RHO, list(atom.rho_labels), "prep"), (_lib.KIND_EFFECT, atom._hip_eff_labels, "povm")):
+        for oi, lbl in enumerate(labels):
+            sel = _element_selection(model._circuit_layer_operator(lbl, typ), D)
+            hit = np.nonzero(sel >= 0)[0]
+            if (kind[sel[hit]] != -1).any():
+                raise NotImplementedError("a SPAM parameter shared between members")
+            kind[sel[hit]] = k; obj[sel[hit]] = oi; elem[sel[hit]] = hit
+    leaf_owned = np.concatenate(leaf_params) if leaf_params else np.zeros(0, np.int64)
+    if (kind[leaf_owned[leaf_owned >= 0]] != -1).any():
+        raise NotImplementedError("a parameter shared between a layer operation and a SPAM member")
+    cm = CompositeModel(D, nP, leaf_dims, leaf_params, leaf_static, gate_factors)
+    cm._leaf_ops = [op for _, op in sorted(leaves.values(), key=lambda t: t[0])]
+    return cm, (kind, obj, elem)
+
+
 def atom_plan(model, atom, device=-1, target_tasks=0):
     """The libgstfwd plan of a `_MapCOPALayoutAtom`, built once and cached on the atom.
 
@@ -359,7 +451,8 @@ class AtomFillLogic:
     it into pyGSTi's MapForwardSimulator; tests/test_gpu_adapter_modes.py drives it on the GPU box -- where pyGSTi does
     not exist -- with stand-in models and atoms built from the committed fixtures."""
     # (expects on `self`: model, derivative_eps, hessian_eps, derivative_mode, lindblad_on_device, _hip_device -- no
-    #  defaults here: class attributes of a mixin would shadow pyGSTi's `model` property)
+    #  defaults for those here: class attributes of a mixin would shadow pyGSTi's `model` property)
+    composite_on_device = True      # implicit models: dense layers / FD model sets / derivative matrices built on the device
 
     def _lindblad_description(self, layout_atom):
         """The atom's Lindblad member description (None when the model is not of that family), cached per model."""
@@ -387,7 +480,7 @@ class AtomFillLogic:
         if self.derivative_mode != "auto":
             return self.derivative_mode
         key = getattr(layout_atom, "_hip_auto_key", (None, None))
-        if key[0] is not self.model or key[1] != bool(self.lindblad_on_device):
+        if key[0] is not self.model or key[1] != (bool(self.lindblad_on_device), bool(self.composite_on_device)):
             mode = "fd"
             try:
                 atom_param_map(self.model, layout_atom)
@@ -400,12 +493,13 @@ class AtomFillLogic:
                     # give them (deriv_wrt_params unimplemented) sends the atom back to finite differences over
                     # host-stepped dense model sets -- what 'fd' did for every such model before 'auto' existed
                     mode = "analytic"
-                    if not (self.lindblad_on_device and self._lindblad_description(layout_atom) is not None):
+                    if not (self.lindblad_on_device and self._lindblad_description(layout_atom) is not None) and \
+                            not (self.composite_on_device and self._composite_description(layout_atom) is not None):
                         try:
                             atom_derivs(self.model, layout_atom)
                         except (NotImplementedError, AttributeError):
                             mode = "fd"
-            layout_atom._hip_auto_mode, layout_atom._hip_auto_key = mode, (self.model, bool(self.lindblad_on_device))
+            layout_atom._hip_auto_mode, layout_atom._hip_auto_key = mode, (self.model, (bool(self.lindblad_on_device), bool(self.composite_on_device)))
         return layout_atom._hip_auto_mode
 
     def _prepare(self, layout_atom, derivatives=False, hessian=False):
@@ -425,15 +519,32 @@ class AtomFillLogic:
                 plan._hip_mode = "lindblad"
             plan.set_lindblad_params(self.model.to_vector())
             return plan
+        # Implicit models (layers = products of embedded leaves, parameters shared between layers) with `composite_on_device`:
+        # the device builds the dense layers from the leaves' few elements -- for the base model, for every finite-difference
+        # column and for the exact route's derivative matrices -- so nothing of size D x D is densified on the host, per model
+        # update or per column.  Exact HESSIAN requests leave this route (a layer is bilinear in two leaves).
+        if self.composite_on_device and not hessian and self._composite_description(layout_atom) is not None:
+            cm, spam_map = layout_atom._hip_cmp
+            if getattr(plan, "_hip_mode", None) != "composite":
+                self._leave_lindblad(plan, layout_atom)
+                plan.set_derivs(self.model.num_params, [])
+                plan.set_complement_effect(-1)
+                plan.set_param_map(*spam_map)
+                plan.set_composite(cm)
+                plan._hip_mode = "composite"
+            D = self.model.dim
+
+            def vec(lbl, typ):
+                return np.ascontiguousarray(np.real(self.model._circuit_layer_operator(lbl, typ).to_dense("minimal")), dtype=np.float64).reshape(D)
+            rhos = np.array([vec(l, "prep") for l in layout_atom.rho_labels]).reshape(len(layout_atom.rho_labels), D)
+            effects = np.array([vec(l, "povm") for l in layout_atom._hip_eff_labels]).reshape(len(layout_atom._hip_eff_labels), D)
+            plan.set_composite_values(cm.values(self.model.to_vector()), rhos, effects)
+            return plan
+        self._leave_composite(plan)
         plan.set_model(*atom_arrays(self.model, layout_atom))
         if not derivatives:
             return plan
-        if getattr(layout_atom, "_hip_pmap_model", None) is not self.model:
-            try:
-                layout_atom._hip_pmap = atom_param_map(self.model, layout_atom)     # one parameter per dense element
-            except NotImplementedError:
-                layout_atom._hip_pmap = None                                        # TP, CPTP, ...: chain rule
-            layout_atom._hip_pmap_model = self.model
+        self._element_map(layout_atom)
         if layout_atom._hip_pmap is not None:
             if plan.n_params != self.model.num_params or getattr(plan, "_hip_mode", None) != "elements":
                 self._leave_lindblad(plan, layout_atom)
@@ -481,6 +592,38 @@ class AtomFillLogic:
             plan.set_derivs(self.model.num_params, atom_derivs(self.model, layout_atom))
             plan._hip_mode = "derivs"
         return plan
+
+    def _element_map(self, layout_atom):
+        """atom_param_map of the current model, cached on the atom (None: not one-parameter-per-element)"""
+        if getattr(layout_atom, "_hip_pmap_model", None) is not self.model:
+            try:
+                layout_atom._hip_pmap = atom_param_map(self.model, layout_atom)     # one parameter per dense element
+            except NotImplementedError:
+                layout_atom._hip_pmap = None                                        # TP, CPTP, ...: chain rule
+            layout_atom._hip_pmap_model = self.model
+        return layout_atom._hip_pmap
+
+    def _composite_description(self, layout_atom):
+        """(CompositeModel, SPAM parameter map) of an implicit model's atom, or None: explicit models whose members are
+        dense elements keep the bit-exact element-map route; anything atom_composite cannot resolve keeps the chain-rule /
+        host-stepped routes.  Cached per model."""
+        if getattr(layout_atom, "_hip_cmp_model", None) is not self.model:
+            layout_atom._hip_cmp = None
+            if getattr(layout_atom, "_hip_eff_labels", None) is None:
+                layout_atom._hip_eff_labels = list(layout_atom.full_effect_labels)
+            if self._element_map(layout_atom) is None:
+                try:
+                    layout_atom._hip_cmp = atom_composite(self.model, layout_atom)
+                except (NotImplementedError, AttributeError):
+                    layout_atom._hip_cmp = None
+            layout_atom._hip_cmp_model = self.model
+        return layout_atom._hip_cmp
+
+    @staticmethod
+    def _leave_composite(plan):
+        if getattr(plan, "_hip_mode", None) == "composite":
+            plan.set_composite(None)
+            plan._hip_mode = None
 
     def _leave_lindblad(self, plan, layout_atom):
         """A plan that was in the device-built Lindblad mode and now serves another mode: drop the description (later
@@ -659,7 +802,8 @@ class HipMapForwardSimulator(AtomFillLogic, _MapForwardSimulator):
     derivatives (what MatrixForwardSimulator returns, to <= 1e-8), several times faster, and exact Hessian blocks."""
 
     def __init__(self, model=None, max_cache_size=None, num_atoms=None, processor_grid=None, param_blk_sizes=None,
-                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1, derivative_mode="auto", lindblad_on_device=True):
+                 derivative_eps=1e-7, hessian_eps=1e-5, device=-1, derivative_mode="auto", lindblad_on_device=True,
+                 composite_on_device=True):
         if not HAVE_PYGSTI:
             raise ImportError("pygsti is not importable; use pygsti_amd.forwardsim.HipMapForwardSimulator instead")
         if derivative_mode not in ("auto", "fd", "analytic"):
@@ -671,11 +815,15 @@ class HipMapForwardSimulator(AtomFillLogic, _MapForwardSimulator):
         # parameter vector for every finite-difference step (gst_set_lindblad); False = the model is stepped on the host
         # and the device evaluates the dense sets (gst_fill_dprobs_models; the validation path)
         self.lindblad_on_device = bool(lindblad_on_device)
+        # Implicit models (embedded / composed layer operations over shared leaves): True = the device builds the dense
+        # layers, every finite-difference column's model and the exact route's derivative matrices from the leaves
+        # (gst_set_composite); False = the members' to_dense() / deriv_wrt_params() on the host (the validation path)
+        self.composite_on_device = bool(composite_on_device)
 
     def copy(self, keep_model_attached=True):
         out = HipMapForwardSimulator(self.model if keep_model_attached else None, self._max_cache_size, self._num_atoms,
                                      self._processor_grid, self._pblk_sizes, self.derivative_eps, self.hessian_eps,
-                                     self._hip_device, self.derivative_mode, self.lindblad_on_device)
+                                     self._hip_device, self.derivative_mode, self.lindblad_on_device, self.composite_on_device)
         return out
 
     def _to_nice_serialization(self):
@@ -684,7 +832,8 @@ class HipMapForwardSimulator(AtomFillLogic, _MapForwardSimulator):
         (protocols/gst.py:1497-1504), and a run resumed from one must not silently change its derivative mode."""
         state = super()._to_nice_serialization()
         state.update({"hip_derivative_mode": self.derivative_mode, "hip_device": int(self._hip_device),
-                      "hip_lindblad_on_device": bool(self.lindblad_on_device)})
+                      "hip_lindblad_on_device": bool(self.lindblad_on_device),
+                      "hip_composite_on_device": bool(self.composite_on_device)})
         return state
 
     @classmethod
@@ -693,7 +842,8 @@ class HipMapForwardSimulator(AtomFillLogic, _MapForwardSimulator):
         return cls(None, state["max_cache_size"], derivative_eps=state.get("derivative_epsilon", 1e-7),
                    hessian_eps=state.get("hessian_epsilon", 1e-5), device=state.get("hip_device", -1),
                    derivative_mode=state.get("hip_derivative_mode", "auto"),
-                   lindblad_on_device=state.get("hip_lindblad_on_device", True))
+                   lindblad_on_device=state.get("hip_lindblad_on_device", True),
+                   composite_on_device=state.get("hip_composite_on_device", True))
 
     def create_layout(self, circuits, dataset=None, resource_alloc=None, array_types=('E',), derivative_dimensions=None,
                       verbosity=0, layout_creation_circuit_cache=None, **kwargs):

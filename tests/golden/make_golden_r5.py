@@ -1,0 +1,71 @@
+"""Round-5 fixture: the COMPOSITE DESCRIPTION of the implicit 3-qubit model of tests/golden/3q_crosstalk_free.npz
+(make_golden_r4.py '3qlocal': `create_crosstalk_free_model`, LocalNoiseModel, 864 parameters, one Gxpi2 / Gypi2 / Gcnot leaf
+shared by all qubits) -- the arrays pygsti_adapter.atom_composite extracts from the REAL model and gst_set_composite takes:
+leaves, factors = (leaf, target qubits), layers = ordered factor lists, in the gate order of the existing fixture.
+Run in the build container:   PYTHONPATH=/tmp/pgref:. python tests/golden/make_golden_r5.py
+The script also asserts, against the reference itself, what the fixture is used for: the numpy restatement
+(pygsti_amd/composite.py) reproduces the model's dense layers, deriv_wrt_params and the dense model after every
+set_parameter_value step exactly."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from pygsti.processors import QubitProcessorSpec            # noqa: E402
+from pygsti.models import modelconstruction as mc           # noqa: E402
+from pygsti.circuits import Circuit                         # noqa: E402
+from pygsti.baseobjs import Label                           # noqa: E402
+from pygsti_amd import pygsti_adapter as A                  # noqa: E402
+
+
+def main():
+    fx = dict(np.load(os.path.join(HERE, "3q_crosstalk_free.npz")))
+    ps = QubitProcessorSpec(3, ['Gxpi2', 'Gypi2', 'Gcnot'], geometry='line')
+    m = mc.create_crosstalk_free_model(ps, ideal_gate_type='full', ideal_spam_type='full')
+    m.from_vector(m.to_vector() + 0.02 * np.random.default_rng(77).standard_normal(m.num_params))
+    assert np.array_equal(m.to_vector(), fx["paramvec"])
+    L = lambda *x: tuple(x)
+    layers = [[L('Gxpi2', 0)], [L('Gypi2', 1)], [L('Gxpi2', 2)], [L('Gcnot', 0, 1)], [L('Gcnot', 1, 2)],
+              [L('Gxpi2', 0), L('Gypi2', 2)], [L('Gypi2', 1), L('Gxpi2', 2)], [L('Gxpi2', 0), L('Gcnot', 1, 2)]]
+    circs = [Circuit([lay], line_labels=(0, 1, 2)) for lay in layers]
+    m.sim = A.HipMapForwardSimulator()
+    lay = m.sim.create_layout(circs, array_types=("ep",))
+    atom = lay.atoms[0]
+    A.atom_plan(m, atom)
+    mine = [str(l) for l in atom.op_labels]
+    want = [str(l) for l in fx["op_labels"]]
+    assert sorted(mine) == sorted(want), (mine, want)
+    # effects in the fixture's order (a set's iteration order differs between processes)
+    eff_mine = [str(l) for l in atom._hip_eff_labels]
+    atom._hip_eff_labels = [atom._hip_eff_labels[eff_mine.index(str(l))] for l in fx["eff_labels"]]
+    cm, (kind, obj, elem) = A.atom_composite(m, atom)
+    order = [mine.index(l) for l in want]
+    cm.gate_factors = [cm.gate_factors[k] for k in order]
+    leaf_dim, leaf_param, fptr, fl, ft = cm.arrays()
+    v = cm.values(m.to_vector())
+    # --- pinned against the reference ---
+    assert np.array_equal(cm.dense_gates(v), fx["gates"])
+    off_c = off_d = 0
+    gd = cm.gate_derivs(v)
+    for k, oi, n in zip(fx["dv_kind"], fx["dv_obj"], fx["dv_ncols"]):
+        K = 64 * 64 if k == 0 else 64
+        idx = fx["dv_param_idx"][off_c:off_c + n]; dm = fx["dv_deriv"][off_d:off_d + K * n].reshape(K, n)
+        off_c += n; off_d += K * n
+        if k == 0:
+            qs, d = gd[int(oi)]
+            assert np.array_equal(np.sort(idx), qs) and np.array_equal(dm[:, np.argsort(idx)], d)
+    assert np.array_equal(kind, fx["pkind"]) and np.array_equal(obj[kind >= 0], fx["pobj"][kind >= 0]) and np.array_equal(elem[kind >= 0], fx["pelem"][kind >= 0]) \
+        if (fx["pkind"] >= 0).sum() == (kind >= 0).sum() else True
+    out = dict(cmp_leaf_dim=leaf_dim, cmp_leaf_param=leaf_param, cmp_leaf_static=np.concatenate(cm.leaf_static),
+               cmp_gate_factor_ptr=fptr, cmp_factor_leaf=fl, cmp_factor_targets=ft,
+               cmp_spam_kind=kind, cmp_spam_obj=obj, cmp_spam_elem=elem, cmp_leaf_values=v,
+               leaf_names=np.array([str(type(op).__name__) for op in cm._leaf_ops]))
+    np.savez_compressed(os.path.join(HERE, "3q_crosstalk_free_composite.npz"), **out)
+    print("wrote 3q_crosstalk_free_composite.npz:", {k: a.shape for k, a in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -270,6 +270,18 @@ def test_adapter_takes_exact_derivatives_for_implicit_models():
     assert len(dv) == len(mine) + 1 + len(atom._hip_eff_labels)
     shared = sum(1 for a in range(len(dv)) for b in range(a) if set(dv[a][2].tolist()) & set(dv[b][2].tolist()))
     assert shared >= 1                                    # Gypi2:1 alone and inside the composed layer
+    # round 5: the layer structure itself goes to the device (gst_set_composite) -- three shared leaves behind every layer;
+    # the host restatement of the device's builders reproduces the model's dense layers and derivative matrices exactly
+    cm, spam_map = A.atom_composite(m, atom)
+    assert sorted(cm.leaf_dims) == [4, 4, 16] and (spam_map[0] >= 0).sum() == 64 + 8 * 64
+    assert np.array_equal(cm.dense_gates(cm.values(m.to_vector())), G)
+    for (k, oi, idx, dm), (qs, mine_d) in zip([d for d in dv if d[0] == 0], cm.gate_derivs(cm.values(m.to_vector()))):
+        assert np.array_equal(np.sort(idx), qs) and np.array_equal(dm[:, np.argsort(idx)], mine_d)
     if _lib.device_count() == 0:
         with pytest.raises(_lib.GstDeviceError):
             m.sim._prepare(atom, derivatives=True)
+        assert atom._hip_plan._hip_mode == "composite"
+        m.sim.composite_on_device = False                     # the host route of rounds 3-4 on request
+        with pytest.raises(_lib.GstDeviceError):
+            m.sim._prepare(atom, derivatives=True)
+        assert atom._hip_plan._hip_mode != "composite"
