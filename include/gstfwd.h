@@ -291,7 +291,17 @@ int gst_get_model(gst_plan *plan, double *gates, double *rhos, double *effects);
  * factors (what ComposedOp / EmbeddedOp.deriv_wrt_params() hand to MatrixForwardSimulator._doperation) and applies the chain
  * rule to the element Jacobian (<= 1e-8 against the Matrix simulator).  Exact HESSIAN blocks of such models are not built
  * here (a layer is bilinear in two leaves): use gst_set_derivs + gst_set_second_derivs for those.  An explicit
- * gst_set_derivs takes precedence in the analytic mode. */
+ * gst_set_derivs takes precedence in the analytic mode.
+ * GENERAL leaves: a leaf whose elements are not parameters themselves (an exponentiated Lindblad generator behind a CPTPLND
+ * one- or two-qubit gate, a ComposedOp of such, ...) is declared with leaf_n_params[l] > 0 and its model parameters (ascending)
+ * in leaf_param_list; its leaf_param entries are -1.  Such a leaf is at most 16 x 16 (64 x 64), so the host keeps
+ * differentiating IT with the reference's own code -- what never happens on the host any more is the embedding and the
+ * products at the register's dimension:
+ *   gst_set_composite_general  after every gst_set_composite_values: leaf_derivs = the general leaves' deriv_wrt_params()
+ *       (row-major [leaf_dim^2][n_params], concatenated in leaf order; may be NULL when only FD fills follow) and
+ *       leaf_fd_values = their dense elements after each of their parameters' finite-difference steps
+ *       ([n_params][leaf_dim^2] per leaf, concatenated; to_dense() after set_parameter_value(q, theta_q + fd_eps), restored
+ *       afterwards; may be NULL when only exact fills follow).  GST_DERIV_FD fills must then use eps == fd_eps. */
 typedef struct gst_composite_desc {
     int32_t n_leaves;
     const int32_t *leaf_dim;          /* [n_leaves] */
@@ -299,9 +309,12 @@ typedef struct gst_composite_desc {
     const int32_t *gate_factor_ptr;   /* [n_gates + 1] */
     const int32_t *factor_leaf;       /* [n_factors] */
     const int32_t *factor_targets;    /* [n_factors][3] */
+    const int32_t *leaf_n_params;     /* [n_leaves]: > 0 for general leaves; NULL: none */
+    const int64_t *leaf_param_list;   /* the general leaves' parameters, concatenated */
 } gst_composite_desc;
 int gst_set_composite(gst_plan *plan, int32_t n_params, const gst_composite_desc *desc);
 int gst_set_composite_values(gst_plan *plan, const double *leaf_values, const double *rhos, const double *effects);
+int gst_set_composite_general(gst_plan *plan, const double *leaf_derivs, const double *leaf_fd_values, double fd_eps);
 /* The dense models the device builds for the finite-difference steps of parameters param_idx (theta_p + eps each):
  * gates[n][n_gates][D][D], rhos[n][n_rhos][D], effects[n][n_effects][D] (host; tests compare them with the reference's). */
 int gst_get_lindblad_model_sets(gst_plan *plan, const int64_t *param_idx, int64_t n_param, double eps, double *gates,

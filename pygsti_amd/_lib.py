@@ -67,7 +67,7 @@ class LindbladMemberDesc(C.Structure):
 
 class CompositeDesc(C.Structure):
     _fields_ = [("n_leaves", C.c_int32), ("leaf_dim", C.c_void_p), ("leaf_param", C.c_void_p), ("gate_factor_ptr", C.c_void_p),
-                ("factor_leaf", C.c_void_p), ("factor_targets", C.c_void_p)]
+                ("factor_leaf", C.c_void_p), ("factor_targets", C.c_void_p), ("leaf_n_params", C.c_void_p), ("leaf_param_list", C.c_void_p)]
 
 
 class CommInfo(C.Structure):
@@ -89,7 +89,7 @@ EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_p
            "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_get_fd_work", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
-           "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_set_composite", "gst_set_composite_values", "gst_get_model", "gst_get_lindblad_model_sets",
+           "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_set_composite", "gst_set_composite_values", "gst_set_composite_general", "gst_get_model", "gst_get_lindblad_model_sets",
            "gst_comm_get_unique_id", "gst_comm_create", "gst_comm_destroy", "gst_comm_allgather_rows",
            "gst_comm_gather_rows", "gst_comm_exchange_blocks", "gst_comm_allreduce_sum", "gst_comm_barrier", "gst_comm_sync", "gst_comm_get_info"]
 
@@ -130,6 +130,7 @@ def lib():
         L.gst_sync.argtypes = [vp]
         L.gst_set_composite.argtypes = [vp, i32, C.POINTER(CompositeDesc)]
         L.gst_set_composite_values.argtypes = [vp, vp, vp, vp]
+        L.gst_set_composite_general.argtypes = [vp, vp, vp, dbl]
         L.gst_device_malloc.argtypes = [vp, i64, C.POINTER(vp)]
         L.gst_device_malloc_tracked.argtypes = [vp, i64, C.POINTER(vp)]
         L.gst_device_free.argtypes = [vp, vp]
@@ -393,8 +394,9 @@ class Plan:
             return
         assert len(model.gate_factors) == self.n_gates and model.D == self.D
         leaf_dim, leaf_param, fptr, fl, ft = model.arrays()
+        n_gen, gen_list = model.general_arrays()
         keep = [_i32(leaf_dim), _i64(leaf_param), _i32(fptr), _i32(fl) if len(fl) else np.zeros(1, np.int32),
-                _i32(ft) if len(ft) else np.full((1, 3), -1, np.int32)]
+                _i32(ft) if len(ft) else np.full((1, 3), -1, np.int32), _i32(n_gen), _i64(gen_list) if len(gen_list) else np.zeros(1, np.int64)]
         d = CompositeDesc(len(leaf_dim), *[a.ctypes.data for a in keep])
         check(lib().gst_set_composite(self._h, int(model.num_params), C.byref(d)))
         self._composite = model
@@ -405,6 +407,13 @@ class Plan:
         v = _f64(leaf_values)
         r = _f64(rhos).reshape(self.n_rhos, self.D); e = _f64(effects).reshape(self.n_effects, self.D)
         check(lib().gst_set_composite_values(self._h, _ptr(v), _ptr(r), _ptr(e)))
+
+    def set_composite_general(self, leaf_derivs=None, leaf_fd_values=None, fd_eps=1e-7):
+        """gst_set_composite_general: the general leaves' deriv_wrt_params ([d*d][np] each, concatenated) and / or their dense
+        elements after every parameter's finite-difference step ([np][d*d] each, concatenated), for the current parameters."""
+        dv = None if leaf_derivs is None else _f64(leaf_derivs)
+        fd = None if leaf_fd_values is None else _f64(leaf_fd_values)
+        check(lib().gst_set_composite_general(self._h, _ptr(dv), _ptr(fd), float(fd_eps)))
 
     def set_lindblad_params(self, theta):
         """The model's parameter vector: the device builds every dense member from it (gst_set_lindblad_params)."""

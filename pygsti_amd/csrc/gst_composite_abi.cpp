@@ -22,14 +22,21 @@ static int cmp_upload(gst_plan* p)
     i32.insert(i32.end(), C.gate_fptr.begin(), C.gate_fptr.end());
     i32.insert(i32.end(), C.factor_leaf.begin(), C.factor_leaf.end());
     i32.insert(i32.end(), C.factor_targets.begin(), C.factor_targets.end());
+    i32.insert(i32.end(), C.leaf_np.begin(), C.leaf_np.end());
     int rc = upload_i32(p->d_cmp_i32, i32, p->stream);
     if (rc) return rc;
     std::vector<int64_t> i64;
     i64.insert(i64.end(), C.leaf_off.begin(), C.leaf_off.end());
     i64.insert(i64.end(), C.leaf_param.begin(), C.leaf_param.end());
+    i64.insert(i64.end(), C.leaf_plist_off.begin(), C.leaf_plist_off.end());
+    i64.insert(i64.end(), C.leaf_deriv_off.begin(), C.leaf_deriv_off.end());
+    i64.insert(i64.end(), C.leaf_fd_off.begin(), C.leaf_fd_off.end());
+    i64.insert(i64.end(), C.leaf_plist.begin(), C.leaf_plist.end());
     HIP_TRY(p->d_cmp_i64.ensure(std::max<size_t>(i64.size(), 1)));
     HIP_TRY(hipMemcpyAsync(p->d_cmp_i64.p, i64.data(), i64.size() * 8, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(p->d_cmp_values.ensure(std::max<size_t>(C.leaf_param.size(), 1)));
+    HIP_TRY(p->d_cmp_gderiv.ensure((size_t)std::max<int64_t>(C.n_deriv_doubles, 1)));
+    HIP_TRY(p->d_cmp_gfd.ensure((size_t)std::max<int64_t>(C.n_fd_doubles, 1)));
     HIP_TRY(p->d_cmp_spam.ensure(std::max<size_t>((size_t)(p->hp.n_rhos + p->hp.n_effects) * p->hp.D, 1)));
     HIP_TRY(p->d_cmp_base.ensure(cmp_set_stride(p)));
     HIP_TRY(p->d_cmp_gates_rm.ensure(std::max<size_t>((size_t)p->hp.n_gates * p->hp.D * p->hp.D, 1)));
@@ -50,9 +57,19 @@ static void cmp_args(gst_plan* p, gst::CompositeArgs& a)
     a.leaf_dim = q; q += C.leaf_dim.size();
     a.gate_fptr = q; q += C.gate_fptr.size();
     a.factor_leaf = q; q += C.factor_leaf.size();
-    a.factor_targets = q;
+    a.factor_targets = q; q += C.factor_targets.size();
     a.leaf_off = p->d_cmp_i64.p;
     a.leaf_param = p->d_cmp_i64.p + C.leaf_off.size();
+    if (C.any_general) {
+        const int64_t* w = a.leaf_param + C.leaf_param.size();
+        a.leaf_np = q;
+        a.leaf_plist_off = w; w += C.leaf_plist_off.size();
+        a.leaf_deriv_off = w; w += C.leaf_deriv_off.size();
+        a.leaf_fd_off = w; w += C.leaf_fd_off.size();
+        a.leaf_plist = w;
+        a.leaf_deriv = p->d_cmp_gderiv.p;
+        a.leaf_fd = C.have_general_fd ? p->d_cmp_gfd.p : nullptr;
+    }
     a.leaf_values = p->d_cmp_values.p;
     a.rhos = p->d_cmp_spam.p;
     a.effects = p->d_cmp_spam.p + (size_t)p->hp.n_rhos * D;
@@ -83,6 +100,8 @@ int run_dprobs_composite(gst_plan* p, double* d_out, int64_t ld, const int64_t* 
     const int64_t nE = h.n_elements, nT = h.n_tasks();
     if (!p->cmp.have_values) return fail(GST_ESTATE, "gst_set_composite_values has not been called");
     if (!(eps != 0.0)) return fail(GST_EINVAL, "eps must be non-zero");
+    if (p->cmp.any_general && (!p->cmp.have_general_fd || p->cmp.general_fd_eps != eps))
+        return fail(GST_ESTATE, "general leaves: gst_set_composite_general must supply the leaves' finite-difference values for this eps");
     for (int64_t c = 0; c < n_param; c++)
         if (param_idx[c] < 0 || param_idx[c] >= p->cmp.n_params) return fail(GST_EINVAL, "parameter index out of range");
     p->cached_kind = 0;
@@ -136,6 +155,8 @@ int run_dprobs_composite_analytic(gst_plan* p, double* d_out, int64_t ld, const 
     const int D = h.D;
     gst_plan::Composite& C = p->cmp;
     if (!C.have_values) return fail(GST_ESTATE, "gst_set_composite_values has not been called");
+    if (C.any_general && !C.have_general_derivs)
+        return fail(GST_ESTATE, "general leaves: gst_set_composite_general must supply the leaves' derivative matrices");
     std::vector<int32_t> kind, obj, ncols;
     std::vector<int64_t> pidx;
     std::vector<double> spam_deriv;                       // the SPAM objects' matrices (host-built, tiny), in object order
@@ -248,6 +269,29 @@ int gst_set_composite(gst_plan* p, int32_t n_params, const gst_composite_desc* d
     N.leaf_param.assign(d->leaf_param, d->leaf_param + off);
     for (int64_t q : N.leaf_param)
         if (q < -1 || q >= n_params) return fail(GST_EINVAL, "a leaf element's parameter index is out of range");
+    N.leaf_np.assign((size_t)d->n_leaves, 0);
+    N.leaf_plist_off.assign((size_t)d->n_leaves, 0); N.leaf_deriv_off.assign((size_t)d->n_leaves, 0); N.leaf_fd_off.assign((size_t)d->n_leaves, 0);
+    if (d->leaf_n_params) {
+        int64_t lo = 0;
+        for (int l = 0; l < d->n_leaves; l++) {
+            const int np = d->leaf_n_params[l];
+            if (np < 0) return fail(GST_EINVAL, "leaf " + std::to_string(l) + ": negative parameter count");
+            if (np == 0) continue;
+            if (!d->leaf_param_list) return fail(GST_EINVAL, "leaf_param_list is NULL");
+            const int64_t dd = (int64_t)N.leaf_dim[(size_t)l] * N.leaf_dim[(size_t)l];
+            for (int64_t e = 0; e < dd; e++)
+                if (N.leaf_param[(size_t)(N.leaf_off[(size_t)l] + e)] != -1) return fail(GST_EINVAL, "leaf " + std::to_string(l) + ": a general leaf's elements carry no element parameters (leaf_param must be -1)");
+            N.leaf_np[(size_t)l] = np; N.any_general = true;
+            N.leaf_plist_off[(size_t)l] = lo; N.leaf_deriv_off[(size_t)l] = N.n_deriv_doubles; N.leaf_fd_off[(size_t)l] = N.n_fd_doubles;
+            for (int c = 0; c < np; c++) {
+                const int64_t q = d->leaf_param_list[lo + c];
+                if (q < 0 || q >= n_params || (c > 0 && q <= d->leaf_param_list[lo + c - 1]))
+                    return fail(GST_EINVAL, "leaf " + std::to_string(l) + ": parameter list must be ascending and in range");
+                N.leaf_plist.push_back(q);
+            }
+            lo += np; N.n_deriv_doubles += dd * np; N.n_fd_doubles += dd * np;
+        }
+    }
     const int nG = p->hp.n_gates;
     N.gate_fptr.assign(d->gate_factor_ptr, d->gate_factor_ptr + nG + 1);
     if (N.gate_fptr[0] != 0) return fail(GST_EINVAL, "gate_factor_ptr[0] must be 0");
@@ -278,6 +322,7 @@ int gst_set_composite(gst_plan* p, int32_t n_params, const gst_composite_desc* d
             const int64_t o = N.leaf_off[(size_t)l], n = (int64_t)N.leaf_dim[(size_t)l] * N.leaf_dim[(size_t)l];
             for (int64_t e = 0; e < n; e++)
                 if (N.leaf_param[(size_t)(o + e)] >= 0) qs.push_back(N.leaf_param[(size_t)(o + e)]);
+            for (int c = 0; c < N.leaf_np[(size_t)l]; c++) qs.push_back(N.leaf_plist[(size_t)(N.leaf_plist_off[(size_t)l] + c)]);
         }
         std::sort(qs.begin(), qs.end());
         qs.erase(std::unique(qs.begin(), qs.end()), qs.end());
@@ -319,6 +364,31 @@ int gst_set_composite_values(gst_plan* p, const double* leaf_values, const doubl
     p->have_model = true;
     p->model_dirty = true;
     C.have_values = true;
+    C.have_general_derivs = false; C.have_general_fd = false;      // (they belong to the previous parameter vector)
+    return GST_OK;
+    });
+}
+
+int gst_set_composite_general(gst_plan* p, const double* leaf_derivs, const double* leaf_fd_values, double fd_eps)
+{
+    return guarded([&]() -> int {
+    if (!p) return fail(GST_EINVAL, "plan is NULL");
+    gst_plan::Composite& C = p->cmp;
+    if (!C.set || !C.have_values) return fail(GST_ESTATE, "gst_set_composite / gst_set_composite_values have not been called");
+    if (!C.any_general) return GST_OK;
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    if (leaf_derivs) {
+        HIP_TRY(hipMemcpyAsync(p->d_cmp_gderiv.p, leaf_derivs, (size_t)C.n_deriv_doubles * 8, hipMemcpyHostToDevice, p->stream));
+        C.have_general_derivs = true;
+    }
+    if (leaf_fd_values) {
+        if (!(fd_eps != 0.0)) return fail(GST_EINVAL, "fd_eps must be non-zero");
+        HIP_TRY(hipMemcpyAsync(p->d_cmp_gfd.p, leaf_fd_values, (size_t)C.n_fd_doubles * 8, hipMemcpyHostToDevice, p->stream));
+        C.have_general_fd = true; C.general_fd_eps = fd_eps;
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->cached_kind = 0;
     return GST_OK;
     });
 }

@@ -315,6 +315,12 @@ struct CompositeArgs {
     const int32_t *leaf_dim;
     const int64_t *leaf_off, *leaf_param;
     const double* leaf_values;
+    // general leaves (any member the host can densify): leaf_np[l] > 0 parameters, listed ascending at leaf_plist +
+    // leaf_plist_off[l]; their derivative matrices [dl*dl][np] at leaf_deriv + leaf_deriv_off[l]; their values after each
+    // parameter's finite-difference step [np][dl*dl] at leaf_fd + leaf_fd_off[l] (NULL: not supplied).  leaf_np NULL: none.
+    const int32_t* leaf_np;
+    const int64_t *leaf_plist_off, *leaf_plist, *leaf_deriv_off, *leaf_fd_off;
+    const double *leaf_deriv, *leaf_fd;
     const int32_t *gate_fptr, *factor_leaf, *factor_targets;
     const double *rhos, *effects;            // the base SPAM vectors
     const int32_t *pkind, *pobj, *pelem;     // the plan's parameter map (SPAM columns of the model sets), or NULL

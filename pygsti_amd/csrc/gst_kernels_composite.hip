@@ -72,11 +72,41 @@ __device__ __forceinline__ void apply_factor(const Digits& dg, const double* f, 
     }
 }
 
-// The (possibly stepped) values of leaf l into LDS: f[e] = value[e] + (param[e] == q ? eps : 0).
+// GENERAL leaves (leaf_np[l] > 0: any member the host can densify -- exponentiated Lindblad generators, ...): position of
+// parameter q in the leaf's ascending parameter list, or -1.  Wave-uniform.
+__device__ __forceinline__ int general_leaf_col(const CompositeArgs& a, int l, int64_t q)
+{
+    const int np = a.leaf_np ? a.leaf_np[l] : 0;
+    const int64_t* lst = a.leaf_plist + (np ? a.leaf_plist_off[l] : 0);
+    int lo = 0, hi = np;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (lst[mid] < q) lo = mid + 1; else hi = mid; }
+    return (lo < np && lst[lo] == q) ? lo : -1;
+}
+
+// Does leaf l move with parameter q?  (all threads; contains a barrier)
+__device__ __forceinline__ bool leaf_holds(const CompositeArgs& a, int l, int64_t q, int t, int nt_threads)
+{
+    if (a.leaf_np && a.leaf_np[l] > 0) return general_leaf_col(a, l, q) >= 0;
+    const int dl = a.leaf_dim[l];
+    const int64_t off = a.leaf_off[l];
+    int mine = 0;
+    for (int e = t; e < dl * dl; e += nt_threads) mine |= (a.leaf_param[off + e] == q);
+    return __syncthreads_or(mine) != 0;
+}
+
+// The (possibly stepped) values of leaf l into LDS.  Element leaves: f[e] = value[e] + (param[e] == q ? eps : 0).
+// General leaves: the host's own perturbed leaf for q (leaf_fd: [np][dl*dl], the reference's to_dense() after
+// set_parameter_value(q, theta_q + eps)), the base values otherwise.
 __device__ __forceinline__ void load_leaf(const CompositeArgs& a, int l, int64_t q, double eps, double* f, int t, int nt_threads)
 {
     const int dl = a.leaf_dim[l];
     const int64_t off = a.leaf_off[l];
+    if (a.leaf_np && a.leaf_np[l] > 0) {
+        const int c = q >= 0 ? general_leaf_col(a, l, q) : -1;
+        const double* src = (c >= 0 && a.leaf_fd) ? a.leaf_fd + a.leaf_fd_off[l] + (int64_t)c * dl * dl : a.leaf_values + off;
+        for (int e = t; e < dl * dl; e += nt_threads) f[e] = src[e];
+        return;
+    }
     for (int e = t; e < dl * dl; e += nt_threads) {
         double v = a.leaf_values[off + e];
         if (q >= 0 && a.leaf_param[off + e] == q) v = v + eps;
@@ -84,11 +114,18 @@ __device__ __forceinline__ void load_leaf(const CompositeArgs& a, int l, int64_t
     }
 }
 
-// The direction of leaf l for parameter q: dF[e] = 1 where param[e] == q, else 0.
+// The direction of leaf l for parameter q: element leaves dF[e] = 1 where param[e] == q, else 0; general leaves column q of
+// the host's deriv_wrt_params() of the leaf (leaf_deriv: [dl*dl][np] row-major).
 __device__ __forceinline__ void load_leaf_direction(const CompositeArgs& a, int l, int64_t q, double* f, int t, int nt_threads)
 {
     const int dl = a.leaf_dim[l];
     const int64_t off = a.leaf_off[l];
+    if (a.leaf_np && a.leaf_np[l] > 0) {
+        const int np = a.leaf_np[l], c = general_leaf_col(a, l, q);
+        const double* dm = a.leaf_deriv + a.leaf_deriv_off[l];
+        for (int e = t; e < dl * dl; e += nt_threads) f[e] = c >= 0 ? dm[(int64_t)e * np + c] : 0.0;
+        return;
+    }
     for (int e = t; e < dl * dl; e += nt_threads) f[e] = (a.leaf_param[off + e] == q) ? 1.0 : 0.0;
 }
 
@@ -125,13 +162,9 @@ __global__ __launch_bounds__(256) void composite_build_kernel(const CompositeArg
     const int f0 = a.gate_fptr[g], f1 = a.gate_fptr[g + 1];
     // does this layer move with q?  (no: the base layer is copied)
     if (q >= 0 && a.base_set) {
-        int mine = 0;
-        for (int f = f0; f < f1; f++) {
-            const int l = a.factor_leaf[f], dl = a.leaf_dim[l];
-            const int64_t off = a.leaf_off[l];
-            for (int e = t; e < dl * dl; e += NT) mine |= (a.leaf_param[off + e] == q);
-        }
-        if (!__syncthreads_or(mine)) {
+        bool mine = false;
+        for (int f = f0; f < f1; f++) mine = leaf_holds(a, a.factor_leaf[f], q, t, NT) || mine;
+        if (!mine) {
             for (int idx = t; idx < D * D; idx += NT) set[(size_t)g * D * D + idx] = a.base_set[(size_t)g * D * D + idx];
             return;
         }
@@ -178,10 +211,7 @@ __global__ __launch_bounds__(256) void composite_deriv_kernel(const CompositeArg
     for (int r = 0; r < MAXR; r++) acc[r] = 0.0;
     for (int k = f0; k < f1; k++) {
         // does factor k's leaf hold q?
-        const int lk = a.factor_leaf[k], dk = a.leaf_dim[lk];
-        int mine = 0;
-        for (int e = t; e < dk * dk; e += NT) mine |= (a.leaf_param[a.leaf_off[lk] + e] == q);
-        if (!__syncthreads_or(mine)) continue;
+        if (!leaf_holds(a, a.factor_leaf[k], q, t, NT)) continue;
         set_identity(X, D, t, NT);
         __syncthreads();
         for (int f = f0; f < f1; f++) {

@@ -217,7 +217,14 @@ struct gst_plan {
         std::vector<int32_t> leaf_dim, gate_fptr, factor_leaf, factor_targets;
         std::vector<int64_t> leaf_off, leaf_param;
         std::vector<std::vector<int64_t>> gate_params;      // per layer: the distinct parameters of its factors' leaves, ascending
+        // general leaves (leaf_np[l] > 0): parameter lists, offsets of their derivative matrices / finite-difference values
+        std::vector<int32_t> leaf_np;
+        std::vector<int64_t> leaf_plist_off, leaf_plist, leaf_deriv_off, leaf_fd_off;
+        int64_t n_deriv_doubles = 0, n_fd_doubles = 0;
+        bool any_general = false, have_general_derivs = false, have_general_fd = false;
+        double general_fd_eps = 0.0;
     } cmp;
+    DevBuf<double> d_cmp_gderiv, d_cmp_gfd;
     DevBuf<int32_t> d_cmp_i32, d_cmp_pmap, d_cmp_items32;   // leaf_dim | gate_fptr | factor_leaf | factor_targets; the parameter map; deriv items
     DevBuf<int64_t> d_cmp_i64, d_cmp_setparam;              // leaf_off | leaf_param; the stepped parameter of each set / deriv item tables
     DevBuf<double> d_cmp_values, d_cmp_spam, d_cmp_base, d_cmp_gates_rm;
@@ -311,7 +318,7 @@ struct gst_plan {
         if (d_out.p) gst::track_touch(d_out.p, d_out.n * 8);
         if (d_jelem.p) gst::track_touch(d_jelem.p, d_jelem.n * 8);
         d_cmp_i32.release(); d_cmp_pmap.release(); d_cmp_items32.release(); d_cmp_i64.release(); d_cmp_setparam.release();
-        d_cmp_values.release(); d_cmp_spam.release(); d_cmp_base.release(); d_cmp_gates_rm.release();
+        d_cmp_values.release(); d_cmp_spam.release(); d_cmp_base.release(); d_cmp_gates_rm.release(); d_cmp_gderiv.release(); d_cmp_gfd.release();
         d_lb_i32.release(); d_lb_i64.release(); d_lb_setparam.release(); d_lb_statics.release(); d_lb_term_re.release();
         d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release(); d_jtj_pmask.release(); for (auto& b : d_lbr_lane) b.release(); d_lbr_order.release();
         d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release();

@@ -315,7 +315,7 @@ def atom_composite(model, atom):
     if D not in (4, 16, 64):
         raise NotImplementedError("composite layers are built on the device for one to three qubits")
     nq = {4: 1, 16: 2, 64: 3}[D]
-    leaves, leaf_dims, leaf_params, leaf_static = {}, [], [], []
+    leaves, leaf_dims, leaf_params, leaf_static, leaf_general = {}, [], [], [], []
 
     def leaf_of(op):
         key = id(op)
@@ -323,7 +323,17 @@ def atom_composite(model, atom):
             d = int(op.dim)
             if d not in (4, 16, 64) or d > D:
                 raise NotImplementedError("a leaf operation of dimension %d" % d)
-            leaf_params.append(_element_selection(op, d * d))
+            try:
+                leaf_params.append(_element_selection(op, d * d))           # ELEMENT leaf: its elements are the parameters
+                leaf_general.append(None)
+            except NotImplementedError:
+                # GENERAL leaf (an exponentiated Lindblad generator ...): the host keeps densifying / differentiating this
+                # small operation with the reference's own code; embedding and products happen on the device
+                idx = np.asarray(op.gpindices_as_array(), np.int64)
+                if len(idx) == 0 or len(set(idx.tolist())) != len(idx) or not hasattr(op, "deriv_wrt_params"):
+                    raise NotImplementedError("leaf %s" % type(op).__name__)
+                leaf_params.append(-np.ones(d * d, np.int64))
+                leaf_general.append(np.sort(idx))
             leaf_static.append(np.ascontiguousarray(np.real(op.to_dense("HilbertSchmidt")), dtype=np.float64).ravel())
             leaf_dims.append(d)
             leaves[key] = (len(leaf_dims) - 1, op)         # (the op is kept alive: ids are only unique among live objects)
@@ -343,7 +353,7 @@ def atom_composite(model, atom):
                 raise NotImplementedError("an embedded operation over a non-qubit space")
             inner = tuple(qubits[lbls.index(t)] for t in op.target_labels)
             return expand(op.embedded_op, inner)
-        if getattr(op, "factorops", None) is not None or hasattr(op, "embedded_op") or hasattr(op, "errorgen"):
+        if getattr(op, "factorops", None) is not None or hasattr(op, "embedded_op"):
             raise NotImplementedError("layer member %s" % name)
         if int(op.dim) != 4 ** len(qubits):
             raise NotImplementedError("a leaf that does not fill its target qubits")
@@ -366,12 +376,46 @@ def atom_composite(model, atom):
             if (kind[sel[hit]] != -1).any():
                 raise NotImplementedError("a SPAM parameter shared between members")
             kind[sel[hit]] = k; obj[sel[hit]] = oi; elem[sel[hit]] = hit
-    leaf_owned = np.concatenate(leaf_params) if leaf_params else np.zeros(0, np.int64)
+    leaf_owned = np.concatenate(leaf_params + [g for g in leaf_general if g is not None]) if leaf_params else np.zeros(0, np.int64)
     if (kind[leaf_owned[leaf_owned >= 0]] != -1).any():
         raise NotImplementedError("a parameter shared between a layer operation and a SPAM member")
-    cm = CompositeModel(D, nP, leaf_dims, leaf_params, leaf_static, gate_factors)
+    cm = CompositeModel(D, nP, leaf_dims, leaf_params, leaf_static, gate_factors, leaf_general)
     cm._leaf_ops = [op for _, op in sorted(leaves.values(), key=lambda t: t[0])]
     return cm, (kind, obj, elem)
+
+
+def composite_general_data(model, cm, want_derivs, fd_eps=None):
+    """What gst_set_composite_values / gst_set_composite_general need from the GENERAL leaves of `cm` at the model's current
+    parameters, computed by the reference's own members on the (small) leaves only: their dense elements; with want_derivs
+    their deriv_wrt_params() in ascending parameter order; with fd_eps their elements after each of their parameters'
+    finite-difference steps -- the model is stepped exactly as mapfill_dprobs_atom steps it
+    (mapforwardsim_calc_densitymx.pyx:362-381) and left at its original vector.  -> (values {l: [d*d]}, derivs {l: [d*d, np]}
+    or None, fd {l: [np, d*d]} or None)"""
+    vals, derivs, fds = {}, ({} if want_derivs else None), ({} if fd_eps is not None else None)
+
+    def dense(op):
+        return np.ascontiguousarray(np.real(op.to_dense("HilbertSchmidt")), dtype=np.float64).ravel()
+    for l in cm.general_leaves:
+        op, d = cm._leaf_ops[l], cm.leaf_dims[l]
+        vals[l] = dense(op)
+        if want_derivs:
+            idx = np.asarray(op.gpindices_as_array(), np.int64)
+            derivs[l] = np.ascontiguousarray(np.real(op.deriv_wrt_params()), dtype=np.float64).reshape(d * d, len(idx))[:, np.argsort(idx)]
+    if fd_eps is not None and cm.general_leaves:
+        orig = model.to_vector().copy()
+        prev = None
+        for l in cm.general_leaves:
+            fds[l] = np.empty((len(cm.leaf_general[l]), cm.leaf_dims[l] ** 2))
+            for c, q in enumerate(int(x) for x in cm.leaf_general[l]):
+                if prev is None:
+                    model.set_parameter_value(q, orig[q] + fd_eps)
+                else:
+                    model.set_parameter_values([prev, q], [orig[prev], orig[q] + fd_eps])
+                fds[l][c] = dense(cm._leaf_ops[l])
+                prev = q
+        if prev is not None:
+            model.set_parameter_value(prev, orig[prev])
+    return vals, derivs, fds
 
 
 def atom_plan(model, atom, device=-1, target_tasks=0):
@@ -538,7 +582,18 @@ class AtomFillLogic:
                 return np.ascontiguousarray(np.real(self.model._circuit_layer_operator(lbl, typ).to_dense("minimal")), dtype=np.float64).reshape(D)
             rhos = np.array([vec(l, "prep") for l in layout_atom.rho_labels]).reshape(len(layout_atom.rho_labels), D)
             effects = np.array([vec(l, "povm") for l in layout_atom._hip_eff_labels]).reshape(len(layout_atom._hip_eff_labels), D)
-            plan.set_composite_values(cm.values(self.model.to_vector()), rhos, effects)
+            if cm.general_leaves:
+                # general leaves (exponentiated Lindblad generators ...): the reference's own members densify / differentiate
+                # the SMALL leaves; finite differences need every leaf parameter's stepped leaf, exact derivatives the leaves'
+                # deriv_wrt_params -- per model update, never per layer and never at the register's dimension
+                want_fd = derivatives and dmode != "analytic"
+                vals, dvs, fds = composite_general_data(self.model, cm, derivatives and dmode == "analytic",
+                                                        self.derivative_eps if want_fd else None)
+                plan.set_composite_values(cm.values(self.model.to_vector(), vals), rhos, effects)
+                if derivatives:
+                    plan.set_composite_general(*cm.pack_general(dvs, fds), fd_eps=self.derivative_eps)
+            else:
+                plan.set_composite_values(cm.values(self.model.to_vector()), rhos, effects)
             return plan
         self._leave_composite(plan)
         plan.set_model(*atom_arrays(self.model, layout_atom))

@@ -210,3 +210,54 @@ def test_adapter_logic_takes_the_device_built_route_for_implicit_models():
     off = M._Sim(model, "auto"); off.composite_on_device = False
     with pytest.raises(AssertionError, match="densified on the host"):
         off._bulk_fill_probs_atom(np.empty(nE), M._Atom(fx), None)
+
+
+def test_general_leaves_cptplnd_implicit_model_on_the_device():
+    """`3q_crosstalk_free_CPTPLND`: D = 64 layers over CPTPLND leaves (static target x exp(Lindblad generator) on one / two
+    qubits; 840 parameters, the leaves shared between layers).  The host hands over what the reference's own members give for
+    the SMALL leaves (values, deriv_wrt_params, values after each parameter step: stored in the fixture); embedding, layer
+    products, the per-column dense models and the layers' derivative matrices are the device's.
+      layers <= 1e-15 from to_dense(); probabilities <= 1e-10 (Map); FD columns <= 1e-8 (Map: the perturbed leaves ARE the
+      reference's, so no exponential-algorithm mismatch is amplified); exact columns <= 1e-8 (Matrix)."""
+    from pygsti_amd import _lib
+    from test_composite import general_data_from_fixture
+    fx = load_fixture("3q_crosstalk_free_CPTPLND")
+    cm = composite_from_fixture(fx, fx)
+    dvs, fds = general_data_from_fixture(cm, fx)
+    eps = float(fx["derivative_eps"])
+    pl = _plan(fx)
+    pl.set_param_map(fx["cmp_spam_kind"], fx["cmp_spam_obj"], fx["cmp_spam_elem"])
+    pl.set_composite(cm)
+    pl.set_composite_values(fx["cmp_leaf_values"], fx["rhos"], fx["effects"])
+    G = pl.get_model()[0]
+    assert np.abs(G - fx["gates"]).max() < 1e-15
+    assert np.abs(pl.fill_probs() - fx["probs"]).max() < 1e-10
+    cols = fx["dprobs_cols"]
+    with pytest.raises(_lib.GstError):                      # general leaves: derivative fills need the leaves' data first
+        pl.fill_dprobs(param_idx=cols, eps=eps)
+    pl.set_composite_general(*cm.pack_general(dvs, fds), fd_eps=eps)
+    Jf = pl.fill_dprobs(param_idx=cols, eps=eps)
+    assert np.abs(Jf - fx["dprobs_map"]).max() < 1e-8, np.abs(Jf - fx["dprobs_map"]).max()
+    with pytest.raises(_lib.GstError):                      # ... and FD fills the step size the leaves were stepped with
+        pl.fill_dprobs(param_idx=cols, eps=2 * eps)
+    Ja = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    rows = matrix_rows_by_circuit(fx)
+    assert np.abs(Ja - fx["matrix_by_circuit_dprobs"][rows]).max() < 1e-8, np.abs(Ja - fx["matrix_by_circuit_dprobs"][rows]).max()
+    # every column: exact vs FD (forward differences: eps x second derivative), every parameter of every leaf reached
+    allc = np.arange(int(fx["nP"]))
+    Jall = pl.fill_dprobs(param_idx=allc, mode=_lib.DERIV_ANALYTIC)
+    Jfd = pl.fill_dprobs(param_idx=allc, eps=eps)
+    assert np.abs(Jall - Jfd).max() < 1e-4 and np.array_equal(Jall[:, cols], Ja)
+    used = np.zeros(int(fx["nP"]), bool)
+    for g in range(len(cm.gate_factors)):
+        used[cm.gate_params(g)] = True
+    assert (np.abs(Jall[:, used]).max(axis=0) > 0).all()
+    # the restatement's layer derivatives are what the device built (compare through the host-supplied route)
+    ref = _plan(fx)
+    ref.set_model(fx["gates"], fx["rhos"], fx["effects"])
+    objs = [(0, g, qs, dm) for g, (qs, dm) in enumerate(cm.gate_derivs(fx["cmp_leaf_values"], dvs))]
+    spam = [(1, 0, np.arange(64), np.eye(64))] + [(2, e, np.nonzero((fx["cmp_spam_kind"] == 2) & (fx["cmp_spam_obj"] == e))[0][np.argsort(
+        fx["cmp_spam_elem"][(fx["cmp_spam_kind"] == 2) & (fx["cmp_spam_obj"] == e)])], np.eye(64)) for e in range(8)]
+    ref.set_derivs(int(fx["nP"]), spam + objs)
+    Jh = ref.fill_dprobs(param_idx=allc, mode=_lib.DERIV_ANALYTIC)
+    assert np.abs(Jall - Jh).max() < 1e-12, np.abs(Jall - Jh).max()
