@@ -417,170 +417,21 @@ def main():
         exchange_probs()
     barrier_sync(plan)
     dtp = ctx.max_over_ranks(time.perf_counter() - tp0)
-    # secondary: the same fill through the log-depth level pass (GST_OPT_FAST_PROBS: germ-power paths by matrix squaring and
-    # doubling on the MFMA cores, <= 1e-10 against the bit-exact probabilities -- what a line search of the optimizer may use)
-    fast_info = None
-    try:
-        exact = plan.memcpy_d2h(np.empty(nE_local), d_probs)
-        plan.set_option(_lib.OPT_FAST_PROBS, 1)
-        for _ in range(2):
-            plan.fill_probs_dev(d_probs)
-        barrier_sync(plan)
-        used = plan.stats()["last_levels"]
-        tf0 = time.perf_counter()
-        for _ in range(n_pr):
-            plan.set_model(gates, rhos, effects)
-            plan.fill_probs_dev(d_probs)
-            exchange_probs()
-        barrier_sync(plan)
-        dtf = ctx.max_over_ranks(time.perf_counter() - tf0)
-        fast = plan.memcpy_d2h(np.empty(nE_local), d_probs)
-        fast_info = {"ms": 1e3 * dtf / n_pr, "probs_per_s": nE_total * n_pr / dtf, "level_pass_used": bool(used),
-                     "max_abs_vs_bit_exact_probs": float(np.abs(fast - exact).max()),
-                     "note": "gst_fill_probs_dev under GST_OPT_FAST_PROBS; bar 1e-10; the default fill stays bit-identical to the reference"}
-    except Exception as e:
-        fast_info = {"error": "%s: %s" % (type(e).__name__, e)}
-    finally:
-        plan.set_option(_lib.OPT_FAST_PROBS, 0)
-        plan.fill_probs_dev(d_probs)
-        barrier_sync(plan)
-
-    # secondary: the same Jacobian by analytic derivatives (MatrixForwardSimulator semantics, <= 1e-8 vs that simulator)
-    ana_info = None
-    if args.deriv == "fd" and not args.no_analytic:
-        for _ in range(2):
-            plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
-        barrier_sync(plan)
-        ta0 = time.perf_counter()
-        n_an = max(3, args.steps)
-        for _ in range(n_an):
-            plan.set_model(gates, rhos, effects)
-            plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
-            exchange_probs()
-        barrier_sync(plan)
-        dta = ctx.max_over_ranks(time.perf_counter() - ta0)
-        ana_kms = plan.stats()["last_kernel_ms"]
-        ana_bytes = 8.0 * nE_local * nP
-        ana_info = {"value": nE_total * nP * n_an / dta, "unit": "Jacobian-elements/s", "ms_per_step": 1e3 * dta / n_an,
-                    "kernel_ms": ana_kms,
-                    "roofline": {"bound": "hbm", "kernel": "analytic_mfma_kernel (+ the backward chain pass that feeds it)",
-                                 "achieved": ana_bytes / (ana_kms * 1e-3) / 1e9 if ana_kms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": ana_bytes / (ana_kms * 1e-3) / 1e9 / HBM_PEAK_GBS if ana_kms > 0 else None,
-                                 "whole_step_frac": ana_bytes / (dta / n_an) / 1e9 / HBM_PEAK_GBS,
-                                 "bytes_per_launch": ana_bytes,
-                                 "note": "algorithmic bytes = the Jacobian write 8*nE*nP; `frac` over the contraction kernel, `whole_step_frac` over the step (chain passes included)"},
-                    "chain_passes": "log-depth level passes" if plan.stats()["last_levels"] else "sequential walks",
-                    "structural_zeros": ("resident (the destination is tracked device memory whose previous contents were this fill's: "
-                                         "the zero blocks of gates a circuit never applies are not stored again)"
-                                         if plan.stats()["last_zeros_resident"] else "stored by every fill"),
-                    "note": "analytic derivatives (reference MatrixForwardSimulator semantics); secondary figure, not `value`"}
-        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the FD Jacobian resident
-        barrier_sync(plan)
-
-    # secondary (N=1): the same design under the CPTPLND parameterisation StandardGST fits by default -- every member a
-    # static target composed with an exponentiated Lindblad error generator (1,920 parameters), the dense members built
-    # ON THE DEVICE for the base model and for every finite-difference step (gst_set_lindblad)
-    cptp_info = None
-    if world == 1 and lay_world == 1 and not args.no_cptplnd:
-        from pygsti_amd import lindblad as LBM
-        lmodel = LBM.LindbladModel.from_target(pack.target_model(), layout.model_gate_labels, layout.effect_labels, "CPTPLND")
-        theta = 0.003 * np.random.default_rng(9).standard_normal(lmodel.num_params)
-        nPl = lmodel.num_params
-        plan.set_lindblad(lmodel)
-        d_outl = plan.device_malloc(nE_local * nPl * 8, tracked=True)
-        pidx_l = np.arange(nPl, dtype=np.int64)
-        try:
-            t_set0 = time.perf_counter()
-            plan.set_lindblad_params(theta)
-            t_set = time.perf_counter() - t_set0
-            plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_FD)       # warm-up
-            barrier_sync(plan)
-            n_c = max(2, min(args.steps, 3))
-            tc0 = time.perf_counter()
-            for _ in range(n_c):
-                plan.set_lindblad_params(theta)
-                plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_FD)
-            barrier_sync(plan)
-            dtc = (time.perf_counter() - tc0) / n_c
-            chk = plan.memcpy_d2h(np.empty(nPl), d_outl + ((nE_local - 1) * nPl) * 8)
-            assert np.isfinite(chk).all()
-            # the same Jacobian with exact derivatives: element Jacobian (analytic contraction) x the members' derivative
-            # matrices, both computed on the device (MatrixForwardSimulator semantics for this parameterisation)
-            dta = None
-            try:
-                plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
-                barrier_sync(plan)
-                ta0 = time.perf_counter()
-                for _ in range(n_c):
-                    plan.set_lindblad_params(theta)
-                    plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
-                barrier_sync(plan)
-                dta = (time.perf_counter() - ta0) / n_c
-            except Exception as e:
-                log("CPTPLND analytic leg failed: %s" % e)
-            cptp_info = {"value": nE_local * nPl / dtc, "unit": "Jacobian-elements/s", "ms_per_step": 1e3 * dtc, "n_params": nPl,
-                         "set_params_ms": 1e3 * t_set,
-                         "analytic_ms_per_step": None if dta is None else 1e3 * dta,
-                         "analytic_elements_per_s": None if dta is None else nE_local * nPl / dta,
-                         "parity": "FD columns vs the reference's Map simulator: <= 1e-8 only for circuits of depth <= 16 (6.9e-9); 5e-8 at depth "
-                                   "41-80 and 7e-8 at depth 1,030 (2Q germ-power families), 1.2e-7 at depth 81-160 (1Q L<=128 design) -- the "
-                                   "perturbed member's exponential (scaled Taylor here, scipy's Pade there) differs in the last bit and the "
-                                   "quotient amplifies it by occurrences/eps; the EXACT route (`analytic_ms_per_step`, the adapter's default "
-                                   "for these models) agrees with the Matrix simulator to 1.2e-11 at depth 1,030 "
-                                   "(profiles/r04_cptplnd_depth_profile_*.json, tests/test_gpu_lindblad.py)",
-                         "note": "bulk_fill_dprobs of the CPTPLND-parameterised model (FD eps=1e-7, Map-simulator semantics): every column's "
-                                 "changed member assembled and exponentiated on the device (no host to_dense per "
-                                 "column), walks share the base pass's states (gates: dirty programs, 4 columns per wavefront; the preparation: 64 per wavefront on the lane-per-model kernel), POVM columns from "
-                                 "the cached final states; round 2's form of the same Jacobian (host-stepped dense model sets, one "
-                                 "independent walk per (program, model)) took 580 ms; secondary figure, not `value`"}
-        finally:
-            plan.device_free(d_outl)
-            plan.set_lindblad(None)
-            plan.set_model(gates, rhos, effects)
-            plan.set_param_map(*layout.param_map(model))
-        plan.fill_dprobs_dev(d_out, nP, pidx, None, 1e-7, d_probs, mode)      # leave the headline Jacobian resident
-        barrier_sync(plan)
-        log("CPTPLND leg done: %.1f ms per Jacobian" % (1e3 * dtc))
-
+    # ---- secondary legs (tools/bench_legs.py): nothing below is part of the timed region -----------------------------------
+    from types import SimpleNamespace
+    import importlib.util
+    _spec = importlib.util.spec_from_file_location("bench_legs", os.path.join(ROOT, "tools", "bench_legs.py"))
+    legs = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(legs)
+    B = SimpleNamespace(args=args, plan=plan, ctx=ctx, comm=comm, world=world, rank=rank, lay_world=lay_world, layout=layout, model=model,
+                        pack=pack, gates=gates, rhos=rhos, effects=effects, d_out=d_out, d_probs=d_probs, d_pfull=d_pfull, pidx=pidx, nP=nP,
+                        nP_local=nP_local, nE_local=nE_local, nE_total=nE_total, mode=mode, blocks=blocks, row0=row0, exchange=exchange,
+                        grid=grid, col_split=col_split, barrier_sync=barrier_sync, exchange_probs=exchange_probs, log=log, n_pr=n_pr,
+                        HBM_PEAK_GBS=HBM_PEAK_GBS)
+    fast_info = legs.fast_probs(B)          # the probability fill through the log-depth level pass (GST_OPT_FAST_PROBS)
+    ana_info = legs.analytic(B)             # the same Jacobian by exact derivatives (MatrixForwardSimulator semantics)
+    cptp_info = legs.cptplnd(B)             # the same design under the CPTPLND parameterisation (device-built Lindblad members)
     log("probs / analytic legs done")
-    # secondary (N>1): the fan-in of the Jacobian row blocks to rank 0 between device buffers (Gatherv,
-    # resourceallocation.py:329-348 -- what `gather_local_array('ep', ...)` is for), alone and behind a fill
-    if world > 1 and comm is not None and not args.no_jacobian_gather and args.scaling == "strong":
-        d_jfull = plan.device_malloc(nE_total * nP * 8) if rank == 0 else None
-        try:
-            if rank == 0:       # the root's own rows in place (one device-to-device copy per fill in a real run)
-                plan.fill_dprobs_dev(d_jfull + row0 * nP * 8, nP, pidx, None, 1e-7, d_probs, mode)
-            comm.gather_rows(d_out, d_jfull, nP, blocks, 0, plan)                       # warm-up (maps peers, opens links)
-            barrier_sync(plan)
-            tg = time.perf_counter()
-            n_g = 3
-            for _ in range(n_g):
-                comm.gather_rows(d_out, d_jfull, nP, blocks, 0, plan)
-            barrier_sync(plan)
-            t_gather = ctx.max_over_ranks(time.perf_counter() - tg) / n_g
-            tg = time.perf_counter()
-            for _ in range(n_g):
-                plan.set_model(gates, rhos, effects)
-                dst = d_jfull + row0 * nP * 8 if rank == 0 else d_out
-                plan.fill_dprobs_dev(dst, nP, pidx, None, 1e-7, d_probs, mode)
-                comm.gather_rows(d_out, d_jfull, nP, blocks, 0, plan)
-            barrier_sync(plan)
-            t_both = ctx.max_over_ranks(time.perf_counter() - tg) / n_g
-            moved = 8.0 * (nE_total - nE_local) * nP if rank == 0 else 0.0
-            moved = ctx.max_over_ranks(moved)
-            exchange["jacobian_gather_to_rank0"] = {
-                "ms": 1e3 * t_gather, "GB": moved / 1e9, "GBps_into_rank0": moved / t_gather / 1e9,
-                "fill_plus_gather_ms": 1e3 * t_both,
-                "elements_per_s_with_gather": nE_total * nP / t_both,
-                "note": "secondary: rows of the other ranks written into rank 0's assembled [nE][nP] array, each block "
-                        "over its own xGMI link (grouped point-to-point under RCCL, peer copies under IPC)"}
-            if rank == 0:
-                chk = plan.memcpy_d2h(np.empty(nP), d_jfull + ((nE_total - 1) * nP) * 8)
-                assert np.isfinite(chk).all()
-        finally:
-            if d_jfull is not None:
-                plan.device_free(d_jfull)
-
+    legs.jacobian_gather(B)                 # N > 1: the Jacobian fan-in to rank 0 (adds exchange['jacobian_gather_to_rank0'])
     # secondary (N=1): the other BASELINE configurations, each with its own roofline fraction -- 1Q L<=128 (configs[1]),
     # the 3-qubit D = 64 model (configs[4]: FD block, full analytic Jacobian, a Hessian block) and one rectangle of the 2Q
     # objective Hessian (FD of FD) -- so that they are driver-timed figures, not builder-only ones
@@ -596,188 +447,10 @@ def main():
         barrier_sync(plan)
 
     log("exchange legs done")
-    # secondary (every N): one Levenberg-Marquardt iteration's device work end to end -- model upload, Jacobian fill,
-    # objective maps (lsvec, dlsvec row scale), J_s^T J_s and J_s^T lsvec on the resident Jacobian, and for N > 1 the
-    # all-reduce of the nP^2 + nP partial sums between device buffers (the path's one real exchange step, SURVEY 8(e) /
-    # row f1).  This is the figure multi-GPU scaling of a FIT hinges on: no Jacobian ever leaves its GPU.
-    lm_info = None
-    if not col_split and not args.no_lm_step:
-        bufs = [plan.device_malloc(n) for n in (nP * nP * 8, nP * 8, nE_local * 8, nE_local * 8, nE_local * 8, nE_local * 8)]
-        d_jtj, d_jtf, d_ls, d_w, d_c, d_N = bufs
-        try:
-            pb = plan.memcpy_d2h(np.empty(nE_local), d_probs)
-            plan.memcpy_h2d(d_c, np.random.default_rng(1234 + rank).binomial(1000, np.clip(pb, 0.0, 1.0)).astype(np.float64))
-            plan.memcpy_h2d(d_N, np.full(nE_local, 1000.0))
-
-            lm_mode = [mode]
-
-            def lm_step():
-                plan.set_model(gates, rhos, effects)
-                plan.fill_dprobs_dev(d_out, nP_local, pidx, None, 1e-7, d_probs, lm_mode[0])
-                plan.objective_rows_dev("logl", d_probs, d_c, d_N, nE_local, d_ls, d_w, want_sum=False)
-                plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj, d_w)          # (scales the rows of J in place first)
-                plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_ls, d_jtf)
-                if world > 1 and comm is not None:
-                    comm.allreduce_sum(d_jtj, nP * nP, plan)
-                    comm.allreduce_sum(d_jtf, nP, plan)
-            lm_step()
-            barrier_sync(plan)
-            n_lm = max(3, min(args.steps, 5))
-            tl = time.perf_counter()
-            for _ in range(n_lm):
-                lm_step()
-            barrier_sync(plan)
-            t_lm = ctx.max_over_ranks(time.perf_counter() - tl) / n_lm
-            chk = plan.memcpy_d2h(np.empty(nP), d_jtf)
-            assert np.isfinite(chk).all()
-            lm_info = {"ms_per_step": 1e3 * t_lm, "elements_per_s": nE_total * nP / t_lm, "unit": "Jacobian-elements/s",
-                       "allreduce_MB": (nP * nP + nP) * 8 / 1e6 if world > 1 else 0.0,
-                       "allreduce_transport": ctx.transport if world > 1 else None,
-                       "note": "fill + Poisson-picture dlogl maps + J^T J (block-sparse split-K MFMA fp64 SYRK) + J^T f"
-                               + (" + all-reduce of nP^2 + nP doubles between device buffers" if world > 1 else "")
-                               + "; the Jacobian never leaves HBM; secondary figure, not `value`"}
-            if mode == _lib.DERIV_FD and not args.no_analytic:
-                # the same iteration with the exact Jacobian (what an optimizer that does not insist on the Map simulator's
-                # finite differences would run; the structural zeros of the re-used Jacobian stay resident under the scaling)
-                lm_mode[0] = _lib.DERIV_ANALYTIC
-                lm_step(); lm_step()
-                barrier_sync(plan)
-                tl = time.perf_counter()
-                for _ in range(n_lm):
-                    lm_step()
-                barrier_sync(plan)
-                t_lma = ctx.max_over_ranks(time.perf_counter() - tl) / n_lm
-                assert np.isfinite(plan.memcpy_d2h(np.empty(nP), d_jtf)).all()
-                lm_info["exact_jacobian_ms_per_step"] = 1e3 * t_lma
-                lm_info["exact_jacobian_zeros_resident"] = bool(plan.stats()["last_zeros_resident"])
-                lm_mode[0] = mode
-        finally:
-            for d in bufs:
-                plan.device_free(d)
-        plan.set_model(gates, rhos, effects)
-        plan.fill_dprobs_dev(d_out, nP_local, pidx, None, 1e-7, d_probs, mode)      # leave the headline Jacobian resident (unscaled)
-        barrier_sync(plan)
-        log("LM-step leg done: %.2f ms" % (1e3 * t_lm))
-    jtj_info = None
-    if args.jtj and col_split and world > 1 and comm is not None:
-        # Normal equations with the columns distributed (distlayout.py:1306-1346): the ranks of an atom-processor split
-        # the atom's ROWS, exchange each other's column blocks between device buffers (gst_comm_exchange_blocks), and
-        # each contracts its [rows/NP x nP] share; then the usual all-reduce of nP^2 doubles.
-        from pygsti_amd.layout import _slice_up_range
-        G = grid[1]
-        share = _slice_up_range(nE_local, G)[layout.param_proc_index]
-        n_my = share.stop - share.start
-        xblocks = layout.column_exchange_blocks(0)
-        d_stage = plan.device_malloc(max(n_my * nP, 1) * 8); d_T = plan.device_malloc(max(n_my * nP, 1) * 8)
-        d_jtj = plan.device_malloc(nP * nP * 8)
-
-        def assemble():
-            comm.exchange_blocks(d_out, d_stage, xblocks, plan)
-            for cs in layout.param_slices:
-                c = cs.stop - cs.start
-                plan.copy_block_dev(d_T + cs.start * 8, nP, d_stage + n_my * cs.start * 8, c, n_my, c)
-        assemble(); plan.fill_jtj_dev(d_T, n_my, nP, nP, d_jtj); comm.allreduce_sum(d_jtj, nP * nP, plan)      # warm-up
-        barrier_sync(plan)
-        tj = time.perf_counter()
-        for _ in range(3):
-            assemble()
-        barrier_sync(plan)
-        t_x = ctx.max_over_ranks((time.perf_counter() - tj) / 3)
-        tj = time.perf_counter()
-        for _ in range(3):
-            plan.fill_jtj_dev(d_T, n_my, nP, nP, d_jtj)
-        barrier_sync(plan)
-        t_jtj = ctx.max_over_ranks((time.perf_counter() - tj) / 3)
-        tj = time.perf_counter()
-        for _ in range(3):
-            comm.allreduce_sum(d_jtj, nP * nP, plan)
-        barrier_sync(plan)
-        t_ar = ctx.max_over_ranks((time.perf_counter() - tj) / 3)
-        sent = 8.0 * nE_local * nP_local * (G - 1) / G
-        jtj_info = {"grid": "%dx%d" % grid, "column_exchange_ms": 1e3 * t_x, "column_exchange_GB_sent_per_rank": sent / 1e9,
-                    "column_exchange_GBps_per_rank": sent / t_x / 1e9, "jtj_ms": 1e3 * t_jtj, "allreduce_ms": 1e3 * t_ar,
-                    "note": "columns distributed over the parameter-processors of an atom-processor: every rank sends the other "
-                            "ranks' row shares of its column slice and receives their slices of its own share (grouped "
-                            "point-to-point under RCCL, peer copies under IPC), contracts [rows/NP x nP] with the MFMA SYRK, "
-                            "then the nP^2 all-reduce"}
-        for d in (d_stage, d_T, d_jtj):
-            plan.device_free(d)
-    elif args.jtj and not col_split:
-        # One Levenberg-Marquardt iteration's worth of data reduction on the resident Jacobian (row f1):
-        # probabilities -> lsvec and dlsvec row scale (Poisson-picture dlogl, synthetic counts N=1000 drawn around the
-        # model's own probabilities) -> J_s^T J_s (split-K MFMA fp64) and J_s^T lsvec (streaming).
-        d_jtj = plan.device_malloc(nP * nP * 8); d_jtf = plan.device_malloc(nP * 8)
-        d_ls = plan.device_malloc(nE_local * 8); d_w = plan.device_malloc(nE_local * 8)
-        d_c = plan.device_malloc(nE_local * 8); d_N = plan.device_malloc(nE_local * 8)
-        pb = plan.memcpy_d2h(np.empty(nE_local), d_probs)
-        rngc = np.random.default_rng(1234 + rank)
-        plan.memcpy_h2d(d_c, rngc.binomial(1000, np.clip(pb, 0.0, 1.0)).astype(np.float64))
-        plan.memcpy_h2d(d_N, np.full(nE_local, 1000.0))
-        obj = plan.objective_rows_dev("logl", d_probs, d_c, d_N, nE_local, d_ls, d_w)                                # warm-up
-        plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj); plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_ls, d_jtf)
-        barrier_sync(plan)
-        tj = time.perf_counter()
-        for _ in range(10):
-            plan.objective_rows_dev("logl", d_probs, d_c, d_N, nE_local, d_ls, d_w, want_sum=False)
-        barrier_sync(plan)
-        t_obj = (time.perf_counter() - tj) / 10
-        tj = time.perf_counter()
-        for _ in range(3):
-            plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj)      # (row scaling in place is a separate 2-pass stream; timed below)
-        barrier_sync(plan)
-        t_jtj = (time.perf_counter() - tj) / 3
-        tj = time.perf_counter()
-        for _ in range(3):
-            plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_ls, d_jtf)
-        barrier_sync(plan)
-        t_jtf = (time.perf_counter() - tj) / 3
-        tj = time.perf_counter()
-        plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj, d_w)     # once, with the row scale (J is scaled in place)
-        barrier_sync(plan)
-        t_jtj_scaled = time.perf_counter() - tj
-        jtj_info = {"objective": "Poisson-picture dlogl, min_prob_clip=radius=1e-4", "objective_value": obj,
-                    "objective_rows_ms": 1e3 * t_obj,
-                    "jtj_ms": 1e3 * t_jtj, "jtj_TFLOPs": 2.0 * nE_local * nP * nP / 2 / t_jtj / 1e12,
-                    "jtj_with_row_scale_ms": 1e3 * t_jtj_scaled,
-                    "jtf_ms": 1e3 * t_jtf, "jtf_GBps": 8.0 * nE_local * nP / t_jtf / 1e9,
-                    "note": "element-wise objective kernel + hand-written split-K MFMA fp64 SYRK / streaming GEMV on the device-resident Jacobian of this rank (flops counted for the triangle: nE*nP^2)"}
-        if world > 1 and comm is not None:
-            # the path's one real exchange step: every rank holds the partial J^T J of its rows; the optimizer needs
-            # the sum -> one all-reduce of nP^2 (+ nP) doubles between the device buffers, cf. distlayout.py:1259,1355
-            comm.allreduce_sum(d_jtj, nP * nP, plan)               # warm-up
-            barrier_sync(plan)
-            ta = time.perf_counter()
-            for _ in range(5):
-                comm.allreduce_sum(d_jtj, nP * nP, plan)
-                comm.allreduce_sum(d_jtf, nP, plan)
-            barrier_sync(plan)
-            jtj_info["allreduce_ms"] = 1e3 * ctx.max_over_ranks(time.perf_counter() - ta) / 5
-            jtj_info["allreduce_MB"] = (nP * nP + nP) * 8 / 1e6
-            jtj_info["allreduce_transport"] = ctx.transport
-        for d in (d_jtj, d_jtf, d_ls, d_w, d_c, d_N):
-            plan.device_free(d)
-
+    lm_info = legs.lm_step(B)               # one Levenberg-Marquardt iteration's device work end to end
+    jtj_info = legs.normal_equations(B)     # --jtj: the normal equations in detail (column-distributed grid or per-kernel timings)
     log("normal-equation leg done")
-    # secondary (N=1): the reference API end to end -- bulk_fill_dprobs into the caller's HOST 'ep' array, PCIe included
-    host_fill = None
-    if world == 1 and lay_world == 1 and not args.no_host_fill:
-        J_host = layout.allocate_local_array("ep", "d")            # page-locked (registered) by the layout
-        log("host array allocated, pinned=%s" % layout.last_array_pinned)
-        pr_host = np.empty(nE_local)
-        plan.fill_dprobs(J_host, pidx, None, 1e-7, pr_host, mode)  # warm-up
-        th = time.perf_counter()
-        n_h = 3
-        for _ in range(n_h):
-            plan.set_model(gates, rhos, effects)
-            plan.fill_dprobs(J_host, pidx, None, 1e-7, pr_host, mode)
-        t_host = (time.perf_counter() - th) / n_h
-        host_fill = {"ms": 1e3 * t_host, "elements_per_s": nE_local * nP / t_host, "GBps": 8.0 * nE_local * nP / t_host / 1e9,
-                     "pinned": bool(getattr(layout, "last_array_pinned", False)),
-                     "note": "gst_fill_dprobs into a host numpy 'ep' array from layout.allocate_local_array (what "
-                             "bulk_fill_dprobs(array, layout) returns in the reference): the FD kernel stores 7 GB straight into the page-locked array over PCIe; never `value`"}
-        layout.free_local_array(J_host)
-        log("host-fill leg done: %.1f ms per fill" % (1e3 * t_host))
-
+    host_fill = legs.host_fill(B)           # the reference API end to end: bulk_fill_dprobs into the caller's HOST array
     def measured_traffic(kernel_prefix):
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
         (profiles/r0x_hbm_counters.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; KB -> bytes, and
@@ -869,6 +542,9 @@ def main():
             "per_rank": {"ms_per_step": per_rank_ms, "dominant_kernel_ms": per_rank_kernel_ms,
                          "note": "each rank's own time for the K steps before the closing barrier; `ms_per_step` is the max over ranks after it"},
             "exchange": exchange,
+            # the north-star variant of the N > 1 figure: every step ALSO fans the Jacobian row blocks in to rank 0 over xGMI
+            # (`value` leaves them distributed, as the reference's bulk_fill_dprobs does); None at N = 1 or when the leg is off
+            "value_incl_jacobian_gather": (exchange or {}).get("jacobian_gather_to_rank0", {}).get("elements_per_s_with_gather"),
             "lm_step": lm_info,
             "normal_equations": jtj_info,
             "analytic_dprobs": ana_info,
