@@ -66,7 +66,10 @@ typedef struct gst_plan gst_plan;
  * are identical because each state is still the same left-to-right product.
  */
 typedef struct {
-    int32_t D;           /* state-vector length d^2 (4 or 16 in this round) */
+    int32_t D;           /* state-vector length: 4 / 16 / 64 (one to three qubits) run natively; any other 2 .. 64 (a qutrit's 9 in the
+                            Gell-Mann basis, a qubit with a leakage level ...) runs zero-padded at the next of those -- every array of
+                            this interface keeps the CALLER's D (gates [n][D][D], element indices i * D + j ...), results are those of the
+                            un-padded sums up to the sign of an exact zero (the padded terms are + 0.0) */
     int32_t n_gates;     /* number of distinct layer operators (atom.op_labels) */
     int32_t n_rhos;      /* atom.rho_labels */
     int32_t n_effects;   /* atom.full_effect_labels */

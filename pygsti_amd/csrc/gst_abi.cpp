@@ -57,9 +57,15 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
     // default slot budget: what fits in LDS at 4 wavefronts per SIMD (16 per CU): one 8 KB slot at D=16
     int32_t max_slots = opt ? opt->max_slots : 0;
     if (p->hp.D != 4 && p->hp.D != 16 && p->hp.D != 64) {
+        // Any other dimension up to 64 (statecreps.cpp:20-58 is dimension-generic: a qutrit in the Gell-Mann basis has 9, a
+        // qubit with a leakage level as well) runs zero-padded at the next supported one.
         const int D = p->hp.D;
-        delete p;
-        return fail(GST_EUNSUPPORTED, "state dimension " + std::to_string(D) + " not supported (4, 16 or 64)");
+        if (D < 2 || D > 64) {
+            delete p;
+            return fail(GST_EUNSUPPORTED, "state dimension " + std::to_string(D) + " not supported (2 .. 64)");
+        }
+        p->D_user = D;
+        p->hp.D = D <= 4 ? 4 : D <= 16 ? 16 : 64;
     }
     // D = 64: the register-blocked derivative kernel keeps save slots in registers and tracks 2 (plans that ask for
     // more run on the LDS-slot kernels).  D <= 16: the lane-per-model kernel keeps slots in LDS at 8*D*64 bytes each
@@ -368,16 +374,21 @@ int gst_set_model(gst_plan* p, const double* gates, const double* rhos, const do
 {
     return guarded([&]() -> int {
     if (!p || !rhos || !effects || (p->hp.n_gates > 0 && !gates)) return fail(GST_EINVAL, "NULL argument");
-    const int D = p->hp.D;
+    const int D = p->hp.D, Du = p->user_D();
     const size_t ng = (size_t)p->hp.n_gates * D * D;
-    p->h_gates.assign(gates, gates + ng);
-    p->h_gates_t.resize(ng);
+    p->h_gates.assign(ng, 0.0);
+    p->h_gates_t.assign(ng, 0.0);
     for (int g = 0; g < p->hp.n_gates; g++)
-        for (int i = 0; i < D; i++)
-            for (int j = 0; j < D; j++)
-                p->h_gates_t[((size_t)g * D + j) * D + i] = gates[((size_t)g * D + i) * D + j];
-    p->h_rhos.assign(rhos, rhos + (size_t)p->hp.n_rhos * D);
-    p->h_effects.assign(effects, effects + (size_t)p->hp.n_effects * D);
+        for (int i = 0; i < Du; i++)
+            for (int j = 0; j < Du; j++) {
+                const double x = gates[((size_t)g * Du + i) * Du + j];
+                p->h_gates[((size_t)g * D + i) * D + j] = x;
+                p->h_gates_t[((size_t)g * D + j) * D + i] = x;
+            }
+    p->h_rhos.assign((size_t)p->hp.n_rhos * D, 0.0);
+    p->h_effects.assign((size_t)p->hp.n_effects * D, 0.0);
+    for (int r = 0; r < p->hp.n_rhos; r++) std::memcpy(&p->h_rhos[(size_t)r * D], rhos + (size_t)r * Du, (size_t)Du * 8);
+    for (int e = 0; e < p->hp.n_effects; e++) std::memcpy(&p->h_effects[(size_t)e * D], effects + (size_t)e * Du, (size_t)Du * 8);
     p->have_model = true;
     p->model_dirty = true;
     return GST_OK;
@@ -388,18 +399,21 @@ int gst_set_param_map(gst_plan* p, int32_t n_params, const int32_t* kind, const 
 {
     return guarded([&]() -> int {
     if (!p || n_params < 0 || (n_params > 0 && (!kind || !obj || !elem))) return fail(GST_EINVAL, "bad argument");
-    const int D = p->hp.D;
+    const int D = p->hp.D, Du = p->user_D();
     for (int32_t i = 0; i < n_params; i++) {
         const int k = kind[i];
         if (k == GST_KIND_NONE) continue;
         const int nobj = k == GST_KIND_GATE ? p->hp.n_gates : k == GST_KIND_RHO ? p->hp.n_rhos : k == GST_KIND_EFFECT ? p->hp.n_effects : -1;
-        const int nel = k == GST_KIND_GATE ? D * D : D;
+        const int nel = k == GST_KIND_GATE ? Du * Du : Du;
         if (nobj < 0 || obj[i] < 0 || obj[i] >= nobj || elem[i] < 0 || elem[i] >= nel)
             return fail(GST_EINVAL, "parameter map entry " + std::to_string(i) + " out of range");
     }
     p->pkind.assign(kind, kind + n_params);
     p->pobj.assign(obj, obj + n_params);
     p->pelem.assign(elem, elem + n_params);
+    if (Du != D)                                   // a gate element (i, j) of the caller's Du x Du matrix sits at i * D + j here
+        for (int32_t i = 0; i < n_params; i++)
+            if (kind[i] == GST_KIND_GATE) p->pelem[(size_t)i] = (elem[i] / Du) * D + elem[i] % Du;
     p->have_pmap = true;
     p->cached_kind = 0;      // device lane tables / column maps describe the old map
     return GST_OK;
@@ -422,7 +436,8 @@ int gst_set_complement_effect(gst_plan* p, int32_t comp_index, const double* ide
     }
     p->comp_index = comp_index;
     p->comp_others.assign(others, others + n_others);
-    p->comp_identity.assign(identity, identity + p->hp.D);
+    p->comp_identity.assign((size_t)p->hp.D, 0.0);
+    std::memcpy(p->comp_identity.data(), identity, (size_t)p->user_D() * 8);
     return GST_OK;
     });
 }
@@ -863,9 +878,18 @@ int gst_get_model(gst_plan* p, double* gates, double* rhos, double* effects)
     return guarded([&]() -> int {
     if (!p) return fail(GST_EINVAL, "plan is NULL");
     if (!p->have_model) return fail(GST_ESTATE, "no model has been set");
-    if (gates) std::memcpy(gates, p->h_gates.data(), p->h_gates.size() * 8);
-    if (rhos) std::memcpy(rhos, p->h_rhos.data(), p->h_rhos.size() * 8);
-    if (effects) std::memcpy(effects, p->h_effects.data(), p->h_effects.size() * 8);
+    const int D = p->hp.D, Du = p->user_D();
+    if (Du == D) {
+        if (gates) std::memcpy(gates, p->h_gates.data(), p->h_gates.size() * 8);
+        if (rhos) std::memcpy(rhos, p->h_rhos.data(), p->h_rhos.size() * 8);
+        if (effects) std::memcpy(effects, p->h_effects.data(), p->h_effects.size() * 8);
+        return GST_OK;
+    }
+    if (gates)
+        for (int g = 0; g < p->hp.n_gates; g++)
+            for (int i = 0; i < Du; i++) std::memcpy(gates + ((size_t)g * Du + i) * Du, &p->h_gates[((size_t)g * D + i) * D], (size_t)Du * 8);
+    if (rhos) for (int r = 0; r < p->hp.n_rhos; r++) std::memcpy(rhos + (size_t)r * Du, &p->h_rhos[(size_t)r * D], (size_t)Du * 8);
+    if (effects) for (int e = 0; e < p->hp.n_effects; e++) std::memcpy(effects + (size_t)e * Du, &p->h_effects[(size_t)e * D], (size_t)Du * 8);
     return GST_OK;
     });
 }

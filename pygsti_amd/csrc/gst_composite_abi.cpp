@@ -252,7 +252,7 @@ int gst_set_composite(gst_plan* p, int32_t n_params, const gst_composite_desc* d
     if (!d || d->n_leaves == 0) { C = gst_plan::Composite(); p->cached_kind = 0; return GST_OK; }
     const int D = p->hp.D;
     const int nq = D == 4 ? 1 : D == 16 ? 2 : D == 64 ? 3 : 0;
-    if (!nq) return fail(GST_EUNSUPPORTED, "composite layers exist for D = 4, 16 and 64");
+    if (!nq || p->D_user) return fail(GST_EUNSUPPORTED, "composite layers exist for D = 4, 16 and 64 (registers of qubits)");
     if (n_params < 0 || d->n_leaves < 0 || !d->leaf_dim || !d->leaf_param || !d->gate_factor_ptr || !d->factor_leaf || !d->factor_targets)
         return fail(GST_EINVAL, "bad argument");
     gst_plan::Composite N;

@@ -539,7 +539,24 @@ int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t*
     p->cached_kind = 0;
     if (n_objs == 0) { p->derivs_set = false; p->dv2_set = false; p->dv2_off.clear(); return GST_OK; }
     if (!kind || !obj || !n_cols || !param_idx || !deriv) return fail(GST_EINVAL, "bad argument");
-    const int D = p->hp.D;
+    const int D = p->hp.D, Du = p->user_D();
+    std::vector<double> padded;            // (a padded dimension: the caller's [Du*Du or Du][n] matrices with their rows moved)
+    if (Du != D) {
+        int64_t nd = 0, ns = 0;
+        for (int32_t o = 0; o < n_objs; o++) nd += (int64_t)(kind[o] == GST_KIND_GATE ? D * D : D) * std::max(n_cols[o], 0);
+        padded.assign((size_t)nd, 0.0);
+        nd = 0;
+        for (int32_t o = 0; o < n_objs; o++) {
+            const int64_t n = std::max(n_cols[o], 0);
+            const bool gate = kind[o] == GST_KIND_GATE;
+            for (int e = 0; e < (gate ? Du * Du : Du); e++) {
+                const int ep = gate ? (e / Du) * D + e % Du : e;
+                std::memcpy(&padded[(size_t)(nd + (int64_t)ep * n)], deriv + ns + (int64_t)e * n, (size_t)n * 8);
+            }
+            nd += (int64_t)(gate ? D * D : D) * n; ns += (int64_t)(gate ? Du * Du : Du) * n;
+        }
+        deriv = padded.data();
+    }
     std::vector<int64_t> off_c((size_t)n_objs + 1, 0), off_d((size_t)n_objs + 1, 0);
     for (int32_t o = 0; o < n_objs; o++) {
         const int k = kind[o];
@@ -576,6 +593,7 @@ int gst_set_second_derivs(gst_plan* p, int32_t n_objs, const int32_t* nonzero, c
     if (!p->derivs_set || (size_t)n_objs != p->dv_kind.size()) return fail(GST_ESTATE, "gst_set_second_derivs follows gst_set_derivs, object for object");
     if (!nonzero) return fail(GST_EINVAL, "bad argument");
     const int D = p->hp.D;
+    if (p->D_user) return fail(GST_EUNSUPPORTED, "second derivative matrices with a padded state dimension");
     std::vector<int64_t> off((size_t)n_objs, -1);
     int64_t total = 0;
     for (int32_t o = 0; o < n_objs; o++) {

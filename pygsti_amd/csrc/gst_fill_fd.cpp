@@ -505,9 +505,10 @@ int run_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, const 
                       double* d_out, int64_t ld, const int64_t* dest_idx, double eps, double* d_probs_out)
 {
     const gst::HostPlan& h = p->hp;
-    const int D = h.D;
+    const int D = h.D, Du = p->user_D();
     const int64_t nE = h.n_elements;
     const size_t ng = (size_t)h.n_gates * D * D, nr = (size_t)h.n_rhos * D, ne = (size_t)h.n_effects * D;
+    const size_t ngu = (size_t)h.n_gates * Du * Du, nru = (size_t)h.n_rhos * Du, neu = (size_t)h.n_effects * Du;   // the caller's sets
     const size_t stride = ng + nr + ne;
     double* d_base = d_probs_out ? d_probs_out : p->d_pbase.p;
     int rc = run_probs(p, d_base, false);
@@ -533,14 +534,15 @@ int run_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, const 
     TIME_REC(p, evk0);
     for (int64_t m0 = 0; m0 < n_models; m0 += chunk) {
         const int64_t nm = std::min<int64_t>(chunk, n_models - m0);
+        if (Du != D) std::fill(stage.begin(), stage.begin() + (size_t)nm * stride, 0.0);
         for (int64_t m = 0; m < nm; m++) {
             double* dst = stage.data() + (size_t)m * stride;
-            const double* G = gates + (size_t)(m0 + m) * ng;
+            const double* G = gates + (size_t)(m0 + m) * ngu;
             for (int g = 0; g < h.n_gates; g++)
-                for (int i = 0; i < D; i++)
-                    for (int j = 0; j < D; j++) dst[((size_t)g * D + j) * D + i] = G[((size_t)g * D + i) * D + j];
-            std::memcpy(dst + ng, rhos + (size_t)(m0 + m) * nr, nr * 8);
-            std::memcpy(dst + ng + nr, effects + (size_t)(m0 + m) * ne, ne * 8);
+                for (int i = 0; i < Du; i++)
+                    for (int j = 0; j < Du; j++) dst[((size_t)g * D + j) * D + i] = G[((size_t)g * Du + i) * Du + j];
+            for (int r = 0; r < h.n_rhos; r++) std::memcpy(dst + ng + (size_t)r * D, rhos + (size_t)(m0 + m) * nru + (size_t)r * Du, (size_t)Du * 8);
+            for (int e = 0; e < h.n_effects; e++) std::memcpy(dst + ng + nr + (size_t)e * D, effects + (size_t)(m0 + m) * neu + (size_t)e * Du, (size_t)Du * 8);
         }
         HIP_TRY(hipMemcpyAsync(p->d_mm_models.p, stage.data(), (size_t)nm * stride * 8, hipMemcpyHostToDevice, p->stream));
         if ((rc = run_models_chunk(p, nm, m0, d_base, d_out, ld, dest_idx ? p->d_mm_dest.p + m0 : nullptr, eps))) return rc;

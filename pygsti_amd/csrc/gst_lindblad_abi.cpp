@@ -353,7 +353,7 @@ int gst_set_lindblad(gst_plan* p, int32_t n_params, int32_t n_members, const gst
     //  the members' kinds, objects and parameter ranges: a new description, or none, invalidates them)
     if (n_members == 0) { L = gst_plan::Lindblad(); p->cached_kind = 0; return GST_OK; }
     const int D = p->hp.D;
-    if (D != 4 && D != 16) return fail(GST_EUNSUPPORTED, "Lindblad members are built on the device for D = 4 and 16");
+    if ((D != 4 && D != 16) || p->D_user) return fail(GST_EUNSUPPORTED, "Lindblad members are built on the device for D = 4 and 16");
     if (n_members < 0 || n_params < 0 || !members || n_terms <= 0 || !term_re || !term_im) return fail(GST_EINVAL, "bad argument");
     gst_plan::Lindblad N;
     N.n_params = n_params; N.n_members = n_members;

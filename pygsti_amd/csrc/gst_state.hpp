@@ -129,6 +129,11 @@ struct gst_plan {
     // parameter map
     std::vector<int32_t> pkind, pobj, pelem;
     bool have_pmap = false;
+    // Caller's state dimension when it is none of 4 / 16 / 64 (a qutrit's 9, a leakage model ...): the plan runs at hp.D = the
+    // next of those, every array that crosses the ABI is zero-padded / un-padded here (0: no padding).  Padded rows and
+    // columns of gates and padded components of states are exact zeros, so every sum the kernels form gains only + 0.0 terms.
+    int D_user = 0;
+    int user_D() const { return D_user ? D_user : hp.D; }
     // work buffers
     DevBuf<double> d_jtj_part, d_jtf_part;   // split-K partial sums of the normal equations
     DevBuf<double> d_base_cache;   // [n_state_ids][D] states of the last base pass

@@ -4,6 +4,7 @@ shared by all qubits) -- the arrays pygsti_adapter.atom_composite extracts from 
 leaves, factors = (leaf, target qubits), layers = ordered factor lists, in the gate order of the existing fixture.
 Run in the build container:   PYTHONPATH=/tmp/pgref:. python tests/golden/make_golden_r5.py            (3q_crosstalk_free_composite)
                               PYTHONPATH=/tmp/pgref:. python tests/golden/make_golden_r5.py cptplnd    (3q_crosstalk_free_CPTPLND)
+                              PYTHONPATH=/tmp/pgref:. python tests/golden/make_golden_r5.py qutrit     (qutrit_XYIMS_L8_depol, D = 9)
 The script also asserts, against the reference itself, what the fixture is used for: the numpy restatement
 (pygsti_amd/composite.py) reproduces the model's dense layers, deriv_wrt_params and the dense model after every
 set_parameter_value step exactly."""
@@ -87,9 +88,41 @@ def cptplnd_case():
           "max|J_map| on the columns:", float(np.abs(fx["dprobs_map"]).max()))
 
 
+def qutrit_case():
+    """qutrit_XYIMS_L8_depol: a state dimension that is none of 4 / 16 / 64 -- the reference's own qutrit model pack
+    (pygsti/modelpacks/legacy/stdQT_XYIMS.py: Gell-Mann basis, D = 9, gates Gi / Gx / Gy / Gm on the symmetric subspace of two
+    qubits, three outcomes), `full` parameterisation (360 parameters), depolarized 0.01 / 0.01; prep-fiducial x germ power x
+    measurement-fiducial circuits to L = 8.  Map probabilities and finite-difference columns, Matrix exact columns, FD-of-FD
+    Hessian block: the library runs it zero-padded at D = 16."""
+    sys.path.insert(0, HERE)
+    from make_golden import dump_case
+    from pygsti.modelpacks.legacy import stdQT_XYIMS as std
+    m = std.target_model()
+    m.set_all_parameterizations("full")
+    m = m.depolarize(op_noise=0.01, spam_noise=0.01)
+    assert m.dim == 9 and m.num_params == 360
+
+    def conv(c):
+        return Circuit([(l.name, 'T0') for l in c], line_labels=('T0',))
+    circs = []
+    for Lmax in (1, 2, 4, 8):
+        for g in std.germs_lite:
+            k = max(1, Lmax // max(len(g), 1))
+            for f1 in std.prepStrs[:4]:
+                for f2 in std.effectStrs[:4]:
+                    circs.append(conv(f1 + g * k + f2))
+    circs = list(dict.fromkeys(circs))
+    nP = m.num_params
+    cols = np.unique(np.concatenate([np.arange(0, 9), np.arange(9, 36, 5), np.arange(36, nP, 7), np.arange(nP - 6, nP)]))
+    blk = (np.array([0, 10, 40, 200]), np.array([3, 12, 41, 120, 300, 359]))
+    dump_case("qutrit_XYIMS_L8_depol", m, circs, dprobs_cols=cols, want_matrix=True, want_hprobs=True, hprobs_blk=blk, matrix_hprobs=False)
+
+
 def main():
     if "cptplnd" in sys.argv[1:]:
         return cptplnd_case()
+    if "qutrit" in sys.argv[1:]:
+        return qutrit_case()
     fx = dict(np.load(os.path.join(HERE, "3q_crosstalk_free.npz")))
     ps = QubitProcessorSpec(3, ['Gxpi2', 'Gypi2', 'Gcnot'], geometry='line')
     m = mc.create_crosstalk_free_model(ps, ideal_gate_type='full', ideal_spam_type='full')
