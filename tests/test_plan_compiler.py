@@ -83,7 +83,7 @@ def test_bad_descriptions_are_rejected_not_crashed():
     bad = dict(fx); bad['t_start'] = fx['t_start'].copy(); bad['t_start'][0] = 5     # cache slot not yet written
     with pytest.raises(ValueError):
         make(bad)
-    bad = dict(fx); bad['D'] = 32
+    bad = dict(fx); bad['D'] = 65                  # (2 .. 64 run, padded to 4 / 16 / 64 where needed: tests/test_general_dimension.py)
     with pytest.raises(_lib.GstError):
         make(bad)
 
