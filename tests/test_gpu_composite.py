@@ -261,3 +261,93 @@ def test_general_leaves_cptplnd_implicit_model_on_the_device():
     ref.set_derivs(int(fx["nP"]), spam + objs)
     Jh = ref.fill_dprobs(param_idx=allc, mode=_lib.DERIV_ANALYTIC)
     assert np.abs(Jall - Jh).max() < 1e-12, np.abs(Jall - Jh).max()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_composite_structures_against_the_restatement(seed):
+    """Randomised: registers of 1-3 qubits, leaves of every dimension that fits (element leaves with static elements and
+    parameters shared BETWEEN leaves, general leaves), targets in arbitrary order, layers of 0-4 factors (repeated leaves
+    included) -- the device's layers, finite-difference model sets (through the probabilities they give) and exact columns
+    against the numpy restatement and the host-supplied derivative route."""
+    from pygsti_amd import _lib
+    from pygsti_amd.composite import CompositeModel
+    rng = np.random.default_rng(1000 + seed)
+    nq = int(rng.integers(1, 4)); D = 4 ** nq
+    n_leaves = int(rng.integers(2, 6))
+    dims = [4 ** int(rng.integers(1, nq + 1)) for _ in range(n_leaves)]
+    nG, nEl = int(rng.integers(2, 6)), int(rng.integers(2, 5))
+    n_spam = D + nEl * D
+    leaf_params, leaf_static, leaf_general, nxt = [], [], [], n_spam
+    pool = []                                             # parameters that may be re-used by a later element leaf
+    for d in dims:
+        if rng.random() < 0.35:                           # general leaf
+            n = int(rng.integers(1, 7))
+            leaf_params.append(-np.ones(d * d, np.int64)); leaf_general.append(np.arange(nxt, nxt + n)); nxt += n
+        else:
+            p = -np.ones(d * d, np.int64)
+            free = rng.random(d * d) < 0.8
+            for e in np.nonzero(free)[0]:
+                if pool and rng.random() < 0.1:
+                    p[e] = pool[int(rng.integers(len(pool)))]
+                else:
+                    p[e] = nxt; pool.append(nxt); nxt += 1
+            leaf_params.append(p); leaf_general.append(None)
+        leaf_static.append(np.eye(d).ravel() + 0.1 * rng.standard_normal(d * d))
+    nP = nxt + 2                                          # two parameters nothing uses
+    gate_factors = []
+    for g in range(nG):
+        fs = []
+        for _ in range(int(rng.integers(0 if g else 1, 5))):
+            l = int(rng.integers(n_leaves))
+            k = {4: 1, 16: 2, 64: 3}[dims[l]]
+            fs.append((l, tuple(int(t) for t in rng.permutation(nq)[:k])))
+        gate_factors.append(fs)
+    cm = CompositeModel(D, nP, dims, leaf_params, leaf_static, gate_factors, leaf_general)
+    theta = 0.1 * rng.standard_normal(nP)
+    theta[:D] = 0; theta[0] = 1.0
+    eps = 1e-7
+    gen_vals = {l: np.eye(dims[l]).ravel() + 0.1 * rng.standard_normal(dims[l] ** 2) for l in cm.general_leaves}
+    gen_dv = {l: rng.standard_normal((dims[l] ** 2, len(cm.leaf_general[l]))) for l in cm.general_leaves}
+    gen_fd = {l: gen_vals[l][None] + eps * gen_dv[l].T + 1e-9 * rng.standard_normal((len(cm.leaf_general[l]), dims[l] ** 2)) for l in cm.general_leaves}
+    v = cm.values(theta, gen_vals)
+    # SPAM: dense elements, parameters 0 .. n_spam - 1
+    rhos = theta[:D].reshape(1, D).copy(); effects = 0.2 * rng.standard_normal((nEl, D)); effects[:, 0] += 0.5
+    theta[D:n_spam] = effects.ravel()
+    kind = -np.ones(nP, np.int32); obj = np.zeros(nP, np.int32); elem = np.zeros(nP, np.int32)
+    kind[:D] = 1; elem[:D] = np.arange(D)
+    kind[D:n_spam] = 2; obj[D:n_spam] = np.repeat(np.arange(nEl), D); elem[D:n_spam] = np.tile(np.arange(D), nEl)
+    # a handful of circuits over the layers
+    n_c = 12
+    lens = rng.integers(0, 9, n_c)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cg = rng.integers(0, nG, int(ptr[-1])).astype(np.int32)
+    nE = n_c * nEl
+    pl = _lib.Plan.from_circuits(D, nG, 1, nEl, nE, np.zeros(n_c, np.int32), ptr, cg, np.arange(n_c + 1, dtype=np.int64) * nEl,
+                                 np.tile(np.arange(nEl, dtype=np.int32), n_c), np.arange(nE, dtype=np.int32))
+    pl.set_param_map(kind, obj, elem)
+    pl.set_composite(cm)
+    pl.set_composite_values(v, rhos, effects)
+    if cm.general_leaves:
+        pl.set_composite_general(*cm.pack_general(gen_dv, gen_fd), fd_eps=eps)
+    G = cm.dense_gates(v)
+    scale = max(1.0, np.abs(G).max())
+    assert np.abs(pl.get_model()[0] - G).max() <= 1e-14 * scale
+    ref = _lib.Plan.from_circuits(D, nG, 1, nEl, nE, np.zeros(n_c, np.int32), ptr, cg, np.arange(n_c + 1, dtype=np.int64) * nEl,
+                                  np.tile(np.arange(nEl, dtype=np.int32), n_c), np.arange(nE, dtype=np.int32))
+    ref.set_model(G, rhos, effects)
+    p0 = ref.fill_probs()
+    pscale = max(1.0, np.abs(p0).max())
+    assert np.abs(pl.fill_probs() - p0).max() <= 1e-13 * pscale
+    allc = np.arange(nP)
+    Gs, Rs, Es = cm.model_sets(v, rhos, effects, (kind, obj, elem), allc, eps, gen_fd)
+    Jm = ref.fill_dprobs_models(Gs, Rs, Es, eps=eps)
+    Jf = pl.fill_dprobs(param_idx=allc, eps=eps)
+    assert np.abs(Jf - Jm).max() <= 1e-6 * pscale                      # same sets to rounding, / eps
+    objs = [(1, 0, np.arange(D), np.eye(D))] + [(2, e, np.arange(D + e * D, D + (e + 1) * D), np.eye(D)) for e in range(nEl)]
+    objs += [(0, g, qs, dm) for g, (qs, dm) in enumerate(cm.gate_derivs(v, gen_dv)) if len(qs)]
+    ref.set_derivs(nP, objs)
+    Jh = ref.fill_dprobs(param_idx=allc, mode=_lib.DERIV_ANALYTIC)
+    Ja = pl.fill_dprobs(param_idx=allc, mode=_lib.DERIV_ANALYTIC)
+    jscale = max(1.0, np.abs(Jh).max())
+    assert np.abs(Ja - Jh).max() <= 1e-11 * jscale
+    assert (Ja[:, -2:] == 0).all() and (Jf[:, -2:] == 0).all()        # parameters nothing uses: exact zero columns

@@ -285,3 +285,41 @@ def test_adapter_takes_exact_derivatives_for_implicit_models():
         with pytest.raises(_lib.GstDeviceError):
             m.sim._prepare(atom, derivatives=True)
         assert atom._hip_plan._hip_mode != "composite"
+
+
+def test_adapter_runs_the_qutrit_model_pack():
+    """A state dimension that is none of 4 / 16 / 64: the reference's qutrit pack (D = 9, Gell-Mann basis).  The adapter hands
+    9 x 9 gates and element indices i * 9 + j to the C ABI, which pads to 16 internally; the plan's programs interpreted in
+    numpy on the un-padded arrays give pyGSTi's probabilities bit for bit, and the element map matches gpindices."""
+    from pygsti.circuits import Circuit
+    from pygsti.modelpacks.legacy import stdQT_XYIMS as std
+    from pygsti.forwardsims import MapForwardSimulator
+    m = std.target_model()
+    m.set_all_parameterizations("full")
+    m = m.depolarize(op_noise=0.01, spam_noise=0.01)
+    circs = [Circuit([(l.name, 'T0') for l in (f1 + g * 2 + f2)], line_labels=('T0',))
+             for g in std.germs_lite[:4] for f1 in std.prepStrs[:3] for f2 in std.effectStrs[:3]]
+    circs = list(dict.fromkeys(circs))
+    ref = m.copy(); ref.sim = MapForwardSimulator()
+    lay_ref = ref.sim.create_layout(circs, array_types=("e",))
+    p_ref = np.empty(lay_ref.num_elements); ref.sim.bulk_fill_probs(p_ref, lay_ref)
+    m.sim = A.HipMapForwardSimulator()
+    lay = m.sim.create_layout(circs, array_types=("e", "ep"))
+    atom = lay.atoms[0]
+    plan = A.atom_plan(m, atom)
+    assert plan.D == 9
+    G, R, E = A.atom_arrays(m, atom)
+    plan.set_model(G, R, E)
+    kind, obj, elem = A.atom_param_map(m, atom)
+    plan.set_param_map(kind, obj, elem)
+    assert m.sim._effective_mode(atom) == "fd"             # element-parameterised: the Map simulator's own finite differences
+    Gb, Rb, Eb = plan.get_model()
+    assert np.array_equal(Gb, G) and np.array_equal(Rb, R) and np.array_equal(Eb, E)
+    w, off = plan.program()
+    n = len(atom.elbl_indices_by_expcircuit)
+    eff_ptr = np.zeros(n + 1, np.int64); el, ed = [], []
+    for i in range(n):
+        el.extend(atom.elbl_indices_by_expcircuit[i]); ed.extend(atom.elindices_by_expcircuit[i]); eff_ptr[i + 1] = len(el)
+    out, written, _ = run_programs(w, off, G, R, E, eff_ptr, np.array(el), np.array(ed), atom.num_elements)
+    assert (written == 1).all()
+    assert_bitwise(out, p_ref, "qutrit: adapter plan vs pyGSTi bulk_fill_probs")
