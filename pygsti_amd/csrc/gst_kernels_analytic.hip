@@ -874,7 +874,8 @@ __global__ __launch_bounds__(256, 2) void analytic_mfma64_kernel(const AnaArgs a
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             double* o = orow + c0 + (16 * tr + kk + 4 * r) * D + 16 * tc + i;
-                            *o = accum ? *o + acc[tr][tc][r] : acc[tr][tc][r];
+                            if (accum) *o = *o + acc[tr][tc][r];
+                            else __builtin_nontemporal_store(acc[tr][tc][r], o);      // written once, never re-read here: keep the state caches in L2
                         }
             } else {
                 const int32_t* cm = a.colmap_gate + (int64_t)g * D * D;
