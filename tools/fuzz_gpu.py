@@ -14,6 +14,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 d64 = len(sys.argv) > 3 and sys.argv[3] == "d64"
 big = len(sys.argv) > 3 and sys.argv[3] == "big"       # thousands of circuits: the default (size-dependent) launch form
+anyd = len(sys.argv) > 3 and sys.argv[3] == "anyd"     # state dimensions that are none of 4 / 16 / 64 (zero-padded behind the C ABI)
 t0 = time.time()
 bad = 0
 for k in range(n_cases):
@@ -29,6 +30,10 @@ for k in range(n_cases):
     if d64:
         D = 64; n_circ = int(rng.choice([10, 40, 120])); nG = int(rng.integers(1, 5)); nEl = int(rng.integers(1, 9))
         max_len = int(rng.choice([4, 20, 60])); max_slots = int(rng.choice([0, 1, 2, 3, 6, 12]))
+    if anyd:
+        D = int(rng.choice([2, 3, 5, 8, 9, 12, 15, 17, 25, 36, 49, 63]))
+        if D > 16:
+            n_circ = int(rng.choice([10, 40, 120])); nG = int(rng.integers(1, 5)); max_len = int(rng.choice([4, 20, 60])); max_slots = int(rng.choice([0, 1, 2, 3]))
     persist = str(rng.choice(["0", "2"]))
     if persist:
         os.environ["GST_TEST_FORCE"] = "persist=%s" % persist
@@ -44,7 +49,7 @@ for k in range(n_cases):
         pl.set_param_map(mdl["pkind"], mdl["pobj"], mdl["pelem"])
         orc = O.Oracle(tbl, mdl)
         assert np.array_equal(pl.fill_probs(), orc.probs()), "probs"
-        cols = rng.permutation(nP)[: min(nP, int(rng.choice([1, 30, 200, nP if not d64 else 700])))]
+        cols = rng.permutation(nP)[: min(nP, int(rng.choice([1, 30, 200, nP if not (d64 or (anyd and D > 16)) else 700])))]
         J = pl.fill_dprobs(param_idx=cols, eps=1e-7)
         assert np.array_equal(J, orc.dprobs(cols, eps=1e-7)), "dprobs"
         assert np.array_equal(pl.fill_dprobs(param_idx=cols, eps=1e-7), J), "dprobs (repeat)"
