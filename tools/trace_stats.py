@@ -52,3 +52,25 @@ for path in sys.argv[1:]:
                 print("  %s pairs: %d, us per estimated unit: %.4f" % (nm, m.sum(), (dur[m] / ev[m]).mean()))
     except FileNotFoundError:
         pass
+    # pace of the long pairs against how crowded their CU was while they ran (round 5): the average number of traced pairs
+    # alive on the same CU during the pair's life
+    try:
+        cukey = key // 4
+        longm = ev > 800
+        if longm.sum() > 5:
+            idx = np.nonzero(longm)[0]
+            crowd = []
+            for i in idx:
+                same = cukey == cukey[i]
+                ov = np.clip(np.minimum(t1[same], t1[i]) - np.maximum(t0[same], t0[i]), 0, None).sum() / max(t1[i] - t0[i], 1)
+                crowd.append(ov)
+            crowd = np.array(crowd); pace = dur[idx] / ev[idx]
+            for lo, hi in ((0, 4), (4, 6), (6, 8), (8, 10), (10, 13)):
+                m = (crowd >= lo) & (crowd < hi)
+                if m.sum():
+                    print("  long pairs with %d-%d pairs alive on their CU: %d, us per application %.3f (min %.3f max %.3f)" % (lo, hi, m.sum(), pace[m].mean(), pace[m].min(), pace[m].max()))
+            print("  long pairs: %d, estimate 50/100: %.0f %.0f; duration 50/100: %.0f %.0f us" % ((longm.sum(),) + tuple(np.percentile(ev[longm], [50, 100])) + tuple(np.percentile(dur[longm], [50, 100]))))
+            print("  all pairs: estimate sum %.0f over %d SIMDs = %.0f each; estimate histogram (<100, <400, <800, <1200, >=1200): %s" % (
+                ev.sum(), len(np.unique(key)), ev.sum() / len(np.unique(key)), [int(((ev >= a) & (ev < b)).sum()) for a, b in ((0, 100), (100, 400), (400, 800), (800, 1200), (1200, 1e9))]))
+    except Exception as e:
+        print("  (crowding analysis failed: %s)" % e)
