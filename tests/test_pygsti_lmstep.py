@@ -192,3 +192,34 @@ def test_device_step_falls_back_to_the_reference_algebra_when_it_does_not_apply(
     J = np.array(o.dlsvec())
     assert o.last_dlsvec_route == "host" and "omitted" in o.last_dlsvec_blocker
     np.testing.assert_allclose(J, np.array(o_ref.dlsvec()), rtol=0, atol=1e-9 * np.abs(J).max())
+
+
+def test_device_dlsvec_with_several_atoms(fake_device):
+    """num_atoms = 3 in one process (the reference's single-process shortcut, distforwardsim.py:98-99): one plan and one
+    device block per atom, J^T J / J^T f summed over them -- equal to the stock objective's products on the same layout."""
+    from pygsti.objectivefns import objectivefns as OF
+    from pygsti.optimize import arraysinterface as ARI
+    pack, edesign, ds = _setup(4)
+    circuits = list(edesign.all_circuits_needing_data)
+    m_ref = pack.target_model().depolarize(op_noise=0.02, spam_noise=0.01)
+    m_hip = m_ref.copy()
+    m_ref.sim = pygsti.forwardsims.MapForwardSimulator(num_atoms=3)
+    m_hip.sim = A.HipMapForwardSimulator(num_atoms=3, derivative_mode="fd")
+    reg = {"min_prob_clip": 1e-4, "radius": 1e-4}
+    o_ref = OF.PoissonPicDeltaLogLFunction.create_from(m_ref, ds, circuits, regularization=reg, method_names=("lsvec", "dlsvec"))
+    o_hip = A.HipPoissonPicDeltaLogLFunction.create_from(m_hip, ds, circuits, regularization=reg, method_names=("lsvec", "dlsvec"))
+    assert len(o_hip.layout.atoms) == 3
+    x = m_ref.to_vector()
+    f_ref = o_ref.lsvec(x).copy(); J_ref = np.array(o_ref.dlsvec(x))
+    f = o_hip.lsvec(x).copy(); dj = o_hip.dlsvec(x)
+    assert o_hip.last_dlsvec_route == "device" and len(dj.parts) == 3
+    # (the two layouts order their elements identically: same circuits, same atom count)
+    ari = ARI.DistributedArraysInterface(o_hip.layout, "normal", o_hip.ex)
+    jtj = ari.allocate_jtj(); jtf = ari.allocate_jtf()
+    ari.fill_jtj(dj, jtj, None); ari.fill_jtf(dj, f, jtf)
+    ref_jtj, ref_jtf = J_ref.T @ J_ref, J_ref.T @ f_ref
+    assert np.abs(jtj - ref_jtj).max() <= 1e-10 * np.abs(ref_jtj).max()
+    assert np.abs(jtf - ref_jtf).max() <= 1e-10 * np.sqrt(np.abs(ref_jtj).max()) * np.linalg.norm(f_ref)
+    assert np.abs(np.asarray(dj) - J_ref).max() <= 1e-9 * np.abs(J_ref).max()
+    names = [c[0] for c in fake_device.log]
+    assert names.count("fill_dprobs_dev") == 3 and names.count("fill_jtj_dev") == 3
