@@ -323,3 +323,43 @@ def test_adapter_runs_the_qutrit_model_pack():
     out, written, _ = run_programs(w, off, G, R, E, eff_ptr, np.array(el), np.array(ed), atom.num_elements)
     assert (written == 1).all()
     assert_bitwise(out, p_ref, "qutrit: adapter plan vs pyGSTi bulk_fill_probs")
+
+
+def test_adapter_general_leaves_for_cptplnd_implicit_models():
+    """`create_crosstalk_free_model(ideal_gate_type='CPTPLND')`: one- and two-qubit gates = static target x exp(Lindblad
+    generator), embedded and composed into 64 x 64 layers.  The description has GENERAL leaves (the exponentiated generators);
+    what the host computes for them per model update -- values, deriv_wrt_params, values after each parameter step -- turns,
+    through the restatement of the device's builders, into the reference's dense layers, layer derivatives and stepped dense
+    models; the drop-in takes this route (and reaches the device call) for FD and for exact derivatives."""
+    from pygsti.processors import QubitProcessorSpec
+    from pygsti.models import modelconstruction as mc
+    from pygsti.circuits import Circuit
+    ps = QubitProcessorSpec(3, ['Gxpi2', 'Gypi2', 'Gcnot'], geometry='line')
+    m = mc.create_crosstalk_free_model(ps, ideal_gate_type='CPTPLND', ideal_spam_type='full')
+    m.from_vector(m.to_vector() + 0.01 * np.random.default_rng(7).standard_normal(m.num_params))
+    m.sim = A.HipMapForwardSimulator()
+    circs = [Circuit([[('Gxpi2', 0), ('Gcnot', 1, 2)], ('Gypi2', 1), [('Gypi2', 1), ('Gxpi2', 2)], ('Gcnot', 1, 0)], line_labels=(0, 1, 2))]
+    lay = m.sim.create_layout(circs, array_types=("ep",))
+    atom = lay.atoms[0]
+    A.atom_plan(m, atom)
+    cm, spam_map = A.atom_composite(m, atom)
+    assert sorted(len(cm.leaf_general[l]) for l in cm.general_leaves) == [12, 12, 240]
+    v0 = m.to_vector().copy()
+    vals, dvs, fds = A.composite_general_data(m, cm, True, 1e-7)
+    assert np.array_equal(m.to_vector(), v0)                         # (the stepping leaves the model where it was)
+    G, R, E = A.atom_arrays(m, atom)
+    v = cm.values(v0, vals)
+    assert np.abs(cm.dense_gates(v) - G).max() < 1e-15
+    for (k, oi, idx, dm), (qs, mine) in zip([d for d in A.atom_derivs(m, atom) if d[0] == 0], cm.gate_derivs(v, dvs)):
+        assert np.array_equal(np.sort(idx), qs) and np.abs(dm[:, np.argsort(idx)] - mine).max() < 1e-14
+    cols = np.array([0, 70, 576, 583, 590, 600, 700, 839])
+    Gs, Rs, Es = cm.model_sets(v, R, E, spam_map, cols, 1e-7, fds)
+    Gr, Rr, Er = A.atom_model_sets(m, atom, cols, 1e-7)
+    assert np.abs(Gs - Gr).max() < 1e-15 and np.array_equal(Rs, Rr) and np.array_equal(Es, Er)
+    if _lib.device_count() == 0:
+        for mode in ("auto", "fd"):
+            m.sim.derivative_mode = mode
+            with pytest.raises(_lib.GstDeviceError):
+                m.sim._prepare(atom, derivatives=True)
+            assert atom._hip_plan._hip_mode == "composite"
+        assert np.array_equal(m.to_vector(), v0)
