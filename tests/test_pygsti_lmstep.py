@@ -223,3 +223,23 @@ def test_device_dlsvec_with_several_atoms(fake_device):
     assert np.abs(np.asarray(dj) - J_ref).max() <= 1e-9 * np.abs(J_ref).max()
     names = [c[0] for c in fake_device.log]
     assert names.count("fill_dprobs_dev") == 3 and names.count("fill_jtj_dev") == 3
+
+
+def test_custom_lm_optimizer_takes_the_device_step_too(fake_device):
+    """pyGSTi's other Levenberg-Marquardt implementation (optimize/customlm.py:556-610) uses the Jacobian the same three ways
+    (shape / nbytes for its log line, ari.norm2_jac, ari.fill_jtj, ari.fill_jtf): a fit through it runs on the device handle."""
+    from pygsti.optimize.customlm import CustomLMOptimizer
+    pack, edesign, ds = _setup(2)
+    data = pygsti.protocols.ProtocolData(edesign, ds)
+    opt = CustomLMOptimizer(maxiter=20, tol=1e-6)
+    proto = pygsti.protocols.GateSetTomography(pack.target_model(), gaugeopt_suite=None, objfn_builders=A.hip_objfn_builders("chi2"),
+                                               optimizer=opt, verbosity=0)
+    res = proto.run(data, simulator=A.HipMapForwardSimulator(derivative_mode="fd"), disable_checkpointing=True)
+    names = [c[0] for c in fake_device.log]
+    assert names.count("fill_jtj_dev") >= 2 and fake_device.host_jacobian_fills == 0 and lmstep.DeviceJacobian.materialisations == 0
+    ref = pygsti.protocols.GateSetTomography(pack.target_model(), gaugeopt_suite=None, objfn_builders=pygsti.protocols.GSTObjFnBuilders.create_from("chi2"),
+                                             optimizer=CustomLMOptimizer(maxiter=20, tol=1e-6), verbosity=0).run(
+        data, simulator=pygsti.forwardsims.MapForwardSimulator(), disable_checkpointing=True)
+    a = res.estimates["GateSetTomography"].models["final iteration estimate"].to_vector()
+    b = ref.estimates["GateSetTomography"].models["final iteration estimate"].to_vector()
+    assert np.abs(a - b).max() < 1e-5
