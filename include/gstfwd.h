@@ -409,6 +409,15 @@ int gst_fill_jtj_dev(gst_plan *plan, double *d_J, int64_t n_rows, int64_t n_cols
                      const double *d_row_scale, double *d_jtj);
 int gst_fill_jtf_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
                      const double *d_f, double *d_jtf);
+/* The same normal equations WITHOUT touching d_J (round 5): d_jtj = (diag(w) J)^T (diag(w) J) and d_jtf =
+ * (diag(w) J)^T f with w = d_row_scale (NULL: all ones) applied while the rows are staged -- every weighted element is
+ * rounded exactly as the in-place scaling of gst_fill_jtj_dev stores it, so both routes return the same bits, but the
+ * 2 x n_rows x n_cols x 8 bytes of the scaling pass' read-modify-write are not moved and d_J stays the plain Jacobian
+ * (so it may be contracted again, copied out, or -- for an exact Jacobian in tracked memory -- keep its resident zeros
+ * whatever the weights are).  Either output may be NULL (d_jtf needs d_f).  Replaces the same reference lines as
+ * gst_fill_jtj_dev / gst_fill_jtf_dev (objectivefns.py:4633-4665 scaling, distlayout.py:1220-1359 products). */
+int gst_fill_normal_eqs_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
+                            const double *d_row_scale, const double *d_f, double *d_jtj, double *d_jtf);
 int gst_memcpy_h2d(gst_plan *plan, void *d_dst, const void *src, int64_t nbytes);
 /* A rows x cols block of doubles between two device arrays with their own leading dimensions (in doubles), enqueued on
  * the plan's stream.  No counterpart in the reference, whose arrays live on the host: it is what re-assembles whole

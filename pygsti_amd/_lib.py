@@ -86,7 +86,7 @@ class Stats(C.Structure):
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_get_fd_work", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_fill_normal_eqs_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_get_fd_work", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_set_composite", "gst_set_composite_values", "gst_set_composite_general", "gst_get_model", "gst_get_lindblad_model_sets",
@@ -120,6 +120,7 @@ def lib():
         L.gst_fill_dprobs_dev.argtypes = [vp, vp, i64, vp, vp, i64, C.c_int, dbl, vp]
         L.gst_fill_jtj_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
         L.gst_fill_jtf_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+        L.gst_fill_normal_eqs_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp, vp]
         L.gst_set_derivs.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
         L.gst_set_complement_effect.argtypes = [vp, i32, vp, i32, vp]
         L.gst_set_second_derivs.argtypes = [vp, i32, vp, vp]
@@ -557,6 +558,13 @@ class Plan:
         check(lib().gst_fill_jtf_dev(self._h, C.c_void_p(int(d_J)), int(n_rows), int(n_cols), int(ld),
                                      C.c_void_p(int(d_f)), C.c_void_p(int(d_jtf))))
 
+    def fill_normal_eqs_dev(self, d_J, n_rows, n_cols, ld, d_row_scale=None, d_f=None, d_jtj=None, d_jtf=None):
+        """(diag(w) J)^T (diag(w) J) -> d_jtj and/or (diag(w) J)^T f -> d_jtf with the weights applied on the fly: d_J is
+        only read (gst_fill_normal_eqs_dev); same bits as fill_jtj_dev(..., d_row_scale) + fill_jtf_dev."""
+        vp = lambda x: None if x is None else C.c_void_p(int(x))
+        check(lib().gst_fill_normal_eqs_dev(self._h, C.c_void_p(int(d_J)), int(n_rows), int(n_cols), int(ld), vp(d_row_scale),
+                                            vp(d_f), vp(d_jtj), vp(d_jtf)))
+
     def objective_rows_dev(self, kind, d_probs, d_counts, d_totals, n, d_lsvec, d_rowscale, d_terms=None,
                            min_prob_clip=1e-4, radius=1e-4, prob_clip_interval=None, want_sum=True):
         """Element-wise objective maps on device probabilities (gst_objective_rows_dev).  kind: 'chi2' | 'logl'.
@@ -587,8 +595,7 @@ class Plan:
         self.memcpy_h2d(d_c, np.ascontiguousarray(counts, np.float64)); self.memcpy_h2d(d_N, np.ascontiguousarray(total_counts, np.float64))
         self.fill_dprobs_dev(d_J, nP, np.arange(nP, dtype=np.int64), None, eps, d_pr, mode)
         total = self.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius, prob_clip_interval)
-        self.fill_jtj_dev(d_J, nE, nP, nP, d_jtj, d_w)          # scales the rows of J in place first
-        self.fill_jtf_dev(d_J, nE, nP, nP, d_ls, d_jtf)
+        self.fill_normal_eqs_dev(d_J, nE, nP, nP, d_w, d_ls, d_jtj, d_jtf)     # weights applied on the fly: J is only read
         jtj = np.empty((nP, nP)); self.memcpy_d2h(jtj, d_jtj)
         jtf = np.empty(nP); self.memcpy_d2h(jtf, d_jtf)
         if lsvec_out is not None:

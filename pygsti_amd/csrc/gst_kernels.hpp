@@ -188,14 +188,17 @@ hipError_t launch_symmetrize(double* C, int64_t n, hipStream_t s);
 int jtj_num_slabs(int64_t n_rows, int n_cols);
 // pmask (may be NULL): per 16-row panel, bit t = the panel holds a non-zero in the 128 columns of tile t
 // (launch_jtj_panel_masks; n_cols <= 32 * 128); panels whose two tiles are not both marked are skipped
+// w (may be NULL): row weights applied while a panel is staged -- (diag(w) J)^T (diag(w) J) with J left untouched
 hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs, double* C, hipStream_t s,
-                      const uint32_t* pmask = nullptr);
-// one streaming pass over J: the panel masks, and with w != NULL the row scaling J <- diag(w) J as well
-hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t ld, const double* w, uint32_t* pmask, hipStream_t s);
+                      const uint32_t* pmask = nullptr, const double* w = nullptr);
+// one streaming pass over J: the panel masks (of diag(w) J when w != NULL), and with write_back the row scaling
+// J <- diag(w) J as well
+hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t ld, const double* w, uint32_t* pmask, hipStream_t s,
+                                  bool write_back = true);
 int jtj_mask_tiles(int n_cols);
 int64_t jtj_mask_panels(int64_t n_rows);
 hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs,
-                      double* y, hipStream_t s);
+                      double* y, hipStream_t s, const double* w = nullptr);
 
 // C[:, colmap[j]] += A[:, a_col0 : a_col0 + K] . B[:, j]  (B row-major [K][n]; colmap[j] < 0: skip) -- MFMA fp64
 hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, int K, const double* B, int n, const int32_t* colmap,

@@ -44,9 +44,14 @@ constexpr int JTJ_PANEL = 16;                           // rows staged per barri
 // streaming pass over J, fused into the row scaling when there is one); a panel contributes to tile pair (ti, tj) only if
 // both bits are set, and the others are skipped outright -- no fetch, no staging, no MFMAs: exact, since what is
 // skipped is a product with zeros.  On the 2Q design a third of the (panel, tile pair) products go.
+// WEIGHTED (round 5): the product of diag(w) J is taken without forming it -- a staged row is multiplied by its weight on
+// the way into LDS (fl(J[r][c] * w[r]), the very number the in-place scaling would have stored, so both routes give the
+// same bits), and J stays as the caller filled it.
+template <bool WEIGHTED>
 __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __restrict__ J, int64_t n_rows, int n_cols,
                                                               int64_t ld, int64_t slab_rows, int n_tiles,
-                                                              double* __restrict__ part, const uint32_t* __restrict__ pmask)
+                                                              double* __restrict__ part, const uint32_t* __restrict__ pmask,
+                                                              const double* __restrict__ w)
 {
     extern __shared__ __attribute__((aligned(16))) double panel_mem[];      // [2][JTJ_PANEL * JTJ_LDS_STRIDE]
     double* const panel0 = panel_mem;
@@ -77,11 +82,13 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __re
     const int soff = sr * JTJ_LDS_STRIDE + sseg * JTJ_TILE + sch * 8;
     typedef double d2_t __attribute__((ext_vector_type(2)));
     d2_t g[JTJ_PANEL / 8][4];
+    double gw[JTJ_PANEL / 8];
     auto fetch = [&](int64_t k) {
 #pragma unroll
         for (int u = 0; u < JTJ_PANEL / 8; u++) {
             const int64_t r = k + sr + 8 * u;
             const bool rv = r < k_end;
+            if (WEIGHTED) gw[u] = rv ? w[r] : 0.0;
             const double* src = J + (rv ? r : 0) * ld + scol;
             if (rv && scol + 8 <= n_cols && (((uintptr_t)src & 15) == 0)) {
 #pragma unroll
@@ -99,7 +106,11 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __re
 #pragma unroll
         for (int u = 0; u < JTJ_PANEL / 8; u++)
 #pragma unroll
-            for (int t = 0; t < 4; t++) *(d2_t*)(pan + soff + 8 * u * JTJ_LDS_STRIDE + 2 * t) = g[u][t];
+            for (int t = 0; t < 4; t++) {
+                d2_t x = g[u][t];
+                if (WEIGHTED) { x.x *= gw[u]; x.y *= gw[u]; }
+                *(d2_t*)(pan + soff + 8 * u * JTJ_LDS_STRIDE + 2 * t) = x;
+            }
     };
     // the next panel at or after k that contributes to this tile pair (workgroup-uniform: scalar loads of the masks)
     auto next_live = [&](int64_t k) -> int64_t {
@@ -153,8 +164,10 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __re
 // Panel masks (and, with `w`, the row scaling J <- diag(w) J in the same pass): one wavefront per (16-row panel, 128-column
 // tile) -- 32 doubles per lane, coalesced 1 KB row segments -- sets bit `tile` of pmask[panel] when anything there is
 // non-zero (after scaling: a zero weight annihilates its row).  pmask must be zeroed before the launch.
+// write_back = false: the weights only decide what counts as non-zero (J is read, never written).
 __global__ __launch_bounds__(256) void jtj_panel_mask_kernel(double* __restrict__ J, int64_t n_rows, int n_cols, int64_t ld,
-                                                             const double* __restrict__ w, int n_tiles, uint32_t* __restrict__ pmask)
+                                                             const double* __restrict__ w, int n_tiles, uint32_t* __restrict__ pmask,
+                                                             bool write_back)
 {
     const int64_t n_panels = (n_rows + JTJ_PANEL - 1) / JTJ_PANEL;
     const int lane = threadIdx.x & 63;
@@ -172,13 +185,13 @@ __global__ __launch_bounds__(256) void jtj_panel_mask_kernel(double* __restrict_
             if (c0 + 1 < n_cols && (((uintptr_t)p & 15) == 0)) {
                 typedef double d2_t __attribute__((ext_vector_type(2)));
                 d2_t x = *(d2_t*)p;
-                if (w) { x.x *= ws; x.y *= ws; *(d2_t*)p = x; }
+                if (w) { x.x *= ws; x.y *= ws; if (write_back) *(d2_t*)p = x; }
                 any = any || x.x != 0.0 || x.y != 0.0;
             } else {
                 for (int q = 0; q < 2; q++)
                     if (c0 + q < n_cols) {
                         double x = p[q];
-                        if (w) { x *= ws; p[q] = x; }
+                        if (w) { x *= ws; if (write_back) p[q] = x; }
                         any = any || x != 0.0;
                     }
             }
@@ -203,8 +216,10 @@ __global__ void jtj_reduce_kernel(const double* __restrict__ part, int n_slabs, 
 }
 
 // Jtf partials: block = 256 consecutive columns x one slab of rows (coalesced 2 KB per row)
+// w != nullptr: (diag(w) J)^T f with the weighted element rounded first, as the in-place scaling stores it
 __global__ void jtf_kernel(const double* __restrict__ J, const double* __restrict__ f, int64_t n_rows, int n_cols,
-                           int64_t ld, int64_t slab_rows, double* __restrict__ part /* [n_slabs][n_cols] */)
+                           int64_t ld, int64_t slab_rows, double* __restrict__ part /* [n_slabs][n_cols] */,
+                           const double* __restrict__ w)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int64_t s = blockIdx.y;
@@ -212,6 +227,17 @@ __global__ void jtf_kernel(const double* __restrict__ J, const double* __restric
     if (c >= n_cols) return;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
     int64_t k = k0;
+    if (w) {
+        for (; k + 3 < k1; k += 4) {
+            acc0 = __builtin_fma(J[k * ld + c] * w[k], f[k], acc0);
+            acc1 = __builtin_fma(J[(k + 1) * ld + c] * w[k + 1], f[k + 1], acc1);
+            acc2 = __builtin_fma(J[(k + 2) * ld + c] * w[k + 2], f[k + 2], acc2);
+            acc3 = __builtin_fma(J[(k + 3) * ld + c] * w[k + 3], f[k + 3], acc3);
+        }
+        for (; k < k1; k++) acc0 = __builtin_fma(J[k * ld + c] * w[k], f[k], acc0);
+        part[s * n_cols + c] = (acc0 + acc1) + (acc2 + acc3);
+        return;
+    }
     for (; k + 3 < k1; k += 4) {
         acc0 = __builtin_fma(J[k * ld + c], f[k], acc0);
         acc1 = __builtin_fma(J[(k + 1) * ld + c], f[k + 1], acc1);
@@ -651,7 +677,8 @@ int jtj_num_slabs(int64_t n_rows, int n_cols)
     return slabs;
 }
 
-hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t ld, const double* w, uint32_t* pmask, hipStream_t s)
+hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t ld, const double* w, uint32_t* pmask, hipStream_t s,
+                                  bool write_back)
 {
     const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
     if (n_tiles > 32 || n_rows <= 0) return hipErrorInvalidValue;
@@ -661,14 +688,14 @@ hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t
     if (e != hipSuccess) return e;
     const int64_t items = n_panels * n_tiles;
     hipLaunchKernelGGL(jtj_panel_mask_kernel, dim3((unsigned)std::min<int64_t>((items + 3) / 4, 65536)), dim3(256), 0, s, J, n_rows, n_cols, ld, w,
-                       n_tiles, pmask);
+                       n_tiles, pmask, write_back);
     return hipGetLastError();
 }
 int jtj_mask_tiles(int n_cols) { return (n_cols + JTJ_TILE - 1) / JTJ_TILE; }
 int64_t jtj_mask_panels(int64_t n_rows) { return (n_rows + JTJ_PANEL - 1) / JTJ_PANEL; }
 
 hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs, double* C,
-                      hipStream_t s, const uint32_t* pmask)
+                      hipStream_t s, const uint32_t* pmask, const double* w)
 {
     const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
@@ -677,11 +704,16 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
     (void)hipGetLastError();
     const size_t lds_bytes = (size_t)2 * JTJ_PANEL * JTJ_LDS_STRIDE * sizeof(double);
     if (lds_bytes > 64 * 1024) {          // per device (a process may drive several GPUs): set on every launch, it is cheap
-        hipError_t ea = hipFuncSetAttribute((const void*)jtj_mfma_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t ea = hipFuncSetAttribute(w ? (const void*)jtj_mfma_lds_kernel<true> : (const void*)jtj_mfma_lds_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (ea != hipSuccess) return ea;
     }
-    hipLaunchKernelGGL(jtj_mfma_lds_kernel, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld,
-                       slab_rows, n_tiles, part, pmask);
+    if (w)
+        hipLaunchKernelGGL(jtj_mfma_lds_kernel<true>, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld,
+                           slab_rows, n_tiles, part, pmask, w);
+    else
+        hipLaunchKernelGGL(jtj_mfma_lds_kernel<false>, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld,
+                           slab_rows, n_tiles, part, pmask, w);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(jtj_reduce_kernel, dim3(2048), dim3(256), 0, s, part, n_slabs, n_cols, C);
@@ -689,12 +721,12 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
 }
 
 hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs,
-                      double* y, hipStream_t s)
+                      double* y, hipStream_t s, const double* w)
 {
     const int64_t slab_rows = (n_rows + n_slabs - 1) / n_slabs;
     (void)hipGetLastError();
     hipLaunchKernelGGL(jtf_kernel, dim3((unsigned)((n_cols + 255) / 256), (unsigned)n_slabs), dim3(256), 0, s, J, f, n_rows,
-                       n_cols, ld, slab_rows, part);
+                       n_cols, ld, slab_rows, part, w);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(jtf_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, s, part, n_slabs, n_cols, y);

@@ -65,6 +65,45 @@ int gst_fill_jtf_dev(gst_plan* p, const double* d_J, int64_t n_rows, int64_t n_c
     });
 }
 
+int gst_fill_normal_eqs_dev(gst_plan* p, const double* d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
+                            const double* d_row_scale, const double* d_f, double* d_jtj, double* d_jtf)
+{
+    return guarded([&]() -> int {
+    if (!p || !d_J || n_rows < 0 || n_cols < 0 || ld < n_cols || n_cols > 0x7fffffff) return fail(GST_EINVAL, "bad argument");
+    if (!d_jtj && !d_jtf) return fail(GST_EINVAL, "nothing to compute: d_jtj and d_jtf are both NULL");
+    if (d_jtf && !d_f) return fail(GST_EINVAL, "d_jtf needs d_f");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    if (n_cols == 0) return GST_OK;
+    TIME_REC(p, ev0);
+    if (d_jtj) {
+        gst::track_touch(d_jtj, (size_t)n_cols * n_cols * 8);
+        // d_J is only read: no claim on it changes (its resident zeros stay zeros whatever the weights are)
+        const bool sparse = p->jtj_sparse && n_rows >= 16384 && gst::jtj_mask_tiles((int)n_cols) >= 4 && gst::jtj_mask_tiles((int)n_cols) <= 32;
+        const uint32_t* d_pmask = nullptr;
+        if (sparse) {
+            HIP_TRY(p->d_jtj_pmask.ensure((size_t)gst::jtj_mask_panels(n_rows)));
+            HIP_TRY(gst::launch_jtj_panel_masks(const_cast<double*>(d_J), n_rows, (int)n_cols, ld, d_row_scale, p->d_jtj_pmask.p, p->stream,
+                                                /*write_back=*/false));
+            d_pmask = p->d_jtj_pmask.p;
+        }
+        const int n_slabs = gst::jtj_num_slabs(n_rows, (int)n_cols);
+        HIP_TRY(p->d_jtj_part.ensure((size_t)n_slabs * n_cols * n_cols));
+        TIME_REC(p, evk0);
+        HIP_TRY(gst::launch_jtj(d_J, n_rows, (int)n_cols, ld, p->d_jtj_part.p, n_slabs, d_jtj, p->stream, d_pmask, d_row_scale));
+        TIME_REC(p, evk1);
+    }
+    if (d_jtf) {
+        const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n_rows + 255) / 256));
+        gst::track_touch(d_jtf, (size_t)n_cols * 8);
+        HIP_TRY(p->d_jtf_part.ensure((size_t)n_slabs * n_cols));
+        HIP_TRY(gst::launch_jtf(d_J, d_f, n_rows, (int)n_cols, ld, p->d_jtf_part.p, n_slabs, d_jtf, p->stream, d_row_scale));
+    }
+    TIME_REC(p, ev1);
+    return GST_OK;
+    });
+}
+
 int gst_objective_rows_dev(gst_plan* p, const gst_objective_desc* d, double* d_probs, const double* d_counts,
                            const double* d_totals, int64_t n, double* d_lsvec, double* d_rowscale, double* d_terms,
                            double* sum_terms)

@@ -38,8 +38,10 @@ from . import _lib
 class DeviceJacobian:
     """The scaled Jacobian of one `dlsvec` call, resident on the device.
 
-    parts: [(plan, d_J, element_slice)] -- per layout atom the plan whose stream owns the block, the device pointer of its
-    row-major [nE_atom][nP] block (ALREADY scaled by the objective's dlsvec row factors) and the rows it covers.
+    parts: [(plan, d_J, element_slice, d_w)] -- per layout atom the plan whose stream owns the block, the device pointer of
+    its row-major [nE_atom][nP] block of dprobs, the rows it covers, and the device vector of the objective's dlsvec row
+    factors: the scaled Jacobian J_s = diag(w) J is never stored, the products apply w on the fly
+    (gst_fill_normal_eqs_dev).  A part without d_w (3-tuple, or None) holds rows that are already scaled.
     jtj: the (nP, nP) sum over atoms of J_s^T J_s (host copy of the device product).
     penalty_rows: (ex, nP) host array of the objective's extra rows (regularisation / CPTP / SPAM penalties), scaled, or None.
 
@@ -50,7 +52,7 @@ class DeviceJacobian:
     materialisations = 0            # class-wide count of host materialisations (tests: a fit on the device path keeps 0)
 
     def __init__(self, parts, jtj, n_elements, n_params, penalty_rows=None):
-        self.parts = list(parts)
+        self.parts = [tuple(p) + (None,) * (4 - len(p)) for p in parts]
         self._jtj = jtj
         self.penalty_rows = penalty_rows
         ex = 0 if penalty_rows is None else penalty_rows.shape[0]
@@ -77,12 +79,15 @@ class DeviceJacobian:
             raise ValueError("fill_jtf: f has %d rows, the Jacobian %d" % (f.shape[0], self.shape[0]))
         out = np.zeros(nP)
         part = np.empty(nP)
-        for plan, d_J, es in self.parts:
+        for plan, d_J, es, d_w in self.parts:
             n = es.stop - es.start
             d_f = plan.workspace("lm_f", n * 8)
             d_o = plan.workspace("lm_jtf", nP * 8)
             plan.memcpy_h2d(d_f, f[es])
-            plan.fill_jtf_dev(d_J, n, nP, nP, d_f, d_o)
+            if d_w is None:
+                plan.fill_jtf_dev(d_J, n, nP, nP, d_f, d_o)
+            else:
+                plan.fill_normal_eqs_dev(d_J, n, nP, nP, d_w, d_f=d_f, d_jtf=d_o)
             plan.memcpy_d2h(part, d_o)
             out += part
         if self.penalty_rows is not None and self.penalty_rows.shape[0]:
@@ -101,12 +106,15 @@ class DeviceJacobian:
         nP = self.shape[1]
         if out is None:
             out = np.empty(self.shape)
-        for plan, d_J, es in self.parts:
-            blk = out[es]
-            if not blk.flags.c_contiguous:
-                tmp = np.empty((es.stop - es.start, nP)); plan.memcpy_d2h(tmp, d_J); out[es] = tmp
-            else:
-                plan.memcpy_d2h(blk, d_J)
+        for plan, d_J, es, d_w in self.parts:
+            view = out[es]
+            blk = view if view.flags.c_contiguous else np.empty((es.stop - es.start, nP))
+            plan.memcpy_d2h(blk, d_J)
+            if d_w is not None:                   # the row factors, applied here as the products apply them on the device
+                w = np.empty(es.stop - es.start); plan.memcpy_d2h(w, d_w)
+                blk *= w[:, None]
+            if blk is not view:
+                out[es] = blk
         if self.penalty_rows is not None and self.penalty_rows.shape[0]:
             out[self.n_elements:] = self.penalty_rows
         return out

@@ -786,11 +786,12 @@ class AtomFillLogic:
                                prob_clip_interval=None, lsvec_to_fill=None, pr_array_to_fill=None):
         """The device half of `TimeIndependentMDCObjectiveFunction.dlsvec` (objectivefns.py:4595-4665) for every atom of
         `layout`: probabilities and Jacobian (this simulator's derivative mode for the model's parameterisation), the
-        objective's element-wise maps (lsvec; the dlsvec row factor (0.5 / lsvec) * dterms), the rows of the Jacobian
-        scaled IN PLACE, and J_s^T J_s -- nothing of size (nE, nP) leaves HBM.  `counts` / `total_counts`: per-element
+        objective's element-wise maps (lsvec; the dlsvec row factor w = (0.5 / lsvec) * dterms), and J_s^T J_s of the scaled
+        Jacobian J_s = diag(w) J with the factors applied on the fly (gst_fill_normal_eqs_dev: J_s is never stored, the
+        device block stays dprobs) -- nothing of size (nE, nP) leaves HBM.  `counts` / `total_counts`: per-element
         arrays in layout order (the objective's `.counts` / `.total_counts`); objective = 'chi2' | 'logl'.
-        Returns (parts, jtj): parts = [(plan, device pointer of the atom's scaled [nE_atom][nP] block, element slice)]
-        (what lmstep.DeviceJacobian wraps), jtj = the (nP, nP) sum over this process's atoms.  The optional host vectors
+        Returns (parts, jtj): parts = [(plan, device pointer of the atom's [nE_atom][nP] dprobs block, element slice,
+        device pointer of its row factors)] (what lmstep.DeviceJacobian wraps), jtj = the (nP, nP) sum over this process's atoms.  The optional host vectors
         receive lsvec and the (clipped) probabilities, as the reference's dlsvec leaves them in `objective.obj` /
         `objective.probs`; `self.last_objective_sum` holds sum(terms).  Not available for models that must be stepped on
         the host ("models" mode: no device-resident Jacobian)."""
@@ -813,14 +814,14 @@ class AtomFillLogic:
             plan.fill_dprobs_dev(d_J, nP, pidx, None, self.derivative_eps, d_pr, mode)
             total += plan.objective_rows_dev(objective, d_pr, d_c, d_N, nE, d_ls, d_w, None, min_prob_clip, radius,
                                              prob_clip_interval)
-            plan.fill_jtj_dev(d_J, nE, nP, nP, d_jtj, d_w)          # scales the rows of J in place first
+            plan.fill_normal_eqs_dev(d_J, nE, nP, nP, d_w, d_jtj=d_jtj)
             plan.memcpy_d2h(part, d_jtj)
             jtj += part
             if lsvec_to_fill is not None:
                 self._d2h_rows(plan, lsvec_to_fill, es, d_ls)
             if pr_array_to_fill is not None:
                 self._d2h_rows(plan, pr_array_to_fill, es, d_pr)
-            parts.append((plan, d_J, es))
+            parts.append((plan, d_J, es, d_w))
         self.last_objective_sum = total
         return parts, jtj
 

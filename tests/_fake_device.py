@@ -151,5 +151,15 @@ class FakePlan:
         J = self._dev(d_J, n_rows * ld).reshape(n_rows, ld)
         self._dev(d_jtf, n_cols)[...] = J[:, :n_cols].T @ self._dev(d_f, n_rows)
 
+    def fill_normal_eqs_dev(self, d_J, n_rows, n_cols, ld, d_row_scale=None, d_f=None, d_jtj=None, d_jtf=None):
+        J = self._dev(d_J, n_rows * ld).reshape(n_rows, ld)[:, :n_cols]
+        Js = J if d_row_scale is None else J * self._dev(d_row_scale, n_rows)[:, None]      # (J itself stays as it is)
+        if d_jtj is not None:
+            FakePlan.log.append(("fill_jtj_dev", (n_rows, n_cols)))
+            self._dev(d_jtj, n_cols * n_cols)[...] = (Js.T @ Js).ravel()
+        if d_jtf is not None:
+            FakePlan.log.append(("fill_jtf_dev", (n_rows, n_cols)))
+            self._dev(d_jtf, n_cols)[...] = Js.T @ self._dev(d_f, n_rows)
+
     def sync(self):
         pass

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import load_fixture, plan_from_fixture
-from pygsti_amd import modelpacks as MP
+from pygsti_amd import _lib, modelpacks as MP
 from pygsti_amd.forwardsim import HipMapForwardSimulator
 from test_host_mirror import _model_from_fixture
 
@@ -157,3 +157,89 @@ def test_jtj_block_sparse_jacobian():
     back = pl.memcpy_d2h(np.empty((n_rows, ld)), d_J)
     assert np.array_equal(back[:, :n_cols], Js) and np.array_equal(back[:, n_cols:], Jp[:, n_cols:])    # padding untouched
     for d in (d_J, d_jtj, d_w): pl.device_free(d)
+
+
+@pytest.mark.parametrize("n_rows,n_cols,pad,sparse", [(20011, 730, 3, True), (5003, 1616, 0, False), (70001, 200, 1, False),
+                                                      (33, 7, 2, False), (16400, 513, 0, True)])
+def test_normal_eqs_without_touching_J(n_rows, n_cols, pad, sparse):
+    """gst_fill_normal_eqs_dev (round 5): the row weights are applied while the rows are staged, so d_J is only read --
+    and since every weighted element is rounded exactly as the in-place scaling stores it, J_s^T J_s and J_s^T f come out
+    with the SAME BITS as gst_fill_jtj_dev(..., d_row_scale) + gst_fill_jtf_dev on a copy.  Block-sparse input (zero
+    blocks, zero weights, a lone non-zero whose weight is zero: the masks are those of diag(w) J), ragged shapes, padding
+    columns, either output alone, no weights at all."""
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    pl = plan_from_fixture(fx)
+    rng = np.random.default_rng(n_rows * 7 + n_cols)
+    ld = n_cols + pad
+    Jp = rng.standard_normal((n_rows, ld)) * np.exp(rng.uniform(-3, 3, size=(1, ld)))
+    if sparse:
+        r = 0
+        while r < n_rows:
+            n = int(rng.integers(3, 90))
+            c0 = int(rng.integers(0, n_cols)); c1 = int(rng.integers(c0, n_cols + 1))
+            if rng.random() < 0.6: Jp[r:r + n, c0:c1] = 0.0
+            r += n
+        Jp[960:976, 128:256] = 0.0; Jp[966, 200] = 5.0                # a lone non-zero in its (panel, tile) ...
+    w = rng.random(n_rows) + 0.5
+    w[rng.random(n_rows) < 0.1] = 0.0
+    if sparse: w[966] = 0.0                                            # ... annihilated by its weight
+    f = rng.standard_normal(n_rows)
+    d_J = pl.device_malloc(Jp.nbytes); d_K = pl.device_malloc(Jp.nbytes)
+    d_a = pl.device_malloc(n_cols * n_cols * 8); d_b = pl.device_malloc(n_cols * n_cols * 8)
+    d_ya = pl.device_malloc(n_cols * 8); d_yb = pl.device_malloc(n_cols * 8)
+    d_w = pl.device_malloc(n_rows * 8); d_f = pl.device_malloc(n_rows * 8)
+    pl.memcpy_h2d(d_J, Jp); pl.memcpy_h2d(d_K, Jp); pl.memcpy_h2d(d_w, w); pl.memcpy_h2d(d_f, f)
+    # the in-place route on the copy
+    pl.fill_jtj_dev(d_K, n_rows, n_cols, ld, d_a, d_w); pl.fill_jtf_dev(d_K, n_rows, n_cols, ld, d_f, d_ya)
+    a = pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_a); ya = pl.memcpy_d2h(np.empty(n_cols), d_ya)
+    # the new route
+    pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w, d_f, d_b, d_yb)
+    b = pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_b); yb = pl.memcpy_d2h(np.empty(n_cols), d_yb)
+    assert np.array_equal(a, b) and np.array_equal(ya, yb)
+    assert np.array_equal(pl.memcpy_d2h(np.empty((n_rows, ld)), d_J), Jp)             # J as the caller left it
+    Js = Jp[:, :n_cols] * w[:, None]
+    want = Js.T @ Js
+    scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1e-300
+    assert (np.abs(b - want) <= 1e-12 * scale).all() and np.abs(yb - Js.T @ f).max() <= 1e-12 * np.abs(Js.T @ f).max()
+    # either output alone; no weights = the plain products
+    pl.memcpy_h2d(d_b, np.zeros((n_cols, n_cols))); pl.memcpy_h2d(d_yb, np.zeros(n_cols))
+    pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w, d_jtj=d_b)
+    assert np.array_equal(pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_b), a) and not pl.memcpy_d2h(np.empty(n_cols), d_yb).any()
+    pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w, d_f=d_f, d_jtf=d_yb)
+    assert np.array_equal(pl.memcpy_d2h(np.empty(n_cols), d_yb), ya)
+    pl.fill_jtj_dev(d_J, n_rows, n_cols, ld, d_a); pl.fill_jtf_dev(d_J, n_rows, n_cols, ld, d_f, d_ya)
+    pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, None, d_f, d_b, d_yb)
+    assert np.array_equal(pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_a), pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_b))
+    assert np.array_equal(pl.memcpy_d2h(np.empty(n_cols), d_ya), pl.memcpy_d2h(np.empty(n_cols), d_yb))
+    with pytest.raises(ValueError):
+        pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w)                           # nothing to compute
+    with pytest.raises(ValueError):
+        pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w, d_jtf=d_yb)               # J^T f without f
+    for d in (d_J, d_K, d_a, d_b, d_ya, d_yb, d_w, d_f): pl.device_free(d)
+
+
+def test_normal_eqs_keep_resident_zeros():
+    """An exact Jacobian in tracked memory keeps its structural zeros resident through the weighted products of
+    gst_fill_normal_eqs_dev -- which never write to it, whatever the weights are (an infinite weight ends the claim of the
+    in-place route; here there is nothing to end) -- so the next exact fill into the same block is still bit-identical
+    to a fill into fresh memory."""
+    fx = load_fixture("smq2Q_XYICNOT_L2_depol")
+    pl = plan_from_fixture(fx)
+    nE, nP = int(fx["nE"]), int(fx["nP"])
+    idx = np.arange(nP)
+    d = pl.device_malloc(nE * nP * 8, tracked=True); d2 = pl.device_malloc(nE * nP * 8)
+    d_w = pl.device_malloc(nE * 8); d_jtj = pl.device_malloc(nP * nP * 8)
+    w = np.random.default_rng(3).random(nE) + 0.5; w[5] = np.inf
+    pl.memcpy_h2d(d_w, w)
+
+    def fill(dst):
+        pl.fill_dprobs_dev(dst, nP, idx, None, 1e-7, None, _lib.DERIV_ANALYTIC); pl.sync()
+        return bool(pl.stats()["last_zeros_resident"])
+    assert not fill(d)
+    pl.fill_normal_eqs_dev(d, nE, nP, nP, d_w, d_jtj=d_jtj)
+    assert fill(d)                                                     # repeated fill: the zeros are not stored again
+    pl.memcpy_h2d(d2, np.full((nE, nP), np.nan))
+    assert not fill(d2)
+    a = pl.memcpy_d2h(np.empty((nE, nP)), d); b = pl.memcpy_d2h(np.empty((nE, nP)), d2)
+    assert np.array_equal(a, b) and (a == 0).mean() > 0.1
+    for x in (d, d2, d_w, d_jtj): pl.device_free(x)

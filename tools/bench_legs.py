@@ -208,13 +208,17 @@ def lm_step(B):
             plan.memcpy_h2d(d_N, np.full(nE_local, 1000.0))
 
             lm_mode = [mode]
+            lm_in_place = [False]
 
             def lm_step():
                 plan.set_model(gates, rhos, effects)
                 plan.fill_dprobs_dev(d_out, nP_local, pidx, None, 1e-7, d_probs, lm_mode[0])
                 plan.objective_rows_dev("logl", d_probs, d_c, d_N, nE_local, d_ls, d_w, want_sum=False)
-                plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj, d_w)          # (scales the rows of J in place first)
-                plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_ls, d_jtf)
+                if lm_in_place[0]:      # rounds 2-4: the rows of J scaled in place by a streaming pass, then contracted
+                    plan.fill_jtj_dev(d_out, nE_local, nP, nP, d_jtj, d_w)
+                    plan.fill_jtf_dev(d_out, nE_local, nP, nP, d_ls, d_jtf)
+                else:                   # round 5: the dlsvec row factors applied while the rows are staged (J only read)
+                    plan.fill_normal_eqs_dev(d_out, nE_local, nP, nP, d_w, d_ls, d_jtj, d_jtf)
                 if world > 1 and comm is not None:
                     comm.allreduce_sum(d_jtj, nP * nP, plan)
                     comm.allreduce_sum(d_jtf, nP, plan)
@@ -231,7 +235,8 @@ def lm_step(B):
             lm_info = {"ms_per_step": 1e3 * t_lm, "elements_per_s": nE_total * nP / t_lm, "unit": "Jacobian-elements/s",
                        "allreduce_MB": (nP * nP + nP) * 8 / 1e6 if world > 1 else 0.0,
                        "allreduce_transport": ctx.transport if world > 1 else None,
-                       "note": "fill + Poisson-picture dlogl maps + J^T J (block-sparse split-K MFMA fp64 SYRK) + J^T f"
+                       "note": "fill + Poisson-picture dlogl maps + J_s^T J_s (block-sparse split-K MFMA fp64 SYRK) + J_s^T f, dlsvec row "
+                               "factors applied while the rows are staged (gst_fill_normal_eqs_dev)"
                                + (" + all-reduce of nP^2 + nP doubles between device buffers" if world > 1 else "")
                                + "; the Jacobian never leaves HBM; secondary figure, not `value`"}
             if mode == _lib.DERIV_FD and not args.no_analytic:
@@ -248,6 +253,18 @@ def lm_step(B):
                 assert np.isfinite(plan.memcpy_d2h(np.empty(nP), d_jtf)).all()
                 lm_info["exact_jacobian_ms_per_step"] = 1e3 * t_lma
                 lm_info["exact_jacobian_zeros_resident"] = bool(plan.stats()["last_zeros_resident"])
+                jtf_new = plan.memcpy_d2h(np.empty(nP), d_jtf); jtj_new = plan.memcpy_d2h(np.empty((nP, nP)), d_jtj)
+                lm_in_place[0] = True
+                lm_step(); lm_step()
+                barrier_sync(plan)
+                tl = time.perf_counter()
+                for _ in range(n_lm):
+                    lm_step()
+                barrier_sync(plan)
+                lm_info["exact_jacobian_in_place_scaling_ms_per_step"] = 1e3 * ctx.max_over_ranks(time.perf_counter() - tl) / n_lm
+                lm_info["weights_on_the_fly_same_bits_as_in_place"] = bool(
+                    np.array_equal(jtf_new, plan.memcpy_d2h(np.empty(nP), d_jtf)) and np.array_equal(jtj_new, plan.memcpy_d2h(np.empty((nP, nP)), d_jtj)))
+                lm_in_place[0] = False
                 lm_mode[0] = mode
         finally:
             for d in bufs:
