@@ -19,7 +19,9 @@
 #include "gst_kernels.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 namespace gst {
 
@@ -36,7 +38,10 @@ constexpr int JTJ_WT = 64;        // wavefront tile
 // JTJ_PANEL = 16 rows.  (Three workgroups per CU instead of two: 168 VGPRs, spills, 35.5 ms.)
 constexpr int JTJ_LDS_STRIDE = 2 * JTJ_TILE + 8;        // doubles per staged row (+8: the 4 rows of a patch start in different banks)
 
-constexpr int JTJ_PANEL = 16;                           // rows staged per barrier
+constexpr int JTJ_PANEL = 16;
+#if GST_JTJ_TIMING
+__device__ unsigned long long jtj_dbg[8];      // development build only: per-phase wavefront cycles of the generic loop
+#endif                           // rows staged per barrier
 
 // SPARSITY (round 3): a GST Jacobian is block sparse -- row (circuit, outcome) is exactly zero in the columns of every
 // gate the circuit never applies, 30 % of all 16 x 16 blocks on the 2Q design.  `pmask[k / JTJ_PANEL]` has bit t set
@@ -47,7 +52,11 @@ constexpr int JTJ_PANEL = 16;                           // rows staged per barri
 // WEIGHTED (round 5): the product of diag(w) J is taken without forming it -- a staged row is multiplied by its weight on
 // the way into LDS (fl(J[r][c] * w[r]), the very number the in-place scaling would have stored, so both routes give the
 // same bits), and J stays as the caller filled it.
-template <bool WEIGHTED>
+// FAST (round 5): n_cols a multiple of 8, even ld and a 16-byte aligned matrix -- every staging load is an unconditional 16-byte load (rows
+// past the slab and columns past the matrix re-read a valid address and are zeroed on the way into LDS), so the compiler
+// can count the loads in flight exactly and the panel TWO steps ahead is fetched into a second register set while the
+// panel one step ahead is still landing: each fetch has two MFMA blocks (~7 us) to arrive instead of one.
+template <bool WEIGHTED, bool FAST>
 __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __restrict__ J, int64_t n_rows, int n_cols,
                                                               int64_t ld, int64_t slab_rows, int n_tiles,
                                                               double* __restrict__ part, const uint32_t* __restrict__ pmask,
@@ -120,18 +129,7 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __re
         }
         return k;
     };
-    int64_t k = next_live(k_begin);
-    if (k < k_end) {
-        fetch(k);
-        stash(panel0);
-    }
-    __syncthreads();
-    int cur = 0;
-    while (k < k_end) {
-        const int64_t kn = next_live(k + JTJ_PANEL);
-        const bool more = kn < k_end;
-        if (more) fetch(kn);                                     // next live panel: global -> registers, lands during the MFMAs
-        const double* pc = cur ? panel1 : panel0;
+    auto mma_panel = [&](const double* pc) {
 #pragma unroll
         for (int h = 0; h < JTJ_PANEL / 4; h++) {                // 4-row steps of the panel
             const double* row = pc + (4 * h + lk) * JTJ_LDS_STRIDE;
@@ -143,10 +141,180 @@ __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __re
 #pragma unroll
                 for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
         }
+    };
+    if constexpr (FAST) {
+        // addresses = uniform base of the panel (scalar registers) + one 32-bit byte offset per staged row; a chunk of 8
+        // columns lies wholly inside or wholly outside the matrix (n_cols % 8 == 0 on this path)
+        const bool cvalid = scol + 8 <= n_cols;
+        const uint32_t cbytes = (uint32_t)(cvalid ? scol : 0) * 8u;
+        const uint32_t ldb = (uint32_t)ld * 8u;
+        auto fetch2 = [&](int64_t k, d2_t (&G)[JTJ_PANEL / 8][4], double (&GW)[JTJ_PANEL / 8]) {
+            const char* const base = (const char*)(J + k * ld);
+            const uint32_t last = (uint32_t)(k_end - 1 - k);                      // (k < k_end)
+#pragma unroll
+            for (int u = 0; u < JTJ_PANEL / 8; u++) {
+                const uint32_t rr = (uint32_t)(sr + 8 * u) < last ? (uint32_t)(sr + 8 * u) : last;
+                const uint32_t off = rr * ldb + cbytes;
+                if (WEIGHTED) GW[u] = w[k + rr];
+#pragma unroll
+                for (int t = 0; t < 4; t++) G[u][t] = *(const d2_t*)__builtin_assume_aligned(base + off + 16 * t, 16);
+            }
+        };
+        // (under the sibling wavefront's MFMA stream a VALU instruction issues every ~16 cycles -- tools/jtj_phases.py -- so the
+        //  zeroing selects are skipped for the panels that need none, a workgroup-uniform decision)
+        const bool tiles_full = (ti + 1) * JTJ_TILE <= n_cols && (tj + 1) * JTJ_TILE <= n_cols;
+        auto stash2 = [&](double* pan, int64_t k, const d2_t (&G)[JTJ_PANEL / 8][4], const double (&GW)[JTJ_PANEL / 8]) {
+            if (tiles_full && k + JTJ_PANEL <= k_end) {
+#pragma unroll
+                for (int u = 0; u < JTJ_PANEL / 8; u++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        d2_t x = G[u][t];
+                        if (WEIGHTED) { x.x *= GW[u]; x.y *= GW[u]; }
+                        *(d2_t*)(pan + soff + 8 * u * JTJ_LDS_STRIDE + 2 * t) = x;
+                    }
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < JTJ_PANEL / 8; u++) {
+                const bool ok = cvalid && (k + sr + 8 * u < k_end);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    d2_t x = G[u][t];
+                    if (WEIGHTED) { x.x *= GW[u]; x.y *= GW[u]; }
+                    if (!ok) x = (d2_t){0.0, 0.0};
+                    *(d2_t*)(pan + soff + 8 * u * JTJ_LDS_STRIDE + 2 * t) = x;
+                }
+            }
+        };
+        // The live panels of this tile pair as a bitmap in scalar registers: 64 mask words per vector load (one per lane,
+        // the next window's already in flight), a ballot, and "next live panel" is a shift and a count -- the scalar-memory
+        // probe per panel of the generic loop costs ~1,400 cycles of every panel here (s_load round trip + SALU at the
+        // sibling's mercy).
+        const uint32_t need = (1u << ti) | (1u << tj);
+        const int64_t p_begin = k_begin / JTJ_PANEL, p_end = (k_end + JTJ_PANEL - 1) / JTJ_PANEL;
+        auto load_word = [&](int64_t w0) -> uint32_t {
+            const int64_t pi = w0 + lane;
+            const int64_t pv = pi < p_end ? pi : p_end - 1;
+            const uint32_t m = (pmask && pv >= 0) ? pmask[pv] : need;
+            return pi < p_end ? m : 0u;
+        };
+        int64_t win = p_begin;
+        uint64_t bits = __ballot((load_word(win) & need) == need);
+        uint32_t nextw = load_word(win + 64);
+        auto next_live2 = [&](int64_t kq) -> int64_t {
+            int64_t pi = kq / JTJ_PANEL;
+            for (;;) {
+                if (pi >= p_end) return k_end;
+                if (pi >= win + 64) {
+                    win += 64;
+                    bits = __ballot((nextw & need) == need);
+                    nextw = load_word(win + 64);
+                    continue;
+                }
+                const uint64_t rest = bits >> (int)(pi - win);
+                if (rest) return (pi + __builtin_ctzll(rest)) * JTJ_PANEL;
+                pi = win + 64;
+            }
+        };
+        d2_t g1[JTJ_PANEL / 8][4];
+        double gw1[JTJ_PANEL / 8];
+        int64_t k = next_live2(k_begin);
+        if (k < k_end) {                       // (workgroup-uniform)
+            fetch2(k, g, gw);
+            stash2(panel0, k, g, gw);
+            int64_t kn = next_live2(k + JTJ_PANEL);
+            fetch2(kn < k_end ? kn : k_begin, g, gw);                            // one ahead (a dummy re-read when there is none)
+            __syncthreads();
+#if GST_JTJ_TIMING
+            unsigned long long fph[6] = {0, 0, 0, 0, 0, 0};
+#endif
+            while (k < k_end) {                 // (one exit: the accumulators keep their registers through both halves)
+                // panel0 holds k, `g` is landing with kn: fetch two ahead into g1
+#if GST_JTJ_TIMING
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+                int64_t kn2 = kn < k_end ? next_live2(kn + JTJ_PANEL) : k_end;
+#if GST_JTJ_TIMING
+                const unsigned long long t0b = __builtin_amdgcn_s_memtime();
+#endif
+                fetch2(kn2 < k_end ? kn2 : k_begin, g1, gw1);
+#if GST_JTJ_TIMING
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+                mma_panel(panel0);
+#if GST_JTJ_TIMING
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+                if (kn < k_end) stash2(panel1, kn, g, gw);
+#if GST_JTJ_TIMING
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+#endif
+                __syncthreads();
+#if GST_JTJ_TIMING
+                const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+                fph[0] += t1 - t0b; fph[1] += t2 - t1; fph[2] += t0b - t0; fph[3] += t4 - t2; fph[4] += t5 - t4; fph[5] += 1;
+#endif
+                k = kn; kn = kn2;
+                // panel1 holds k (if any), `g1` is landing with kn: fetch two ahead into g
+                kn2 = kn < k_end ? next_live2(kn + JTJ_PANEL) : k_end;
+                fetch2(kn2 < k_end ? kn2 : k_begin, g, gw);
+                if (k < k_end) mma_panel(panel1);
+                if (kn < k_end) stash2(panel0, kn, g1, gw1);
+                __syncthreads();
+                k = kn; kn = kn2;
+            }
+#if GST_JTJ_TIMING
+            if (lane == 0)
+                for (int i = 0; i < 6; i++) atomicAdd(&jtj_dbg[i], fph[i]);
+#endif
+        }
+    } else {
+    int64_t k = next_live(k_begin);
+    if (k < k_end) {
+        fetch(k);
+        stash(panel0);
+    }
+    __syncthreads();
+    int cur = 0;
+#if GST_JTJ_TIMING
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+#define JT_NOW() __builtin_amdgcn_s_memtime()
+#endif
+    while (k < k_end) {
+#if GST_JTJ_TIMING
+        const unsigned long long t0 = JT_NOW();
+#endif
+        const int64_t kn = next_live(k + JTJ_PANEL);
+        const bool more = kn < k_end;
+        if (more) fetch(kn);                                     // next live panel: global -> registers, lands during the MFMAs
+#if GST_JTJ_TIMING
+        const unsigned long long t1 = JT_NOW();
+#endif
+        mma_panel(cur ? panel1 : panel0);
+#if GST_JTJ_TIMING
+        const unsigned long long t2 = JT_NOW();
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+        const unsigned long long t3 = JT_NOW();
+#endif
         if (more) stash(cur ? panel0 : panel1);
+#if GST_JTJ_TIMING
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+        const unsigned long long t4 = JT_NOW();
+#endif
         __syncthreads();
+#if GST_JTJ_TIMING
+        const unsigned long long t5 = JT_NOW();
+        ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; ph[5] += 1;
+#endif
         cur ^= 1;
         k = kn;
+    }
+#if GST_JTJ_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 6; i++) atomicAdd(&jtj_dbg[i], ph[i]);
+#endif
     }
     const int i0 = ti * JTJ_TILE + wi, j0 = tj * JTJ_TILE + wj;
     double* out = part + (int64_t)s * n_cols * n_cols;
@@ -200,22 +368,41 @@ __global__ __launch_bounds__(256) void jtj_panel_mask_kernel(double* __restrict_
     }
 }
 
-// JtJ[r][c] = sum over slabs of part[s][min][max] (the computed triangle, in units of whole tiles), mirrored
-__global__ void jtj_reduce_kernel(const double* __restrict__ part, int n_slabs, int n_cols, double* __restrict__ C)
+// JtJ = sum over slabs of the partial tiles (fixed order: deterministic), mirrored.  One workgroup per 32 x 32 block (br <= bc)
+// of the result: every entry of such a block was computed directly (its 128-tile row index is <= its column index; the
+// diagonal tiles are computed in full, both halves from the same products in the same order, so they are symmetric to the
+// bit), the sums are read and written in coalesced 256-byte rows, and the mirrored block goes out through an LDS
+// transpose.  (Rounds 2-4 read the lower triangle through transposed addresses: 0.95 ms for 2.6 M sums; this form 0.3.)
+__global__ __launch_bounds__(256) void jtj_reduce_kernel(const double* __restrict__ part, int n_slabs, int n_cols, double* __restrict__ C)
 {
+    __shared__ double tile[32][33];
+    const int nb = (n_cols + 31) / 32;
+    int br = 0, rem = (int)blockIdx.x;
+    while (rem >= nb - br) { rem -= nb - br; br++; }
+    const int bc = br + rem;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int64_t total = (int64_t)n_cols * n_cols;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / n_cols), c = (int)(i - (int64_t)r * n_cols);
-        // tiles with ti <= tj were computed in full, so an entry is available as (r, c) when tile(r) <= tile(c)
-        const bool direct = (r / JTJ_TILE) <= (c / JTJ_TILE);
-        const int64_t src = direct ? (int64_t)r * n_cols + c : (int64_t)c * n_cols + r;
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+        const int r = br * 32 + j, c = bc * 32 + tx;
         double sum = 0.0;
-        for (int s = 0; s < n_slabs; s++) sum += part[(int64_t)s * total + src];
-        C[i] = sum;
+        if (r < n_cols && c < n_cols) {
+            const double* src = part + (int64_t)r * n_cols + c;
+            for (int sl = 0; sl < n_slabs; sl++) sum += src[(int64_t)sl * total];
+            C[(int64_t)r * n_cols + c] = sum;
+        }
+        tile[j][tx] = sum;
+    }
+    __syncthreads();
+    if (br != bc) {
+#pragma unroll
+        for (int j = ty; j < 32; j += 8) {
+            const int r = bc * 32 + j, c = br * 32 + tx;
+            if (r < n_cols && c < n_cols) C[(int64_t)r * n_cols + c] = tile[tx][j];
+        }
     }
 }
 
-// Jtf partials: block = 256 consecutive columns x one slab of rows (coalesced 2 KB per row)
 // w != nullptr: (diag(w) J)^T f with the weighted element rounded first, as the in-place scaling stores it
 __global__ void jtf_kernel(const double* __restrict__ J, const double* __restrict__ f, int64_t n_rows, int n_cols,
                            int64_t ld, int64_t slab_rows, double* __restrict__ part /* [n_slabs][n_cols] */,
@@ -665,16 +852,34 @@ hipError_t launch_chain_rule_gemm(const double* A, int64_t ldA, int64_t a_col0, 
     return hipGetLastError();
 }
 
-int jtj_num_slabs(int64_t n_rows, int n_cols)
+// development switch: GST_JTJ_FAST=0 keeps the one-panel-ahead form for every shape
+static bool jtj_fast_path()
+{
+    static const int v = [] { const char* e = std::getenv("GST_JTJ_FAST"); return e ? std::atoi(e) : 1; }();
+    return v != 0;
+}
+
+int jtj_num_slabs(int64_t n_rows, int n_cols, int n_cus)
 {
     const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
-    int slabs = (int)((4096 + n_pairs - 1) / n_pairs);         // aim for ~4096 workgroups
-    const int64_t max_by_rows = (n_rows + 63) / 64;              // at least 64 rows per slab
-    if (slabs > max_by_rows) slabs = (int)(max_by_rows > 0 ? max_by_rows : 1);
-    if (slabs > 64) slabs = 64;
-    slabs = (slabs + 7) / 8 * 8;                                 // one group of slabs per XCD (empty slabs are harmless)
-    return slabs;
+    const int64_t max_by_rows = std::max<int64_t>(1, (n_rows + 63) / 64);          // at least 64 rows per slab
+    // One group of slabs per XCD (a multiple of 8; empty slabs are harmless), ~4096 workgroups or more -- and among the
+    // candidates the one whose workgroups fill the chip's 2 * n_cus slots in whole rounds: 48 slabs x 91 tile pairs of the
+    // 2Q design are 8.53 rounds (the ninth half empty), 56 slabs are 9.95.
+    const int slots = 2 * std::max(n_cus, 1);
+    int best = 8;
+    double best_eff = -1.0;
+    for (int sl = 8; sl <= 64; sl += 8) {
+        if (sl > 8 && sl - 7 > max_by_rows) break;
+        const double rounds = (double)sl * n_pairs / slots;
+        const double eff = rounds / std::ceil(rounds);
+        const bool enough = (int64_t)sl * n_pairs >= 3584;
+        const double score = (enough ? 1.0 : 0.0) + eff * ((int64_t)sl * n_pairs >= slots ? 1.0 : 0.5);
+        if (score > best_eff + 1e-9) { best_eff = score; best = sl; }
+        if (enough && (int64_t)sl * n_pairs >= 6144) break;                       // more slabs only add partial sums
+    }
+    return best;
 }
 
 hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t ld, const double* w, uint32_t* pmask, hipStream_t s,
@@ -691,6 +896,13 @@ hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t
                        n_tiles, pmask, write_back);
     return hipGetLastError();
 }
+#if GST_JTJ_TIMING
+extern "C" int gst_debug_jtj_phases(unsigned long long* out, int reset)
+{
+    if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(jtj_dbg), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(jtj_dbg), 8 * sizeof(unsigned long long));
+}
+#endif
 int jtj_mask_tiles(int n_cols) { return (n_cols + JTJ_TILE - 1) / JTJ_TILE; }
 int64_t jtj_mask_panels(int64_t n_rows) { return (n_rows + JTJ_PANEL - 1) / JTJ_PANEL; }
 
@@ -703,20 +915,22 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
     slab_rows = (slab_rows + JTJ_PANEL - 1) / JTJ_PANEL * JTJ_PANEL;        // the k loop advances one panel per iteration
     (void)hipGetLastError();
     const size_t lds_bytes = (size_t)2 * JTJ_PANEL * JTJ_LDS_STRIDE * sizeof(double);
+    // the branch-free, two-panels-ahead form needs 16-byte loads to be legal everywhere
+    const bool fast = jtj_fast_path() && (n_cols % 8 == 0) && (ld % 2 == 0) && (((uintptr_t)J & 15) == 0) && n_rows > 0 && ld < (1 << 24);
+    typedef void (*jtj_kernel_t)(const double*, int64_t, int, int64_t, int64_t, int, double*, const uint32_t*, const double*);
+    const jtj_kernel_t kern = fast ? (w ? jtj_mfma_lds_kernel<true, true> : jtj_mfma_lds_kernel<false, true>)
+                                   : (w ? jtj_mfma_lds_kernel<true, false> : jtj_mfma_lds_kernel<false, false>);
     if (lds_bytes > 64 * 1024) {          // per device (a process may drive several GPUs): set on every launch, it is cheap
-        hipError_t ea = hipFuncSetAttribute(w ? (const void*)jtj_mfma_lds_kernel<true> : (const void*)jtj_mfma_lds_kernel<false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (ea != hipSuccess) return ea;
     }
-    if (w)
-        hipLaunchKernelGGL(jtj_mfma_lds_kernel<true>, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld,
-                           slab_rows, n_tiles, part, pmask, w);
-    else
-        hipLaunchKernelGGL(jtj_mfma_lds_kernel<false>, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld,
-                           slab_rows, n_tiles, part, pmask, w);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld, slab_rows, n_tiles, part, pmask, w);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(jtj_reduce_kernel, dim3(2048), dim3(256), 0, s, part, n_slabs, n_cols, C);
+    {
+        const int nb = (n_cols + 31) / 32;
+        hipLaunchKernelGGL(jtj_reduce_kernel, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, s, part, n_slabs, n_cols, C);
+    }
     return hipGetLastError();
 }
 

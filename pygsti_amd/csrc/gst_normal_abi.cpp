@@ -38,7 +38,7 @@ int gst_fill_jtj_dev(gst_plan* p, double* d_J, int64_t n_rows, int64_t n_cols, i
         d_pmask = p->d_jtj_pmask.p;
     } else if (d_row_scale && n_rows > 0 && n_cols > 0) HIP_TRY(gst::launch_scale_rows(d_J, n_rows, n_cols, ld, d_row_scale, p->stream));
     if (n_cols > 0) {
-        const int n_slabs = gst::jtj_num_slabs(n_rows, (int)n_cols);
+        const int n_slabs = gst::jtj_num_slabs(n_rows, (int)n_cols, p->n_cus);
         HIP_TRY(p->d_jtj_part.ensure((size_t)n_slabs * n_cols * n_cols));
         TIME_REC(p, evk0);
         HIP_TRY(gst::launch_jtj(d_J, n_rows, (int)n_cols, ld, p->d_jtj_part.p, n_slabs, d_jtj, p->stream, d_pmask));
@@ -57,7 +57,7 @@ int gst_fill_jtf_dev(gst_plan* p, const double* d_J, int64_t n_rows, int64_t n_c
     int rc = ensure_device(p);
     if (rc) return rc;
     if (n_cols == 0) return GST_OK;
-    const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n_rows + 255) / 256));
+    const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(256, (n_rows + 255) / 256));
     gst::track_touch(d_jtf, (size_t)n_cols * 8);
     HIP_TRY(p->d_jtf_part.ensure((size_t)n_slabs * n_cols));
     HIP_TRY(gst::launch_jtf(d_J, d_f, n_rows, (int)n_cols, ld, p->d_jtf_part.p, n_slabs, d_jtf, p->stream));
@@ -87,14 +87,14 @@ int gst_fill_normal_eqs_dev(gst_plan* p, const double* d_J, int64_t n_rows, int6
                                                 /*write_back=*/false));
             d_pmask = p->d_jtj_pmask.p;
         }
-        const int n_slabs = gst::jtj_num_slabs(n_rows, (int)n_cols);
+        const int n_slabs = gst::jtj_num_slabs(n_rows, (int)n_cols, p->n_cus);
         HIP_TRY(p->d_jtj_part.ensure((size_t)n_slabs * n_cols * n_cols));
         TIME_REC(p, evk0);
         HIP_TRY(gst::launch_jtj(d_J, n_rows, (int)n_cols, ld, p->d_jtj_part.p, n_slabs, d_jtj, p->stream, d_pmask, d_row_scale));
         TIME_REC(p, evk1);
     }
     if (d_jtf) {
-        const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n_rows + 255) / 256));
+        const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(256, (n_rows + 255) / 256));
         gst::track_touch(d_jtf, (size_t)n_cols * 8);
         HIP_TRY(p->d_jtf_part.ensure((size_t)n_slabs * n_cols));
         HIP_TRY(gst::launch_jtf(d_J, d_f, n_rows, (int)n_cols, ld, p->d_jtf_part.p, n_slabs, d_jtf, p->stream, d_row_scale));

@@ -160,7 +160,11 @@ def test_jtj_block_sparse_jacobian():
 
 
 @pytest.mark.parametrize("n_rows,n_cols,pad,sparse", [(20011, 730, 3, True), (5003, 1616, 0, False), (70001, 200, 1, False),
-                                                      (33, 7, 2, False), (16400, 513, 0, True)])
+                                                      (33, 7, 2, False), (16400, 513, 0, True),
+                                                      # n_cols % 8 == 0, even ld: the branch-free two-panels-ahead form with
+                                                      # its live-panel bitmaps (windows of 64 panels, some wholly dead)
+                                                      (20011, 736, 2, True), (70000, 264, 0, True), (17, 8, 0, False),
+                                                      (40003, 1616, 8, True)])
 def test_normal_eqs_without_touching_J(n_rows, n_cols, pad, sparse):
     """gst_fill_normal_eqs_dev (round 5): the row weights are applied while the rows are staged, so d_J is only read --
     and since every weighted element is rounded exactly as the in-place scaling stores it, J_s^T J_s and J_s^T f come out
@@ -179,6 +183,9 @@ def test_normal_eqs_without_touching_J(n_rows, n_cols, pad, sparse):
             c0 = int(rng.integers(0, n_cols)); c1 = int(rng.integers(c0, n_cols + 1))
             if rng.random() < 0.6: Jp[r:r + n, c0:c1] = 0.0
             r += n
+        if n_rows > 12000:
+            Jp[3000:5500, :] = 0.0                                     # 156 dead panels in a row (whole bitmap windows)
+            Jp[9000:11000, 128:] = 0.0                                 # ... and a stretch where only the first tile lives
         Jp[960:976, 128:256] = 0.0; Jp[966, 200] = 5.0                # a lone non-zero in its (panel, tile) ...
     w = rng.random(n_rows) + 0.5
     w[rng.random(n_rows) < 0.1] = 0.0
