@@ -411,7 +411,9 @@ int gst_fill_jtf_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t 
                      const double *d_f, double *d_jtf);
 /* The same normal equations WITHOUT touching d_J (round 5): d_jtj = (diag(w) J)^T (diag(w) J) and d_jtf =
  * (diag(w) J)^T f with w = d_row_scale (NULL: all ones) applied while the rows are staged -- every weighted element is
- * rounded exactly as the in-place scaling of gst_fill_jtj_dev stores it, so both routes return the same bits, but the
+ * rounded exactly as the in-place scaling of gst_fill_jtj_dev stores it, so d_jtj comes out with the same bits (d_jtf too,
+ * except on the block-sparse path of large matrices -- >= 16,384 rows, > 384 columns, both outputs requested -- where the
+ * pass that marks the live panels also carries J_s^T f: one read of d_J for both, another fixed summation order), but the
  * 2 x n_rows x n_cols x 8 bytes of the scaling pass' read-modify-write are not moved and d_J stays the plain Jacobian
  * (so it may be contracted again, copied out, or -- for an exact Jacobian in tracked memory -- keep its resident zeros
  * whatever the weights are).  Either output may be NULL (d_jtf needs d_f).  Replaces the same reference lines as

@@ -195,8 +195,13 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
 // J <- diag(w) J as well
 hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t ld, const double* w, uint32_t* pmask, hipStream_t s,
                                   bool write_back = true);
+// the masks of diag(w) J and (diag(w) J)^T f -> y in one read-only pass (part: [n_ranges][n_cols] scratch)
+int jtj_mask_jtf_ranges(int64_t n_rows, int n_cols);
+hipError_t launch_jtj_mask_jtf(const double* J, int64_t n_rows, int n_cols, int64_t ld, const double* w, const double* f, uint32_t* pmask,
+                               double* part, int n_ranges, double* y, hipStream_t s);
 int jtj_mask_tiles(int n_cols);
 int64_t jtj_mask_panels(int64_t n_rows);
+int64_t jtj_mask_words(int64_t n_rows);      // allocation of a mask buffer: the panel masks + pair counts + ranked pairs
 hipError_t launch_jtf(const double* J, const double* f, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs,
                       double* y, hipStream_t s, const double* w = nullptr);
 

@@ -60,14 +60,16 @@ template <bool WEIGHTED, bool FAST>
 __global__ __launch_bounds__(256, 2) void jtj_mfma_lds_kernel(const double* __restrict__ J, int64_t n_rows, int n_cols,
                                                               int64_t ld, int64_t slab_rows, int n_tiles,
                                                               double* __restrict__ part, const uint32_t* __restrict__ pmask,
-                                                              const double* __restrict__ w)
+                                                              const double* __restrict__ w, const uint32_t* __restrict__ pair_order)
 {
     extern __shared__ __attribute__((aligned(16))) double panel_mem[];      // [2][JTJ_PANEL * JTJ_LDS_STRIDE]
     double* const panel0 = panel_mem;
     double* const panel1 = panel_mem + JTJ_PANEL * JTJ_LDS_STRIDE;
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
     const int xcd = blockIdx.x % 8, q = blockIdx.x / 8;
-    const int p = q % n_pairs;
+    // (pair_order: the tile pairs with the most live panels first -- with a block-sparse Jacobian a pair's work varies 3 x,
+    //  and whatever is dispatched last should be short)
+    const int p = pair_order ? (int)pair_order[q % n_pairs] : q % n_pairs;
     const int64_t s = (int64_t)(q / n_pairs) * 8 + xcd;
     int ti = 0, rem = p;
     while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ti++; }
@@ -366,6 +368,97 @@ __global__ __launch_bounds__(256) void jtj_panel_mask_kernel(double* __restrict_
         }
         if (__ballot(any) != 0 && lane == 0) atomicOr(&pmask[panel], 1u << tile);
     }
+}
+
+// Live panels per tile pair (from the panel masks) and the pairs ranked by them, heaviest first: two tiny launches
+// (~10 us) that let jtj_mfma_lds_kernel dispatch every slab's long pairs before its short ones.
+constexpr int JTJ_MAX_PAIRS = 32 * 33 / 2;
+__global__ __launch_bounds__(256) void jtj_pair_count_kernel(const uint32_t* __restrict__ pmask, int64_t n_panels, int n_tiles,
+                                                             uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t loc[JTJ_MAX_PAIRS];
+    const int n_pairs = n_tiles * (n_tiles + 1) / 2;
+    for (int i = threadIdx.x; i < n_pairs; i += 256) loc[i] = 0;
+    __syncthreads();
+    for (int64_t pi = (int64_t)blockIdx.x * 256 + threadIdx.x; pi < n_panels; pi += (int64_t)gridDim.x * 256) {
+        const uint32_t m = pmask[pi];
+        for (uint32_t a = m; a; a &= a - 1) {
+            const int i = __builtin_ctz(a);
+            const int base = i * n_tiles - i * (i - 1) / 2 - i;              // index of pair (i, j) = base + j
+            for (uint32_t b = a; b; b &= b - 1) atomicAdd(&loc[base + __builtin_ctz(b)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_pairs; i += 256)
+        if (loc[i]) atomicAdd(&counts[i], loc[i]);
+}
+__global__ __launch_bounds__(1024) void jtj_pair_rank_kernel(const uint32_t* __restrict__ counts, int n_pairs, uint32_t* __restrict__ order)
+{
+    const int p = threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t c = counts[p];
+    int rank = 0;
+    for (int q = 0; q < n_pairs; q++) {
+        const uint32_t d = counts[q];
+        rank += (d > c || (d == c && q < p)) ? 1 : 0;
+    }
+    order[rank] = (uint32_t)p;
+}
+
+// The panel masks of diag(w) J AND (diag(w) J)^T f in ONE streaming pass over J (round 5; J is only read): a wavefront owns a
+// 128-column tile over a contiguous range of panels -- lane l the columns 2l, 2l + 1 -- marks the panels of its range that
+// hold anything in the tile and carries the tile's 128 partial sums of J_s^T f through the range in registers (rows in
+// ascending order, one fused multiply-add per element on the weighted, rounded element: deterministic); the ranges are
+// summed by jtf_reduce_kernel.  Saves the second 7 GB read of the 2Q design's Jacobian (jtf_kernel: 1.2 ms).
+// pmask must be zeroed before the launch; part is [n_ranges][n_cols].
+__global__ __launch_bounds__(256) void jtj_mask_jtf_kernel(const double* __restrict__ J, int64_t n_rows, int n_cols, int64_t ld,
+                                                           const double* __restrict__ w, const double* __restrict__ f, int n_tiles,
+                                                           uint32_t* __restrict__ pmask, int n_ranges, int64_t panels_per_range,
+                                                           double* __restrict__ part)
+{
+    const int64_t n_panels = (n_rows + JTJ_PANEL - 1) / JTJ_PANEL;
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform: w, f by scalar loads)
+    if (item >= (int64_t)n_ranges * n_tiles) return;
+    const int64_t range = item / n_tiles;
+    const int tile = (int)(item - range * n_tiles);
+    const int c0 = tile * JTJ_TILE + 2 * lane;
+    const int64_t p0 = range * panels_per_range, p1 = (p0 + panels_per_range < n_panels) ? p0 + panels_per_range : n_panels;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    double a0 = 0.0, a1 = 0.0;
+    const bool pairable = c0 + 1 < n_cols && (ld % 2 == 0) && ((((uintptr_t)J) & 15) == 0);      // 16-byte loads legal on every row
+    for (int64_t panel = p0; panel < p1; panel++) {
+        bool any = false;
+        const int64_t r0 = panel * JTJ_PANEL;
+        const int nr = (int)((r0 + JTJ_PANEL <= n_rows) ? JTJ_PANEL : n_rows - r0);
+        if (pairable && nr == JTJ_PANEL) {
+            d2_t x[JTJ_PANEL];
+#pragma unroll
+            for (int r = 0; r < JTJ_PANEL; r++) x[r] = *(const d2_t*)(J + (r0 + r) * ld + c0);
+#pragma unroll
+            for (int r = 0; r < JTJ_PANEL; r++) {
+                const double ws = w ? w[r0 + r] : 1.0, fs = f[r0 + r];
+                d2_t y = x[r];
+                if (w) { y.x *= ws; y.y *= ws; }
+                any = any || y.x != 0.0 || y.y != 0.0;
+                a0 = __builtin_fma(y.x, fs, a0);
+                a1 = __builtin_fma(y.y, fs, a1);
+            }
+        } else {
+            for (int r = 0; r < nr; r++) {
+                const double* p = J + (r0 + r) * ld + c0;
+                const double ws = w ? w[r0 + r] : 1.0, fs = f[r0 + r];
+                double y0 = (c0 < n_cols) ? p[0] : 0.0, y1 = (c0 + 1 < n_cols) ? p[1] : 0.0;
+                if (w) { y0 *= ws; y1 *= ws; }
+                any = any || y0 != 0.0 || y1 != 0.0;
+                a0 = __builtin_fma(y0, fs, a0);
+                a1 = __builtin_fma(y1, fs, a1);
+            }
+        }
+        if (__ballot(any) != 0 && lane == 0) atomicOr(&pmask[panel], 1u << tile);
+    }
+    if (c0 < n_cols) part[range * n_cols + c0] = a0;
+    if (c0 + 1 < n_cols) part[range * n_cols + c0 + 1] = a1;
 }
 
 // JtJ = sum over slabs of the partial tiles (fixed order: deterministic), mirrored.  One workgroup per 32 x 32 block (br <= bc)
@@ -889,7 +982,7 @@ hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t
     if (n_tiles > 32 || n_rows <= 0) return hipErrorInvalidValue;
     const int64_t n_panels = (n_rows + JTJ_PANEL - 1) / JTJ_PANEL;
     (void)hipGetLastError();
-    hipError_t e = hipMemsetAsync(pmask, 0, (size_t)n_panels * 4, s);
+    hipError_t e = hipMemsetAsync(pmask, 0, (size_t)(n_panels + JTJ_MAX_PAIRS) * 4, s);      // masks + pair counts
     if (e != hipSuccess) return e;
     const int64_t items = n_panels * n_tiles;
     hipLaunchKernelGGL(jtj_panel_mask_kernel, dim3((unsigned)std::min<int64_t>((items + 3) / 4, 65536)), dim3(256), 0, s, J, n_rows, n_cols, ld, w,
@@ -903,8 +996,36 @@ extern "C" int gst_debug_jtj_phases(unsigned long long* out, int reset)
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(jtj_dbg), 8 * sizeof(unsigned long long));
 }
 #endif
+int jtj_mask_jtf_ranges(int64_t n_rows, int n_cols)
+{
+    const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
+    const int64_t n_panels = (n_rows + JTJ_PANEL - 1) / JTJ_PANEL;
+    int64_t ranges = (4096 + n_tiles - 1) / n_tiles;                      // ~4096 wavefronts
+    if (ranges > n_panels / 8) ranges = n_panels / 8;                     // at least 8 panels each
+    if (ranges > 512) ranges = 512;
+    return (int)(ranges < 1 ? 1 : ranges);
+}
+hipError_t launch_jtj_mask_jtf(const double* J, int64_t n_rows, int n_cols, int64_t ld, const double* w, const double* f, uint32_t* pmask,
+                               double* part, int n_ranges, double* y, hipStream_t s)
+{
+    const int n_tiles = (n_cols + JTJ_TILE - 1) / JTJ_TILE;
+    if (n_tiles > 32 || n_rows <= 0 || n_ranges < 1) return hipErrorInvalidValue;
+    const int64_t n_panels = (n_rows + JTJ_PANEL - 1) / JTJ_PANEL;
+    (void)hipGetLastError();
+    hipError_t e = hipMemsetAsync(pmask, 0, (size_t)(n_panels + JTJ_MAX_PAIRS) * 4, s);      // masks + pair counts
+    if (e != hipSuccess) return e;
+    const int64_t ppr = (n_panels + n_ranges - 1) / n_ranges;
+    const int64_t items = (int64_t)n_ranges * n_tiles;
+    hipLaunchKernelGGL(jtj_mask_jtf_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, J, n_rows, n_cols, ld, w, f, n_tiles, pmask,
+                       n_ranges, ppr, part);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(jtf_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, s, part, n_ranges, n_cols, y);
+    return hipGetLastError();
+}
 int jtj_mask_tiles(int n_cols) { return (n_cols + JTJ_TILE - 1) / JTJ_TILE; }
 int64_t jtj_mask_panels(int64_t n_rows) { return (n_rows + JTJ_PANEL - 1) / JTJ_PANEL; }
+int64_t jtj_mask_words(int64_t n_rows) { return jtj_mask_panels(n_rows) + 2 * JTJ_MAX_PAIRS; }
 
 hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, double* part, int n_slabs, double* C,
                       hipStream_t s, const uint32_t* pmask, const double* w)
@@ -917,14 +1038,26 @@ hipError_t launch_jtj(const double* J, int64_t n_rows, int n_cols, int64_t ld, d
     const size_t lds_bytes = (size_t)2 * JTJ_PANEL * JTJ_LDS_STRIDE * sizeof(double);
     // the branch-free, two-panels-ahead form needs 16-byte loads to be legal everywhere
     const bool fast = jtj_fast_path() && (n_cols % 8 == 0) && (ld % 2 == 0) && (((uintptr_t)J & 15) == 0) && n_rows > 0 && ld < (1 << 24);
-    typedef void (*jtj_kernel_t)(const double*, int64_t, int, int64_t, int64_t, int, double*, const uint32_t*, const double*);
+    typedef void (*jtj_kernel_t)(const double*, int64_t, int, int64_t, int64_t, int, double*, const uint32_t*, const double*, const uint32_t*);
     const jtj_kernel_t kern = fast ? (w ? jtj_mfma_lds_kernel<true, true> : jtj_mfma_lds_kernel<false, true>)
                                    : (w ? jtj_mfma_lds_kernel<true, false> : jtj_mfma_lds_kernel<false, false>);
     if (lds_bytes > 64 * 1024) {          // per device (a process may drive several GPUs): set on every launch, it is cheap
         hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (ea != hipSuccess) return ea;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld, slab_rows, n_tiles, part, pmask, w);
+    const uint32_t* order = nullptr;
+    if (pmask && n_pairs <= JTJ_MAX_PAIRS && n_pairs <= 1024) {
+        // (the words behind the masks: pair counts, zeroed with the masks, then the ranked pairs -- jtj_mask_words())
+        const int64_t n_panels = (n_rows + JTJ_PANEL - 1) / JTJ_PANEL;
+        uint32_t* counts = const_cast<uint32_t*>(pmask) + n_panels;
+        uint32_t* ord = counts + JTJ_MAX_PAIRS;
+        hipLaunchKernelGGL(jtj_pair_count_kernel, dim3(64), dim3(256), 0, s, pmask, n_panels, n_tiles, counts);
+        hipLaunchKernelGGL(jtj_pair_rank_kernel, dim3(1), dim3(1024), 0, s, counts, n_pairs, ord);
+        hipError_t eo = hipGetLastError();
+        if (eo != hipSuccess) return eo;
+        order = ord;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_pairs * n_slabs)), dim3(256), lds_bytes, s, J, n_rows, n_cols, ld, slab_rows, n_tiles, part, pmask, w, order);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     {

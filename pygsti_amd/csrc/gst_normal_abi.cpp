@@ -33,7 +33,7 @@ int gst_fill_jtj_dev(gst_plan* p, double* d_J, int64_t n_rows, int64_t n_cols, i
     const bool sparse = p->jtj_sparse && n_rows >= 16384 && gst::jtj_mask_tiles((int)n_cols) >= 4 && gst::jtj_mask_tiles((int)n_cols) <= 32;
     const uint32_t* d_pmask = nullptr;
     if (sparse) {
-        HIP_TRY(p->d_jtj_pmask.ensure((size_t)gst::jtj_mask_panels(n_rows)));
+        HIP_TRY(p->d_jtj_pmask.ensure((size_t)gst::jtj_mask_words(n_rows)));
         HIP_TRY(gst::launch_jtj_panel_masks(d_J, n_rows, (int)n_cols, ld, d_row_scale, p->d_jtj_pmask.p, p->stream));
         d_pmask = p->d_jtj_pmask.p;
     } else if (d_row_scale && n_rows > 0 && n_cols > 0) HIP_TRY(gst::launch_scale_rows(d_J, n_rows, n_cols, ld, d_row_scale, p->stream));
@@ -76,15 +76,26 @@ int gst_fill_normal_eqs_dev(gst_plan* p, const double* d_J, int64_t n_rows, int6
     if (rc) return rc;
     if (n_cols == 0) return GST_OK;
     TIME_REC(p, ev0);
+    bool jtf_done = false;
     if (d_jtj) {
         gst::track_touch(d_jtj, (size_t)n_cols * n_cols * 8);
         // d_J is only read: no claim on it changes (its resident zeros stay zeros whatever the weights are)
         const bool sparse = p->jtj_sparse && n_rows >= 16384 && gst::jtj_mask_tiles((int)n_cols) >= 4 && gst::jtj_mask_tiles((int)n_cols) <= 32;
         const uint32_t* d_pmask = nullptr;
         if (sparse) {
-            HIP_TRY(p->d_jtj_pmask.ensure((size_t)gst::jtj_mask_panels(n_rows)));
-            HIP_TRY(gst::launch_jtj_panel_masks(const_cast<double*>(d_J), n_rows, (int)n_cols, ld, d_row_scale, p->d_jtj_pmask.p, p->stream,
-                                                /*write_back=*/false));
+            HIP_TRY(p->d_jtj_pmask.ensure((size_t)gst::jtj_mask_words(n_rows)));
+            if (d_jtf) {
+                // one read of J for the masks and J_s^T f together (the sums are carried through ranges of panels: another
+                // summation order than gst_fill_jtf_dev's, equally deterministic)
+                const int n_ranges = gst::jtj_mask_jtf_ranges(n_rows, (int)n_cols);
+                gst::track_touch(d_jtf, (size_t)n_cols * 8);
+                HIP_TRY(p->d_jtf_part.ensure((size_t)n_ranges * n_cols));
+                HIP_TRY(gst::launch_jtj_mask_jtf(d_J, n_rows, (int)n_cols, ld, d_row_scale, d_f, p->d_jtj_pmask.p, p->d_jtf_part.p, n_ranges,
+                                                 d_jtf, p->stream));
+                jtf_done = true;
+            } else
+                HIP_TRY(gst::launch_jtj_panel_masks(const_cast<double*>(d_J), n_rows, (int)n_cols, ld, d_row_scale, p->d_jtj_pmask.p, p->stream,
+                                                    /*write_back=*/false));
             d_pmask = p->d_jtj_pmask.p;
         }
         const int n_slabs = gst::jtj_num_slabs(n_rows, (int)n_cols, p->n_cus);
@@ -93,7 +104,7 @@ int gst_fill_normal_eqs_dev(gst_plan* p, const double* d_J, int64_t n_rows, int6
         HIP_TRY(gst::launch_jtj(d_J, n_rows, (int)n_cols, ld, p->d_jtj_part.p, n_slabs, d_jtj, p->stream, d_pmask, d_row_scale));
         TIME_REC(p, evk1);
     }
-    if (d_jtf) {
+    if (d_jtf && !jtf_done) {
         const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(256, (n_rows + 255) / 256));
         gst::track_touch(d_jtf, (size_t)n_cols * 8);
         HIP_TRY(p->d_jtf_part.ensure((size_t)n_slabs * n_cols));

@@ -202,7 +202,11 @@ def test_normal_eqs_without_touching_J(n_rows, n_cols, pad, sparse):
     # the new route
     pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w, d_f, d_b, d_yb)
     b = pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_b); yb = pl.memcpy_d2h(np.empty(n_cols), d_yb)
-    assert np.array_equal(a, b) and np.array_equal(ya, yb)
+    # J_s^T J_s: the same bits.  J_s^T f: the same bits on the small shapes; on the block-sparse path (>= 16,384 rows, >= 4
+    # column tiles) it is summed by the pass that marks the live panels -- one read of J for both, another (fixed) order
+    fused = n_rows >= 16384 and n_cols > 384
+    assert np.array_equal(a, b)
+    assert np.abs(ya - yb).max() <= 1e-13 * np.abs(ya).max() and (fused or np.array_equal(ya, yb))
     assert np.array_equal(pl.memcpy_d2h(np.empty((n_rows, ld)), d_J), Jp)             # J as the caller left it
     Js = Jp[:, :n_cols] * w[:, None]
     want = Js.T @ Js
@@ -213,11 +217,16 @@ def test_normal_eqs_without_touching_J(n_rows, n_cols, pad, sparse):
     pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w, d_jtj=d_b)
     assert np.array_equal(pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_b), a) and not pl.memcpy_d2h(np.empty(n_cols), d_yb).any()
     pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w, d_f=d_f, d_jtf=d_yb)
-    assert np.array_equal(pl.memcpy_d2h(np.empty(n_cols), d_yb), ya)
+    assert np.array_equal(pl.memcpy_d2h(np.empty(n_cols), d_yb), ya)                  # (J^T f alone: the streaming kernel of gst_fill_jtf_dev)
+    pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w, d_f, d_b, d_yb)
+    y2 = pl.memcpy_d2h(np.empty(n_cols), d_yb)
+    pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w, d_f, d_b, d_yb)
+    assert np.array_equal(pl.memcpy_d2h(np.empty(n_cols), d_yb), y2) and np.array_equal(y2, yb)     # deterministic
     pl.fill_jtj_dev(d_J, n_rows, n_cols, ld, d_a); pl.fill_jtf_dev(d_J, n_rows, n_cols, ld, d_f, d_ya)
     pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, None, d_f, d_b, d_yb)
     assert np.array_equal(pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_a), pl.memcpy_d2h(np.empty((n_cols, n_cols)), d_b))
-    assert np.array_equal(pl.memcpy_d2h(np.empty(n_cols), d_ya), pl.memcpy_d2h(np.empty(n_cols), d_yb))
+    ya0, yb0 = pl.memcpy_d2h(np.empty(n_cols), d_ya), pl.memcpy_d2h(np.empty(n_cols), d_yb)
+    assert np.abs(ya0 - yb0).max() <= 1e-13 * np.abs(ya0).max() and (fused or np.array_equal(ya0, yb0))
     with pytest.raises(ValueError):
         pl.fill_normal_eqs_dev(d_J, n_rows, n_cols, ld, d_w)                           # nothing to compute
     with pytest.raises(ValueError):

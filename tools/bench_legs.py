@@ -262,8 +262,9 @@ def lm_step(B):
                     lm_step()
                 barrier_sync(plan)
                 lm_info["exact_jacobian_in_place_scaling_ms_per_step"] = 1e3 * ctx.max_over_ranks(time.perf_counter() - tl) / n_lm
-                lm_info["weights_on_the_fly_same_bits_as_in_place"] = bool(
-                    np.array_equal(jtf_new, plan.memcpy_d2h(np.empty(nP), d_jtf)) and np.array_equal(jtj_new, plan.memcpy_d2h(np.empty((nP, nP)), d_jtj)))
+                jtf_old = plan.memcpy_d2h(np.empty(nP), d_jtf)
+                lm_info["weights_on_the_fly_jtj_same_bits_as_in_place"] = bool(np.array_equal(jtj_new, plan.memcpy_d2h(np.empty((nP, nP)), d_jtj)))
+                lm_info["weights_on_the_fly_jtf_max_rel_diff"] = float(np.abs(jtf_new - jtf_old).max() / max(np.abs(jtf_old).max(), 1e-300))
                 lm_in_place[0] = False
                 lm_mode[0] = mode
         finally:
