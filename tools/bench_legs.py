@@ -265,6 +265,7 @@ def lm_step(B):
                 jtf_old = plan.memcpy_d2h(np.empty(nP), d_jtf)
                 lm_info["weights_on_the_fly_jtj_same_bits_as_in_place"] = bool(np.array_equal(jtj_new, plan.memcpy_d2h(np.empty((nP, nP)), d_jtj)))
                 lm_info["weights_on_the_fly_jtf_max_rel_diff"] = float(np.abs(jtf_new - jtf_old).max() / max(np.abs(jtf_old).max(), 1e-300))
+                lm_info["jtf_max_abs"] = float(np.abs(jtf_old).max())
                 lm_in_place[0] = False
                 lm_mode[0] = mode
         finally:
