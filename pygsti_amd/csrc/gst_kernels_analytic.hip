@@ -228,9 +228,17 @@ constexpr int ANA_MFMA_WPS = GST_ANA_WPS;
 constexpr int ANA_STREAM_M = GST_ANA_STREAM_M;
 
 // WIDE: a state cache of 4 GB or more -- 64-bit per-lane byte offsets instead of 32-bit ones (AnaArgs::wide)
+#if GST_ANA_TIMING
+__device__ unsigned long long ana_dbg[16];     // development build only (tools/ana_phases.py): per-phase wavefront cycles
+#define AT_NOW() __builtin_amdgcn_s_memtime()
+#endif
 template <bool WIDE>
 __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const AnaArgs a)
 {
+#if GST_ANA_TIMING
+    unsigned long long at[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long at_start = AT_NOW();
+#endif
     constexpr int D = 16, NX = 4;
     using off_t = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
     const int lane = threadIdx.x & 63;
@@ -392,6 +400,9 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     for (int probe = 0;;) {
         int64_t ci;
+#if GST_ANA_TIMING
+        const unsigned long long t_f0 = AT_NOW();
+#endif
         if (a.group_fetch) {
             __syncthreads();                   // (everybody has read the previous group's s_fetch)
             if (threadIdx.x == 0) {
@@ -419,6 +430,10 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
             ci = (int64_t)r_begin + (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
             if (ci >= (int64_t)r_end) { probe++; continue; }
         }
+#if GST_ANA_TIMING
+        const unsigned long long t_f1 = AT_NOW();
+        at[0] += t_f1 - t_f0; at[9] += 1;
+#endif
         const int64_t c = as_const(a.circ_order)[ci];
         const int64_t c2 = a.circ_partner ? (int64_t)as_const(a.circ_partner)[ci] : -1;
         if (c2 >= 0) {
@@ -433,6 +448,10 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
             outcomes(x02, x02, NX, e_l2, dest_l2, e_u2, dest_u2);
             spam_columns(c, e_l, dest_l);
             spam_columns(c2, e_l2, dest_l2);
+#if GST_ANA_TIMING
+            const unsigned long long t_s1 = AT_NOW();
+            at[1] += t_s1 - t_f1;
+#endif
             if (a.blk_ptr) {
                 // The item as ONE stream of 4-slot blocks (host-built, AnaArgs::blk_*): the three-stage pipeline of `sweep`
                 // runs through all gates and segments of the item -- indices two blocks ahead, state vectors one block
@@ -481,6 +500,10 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                         }
                     }
                 };
+#if GST_ANA_TIMING
+                const unsigned long long t_l0 = AT_NOW();
+                at[4] += t_l0 - t_s1;
+#endif
                 Cur cur0 = seek(0);
                 zero_gates(0, cur0.g);
                 if (cur0.g < nG) {
@@ -508,6 +531,9 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                         }
                     };
                     auto mma = [&](const double (&F1)[SM], const double (&F2)[SM], const double (&Bv)[SM][NX], const bool (&ok1)[SM], const bool (&ok2)[SM]) {
+#if GST_ANA_TIMING
+                        at[7] += 1;
+#endif
 #pragma unroll
                         for (int m = 0; m < SM; m++) {
                             const double Fa = ok1[m] ? F1[m] : 0.0, Fb2 = ok2[m] ? F2[m] : 0.0;
@@ -520,12 +546,18 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                     };
                     auto flush_if_last = [&](const Cur& q, const Cur& next) {
                         if (q.pos + 1 != q.end) return;
+#if GST_ANA_TIMING
+                        const unsigned long long t_x0 = AT_NOW();
+#endif
                         const int32_t c0 = __builtin_amdgcn_readlane(c0_l, q.g);
                         store_block(q.g, c0, NX, dest_u, acc);
                         store_block(q.g, c0, NX, dest_u2, acc2);
 #pragma unroll
                         for (int x = 0; x < NX; x++) { acc[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; acc2[x] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
                         zero_gates(q.g + 1, next.g);          // (the gates between this one and the next block's)
+#if GST_ANA_TIMING
+                        at[3] += AT_NOW() - t_x0; at[8] += 1;
+#endif
                     };
                     Cur cur1 = advance(cur0), cur2 = advance(cur1);
                     int32_t f1A[SM], f2A[SM], rrA[SM], f1B[SM], f2B[SM], rrB[SM];
@@ -557,6 +589,9 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
                         if (cur0.g >= nG) break;
                     }
                 }
+#if GST_ANA_TIMING
+                at[2] += AT_NOW() - t_l0;      // (stream loop incl. the flushes: subtract at[3])
+#endif
                 continue;
             }
             for (int g = 0; g < nG; g++) {
@@ -661,6 +696,11 @@ __global__ __launch_bounds__(256, ANA_MFMA_WPS) void analytic_mfma_kernel(const 
             }
         }
     }
+#if GST_ANA_TIMING
+    at[5] = AT_NOW() - at_start;
+    if (lane == 0)
+        for (int q = 0; q < 10; q++) atomicAdd(&ana_dbg[q], at[q]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -998,4 +1038,11 @@ hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
+#if GST_ANA_TIMING
+extern "C" int gst_debug_ana_phases(unsigned long long* out, int reset)
+{
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(ana_dbg), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ana_dbg), 16 * sizeof(unsigned long long));
+}
+#endif
 }  // namespace gst
