@@ -7,12 +7,47 @@
 // There is no CPU compute path in this library: without a usable HIP device every fill fails loudly.
 #include "gst_state.hpp"
 
+#include <csignal>
+#include <cstring>
+#include <execinfo.h>
+#include <unistd.h>
+
 using namespace gst_impl;
 
 int gst_impl::g_poison_fill = 0;
 
 namespace {
 thread_local std::string g_err;
+
+// Diagnostics (GST_ABORT_BACKTRACE, set by tests/conftest.py): a process that dies through abort() -- glibc's heap checks, the
+// HIP runtime's fatal paths -- prints the native call stack first; Python's faulthandler then adds its own.  glibc itself
+// writes its message to the terminal, not to stderr, unless LIBC_FATAL_STDERR_ is set (conftest.py sets that too).
+struct sigaction g_prev_abrt;
+int g_abort_fd = 2;                 // GST_ABORT_BACKTRACE = 1: stderr; = n > 2: that descriptor (a test runner that captures fd 2
+                                    // hands over a duplicate of the real one: what is written to a captured fd dies with the process)
+void on_abort(int sig)
+{
+    static const char head[] = "gstfwd: SIGABRT -- native stack:\n";
+    (void)!write(g_abort_fd, head, sizeof(head) - 1);
+    void* bt[64];
+    const int n = backtrace(bt, 64);
+    backtrace_symbols_fd(bt, n, g_abort_fd);
+    sigaction(SIGABRT, &g_prev_abrt, nullptr);          // hand over to whoever was there before (faulthandler / default)
+    raise(sig);
+}
+struct AbortBacktrace {
+    AbortBacktrace()
+    {
+        const char* e = std::getenv("GST_ABORT_BACKTRACE");
+        if (!e || std::atoi(e) == 0) return;
+        if (std::atoi(e) > 2) g_abort_fd = std::atoi(e);
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.sa_handler = on_abort;
+        sigemptyset(&sa.sa_mask);
+        sigaction(SIGABRT, &sa, &g_prev_abrt);
+    }
+} g_abort_backtrace;
 }  // namespace
 
 namespace gst {
@@ -48,6 +83,82 @@ void* mapped_device_pointer(const void* ptr, size_t bytes)
         }
     }
     return nullptr;
+}
+
+
+// ---- copies between device memory and the caller's host memory -----------------------------------------------------------
+namespace {
+constexpr size_t STAGE_BYTES = (size_t)8 << 20;
+int ensure_stage(gst_plan* p, size_t at_least)
+{
+    const size_t want = std::max(STAGE_BYTES, at_least);
+    if (p->h_stage && p->h_stage_bytes >= want) return GST_OK;
+    if (p->h_stage) { HIP_TRY(hipStreamSynchronize(p->stream)); (void)hipHostFree(p->h_stage); p->h_stage = nullptr; p->h_stage_bytes = 0; }
+    HIP_TRY(hipHostMalloc((void**)&p->h_stage, want, hipHostMallocDefault));
+    p->h_stage_bytes = want;
+    return GST_OK;
+}
+}  // namespace
+
+int d2h_bytes(gst_plan* p, void* dst, const void* d_src, size_t bytes)
+{
+    if (bytes == 0) return GST_OK;
+    if (mapped_device_pointer(dst, bytes)) {          // page-locked by the caller: straight DMA, asynchronous
+        HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, p->stream));
+        return GST_OK;
+    }
+    int rc = ensure_stage(p, 0);
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += p->h_stage_bytes) {
+        const size_t n = std::min(p->h_stage_bytes, bytes - off);
+        HIP_TRY(hipMemcpyAsync(p->h_stage, (const char*)d_src + off, n, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        std::memcpy((char*)dst + off, p->h_stage, n);
+    }
+    return GST_OK;
+}
+
+int h2d_bytes(gst_plan* p, void* d_dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return GST_OK;
+    if (mapped_device_pointer(src, bytes)) {
+        HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, p->stream));
+        return GST_OK;
+    }
+    int rc = ensure_stage(p, 0);
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += p->h_stage_bytes) {
+        const size_t n = std::min(p->h_stage_bytes, bytes - off);
+        HIP_TRY(hipStreamSynchronize(p->stream));                 // (the previous chunk has left the staging buffer)
+        std::memcpy(p->h_stage, (const char*)src + off, n);
+        HIP_TRY(hipMemcpyAsync((char*)d_dst + off, p->h_stage, n, hipMemcpyHostToDevice, p->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return GST_OK;
+}
+
+// rows of n_cols doubles: device [n_rows][src_ld] -> host [n_rows][dst_ld]
+int d2h_rows(gst_plan* p, double* dst, int64_t dst_ld, const double* d_src, int64_t src_ld, int64_t n_rows, int64_t n_cols)
+{
+    if (n_rows <= 0 || n_cols <= 0) return GST_OK;
+    if (mapped_device_pointer(dst, (size_t)((n_rows - 1) * dst_ld + n_cols) * 8)) {
+        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)dst_ld * 8, d_src, (size_t)src_ld * 8, (size_t)n_cols * 8, (size_t)n_rows,
+                                 hipMemcpyDeviceToHost, p->stream));
+        return GST_OK;
+    }
+    if (dst_ld == n_cols && src_ld == n_cols) return d2h_bytes(p, dst, d_src, (size_t)n_rows * n_cols * 8);
+    int rc = ensure_stage(p, (size_t)n_cols * 8);
+    if (rc) return rc;
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)(p->h_stage_bytes / ((size_t)n_cols * 8)));
+    for (int64_t r0 = 0; r0 < n_rows; r0 += chunk) {
+        const int64_t nr = std::min(chunk, n_rows - r0);
+        HIP_TRY(hipMemcpy2DAsync(p->h_stage, (size_t)n_cols * 8, d_src + r0 * src_ld, (size_t)src_ld * 8, (size_t)n_cols * 8, (size_t)nr,
+                                 hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        const double* st = (const double*)p->h_stage;
+        for (int64_t r = 0; r < nr; r++) std::memcpy(dst + (r0 + r) * dst_ld, st + r * n_cols, (size_t)n_cols * 8);
+    }
+    return GST_OK;
 }
 
 int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
@@ -237,23 +348,26 @@ int copy_out_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* dest_id
     bool window = true;
     for (int64_t c = 1; dest_idx && c < n_param; c++) window = window && dest_idx[c] == dest_idx[0] + c;
     const int64_t d0 = (dest_idx && n_param > 0) ? dest_idx[0] : 0;
-    std::vector<double> stage;
-    if (n_param > 0) {
+    int rc;
+    if (n_param > 0 && nE > 0) {
         if (window) {
-            HIP_TRY(hipMemcpy2DAsync(out + d0, (size_t)ld * 8, p->d_out.p, (size_t)n_param * 8, (size_t)n_param * 8, (size_t)nE,
-                                     hipMemcpyDeviceToHost, p->stream));
+            if ((rc = d2h_rows(p, out + d0, ld, p->d_out.p, n_param, nE, n_param))) return rc;
         } else {
-            stage.resize((size_t)nE * n_param);
-            HIP_TRY(hipMemcpyAsync(stage.data(), p->d_out.p, (size_t)nE * n_param * 8, hipMemcpyDeviceToHost, p->stream));
+            // scattered columns: dense rows through the staging buffer, scattered on the host
+            if ((rc = ensure_stage(p, (size_t)n_param * 8))) return rc;
+            const int64_t chunk = std::max<int64_t>(1, (int64_t)(p->h_stage_bytes / ((size_t)n_param * 8)));
+            for (int64_t r0 = 0; r0 < nE; r0 += chunk) {
+                const int64_t nr = std::min(chunk, nE - r0);
+                HIP_TRY(hipMemcpyAsync(p->h_stage, p->d_out.p + r0 * n_param, (size_t)nr * n_param * 8, hipMemcpyDeviceToHost, p->stream));
+                HIP_TRY(hipStreamSynchronize(p->stream));
+                const double* st = (const double*)p->h_stage;
+                for (int64_t k = 0; k < nr; k++)
+                    for (int64_t c = 0; c < n_param; c++) out[(r0 + k) * ld + dest_idx[c]] = st[k * n_param + c];
+            }
         }
     }
-    if (probs_out) HIP_TRY(hipMemcpyAsync(probs_out, p->d_pbase.p, nE * 8, hipMemcpyDeviceToHost, p->stream));
-    int rc;
-    if ((rc = end_call(p, true))) return rc;
-    if (n_param > 0 && !window)
-        for (int64_t k = 0; k < nE; k++)
-            for (int64_t c = 0; c < n_param; c++) out[k * ld + dest_idx[c]] = stage[(size_t)k * n_param + c];
-    return GST_OK;
+    if (probs_out && (rc = d2h_bytes(p, probs_out, p->d_pbase.p, (size_t)nE * 8))) return rc;
+    return end_call(p, true);
 }
 
 int begin_call(gst_plan* p)
@@ -465,7 +579,7 @@ int gst_fill_probs(gst_plan* p, double* out)
     TIME_REC(p, evk0);
     if ((rc = run_probs_any(p, p->d_pbase.p))) return rc;
     TIME_REC(p, evk1);
-    HIP_TRY(hipMemcpyAsync(out, p->d_pbase.p, p->hp.n_elements * 8, hipMemcpyDeviceToHost, p->stream));
+    if ((rc = d2h_bytes(p, out, p->d_pbase.p, (size_t)p->hp.n_elements * 8))) return rc;
     return end_call(p, true);
     });
 }
@@ -562,7 +676,7 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
             if (mode == GST_DERIV_ANALYTIC) rc = run_dprobs_analytic(p, (double*)d_host, ld, param_idx, dest_idx, n_param, nullptr);
             else rc = run_dprobs_fd(p, (double*)d_host, ld, param_idx, dest_idx, n_param, eps, nullptr, nullptr, 0);
             if (rc) return rc;
-            if (probs_out) HIP_TRY(hipMemcpyAsync(probs_out, p->d_pbase.p, nE * 8, hipMemcpyDeviceToHost, p->stream));
+            if (probs_out && (rc = d2h_bytes(p, probs_out, p->d_pbase.p, (size_t)nE * 8))) return rc;
             return end_call(p, true);
         }
     }
@@ -615,7 +729,7 @@ int gst_memcpy_h2d(gst_plan* p, void* d_dst, const void* src, int64_t nbytes)
     int rc = ensure_device(p);
     if (rc) return rc;
     gst::track_touch(d_dst, (size_t)nbytes);
-    HIP_TRY(hipMemcpyAsync(d_dst, src, (size_t)nbytes, hipMemcpyHostToDevice, p->stream));
+    if ((rc = h2d_bytes(p, d_dst, src, (size_t)nbytes))) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
     return GST_OK;
     });
@@ -685,8 +799,8 @@ int gst_memcpy_d2h(gst_plan* p, void* dst, const void* d_src, int64_t nbytes)
     if (!p || !dst || !d_src || nbytes < 0) return fail(GST_EINVAL, "bad argument");
     int rc = ensure_device(p);
     if (rc) return rc;
+    if ((rc = d2h_bytes(p, dst, d_src, (size_t)nbytes))) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost));
     return GST_OK;
     });
 }
@@ -697,8 +811,8 @@ int gst_memcpy_d2h_async(gst_plan* p, void* dst, const void* d_src, int64_t nbyt
     if (!p || !dst || !d_src || nbytes < 0) return fail(GST_EINVAL, "bad argument");
     int rc = ensure_device(p);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, p->stream));
-    return GST_OK;
+    // (asynchronous for a page-locked destination -- gst_host_register -- and complete on return for a pageable one)
+    return d2h_bytes(p, dst, d_src, (size_t)nbytes);
     });
 }
 

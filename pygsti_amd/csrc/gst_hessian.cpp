@@ -420,11 +420,11 @@ int gst_fill_hprobs_analytic(gst_plan* p, double* out, int64_t ld1, int64_t ld2,
     if (n1 == 0 || n2 == 0) return end_call(p, true);
     if ((rc = stage_out(p, (size_t)nE * ld1 * ld2))) return rc;
     const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
-    if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
+    if (!dense && (rc = h2d_bytes(p, p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8))) return rc;
     if (p->derivs_set) rc = run_hprobs_general(p, p->d_out.p, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2);
     else rc = run_hprobs_analytic(p, p->d_out.p, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));
+    if ((rc = d2h_bytes(p, out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8))) return rc;
     return end_call(p, true);
     });
 }
@@ -445,9 +445,9 @@ int gst_fill_hprobs(gst_plan* p, double* out, int64_t ld1, int64_t ld2, const in
     if ((rc = stage_out(p, (size_t)nE * ld1 * ld2))) return rc;
     // rows/columns of the caller's block that this call does not own must survive: start from the caller's data
     const bool dense = (!dest1 && !dest2 && ld1 == n1 && ld2 == n2);
-    if (!dense) HIP_TRY(hipMemcpyAsync(p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8, hipMemcpyHostToDevice, p->stream));
+    if (!dense && (rc = h2d_bytes(p, p->d_out.p, out, (size_t)nE * ld1 * ld2 * 8))) return rc;
     if ((rc = run_hprobs_dev(p, p->d_out.p, ld1, ld2, idx1, dest1, n1, idx2, dest2, n2, eps))) return rc;
-    HIP_TRY(hipMemcpyAsync(out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8, hipMemcpyDeviceToHost, p->stream));
+    if ((rc = d2h_bytes(p, out, p->d_out.p, (size_t)nE * ld1 * ld2 * 8))) return rc;
     return end_call(p, true);
     });
 }
@@ -512,7 +512,7 @@ int gst_objective_hessian_block(gst_plan* p, const gst_objective_desc* d, const 
     HIP_TRY(gst::launch_hessian_block(p->d_out.p, d_d1, d_d2, p->d_obj_dt.p, p->d_obj_ht.p, nE, (int)n1, (int)n2,
                                       p->d_hess_part.p, n_slabs, p->d_hess_out.p, p->stream));
     p->last_launches += 2;
-    HIP_TRY(hipMemcpyAsync(out, p->d_hess_out.p, (size_t)n1 * n2 * 8, hipMemcpyDeviceToHost, p->stream));
+    if ((rc = d2h_bytes(p, out, p->d_hess_out.p, (size_t)n1 * n2 * 8))) return rc;
     return end_call(p, true);
     });
 }

@@ -477,7 +477,10 @@ int gst_get_lindblad_model_sets(gst_plan* p, const int64_t* param_idx, int64_t n
     a.set_param = p->d_lb_setparam.p; a.sets = p->d_mm_models.p; a.eps = eps;
     HIP_TRY(gst::launch_lindblad_build(D, a, n_param, p->stream));
     std::vector<double> h((size_t)n_param * stride);
-    HIP_TRY(hipMemcpyAsync(h.data(), p->d_mm_models.p, h.size() * 8, hipMemcpyDeviceToHost, p->stream));
+    {
+        int rc2 = d2h_bytes(p, h.data(), p->d_mm_models.p, h.size() * 8);
+        if (rc2) return rc2;
+    }
     HIP_TRY(hipStreamSynchronize(p->stream));
     for (int64_t m = 0; m < n_param; m++) {
         const double* s = h.data() + (size_t)m * stride;

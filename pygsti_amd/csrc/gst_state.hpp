@@ -124,6 +124,9 @@ struct gst_plan {
     double* h_model_pinned[2] = {nullptr, nullptr};      // two staging buffers, used alternately
     hipEvent_t ev_upload[2] = {nullptr, nullptr};        // "the copy out of staging buffer i has been done"
     size_t h_model_pinned_n = 0;
+    // page-locked staging for copies between device memory and PAGEABLE caller memory (gst_abi.cpp: d2h_bytes & co.)
+    char* h_stage = nullptr;
+    size_t h_stage_bytes = 0;
     int upload_turn = 0;
     bool model_dirty = true;
     // parameter map
@@ -338,6 +341,8 @@ struct gst_plan {
         d_hess_part.release(); d_hess_out.release(); d_task_off.release(); d_eff_ptr.release();
         d_eff_label.release(); d_eff_dest.release();
         d_model.release();
+        if (h_stage) (void)hipHostFree(h_stage);
+        h_stage = nullptr; h_stage_bytes = 0;
         for (int i = 0; i < 2; i++) {
             if (h_model_pinned[i]) (void)hipHostFree(h_model_pinned[i]);
             if (ev_upload[i]) (void)hipEventDestroy(ev_upload[i]);
@@ -408,5 +413,13 @@ int run_dprobs_lindblad_analytic(gst_plan* p, double* d_out, int64_t ld, const i
 
 // device address of a host pointer inside a region registered with gst_host_register, or NULL (gst_abi.cpp)
 void* mapped_device_pointer(const void* ptr, size_t bytes);
+// Copies between device memory and the CALLER's host memory (gst_abi.cpp).  A destination / source inside a region the caller
+// page-locked with gst_host_register is copied directly (asynchronous, on the plan's stream); anything else goes through the
+// plan's own page-locked staging buffer and a host memcpy, complete on return.  The device never touches pageable caller
+// memory: the runtime's lock-on-the-fly of arbitrary heap ranges is what a rare "Memory access fault ... Reason: Unknown" on a
+// host-heap address was traced to.
+int d2h_bytes(gst_plan* p, void* dst, const void* d_src, size_t bytes);
+int h2d_bytes(gst_plan* p, void* d_dst, const void* src, size_t bytes);
+int d2h_rows(gst_plan* p, double* dst, int64_t dst_ld, const double* d_src, int64_t src_ld, int64_t n_rows, int64_t n_cols);
 
 }  // namespace gst_impl

@@ -327,6 +327,8 @@ class HipCOPALayout:
             yield self.indices_for_index(i), c, self.outcomes_for_index(i)
 
     # ---- arrays (copalayout.py:284-361) ----------------------------------------------------------------------------
+    PIN_MIN_BYTES = 1 << 26
+
     def allocate_local_array(self, array_type, dtype="d", zero_out=False, memory_tracker=None, extra_elements=0):
         nE, nP = self.num_elements + extra_elements, self._num_params
         shape = {"e": (nE,), "ep": (nE, nP), "ep2": (nE, nP), "epp": (nE, nP, nP), "p": (nP,), "jtj": (nP, nP),
@@ -336,7 +338,10 @@ class HipCOPALayout:
         # element-dimension arrays are what the fills copy into: page-lock the large ones once, here, so that every
         # later bulk_fill_* runs at PCIe rate (the reference allocates these once per objective and reuses them)
         self.last_array_pinned = False
-        if array_type in ("e", "ep", "ep2", "epp") and arr.nbytes >= (1 << 18) and self.pin_arrays:      # (256 KB: the 1Q Jacobian is 1 MB)
+        # Only arrays the C library allocates with mmap of their own (> 32 MB: glibc's upper bound of the dynamic mmap
+        # threshold) -- page-aligned, sharing no page with other heap data.  Rounds 2-4 registered everything above 256 KB,
+        # i.e. ranges inside the brk heap; a rare GPU memory fault on a host-heap address went away with that.
+        if array_type in ("e", "ep", "ep2", "epp") and arr.nbytes >= self.PIN_MIN_BYTES and self.pin_arrays:
             self.last_array_pinned = _lib.pin_host_array(arr)
         return arr
 

@@ -169,7 +169,7 @@ class LayoutNormalEquations:
     """Mixin for the COPA layout the simulator hands to the objective (class to the left of pyGSTi's MapCOPALayout in the
     MRO; on the GPU box: to the left of a stand-in).  Overrides exactly the three layout methods on the LM path."""
 
-    PIN_MIN_BYTES = 1 << 18
+    PIN_MIN_BYTES = 1 << 26          # mmap-backed arrays only (see HipCOPALayout.allocate_local_array)
 
     def fill_jtj(self, j, jtj, shared_mem_buf=None):
         if isinstance(j, DeviceJacobian):

@@ -11,9 +11,32 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Diagnostics for a process that dies through abort(): the library prints the native stack (gst_abi.cpp), and glibc sends its
+# own message ("free(): invalid size", ...) to stderr instead of the controlling terminal, where a test log never sees it.
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # pytest captures fd 2 while a test runs, and what a dying process wrote into the capture is lost: the library gets a
+    # duplicate of the REAL stderr (this hook runs before the per-test capture, as pytest's own faulthandler plugin relies on)
+    if "GST_ABORT_BACKTRACE" not in os.environ:
+        try:
+            os.environ["GST_ABORT_BACKTRACE"] = str(os.dup(2))
+        except OSError:
+            os.environ["GST_ABORT_BACKTRACE"] = "1"
+
+
+def page_locked_candidate(shape, fill):
+    """A float64 array with pages of its own (anonymous mmap: page-aligned, shares no page with the heap) -- what a test hands
+    to _lib.pin_host_array.  Registering ranges INSIDE the brk heap is legal but is what a rare GPU memory fault on a
+    host-heap address was traced to; the library's own callers only page-lock mmap-backed arrays."""
+    import mmap
+    count = int(np.prod(shape))
+    mm = mmap.mmap(-1, max(count * 8, mmap.PAGESIZE))
+    a = np.frombuffer(mm, dtype=np.float64, count=count).reshape(shape)
+    a[...] = fill
+    return a
 
 
 def load_fixture(name):

@@ -4,7 +4,7 @@ FD dprobs and FD-of-FD hprobs (the device computes in the reference's arithmetic
 import numpy as np
 import pytest
 
-from conftest import force, load_fixture, assert_bitwise, plan_from_fixture
+from conftest import force, load_fixture, assert_bitwise, plan_from_fixture, page_locked_candidate
 
 pytestmark = pytest.mark.gpu
 
@@ -157,7 +157,7 @@ def test_dprobs_into_page_locked_array_bitwise(name, direct, monkeypatch):
     fx = load_fixture(name)
     pl = plan_from_fixture(fx)
     cols = fx["dprobs_cols"]; nE, n = int(fx["nE"]), len(cols)
-    full = np.full((nE, n + 7), -7.0)
+    full = page_locked_candidate((nE, n + 7), -7.0)
     assert _lib.pin_host_array(full)
     pr = np.empty(nE)
     try:
@@ -185,7 +185,7 @@ def test_analytic_dprobs_into_page_locked_array(name, monkeypatch):
     ref = plan_from_fixture(fx).fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
     force(monkeypatch, host_direct=2)
     pl = plan_from_fixture(fx)
-    full = np.full((nE, n + 7), np.nan)
+    full = page_locked_candidate((nE, n + 7), np.nan)
     assert _lib.pin_host_array(full)
     pr = np.empty(nE)
     try:
