@@ -549,7 +549,8 @@ int gst_device_touch(gst_plan *plan, void *d_ptr, int64_t nbytes);
 int gst_memcpy_d2h(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
 /* The same copy enqueued on the plan's stream without waiting for it (gst_sync completes it): lets one process drain
  * the plans of several GPUs side by side -- with a page-locked destination (gst_host_register) the copies of different
- * devices overlap; a pageable one makes the call synchronous, which is still correct. */
+ * devices overlap; a pageable one makes the call synchronous (the library copies through its own page-locked staging
+ * buffer: the device never touches pageable caller memory), which is still correct. */
 int gst_memcpy_d2h_async(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
 
 /* Page-lock a caller-owned host array (hipHostRegister, portable across devices) so that the host-output fills

@@ -196,7 +196,9 @@ def _ptr(a):
 def pin_host_array(arr):
     """Page-lock a C-contiguous numpy array for full-rate PCIe copies (gst_host_register); the lock is released when
     the array is garbage-collected or through `unpin_host_array`.  Returns True when pinned, False when no device
-    exists (the array then stays pageable -- fills still work where a device is)."""
+    exists (the array then stays pageable -- fills still work where a device is).  Meant for arrays with pages of their own
+    (numpy serves >= 64 MB by an mmap per array; the library's own callers page-lock nothing smaller): a range inside the
+    brk heap shares its first and last page with other allocations."""
     import weakref
     if not arr.flags.c_contiguous or arr.nbytes == 0:
         return False
