@@ -327,23 +327,34 @@ class HipCOPALayout:
             yield self.indices_for_index(i), c, self.outcomes_for_index(i)
 
     # ---- arrays (copalayout.py:284-361) ----------------------------------------------------------------------------
-    PIN_MIN_BYTES = 1 << 26
+    PIN_MIN_BYTES = 1 << 18          # (256 KB: the 1Q Jacobian is 1 MB)
+
+    @staticmethod
+    def _own_pages_array(shape, dtype):
+        """A zero-filled array on pages of its own (anonymous mmap: page-aligned, shares no page with the heap) -- what may be
+        handed to gst_host_register.  numpy itself serves arrays below 32 MB from the brk heap, where a registered range
+        shares its first and last page with other allocations (the GPU fault on a host-heap address)."""
+        import mmap
+        dt = np.dtype(dtype)
+        count = int(np.prod(shape, dtype=np.int64))
+        mm = mmap.mmap(-1, max(count * dt.itemsize, mmap.PAGESIZE))
+        return np.frombuffer(mm, dtype=dt, count=count).reshape(shape)
 
     def allocate_local_array(self, array_type, dtype="d", zero_out=False, memory_tracker=None, extra_elements=0):
         nE, nP = self.num_elements + extra_elements, self._num_params
         shape = {"e": (nE,), "ep": (nE, nP), "ep2": (nE, nP), "epp": (nE, nP, nP), "p": (nP,), "jtj": (nP, nP),
                  "jtf": (nP,), "c": (self.num_circuits,), "cp": (self.num_circuits, nP),
                  "cp2": (self.num_circuits, nP), "cpp": (self.num_circuits, nP, nP)}[array_type]
-        arr = np.zeros(shape, dtype) if zero_out else np.empty(shape, dtype)
         # element-dimension arrays are what the fills copy into: page-lock the large ones once, here, so that every
-        # later bulk_fill_* runs at PCIe rate (the reference allocates these once per objective and reuses them)
+        # later bulk_fill_* runs at PCIe rate (the reference allocates these once per objective and reuses them) -- on
+        # pages of their own
         self.last_array_pinned = False
-        # Only arrays the C library allocates with mmap of their own (> 32 MB: glibc's upper bound of the dynamic mmap
-        # threshold) -- page-aligned, sharing no page with other heap data.  Rounds 2-4 registered everything above 256 KB,
-        # i.e. ranges inside the brk heap; a rare GPU memory fault on a host-heap address went away with that.
-        if array_type in ("e", "ep", "ep2", "epp") and arr.nbytes >= self.PIN_MIN_BYTES and self.pin_arrays:
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        if array_type in ("e", "ep", "ep2", "epp") and nbytes >= self.PIN_MIN_BYTES and self.pin_arrays:
+            arr = self._own_pages_array(shape, dtype)
             self.last_array_pinned = _lib.pin_host_array(arr)
-        return arr
+            return arr
+        return np.zeros(shape, dtype) if zero_out else np.empty(shape, dtype)
 
     def free_local_array(self, local_array):
         if isinstance(local_array, np.ndarray):

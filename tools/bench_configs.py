@@ -76,7 +76,7 @@ def one_q():
     t_an = timed(lambda: plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_ANALYTIC), plan, 200)
     st = plan.stats()
     # one blocking fill at a time (what a caller that needs the result sees), host arrays included
-    J = layout.allocate_local_array("ep"); pr = layout.allocate_local_array("e")     # (what bulk_fill_dprobs(array, layout) is handed: page-locked from 256 KB)
+    J = layout.allocate_local_array("ep"); pr = layout.allocate_local_array("e")     # (what bulk_fill_dprobs(array, layout) is handed: page-locked from 256 KB, on pages of its own)
     def lat(fn, reps=200):
         fn()
         t0 = time.perf_counter()
