@@ -558,6 +558,10 @@ int gst_memcpy_d2h_async(gst_plan *plan, void *dst, const void *d_src, int64_t n
  * pageable staging -- the counterpart of the reference allocating its 'ep' arrays once per objective
  * (layout.allocate_local_array, pygsti/layouts/copalayout.py:284-361) and reusing them every iteration.  Unregister before
  * the memory is freed.  Both fail with GST_ENODEVICE when no device exists (the array then simply stays pageable).
+ * Register memory that owns its pages (an mmap of its own, whole aligned pages; numpy gives such memory to arrays of
+ * >= 32 MB): a range inside the malloc heap shares its first and last page with unrelated allocations, and registering /
+ * unregistering such ranges over and over is what a rare GPU memory fault on a host-heap address was traced to.
+ * A host destination that is NOT registered is filled through the library's own page-locked staging buffer.
  * The region is also mapped into the device's address space: a finite-difference gst_fill_dprobs whose destination lies
  * inside it (requests of >= 64 columns) has its kernel write the Jacobian straight into the host array (512-byte row segments over PCIe while the
  * walk is still computing; no HBM staging of the result), honouring (ld, dest_idx) as always. */

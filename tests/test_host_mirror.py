@@ -454,3 +454,24 @@ def test_column_exchange_blocks_assemble_whole_rows(grid, n_atoms):
         for a0, spans in covered.items():
             spans.sort()
             assert spans[0][0] == a0 and all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+
+
+def test_page_locked_candidates_own_their_pages():
+    """Arrays that allocate_local_array may hand to gst_host_register come from an anonymous mmap: page-aligned, zero-filled,
+    writable, sharing no page with the heap; small arrays and parameter-dimension arrays stay plain numpy.  (No
+    device here: the registration itself reports False and the array is simply pageable.)"""
+    import mmap
+    pack = MP.smq1Q_XYI
+    model = pack.target_model()
+    lay = HipCOPALayout(pack.create_gst_circuits(128), model)
+    J = lay.allocate_local_array("ep")
+    assert J.shape == (lay.num_elements, model.num_params) and J.nbytes >= HipCOPALayout.PIN_MIN_BYTES
+    assert J.ctypes.data % mmap.PAGESIZE == 0 and J.flags.c_contiguous and J.flags.writeable and not J.any()
+    assert lay.last_array_pinned is False
+    J[3, 5] = 2.0; v = J[2:5, :]
+    lay.free_local_array(J); del J
+    assert v[1, 5] == 2.0                                   # a view keeps the mapping alive
+    small = lay.allocate_local_array("jtf")
+    assert small.shape == (model.num_params,) and small.base is None
+    lay.pin_arrays = False
+    assert lay.allocate_local_array("ep").base is None      # pinning switched off: plain numpy
