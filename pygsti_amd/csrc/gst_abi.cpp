@@ -23,7 +23,7 @@ thread_local std::string g_err;
 // HIP runtime's fatal paths -- prints the native call stack first; Python's faulthandler then adds its own.  glibc itself
 // writes its message to the terminal, not to stderr, unless LIBC_FATAL_STDERR_ is set (conftest.py sets that too).
 struct sigaction g_prev_abrt;
-int g_abort_fd = 2;                 // GST_ABORT_BACKTRACE = 1: stderr; = n > 2: that descriptor (a test runner that captures fd 2
+int g_abort_fd = 2;                 // GST_ABORT_BACKTRACE = 1: stderr; = "n:pid", n > 2: that descriptor (a test runner that captures fd 2
                                     // hands over a duplicate of the real one: what is written to a captured fd dies with the process)
 void on_abort(int sig)
 {
@@ -40,7 +40,10 @@ struct AbortBacktrace {
     {
         const char* e = std::getenv("GST_ABORT_BACKTRACE");
         if (!e || std::atoi(e) == 0) return;
-        if (std::atoi(e) > 2) g_abort_fd = std::atoi(e);
+        // "fd:pid": the descriptor is meaningful in the process that duplicated it only (a spawned child inherits the variable,
+        // not the descriptor -- or worse, has the number in use for something else)
+        const char* colon = std::strchr(e, ':');
+        if (std::atoi(e) > 2 && colon && std::atol(colon + 1) == (long)getpid()) g_abort_fd = std::atoi(e);
         struct sigaction sa;
         std::memset(&sa, 0, sizeof(sa));
         sa.sa_handler = on_abort;

@@ -22,7 +22,7 @@ def pytest_configure(config):
     # duplicate of the REAL stderr (this hook runs before the per-test capture, as pytest's own faulthandler plugin relies on)
     if "GST_ABORT_BACKTRACE" not in os.environ:
         try:
-            os.environ["GST_ABORT_BACKTRACE"] = str(os.dup(2))
+            os.environ["GST_ABORT_BACKTRACE"] = "%d:%d" % (os.dup(2), os.getpid())
         except OSError:
             os.environ["GST_ABORT_BACKTRACE"] = "1"
 
