@@ -27,6 +27,10 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table
+ * (tests/test_abi_and_rules.py compares `nm -D` with this header, both ways). */
+#define GST_API __attribute__((visibility("default")))
+
 #define GST_OK 0
 #define GST_EINVAL (-1)     /* bad argument / inconsistent plan description */
 #define GST_ENODEVICE (-2)  /* no usable HIP device (the library never falls back to the CPU) */
@@ -129,7 +133,7 @@ typedef struct {
     int32_t last_zeros_resident;   /* 1: the last exact Jacobian fill did not re-store the destination's structural zeros */
 } gst_stats;
 
-int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *opt, gst_plan **out);
+GST_API int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *opt, gst_plan **out);
 
 /* Run-time options of a plan.
  *   GST_OPT_ANALYTIC_KEEP_ZEROS (value 0 / 1 / 2): the structural zeros of GST_DERIV_ANALYTIC Jacobians (D = 16).
@@ -167,18 +171,18 @@ int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *op
  *       difference them.  Finite-difference fills never use it. */
 #define GST_OPT_FAST_CHAINS 2
 #define GST_OPT_FAST_PROBS 3
-int gst_set_option(gst_plan *plan, int32_t option, int64_t value);
-int gst_plan_create_from_circuits(const gst_circuits_desc *desc, const gst_options *opt, gst_plan **out);
-int gst_plan_destroy(gst_plan *plan);
+GST_API int gst_set_option(gst_plan *plan, int32_t option, int64_t value);
+GST_API int gst_plan_create_from_circuits(const gst_circuits_desc *desc, const gst_options *opt, gst_plan **out);
+GST_API int gst_plan_destroy(gst_plan *plan);
 
 /* Dense model arrays (what the reference's reps borrow: OpRepDenseSuperop.base, StateRepDense.data,
  * EffectRepConjugatedState.state_rep.data; evotypes/densitymx/opreps.pyx:75-90), C-contiguous f64:
  * gates[n_gates][D][D], rhos[n_rhos][D], effects[n_effects][D].  Re-call after every
  * model.from_vector(); costs one small H2D copy. */
-int gst_set_model(gst_plan *plan, const double *gates, const double *rhos, const double *effects);
+GST_API int gst_set_model(gst_plan *plan, const double *gates, const double *rhos, const double *effects);
 
 /* Parameter p perturbs element `elem[p]` (flat, row-major) of object `obj[p]` of kind `kind[p]`. */
-int gst_set_param_map(gst_plan *plan, int32_t n_params, const int32_t *kind, const int32_t *obj,
+GST_API int gst_set_param_map(gst_plan *plan, int32_t n_params, const int32_t *kind, const int32_t *obj,
                       const int32_t *elem);
 
 /* "full TP" POVMs in the finite-difference modes.  The last effect of a TPPOVM is not parameterised: it is
@@ -192,7 +196,7 @@ int gst_set_param_map(gst_plan *plan, int32_t n_params, const int32_t *kind, con
  * from_vector / set_parameter_value do); no parameter may map to the complement itself; the GST_DERIV_ANALYTIC element
  * map returns GST_EUNSUPPORTED (use gst_set_derivs for exact derivatives of such models).  TPState / FullTPOp need nothing beyond gst_set_param_map: their parameters are
  * plain dense elements.  comp_index < 0 clears.  One complement per plan (one POVM per atom alphabet). */
-int gst_set_complement_effect(gst_plan *plan, int32_t comp_index, const double *identity, int32_t n_others,
+GST_API int gst_set_complement_effect(gst_plan *plan, int32_t comp_index, const double *identity, int32_t n_others,
                               const int32_t *others);
 
 /* General parameterisations (TP, CPTP, ... -- anything whose members answer deriv_wrt_params) in GST_DERIV_ANALYTIC:
@@ -205,7 +209,7 @@ int gst_set_complement_effect(gst_plan *plan, int32_t comp_index, const double *
  * for parameters 0 .. n_params-1 (the (kind,obj,elem) map of gst_set_param_map is not used in that mode; a parameter
  * may appear in several objects, e.g. a TP POVM's complement effect).  Re-call after gst_set_model whenever the
  * derivatives depend on the parameter values (non-linear parameterisations).  n_objs = 0 clears. */
-int gst_set_derivs(gst_plan *plan, int32_t n_params, int32_t n_objs, const int32_t *kind, const int32_t *obj,
+GST_API int gst_set_derivs(gst_plan *plan, int32_t n_params, int32_t n_objs, const int32_t *kind, const int32_t *obj,
                    const int32_t *n_cols, const int64_t *param_idx, const double *deriv);
 
 /* Lindblad-parameterised models (CPTPLND, GLND, H+S ...: what `target_model('CPTPLND')` and StandardGST's default modes
@@ -256,11 +260,11 @@ typedef struct {
     int64_t term_offset;         /* first of this member's terms in term_re / term_im */
     const double *static_part;
 } gst_lindblad_member;
-int gst_set_lindblad(gst_plan *plan, int32_t n_params, int32_t n_members, const gst_lindblad_member *members,
+GST_API int gst_set_lindblad(gst_plan *plan, int32_t n_params, int32_t n_members, const gst_lindblad_member *members,
                      int64_t n_terms, const double *term_re, const double *term_im);
-int gst_set_lindblad_params(gst_plan *plan, const double *theta);
+GST_API int gst_set_lindblad_params(gst_plan *plan, const double *theta);
 /* The plan's current dense model (row-major, the layout of gst_set_model); any pointer may be NULL. */
-int gst_get_model(gst_plan *plan, double *gates, double *rhos, double *effects);
+GST_API int gst_get_model(gst_plan *plan, double *gates, double *rhos, double *effects);
 
 /* Implicit models (pyGSTi's LocalNoiseModel / CloudNoiseModel, e.g. create_crosstalk_free_model): a circuit layer is not a
  * stored dense superoperator but a ComposedOp of EmbeddedOps -- small one- and two-qubit operations embedded into the
@@ -315,23 +319,23 @@ typedef struct gst_composite_desc {
     const int32_t *leaf_n_params;     /* [n_leaves]: > 0 for general leaves; NULL: none */
     const int64_t *leaf_param_list;   /* the general leaves' parameters, concatenated */
 } gst_composite_desc;
-int gst_set_composite(gst_plan *plan, int32_t n_params, const gst_composite_desc *desc);
-int gst_set_composite_values(gst_plan *plan, const double *leaf_values, const double *rhos, const double *effects);
-int gst_set_composite_general(gst_plan *plan, const double *leaf_derivs, const double *leaf_fd_values, double fd_eps);
+GST_API int gst_set_composite(gst_plan *plan, int32_t n_params, const gst_composite_desc *desc);
+GST_API int gst_set_composite_values(gst_plan *plan, const double *leaf_values, const double *rhos, const double *effects);
+GST_API int gst_set_composite_general(gst_plan *plan, const double *leaf_derivs, const double *leaf_fd_values, double fd_eps);
 /* The dense models the device builds for the finite-difference steps of parameters param_idx (theta_p + eps each):
  * gates[n][n_gates][D][D], rhos[n][n_rhos][D], effects[n][n_effects][D] (host; tests compare them with the reference's). */
-int gst_get_lindblad_model_sets(gst_plan *plan, const int64_t *param_idx, int64_t n_param, double eps, double *gates,
+GST_API int gst_get_lindblad_model_sets(gst_plan *plan, const int64_t *param_idx, int64_t n_param, double eps, double *gates,
                                 double *rhos, double *effects);
 
 /* probs: out[n_elements] (host). */
-int gst_fill_probs(gst_plan *plan, double *out);
+GST_API int gst_fill_probs(gst_plan *plan, double *out);
 
 /* dprobs: out[k*ld + dest_idx[c]] = d p_k / d theta_{param_idx[c]} for c < n_param (host, row-major,
  * leading dimension ld so that a column window of an 'ep' array can be filled in place).
  * dest_idx == NULL means dest c.  probs_out (may be NULL) receives the probabilities, as
  * bulk_fill_dprobs(pr_array_to_fill=...) does.  mode/eps: GST_DERIV_FD with the simulator's
  * derivative_eps (1e-7 in the reference, mapforwardsim.py:166-172). */
-int gst_fill_dprobs(gst_plan *plan, double *out, int64_t ld, const int64_t *param_idx,
+GST_API int gst_fill_dprobs(gst_plan *plan, double *out, int64_t ld, const int64_t *param_idx,
                     const int64_t *dest_idx, int64_t n_param, int mode, double eps, double *probs_out);
 
 /* Finite-difference Jacobian columns for ANY parameterisation (CPTPLND, composed / embedded / exponentiated members,
@@ -348,11 +352,11 @@ int gst_fill_dprobs(gst_plan *plan, double *out, int64_t ld, const int64_t *para
  * Accuracy: the reference propagates non-dense members (ComposedOp / ExpErrorgenOp reps, opcreps.cpp:242-524) factor by
  * factor, this path through their dense product, so probabilities agree to rounding (~1e-16) and the quotients to
  * ~1e-16 / eps, not bit for bit. */
-int gst_fill_dprobs_models(gst_plan *plan, int64_t n_models, const double *gates, const double *rhos,
+GST_API int gst_fill_dprobs_models(gst_plan *plan, int64_t n_models, const double *gates, const double *rhos,
                            const double *effects, double *out, int64_t ld, const int64_t *dest_idx, double eps,
                            double *probs_out);
 /* device-resident output (d_out, d_probs_out on the plan's device); the model sets are still host arrays */
-int gst_fill_dprobs_models_dev(gst_plan *plan, int64_t n_models, const double *gates, const double *rhos,
+GST_API int gst_fill_dprobs_models_dev(gst_plan *plan, int64_t n_models, const double *gates, const double *rhos,
                                const double *effects, double *d_out, int64_t ld, const int64_t *dest_idx, double eps,
                                double *d_probs_out);
 
@@ -363,12 +367,12 @@ int gst_fill_dprobs_models_dev(gst_plan *plan, int64_t n_models, const double *g
  * tensor; hess holds them concatenated, each row-major [n_elem][n_cols[o]][n_cols[o]].  While set,
  * gst_fill_hprobs_analytic / gst_objective_hessian_block(analytic) add  sum_a (d p / d elem_a) d^2 elem_a / d p1 d p2.
  * Cleared by gst_set_derivs (call it first); n_objs = 0 clears. */
-int gst_set_second_derivs(gst_plan *plan, int32_t n_objs, const int32_t *nonzero, const double *hess);
+GST_API int gst_set_second_derivs(gst_plan *plan, int32_t n_objs, const int32_t *nonzero, const double *hess);
 
 /* hprobs block: out[(k*ld1 + dest1[a])*ld2 + dest2[b]] = d2 p_k / d theta_{idx1[a]} d theta_{idx2[b]}
  * by finite differences of finite differences with step eps, bit-for-bit
  * MapForwardSimulator._mapfill_hprobs_atom (mapforwardsim.py:394-438). */
-int gst_fill_hprobs(gst_plan *plan, double *out, int64_t ld1, int64_t ld2,
+GST_API int gst_fill_hprobs(gst_plan *plan, double *out, int64_t ld1, int64_t ld2,
                     const int64_t *idx1, const int64_t *dest1, int64_t n1,
                     const int64_t *idx2, const int64_t *dest2, int64_t n2, double eps);
 
@@ -380,16 +384,16 @@ int gst_fill_hprobs(gst_plan *plan, double *out, int64_t ld1, int64_t ld2,
  * LINEAR in their parameters (TP: has_nonzero_hessian() is False for every member): the element Hessian of the elements
  * the requested parameters touch, contracted with the derivative columns on both sides.  Members with second
  * derivatives (CPTPLND, ...) additionally need gst_set_second_derivs (the J_elem . hessian_wrt_params term). */
-int gst_fill_hprobs_analytic(gst_plan *plan, double *out, int64_t ld1, int64_t ld2, const int64_t *idx1,
+GST_API int gst_fill_hprobs_analytic(gst_plan *plan, double *out, int64_t ld1, int64_t ld2, const int64_t *idx1,
                              const int64_t *dest1, int64_t n1, const int64_t *idx2, const int64_t *dest2, int64_t n2);
 
 /* Device-resident variants: `d_out` / `d_probs_out` are device pointers on the plan's device
  * (e.g. a buffer the caller shares with RCCL).  Asynchronous on the plan's stream. */
-int gst_fill_probs_dev(gst_plan *plan, double *d_out);
-int gst_fill_dprobs_dev(gst_plan *plan, double *d_out, int64_t ld, const int64_t *param_idx,
+GST_API int gst_fill_probs_dev(gst_plan *plan, double *d_out);
+GST_API int gst_fill_dprobs_dev(gst_plan *plan, double *d_out, int64_t ld, const int64_t *param_idx,
                         const int64_t *dest_idx, int64_t n_param, int mode, double eps,
                         double *d_probs_out);
-int gst_sync(gst_plan *plan);
+GST_API int gst_sync(gst_plan *plan);
 
 /* Normal equations of the least-squares fit on the device ("next" row f1 of SURVEY 8(f); the reference does this
  * on the host after the Jacobian has been scaled by the objective's dterms: layout.fill_jtj / fill_jtf,
@@ -405,9 +409,9 @@ int gst_sync(gst_plan *plan);
  *   gst_fill_jtf_dev: d_jtf[n_cols] = d_J^T f,  f = d_f[n_rows]   (= J_s^T f after a scaled gst_fill_jtj_dev)
  * With several ranks each computes the partial sums of its own rows; gst_comm_allreduce_sum (RCCL) adds the
  * n_cols^2 doubles on the device. */
-int gst_fill_jtj_dev(gst_plan *plan, double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
+GST_API int gst_fill_jtj_dev(gst_plan *plan, double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
                      const double *d_row_scale, double *d_jtj);
-int gst_fill_jtf_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
+GST_API int gst_fill_jtf_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
                      const double *d_f, double *d_jtf);
 /* The same normal equations WITHOUT touching d_J (round 5): d_jtj = (diag(w) J)^T (diag(w) J) and d_jtf =
  * (diag(w) J)^T f with w = d_row_scale (NULL: all ones) applied while the rows are staged -- every weighted element is
@@ -418,14 +422,14 @@ int gst_fill_jtf_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t 
  * (so it may be contracted again, copied out, or -- for an exact Jacobian in tracked memory -- keep its resident zeros
  * whatever the weights are).  Either output may be NULL (d_jtf needs d_f).  Replaces the same reference lines as
  * gst_fill_jtj_dev / gst_fill_jtf_dev (objectivefns.py:4633-4665 scaling, distlayout.py:1220-1359 products). */
-int gst_fill_normal_eqs_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
+GST_API int gst_fill_normal_eqs_dev(gst_plan *plan, const double *d_J, int64_t n_rows, int64_t n_cols, int64_t ld,
                             const double *d_row_scale, const double *d_f, double *d_jtj, double *d_jtf);
-int gst_memcpy_h2d(gst_plan *plan, void *d_dst, const void *src, int64_t nbytes);
+GST_API int gst_memcpy_h2d(gst_plan *plan, void *d_dst, const void *src, int64_t nbytes);
 /* A rows x cols block of doubles between two device arrays with their own leading dimensions (in doubles), enqueued on
  * the plan's stream.  No counterpart in the reference, whose arrays live on the host: it is what re-assembles whole
  * Jacobian rows from the column blocks the parameter-processors of an atom-processor hold (the reference broadcasts
  * transposed column blocks between host arrays for the same purpose, layouts/distlayout.py:1306-1346). */
-int gst_copy_block_dev(gst_plan *plan, double *d_dst, int64_t dst_ld, const double *d_src, int64_t src_ld,
+GST_API int gst_copy_block_dev(gst_plan *plan, double *d_dst, int64_t dst_ld, const double *d_src, int64_t src_ld,
                        int64_t n_rows, int64_t n_cols);
 
 /* Element-wise objective maps on device-resident probabilities (row f1): what the reference evaluates with numpy
@@ -448,7 +452,7 @@ typedef struct gst_objective_desc {
     double radius;           /* dlogl: zero-frequency radius ("harsh" regularisation) */
     double prob_clip_lo, prob_clip_hi;
 } gst_objective_desc;
-int gst_objective_rows_dev(gst_plan *plan, const gst_objective_desc *desc, double *d_probs, const double *d_counts,
+GST_API int gst_objective_rows_dev(gst_plan *plan, const gst_objective_desc *desc, double *d_probs, const double *d_counts,
                            const double *d_totals, int64_t n, double *d_lsvec, double *d_rowscale, double *d_terms,
                            double *sum_terms);
 
@@ -465,7 +469,7 @@ int gst_objective_rows_dev(gst_plan *plan, const gst_objective_desc *desc, doubl
  * desc->hessian_mode = GST_DERIV_ANALYTIC uses the exact dprobs / hprobs instead; with gst_set_derivs set (linear
  * general parameterisations, see gst_fill_hprobs_analytic) that is the only mode.  A complement effect
  * (gst_set_complement_effect) is honoured by the FD mode. */
-int gst_objective_hessian_block(gst_plan *plan, const gst_objective_desc *desc, const double *d_counts,
+GST_API int gst_objective_hessian_block(gst_plan *plan, const gst_objective_desc *desc, const double *d_counts,
                                 const double *d_totals, const int64_t *idx1, int64_t n1, const int64_t *idx2,
                                 int64_t n2, double eps, double *out);
 
@@ -493,9 +497,9 @@ typedef struct gst_comm gst_comm;
 #define GST_COMM_ID_BYTES 128
 #define GST_TRANSPORT_RCCL 0
 #define GST_TRANSPORT_IPC 1
-int gst_comm_get_unique_id(int transport, void *id_out);
-int gst_comm_create(int transport, int device, int rank, int size, const void *id, gst_comm **out);
-int gst_comm_destroy(gst_comm *comm);
+GST_API int gst_comm_get_unique_id(int transport, void *id_out);
+GST_API int gst_comm_create(int transport, int device, int rank, int size, const void *id, gst_comm **out);
+GST_API int gst_comm_destroy(gst_comm *comm);
 
 /* Row blocks of a row-major [n_rows][row_doubles] f64 array: block b = rows [blk_row0[b], blk_row0[b] + blk_rows[b]) of the
  * ASSEMBLED array, owned (filled) by rank blk_owner[b] (a rank may own several: atoms r, r + size, ...).  Every rank passes
@@ -504,9 +508,9 @@ int gst_comm_destroy(gst_comm *comm);
  *       (the _dev fills write there directly); on return (stream order) every rank holds all blocks.
  *   gst_comm_gather_rows: only `root` holds the full-size array (d_full, own blocks in place); the other ranks pass
  *       d_local = their own blocks packed one after another in block order (d_full is ignored there).  Gatherv. */
-int gst_comm_allgather_rows(gst_comm *comm, gst_plan *plan, double *d_full, int64_t row_doubles, int32_t n_blocks,
+GST_API int gst_comm_allgather_rows(gst_comm *comm, gst_plan *plan, double *d_full, int64_t row_doubles, int32_t n_blocks,
                             const int32_t *blk_owner, const int64_t *blk_row0, const int64_t *blk_rows);
-int gst_comm_gather_rows(gst_comm *comm, gst_plan *plan, const double *d_local, double *d_full, int64_t row_doubles,
+GST_API int gst_comm_gather_rows(gst_comm *comm, gst_plan *plan, const double *d_local, double *d_full, int64_t row_doubles,
                          int32_t n_blocks, const int32_t *blk_owner, const int64_t *blk_row0, const int64_t *blk_rows,
                          int32_t root);
 /* General block exchange between device arrays (an Alltoallv): block b = blk_count[b] doubles read at d_src + blk_src_off[b]
@@ -516,13 +520,13 @@ int gst_comm_gather_rows(gst_comm *comm, gst_plan *plan, const double *d_local, 
  * (layouts/distlayout.py:1306-1346: the reference broadcasts each column slice's transpose between host arrays): every
  * rank sends its columns of the row range another rank will contract and receives that range's other columns.  Grouped
  * ncclSend / ncclRecv under RCCL (each pair over its own xGMI link), peer copies under the IPC transport. */
-int gst_comm_exchange_blocks(gst_comm *comm, gst_plan *plan, const double *d_src, double *d_dst, int32_t n_blocks,
+GST_API int gst_comm_exchange_blocks(gst_comm *comm, gst_plan *plan, const double *d_src, double *d_dst, int32_t n_blocks,
                              const int32_t *blk_src_rank, const int32_t *blk_dst_rank, const int64_t *blk_src_off,
                              const int64_t *blk_dst_off, const int64_t *blk_count);
 /* d_buf[0..n) <- sum over ranks of their d_buf, on every rank (in place). */
-int gst_comm_allreduce_sum(gst_comm *comm, gst_plan *plan, double *d_buf, int64_t n);
-int gst_comm_barrier(gst_comm *comm);                 /* all ranks have reached this call; outstanding exchanges done */
-int gst_comm_sync(gst_comm *comm);                    /* the comm's own stream (plan == NULL operations) */
+GST_API int gst_comm_allreduce_sum(gst_comm *comm, gst_plan *plan, double *d_buf, int64_t n);
+GST_API int gst_comm_barrier(gst_comm *comm);                 /* all ranks have reached this call; outstanding exchanges done */
+GST_API int gst_comm_sync(gst_comm *comm);                    /* the comm's own stream (plan == NULL operations) */
 typedef struct {
     int32_t transport, rank, size, device;
     int32_t rccl_version;        /* ncclGetVersion code of the library bound at run time (0 for the IPC transport) */
@@ -530,28 +534,28 @@ typedef struct {
                                     destinations that alternate are re-published under their old id and do not re-open */
     int32_t reserved[2];
 } gst_comm_info;
-int gst_comm_get_info(const gst_comm *comm, gst_comm_info *out);
+GST_API int gst_comm_get_info(const gst_comm *comm, gst_comm_info *out);
 
 /* Plain device-buffer helpers on the plan's device, so that callers without any GPU framework can
  * keep results resident (bench.py, tests).  Buffers from any other allocator work equally. */
-int gst_device_malloc(gst_plan *plan, int64_t nbytes, void **d_ptr);
+GST_API int gst_device_malloc(gst_plan *plan, int64_t nbytes, void **d_ptr);
 /* The same allocation, declared TRACKED: the caller states that every write to this memory goes through this library
  * (fills, gst_memcpy_h2d, gst_copy_block_dev, the objective maps, gst_comm_*; each reports what it overwrites) or is
  * announced with gst_device_touch.  Only such memory -- and the plans' private staging buffers -- is eligible for the
  * default of GST_OPT_ANALYTIC_KEEP_ZEROS (2): a repeated exact fill skips the structural zeros it left there itself.
  * Memory from gst_device_malloc or from any other allocator is never trusted without the explicit promise (value 1).
  * Released with gst_device_free. */
-int gst_device_malloc_tracked(gst_plan *plan, int64_t nbytes, void **d_ptr);
-int gst_device_free(gst_plan *plan, void *d_ptr);
+GST_API int gst_device_malloc_tracked(gst_plan *plan, int64_t nbytes, void **d_ptr);
+GST_API int gst_device_free(gst_plan *plan, void *d_ptr);
 /* The caller wrote [d_ptr, d_ptr + nbytes) of gst_device_malloc_tracked memory by means other than this library (its own
  * kernel, a peer copy): whatever the library remembered about the contents is forgotten. */
-int gst_device_touch(gst_plan *plan, void *d_ptr, int64_t nbytes);
-int gst_memcpy_d2h(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
+GST_API int gst_device_touch(gst_plan *plan, void *d_ptr, int64_t nbytes);
+GST_API int gst_memcpy_d2h(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
 /* The same copy enqueued on the plan's stream without waiting for it (gst_sync completes it): lets one process drain
  * the plans of several GPUs side by side -- with a page-locked destination (gst_host_register) the copies of different
  * devices overlap; a pageable one makes the call synchronous (the library copies through its own page-locked staging
  * buffer: the device never touches pageable caller memory), which is still correct. */
-int gst_memcpy_d2h_async(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
+GST_API int gst_memcpy_d2h_async(gst_plan *plan, void *dst, const void *d_src, int64_t nbytes);
 
 /* Page-lock a caller-owned host array (hipHostRegister, portable across devices) so that the host-output fills
  * (gst_fill_probs / gst_fill_dprobs / gst_fill_hprobs*) copy into it at full PCIe rate instead of through the runtime's
@@ -565,14 +569,14 @@ int gst_memcpy_d2h_async(gst_plan *plan, void *dst, const void *d_src, int64_t n
  * The region is also mapped into the device's address space: a finite-difference gst_fill_dprobs whose destination lies
  * inside it (requests of >= 64 columns) has its kernel write the Jacobian straight into the host array (512-byte row segments over PCIe while the
  * walk is still computing; no HBM staging of the result), honouring (ld, dest_idx) as always. */
-int gst_host_register(void *ptr, int64_t nbytes);
-int gst_host_unregister(void *ptr);
+GST_API int gst_host_register(void *ptr, int64_t nbytes);
+GST_API int gst_host_unregister(void *ptr);
 
 /* Introspection (tests, bench, DESIGN.md numbers). */
-int gst_get_stats(const gst_plan *plan, gst_stats *out);
+GST_API int gst_get_stats(const gst_plan *plan, gst_stats *out);
 /* Copies up to `cap` program words of the concatenated walk programs; returns the total count in
  * *n_words.  task_off (may be NULL) receives n_tasks+1 offsets when cap_tasks suffices. */
-int gst_get_program(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words,
+GST_API int gst_get_program(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words,
                     int64_t *task_off, int64_t cap_tasks);
 /* The "dirty programs" of finite differences over whole-object perturbations (gst_set_lindblad): for task t and object
  * class c (gate c for c < n_gates, preparation c - n_gates behind them; *n_classes = n_gates + n_rhos) the part of the
@@ -586,10 +590,10 @@ int gst_get_program(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t 
  * suffice.  node_parent / node_sym (may be NULL): the state graph the ids refer to (for which = 1 the reversed plan's).
  * info[13] = usable, worthwhile, nv, scratch matrices per task, most stages of a task, stages, tiles, chains, nodes on
  * chains, sum over tasks of the deepest node, states, tasks, states produced. */
-int gst_get_level_program(const gst_plan *plan, int32_t which, int32_t *words, int64_t cap_words, int64_t *n_words, int32_t *ids,
+GST_API int gst_get_level_program(const gst_plan *plan, int32_t which, int32_t *words, int64_t cap_words, int64_t *n_words, int32_t *ids,
                           int64_t cap_ids, int64_t *n_ids, int64_t *task_off, int64_t cap_tasks, int32_t *node_parent,
                           int32_t *node_sym, int64_t cap_nodes, int64_t *info);
-int gst_get_dirty_programs(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words, int64_t *prog_off,
+GST_API int gst_get_dirty_programs(const gst_plan *plan, uint32_t *words, int64_t cap, int64_t *n_words, int64_t *prog_off,
                            int64_t cap_progs, int32_t *n_classes);
 
 /* Host-side utility of layout construction (no device, no plan): the circuits in prefix order.  Circuit c's key is
@@ -599,18 +603,18 @@ int gst_get_dirty_programs(const gst_plan *plan, uint32_t *words, int64_t cap, i
  * predecessor (0 for k = 0).  What `PrefixTable` / the distributed layouts' circuit partition compute with Python tuple
  * compares (layouts/prefixtable.py:26-101, 154-288: 16 s at 2Q L<=1024): the atoms of a multi-GPU layout are contiguous runs
  * of this order, cut where lcp is small.  circ_head may be NULL (one preparation). */
-int gst_sort_circuits(int64_t n_circuits, const int64_t *circ_ptr, const int32_t *circ_syms, const int32_t *circ_head,
+GST_API int gst_sort_circuits(int64_t n_circuits, const int64_t *circ_ptr, const int32_t *circ_syms, const int32_t *circ_head,
                       int64_t *order_out, int64_t *lcp_out);
 /* first_out[c * n_syms + g] = position of the first occurrence of symbol g in circuit c, -1 if it never occurs (host-only):
  * what decides which parameter wavefronts of a finite-difference Jacobian re-propagate a state (those of the gates on its
  * path) -- the measure the atoms of a multi-GPU layout are balanced on. */
-int gst_circuit_first_use(int64_t n_circuits, const int64_t *circ_ptr, const int32_t *circ_syms, int32_t n_syms,
+GST_API int gst_circuit_first_use(int64_t n_circuits, const int64_t *circ_ptr, const int32_t *circ_syms, int32_t n_syms,
                           int64_t *first_out);
 
 /* The per-SIMD queues the persistent finite-difference launch of a small atom would use for these columns (host-side
  * only, no device needed): estimated work of each of n_queues queues after longest-first packing and hand-overs
  * (handover: 0 none, 1 balance, 2 cut every walk).  Needs gst_set_param_map.  D <= 16. */
-int gst_get_fd_queues(gst_plan *plan, const int64_t *param_idx, int64_t n_param, int32_t n_queues, int32_t handover,
+GST_API int gst_get_fd_queues(gst_plan *plan, const int64_t *param_idx, int64_t n_param, int32_t n_queues, int32_t handover,
                       int64_t *load_out, int32_t *n_pairs, int32_t *n_handovers);
 
 /* EXACT arithmetic of one GST_DERIV_FD fill of these columns by the lane-per-model walk (D <= 16; host-side only, no device
@@ -623,16 +627,16 @@ int gst_get_fd_queues(gst_plan *plan, const int64_t *param_idx, int64_t n_param,
  *   [6] wavefronts the columns are packed into   [7] tasks
  * Executed flops of the fill = 2 D^2 * 64 * out[0] + 2 D * 64 * out[2] (every lane of a wavefront issues); the reference
  * schedule's flops = n_param * (2 D^2 A + 2 D nE). */
-int gst_get_fd_work(gst_plan *plan, const int64_t *param_idx, int64_t n_param, int64_t *out);
+GST_API int gst_get_fd_work(gst_plan *plan, const int64_t *param_idx, int64_t n_param, int64_t *out);
 
 /* The state-id graph behind the NODE markers: parent state id (-1 for a state preparation) and gate / rho index of
  * every state, and the id of each expanded circuit's final state (what the analytic mode walks backwards). */
-int gst_get_state_graph(const gst_plan *plan, int32_t *node_parent, int32_t *node_sym, int64_t cap_nodes,
+GST_API int gst_get_state_graph(const gst_plan *plan, int32_t *node_parent, int32_t *node_sym, int64_t cap_nodes,
                         int32_t *circ_leaf, int64_t cap_circuits, int64_t *n_nodes);
 
-int gst_device_count(int32_t *n);
-const char *gst_last_error(void);
-const char *gst_version(void);
+GST_API int gst_device_count(int32_t *n);
+GST_API const char *gst_last_error(void);
+GST_API const char *gst_version(void);
 
 /* Walk-program encoding (one 32-bit word per instruction, opcode in the top 4 bits) -- public so
  * that tests can interpret programs independently of the device code. */

@@ -140,6 +140,26 @@ int h2d_bytes(gst_plan* p, void* d_dst, const void* src, size_t bytes)
     return GST_OK;
 }
 
+int h2d_async(gst_plan* p, void* d_dst, const void* src, size_t bytes)
+{
+    constexpr size_t RING = (size_t)4 << 20;
+    if (bytes == 0) return GST_OK;
+    if (bytes > RING / 2 || mapped_device_pointer(src, bytes)) return h2d_bytes(p, d_dst, src, bytes);
+    if (!p->h_up) {
+        HIP_TRY(hipHostMalloc((void**)&p->h_up, RING, hipHostMallocDefault));
+        p->h_up_bytes = RING; p->h_up_at = 0;
+    }
+    size_t at = (p->h_up_at + 63) & ~(size_t)63;
+    if (at + bytes > p->h_up_bytes) {                 // wrap: every copy out of the ring so far was issued on p->stream
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        at = 0;
+    }
+    std::memcpy(p->h_up + at, src, bytes);
+    HIP_TRY(hipMemcpyAsync(d_dst, p->h_up + at, bytes, hipMemcpyHostToDevice, p->stream));
+    p->h_up_at = at + bytes;
+    return GST_OK;
+}
+
 // rows of n_cols doubles: device [n_rows][src_ld] -> host [n_rows][dst_ld]
 int d2h_rows(gst_plan* p, double* dst, int64_t dst_ld, const double* d_src, int64_t src_ld, int64_t n_rows, int64_t n_cols)
 {
@@ -265,12 +285,12 @@ int ensure_device(gst_plan* p)
     HIP_TRY(p->d_eff_ptr.ensure(h.eff_ptr.size()));
     HIP_TRY(p->d_eff_label.ensure(h.eff_label.size()));
     HIP_TRY(p->d_eff_dest.ensure(h.eff_dest.size()));
-    HIP_TRY(hipMemcpy(p->d_prog.p, h.prog.data(), h.prog.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p->d_task_off.p, h.task_off.data(), h.task_off.size() * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p->d_eff_ptr.p, h.eff_ptr.data(), h.eff_ptr.size() * 4, hipMemcpyHostToDevice));
+    H2D_TRY(p, p->d_prog.p, h.prog.data(), h.prog.size() * 4);
+    H2D_TRY(p, p->d_task_off.p, h.task_off.data(), h.task_off.size() * 8);
+    H2D_TRY(p, p->d_eff_ptr.p, h.eff_ptr.data(), h.eff_ptr.size() * 4);
     if (!h.eff_label.empty()) {
-        HIP_TRY(hipMemcpy(p->d_eff_label.p, h.eff_label.data(), h.eff_label.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->d_eff_dest.p, h.eff_dest.data(), h.eff_dest.size() * 4, hipMemcpyHostToDevice));
+        H2D_TRY(p, p->d_eff_label.p, h.eff_label.data(), h.eff_label.size() * 4);
+        H2D_TRY(p, p->d_eff_dest.p, h.eff_dest.data(), h.eff_dest.size() * 4);
     }
     HIP_TRY(p->d_pbase.ensure(h.n_elements));
     p->dev_ready = true;
@@ -307,10 +327,10 @@ int upload_model(gst_plan* p)
     return GST_OK;
 }
 
-int upload_i32(DevBuf<int32_t>& b, const std::vector<int32_t>& v, hipStream_t s)
+int upload_i32(gst_plan* p, DevBuf<int32_t>& b, const std::vector<int32_t>& v)
 {
     HIP_TRY(b.ensure(v.size()));
-    if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice, s));
+    if (!v.empty()) H2D_TRY(p, b.p, v.data(), v.size() * 4);
     return GST_OK;
 }
 
@@ -880,8 +900,8 @@ int gst_get_stats(const gst_plan* p, gst_stats* s)
     if (p->last_fd_form >= 1 && p->d_bin_head.p && p->n_bins > 0 && p->dev_ready) {
         uint32_t flag = 0;                  // the abort flag sits behind the queue heads
         HIP_TRY(hipSetDevice(p->device));
-        HIP_TRY(hipMemcpyAsync(&flag, p->d_bin_head.p + p->n_bins, 4, hipMemcpyDeviceToHost, p->stream));
-        HIP_TRY(hipStreamSynchronize(p->stream));
+        int rc = d2h_bytes(const_cast<gst_plan*>(p), &flag, p->d_bin_head.p + p->n_bins, 4);      // (through the staging buffer, as every copy)
+        if (rc) return rc;
         s->last_fd_aborted = flag != 0 ? 1 : 0;
     }
     return GST_OK;

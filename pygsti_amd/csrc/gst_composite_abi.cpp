@@ -23,7 +23,7 @@ static int cmp_upload(gst_plan* p)
     i32.insert(i32.end(), C.factor_leaf.begin(), C.factor_leaf.end());
     i32.insert(i32.end(), C.factor_targets.begin(), C.factor_targets.end());
     i32.insert(i32.end(), C.leaf_np.begin(), C.leaf_np.end());
-    int rc = upload_i32(p->d_cmp_i32, i32, p->stream);
+    int rc = upload_i32(p, p->d_cmp_i32, i32);
     if (rc) return rc;
     std::vector<int64_t> i64;
     i64.insert(i64.end(), C.leaf_off.begin(), C.leaf_off.end());
@@ -33,7 +33,7 @@ static int cmp_upload(gst_plan* p)
     i64.insert(i64.end(), C.leaf_fd_off.begin(), C.leaf_fd_off.end());
     i64.insert(i64.end(), C.leaf_plist.begin(), C.leaf_plist.end());
     HIP_TRY(p->d_cmp_i64.ensure(std::max<size_t>(i64.size(), 1)));
-    HIP_TRY(hipMemcpyAsync(p->d_cmp_i64.p, i64.data(), i64.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_cmp_i64.p, i64.data(), i64.size() * 8);
     HIP_TRY(p->d_cmp_values.ensure(std::max<size_t>(C.leaf_param.size(), 1)));
     HIP_TRY(p->d_cmp_gderiv.ensure((size_t)std::max<int64_t>(C.n_deriv_doubles, 1)));
     HIP_TRY(p->d_cmp_gfd.ensure((size_t)std::max<int64_t>(C.n_fd_doubles, 1)));
@@ -84,7 +84,7 @@ static int cmp_upload_pmap(gst_plan* p, gst::CompositeArgs& a)
     v.insert(v.end(), p->pkind.begin(), p->pkind.end());
     v.insert(v.end(), p->pobj.begin(), p->pobj.end());
     v.insert(v.end(), p->pelem.begin(), p->pelem.end());
-    int rc = upload_i32(p->d_cmp_pmap, v, p->stream);
+    int rc = upload_i32(p, p->d_cmp_pmap, v);
     if (rc) return rc;
     const size_t n = p->pkind.size();
     a.pkind = p->d_cmp_pmap.p; a.pobj = p->d_cmp_pmap.p + n; a.pelem = p->d_cmp_pmap.p + 2 * n;
@@ -116,7 +116,7 @@ int run_dprobs_composite(gst_plan* p, double* d_out, int64_t ld, const int64_t* 
     HIP_TRY(p->d_mm_models.ensure((size_t)chunk * stride));
     HIP_TRY(p->d_mm_raw.ensure((size_t)chunk * (size_t)std::max<int64_t>(nE, 1)));
     HIP_TRY(p->d_cmp_setparam.ensure((size_t)n_param));
-    HIP_TRY(hipMemcpyAsync(p->d_cmp_setparam.p, param_idx, (size_t)n_param * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_cmp_setparam.p, param_idx, (size_t)n_param * 8);
     std::vector<int32_t> dest32;
     if (dest_idx) {
         dest32.resize((size_t)n_param);
@@ -124,7 +124,7 @@ int run_dprobs_composite(gst_plan* p, double* d_out, int64_t ld, const int64_t* 
             if (dest_idx[m] < 0 || dest_idx[m] >= ld) return fail(GST_EINVAL, "destination column out of range");
             dest32[(size_t)m] = (int32_t)dest_idx[m];
         }
-        if ((rc = upload_i32(p->d_mm_dest, dest32, p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_mm_dest, dest32))) return rc;
     } else if (n_param > ld) return fail(GST_EINVAL, "more columns than the leading dimension");
     gst::CompositeArgs a;
     cmp_args(p, a);
@@ -212,7 +212,7 @@ int run_dprobs_composite_analytic(gst_plan* p, double* d_out, int64_t ld, const 
     HIP_TRY(p->d_dv_deriv.ensure((size_t)std::max<int64_t>(doff, 1)));
     for (size_t o = 0, at = 0; o < n_spam_objs; o++) {
         const size_t n = (size_t)D * (size_t)ncols[o];
-        HIP_TRY(hipMemcpyAsync(p->d_dv_deriv.p + spam_off[o], spam_deriv.data() + at, n * 8, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_dv_deriv.p + spam_off[o], spam_deriv.data() + at, n * 8);
         at += n;
     }
     // item tables: [item_gate | item_col | gate_ncols] (int32) and [item_param | gate_doff] (int64)
@@ -220,13 +220,13 @@ int run_dprobs_composite_analytic(gst_plan* p, double* d_out, int64_t ld, const 
     t32.insert(t32.end(), item_gate.begin(), item_gate.end());
     t32.insert(t32.end(), item_col.begin(), item_col.end());
     t32.insert(t32.end(), gate_ncols.begin(), gate_ncols.end());
-    int rc = upload_i32(p->d_cmp_items32, t32, p->stream);
+    int rc = upload_i32(p, p->d_cmp_items32, t32);
     if (rc) return rc;
     std::vector<int64_t> t64;
     t64.insert(t64.end(), item_param.begin(), item_param.end());
     t64.insert(t64.end(), gate_doff.begin(), gate_doff.end());
     HIP_TRY(p->d_cmp_setparam.ensure(std::max<size_t>(t64.size(), 1)));
-    HIP_TRY(hipMemcpyAsync(p->d_cmp_setparam.p, t64.data(), t64.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_cmp_setparam.p, t64.data(), t64.size() * 8);
     gst::CompositeArgs a;
     cmp_args(p, a);
     const size_t ni = item_gate.size();
@@ -345,9 +345,9 @@ int gst_set_composite_values(gst_plan* p, const double* leaf_values, const doubl
     gst_plan::Composite& C = p->cmp;
     const int D = p->hp.D;
     const size_t ng = (size_t)p->hp.n_gates * D * D, nr = (size_t)p->hp.n_rhos * D, ne = (size_t)p->hp.n_effects * D;
-    HIP_TRY(hipMemcpyAsync(p->d_cmp_values.p, leaf_values, C.leaf_param.size() * 8, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->d_cmp_spam.p, rhos, nr * 8, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->d_cmp_spam.p + nr, effects, ne * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_cmp_values.p, leaf_values, C.leaf_param.size() * 8);
+    H2D_TRY(p, p->d_cmp_spam.p, rhos, nr * 8);
+    H2D_TRY(p, p->d_cmp_spam.p + nr, effects, ne * 8);
     gst::CompositeArgs a;
     cmp_args(p, a);
     a.set_param = nullptr; a.base_set = nullptr; a.sets = p->d_cmp_base.p; a.gates_rowmajor = p->d_cmp_gates_rm.p; a.eps = 0.0;
@@ -355,9 +355,9 @@ int gst_set_composite_values(gst_plan* p, const double* leaf_values, const doubl
     // the base model also becomes the plan's model (what gst_set_model would have been given)
     std::vector<double> set(ng + nr + ne);
     p->h_gates.resize(ng);
-    HIP_TRY(hipMemcpyAsync(set.data(), p->d_cmp_base.p, set.size() * 8, hipMemcpyDeviceToHost, p->stream));
-    if (ng) HIP_TRY(hipMemcpyAsync(p->h_gates.data(), p->d_cmp_gates_rm.p, ng * 8, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    int rc2 = d2h_bytes(p, set.data(), p->d_cmp_base.p, set.size() * 8);
+    if (!rc2 && ng) rc2 = d2h_bytes(p, p->h_gates.data(), p->d_cmp_gates_rm.p, ng * 8);
+    if (rc2) return rc2;
     p->h_gates_t.assign(set.begin(), set.begin() + (long)ng);
     p->h_rhos.assign(set.begin() + (long)ng, set.begin() + (long)(ng + nr));
     p->h_effects.assign(set.begin() + (long)(ng + nr), set.end());
@@ -379,12 +379,12 @@ int gst_set_composite_general(gst_plan* p, const double* leaf_derivs, const doub
     int rc = ensure_device(p);
     if (rc) return rc;
     if (leaf_derivs) {
-        HIP_TRY(hipMemcpyAsync(p->d_cmp_gderiv.p, leaf_derivs, (size_t)C.n_deriv_doubles * 8, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_cmp_gderiv.p, leaf_derivs, (size_t)C.n_deriv_doubles * 8);
         C.have_general_derivs = true;
     }
     if (leaf_fd_values) {
         if (!(fd_eps != 0.0)) return fail(GST_EINVAL, "fd_eps must be non-zero");
-        HIP_TRY(hipMemcpyAsync(p->d_cmp_gfd.p, leaf_fd_values, (size_t)C.n_fd_doubles * 8, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_cmp_gfd.p, leaf_fd_values, (size_t)C.n_fd_doubles * 8);
         C.have_general_fd = true; C.general_fd_eps = fd_eps;
     }
     HIP_TRY(hipStreamSynchronize(p->stream));

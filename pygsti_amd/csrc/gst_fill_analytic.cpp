@@ -21,18 +21,18 @@ int ensure_reverse(gst_plan* p)
     gst::build_pair_tables(h, p->rev, pf, pr, pos_ptr);
     HIP_TRY(p->d_rprog.ensure(p->rev.prog.size() + 64));
     HIP_TRY(hipMemsetAsync(p->d_rprog.p, 0, (p->rev.prog.size() + 64) * 4, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->d_rprog.p, p->rev.prog.data(), p->rev.prog.size() * 4, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_rprog.p, p->rev.prog.data(), p->rev.prog.size() * 4);
     HIP_TRY(p->d_rtask_off.ensure(p->rev.task_off.size()));
-    HIP_TRY(hipMemcpyAsync(p->d_rtask_off.p, p->rev.task_off.data(), p->rev.task_off.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_rtask_off.p, p->rev.task_off.data(), p->rev.task_off.size() * 8);
     HIP_TRY(p->d_pos_ptr.ensure(pos_ptr.size()));
-    HIP_TRY(hipMemcpyAsync(p->d_pos_ptr.p, pos_ptr.data(), pos_ptr.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_pos_ptr.p, pos_ptr.data(), pos_ptr.size() * 8);
     int rc;
     std::vector<int32_t> zeros((size_t)h.n_circuits + 1, 0);
-    if ((rc = upload_i32(p->d_reff_ptr, zeros, p->stream))) return rc;
-    if ((rc = upload_i32(p->d_rev_leaf, p->rev.circ_leaf, p->stream))) return rc;
-    if ((rc = upload_i32(p->d_pair_f, pf, p->stream))) return rc;
-    if ((rc = upload_i32(p->d_pair_r, pr, p->stream))) return rc;
-    if ((rc = upload_i32(p->d_circ_rho, h.circ_rho, p->stream))) return rc;
+    if ((rc = upload_i32(p, p->d_reff_ptr, zeros))) return rc;
+    if ((rc = upload_i32(p, p->d_rev_leaf, p->rev.circ_leaf))) return rc;
+    if ((rc = upload_i32(p, p->d_pair_f, pf))) return rc;
+    if ((rc = upload_i32(p, p->d_pair_r, pr))) return rc;
+    if ((rc = upload_i32(p, p->d_circ_rho, h.circ_rho))) return rc;
     std::vector<int32_t> order((size_t)h.n_circuits);
     for (int64_t c = 0; c < h.n_circuits; c++) order[(size_t)c] = (int32_t)c;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->rev.circ_leaf[x] < p->rev.circ_leaf[y]; });
@@ -120,11 +120,11 @@ int ensure_reverse(gst_plan* p)
     }
     const int64_t n_items = (int64_t)item_first.size();
     if (h.D == 16) {
-        if ((rc = upload_i32(p->d_circ_order, item_first, p->stream))) return rc;
-        if ((rc = upload_i32(p->d_circ_partner, item_partner, p->stream))) return rc;
-        if ((rc = upload_i32(p->d_pair_common, item_common, p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_circ_order, item_first))) return rc;
+        if ((rc = upload_i32(p, p->d_circ_partner, item_partner))) return rc;
+        if ((rc = upload_i32(p, p->d_pair_common, item_common))) return rc;
     } else {
-        if ((rc = upload_i32(p->d_circ_order, order, p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_circ_order, order))) return rc;
     }
     // 8 contiguous ranges of the item list with equal numbers of gate applications (+ a constant per circuit)
     std::vector<uint32_t> range_begin(9, 0);
@@ -149,7 +149,7 @@ int ensure_reverse(gst_plan* p)
         for (int r = 0; r <= 8; r++) range_begin[r] = (uint32_t)(h.n_circuits * r / 8);
     }
     HIP_TRY(p->d_range_begin.ensure(9));
-    HIP_TRY(hipMemcpyAsync(p->d_range_begin.p, range_begin.data(), 9 * 4, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_range_begin.p, range_begin.data(), 9 * 4);
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(p->d_work_counter.ensure(8));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -178,10 +178,10 @@ int ensure_reverse(gst_plan* p)
         }
         bptr[(size_t)n_items * nG] = (int32_t)(bf1.size() / blk_slots);
         if (bf1.empty()) { bf1.assign(blk_slots, -1); bf2.assign(blk_slots, -1); br.assign(blk_slots, 0); }
-        if ((rc = upload_i32(p->d_blk_f1, bf1, p->stream))) return rc;
-        if ((rc = upload_i32(p->d_blk_f2, bf2, p->stream))) return rc;
-        if ((rc = upload_i32(p->d_blk_r, br, p->stream))) return rc;
-        if ((rc = upload_i32(p->d_blk_ptr, bptr, p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_blk_f1, bf1))) return rc;
+        if ((rc = upload_i32(p, p->d_blk_f2, bf2))) return rc;
+        if ((rc = upload_i32(p, p->d_blk_r, br))) return rc;
+        if ((rc = upload_i32(p, p->d_blk_ptr, bptr))) return rc;
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
     if (h.D == 16) build_levels_host(p, true);      // (needs the reversed plan's state graph, dropped below; whatever GST_OPT_FAST_CHAINS says NOW)
@@ -244,23 +244,23 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
             col0[g] = contiguous ? m[0] : (any ? -1 : -2);
         }
         if (!p->graph_uploaded) {
-            if ((rc = upload_i32(p->d_node_parent, h.node_parent, p->stream))) return rc;
-            if ((rc = upload_i32(p->d_node_sym, h.node_sym, p->stream))) return rc;
+            if ((rc = upload_i32(p, p->d_node_parent, h.node_parent))) return rc;
+            if ((rc = upload_i32(p, p->d_node_sym, h.node_sym))) return rc;
             {   // run[id] = 1 + run[id-1] while parent(id) == id-1 is a gate state reached by a consecutive id
                 std::vector<int32_t> run(h.n_state_ids, 0);
                 for (int64_t i = 1; i < h.n_state_ids; i++)
                     if (h.node_parent[i] == i - 1) run[i] = 1 + ((h.node_parent[i - 1] >= 0 && h.node_parent[i - 1] == i - 2) ? run[i - 1] : 0);
-                if ((rc = upload_i32(p->d_node_run, run, p->stream))) return rc;
+                if ((rc = upload_i32(p, p->d_node_run, run))) return rc;
                 HIP_TRY(hipStreamSynchronize(p->stream));
             }
-            if ((rc = upload_i32(p->d_circ_leaf, h.circ_leaf, p->stream))) return rc;
+            if ((rc = upload_i32(p, p->d_circ_leaf, h.circ_leaf))) return rc;
             p->graph_uploaded = true;
         }
         p->cached_kind = 0;
-        if ((rc = upload_i32(p->d_gate_col0, col0, p->stream))) return rc;
-        if ((rc = upload_i32(p->d_cm_gate, cm_gate, p->stream))) return rc;
-        if ((rc = upload_i32(p->d_cm_rho, cm_rho, p->stream))) return rc;
-        if ((rc = upload_i32(p->d_cm_eff, cm_eff, p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_gate_col0, col0))) return rc;
+        if ((rc = upload_i32(p, p->d_cm_gate, cm_gate))) return rc;
+        if ((rc = upload_i32(p, p->d_cm_rho, cm_rho))) return rc;
+        if ((rc = upload_i32(p, p->d_cm_eff, cm_eff))) return rc;
         HIP_TRY(hipStreamSynchronize(p->stream));          // host vectors above go out of scope
         p->remember_request(2, param_idx, dest_idx, n_param);
         p->cached_none_cols = none_cols;
@@ -440,7 +440,7 @@ int ensure_rowmask(gst_plan* p)
         for (int32_t x = h.eff_ptr[(size_t)c]; x < h.eff_ptr[(size_t)c + 1]; x++) mask[(size_t)(h.eff_dest[(size_t)x] >> 5)] |= gs;
     }
     HIP_TRY(p->d_rowmask.ensure(mask.size()));
-    HIP_TRY(hipMemcpyAsync(p->d_rowmask.p, mask.data(), mask.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_rowmask.p, mask.data(), mask.size() * 8);
     HIP_TRY(hipStreamSynchronize(p->stream));
     p->rowmask_ok = true;
     return GST_OK;
@@ -501,7 +501,7 @@ int run_dprobs_general(gst_plan* p, double* d_out, int64_t ld, const int64_t* pa
     HIP_TRY(p->d_dv_colmap.ensure((size_t)std::max<int64_t>(p->dv_off_cols.back(), 1)));
     std::vector<int32_t> colmap((size_t)p->dv_off_cols.back());
     for (size_t c = 0; c < colmap.size(); c++) colmap[c] = dest_of[(size_t)p->dv_param_idx[c]];
-    if (!colmap.empty()) HIP_TRY(hipMemcpyAsync(p->d_dv_colmap.p, colmap.data(), colmap.size() * 4, hipMemcpyHostToDevice, p->stream));
+    if (!colmap.empty()) H2D_TRY(p, p->d_dv_colmap.p, colmap.data(), colmap.size() * 4);
     HIP_TRY(hipStreamSynchronize(p->stream));          // `colmap` goes out of scope
     if ((rc = ensure_rowmask(p))) return rc;
     for (size_t o = 0; o < p->dv_kind.size(); o++) {
@@ -577,7 +577,7 @@ int gst_set_derivs(gst_plan* p, int32_t n_params, int32_t n_objs, const int32_t*
     p->dv2_set = false; p->dv2_off.clear();
     HIP_TRY(p->d_dv_deriv.ensure((size_t)std::max<int64_t>(off_d[n_objs], 1)));
     if (off_d[n_objs] > 0) {
-        HIP_TRY(hipMemcpyAsync(p->d_dv_deriv.p, deriv, (size_t)off_d[n_objs] * 8, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_dv_deriv.p, deriv, (size_t)off_d[n_objs] * 8);
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
     p->derivs_set = true;
@@ -607,7 +607,7 @@ int gst_set_second_derivs(gst_plan* p, int32_t n_objs, const int32_t* nonzero, c
     if (rc) return rc;
     HIP_TRY(p->d_dv2.ensure((size_t)std::max<int64_t>(total, 1)));
     if (total > 0) {
-        HIP_TRY(hipMemcpyAsync(p->d_dv2.p, hess, (size_t)total * 8, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_dv2.p, hess, (size_t)total * 8);
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
     p->dv2_off = off;

@@ -64,12 +64,12 @@ int ensure_levels(gst_plan* p, bool rev, bool probs_only)
     build_levels_host(p, rev, probs_only);
     if (!L.usable || L.uploaded) return GST_OK;
     int rc;
-    if ((rc = upload_i32(L.d_words, L.prog.words, p->stream))) return rc;
-    if ((rc = upload_i32(L.d_ids, L.prog.ids, p->stream))) return rc;
+    if ((rc = upload_i32(p, L.d_words, L.prog.words))) return rc;
+    if ((rc = upload_i32(p, L.d_ids, L.prog.ids))) return rc;
     HIP_TRY(L.d_task_off.ensure(L.prog.task_off.size()));
-    HIP_TRY(hipMemcpyAsync(L.d_task_off.p, L.prog.task_off.data(), L.prog.task_off.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, L.d_task_off.p, L.prog.task_off.data(), L.prog.task_off.size() * 8);
     HIP_TRY(L.d_ids_off.ensure(L.prog.task_ids_off.size()));
-    HIP_TRY(hipMemcpyAsync(L.d_ids_off.p, L.prog.task_ids_off.data(), L.prog.task_ids_off.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, L.d_ids_off.p, L.prog.task_ids_off.data(), L.prog.task_ids_off.size() * 8);
     HIP_TRY(L.d_mats.ensure(std::max<size_t>((size_t)h.n_tasks() * (size_t)std::max(L.prog.max_mats, 1) * 256, 1)));
     HIP_TRY(hipStreamSynchronize(p->stream));
     L.uploaded = true;
@@ -104,7 +104,7 @@ int run_levels_forward(gst_plan* p, double* d_dst, bool probs_only)
     p->last_launches++;
     if (d_dst) {
         if (!p->leaf_uploaded) {
-            if ((rc = upload_i32(p->d_circ_leaf, h.circ_leaf, p->stream))) return rc;
+            if ((rc = upload_i32(p, p->d_circ_leaf, h.circ_leaf))) return rc;
             HIP_TRY(hipStreamSynchronize(p->stream));
             p->leaf_uploaded = true;
         }
@@ -252,7 +252,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
             p->ecol_tab.insert(p->ecol_tab.end(), ee.begin(), ee.end());
             p->ecol_tab.insert(p->ecol_tab.end(), ed.begin(), ed.end());
             p->ecol_tab.insert(p->ecol_tab.end(), et.begin(), et.end());
-            if ((rc = upload_i32(p->d_ecol_tab, p->ecol_tab, p->stream))) return rc;
+            if ((rc = upload_i32(p, p->d_ecol_tab, p->ecol_tab))) return rc;
         }
         const bool filtered = p->comp_index >= 0;
         const int64_t* l_idx = filtered ? w_idx.data() : param_idx;
@@ -262,10 +262,10 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         else pack_lanes(p, l_idx, l_dest, l_n, L, fused);
         p->cached_kind = 0;
         p->cached_fused = fused;
-        if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
-        if ((rc = upload_i32(p->d_lane[1], L.kind[0], p->stream))) return rc;
-        if ((rc = upload_i32(p->d_lane[2], L.obj[0], p->stream))) return rc;
-        if ((rc = upload_i32(p->d_lane[3], L.elem[0], p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_lane[0], L.col))) return rc;
+        if ((rc = upload_i32(p, p->d_lane[1], L.kind[0]))) return rc;
+        if ((rc = upload_i32(p, p->d_lane[2], L.obj[0]))) return rc;
+        if ((rc = upload_i32(p, p->d_lane[3], L.elem[0]))) return rc;
         // Launch order: longest (task, wavefront) pairs first.  A wavefront's work in a task is set by the objects
         // its lanes perturb (a gate the task never applies costs almost nothing, a gate of the germ costs the whole
         // chain), so with only a few pairs per SIMD -- a 1/8 atom of the 2Q design has 4.4 -- the order decides how
@@ -280,7 +280,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
             std::vector<uint32_t> order(items.size());
             for (size_t i = 0; i < items.size(); i++) order[i] = items[i].second;
             HIP_TRY(p->d_block_order.ensure(order.size()));
-            HIP_TRY(hipMemcpyAsync(p->d_block_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, p->stream));
+            H2D_TRY(p, p->d_block_order.p, order.data(), order.size() * 4);
             HIP_TRY(hipStreamSynchronize(p->stream));
             p->have_block_order = true;
             if (const char* tp = std::getenv("GST_FD_TRACE")) {          // development aid: the estimates next to the trace
@@ -316,15 +316,15 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
                 const std::vector<int32_t>& ho_index = Q.ho_index;
                 const std::vector<int32_t>& ho_pc = Q.ho_pc;
                 std::vector<int32_t> ho_live(Q.ho_live.begin(), Q.ho_live.end());
-                if ((rc = upload_i32(p->d_bin_ptr, bptr, p->stream))) return rc;
+                if ((rc = upload_i32(p, p->d_bin_ptr, bptr))) return rc;
                 HIP_TRY(p->d_bin_items.ensure(bitems.size()));
-                HIP_TRY(hipMemcpyAsync(p->d_bin_items.p, bitems.data(), bitems.size() * 4, hipMemcpyHostToDevice, p->stream));
+                H2D_TRY(p, p->d_bin_items.p, bitems.data(), bitems.size() * 4);
                 HIP_TRY(p->d_bin_head.ensure((size_t)n_bins + 1));            // (+ the abort flag)
                 p->n_split = n_split;
                 if (n_split > 0) {
-                    if ((rc = upload_i32(p->d_ho_index, ho_index, p->stream))) return rc;
-                    if ((rc = upload_i32(p->d_task_split_pc, ho_pc, p->stream))) return rc;
-                    if ((rc = upload_i32(p->d_ho_live, ho_live, p->stream))) return rc;
+                    if ((rc = upload_i32(p, p->d_ho_index, ho_index))) return rc;
+                    if ((rc = upload_i32(p, p->d_task_split_pc, ho_pc))) return rc;
+                    if ((rc = upload_i32(p, p->d_ho_live, ho_live))) return rc;
                     HIP_TRY(p->d_ho_state.ensure((size_t)n_split * (size_t)(1 + std::max(p->hp.max_slots, 0)) * p->hp.D * 64));
                     HIP_TRY(p->d_ho_tag.ensure((size_t)n_split * 4));
                     HIP_TRY(p->d_ho_id.ensure((size_t)n_split));
@@ -389,9 +389,9 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
             p->ecol_val[nc + k] = p->comp_identity[i] - sum;
         }
         HIP_TRY(p->d_ecol_val.ensure(p->ecol_val.size()));
-        HIP_TRY(hipMemcpyAsync(p->d_ecol_val.p, p->ecol_val.data(), p->ecol_val.size() * 8, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_ecol_val.p, p->ecol_val.data(), p->ecol_val.size() * 8);
         if (!p->leaf_uploaded) {
-            if ((rc = upload_i32(p->d_circ_leaf, p->hp.circ_leaf, p->stream))) return rc;
+            if ((rc = upload_i32(p, p->d_circ_leaf, p->hp.circ_leaf))) return rc;
             p->leaf_uploaded = true;
         }
         gst::EffectFDArgs ea;
@@ -468,8 +468,8 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
     p->last_launches++;
     if (a.trace) {
         std::vector<uint64_t> h(1 + 4 * n_trace);
-        HIP_TRY(hipMemcpyAsync(h.data(), p->d_trace.p, h.size() * 8, hipMemcpyDeviceToHost, p->stream));
-        HIP_TRY(hipStreamSynchronize(p->stream));
+        int rc_t = d2h_bytes(p, h.data(), p->d_trace.p, h.size() * 8);
+        if (rc_t) return rc_t;
         if (FILE* f = std::fopen(trace_path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
     }
     return GST_OK;
@@ -528,7 +528,7 @@ int run_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, const 
             if (dest_idx[m] < 0 || dest_idx[m] >= ld) return fail(GST_EINVAL, "destination column out of range");
             dest32[(size_t)m] = (int32_t)dest_idx[m];
         }
-        if ((rc = upload_i32(p->d_mm_dest, dest32, p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_mm_dest, dest32))) return rc;
     } else if (n_models > ld) return fail(GST_EINVAL, "more model sets than columns");
     std::vector<double> stage((size_t)chunk * stride);
     TIME_REC(p, evk0);
@@ -544,7 +544,7 @@ int run_dprobs_models(gst_plan* p, int64_t n_models, const double* gates, const 
             for (int r = 0; r < h.n_rhos; r++) std::memcpy(dst + ng + (size_t)r * D, rhos + (size_t)(m0 + m) * nru + (size_t)r * Du, (size_t)Du * 8);
             for (int e = 0; e < h.n_effects; e++) std::memcpy(dst + ng + nr + (size_t)e * D, effects + (size_t)(m0 + m) * neu + (size_t)e * Du, (size_t)Du * 8);
         }
-        HIP_TRY(hipMemcpyAsync(p->d_mm_models.p, stage.data(), (size_t)nm * stride * 8, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_mm_models.p, stage.data(), (size_t)nm * stride * 8);
         if ((rc = run_models_chunk(p, nm, m0, d_base, d_out, ld, dest_idx ? p->d_mm_dest.p + m0 : nullptr, eps))) return rc;
         HIP_TRY(hipStreamSynchronize(p->stream));          // the staging vector is refilled by the next chunk
     }

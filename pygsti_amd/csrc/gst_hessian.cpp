@@ -50,7 +50,7 @@ static int run_hprobs_composed(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
     const int32_t* d_dest2 = nullptr;
     if (dest2) {
         std::vector<int32_t> d2(dest2, dest2 + n2);
-        if ((rc = upload_i32(p->d_hdest, d2, p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_hdest, d2))) return rc;
         d_dest2 = p->d_hdest.p;
     }
     const std::vector<double> g0 = p->h_gates, gt0 = p->h_gates_t, r0 = p->h_rhos, e0 = p->h_effects;
@@ -127,15 +127,15 @@ static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, co
     }
     L.n_waves = rows ? (int32_t)L.col.size() : (int32_t)(L.col.size() / 64);
     p->cached_kind = 0;      // the shared lane tables are about to hold the (i, j) pairs
-    if ((rc = upload_i32(p->d_lane[0], L.col, p->stream))) return rc;
+    if ((rc = upload_i32(p, p->d_lane[0], L.col))) return rc;
     for (int s = 0; s < 2; s++) {
-        if ((rc = upload_i32(p->d_lane[1 + 3 * s], L.kind[s], p->stream))) return rc;
-        if ((rc = upload_i32(p->d_lane[2 + 3 * s], L.obj[s], p->stream))) return rc;
-        if ((rc = upload_i32(p->d_lane[3 + 3 * s], L.elem[s], p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_lane[1 + 3 * s], L.kind[s]))) return rc;
+        if ((rc = upload_i32(p, p->d_lane[2 + 3 * s], L.obj[s]))) return rc;
+        if ((rc = upload_i32(p, p->d_lane[3 + 3 * s], L.elem[s]))) return rc;
     }
-    if ((rc = upload_i32(p->d_wave_row, wave_row, p->stream))) return rc;
-    if ((rc = upload_i32(p->d_wave_rowidx, wave_rowidx, p->stream))) return rc;
-    if ((rc = upload_i32(p->d_lane_colidx, lane_colidx, p->stream))) return rc;
+    if ((rc = upload_i32(p, p->d_wave_row, wave_row))) return rc;
+    if ((rc = upload_i32(p, p->d_wave_rowidx, wave_rowidx))) return rc;
+    if ((rc = upload_i32(p, p->d_lane_colidx, lane_colidx))) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
     gst::WalkArgs a;
     base_args(p, a);
@@ -156,9 +156,9 @@ static int run_hprobs_dev(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2, co
     } else {
         const bool comp = p->comp_index >= 0;
         if (comp) {       // the complement description rides in the (otherwise unused here) effect-column tables
-            if ((rc = upload_i32(p->d_ecol_tab, p->comp_others, p->stream))) return rc;
+            if ((rc = upload_i32(p, p->d_ecol_tab, p->comp_others))) return rc;
             HIP_TRY(p->d_ecol_val.ensure(p->comp_identity.size()));
-            HIP_TRY(hipMemcpyAsync(p->d_ecol_val.p, p->comp_identity.data(), p->comp_identity.size() * 8, hipMemcpyHostToDevice, p->stream));
+            H2D_TRY(p, p->d_ecol_val.p, p->comp_identity.data(), p->comp_identity.size() * 8);
             a.comp_index = p->comp_index; a.n_others = (int32_t)p->comp_others.size();
             a.comp_others = p->d_ecol_tab.p; a.comp_identity = p->d_ecol_val.p;
             p->cached_kind = 0;
@@ -218,7 +218,7 @@ static int run_hprobs_analytic(gst_plan* p, double* d_H, int64_t ld1, int64_t ld
                 else if (k == GST_KIND_EFFECT && v > 0 && o == v - 1) { t[12 + q] = -1; t[16 + q] = el; }
             }
         }
-        HIP_TRY(hipMemcpyAsync(p->d_theta.p, th.data(), th.size() * 4, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_theta.p, th.data(), th.size() * 4);
         HIP_TRY(hipStreamSynchronize(p->stream));
         gst::DWalkArgs w;
         std::memset(&w, 0, sizeof(w));
@@ -363,9 +363,9 @@ static int run_hprobs_general(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2
     std::vector<double> w(c1.w);
     w.insert(w.end(), c2.w.begin(), c2.w.end());
     if (w.empty()) w.push_back(0.0);
-    if ((rc = upload_i32(p->d_hcsc, tab, p->stream))) return rc;
+    if ((rc = upload_i32(p, p->d_hcsc, tab))) return rc;
     HIP_TRY(p->d_hw.ensure(w.size()));
-    HIP_TRY(hipMemcpyAsync(p->d_hw.p, w.data(), w.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_hw.p, w.data(), w.size() * 8);
     HIP_TRY(gst::launch_hessian_chain_rule(p->d_helem.p, nE, (int)m1, (int)m2, p->d_hcsc.p + o_p1, p->d_hcsc.p + o_r1, p->d_hw.p,
                                            p->d_hcsc.p + o_d1, (int)n1, p->d_hcsc.p + o_p2, p->d_hcsc.p + o_r2,
                                            p->d_hw.p + c1.w.size(), p->d_hcsc.p + o_d2, (int)n2, d_H, ld1, ld2, p->stream));
@@ -396,7 +396,7 @@ static int run_hprobs_general(gst_plan* p, double* d_H, int64_t ld1, int64_t ld2
                 }
             }
             if (!any) continue;
-            if ((rc = upload_i32(p->d_dv_colmap, cmap, p->stream))) return rc;
+            if ((rc = upload_i32(p, p->d_dv_colmap, cmap))) return rc;
             HIP_TRY(gst::launch_chain_rule_gemm(p->d_jelem.p, n_el, a0, K, p->d_dv2.p + p->dv2_off[o], nc * nc, p->d_dv_colmap.p,
                                                 d_H, ld1 * ld2, nE, p->stream));
             p->last_launches++;

@@ -1039,7 +1039,7 @@ hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream)
 }
 
 #if GST_ANA_TIMING
-extern "C" int gst_debug_ana_phases(unsigned long long* out, int reset)
+extern "C" __attribute__((visibility("default"))) int gst_debug_ana_phases(unsigned long long* out, int reset)
 {
     if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(ana_dbg), z, sizeof(z)); }
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ana_dbg), 16 * sizeof(unsigned long long));

@@ -990,7 +990,7 @@ hipError_t launch_jtj_panel_masks(double* J, int64_t n_rows, int n_cols, int64_t
     return hipGetLastError();
 }
 #if GST_JTJ_TIMING
-extern "C" int gst_debug_jtj_phases(unsigned long long* out, int reset)
+extern "C" __attribute__((visibility("default"))) int gst_debug_jtj_phases(unsigned long long* out, int reset)
 {
     if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(jtj_dbg), z, sizeof(z)); }
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(jtj_dbg), 8 * sizeof(unsigned long long));

@@ -23,15 +23,15 @@ int lb_upload(gst_plan* p)
     std::vector<int64_t> i64;
     for (const auto* v : {&L.param0, &L.term_off, &L.static_off}) i64.insert(i64.end(), v->begin(), v->end());
     int rc;
-    if ((rc = upload_i32(p->d_lb_i32, i32, p->stream))) return rc;
+    if ((rc = upload_i32(p, p->d_lb_i32, i32))) return rc;
     HIP_TRY(p->d_lb_i64.ensure(i64.size()));
-    HIP_TRY(hipMemcpyAsync(p->d_lb_i64.p, i64.data(), i64.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_lb_i64.p, i64.data(), i64.size() * 8);
     HIP_TRY(p->d_lb_statics.ensure(L.statics.size()));
-    HIP_TRY(hipMemcpyAsync(p->d_lb_statics.p, L.statics.data(), L.statics.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_lb_statics.p, L.statics.data(), L.statics.size() * 8);
     HIP_TRY(p->d_lb_term_re.ensure(L.term_re.size()));
-    HIP_TRY(hipMemcpyAsync(p->d_lb_term_re.p, L.term_re.data(), L.term_re.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_lb_term_re.p, L.term_re.data(), L.term_re.size() * 8);
     HIP_TRY(p->d_lb_term_im.ensure(L.term_im.size()));
-    HIP_TRY(hipMemcpyAsync(p->d_lb_term_im.p, L.term_im.data(), L.term_im.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_lb_term_im.p, L.term_im.data(), L.term_im.size() * 8);
     HIP_TRY(p->d_lb_theta.ensure((size_t)std::max(L.n_params, 1)));
     HIP_TRY(p->d_lb_base.ensure(lb_set_stride(p)));
     HIP_TRY(p->d_lb_gates_rm.ensure(std::max<size_t>((size_t)p->hp.n_gates * p->hp.D * p->hp.D, 1)));
@@ -74,14 +74,14 @@ int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int
         gst::build_dirty_programs(h, p->dirty);
         HIP_TRY(p->d_dirty_words.ensure(p->dirty.words.size() + 64));
         HIP_TRY(hipMemsetAsync(p->d_dirty_words.p, 0, (p->dirty.words.size() + 64) * 4, p->stream));
-        HIP_TRY(hipMemcpyAsync(p->d_dirty_words.p, p->dirty.words.data(), p->dirty.words.size() * 4, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_dirty_words.p, p->dirty.words.data(), p->dirty.words.size() * 4);
         HIP_TRY(p->d_dirty_off.ensure(p->dirty.off.size()));
-        HIP_TRY(hipMemcpyAsync(p->d_dirty_off.p, p->dirty.off.data(), p->dirty.off.size() * 8, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_dirty_off.p, p->dirty.off.data(), p->dirty.off.size() * 8);
         HIP_TRY(hipStreamSynchronize(p->stream));
         p->dirty_ready = true;
     }
     if (!p->leaf_uploaded) {
-        if ((rc = upload_i32(p->d_circ_leaf, h.circ_leaf, p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_circ_leaf, h.circ_leaf))) return rc;
         p->leaf_uploaded = true;
     }
     if (!p->request_cached(5, param_idx, dest_idx, n_param)) {
@@ -152,10 +152,10 @@ int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int
         // wave tables: kind | obj | n_eff | col0 | ncols (n_pw each), then col_dest (n_param), then the zero-fill list
         std::vector<int32_t> tab;
         for (const auto* v : {&wk, &wo, &wn, &w0, &wc, &cdest, &zero_dest}) tab.insert(tab.end(), v->begin(), v->end());
-        if ((rc = upload_i32(p->d_lb_waves, tab, p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_lb_waves, tab))) return rc;
         p->lb_n_zero = (int32_t)zero_dest.size();
         HIP_TRY(p->d_lb_setparam.ensure(set_param.size()));
-        HIP_TRY(hipMemcpyAsync(p->d_lb_setparam.p, set_param.data(), set_param.size() * 8, hipMemcpyHostToDevice, p->stream));
+        H2D_TRY(p, p->d_lb_setparam.p, set_param.data(), set_param.size() * 8);
         HIP_TRY(p->d_lb_pert.ensure((size_t)n_param * D * D));
         // work items: (dirty program of (task, the wavefront's class), wavefront), expensive first; empty programs -- the task
         // never shows the member to an outcome -- are no items at all
@@ -174,12 +174,12 @@ int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int
         std::vector<int32_t> ipw(items.size());
         for (size_t i = 0; i < items.size(); i++) { iprog[i] = items[i].second.first; ipw[i] = items[i].second.second; }
         HIP_TRY(p->d_block_order.ensure(iprog.size() + 1));
-        if (!iprog.empty()) HIP_TRY(hipMemcpyAsync(p->d_block_order.p, iprog.data(), iprog.size() * 4, hipMemcpyHostToDevice, p->stream));
-        if ((rc = upload_i32(p->d_lb_item_pw, ipw, p->stream))) return rc;
+        if (!iprog.empty()) H2D_TRY(p, p->d_block_order.p, iprog.data(), iprog.size() * 4);
+        if ((rc = upload_i32(p, p->d_lb_item_pw, ipw))) return rc;
         p->lbr_n_waves = (int32_t)(rl_col.size() / 64);
         if (p->lbr_n_waves > 0) {
-            if ((rc = upload_i32(p->d_lbr_lane[0], rl_col, p->stream)) || (rc = upload_i32(p->d_lbr_lane[1], rl_kind, p->stream)) ||
-                (rc = upload_i32(p->d_lbr_lane[2], rl_obj, p->stream)) || (rc = upload_i32(p->d_lbr_lane[3], rl_elem, p->stream))) return rc;
+            if ((rc = upload_i32(p, p->d_lbr_lane[0], rl_col)) || (rc = upload_i32(p, p->d_lbr_lane[1], rl_kind)) ||
+                (rc = upload_i32(p, p->d_lbr_lane[2], rl_obj)) || (rc = upload_i32(p, p->d_lbr_lane[3], rl_elem))) return rc;
             // (task, wavefront) pairs, longest programs first: every pair walks its whole task
             std::vector<int64_t> order((size_t)nT);
             for (int64_t t = 0; t < nT; t++) order[(size_t)t] = t;
@@ -188,7 +188,7 @@ int run_dprobs_lindblad_shared(gst_plan* p, double* d_out, int64_t ld, const int
             bo.reserve((size_t)nT * p->lbr_n_waves);
             for (int64_t t : order) for (int32_t w = 0; w < p->lbr_n_waves; w++) bo.push_back((uint32_t)(t * p->lbr_n_waves + w));
             HIP_TRY(p->d_lbr_order.ensure(bo.size() + 1));
-            HIP_TRY(hipMemcpyAsync(p->d_lbr_order.p, bo.data(), bo.size() * 4, hipMemcpyHostToDevice, p->stream));
+            H2D_TRY(p, p->d_lbr_order.p, bo.data(), bo.size() * 4);
         }
         HIP_TRY(hipStreamSynchronize(p->stream));          // the host vectors go out of scope
         p->lb_n_pwaves = n_pw;
@@ -263,7 +263,7 @@ int run_dprobs_lindblad(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     HIP_TRY(p->d_mm_models.ensure((size_t)chunk * stride));
     HIP_TRY(p->d_mm_raw.ensure((size_t)chunk * (size_t)std::max<int64_t>(nE, 1)));
     HIP_TRY(p->d_lb_setparam.ensure((size_t)n_param));
-    HIP_TRY(hipMemcpyAsync(p->d_lb_setparam.p, param_idx, (size_t)n_param * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_lb_setparam.p, param_idx, (size_t)n_param * 8);
     std::vector<int32_t> dest32;
     if (dest_idx) {
         dest32.resize((size_t)n_param);
@@ -271,7 +271,7 @@ int run_dprobs_lindblad(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
             if (dest_idx[m] < 0 || dest_idx[m] >= ld) return fail(GST_EINVAL, "destination column out of range");
             dest32[(size_t)m] = (int32_t)dest_idx[m];
         }
-        if ((rc = upload_i32(p->d_mm_dest, dest32, p->stream))) return rc;
+        if ((rc = upload_i32(p, p->d_mm_dest, dest32))) return rc;
     } else if (n_param > ld) return fail(GST_EINVAL, "more columns than the leading dimension");
     HIP_TRY(hipStreamSynchronize(p->stream));              // (param_idx / dest32 are the caller's / a local)
     TIME_REC(p, evk0);
@@ -327,8 +327,8 @@ int run_dprobs_lindblad_analytic(gst_plan* p, double* d_out, int64_t ld, const i
     p->dv2_set = false; p->dv2_off.clear();
     HIP_TRY(p->d_dv_deriv.ensure((size_t)std::max<int64_t>(doff, 1)));
     HIP_TRY(p->d_lb_setparam.ensure(set_param.size() + member_off.size()));
-    HIP_TRY(hipMemcpyAsync(p->d_lb_setparam.p, set_param.data(), set_param.size() * 8, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->d_lb_setparam.p + set_param.size(), member_off.data(), member_off.size() * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_lb_setparam.p, set_param.data(), set_param.size() * 8);
+    H2D_TRY(p, p->d_lb_setparam.p + set_param.size(), member_off.data(), member_off.size() * 8);
     gst::LbArgs a;
     lb_args(p, a);
     a.set_param = p->d_lb_setparam.p; a.deriv_out = p->d_dv_deriv.p; a.deriv_off = p->d_lb_setparam.p + set_param.size(); a.eps = 0.0;
@@ -434,7 +434,7 @@ int gst_set_lindblad_params(gst_plan* p, const double* theta)
     if ((rc = lb_upload(p))) return rc;
     gst_plan::Lindblad& L = p->lb;
     L.theta.assign(theta, theta + L.n_params);
-    HIP_TRY(hipMemcpyAsync(p->d_lb_theta.p, L.theta.data(), (size_t)L.n_params * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_lb_theta.p, L.theta.data(), (size_t)L.n_params * 8);
     gst::LbArgs a;
     lb_args(p, a);
     a.set_param = nullptr; a.sets = p->d_lb_base.p; a.gates_rowmajor = p->d_lb_gates_rm.p; a.eps = 0.0;
@@ -444,9 +444,9 @@ int gst_set_lindblad_params(gst_plan* p, const double* theta)
     const size_t ng = (size_t)p->hp.n_gates * D * D, nr = (size_t)p->hp.n_rhos * D, ne = (size_t)p->hp.n_effects * D;
     std::vector<double> set(ng + nr + ne);
     p->h_gates.resize(ng);
-    HIP_TRY(hipMemcpyAsync(set.data(), p->d_lb_base.p, set.size() * 8, hipMemcpyDeviceToHost, p->stream));
-    if (ng) HIP_TRY(hipMemcpyAsync(p->h_gates.data(), p->d_lb_gates_rm.p, ng * 8, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    int rc2 = d2h_bytes(p, set.data(), p->d_lb_base.p, set.size() * 8);
+    if (!rc2 && ng) rc2 = d2h_bytes(p, p->h_gates.data(), p->d_lb_gates_rm.p, ng * 8);
+    if (rc2) return rc2;
     p->h_gates_t.assign(set.begin(), set.begin() + (long)ng);
     p->h_rhos.assign(set.begin() + (long)ng, set.begin() + (long)(ng + nr));
     p->h_effects.assign(set.begin() + (long)(ng + nr), set.end());
@@ -471,7 +471,7 @@ int gst_get_lindblad_model_sets(gst_plan* p, const int64_t* param_idx, int64_t n
     const size_t ng = (size_t)p->hp.n_gates * D * D, nr = (size_t)p->hp.n_rhos * D, ne = (size_t)p->hp.n_effects * D, stride = ng + nr + ne;
     HIP_TRY(p->d_mm_models.ensure((size_t)n_param * stride));
     HIP_TRY(p->d_lb_setparam.ensure((size_t)n_param));
-    HIP_TRY(hipMemcpyAsync(p->d_lb_setparam.p, param_idx, (size_t)n_param * 8, hipMemcpyHostToDevice, p->stream));
+    H2D_TRY(p, p->d_lb_setparam.p, param_idx, (size_t)n_param * 8);
     gst::LbArgs a;
     lb_args(p, a);
     a.set_param = p->d_lb_setparam.p; a.sets = p->d_mm_models.p; a.eps = eps;

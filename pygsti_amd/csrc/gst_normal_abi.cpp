@@ -135,8 +135,7 @@ int gst_objective_rows_dev(gst_plan* p, const gst_objective_desc* d, double* d_p
                                        d->prob_clip_hi, d_lsvec, d_rowscale, d_terms, p->d_obj_part.p, n_blocks, p->stream));
     if (sum_terms) {
         std::vector<double> part((size_t)n_blocks);
-        HIP_TRY(hipMemcpyAsync(part.data(), p->d_obj_part.p, part.size() * 8, hipMemcpyDeviceToHost, p->stream));
-        HIP_TRY(hipStreamSynchronize(p->stream));
+        if ((rc = d2h_bytes(p, part.data(), p->d_obj_part.p, part.size() * 8))) return rc;
         double s = 0.0;
         for (double x : part) s += x;
         *sum_terms = s;

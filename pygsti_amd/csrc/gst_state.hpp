@@ -127,6 +127,10 @@ struct gst_plan {
     // page-locked staging for copies between device memory and PAGEABLE caller memory (gst_abi.cpp: d2h_bytes & co.)
     char* h_stage = nullptr;
     size_t h_stage_bytes = 0;
+    // page-locked upload ring (h2d_async): the library's own tables and small caller arrays are copied INTO it at call time and
+    // leave it asynchronously on `stream`; a wrap waits for the stream
+    char* h_up = nullptr;
+    size_t h_up_bytes = 0, h_up_at = 0;
     int upload_turn = 0;
     bool model_dirty = true;
     // parameter map
@@ -343,6 +347,8 @@ struct gst_plan {
         d_model.release();
         if (h_stage) (void)hipHostFree(h_stage);
         h_stage = nullptr; h_stage_bytes = 0;
+        if (h_up) (void)hipHostFree(h_up);
+        h_up = nullptr; h_up_bytes = 0;
         for (int i = 0; i < 2; i++) {
             if (h_model_pinned[i]) (void)hipHostFree(h_model_pinned[i]);
             if (ev_upload[i]) (void)hipEventDestroy(ev_upload[i]);
@@ -386,7 +392,7 @@ int run_levels_forward(gst_plan* p, double* d_dst, bool probs_only = false);
 int run_probs_any(gst_plan* p, double* d_dst);
 void pack_lanes(const gst_plan* p, const int64_t* param_idx, const int64_t* dest_idx, int64_t n, LaneLayout& L, bool keep_lane63_idle = false);
 void pack_waves(const gst_plan* p, const int64_t* param_idx, const int64_t* dest_idx, int64_t n, LaneLayout& L);
-int upload_i32(DevBuf<int32_t>& b, const std::vector<int32_t>& v, hipStream_t s);
+int upload_i32(gst_plan* p, DevBuf<int32_t>& b, const std::vector<int32_t>& v);
 size_t jac_extent(int64_t n_rows, int64_t ld, const int64_t* dest_idx, int64_t n_param);
 int64_t nE_total(const gst_plan* p);
 int stage_out(gst_plan* p, size_t count, bool keeps_claims = false);
@@ -413,13 +419,23 @@ int run_dprobs_lindblad_analytic(gst_plan* p, double* d_out, int64_t ld, const i
 
 // device address of a host pointer inside a region registered with gst_host_register, or NULL (gst_abi.cpp)
 void* mapped_device_pointer(const void* ptr, size_t bytes);
-// Copies between device memory and the CALLER's host memory (gst_abi.cpp).  A destination / source inside a region the caller
-// page-locked with gst_host_register is copied directly (asynchronous, on the plan's stream); anything else goes through the
-// plan's own page-locked staging buffer and a host memcpy, complete on return.  The device never touches pageable caller
-// memory: the runtime's lock-on-the-fly of arbitrary heap ranges is what a rare "Memory access fault ... Reason: Unknown" on a
-// host-heap address was traced to.
+// EVERY copy between device memory and host memory that is not the library's own page-locked allocation goes through these
+// (gst_abi.cpp; tests/test_abi_and_rules.py greps the sources for any other hipMemcpy* with a host side).  A destination /
+// source inside a region the caller page-locked with gst_host_register is copied directly (asynchronous, on the plan's
+// stream); anything else goes through the plan's own page-locked buffers and a host memcpy.  The device never touches pageable
+// memory -- the caller's or the library's own heap vectors: the runtime's lock-on-the-fly of arbitrary heap ranges is what a
+// rare "Memory access fault ... Reason: Unknown" on a host-heap address was traced to.
+//   d2h_bytes / d2h_rows / h2d_bytes  complete on return (staging buffer + memcpy)
+//   h2d_async                         the source is consumed on return (copied into the upload ring), the device copy is
+//                                     asynchronous on p->stream; sources above half the ring take h2d_bytes
 int d2h_bytes(gst_plan* p, void* dst, const void* d_src, size_t bytes);
 int h2d_bytes(gst_plan* p, void* d_dst, const void* src, size_t bytes);
+int h2d_async(gst_plan* p, void* d_dst, const void* src, size_t bytes);
 int d2h_rows(gst_plan* p, double* dst, int64_t dst_ld, const double* d_src, int64_t src_ld, int64_t n_rows, int64_t n_cols);
+#define H2D_TRY(p, dst, src, bytes)                                              \
+    do {                                                                         \
+        int rc_h2d_ = gst_impl::h2d_async((p), (dst), (src), (bytes));           \
+        if (rc_h2d_) return rc_h2d_;                                             \
+    } while (0)
 
 }  // namespace gst_impl

@@ -20,6 +20,45 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.gst_version()
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """-fvisibility=hidden + GST_API: the dynamic symbol table's FUNCTIONS are the header's entry points, no C++ internals
+    (what remains beside them: weak std:: template instances, and the kernel handle objects hipcc emits per __global__)."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "gstfwd.h")).read()
+    declared = set(re.findall(r"\b(gst_[a-z0-9_]+)\s*\(", hdr))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    funcs, others = set(), []
+    for line in out.splitlines():
+        parts = line.split()
+        if len(parts) != 3:
+            continue
+        kind, name = parts[1], parts[2]
+        if kind in ("T", "t"):
+            funcs.add(name)
+        elif kind in ("W", "w"):
+            others.append(name)
+    assert funcs == declared, funcs ^ declared
+    assert all(n.startswith(("_ZNSt", "_ZNKSt", "_ZSt", "_ZN9__gnu_cxx", "_ZNK9__gnu_cxx", "_ZTSSt", "_ZTISt", "_ZTVSt", "_ZGVZNKSt", "_ZZNKSt"))
+               for n in others), [n for n in others if "St" not in n[:8]][:10]
+
+
+def test_every_host_copy_goes_through_the_staging_helpers():
+    """the device never touches pageable host memory -- every hipMemcpy* with a host side lives in the four helpers of
+    gst_abi.cpp (d2h_bytes, h2d_bytes, h2d_async, d2h_rows), the model upload from its own page-locked buffers, and the
+    staged row copy of copy_out_dprobs."""
+    src_dir = os.path.join(ROOT, "pygsti_amd", "csrc")
+    for f in sorted(os.listdir(src_dir)):
+        if not f.endswith((".cpp", ".hpp", ".hip")):
+            continue
+        for i, line in enumerate(open(os.path.join(src_dir, f)).read().splitlines(), 1):
+            if not re.search(r"\bhipMemcpy\w*\(", line) or line.lstrip().startswith("//"):
+                continue
+            if "hipMemcpyDeviceToDevice" in line or "Symbol(" in line:     # (symbol copies: the phase timers of the development builds)
+                continue
+            assert f == "gst_abi.cpp" and re.search(r"h_stage|h_up|h_model_pinned|\bh, total|mapped|\(dst, d_src|\(d_dst, src|hipMemcpy2DAsync\(dst", line) or \
+                (f == "gst_comm.cpp" and "peer" in line), "%s:%d: %s" % (f, i, line.strip())
+
+
 def _no_gpu():
     return _lib.device_count() == 0
 
