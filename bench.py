@@ -235,6 +235,28 @@ def self_launch(n):
     return rc
 
 
+def fd_roofline(flops_schedule, fd_exec, k_ms, jac_bytes, traffic):
+    """The `roofline` object of the FD headline.  `frac` prices what the kernel ISSUES (gst_get_fd_work walks the plan's
+    programs with the kernel's own clean/dirty rule) against the dense fp64 peak; the reference schedule's flops (SURVEY 8(d):
+    nP*(2*D^2*A + 2*D*nE), 42 % of which the kernel skips as provably bit-identical to the base pass) are `frac_schedule`.
+    Flat scalars and short strings only: the driver's record keeps those."""
+    sec = k_ms * 1e-3
+    issued = fd_exec["issued_flops_per_launch"] if fd_exec else flops_schedule
+    r = {"bound": "mfma", "compute_unit": "valu_f64", "kernel": "walk_kernel<16,1>",
+         "achieved": issued / sec / 1e12, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": issued / sec / 1e12 / F64_VALU_PEAK_TFLOPS,
+         "frac_schedule": flops_schedule / sec / 1e12 / F64_VALU_PEAK_TFLOPS,
+         "frac_of_unfused_ceiling": issued / sec / 1e12 / (0.5 * F64_VALU_PEAK_TFLOPS),
+         "kernel_ms": k_ms, "flops_per_launch": issued, "flops_schedule_per_launch": flops_schedule,
+         "executed_over_schedule": (fd_exec or {}).get("executed_over_schedule"),
+         "mul_add_share_of_pmc_valu": (fd_exec or {}).get("mul_add_share_of_pmc_valu"),
+         "hbm_write_GBps": jac_bytes / sec / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS, "traffic": traffic,
+         "bound_note": "compute roof = dense fp64 78.6 TFLOP/s (MFMA and vector FMA alike); the walk runs on the fp64 VALU",
+         "note": "frac = issued mul+add flops (no FMA: bit parity, own ceiling 0.5); frac_schedule = SURVEY 8(d) flops incl. skipped",
+         "executed": fd_exec}
+    return r
+
+
 _T0 = time.perf_counter()
 
 
@@ -498,6 +520,9 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "note": "algorithmic bytes = the Jacobian write 8*nE*nP; the kernel gathers forward and backward state vectors (20 GB of L2 traffic, of which the PMC `traffic` figure is what reaches HBM)",
                     "kernel_ms": k_ms, "bytes_per_launch": jac_bytes, "traffic": measured_traffic("analytic_mfma_kernel")}
+            if roof["traffic"]:
+                roof["traffic_over_algorithmic"] = roof["traffic"] / jac_bytes
+                roof["traffic_frac_of_peak"] = roof["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         else:
             roof = None
         fd_exec = None
@@ -558,19 +583,28 @@ def main():
                                "achieved": (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local) / (dtp / n_pr) / 1e12,
                                "frac": (2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE_local) / (dtp / n_pr) / 1e12 / F64_VALU_PEAK_TFLOPS,
                                "note": "one probability pass is a latency chain -- %d tasks of ~%d dependent mat-vecs on 1,024 SIMDs, 221 ns per step -- not a throughput kernel: the fraction of the compute roof SURVEY 8(d) names is what bit-exact sequential order leaves" % (st["n_tasks"], st["applies_per_pass"] // max(st["n_tasks"], 1))},
-            "roofline": roof or {"bound": "mfma", "compute_unit": "valu_f64",
-                         "bound_note": "the compute roof (\"mfma\" in this line's vocabulary): dense fp64 peak 78.6 TFLOP/s, which on MI355X is both the MFMA and the vector-FMA rate. The kernel runs on the fp64 VECTOR ALU -- no matrix instruction can reproduce the reference's un-fused, ordered sums -- so `frac` is against the roof the contract names and `compute_unit` says which pipe does the work",
-                         "kernel": "walk_kernel<16,1>", "achieved": flops / (k_ms * 1e-3) / 1e12,
-                         "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / (k_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
-                         "note": "flops = the reference schedule's nP*(2*D^2*A + 2*D*nE) (SURVEY 8(d)); `executed` = what the kernel issues after skipping every state that is provably bit-identical to the base pass (measured from the plan's programs by gst_get_fd_work, not assumed), as separate v_mul_f64 + v_add_f64 (no FMA: bitwise parity), whose own ceiling is 0.5 of the FMA peak: `frac_of_unfused_ceiling`",
-                         "executed": fd_exec,
-                         "kernel_ms": k_ms, "flops_per_launch": flops,
-                         "hbm_write_GBps": jac_bytes / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
-                         "traffic": measured_traffic("walk_kernel<16, 1")},
+            "roofline": roof or fd_roofline(flops, fd_exec, k_ms, jac_bytes, measured_traffic("walk_kernel<16, 1")),
             "plan": {k: st[k] for k in ("n_circuits", "n_elements", "sum_depth", "trie_nodes", "applies_per_pass",
                                         "n_tasks", "prog_words", "max_slots")},
         }
+        # flat copies of the figures a reader should not have to open profiles/ for, inside the objects the driver's record keeps
+        rf = out["roofline"]
+        if ana_info and ana_info.get("roofline"):
+            ar = ana_info["roofline"]
+            tr = measured_traffic("analytic_mfma_kernel")
+            rf["analytic_kernel"] = "analytic_mfma_kernel"
+            rf["analytic_kernel_ms"] = ana_info["kernel_ms"]
+            rf["analytic_frac_hbm"] = ar["frac"]
+            rf["analytic_whole_step_frac_hbm"] = ar["whole_step_frac"]
+            rf["analytic_bytes_algorithmic"] = ar["bytes_per_launch"]
+            rf["analytic_traffic"] = tr
+            rf["analytic_traffic_frac_of_peak"] = (tr / (ana_info["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr and ana_info["kernel_ms"] else None
+            rf["analytic_zeros_resident"] = ana_info["structural_zeros"].startswith("resident")
+        if host_fill:
+            out["config"]["host_fill_elements_per_s"] = host_fill.get("elements_per_s")
+            out["config"]["host_fill_ms"] = host_fill.get("ms")
+        if lm_info:
+            out["config"]["lm_step_ms"] = lm_info.get("ms_per_step")
         if world == 1 and not args.no_cpu_baseline:
             pctx = None
             if lay_world == 1 and args.deriv == "fd":
@@ -582,6 +616,17 @@ def main():
                         "param_map": layout.param_map(model),
                         "cols": parity_columns(D, len(gates), len(effects), nP)}
             out["cpu_baseline"], out["cpu_baseline_allcores"], out["parity"] = cpu_baseline(pack, model, args.max_len, args.design, pctx)
+            cb = out["cpu_baseline"]
+            if out["parity"]:
+                cb["parity_bitwise"] = out["parity"]["bitwise"]
+                cb["parity_rows_x_cols"] = "%d x %d" % (out["parity"]["n_rows"], out["parity"]["n_cols"])
+            cb["allcores_value"] = out["cpu_baseline_allcores"]["value"]
+            cb["allcores_cores"] = out["cpu_baseline_allcores"]["cores"]
+            # the REAL Cython path (BASELINE.md / SURVEY App. C: probed in the build container, 1 Xeon core @2.1 GHz, lite design,
+            # per-column model.set_parameter_value Python included) -- context for the C++-reps-under-a-restated-loop figure above
+            cb["reference_cython_probe_value"] = 1.66e6
+            cb["reference_cython_probe_note"] = "BASELINE.md: real Cython bulk_fill_dprobs, 2Q L<=1024 lite, 1 core, build container"
+            cb["driver_loop"] = "restated (oracle/ref_driver.cpp) over the reference's own C++ reps; no per-column Python"
             log("cpu baseline done")
         print(json.dumps(out))
     plan.device_free(d_out)

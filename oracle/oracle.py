@@ -33,11 +33,52 @@ class _Model(C.Structure):
                 ("nP", C.c_int32), ("pkind", C.c_void_p), ("pobj", C.c_void_p), ("pelem", C.c_void_p)]
 
 
+REF_SO = os.path.join(HERE, "_ref", "libgst_ref.so")
+REF_HASH = os.path.join(HERE, "ref_build.sha256")      # tracked: the hash of the library `make _ref` produced where /root/reference exists
+
+
+def _sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 def build(ref=True):
-    """Compile liboracle.so (always) and _ref/libgst_ref.so (when /root/reference is present)."""
+    """Compile liboracle.so (always) and _ref/libgst_ref.so (when /root/reference is present).  Where the reference build
+    happens its hash is recorded in oracle/ref_build.sha256 (committed); everywhere else -- the GPU box, where the library
+    arrives prebuilt and cannot be rebuilt -- `verify_ref()` checks the shipped binary against that record."""
     subprocess.check_call(["make", "-s", "-C", HERE])
     if ref and os.path.isdir("/root/reference/pygsti/evotypes/densitymx"):
         subprocess.check_call(["make", "-s", "-C", HERE, "_ref"])
+        digest = _sha256(REF_SO)
+        have = open(REF_HASH).read().split()[0] if os.path.exists(REF_HASH) else None
+        if have != digest:
+            with open(REF_HASH, "w") as f:
+                f.write(digest + "  oracle/_ref/libgst_ref.so  (g++ -O3 -std=c++11 -ffp-contract=off, oracle/Makefile)\n")
+
+
+_ref_verified = None
+
+
+def verify_ref():
+    """True when oracle/_ref/libgst_ref.so is the binary oracle/ref_build.sha256 records (checked once per process); raises
+    when a library is present that is NOT that binary -- a "reference"-kind check must never run on something else."""
+    global _ref_verified
+    if _ref_verified is None:
+        if not os.path.exists(REF_SO):
+            _ref_verified = False
+        elif not os.path.exists(REF_HASH):
+            raise RuntimeError("oracle/_ref/libgst_ref.so exists but oracle/ref_build.sha256 does not: rebuild with oracle.build()")
+        else:
+            want = open(REF_HASH).read().split()[0]
+            got = _sha256(REF_SO)
+            if want != got:
+                raise RuntimeError("oracle/_ref/libgst_ref.so (sha256 %s) is not the build recorded in oracle/ref_build.sha256 (%s)" % (got[:16], want[:16]))
+            _ref_verified = True
+    return _ref_verified
 
 
 def _ptr(a):
@@ -53,6 +94,8 @@ class Oracle:
         path = os.path.join(HERE, "liboracle.so") if kind == "port" else os.path.join(HERE, "_ref", "libgst_ref.so")
         if not os.path.exists(path):
             raise RuntimeError("oracle library %s is not built (run oracle.build())" % path)
+        if kind != "port":
+            verify_ref()
         self.kind = kind
         self.lib = C.CDLL(path)
         self.prefix = "oracle_" if kind == "port" else "ref_"

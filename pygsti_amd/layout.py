@@ -226,8 +226,17 @@ class HipCOPALayout:
         self.param_slices = _slice_up_range(self._num_params, np1)          # matches the param-processor indices
         self.param2_slices = _slice_up_range(self._num_params, np2)
         self.max_param_slice_length = max(s.stop - s.start for s in self.param_slices)
-        # one process per GPU: atom-processor k owns atoms k, k+na, ... (all of them when there is one)
-        self.atoms = [at for a, at in enumerate(atoms) if a % na == self.atom_proc_index]
+        # one process per GPU: atom-processor k owns a SEQUENTIAL block of atoms (distribute_indices_base + _assert_sequential,
+        # distlayout.py:327-329 / mpitools.py:191-215: the first `natoms mod na` processors get one atom more), so that its rows
+        # are one contiguous range [off_k, off_k + nE_k) of the global element dimension
+        self._atom_proc = np.empty(len(atoms), np.int64)
+        for g, sl in enumerate(_slice_up_range(len(atoms), na)):
+            self._atom_proc[sl] = g
+        self.atoms = [at for a, at in enumerate(atoms) if self._atom_proc[a] == self.atom_proc_index]
+        mine = [a for a in range(len(atoms)) if self._atom_proc[a] == self.atom_proc_index]
+        assert mine == list(range(mine[0], mine[0] + len(mine))), "an atom-processor's atoms must be sequential"
+        assert all(self.atoms[i].element_slice.stop == self.atoms[i + 1].element_slice.start for i in range(len(self.atoms) - 1))
+        self.local_element_slice = slice(self.atoms[0].element_slice.start, self.atoms[-1].element_slice.stop)   # this rank's rows
         self.num_elements = self.global_num_elements   # arrays are allocated full-size; see allocate_local_array
         self.host_element_slice = slice(0, self.global_num_elements)
         self.global_param_slice = self.param_slices[self.param_proc_index]
@@ -368,7 +377,7 @@ class HipCOPALayout:
     def atom_owner_rank(self, atom_index):
         """The first rank of the atom-processor that holds atom `atom_index` (the one that contributes its rows to
         element-only gathers; its peers hold the same rows)."""
-        return self.rank_of(atom_index % self.processor_grid[0])
+        return self.rank_of(int(self._atom_proc[atom_index]))
 
     def owned_blocks(self, array_type, rank):
         """[(row start, row stop, col slice or None, col2 slice or None)]: the blocks of a full-size local array of
@@ -382,10 +391,10 @@ class HipCOPALayout:
             return []
         c1 = None if dims == 0 else (self.param2_slices[ip2] if array_type == "ep2" else self.param_slices[ip1])
         c2 = self.param2_slices[ip2] if dims == 2 else None
-        return [(at.element_slice.start, at.element_slice.stop, c1, c2) for a, at in enumerate(self.all_atoms) if a % na == ia]
+        return [(at.element_slice.start, at.element_slice.stop, c1, c2) for a, at in enumerate(self.all_atoms) if self._atom_proc[a] == ia]
 
     def atoms_of_processor(self, atom_proc):
-        return [at for a, at in enumerate(self.all_atoms) if a % self.processor_grid[0] == atom_proc]
+        return [at for a, at in enumerate(self.all_atoms) if self._atom_proc[a] == atom_proc]
 
     def column_exchange_blocks(self, k):
         """Block list of gst_comm_exchange_blocks for round k of the column-distributed normal equations: every

@@ -42,8 +42,11 @@ def _worker(rank, size, port, q):
     g_root = lay.gather_local_array("ep", arr)
     ok_root = ok_root and np.array_equal(g_all, full.numpy()) and ((g_root is None) if rank != 0 else np.array_equal(g_root, g_all))
     blocks = gdist.row_blocks(lay, size)
-    ok_root = ok_root and [b[0] for b in blocks] == [a % size for a in range(len(lay.all_atoms))] \
-        and sum(b[2] for b in blocks) == lay.global_num_elements
+    # sequential dealing (distlayout.py:327-329): 4 atoms on 2 ranks -> owners 0 0 1 1, a rank's rows one contiguous range
+    ok_root = ok_root and [b[0] for b in blocks] == [a * size // len(lay.all_atoms) for a in range(len(lay.all_atoms))] \
+        and sum(b[2] for b in blocks) == lay.global_num_elements \
+        and lay.local_element_slice == slice(lay.atoms[0].element_slice.start, lay.atoms[-1].element_slice.stop) \
+        and sum(a.num_elements for a in lay.atoms) == lay.local_element_slice.stop - lay.local_element_slice.start
     part = np.full(3, float(rank + 1)); gdist.allreduce_sum_host(part)
     ok_root = ok_root and np.array_equal(part, np.full(3, 3.0)) and ctx.max_over_ranks(rank) == 1.0
     q.put((rank, full.numpy(), ok_root, [(a.element_slice.start, a.element_slice.stop) for a in lay.atoms]))
@@ -83,7 +86,7 @@ def test_two_rank_sharding_and_gather():
     assert np.array_equal(full0[:, 2], np.arange(lay.num_elements))
     owners = full0[:, 1]
     for a, at in enumerate(lay.all_atoms):
-        assert (owners[at.element_slice] == a % 2).all()
+        assert (owners[at.element_slice] == a // 2).all()          # sequential blocks: atoms 0,1 -> rank 0; 2,3 -> rank 1
 
 
 def _grid_worker(rank, size, port, q, grid, n_atoms):
@@ -115,7 +118,7 @@ def _grid_worker(rank, size, port, q, grid, n_atoms):
         if t == "ep":       # whole rows of the rank's own atoms (what fill_jtj contracts), other atom-processors' rows untouched
             comp = lay._complete_columns(loc)
             for a, at in enumerate(lay.all_atoms):
-                mine = a % lay.processor_grid[0] == lay.atom_proc_index
+                mine = lay._atom_proc[a] == lay.atom_proc_index
                 ok = ok and (np.array_equal(comp[at.element_slice], full[at.element_slice]) if mine else np.isnan(comp[at.element_slice]).all())
     shares = [(lay._row_share(at).start, lay._row_share(at).stop) for at in lay.atoms]
     q.put((rank, ok, shares, [(at.element_slice.start, at.element_slice.stop) for at in lay.atoms]))

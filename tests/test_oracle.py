@@ -178,3 +178,22 @@ def test_deep_cptplnd_fixtures(oracle_built, name, jtol):
         err = np.abs(J - fx["dprobs_map"])
         assert err.max() <= 1e-8, err.max()
         assert depth.max() >= 1030
+
+
+def test_shipped_reference_build_is_the_recorded_one(oracle_built, tmp_path, monkeypatch):
+    """oracle/_ref cannot be rebuilt where /root/reference does not exist (the GPU box): a "reference"-kind checker only runs
+    on the binary whose hash the build container recorded (oracle/ref_build.sha256), and refuses anything else."""
+    import shutil
+    O = oracle_built
+    if not os.path.exists(O.REF_SO):
+        pytest.skip("oracle/_ref is not built here")
+    monkeypatch.setattr(O, "_ref_verified", None)
+    assert O.verify_ref() is True
+    fake = tmp_path / "libgst_ref.so"
+    shutil.copy(O.REF_SO, fake)
+    with open(fake, "ab") as f:
+        f.write(b"\0")
+    monkeypatch.setattr(O, "REF_SO", str(fake))
+    monkeypatch.setattr(O, "_ref_verified", None)
+    with pytest.raises(RuntimeError, match="not the build recorded"):
+        O.verify_ref()
