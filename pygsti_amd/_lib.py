@@ -562,7 +562,9 @@ class Plan:
 
     def fill_normal_eqs_dev(self, d_J, n_rows, n_cols, ld, d_row_scale=None, d_f=None, d_jtj=None, d_jtf=None):
         """(diag(w) J)^T (diag(w) J) -> d_jtj and/or (diag(w) J)^T f -> d_jtf with the weights applied on the fly: d_J is
-        only read (gst_fill_normal_eqs_dev); same bits as fill_jtj_dev(..., d_row_scale) + fill_jtf_dev."""
+        only read (gst_fill_normal_eqs_dev).  d_jtj has the bits of fill_jtj_dev(..., d_row_scale); d_jtf has the bits of fill_jtf_dev
+        EXCEPT on the block-sparse path (>= 16,384 rows, > 384 columns, both outputs requested), where the pass that marks
+        the live panels also carries J_s^T f: deterministic, but another fixed summation order (include/gstfwd.h)."""
         vp = lambda x: None if x is None else C.c_void_p(int(x))
         check(lib().gst_fill_normal_eqs_dev(self._h, C.c_void_p(int(d_J)), int(n_rows), int(n_cols), int(ld), vp(d_row_scale),
                                             vp(d_f), vp(d_jtj), vp(d_jtf)))

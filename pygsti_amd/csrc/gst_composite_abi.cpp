@@ -79,7 +79,7 @@ static void cmp_args(gst_plan* p, gst::CompositeArgs& a)
 // The plan's parameter map (SPAM columns) on the device for the builder; parameters of the leaves carry GST_KIND_NONE there.
 static int cmp_upload_pmap(gst_plan* p, gst::CompositeArgs& a)
 {
-    if (!p->have_pmap || (int64_t)p->pkind.size() != p->cmp.n_params) return GST_OK;      // (no map: SPAM columns stay at the base model)
+    if (!p->have_pmap || (int64_t)p->pkind.size() != p->cmp.n_params) return GST_OK;      // (refused earlier: cmp_require_pmap)
     std::vector<int32_t> v;
     v.insert(v.end(), p->pkind.begin(), p->pkind.end());
     v.insert(v.end(), p->pobj.begin(), p->pobj.end());
@@ -91,6 +91,16 @@ static int cmp_upload_pmap(gst_plan* p, gst::CompositeArgs& a)
     return GST_OK;
 }
 
+// The SPAM parameters of an implicit model are described by the plan's parameter map (GST_KIND_NONE for the leaves' own and
+// for parameters of objects the atom never applies).  Without a map of the model's size the SPAM columns would silently come
+// out as zeros: refuse instead.
+static int cmp_require_pmap(const gst_plan* p)
+{
+    if (p->have_pmap && (int64_t)p->pkind.size() == p->cmp.n_params) return GST_OK;
+    return fail(GST_ESTATE, "gst_set_composite is active: gst_set_param_map must describe the model's " + std::to_string(p->cmp.n_params) +
+                            " parameters (SPAM elements; GST_KIND_NONE elsewhere) before a Jacobian is requested");
+}
+
 // FD Jacobian columns of an implicit model: the device builds the complete dense model after every parameter step and walks
 // every (program, model set) pair (the whole-model walk of gst_fill_dprobs_models, fed from device memory).
 int run_dprobs_composite(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx, int64_t n_param,
@@ -99,6 +109,7 @@ int run_dprobs_composite(gst_plan* p, double* d_out, int64_t ld, const int64_t* 
     const gst::HostPlan& h = p->hp;
     const int64_t nE = h.n_elements, nT = h.n_tasks();
     if (!p->cmp.have_values) return fail(GST_ESTATE, "gst_set_composite_values has not been called");
+    if (int rcp = cmp_require_pmap(p)) return rcp;
     if (!(eps != 0.0)) return fail(GST_EINVAL, "eps must be non-zero");
     if (p->cmp.any_general && (!p->cmp.have_general_fd || p->cmp.general_fd_eps != eps))
         return fail(GST_ESTATE, "general leaves: gst_set_composite_general must supply the leaves' finite-difference values for this eps");
@@ -155,6 +166,7 @@ int run_dprobs_composite_analytic(gst_plan* p, double* d_out, int64_t ld, const 
     const int D = h.D;
     gst_plan::Composite& C = p->cmp;
     if (!C.have_values) return fail(GST_ESTATE, "gst_set_composite_values has not been called");
+    if (int rcp = cmp_require_pmap(p)) return rcp;
     if (C.any_general && !C.have_general_derivs)
         return fail(GST_ESTATE, "general leaves: gst_set_composite_general must supply the leaves' derivative matrices");
     std::vector<int32_t> kind, obj, ncols;

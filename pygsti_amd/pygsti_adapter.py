@@ -316,6 +316,7 @@ def atom_composite(model, atom):
         raise NotImplementedError("composite layers are built on the device for one to three qubits")
     nq = {4: 1, 16: 2, 64: 3}[D]
     leaves, leaf_dims, leaf_params, leaf_static, leaf_general = {}, [], [], [], []
+    derivs_ok = [True]
 
     def leaf_of(op):
         key = id(op)
@@ -332,6 +333,10 @@ def atom_composite(model, atom):
                 idx = np.asarray(op.gpindices_as_array(), np.int64)
                 if len(idx) == 0 or len(set(idx.tolist())) != len(idx) or not hasattr(op, "deriv_wrt_params"):
                     raise NotImplementedError("leaf %s" % type(op).__name__)
+                try:                    # the base class HAS the attribute and raises when called (linearop.py): ask once
+                    op.deriv_wrt_params()
+                except NotImplementedError:
+                    derivs_ok[0] = False    # finite differences over this leaf's host-stepped values still work
                 leaf_params.append(-np.ones(d * d, np.int64))
                 leaf_general.append(np.sort(idx))
             leaf_static.append(np.ascontiguousarray(np.real(op.to_dense("HilbertSchmidt")), dtype=np.float64).ravel())
@@ -381,6 +386,7 @@ def atom_composite(model, atom):
         raise NotImplementedError("a parameter shared between a layer operation and a SPAM member")
     cm = CompositeModel(D, nP, leaf_dims, leaf_params, leaf_static, gate_factors, leaf_general)
     cm._leaf_ops = [op for _, op in sorted(leaves.values(), key=lambda t: t[0])]
+    cm.derivs_ok = derivs_ok[0]          # every general leaf can give deriv_wrt_params: the exact route is available
     return cm, (kind, obj, elem)
 
 
@@ -537,8 +543,10 @@ class AtomFillLogic:
                     # give them (deriv_wrt_params unimplemented) sends the atom back to finite differences over
                     # host-stepped dense model sets -- what 'fd' did for every such model before 'auto' existed
                     mode = "analytic"
-                    if not (self.lindblad_on_device and self._lindblad_description(layout_atom) is not None) and \
-                            not (self.composite_on_device and self._composite_description(layout_atom) is not None):
+                    cmp_desc = self._composite_description(layout_atom) if self.composite_on_device else None
+                    if cmp_desc is not None and not getattr(cmp_desc[0], "derivs_ok", True):
+                        mode = "fd"         # a general leaf without deriv_wrt_params: FD over its host-stepped values
+                    elif not (self.lindblad_on_device and self._lindblad_description(layout_atom) is not None) and cmp_desc is None:
                         try:
                             atom_derivs(self.model, layout_atom)
                         except (NotImplementedError, AttributeError):
