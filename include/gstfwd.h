@@ -237,22 +237,24 @@ GST_API int gst_set_derivs(gst_plan *plan, int32_t n_params, int32_t n_objs, con
  *       composes every member; the result is the plan's model for ALL fills (gst_get_model reads it back).
  * While set, GST_DERIV_FD columns of gst_fill_dprobs(_dev) are those of mapfill_dprobs_atom for such a model
  * (mapforwardsim_calc_densitymx.pyx:349-381: set_parameter_value(i, theta_i + eps), re-propagate, (p2 - p) / eps): the
- * device builds the dense model after every step itself -- no host densification and no PCIe traffic per column
- * (gst_fill_dprobs_models is the host-stepped form of the same walk).  Accuracy: the reference propagates through the
- * composed member factor by factor and exponentiates with a Pade approximant; dense members agree to ~1e-16, probabilities
- * to ~1e-15.  THE FD QUOTIENTS OF THIS ROUTE ARE OUTSIDE THE 1e-8 BAR AT DEPTH: a last-bit difference of the perturbed member
- * is amplified by (occurrences of the member in the circuit) / eps -- measured against the Map simulator <= 1e-8 for
- * circuits of depth <= 8, 1.5e-8 to depth 16, 7e-8 at depth 41-80, 1.2e-7 at depth 81-160 (1Q) and 7e-8 at depth 1,030 (2Q)
- * (tests/test_gpu_lindblad.py asserts that envelope with < 3x head-room).  No implementation can do better against that
- * oracle short of reproducing scipy's Pade solve bit for bit: the reference's own quotients carry the same amplified
- * rounding (dense-vs-composed evaluation of IDENTICAL members already moves them by 4e-9).  Use it for speed studies; for
- * fits use GST_DERIV_ANALYTIC (below; 1e-11 at depth 1,030 -- what the adapter's derivative_mode="auto" selects), or the
- * host-stepped gst_fill_dprobs_models, which walks the REFERENCE's perturbed dense members (4e-9, flat in depth).
+ * device builds the dense model after every step itself -- no host densification and no PCIe traffic per column.
+ * THAT ROUTE IS OFFERED ONLY WHERE IT MEETS THE 1e-8 PARITY BAR: plans whose deepest circuit has at most
+ * GST_LINDBLAD_FD_MAX_DEPTH gate applications.  The device exponentiates by a scaled Taylor series, the reference by
+ * scipy's Pade approximant; the perturbed members differ in their last bits (~1e-16), and a finite-difference quotient
+ * amplifies that by (occurrences of the member in the circuit) / eps -- measured against the Map simulator: <= 6.9e-9 to
+ * depth 16, 5e-8 at depth 41-80, 1.2e-7 at depth 81-160 (profiles/r04_cptplnd_depth_profile_*.json).  No implementation can
+ * do better short of reproducing the LAPACK solve inside scipy's expm bit for bit.  On a deeper plan the FD request fails
+ * with GST_EUNSUPPORTED (round 6; until then the header carried the envelope as a warning) and the caller takes
+ *   - GST_DERIV_ANALYTIC (below): exact, 1e-11 at depth 1,030, faster than the FD walk -- what the adapter's
+ *     derivative_mode="auto" has always selected for these models; or
+ *   - gst_fill_dprobs_models on a plain plan (gst_set_lindblad cleared, gst_set_model with the host's dense members): the
+ *     walk over the REFERENCE's own perturbed dense members, 4e-9 flat in depth -- what the adapter's "fd" does at depth.
  * GST_DERIV_ANALYTIC columns are exact: the device computes every member's d(dense)/d(parameter) itself -- the Frechet
  * derivative of the exponential in the direction dL/dtheta_p, composed with the static factor: what the reference's
  * ExpErrorgenOp.deriv_wrt_params() (experrorgenop.py:213-260) hands to MatrixForwardSimulator._doperation -- and applies the
  * chain rule to the element Jacobian (<= 1e-8 against the Matrix simulator).  (An explicit gst_set_derivs still takes
  * precedence in that mode; exact Hessian blocks of such models need it, with gst_set_second_derivs.) */
+#define GST_LINDBLAD_FD_MAX_DEPTH 16
 typedef struct {
     int32_t kind, obj, n_eff, n_blocks;
     int32_t block_type[4], block_mode[4], block_n[4];

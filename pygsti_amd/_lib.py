@@ -30,6 +30,13 @@ class GstError(RuntimeError):
     pass
 
 
+class GstUnsupported(GstError):
+    """GST_EUNSUPPORTED: the request is outside what the library offers (dimension, mode, depth ...)."""
+
+
+LINDBLAD_FD_MAX_DEPTH = 16      # GST_LINDBLAD_FD_MAX_DEPTH: FD over device-built Lindblad members meets 1e-8 up to this depth only
+
+
 class GstDeviceError(GstError):
     """No usable MI355X / HIP runtime.  The library never computes on the CPU instead."""
 
@@ -180,6 +187,8 @@ def check(rc):
         raise GstDeviceError(msg)
     if rc == GST_EINVAL:
         raise ValueError(msg)
+    if rc == GST_EUNSUPPORTED:
+        raise GstUnsupported("libgstfwd error %d: %s" % (rc, msg))
     raise GstError("libgstfwd error %d: %s" % (rc, msg))
 
 

@@ -607,6 +607,16 @@ int gst_fill_probs(gst_plan* p, double* out)
     });
 }
 
+// FD over device-built Lindblad members exists only where it meets the 1e-8 bar (include/gstfwd.h, gst_set_lindblad)
+static int lindblad_fd_gate(const gst_plan* p, int mode)
+{
+    if (mode != GST_DERIV_FD || !p->lb.set || p->hp.max_depth <= GST_LINDBLAD_FD_MAX_DEPTH) return GST_OK;
+    return fail(GST_EUNSUPPORTED, "finite differences over device-built Lindblad members are offered for circuits of depth <= " +
+                std::to_string(GST_LINDBLAD_FD_MAX_DEPTH) + " only (this plan: " + std::to_string(p->hp.max_depth) +
+                "): beyond, the quotient amplifies last-bit differences of the exponential past 1e-8 -- use GST_DERIV_ANALYTIC, or "
+                "gst_fill_dprobs_models over the host's own perturbed members");
+}
+
 int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_idx, const int64_t* dest_idx,
                         int64_t n_param, int mode, double eps, double* d_probs_out)
 {
@@ -615,6 +625,7 @@ int gst_fill_dprobs_dev(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (rc) return rc;
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!d_out && n_param > 0) return fail(GST_EINVAL, "d_out is NULL");
+    if ((rc = lindblad_fd_gate(p, mode))) return rc;
     // what this call overwrites no longer holds an earlier exact Jacobian's zeros (the plain exact fill keeps its own books)
     if (d_probs_out) gst::track_touch(d_probs_out, (size_t)p->hp.n_elements * 8);
     if (n_param > 0 && (mode == GST_DERIV_FD || p->lb.set || p->cmp.set || p->derivs_set)) gst::track_touch(d_out, jac_extent(p->hp.n_elements, ld, dest_idx, n_param));
@@ -660,6 +671,7 @@ int gst_fill_dprobs(gst_plan* p, double* out, int64_t ld, const int64_t* param_i
     if (rc) return rc;
     if (mode != GST_DERIV_FD && mode != GST_DERIV_ANALYTIC) return fail(GST_EINVAL, "unknown derivative mode");
     if (!out && n_param > 0) return fail(GST_EINVAL, "out is NULL");
+    if ((rc = lindblad_fd_gate(p, mode))) return rc;
     if (p->cmp.set && (mode == GST_DERIV_FD || !p->derivs_set)) {
         if (n_param < 0 || (n_param > 0 && !param_idx)) return fail(GST_EINVAL, "bad parameter list");
         if ((rc = stage_out(p, (size_t)p->hp.n_elements * std::max<int64_t>(n_param, 1)))) return rc;

@@ -158,6 +158,17 @@ class HipMapForwardSimulator:
         pidx = _to_index_array(param_slice, nP)
         didx = None if dest_param_slice is None else _to_index_array(dest_param_slice, array_to_fill.shape[1])
         mode = _lib.DERIV_ANALYTIC if self.derivative_mode == "analytic" else _lib.DERIV_FD
+        if mode == _lib.DERIV_FD and getattr(plan, "_lb_desc", None) is not None and plan.stats()["max_depth"] > _lib.LINDBLAD_FD_MAX_DEPTH:
+            # Finite differences of a Lindblad-parameterised model at depth: the library offers the device-built route only
+            # where it meets the 1e-8 bar (GST_LINDBLAD_FD_MAX_DEPTH).  Beyond, base AND stepped members come from the HOST
+            # (this model's own exponential -- the reference's scipy expm), as the reference steps them, and the device walks
+            # those dense sets (gst_fill_dprobs_models): both sides of every quotient carry the same member rounding.
+            desc, th = plan._lb_desc, self.model.to_vector()
+            plan.set_lindblad(None); plan._lb_desc = None
+            plan.set_model(*desc.dense(th))
+            Gs, Rs, Es = desc.model_sets(th, pidx, self.derivative_eps)
+            plan.fill_dprobs_models(Gs, Rs, Es, array_to_fill, didx, self.derivative_eps, pr_array_to_fill)
+            return
         plan.fill_dprobs(array_to_fill, pidx, didx, self.derivative_eps, pr_array_to_fill, mode)
 
     def _bulk_fill_hprobs_atom(self, array_to_fill, dest_param_slice1, dest_param_slice2, layout_atom,

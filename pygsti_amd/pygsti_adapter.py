@@ -563,7 +563,11 @@ class AtomFillLogic:
         # exponential and the host's Pade approximant differ in the last bit, which a line search would see).  Skips the
         # host to_dense() of every member as well.  Only exact HESSIAN requests leave this route (they need the host's
         # deriv / hessian matrices, `derivs` mode below); the next fill re-enters it.
-        if self.lindblad_on_device and not hessian and self._lindblad_description(layout_atom) is not None:
+        # (forced derivative_mode="fd" at depth: the library offers FD over device-built members only where it meets the 1e-8
+        #  bar -- GST_LINDBLAD_FD_MAX_DEPTH -- so such a request walks host-stepped dense model sets below: the reference's own
+        #  perturbed members, as before `lindblad_on_device` existed)
+        lb_fd_deep = derivatives and not hessian and dmode != "analytic" and plan.stats()["max_depth"] > _lib.LINDBLAD_FD_MAX_DEPTH
+        if self.lindblad_on_device and not hessian and not lb_fd_deep and self._lindblad_description(layout_atom) is not None:
             if getattr(plan, "_hip_mode", None) != "lindblad":
                 plan.set_derivs(self.model.num_params, [])
                 plan.set_complement_effect(-1)
@@ -628,7 +632,7 @@ class AtomFillLogic:
             if layout_atom._hip_tpmap is None:
                 # Lindblad-parameterised members (CPTPLND, GLND, H+S) under an FD-of-FD Hessian request (everything else
                 # returned at the top): the device builds them from the parameter vector, for the base model and every step
-                if self._lindblad_description(layout_atom) is not None and self.lindblad_on_device:
+                if self._lindblad_description(layout_atom) is not None and self.lindblad_on_device and not lb_fd_deep:
                     if getattr(plan, "_hip_mode", None) != "lindblad":
                         plan.set_derivs(self.model.num_params, [])
                         plan.set_complement_effect(-1)

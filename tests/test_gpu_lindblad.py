@@ -188,52 +188,78 @@ def test_analytic_jacobian_of_a_cptplnd_model_with_device_computed_member_deriva
 
 
 DEEP = [("smq1Q_XYI_L128_CPTPLND", 1), ("smq2Q_XYICNOT_L1024_CPTPLND_deep", 2)]
-# measured round 4 (1Q / 2Q): 8.9e-9 / 6.9e-9, 1.5e-8 / 4.4e-9, 3.6e-8 / -, 6.8e-8 / 5.2e-8, 1.2e-7 / -, - / -, - / 7.0e-8
-FD_VS_MAP_ENVELOPE = {(0, 8): 1e-8, (9, 16): 4e-8, (17, 40): 1e-7, (41, 80): 2e-7, (81, 160): 3.5e-7, (161, 600): 3.5e-7,
-                      (601, 2000): 2e-7}
 
 
 @pytest.mark.parametrize("name,nq", DEEP)
-def test_cptplnd_models_at_depth_error_profile(name, nq):
-    """CPTPLND models where the numbers are quoted (round 4): the full 1Q L<=128 design and whole 2Q germ-power families
-    to depth 1,030, both derivative modes against the reference simulator each one mirrors.
+def test_cptplnd_models_at_depth(name, nq):
+    """CPTPLND models where the numbers are quoted: the full 1Q L<=128 design and whole 2Q germ-power families to depth
+    1,030, against the reference simulator each derivative mode mirrors -- every offered route inside the stated tolerance.
 
     * probabilities <= 1e-10 at every depth;
-    * ANALYTIC (device-computed member derivatives + chain rule) vs the Matrix simulator: <= 1e-8 ABSOLUTE at every
-      depth -- the defensible default for these models;
-    * FD (device-built perturbed members) vs the Map simulator: the two sides exponentiate with different algorithms
-      (scaled Taylor here, scipy's Pade approximant there), so the perturbed member differs from the reference's in the
-      last bit and the quotient amplifies that by (occurrences of the member in the circuit) / eps: <= 1e-8 only for
-      SHALLOW circuits; the bound asserted at depth is the measured one with head-room, and the profile is written to
-      gpurun_out/ for DESIGN.md.  (The reference's own two simulators differ by 9e-3 here: FD truncation.)"""
-    import json
-    import os
-    from conftest import matrix_rows_by_circuit, element_depth, ROOT
+    * ANALYTIC (device-computed member derivatives + chain rule) vs the Matrix simulator: <= 1e-8 ABSOLUTE at every depth;
+    * FD over DEVICE-built members is refused at depth (GST_EUNSUPPORTED beyond GST_LINDBLAD_FD_MAX_DEPTH = 16: the device's
+      scaled-Taylor exponential and scipy's Pade approximant differ in the last bit of the perturbed member, and the quotient
+      amplifies that by occurrences / eps -- 5e-8 ... 1.2e-7 beyond depth 40, profiles/r04_cptplnd_depth_profile_*.json);
+    * FD at depth is the walk over the REFERENCE's own dense members after every step (`mm_*` of the fixture: what
+      model.set_parameter_value produced in pyGSTi), base model included: <= 1e-8 vs the Map simulator at EVERY depth."""
+    from conftest import matrix_rows_by_circuit, element_depth
     from pygsti_amd import _lib
     fx, lb, model, pl = _plan(name, nq)
     depth = element_depth(fx)
+    assert depth.max() > _lib.LINDBLAD_FD_MAX_DEPTH and pl.stats()["max_depth"] == depth.max()
     cols = fx["dprobs_cols"]
     p = pl.fill_probs()
     assert np.abs(p - fx["probs"]).max() < 1e-10
-    Jf = pl.fill_dprobs(param_idx=cols, eps=float(fx["derivative_eps"]))
+    with pytest.raises(_lib.GstUnsupported, match="depth"):
+        pl.fill_dprobs(param_idx=cols, eps=float(fx["derivative_eps"]))
+    d = pl.device_malloc(int(fx["nE"]) * len(cols) * 8)
+    with pytest.raises(_lib.GstUnsupported, match="depth"):
+        pl.fill_dprobs_dev(d, len(cols), cols, None, float(fx["derivative_eps"]), None)
+    pl.device_free(d)
     Ja = pl.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
     rows = matrix_rows_by_circuit(fx)
-    e_fd = np.abs(Jf - fx["dprobs_map"]).max(axis=1)
     e_an = np.abs(Ja - fx["matrix_by_circuit_dprobs"][rows]).max(axis=1)
-    prof = {}
-    for lo, hi in ((0, 8), (9, 16), (17, 40), (41, 80), (81, 160), (161, 600), (601, 2000)):
-        m = (depth >= lo) & (depth <= hi)
-        if m.any():
-            prof["%d-%d" % (lo, hi)] = {"fd_vs_map": float(e_fd[m].max()), "analytic_vs_matrix": float(e_an[m].max()), "elements": int(m.sum())}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r05_cptplnd_depth_profile_%s.json" % name), "w") as f:
-        json.dump({"fixture": name, "max_abs_J": float(np.abs(fx["dprobs_map"]).max()), "by_depth": prof}, f, indent=1)
-    assert e_an.max() < 1e-8, ("analytic vs Matrix", e_an.max(), prof)
-    # FD vs Map: the measured envelope per depth bin (profiles/r04_cptplnd_depth_profile_*.json, maximum over the 1Q and 2Q
-    # fixtures) with less than 3x head-room -- a 3x regression of the device's exponential or of the FD route fails here.
-    # Beyond depth 8 this route is OUTSIDE the 1e-8 bar by construction (see the docstring); `derivative_mode="auto"` never
-    # selects it.
-    for (lo, hi), bound in FD_VS_MAP_ENVELOPE.items():
-        m = (depth >= lo) & (depth <= hi)
-        if m.any():
-            assert e_fd[m].max() < bound, ("FD vs Map, depth %d-%d" % (lo, hi), float(e_fd[m].max()), bound, prof)
+    assert e_an.max() < 1e-8, ("analytic vs Matrix", e_an.max())
+    if "mm_gates" in fx:
+        pl.set_lindblad(None)
+        pl.set_model(fx["gates"], fx["rhos"], fx["effects"])              # the reference's own base members
+        pr = np.empty(int(fx["nE"]))
+        Jm = pl.fill_dprobs_models(fx["mm_gates"], fx["mm_rhos"], fx["mm_effects"], eps=float(fx["derivative_eps"]), probs_out=pr)
+        assert np.abs(pr - fx["probs"]).max() < 1e-10
+        e_fd = np.abs(Jm - fx["dprobs_map"]).max(axis=1)
+        for lo, hi in ((0, 16), (17, 80), (81, 600), (601, 2000)):
+            m = (depth >= lo) & (depth <= hi)
+            if m.any():
+                assert e_fd[m].max() < 1e-8, ("host-stepped FD vs Map, depth %d-%d" % (lo, hi), float(e_fd[m].max()))
+
+
+def test_deep_lindblad_fd_through_the_host_mirror_takes_host_stepped_members():
+    """HipMapForwardSimulator (derivative_mode 'fd') on a Lindblad-parameterised model at depth > 16: base and stepped members
+    from the model's own (host, scipy) exponential, walked as dense sets -- equal to an explicit gst_fill_dprobs_models over
+    `model_sets`, and consistent with the exact route to FD accuracy; shallow layouts keep the device-built route."""
+    from pygsti_amd import modelpacks as MP, _lib
+    from pygsti_amd.forwardsim import HipMapForwardSimulator
+    pack = MP.smq1Q_XYI
+    m = LB.LindbladExplicitModel(pack.target_model(), "CPTPLND")
+    rng = np.random.default_rng(9)
+    th = 0.03 * rng.standard_normal(m.num_params)
+    m.from_vector(th)
+    circuits = pack.create_gst_circuits(32)
+    sim = HipMapForwardSimulator(m, num_atoms=1)
+    lay = sim.create_layout(circuits)
+    nE, nP = lay.num_elements, m.num_params
+    atom = lay.atoms[0]
+    assert atom.plan().stats()["max_depth"] > _lib.LINDBLAD_FD_MAX_DEPTH
+    J = np.empty((nE, nP)); pr = np.empty(nE)
+    sim.bulk_fill_dprobs(J, lay, pr_array_to_fill=pr)
+    desc = m.lindblad_description(lay.model_gate_labels, lay.effect_labels)
+    pl = atom.plan()
+    pl.set_lindblad(None); pl.set_model(*desc.dense(th))
+    J2 = pl.fill_dprobs_models(*desc.model_sets(th, np.arange(nP), 1e-7), eps=1e-7)
+    assert np.array_equal(J, J2)
+    sim2 = HipMapForwardSimulator(m, num_atoms=1, derivative_mode="analytic")
+    lay2 = sim2.create_layout(circuits)
+    Ja = np.empty((nE, nP)); sim2.bulk_fill_dprobs(Ja, lay2)
+    assert np.abs(J - Ja).max() < 2e-4 * max(1.0, np.abs(Ja).max())        # (FD truncation error at L = 32)
+    p = np.empty(nE); sim.bulk_fill_probs(p, lay)                           # the next fill re-enters the device-built route
+    assert np.abs(p - pr).max() < 1e-12

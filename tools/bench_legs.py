@@ -100,46 +100,33 @@ def cptplnd(B):
             t_set0 = time.perf_counter()
             plan.set_lindblad_params(theta)
             t_set = time.perf_counter() - t_set0
-            plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_FD)       # warm-up
-            barrier_sync(plan)
             n_c = max(2, min(args.steps, 3))
-            tc0 = time.perf_counter()
+            # exact derivatives: element Jacobian (analytic contraction) x the members' derivative matrices (Frechet derivative
+            # of the exponential), both computed on the device -- MatrixForwardSimulator semantics for this parameterisation.
+            # (FD over device-built members is not offered at this depth: GST_LINDBLAD_FD_MAX_DEPTH, include/gstfwd.h)
+            plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
+            barrier_sync(plan)
+            ta0 = time.perf_counter()
             for _ in range(n_c):
                 plan.set_lindblad_params(theta)
-                plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_FD)
+                plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
             barrier_sync(plan)
-            dtc = (time.perf_counter() - tc0) / n_c
+            dtc = (time.perf_counter() - ta0) / n_c
             chk = plan.memcpy_d2h(np.empty(nPl), d_outl + ((nE_local - 1) * nPl) * 8)
             assert np.isfinite(chk).all()
-            # the same Jacobian with exact derivatives: element Jacobian (analytic contraction) x the members' derivative
-            # matrices, both computed on the device (MatrixForwardSimulator semantics for this parameterisation)
-            dta = None
+            refused = None
             try:
-                plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
-                barrier_sync(plan)
-                ta0 = time.perf_counter()
-                for _ in range(n_c):
-                    plan.set_lindblad_params(theta)
-                    plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_ANALYTIC)
-                barrier_sync(plan)
-                dta = (time.perf_counter() - ta0) / n_c
-            except Exception as e:
-                log("CPTPLND analytic leg failed: %s" % e)
+                plan.fill_dprobs_dev(d_outl, nPl, pidx_l, None, 1e-7, d_probs, _lib.DERIV_FD)
+            except _lib.GstUnsupported as e:
+                refused = str(e)[:160]
             cptp_info = {"value": nE_local * nPl / dtc, "unit": "Jacobian-elements/s", "ms_per_step": 1e3 * dtc, "n_params": nPl,
-                         "set_params_ms": 1e3 * t_set,
-                         "analytic_ms_per_step": None if dta is None else 1e3 * dta,
-                         "analytic_elements_per_s": None if dta is None else nE_local * nPl / dta,
-                         "parity": "FD columns vs the reference's Map simulator: <= 1e-8 only for circuits of depth <= 16 (6.9e-9); 5e-8 at depth "
-                                   "41-80 and 7e-8 at depth 1,030 (2Q germ-power families), 1.2e-7 at depth 81-160 (1Q L<=128 design) -- the "
-                                   "perturbed member's exponential (scaled Taylor here, scipy's Pade there) differs in the last bit and the "
-                                   "quotient amplifies it by occurrences/eps; the EXACT route (`analytic_ms_per_step`, the adapter's default "
-                                   "for these models) agrees with the Matrix simulator to 1.2e-11 at depth 1,030 "
-                                   "(profiles/r04_cptplnd_depth_profile_*.json, tests/test_gpu_lindblad.py)",
-                         "note": "bulk_fill_dprobs of the CPTPLND-parameterised model (FD eps=1e-7, Map-simulator semantics): every column's "
-                                 "changed member assembled and exponentiated on the device (no host to_dense per "
-                                 "column), walks share the base pass's states (gates: dirty programs, 4 columns per wavefront; the preparation: 64 per wavefront on the lane-per-model kernel), POVM columns from "
-                                 "the cached final states; round 2's form of the same Jacobian (host-stepped dense model sets, one "
-                                 "independent walk per (program, model)) took 580 ms; secondary figure, not `value`"}
+                         "set_params_ms": 1e3 * t_set, "derivative": "exact (GST_DERIV_ANALYTIC)",
+                         "fd_over_device_built_members": "refused at this depth" if refused else "NOT refused (unexpected)",
+                         "parity": "exact route vs the Matrix simulator: <= 1e-8 at every depth (1.2e-11 at depth 1,030; tests/test_gpu_lindblad.py); "
+                                   "FD at depth = gst_fill_dprobs_models over the reference's own stepped members (<= 1e-8)",
+                         "note": "bulk_fill_dprobs of the CPTPLND-parameterised model: base members and every member's d(dense)/d(parameter) "
+                                 "built on the device from the parameter vector, element Jacobian x chain-rule GEMM on the matrix cores; "
+                                 "secondary figure, not `value`"}
         finally:
             plan.device_free(d_outl)
             plan.set_lindblad(None)
