@@ -288,6 +288,7 @@ def main():
     ap.add_argument("--store-zeros", action="store_true", help="analytic legs: GST_OPT_ANALYTIC_KEEP_ZEROS = 0 (every fill stores the structural zeros again: the round-3 default)")
     ap.add_argument("--no-other-configs", action="store_true", help="N=1: skip the secondary legs of the other BASELINE configurations (1Q, 3Q, Hessian block)")
     ap.add_argument("--no-lm-step", action="store_true", help="skip the secondary LM-iteration timing (fill + objective maps + J^T J + J^T f [+ all-reduce])")
+    ap.add_argument("--no-fit-replay", action="store_true", help="N=1: skip the replay of the recorded 2Q L<=64 GST fit (the reference's only published end-to-end workload)")
     ap.add_argument("--no-cptplnd", action="store_true", help="N=1: skip the secondary CPTPLND (Lindblad-parameterised) Jacobian timing")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="development aid (N=1 only): time rank 0's atom of an N-atom strong-scaling layout on this one "
@@ -386,6 +387,25 @@ def main():
                             "resourceallocation.py:316-348); Jacobian rows stay on their ranks as bulk_fill_dprobs leaves them",
                     "fallback_reason": ctx.comm_error}
     host_stage = np.empty(nE_total) if (world > 1 and comm is None) else None
+    # N > 1, what `north_star` asks for: the Jacobian blocks end up on rank 0.  Rank 0's assembled [nE][nP] array is mapped into
+    # every rank (gst_comm_map_root_buffer) and each fill writes its rows THERE -- the kernel's stores cross xGMI while it runs,
+    # there is no separate gather pass.  When the mapping is not available the rows stay on their ranks (the reference's own
+    # bulk_fill_dprobs leaves them distributed, too) and the line says so.
+    d_jfull, d_direct = None, None
+    if world > 1 and comm is not None and not args.no_jacobian_gather and not col_split:
+        ok = 1.0
+        try:
+            if rank == 0:
+                d_jfull = plan.device_malloc(nE_total * nP * 8)
+            mapped = comm.map_root_buffer(d_jfull or 0, 0)
+            d_direct = mapped + row0 * nP * 8
+        except Exception as e:
+            ok = 0.0
+            exchange["jacobian_fan_in_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+        if ctx.max_over_ranks(1.0 - ok) > 0.0:          # (all ranks or none)
+            d_direct = None
+        exchange["jacobian_fan_in"] = ("every fill writes its row block straight into rank 0's assembled array (peer-mapped over xGMI, "
+                                       "gst_comm_map_root_buffer): included in `value`") if d_direct else "not available: rows stay on their ranks"
 
     def exchange_probs():
         if world == 1:
@@ -396,9 +416,9 @@ def main():
             plan.memcpy_d2h(host_stage[row0:row0 + nE_local], d_probs)
             plan.memcpy_h2d(d_pfull, gdist.gather_elements(host_stage, layout))
 
-    def step():
+    def step(dst=None):
         plan.set_model(gates, rhos, effects)          # from_vector -> new dense arrays -> H2D
-        plan.fill_dprobs_dev(d_out, nP_local, pidx, None, 1e-7, d_probs, mode)
+        plan.fill_dprobs_dev(dst or d_direct or d_out, nP_local, pidx, None, 1e-7, d_probs, mode)
         exchange_probs()
 
     for _ in range(args.warmup):
@@ -427,6 +447,19 @@ def main():
         assert abs(pf.sum() - n_circ_total) < 1e-6 * n_circ_total, "assembled probabilities must sum to 1 per circuit"
 
     log("timed steps done: %.2f ms/step" % (1e3 * dt / args.steps))
+    value_rows_distributed = None
+    if d_direct:
+        if rank == 0:               # the assembled Jacobian is complete on rank 0: every row finite, the last block included
+            chk = plan.memcpy_d2h(np.empty(nP), d_jfull + ((nE_total - 1) * nP) * 8)
+            assert np.isfinite(chk).all(), "the assembled Jacobian on rank 0 has unwritten rows"
+        for _ in range(2):
+            step(d_out)
+        barrier_sync(plan)
+        td0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(d_out)
+        barrier_sync(plan)
+        value_rows_distributed = nE_total * nP * args.steps / ctx.max_over_ranks(time.perf_counter() - td0)
     # secondary: probabilities only (+ their all-gather)
     for _ in range(2):
         plan.fill_probs_dev(d_probs)
@@ -473,6 +506,17 @@ def main():
     jtj_info = legs.normal_equations(B)     # --jtj: the normal equations in detail (column-distributed grid or per-kernel timings)
     log("normal-equation leg done")
     host_fill = legs.host_fill(B)           # the reference API end to end: bulk_fill_dprobs into the caller's HOST array
+    # the reference's only published end-to-end figure (mpi_2D_scaling: smq2Q L<=64 GST, 3,113 s on one rank): every LM iteration
+    # of a recorded run of it replayed on the device, checked against checksums of the reference's own normal equations
+    fit_info = None
+    if world == 1 and lay_world == 1 and not args.no_fit_replay:
+        try:
+            _fs = importlib.util.spec_from_file_location("fit_replay2q", os.path.join(ROOT, "tools", "fit_replay2q.py"))
+            _fm = importlib.util.module_from_spec(_fs); _fs.loader.exec_module(_fm)
+            fit_info = _fm.replay(device=device)
+        except Exception as e:                       # a secondary leg must not take the headline down with it
+            fit_info = {"error": "%s: %s" % (type(e).__name__, e)}
+        log("fit replay leg done")
     def measured_traffic(kernel_prefix):
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
         (profiles/r0x_hbm_counters.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; KB -> bytes, and
@@ -558,7 +602,9 @@ def main():
                                        args.max_len, args.design, len(circuits), layout.global_num_elements, nP, D,
                                        "" if world == 1 else (" -- x%d designs, one per rank (%d circuits in all)" % (world, n_circ_total)
                                                               if args.scaling == "weak" else " -- dealt to %d atoms" % world)),
-                       "destination": "device (HBM-resident Jacobian, gst_fill_dprobs_dev); the reference API's host-array fill is the `host_fill` leg (PCIe-bound)",
+                       "destination": ("rank 0's assembled HBM-resident Jacobian: every rank's fill writes its rows there over xGMI (gst_comm_map_root_buffer)"
+                                       if d_direct else
+                                       "device (HBM-resident Jacobian, gst_fill_dprobs_dev); the reference API's host-array fill is the `host_fill` leg (PCIe-bound)"),
                        "derivative": ("forward finite differences, eps=1e-7 (reference MapForwardSimulator semantics)"
                                       if args.deriv == "fd" else "analytic (reference MatrixForwardSimulator semantics)"),
                        "parallelism": (("atoms%d" % world) if not grid else ("grid %dx%d (atom-processors x parameter-processors)" % grid))
@@ -570,11 +616,14 @@ def main():
             # the north-star variant of the N > 1 figure: every step ALSO fans the Jacobian row blocks in to rank 0 over xGMI
             # (`value` leaves them distributed, as the reference's bulk_fill_dprobs does); None at N = 1 or when the leg is off
             "value_incl_jacobian_gather": (exchange or {}).get("jacobian_gather_to_rank0", {}).get("elements_per_s_with_gather"),
+            # N > 1 with the fan-in inside `value`: the same K steps with every rank's rows left on its own GPU (the reference's layout)
+            "value_rows_distributed": value_rows_distributed,
             "lm_step": lm_info,
             "normal_equations": jtj_info,
             "analytic_dprobs": ana_info,
             "cptplnd_dprobs": cptp_info,
             "other_configs": other_configs,
+            "gst_fit_2Q_L64": fit_info,
             "host_fill": host_fill,
             "probs_per_s": nE_total * n_pr / dtp,
             "probs_ms": 1e3 * dtp / n_pr,
@@ -605,6 +654,12 @@ def main():
             out["config"]["host_fill_ms"] = host_fill.get("ms")
         if lm_info:
             out["config"]["lm_step_ms"] = lm_info.get("ms_per_step")
+        if fit_info and "error" not in fit_info:
+            out["config"]["fit_2Q_L64_iterations"] = fit_info["iterations"]
+            out["config"]["fit_2Q_L64_device_ms_sum"] = fit_info["device_ms_sum"]
+            out["config"]["fit_2Q_L64_worst_checksum_deviation"] = fit_info["worst"]
+            out["config"]["fit_2Q_L64_reference_s"] = "published 3113 s (1 rank); %.0f s in the build container, %.0f s of it inside these dlsvec calls" % (
+                fit_info["reference_run_seconds_build_container"], fit_info["reference_dlsvec_seconds_same_calls"])
         if world == 1 and not args.no_cpu_baseline:
             pctx = None
             if lay_world == 1 and args.deriv == "fd":
@@ -629,14 +684,16 @@ def main():
             cb["driver_loop"] = "restated (oracle/ref_driver.cpp) over the reference's own C++ reps; no per-column Python"
             log("cpu baseline done")
         print(json.dumps(out))
+    if world > 1:
+        ctx.barrier()               # (nobody frees the mapped array while a peer may still write into it)
+    if d_jfull:
+        plan.device_free(d_jfull)
     plan.device_free(d_out)
     plan.device_free(d_pfull)
     if world > 1:
         ctx.barrier()
         with gdist._StdoutToStderr():          # (communicator teardown may print as well)
-            ctx.close()
-            import torch.distributed as dist
-            dist.destroy_process_group()
+            ctx.shutdown()
 
 
 if __name__ == "__main__":

@@ -515,6 +515,15 @@ GST_API int gst_comm_allgather_rows(gst_comm *comm, gst_plan *plan, double *d_fu
 GST_API int gst_comm_gather_rows(gst_comm *comm, gst_plan *plan, const double *d_local, double *d_full, int64_t row_doubles,
                          int32_t n_blocks, const int32_t *blk_owner, const int64_t *blk_row0, const int64_t *blk_rows,
                          int32_t root);
+/* The fan-in without a copy (round 6): collective; every rank receives in *d_mapped a device pointer, valid in ITS process,
+ * onto `root`'s buffer d_buf (the root passes its own pointer and gets it back; the others pass anything).  A rank then fills
+ * its row block straight into the assembled array -- gst_fill_dprobs_dev(plan, (double *)mapped + row0 * ld, ...) -- and the
+ * kernel's stores cross xGMI while it runs: what `north_star` calls the gather of the Jacobian blocks to rank 0 costs no pass
+ * of its own (the reference gathers host arrays after the fill, resourceallocation.py:329-348).  The root must not free d_buf
+ * before every rank is done with the mapping (gst_comm_barrier); mappings are closed by gst_comm_destroy.  Transport: the
+ * root's HIP IPC handle travels through the shared-memory mailbox (GST_TRANSPORT_IPC) or through the RCCL communicator itself
+ * (80 bytes, ncclSend / ncclRecv); ranks must be on one node. */
+GST_API int gst_comm_map_root_buffer(gst_comm *comm, int32_t root, void *d_buf, void **d_mapped);
 /* General block exchange between device arrays (an Alltoallv): block b = blk_count[b] doubles read at d_src + blk_src_off[b]
  * on rank blk_src_rank[b] and written at d_dst + blk_dst_off[b] on rank blk_dst_rank[b] (offsets in doubles; a block whose two
  * ranks coincide is a local copy).  Every rank passes the same list and its OWN d_src / d_dst.  This is the exchange step of

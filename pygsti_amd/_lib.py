@@ -98,7 +98,7 @@ EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_p
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_set_composite", "gst_set_composite_values", "gst_set_composite_general", "gst_get_model", "gst_get_lindblad_model_sets",
            "gst_comm_get_unique_id", "gst_comm_create", "gst_comm_destroy", "gst_comm_allgather_rows",
-           "gst_comm_gather_rows", "gst_comm_exchange_blocks", "gst_comm_allreduce_sum", "gst_comm_barrier", "gst_comm_sync", "gst_comm_get_info"]
+           "gst_comm_gather_rows", "gst_comm_map_root_buffer", "gst_comm_exchange_blocks", "gst_comm_allreduce_sum", "gst_comm_barrier", "gst_comm_sync", "gst_comm_get_info"]
 
 _lib = None
 
@@ -168,6 +168,7 @@ def lib():
         L.gst_comm_destroy.argtypes = [vp]
         L.gst_comm_allgather_rows.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
         L.gst_comm_gather_rows.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, i32]
+        L.gst_comm_map_root_buffer.argtypes = [vp, i32, vp, C.POINTER(C.c_void_p)]
         L.gst_comm_exchange_blocks.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.gst_comm_allreduce_sum.argtypes = [vp, vp, vp, i64]
         L.gst_comm_barrier.argtypes = [vp]
@@ -377,7 +378,8 @@ class Plan:
         for m in members:
             # (members built from Pauli matrices share a table per block structure; given term arrays are shared when they
             #  are the same array contents)
-            key = (m.n_qubits, tuple(m.blocks), hash(m.term_re.tobytes()) ^ hash(m.term_im.tobytes()))
+            tk = getattr(m, "_term_key", None)
+            key = (m.n_qubits, tuple(m.blocks), tk if tk is not None else hash(m.term_re.tobytes()) ^ hash(m.term_im.tobytes()))
             if key not in tables:
                 tables[key] = n_terms
                 n_terms += m.n_coeffs
@@ -811,6 +813,13 @@ class Comm:
                                          None if d_local is None else C.c_void_p(int(d_local)),
                                          None if d_full is None else C.c_void_p(int(d_full)), int(row_doubles),
                                          len(owner), _ptr(owner), _ptr(row0), _ptr(rows), int(root)))
+
+    def map_root_buffer(self, d_buf, root=0):
+        """Collective (gst_comm_map_root_buffer): a device pointer, valid in THIS process, onto rank `root`'s buffer `d_buf`
+        (the root gets its own pointer back): fills write their row blocks straight into the assembled array over xGMI."""
+        out = C.c_void_p()
+        check(lib().gst_comm_map_root_buffer(self._h, int(root), C.c_void_p(int(d_buf or 0)), C.byref(out)))
+        return int(out.value or 0)
 
     def exchange_blocks(self, d_src, d_dst, blocks, plan=None):
         """blocks = [(src rank, dst rank, src offset, dst offset, count)] in doubles: the same list on every rank, each with

@@ -249,6 +249,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
             else if (key == "hess_composed") p->hess_composed = iv != 0;
             else if (key == "cache_limit") p->test_cache_limit = val;
             else if (key == "poison") g_poison_fill = iv ? 0xFF : 0;
+            else if (key == "comm_self") {}          // (read by gst_comm_create: gst_comm.cpp)
             else { delete p; return fail(GST_EINVAL, "GST_TEST_FORCE: unknown key '" + key + "'"); }
         }
     }

@@ -130,7 +130,8 @@ struct IpcMailbox {
     IpcSlot slot[IPC_MAX_RANKS];
 };
 
-struct OpenedHandle { uint64_t alloc_id = 0; void* base = nullptr; uint64_t last_use = 0; };
+struct OpenedHandle { uint64_t alloc_id = 0; void* base = nullptr; uint64_t last_use = 0; bool pinned = false; };   // pinned: handed out by gst_comm_map_root_buffer, never evicted
+struct RootDesc { hipIpcMemHandle_t handle; uint64_t offset, bytes; };        // what a root sends its peers under RCCL (80 bytes)
 constexpr int IPC_MAPPINGS_PER_PEER = 8;       // a peer's destinations alternate (Jacobian, probabilities, staging ...)
 
 }  // namespace
@@ -156,6 +157,13 @@ struct gst_comm {
     uint64_t use_clock = 0;
     double* stage = nullptr;                              // all-reduce staging [size][stage_n]
     size_t stage_n = 0;
+    // gst_comm_map_root_buffer under RCCL: descriptor staging (page-locked host + device), mappings opened so far
+    RootDesc* h_desc = nullptr;
+    char* d_desc = nullptr;
+    struct RootMap { hipIpcMemHandle_t handle; void* base; };
+    bool test_self_send = false;                          // GST_TEST_FORCE comm_self=1 (tests): blocks that stay on their rank travel
+                                                          // through ncclSend / ncclRecv to the rank itself instead of a local copy
+    std::vector<RootMap> root_maps;
 };
 
 namespace {
@@ -217,7 +225,7 @@ int ipc_publish(gst_comm* c, const void* ptr)
 }
 
 // Device address, in THIS process, of peer `r`'s published destination buffer.
-int ipc_peer_ptr(gst_comm* c, int r, char** out)
+int ipc_peer_ptr(gst_comm* c, int r, char** out, bool pin = false)
 {
     const IpcSlot& s = c->box->slot[r];
     OpenedHandle* set = &c->opened[(size_t)r * IPC_MAPPINGS_PER_PEER];
@@ -225,10 +233,12 @@ int ipc_peer_ptr(gst_comm* c, int r, char** out)
     OpenedHandle* lru = nullptr;               // victim: an empty entry if there is one, else the least recently used
     for (int k = 0; k < IPC_MAPPINGS_PER_PEER; k++) {
         if (set[k].base && set[k].alloc_id == s.alloc_id) hit = &set[k];
+        if (set[k].pinned) continue;
         if (!lru) lru = &set[k];
         else if (lru->base && (!set[k].base || set[k].last_use < lru->last_use)) lru = &set[k];
     }
     if (!hit) {
+        if (!lru) return set_error(GST_EUNSUPPORTED, "every IPC mapping of this peer is pinned by gst_comm_map_root_buffer");
         if (lru->base) { (void)hipIpcCloseMemHandle(lru->base); lru->base = nullptr; lru->alloc_id = 0; }
         void* p = nullptr;
         HIP_TRYC(hipIpcOpenMemHandle(&p, s.handle, hipIpcMemLazyEnablePeerAccess));
@@ -238,6 +248,7 @@ int ipc_peer_ptr(gst_comm* c, int r, char** out)
     }
     hit->last_use = ++c->use_clock;
     OpenedHandle& o = *hit;
+    if (pin) o.pinned = true;
     *out = (char*)o.base + s.offset;
     return GST_OK;
 }
@@ -353,7 +364,8 @@ int exchange_blocks(gst_comm* c, hipStream_t st, const double* d_src, double* d_
     if (i_recv && !d_dst) return set_error(GST_EINVAL, "d_dst is NULL on a receiving rank");
     HIP_TRYC(hipSetDevice(c->device));
     // blocks that stay on their rank: a device-to-device copy in stream order
-    for (int32_t k = 0; k < n; k++)
+    const bool self_send = c->test_self_send && c->transport == GST_TRANSPORT_RCCL;
+    for (int32_t k = 0; k < n && !self_send; k++)
         if (cnt[k] > 0 && src_rank[k] == c->rank && dst_rank[k] == c->rank)
             HIP_TRYC(hipMemcpyAsync(d_dst + dst_off[k], d_src + src_off[k], (size_t)cnt[k] * 8, hipMemcpyDeviceToDevice, st));
     if (c->size == 1 && c->transport != GST_TRANSPORT_RCCL) return GST_OK;
@@ -363,9 +375,9 @@ int exchange_blocks(gst_comm* c, hipStream_t st, const double* d_src, double* d_
         ncclResult_t bad = ncclSuccess;
         const char* what = "";
         for (int32_t k = 0; k < n && bad == ncclSuccess; k++) {
-            if (cnt[k] == 0 || src_rank[k] == dst_rank[k]) continue;
+            if (cnt[k] == 0 || (src_rank[k] == dst_rank[k] && !self_send)) continue;
             if (src_rank[k] == c->rank) { bad = A->Send(d_src + src_off[k], (size_t)cnt[k], ncclDouble, dst_rank[k], c->nccl, st); what = "ncclSend"; }
-            else if (dst_rank[k] == c->rank) { bad = A->Recv(d_dst + dst_off[k], (size_t)cnt[k], ncclDouble, src_rank[k], c->nccl, st); what = "ncclRecv"; }
+            if (bad == ncclSuccess && dst_rank[k] == c->rank) { bad = A->Recv(d_dst + dst_off[k], (size_t)cnt[k], ncclDouble, src_rank[k], c->nccl, st); what = "ncclRecv"; }
         }
         const ncclResult_t ended = A->GroupEnd();
         if (bad != ncclSuccess) return set_error(GST_EHIP, std::string(what) + ": " + A->GetErrorString(bad));
@@ -472,6 +484,7 @@ int gst_comm_create(int transport, int device, int rank, int size, const void* i
         HIP_TRYC(hipSetDevice(device));
         gst_comm* c = new gst_comm();
         c->transport = transport; c->rank = rank; c->size = size; c->device = device;
+        if (const char* tf = std::getenv("GST_TEST_FORCE")) c->test_self_send = std::strstr(tf, "comm_self=1") != nullptr;
         hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (es != hipSuccess) { delete c; return set_error(GST_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(es)); }
         if (transport == GST_TRANSPORT_RCCL) {
@@ -568,6 +581,9 @@ int gst_comm_destroy(gst_comm* c)
             munmap(c->box, sizeof(IpcMailbox));
         }
         if (c->stage) (void)hipFree(c->stage);
+        for (auto& m : c->root_maps) if (m.base) (void)hipIpcCloseMemHandle(m.base);
+        if (c->h_desc) (void)hipHostFree(c->h_desc);
+        if (c->d_desc) (void)hipFree(c->d_desc);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return GST_OK;
@@ -602,6 +618,60 @@ int gst_comm_gather_rows(gst_comm* c, gst_plan* plan, const double* d_local, dou
         hipStream_t st = pick_stream(c, plan, &rc);
         if (rc) return rc;
         return exchange_rows(c, st, d_local, d_full, row_doubles, b, root);
+    });
+}
+
+// The fan-in WITHOUT a copy: every rank gets a device pointer, valid in its own process, onto `root`'s buffer, so that its fill
+// writes its row block straight into the assembled array -- over xGMI while the kernel runs.  The path's "gather to rank 0"
+// then costs no separate pass over the data (resourceallocation.py:329-348 is a Gatherv of host arrays after the fill).
+int gst_comm_map_root_buffer(gst_comm* c, int32_t root, void* d_buf, void** d_mapped)
+{
+    return guarded([&]() -> int {
+        if (!c || !d_mapped) return set_error(GST_EINVAL, "NULL argument");
+        *d_mapped = nullptr;
+        if (root < 0 || root >= c->size) return set_error(GST_EINVAL, "root out of range");
+        if (c->rank == root && !d_buf) return set_error(GST_EINVAL, "d_buf is NULL on the root");
+        HIP_TRYC(hipSetDevice(c->device));
+        if (c->size == 1) { *d_mapped = d_buf; return GST_OK; }
+        if (c->transport == GST_TRANSPORT_IPC) {
+            int rc;
+            if (c->rank == root && (rc = ipc_publish(c, d_buf))) { (void)ipc_barrier(c); (void)ipc_barrier(c); return rc; }
+            if ((rc = ipc_barrier(c))) return rc;
+            int rc_open = GST_OK;
+            if (c->rank == root) *d_mapped = d_buf;
+            else { char* ptr = nullptr; rc_open = ipc_peer_ptr(c, root, &ptr, true); *d_mapped = ptr; }
+            if ((rc = ipc_barrier(c))) return rc;          // (the root's slot may be re-published from here on)
+            return rc_open;
+        }
+        // RCCL: the root's (IPC handle, offset, size) travels as 80 bytes through the communicator itself
+        if (!c->h_desc) HIP_TRYC(hipHostMalloc((void**)&c->h_desc, sizeof(RootDesc), hipHostMallocDefault));
+        if (!c->d_desc) HIP_TRYC(hipMalloc((void**)&c->d_desc, sizeof(RootDesc)));
+        const RcclApi* A = c->api;
+        if (c->rank == root) {
+            void* base = nullptr; size_t bytes = 0;
+            HIP_TRYC(hipMemGetAddressRange((hipDeviceptr_t*)&base, &bytes, (hipDeviceptr_t)d_buf));
+            std::memset(c->h_desc, 0, sizeof(RootDesc));
+            HIP_TRYC(hipIpcGetMemHandle(&c->h_desc->handle, base));
+            c->h_desc->offset = (uint64_t)((char*)d_buf - (char*)base); c->h_desc->bytes = bytes;
+            HIP_TRYC(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RootDesc), hipMemcpyHostToDevice, c->stream));
+        }
+        NCCL_TRY(A, A->GroupStart());
+        ncclResult_t bad = ncclSuccess;
+        if (c->rank == root) { for (int r = 0; r < c->size && bad == ncclSuccess; r++) if (r != root) bad = A->Send(c->d_desc, sizeof(RootDesc), ncclChar, r, c->nccl, c->stream); }
+        else bad = A->Recv(c->d_desc, sizeof(RootDesc), ncclChar, root, c->nccl, c->stream);
+        const ncclResult_t ended = A->GroupEnd();
+        if (bad != ncclSuccess) return set_error(GST_EHIP, std::string("gst_comm_map_root_buffer: ") + A->GetErrorString(bad));
+        if (ended != ncclSuccess) return set_error(GST_EHIP, std::string("ncclGroupEnd: ") + A->GetErrorString(ended));
+        if (c->rank == root) { HIP_TRYC(hipStreamSynchronize(c->stream)); *d_mapped = d_buf; return GST_OK; }
+        HIP_TRYC(hipMemcpyAsync(c->h_desc, c->d_desc, sizeof(RootDesc), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRYC(hipStreamSynchronize(c->stream));
+        for (auto& m : c->root_maps)
+            if (std::memcmp(&m.handle, &c->h_desc->handle, sizeof(hipIpcMemHandle_t)) == 0) { *d_mapped = (char*)m.base + c->h_desc->offset; return GST_OK; }
+        void* p = nullptr;
+        HIP_TRYC(hipIpcOpenMemHandle(&p, c->h_desc->handle, hipIpcMemLazyEnablePeerAccess));
+        c->root_maps.push_back({c->h_desc->handle, p});
+        *d_mapped = (char*)p + c->h_desc->offset;
+        return GST_OK;
     });
 }
 

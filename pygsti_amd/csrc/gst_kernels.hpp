@@ -313,6 +313,11 @@ hipError_t launch_lindblad_build(int D, const LbArgs& a, int64_t n_sets, hipStre
 // d(dense member)/d(parameter set_param[b]) for workgroup b: column (set_param[b] - param0[m]) of member m's row-major
 // [n_elem][n_params[m]] matrix at deriv_out + deriv_off[m] (a POVM: n_eff matrices [D][n_params] one after another)
 hipError_t launch_lindblad_derivs(int D, const LbArgs& a, int64_t n_params_total, hipStream_t stream);
+// D = 64 (gst_kernels_lindblad.hip): base members through a per-member workspace (scaled generator, Taylor terms, squares)
+// that the derivative kernel of the same parameter vector re-uses
+size_t lindblad64_workspace_doubles(int n_members);
+hipError_t launch_lindblad64_build(const LbArgs& a, double* ws, int max_member_params, hipStream_t stream);
+hipError_t launch_lindblad64_derivs(const LbArgs& a, const double* ws, int64_t n_params_total, hipStream_t stream);
 
 // Layer operations of implicit models (gst_kernels_composite.hip): layer g = Emb(f_{n-1}) ... Emb(f_0) over its factors
 // gate_fptr[g] .. gate_fptr[g + 1]; factor f embeds leaf factor_leaf[f] (leaf_dim x leaf_dim, row-major values at

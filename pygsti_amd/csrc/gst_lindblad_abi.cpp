@@ -35,6 +35,7 @@ int lb_upload(gst_plan* p)
     HIP_TRY(p->d_lb_theta.ensure((size_t)std::max(L.n_params, 1)));
     HIP_TRY(p->d_lb_base.ensure(lb_set_stride(p)));
     HIP_TRY(p->d_lb_gates_rm.ensure(std::max<size_t>((size_t)p->hp.n_gates * p->hp.D * p->hp.D, 1)));
+    if (p->hp.D == 64) HIP_TRY(p->d_lb_ws64.ensure(gst::lindblad64_workspace_doubles(L.n_members)));
     HIP_TRY(hipStreamSynchronize(p->stream));
     L.uploaded = true;
     return GST_OK;
@@ -247,6 +248,7 @@ int run_dprobs_lindblad(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     const gst::HostPlan& h = p->hp;
     const int64_t nE = h.n_elements, nT = h.n_tasks();
     if (!p->lb.have_theta) return fail(GST_ESTATE, "gst_set_lindblad_params has not been called");
+    if (h.D == 64) return fail(GST_EUNSUPPORTED, "three-qubit Lindblad members: exact derivatives (GST_DERIV_ANALYTIC) only");
     if (!(eps != 0.0)) return fail(GST_EINVAL, "eps must be non-zero");
     for (int64_t c = 0; c < n_param; c++)
         if (param_idx[c] < 0 || param_idx[c] >= p->lb.n_params) return fail(GST_EINVAL, "parameter index out of range");
@@ -332,7 +334,8 @@ int run_dprobs_lindblad_analytic(gst_plan* p, double* d_out, int64_t ld, const i
     gst::LbArgs a;
     lb_args(p, a);
     a.set_param = p->d_lb_setparam.p; a.deriv_out = p->d_dv_deriv.p; a.deriv_off = p->d_lb_setparam.p + set_param.size(); a.eps = 0.0;
-    HIP_TRY(gst::launch_lindblad_derivs(D, a, (int64_t)set_param.size(), p->stream));
+    if (D == 64) HIP_TRY(gst::launch_lindblad64_derivs(a, p->d_lb_ws64.p, (int64_t)set_param.size(), p->stream));
+    else HIP_TRY(gst::launch_lindblad_derivs(D, a, (int64_t)set_param.size(), p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));          // (the host vectors above go out of scope)
     p->last_launches++;
     p->cached_kind = 0;
@@ -353,7 +356,7 @@ int gst_set_lindblad(gst_plan* p, int32_t n_params, int32_t n_members, const gst
     //  the members' kinds, objects and parameter ranges: a new description, or none, invalidates them)
     if (n_members == 0) { L = gst_plan::Lindblad(); p->cached_kind = 0; return GST_OK; }
     const int D = p->hp.D;
-    if ((D != 4 && D != 16) || p->D_user) return fail(GST_EUNSUPPORTED, "Lindblad members are built on the device for D = 4 and 16");
+    if ((D != 4 && D != 16 && D != 64) || p->D_user) return fail(GST_EUNSUPPORTED, "Lindblad members are built on the device for D = 4, 16 and 64");
     if (n_members < 0 || n_params < 0 || !members || n_terms <= 0 || !term_re || !term_im) return fail(GST_EINVAL, "bad argument");
     gst_plan::Lindblad N;
     N.n_params = n_params; N.n_members = n_members;
@@ -370,7 +373,8 @@ int gst_set_lindblad(gst_plan* p, int32_t n_params, int32_t n_members, const gst
             if (bt < 0 || bt > 2 || md < 0 || md > 1 || n < 1 || n > nb_max) return fail(GST_EINVAL, who + "bad coefficient block");
             np += bt == 2 ? (int64_t)n * n : n; nc += bt == 2 ? (int64_t)n * n : n;
         }
-        if (np > gst::lb_max_coeffs(D)) return fail(GST_EUNSUPPORTED, who + "too many parameters for one member");
+        // (D = 64: the kernels keep one member's parameters and coefficients in LDS -- a Hamiltonian block plus ONE 'other' block)
+        if (np > (D == 64 ? 63 + 63 * 63 : gst::lb_max_coeffs(D))) return fail(GST_EUNSUPPORTED, who + "too many parameters for one member");
         if (M.param0 < 0 || M.param0 + np > n_params) return fail(GST_EINVAL, who + "parameter range outside the model's");
         if (M.term_offset < 0 || M.term_offset + nc > n_terms) return fail(GST_EINVAL, who + "term range outside the term table");
         size_t n_static = 0;
@@ -438,7 +442,12 @@ int gst_set_lindblad_params(gst_plan* p, const double* theta)
     gst::LbArgs a;
     lb_args(p, a);
     a.set_param = nullptr; a.sets = p->d_lb_base.p; a.gates_rowmajor = p->d_lb_gates_rm.p; a.eps = 0.0;
-    HIP_TRY(gst::launch_lindblad_build(p->hp.D, a, L.n_members, p->stream));
+    if (p->hp.D == 64) {
+        int max_np = 1;
+        for (int32_t v : L.n_par) max_np = std::max(max_np, (int)v);
+        HIP_TRY(gst::launch_lindblad64_build(a, p->d_lb_ws64.p, max_np, p->stream));
+    } else
+        HIP_TRY(gst::launch_lindblad_build(p->hp.D, a, L.n_members, p->stream));
     // the base model also becomes the plan's model (what gst_set_model would have been given): 13 KB back over PCIe
     const int D = p->hp.D;
     const size_t ng = (size_t)p->hp.n_gates * D * D, nr = (size_t)p->hp.n_rhos * D, ne = (size_t)p->hp.n_effects * D;
@@ -468,6 +477,7 @@ int gst_get_lindblad_model_sets(gst_plan* p, const int64_t* param_idx, int64_t n
         if (param_idx[c] < 0 || param_idx[c] >= p->lb.n_params) return fail(GST_EINVAL, "parameter index out of range");
     if (n_param == 0) return GST_OK;
     const int D = p->hp.D;
+    if (D == 64) return fail(GST_EUNSUPPORTED, "perturbed model sets of three-qubit Lindblad members are not built (exact derivatives only)");
     const size_t ng = (size_t)p->hp.n_gates * D * D, nr = (size_t)p->hp.n_rhos * D, ne = (size_t)p->hp.n_effects * D, stride = ng + nr + ne;
     HIP_TRY(p->d_mm_models.ensure((size_t)n_param * stride));
     HIP_TRY(p->d_lb_setparam.ensure((size_t)n_param));

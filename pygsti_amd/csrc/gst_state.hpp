@@ -243,6 +243,7 @@ struct gst_plan {
     DevBuf<int32_t> d_lb_i32;               // kind | obj | n_eff | n_par | n_blocks | blk_type | blk_mode | blk_n
     DevBuf<int64_t> d_lb_i64, d_lb_setparam;   // param0 | term_off | static_off; the stepped parameter of each set
     DevBuf<double> d_lb_statics, d_lb_term_re, d_lb_term_im, d_lb_theta, d_lb_base, d_lb_gates_rm, d_lb_pert;
+    DevBuf<double> d_lb_ws64;               // D = 64: per-member workspace of the exponential (gst_kernels_lindblad.hip)
     DevBuf<int32_t> d_lb_waves;             // walk_pert_kernel's wave tables: kind | obj | n_eff | col0 | ncols | col_dest
     int32_t lb_n_pwaves = 0, lb_n_zero = 0;
     int64_t lb_n_sets = 0;                  // perturbed member sets of the cached request (columns of parameters that belong to a member)
@@ -332,7 +333,7 @@ struct gst_plan {
         d_cmp_i32.release(); d_cmp_pmap.release(); d_cmp_items32.release(); d_cmp_i64.release(); d_cmp_setparam.release();
         d_cmp_values.release(); d_cmp_spam.release(); d_cmp_base.release(); d_cmp_gates_rm.release(); d_cmp_gderiv.release(); d_cmp_gfd.release();
         d_lb_i32.release(); d_lb_i64.release(); d_lb_setparam.release(); d_lb_statics.release(); d_lb_term_re.release();
-        d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release(); d_jtj_pmask.release(); for (auto& b : d_lbr_lane) b.release(); d_lbr_order.release();
+        d_lb_term_im.release(); d_lb_theta.release(); d_lb_base.release(); d_lb_gates_rm.release(); d_lb_pert.release(); d_lb_ws64.release(); d_lb_waves.release(); d_dirty_words.release(); d_dirty_off.release(); d_lb_item_pw.release(); d_jtj_pmask.release(); for (auto& b : d_lbr_lane) b.release(); d_lbr_order.release();
         d_prog.release(); d_block_order.release(); d_obj_part.release(); d_bin_ptr.release(); d_bin_items.release();
         d_bin_head.release(); d_trace.release(); d_ecol_tab.release(); d_ecol_val.release(); d_rprog.release();
         d_rtask_off.release(); d_pos_ptr.release(); d_reff_ptr.release(); d_rev_leaf.release(); d_pair_f.release();

@@ -9,8 +9,9 @@ Gatherv / Allgatherv, resourceallocation.py:316-348) or for summed normal equati
 distlayout.py:1220-1359, on `allreduce_sum`, resourceallocation.py:441-508).
 
 Two planes:
-  * control (rendezvous, barriers, max-over-ranks timing, small host arrays): a `torch.distributed` *gloo* group --
-    PyTorch is plumbing here and never sees device data;
+  * control (rendezvous, barriers, max-over-ranks timing, small host arrays): a `control.ControlPlane` -- an mpi4py
+    communicator where the reference's callers have one (`control.MpiControl`, resourceallocation.py:43-120), a gloo group
+    for tests and bench.py (`control_gloo.GlooControl`, the one module that imports torch).  This module imports neither;
   * data (row blocks of probabilities / Jacobians, J^T J sums): `_lib.Comm`, the C ABI's gst_comm_* -- RCCL over xGMI
     between device pointers, or the intra-node IPC transport (ranks sharing a GPU; fallback when RCCL cannot start).
 """
@@ -18,7 +19,7 @@ import os
 
 import numpy as np
 
-from . import _lib
+from . import _lib, control as _control
 
 
 def env_rank_size():
@@ -72,12 +73,13 @@ class _StdoutToStderr:
 
 
 class DistContext:
-    """Control group (gloo) + data communicator (gst_comm) of this process.  `comm` is None when size == 1 or when
-    no device transport could be created (`comm_error` says why): callers then stay on the host paths."""
+    """Control plane + data communicator (gst_comm) of this process.  `comm` is None when size == 1 or when no device
+    transport could be created (`comm_error` says why): callers then stay on the host paths."""
 
-    def __init__(self, rank, size, local_rank, group, comm, comm_error=None):
+    def __init__(self, rank, size, local_rank, group, comm, comm_error=None, control=None):
         self.rank, self.size, self.local_rank = rank, size, local_rank
         self.group, self.comm, self.comm_error = group, comm, comm_error
+        self.control = control if control is not None else _control.SingleControl()
 
     @property
     def transport(self):
@@ -85,62 +87,57 @@ class DistContext:
 
     def barrier(self):
         if self.size > 1:
-            import torch.distributed as dist
-            dist.barrier(group=self.group)
+            self.control.barrier()
 
     def max_over_ranks(self, x):
-        if self.size == 1:
-            return float(x)
-        import torch
-        import torch.distributed as dist
-        t = torch.tensor([float(x)], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        return float(t.item())
+        return float(x) if self.size == 1 else self.control.max_float(x)
 
     def all_floats(self, x):
         """[x of rank 0, x of rank 1, ...] on every rank."""
-        if self.size == 1:
-            return [float(x)]
-        import torch
-        import torch.distributed as dist
-        t = torch.zeros(self.size, dtype=torch.float64)
-        t[self.rank] = float(x)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return [float(v) for v in t]
+        return [float(x)] if self.size == 1 else self.control.all_floats(x)
 
     def all_ok(self, ok):
         """True iff `ok` on every rank."""
         return self.max_over_ranks(0.0 if ok else 1.0) == 0.0
 
     def broadcast_bytes(self, payload, src=0):
-        if self.size == 1:
-            return payload
-        import torch.distributed as dist
-        box = [payload if self.rank == src else None]
-        dist.broadcast_object_list(box, src=src, group=self.group)
-        return box[0]
+        return payload if self.size == 1 else self.control.bcast_bytes(payload, src)
 
     def close(self):
         if self.comm is not None:
             self.comm.close()
             self.comm = None
 
+    def shutdown(self):
+        """close() + leave the control group (gloo: destroy the process group)."""
+        self.close()
+        if hasattr(self.control, "shutdown"):
+            self.control.shutdown()
+        _control.set_current(None)
 
-def init(device=None, transport="auto", want_comm=True):
-    """Join the job `torch.distributed.run` (or any launcher exporting RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)
-    started: a gloo control group, then the device communicator.  transport: 'rccl', 'ipc' or 'auto' (RCCL, and if any
-    rank fails to create it -- e.g. ranks sharing a GPU -- all ranks fall back to IPC together).  GST_TRANSPORT in the
-    environment overrides `transport`."""
+
+def init(device=None, transport="auto", want_comm=True, control=None, mpi_comm=None):
+    """Join the job: the control plane first, then the device communicator.
+    control  : a `control.ControlPlane`; or
+    mpi_comm : an mpi4py communicator (the reference's `ResourceAllocation.comm`) -> `control.MpiControl`; or neither: the
+               job `torch.distributed.run` (or any launcher exporting RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) started,
+               joined as a gloo group (`control_gloo.GlooControl`).
+    transport: 'rccl', 'ipc' or 'auto' (RCCL, and if any rank fails to create it -- e.g. ranks sharing a GPU -- all ranks fall
+               back to IPC together).  GST_TRANSPORT in the environment overrides it."""
     rank, size, local_rank = env_rank_size()
+    if control is None and mpi_comm is not None:
+        control = _control.MpiControl(mpi_comm)
+    if control is not None:
+        rank, size = control.rank, control.size
     if size == 1:
         return DistContext(0, 1, local_rank, None, None)
     _lib.lib()          # libgstfwd (and with it ROCm's HIP runtime) is loaded BEFORE torch brings its bundled copies
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if control is None:
+        from .control_gloo import GlooControl
         with _StdoutToStderr():
-            dist.init_process_group("gloo")
-    ctx = DistContext(rank, size, local_rank, None, None)
+            control = GlooControl()
+    _control.set_current(control)
+    ctx = DistContext(rank, size, local_rank, getattr(control, "group", None), None, control=control)
     if not want_comm:
         return ctx
     with _StdoutToStderr():
@@ -222,58 +219,59 @@ def gather_elements_dev(ctx, layout, d_local, d_full, row_doubles=1, root=0, pla
 
 
 # ---- host arrays (the reference's semantics on numpy arrays; small ones: probabilities, objective terms) --------------
-def gather_elements(local, layout, group=None, dst=None):
-    """Assemble a full element-dimension HOST array from per-rank row blocks through the control group.
+def _ctl(control=None):
+    ctl = control if control is not None else _control.current()
+    if ctl is None:
+        raise RuntimeError("no control plane: call pygsti_amd.dist.init() (gloo), or pass an mpi4py communicator / a ControlPlane")
+    return ctl
 
-    local : numpy array or CPU torch tensor of shape (num_elements, ...) in which THIS rank's rows are filled.
-    dst   : None -> all ranks receive the assembled array (all_gather of padded blocks); int -> only that rank does.
-    """
-    import torch
-    import torch.distributed as dist
-    as_numpy = isinstance(local, np.ndarray)
-    loc = torch.from_numpy(np.ascontiguousarray(local)) if as_numpy else local
-    rank, size = dist.get_rank(group), dist.get_world_size(group)
+
+def _exchange_padded(ctl, send, dst):
+    return ctl.allgather_array(send) if dst is None else ctl.gather_array(send, dst)
+
+
+def gather_elements(local, layout, group=None, dst=None, control=None):
+    """Assemble a full element-dimension HOST array from per-rank row blocks through the control plane.
+
+    local : numpy array of shape (num_elements, ...) in which THIS rank's rows are filled.
+    dst   : None -> all ranks receive the assembled array (all-gather of padded blocks); int -> only that rank does."""
+    ctl = _ctl(control)
+    loc = np.ascontiguousarray(local)
+    rank, size = ctl.rank, ctl.size
     blocks = [owned_row_blocks(layout, r, size) for r in range(size)]
     rows = [sum(b - a for a, b in bl) for bl in blocks]
     pad = max(rows)
-    tail = tuple(loc.shape[1:])
-    send = torch.zeros((pad,) + tail, dtype=loc.dtype, device=loc.device)
+    send = np.zeros((pad,) + tuple(loc.shape[1:]), loc.dtype)
     off = 0
     for a, b in blocks[rank]:
         send[off:off + (b - a)] = loc[a:b]
         off += b - a
-    if dst is None:
-        recv = [torch.empty_like(send) for _ in range(size)]
-        dist.all_gather(recv, send, group=group)
-    else:
-        recv = [torch.empty_like(send) for _ in range(size)] if rank == dst else None
-        dist.gather(send, recv, dst=dst, group=group)
-        if rank != dst:
-            return None
-    out = torch.empty_like(loc)
+    recv = _exchange_padded(ctl, send, dst)
+    if recv is None:
+        return None
+    out = np.empty_like(loc)
     for r in range(size):
         off = 0
         for a, b in blocks[r]:
             out[a:b] = recv[r][off:off + (b - a)]
             off += b - a
-    return out.numpy() if as_numpy else out
+    return out
 
 
-def gather_blocks(local, layout, array_type, group=None, dst=None, within_atom_proc=False):
+def gather_blocks(local, layout, array_type, group=None, dst=None, within_atom_proc=False, control=None):
     """Assemble a full HOST array of `array_type` ('e', 'ep', 'ep2', 'epp') from the blocks the ranks hold under the
     layout's processor grid -- rows by atom-processor, columns by parameter-processor (`layout.owned_blocks`) -- through
-    the control group (gather_local_array, distlayout.py:1010-1156).
+    the control plane (gather_local_array, distlayout.py:1010-1156).
 
     dst : None -> every rank receives the assembled array; int -> only that rank does (the others get None).
     within_atom_proc : only the blocks of this rank's own atom-processor are placed (what fill_jtj needs: whole rows of
         the rank's own atoms); rows of other atom-processors keep the local array's content."""
-    import torch
-    import torch.distributed as dist
+    ctl = _ctl(control)
     loc = np.ascontiguousarray(local)
-    rank, size = dist.get_rank(group), dist.get_world_size(group)
+    rank, size = ctl.rank, ctl.size
     if array_type in ("e",) or layout.processor_grid[1] * layout.processor_grid[2] == 1:
         if not within_atom_proc:
-            return gather_elements(loc, layout, group, dst)
+            return gather_elements(loc, layout, None, dst, ctl)
 
     def cut(arr, blk):
         r0, r1, c1, c2 = blk
@@ -282,30 +280,23 @@ def gather_blocks(local, layout, array_type, group=None, dst=None, within_atom_p
         if c2 is not None: v = v[:, :, c2]
         return v
     blocks = [layout.owned_blocks(array_type, r) for r in range(size)]
-    tail = loc.shape[{"e": 1, "ep": 2, "ep2": 2, "epp": 3}[array_type]:]
-    unit = int(np.prod(tail)) if tail else 1
     counts = [sum(cut(loc, b).size for b in bl) for bl in blocks]          # (shapes only: views)
     pad = max(max(counts), 1)
-    send = torch.zeros(pad, dtype=torch.from_numpy(loc.reshape(-1)[:1]).dtype)
+    send = np.zeros(pad, loc.dtype)
     off = 0
     for b in blocks[rank]:
         v = np.ascontiguousarray(cut(loc, b)).reshape(-1)
-        send[off:off + v.size] = torch.from_numpy(v)
+        send[off:off + v.size] = v
         off += v.size
-    if dst is None:
-        recv = [torch.empty_like(send) for _ in range(size)]
-        dist.all_gather(recv, send, group=group)
-    else:
-        recv = [torch.empty_like(send) for _ in range(size)] if rank == dst else None
-        dist.gather(send, recv, dst=dst, group=group)
-        if rank != dst:
-            return None
+    recv = _exchange_padded(ctl, send, dst)
+    if recv is None:
+        return None
     out = loc.copy() if within_atom_proc else np.empty_like(loc)
     na, np1, np2 = layout.processor_grid
     for r in range(size):
         if within_atom_proc and r // (np1 * np2) != layout.atom_proc_index:
             continue
-        buf = recv[r].numpy(); off = 0
+        buf = recv[r]; off = 0
         for b in blocks[r]:
             v = cut(out, b)
             v[...] = buf[off:off + v.size].reshape(v.shape)
@@ -313,16 +304,15 @@ def gather_blocks(local, layout, array_type, group=None, dst=None, within_atom_p
     return out
 
 
-def allreduce_sum_host(arr, group=None, expect_size=1, comm=None):
+def allreduce_sum_host(arr, group=None, expect_size=1, comm=None, control=None):
     """In-place sum of a host numpy array over the ranks (`allreduce_sum`, resourceallocation.py:441-508).
 
     expect_size : the number of ranks the CALLER's layout was built for.  When it is > 1 the sum must really happen:
-        through the torch.distributed control group when one exists, else through `comm` -- an mpi4py-style
+        through the control plane this process joined (pygsti_amd.dist.init), else through `comm` -- an mpi4py-style
         communicator (the reference's `ResourceAllocation.comm`) -- else a RuntimeError: handing back one rank's
         partial J^T J as if it were the sum would be silent corruption."""
-    import torch
-    import torch.distributed as dist
-    if not dist.is_initialized():
+    ctl = control if control is not None else _control.current()
+    if ctl is None:
         if expect_size > 1:
             if comm is not None and hasattr(comm, "Allreduce"):
                 buf = np.ascontiguousarray(arr)
@@ -330,15 +320,11 @@ def allreduce_sum_host(arr, group=None, expect_size=1, comm=None):
                 comm.Allreduce(buf, out)          # mpi4py: op defaults to SUM
                 arr[...] = out
                 return arr
-            raise RuntimeError("layout spans %d ranks but this process has neither a torch.distributed group "
+            raise RuntimeError("layout spans %d ranks but this process has neither a control plane "
                                "(pygsti_amd.dist.init) nor an MPI communicator: cannot sum over ranks" % expect_size)
         return arr
-    if dist.get_world_size(group) == 1:
+    if ctl.size == 1:
         if expect_size > 1:
             raise RuntimeError("layout spans %d ranks but the process group has one" % expect_size)
         return arr
-    t = torch.from_numpy(arr) if arr.flags.c_contiguous else torch.from_numpy(np.ascontiguousarray(arr))
-    dist.all_reduce(t, group=group)
-    if not arr.flags.c_contiguous:
-        arr[...] = t.numpy()
-    return arr
+    return ctl.allreduce_sum(arr)

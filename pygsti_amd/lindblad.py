@@ -67,6 +67,7 @@ def _left_right(a, b):
 
 
 _TERM_CACHE = {}
+_MEMBER_TERMS = {}
 
 
 def term_superops(n_qubits, block_type):
@@ -145,13 +146,16 @@ class LindbladMember:
         self.D = 4 ** self.n_qubits
         self.n_eff = self.static.shape[0] if self.kind == KIND_POVM else 1
         self.n_params = sum(block_num_params(t, m, n) for t, m, n in self.blocks)
-        terms = np.concatenate([term_superops(self.n_qubits, t) for t, _, _ in self.blocks], axis=0)
         for t, _, n in self.blocks:
             assert n == self.D - 1, "blocks over the full Pauli basis"
-        # L = sum_k Re(c_k) term_re[k] + Im(c_k) term_im[k]
-        self.term_re = np.ascontiguousarray(terms.real)
-        self.term_im = np.ascontiguousarray(-terms.imag)
-        self.n_coeffs = terms.shape[0]
+        # L = sum_k Re(c_k) term_re[k] + Im(c_k) term_im[k]; members over the same basis with the same block types SHARE the
+        # arrays (three qubits: 2 x 132 MB per table)
+        self._term_key = ("pauli", self.n_qubits, tuple(t for t, _, _ in self.blocks))
+        if self._term_key not in _MEMBER_TERMS:
+            terms = np.concatenate([term_superops(self.n_qubits, t) for t, _, _ in self.blocks], axis=0)
+            _MEMBER_TERMS[self._term_key] = (np.ascontiguousarray(terms.real), np.ascontiguousarray(-terms.imag))
+        self.term_re, self.term_im = _MEMBER_TERMS[self._term_key]
+        self.n_coeffs = self.term_re.shape[0]
 
     @classmethod
     def from_terms(cls, kind, obj, param0, blocks, static, terms):

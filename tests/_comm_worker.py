@@ -78,15 +78,26 @@ def main():
         ctx.comm.allreduce_sum(d_v, n, p0); p0.sync()
         got = np.empty(n); p0.memcpy_d2h(got, d_v); sums.append(got)
         p0.device_free(d_v)
+    # (4) the fan-in without a copy: rank 0's assembled array mapped into every rank; the fills write their rows there directly
+    d_direct = p0.device_malloc(nE * nC * 8) if rank == 0 else 0
+    if rank == 0:
+        p0.memcpy_h2d(d_direct, np.full(nE * nC, np.nan))
+    mapped = ctx.comm.map_root_buffer(d_direct, 0)
+    assert mapped != 0 and (rank != 0 or mapped == d_direct)
+    for at, pl in zip(lay.atoms, plans):
+        pl.fill_dprobs_dev(mapped + at.element_slice.start * nC * 8, nC, cols, None, 1e-7, None)
+        pl.sync()
+    ctx.barrier()
+    J_direct = np.zeros((0, nC))
+    if rank == 0:
+        J_direct = np.empty((nE, nC)); p0.memcpy_d2h(J_direct, d_direct)
     ctx.barrier()
     idx = np.concatenate([np.arange(*lay.indices_for_index(i).indices(nE)) for i in range(len(circuits))])
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), J=J[idx], P=P[idx], J_root=J_root[idx] if rank == 0 else np.zeros(0),
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), J=J[idx], P=P[idx], J_root=J_root[idx] if rank == 0 else np.zeros(0), J_direct=J_direct[idx] if rank == 0 else np.zeros(0),
              s0=sums[0], s1=sums[1], transport=ctx.transport, reopens=reopens, owned=np.array([a.element_slice.start for a in lay.atoms]))
-    for d in (d_J, d_P, d_loc, d_root):
+    for d in (d_J, d_P, d_loc, d_root) + ((d_direct,) if rank == 0 else ()):
         p0.device_free(d)
-    ctx.close()
-    import torch.distributed as dist
-    dist.destroy_process_group()
+    ctx.shutdown()
 
 
 if __name__ == "__main__":

@@ -70,9 +70,7 @@ def main():
              jtj=jtj, jtf=jtf, H_all=H_all, n_filled=int(filled.sum()), h_filled=int((~np.isnan(H)).sum()),
              gps=np.array([lay.global_param_slice.start, lay.global_param_slice.stop, lay.global_param2_slice.start, lay.global_param2_slice.stop]),
              owned=np.array([a.element_slice.start for a in lay.atoms]), root_none=(J_root is None))
-    ctx.close()
-    import torch.distributed as dist
-    dist.destroy_process_group()
+    ctx.shutdown()
 
 
 if __name__ == "__main__":

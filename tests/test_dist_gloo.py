@@ -13,34 +13,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, size, port, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size))
-    import torch
-    import torch.distributed as dist
     from pygsti_amd import modelpacks as MP, dist as gdist
     from pygsti_amd.layout import HipCOPALayout
     from _interp import run_programs
     ctx = gdist.init(want_comm=False)          # the control plane (gloo); no device communicator on a CPU box
     assert (ctx.rank, ctx.size) == (rank, size) and ctx.comm is None
+    from pygsti_amd import control as CTL
+    assert isinstance(ctx.control, CTL.ControlPlane) and CTL.current() is ctx.control and "torch" not in gdist.__dict__
     pack = MP.smq1Q_XYI
     model = pack.target_model().depolarize(0.01, 0.01)
     circuits = pack.create_gst_circuits(8)
     lay = HipCOPALayout(circuits, model, num_atoms=4, rank=rank, size=size)
     G, R, E = lay.model_arrays(model)
-    local = torch.full((lay.num_elements, 3), float("nan"), dtype=torch.float64)
+    local = np.full((lay.num_elements, 3), np.nan)
     for atom in lay.atoms:                          # only this rank's atoms
         w, off = atom.plan().program()
         n = len(atom.circuit_indices); nO = lay.num_outcomes
         o, written, _ = run_programs(w, off, G, R, E, np.arange(n + 1) * nO, np.tile(np.arange(nO), n), np.arange(n * nO), n * nO)
-        local[atom.element_slice, 0] = torch.from_numpy(o)
+        local[atom.element_slice, 0] = o
         local[atom.element_slice, 1] = rank
-        local[atom.element_slice, 2] = torch.arange(atom.element_slice.start, atom.element_slice.stop, dtype=torch.float64)
+        local[atom.element_slice, 2] = np.arange(atom.element_slice.start, atom.element_slice.stop, dtype=np.float64)
     full = gdist.gather_elements(local, lay)                  # all ranks
     root = gdist.gather_elements(local, lay, dst=0)           # rank 0 only
-    ok_root = (root is None) if rank != 0 else bool(torch.equal(root, full))
+    ok_root = (root is None) if rank != 0 else bool(np.array_equal(root, full))
     # the layout's own gather (distlayout.py:1010-1156 semantics) on a host numpy array, + block bookkeeping
-    arr = local.numpy().copy()
+    arr = local.copy()
     g_all = lay.allgather_local_array("ep", arr)
     g_root = lay.gather_local_array("ep", arr)
-    ok_root = ok_root and np.array_equal(g_all, full.numpy()) and ((g_root is None) if rank != 0 else np.array_equal(g_root, g_all))
+    ok_root = ok_root and np.array_equal(g_all, full) and ((g_root is None) if rank != 0 else np.array_equal(g_root, g_all))
     blocks = gdist.row_blocks(lay, size)
     # sequential dealing (distlayout.py:327-329): 4 atoms on 2 ranks -> owners 0 0 1 1, a rank's rows one contiguous range
     ok_root = ok_root and [b[0] for b in blocks] == [a * size // len(lay.all_atoms) for a in range(len(lay.all_atoms))] \
@@ -49,8 +49,8 @@ def _worker(rank, size, port, q):
         and sum(a.num_elements for a in lay.atoms) == lay.local_element_slice.stop - lay.local_element_slice.start
     part = np.full(3, float(rank + 1)); gdist.allreduce_sum_host(part)
     ok_root = ok_root and np.array_equal(part, np.full(3, 3.0)) and ctx.max_over_ranks(rank) == 1.0
-    q.put((rank, full.numpy(), ok_root, [(a.element_slice.start, a.element_slice.stop) for a in lay.atoms]))
-    dist.destroy_process_group()
+    q.put((rank, full, ok_root, [(a.element_slice.start, a.element_slice.stop) for a in lay.atoms]))
+    ctx.shutdown()
 
 
 def test_two_rank_sharding_and_gather():
@@ -92,7 +92,6 @@ def test_two_rank_sharding_and_gather():
 def _grid_worker(rank, size, port, q, grid, n_atoms):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size))
-    import torch.distributed as dist
     from pygsti_amd import modelpacks as MP, dist as gdist
     from pygsti_amd.layout import HipCOPALayout
     ctx = gdist.init(want_comm=False)
@@ -122,7 +121,7 @@ def _grid_worker(rank, size, port, q, grid, n_atoms):
                 ok = ok and (np.array_equal(comp[at.element_slice], full[at.element_slice]) if mine else np.isnan(comp[at.element_slice]).all())
     shares = [(lay._row_share(at).start, lay._row_share(at).stop) for at in lay.atoms]
     q.put((rank, ok, shares, [(at.element_slice.start, at.element_slice.stop) for at in lay.atoms]))
-    dist.destroy_process_group()
+    ctx.shutdown()
 
 
 @pytest.mark.parametrize("grid,n_atoms", [((1, 2), 2), ((2, 2), 4), ((1, 2, 2), 1)])

@@ -44,6 +44,36 @@ def test_rccl_one_rank_communicator_on_device():
     comm.close()
 
 
+def test_rccl_send_recv_group_executes_with_one_rank(monkeypatch):
+    """The branch a one-rank job never enters: ncclGroupStart ... ncclSend / ncclRecv ... ncclGroupEnd with a PEER.  RCCL allows
+    a rank to send to itself inside a group, so the test hook `comm_self=1` routes the blocks that stay on their rank through
+    exactly that code (gst_comm_exchange_blocks) instead of a local copy: the first multi-GPU run is then not the first
+    execution of it.  Same block list as the column exchange of the processor grid: several blocks, ragged sizes, a gap."""
+    from pygsti_amd import _lib
+    from conftest import plan_from_fixture, force
+    force(monkeypatch, comm_self=1)
+    uid = _lib.Comm.unique_id(_lib.TRANSPORT_RCCL)
+    comm = _lib.Comm(0, 1, uid, 0, _lib.TRANSPORT_RCCL)
+    fx = load_fixture("smq1Q_XYI_L4_depol")
+    pl = plan_from_fixture(fx, device=0)
+    n = 100_000
+    src = np.random.default_rng(5).standard_normal(n)
+    d_src = pl.device_malloc(n * 8); d_dst = pl.device_malloc(n * 8)
+    pl.memcpy_h2d(d_src, src); pl.memcpy_h2d(d_dst, np.full(n, np.nan))
+    # (src rank, dst rank, src offset, dst offset, count) in doubles
+    blocks = [(0, 0, 0, 50_000, 1_000), (0, 0, 1_000, 0, 7), (0, 0, 20_000, 60_000, 33_333), (0, 0, 99_999, 99_999, 1)]
+    comm.exchange_blocks(d_src, d_dst, blocks, pl)
+    pl.sync()
+    comm.barrier()
+    got = np.empty(n); pl.memcpy_d2h(got, d_dst)
+    want = np.full(n, np.nan)
+    for _, _, so, do, cnt in blocks:
+        want[do:do + cnt] = src[so:so + cnt]
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(want)], want[~np.isnan(want)])
+    pl.device_free(d_src); pl.device_free(d_dst)
+    comm.close()
+
+
 def _run_job(tmp_path, n_ranks, transport, n_atoms, distinct=False):
     port = 29500 + (os.getpid() * 7 + n_ranks * 13 + n_atoms) % 2000
     procs = []
@@ -86,6 +116,8 @@ def test_ranks_sharing_one_gpu_assemble_the_reference_jacobian_bitwise(tmp_path,
             else:
                 np.testing.assert_allclose(d[key], want, rtol=1e-14, atol=1e-300)
     assert_bitwise(res[0]["J_root"], fx["dprobs_map"], "Jacobian gathered to rank 0 (Gatherv)")
+    # the fan-in without a copy: every rank's fill wrote its rows straight into rank 0's array (gst_comm_map_root_buffer)
+    assert_bitwise(res[0]["J_direct"], fx["dprobs_map"], "Jacobian filled directly into rank 0's assembled array")
     owned = [set(d["owned"].tolist()) for d in res]
     assert not set.intersection(*owned) and sum(len(o) for o in owned) == n_atoms
 
@@ -122,5 +154,6 @@ def test_ranks_on_distinct_gpus_over_rccl_assemble_the_reference_jacobian_bitwis
                 want = want + v[q][:n]
             np.testing.assert_allclose(d[key], want, rtol=1e-14, atol=1e-300)
     assert_bitwise(res[0]["J_root"], fx["dprobs_map"], "Jacobian gathered to rank 0 (Gatherv) over RCCL")
+    assert_bitwise(res[0]["J_direct"], fx["dprobs_map"], "Jacobian filled directly into rank 0's array (IPC handle sent through RCCL)")
     owned = [set(d["owned"].tolist()) for d in res]
     assert sum(len(o) for o in owned) == n_ranks and len(set.union(*owned)) == n_ranks

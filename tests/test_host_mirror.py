@@ -475,3 +475,50 @@ def test_page_locked_candidates_own_their_pages():
     assert small.shape == (model.num_params,) and small.base is None
     lay.pin_arrays = False
     assert lay.allocate_local_array("ep").base is None      # pinning switched off: plain numpy
+
+
+def test_mpi_control_plane_speaks_mpi4py():
+    """`control.MpiControl` over an mpi4py-style communicator (what the reference's callers hold in ResourceAllocation.comm,
+    resourceallocation.py:43-120): the three primitives and the host-array collectives, against a duck-typed 3-rank
+    communicator that plays all ranks at once; `dist.gather_elements` / `allreduce_sum_host` run over it."""
+    from pygsti_amd import control as CTL, dist as gdist, modelpacks as MP
+    from pygsti_amd.layout import HipCOPALayout
+
+    class _World:                       # what every rank would contribute, keyed by collective call number
+        def __init__(self, size):
+            self.size = size
+
+    class _Comm:
+        """rank `me` of `size`; the other ranks' send buffers are produced by `others(me_send, r)`"""
+        def __init__(self, me, size, others):
+            self.me, self.size, self.others = me, size, others
+        def Get_rank(self): return self.me
+        def Get_size(self): return self.size
+        def bcast(self, payload, root=0): return payload if self.me == root else ("from", root)
+        def Barrier(self): self.barriers = getattr(self, "barriers", 0) + 1
+        def Allreduce(self, send, recv, op=None):
+            vals = [self.others(send, r) for r in range(self.size)]
+            recv[...] = np.max(vals, axis=0) if op is not None else np.sum(vals, axis=0)
+        def Allgather(self, send, recv):
+            for r in range(self.size): recv[r] = self.others(send, r)
+        def Gather(self, send, recv, root=0):
+            if self.me == root:
+                for r in range(self.size): recv[r] = self.others(send, r)
+
+    ctl = CTL.MpiControl(_Comm(1, 3, lambda s, r: s * (r + 1.0)))
+    assert (ctl.rank, ctl.size) == (1, 3) and ctl.bcast_bytes(b"id", 1) == b"id" and ctl.bcast_bytes(None, 0) == ("from", 0)
+    ctl.barrier(); assert ctl.comm.barriers == 1
+    assert ctl.max_float(2.0) == 6.0 and ctl.all_floats(2.0) == [2.0, 4.0, 6.0]
+    a = np.arange(4.0); ctl.allreduce_sum(a); assert np.array_equal(a, np.arange(4.0) * 6.0)
+    assert ctl.gather_array(np.ones(2), 0) is None and len(ctl.gather_array(np.ones(2), 1)) == 3
+    # the layout mirror's host gather over it: every rank "sends" the same padded rows here, so the assembled array repeats
+    # this rank's block pattern -- enough to check the block bookkeeping end to end without three processes
+    pack = MP.smq1Q_XYI
+    model = pack.target_model()
+    lay = HipCOPALayout(pack.create_gst_circuits(2), model, num_atoms=3, rank=1, size=3)
+    ctl2 = CTL.MpiControl(_Comm(1, 3, lambda s, r: s))
+    loc = np.arange(lay.global_num_elements, dtype=np.float64)
+    out = gdist.gather_elements(loc, lay, control=ctl2)
+    mine = lay.atoms[0].element_slice
+    assert np.array_equal(out[mine], loc[mine])
+    part = np.ones(5); gdist.allreduce_sum_host(part, expect_size=3, control=ctl2); assert np.array_equal(part, np.full(5, 3.0))
