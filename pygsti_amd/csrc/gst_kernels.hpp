@@ -176,6 +176,23 @@ struct AnaArgs {
     int32_t zeros_resident;       // D = 16 stream form: the blocks of gates an item never applies already hold zeros in `out`: not stored
     const uint32_t* zeros_ok;     // ... unless this device word (NULL: none) reads 0: a row scaling met a non-finite factor since
 };
+// The D = 16 contraction over TILES of circuits that share their forward chains row-wise and their backward chains
+// column-wise (gst_kernels_tiles.hip; the host finds them: build_tiles in gst_fill_analytic.cpp)
+constexpr int TILE_ROWS = 8, TILE_COLS = 4;
+struct TileArgs {
+    AnaArgs a;                    // caches, column maps, destination, effect CSR, circ_leaf / rev_leaf / circ_rho, zeros_*
+    int32_t n_tiles;
+    const int32_t* tile_order;    // [n_tiles] launch order (heaviest first)
+    const int32_t* tile_cid;      // [n_tiles][TILE_ROWS * TILE_COLS]: circuit of (row, column) at row * TILE_COLS + column, or -1
+    const int32_t* tile_blk;      // [n_tiles][n_gates + 1]: the segment blocks of gate g are tile_blk[.. + g] .. tile_blk[.. + g + 1]
+    const int32_t* tsf;           // [n_blocks][4 slots][TILE_ROWS]: forward state id per row (-1: dead slot / absent row)
+    const int32_t* tsr;           // [n_blocks][4 slots][TILE_COLS]: backward state id per column (-1: dead)
+    const int32_t* rem_ptr;       // [n_tiles][n_gates][TILE_ROWS * TILE_COLS + 1]: remnant blocks of (gate, circuit slot)
+    const int32_t* rem_f;         // [n_rem_blocks][4]: forward id (-1: dead slot)
+    const int32_t* rem_r;         // [n_rem_blocks][4]: backward id (always valid)
+    uint32_t* counter;            // one word, zeroed before the launch
+};
+hipError_t launch_analytic_tiles(const TileArgs& t, int n_cus, hipStream_t stream);
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);
 hipError_t launch_analytic_mfma(const AnaArgs& a, hipStream_t stream);   // D = 16
 int analytic_stream_chunks();        // chunks of 4 slots per block of the D = 16 stream (the host pads every gate's slots to whole blocks)

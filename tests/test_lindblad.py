@@ -142,3 +142,22 @@ def test_member_derivatives_match_the_reference():
             dv = np.zeros_like(v); dv[q] = 1e-6
             fd = (LB.block_coefficients(bt, md, n, v + dv) - LB.block_coefficients(bt, md, n, v - dv)) / 2e-6
             assert np.abs(J[:, q] - fd).max() < 1e-8
+
+
+def test_three_qubit_members_match_the_reference():
+    """A Lindblad member of FULL dimension 64 (4,032 parameters: 63 Hamiltonian + 63 x 63 Cholesky coefficients over the
+    three-qubit Paulis): the native construction -- term superoperators from Pauli matrices, coefficients, generator,
+    exponential, composition with the static factor -- against the reference's own members of a three-qubit explicit CPTPLND
+    model (tests/golden/make_golden_r6.py: `errorgen.to_dense()`, `ExpErrorgenOp.to_dense()`, the dense members)."""
+    fx, lb = load_fixture("3q_explicit_CPTPLND"), load_fixture("lindblad_3q_explicit_CPTPLND")
+    model = LB.LindbladModel.from_fixture(lb, 3)
+    th = lb["paramvec"]
+    assert model.num_params == len(th) == 5 * 4032 and model.D == 64
+    assert model.members[0].term_re is model.members[1].term_re          # (one 132 MB table, shared)
+    for m, mem in enumerate(model.members):
+        loc = th[mem.param0:mem.param0 + mem.n_params]
+        L = mem.errorgen(loc)
+        assert np.abs(L - lb["m%d_errgen" % m]).max() < 1e-13 * max(1.0, np.abs(L).max()), m
+        assert np.abs(mem.exp(loc) - lb["m%d_exp" % m]).max() < 1e-13, m
+    G, R, E = model.dense(th)
+    assert np.abs(G - fx["gates"]).max() < 1e-13 and np.abs(R - fx["rhos"]).max() < 1e-13 and np.abs(E - fx["effects"]).max() < 1e-13
