@@ -131,6 +131,9 @@ typedef struct {
     int32_t last_levels;       /* 1: the last fill took its forward states from the log-depth level pass (GST_OPT_FAST_CHAINS /
                                   GST_OPT_FAST_PROBS), 0: from the sequential walk */
     int32_t last_zeros_resident;   /* 1: the last exact Jacobian fill did not re-store the destination's structural zeros */
+    int32_t last_tiles;            /* tiles the last exact Jacobian fill contracted on the tile kernel (0: item kernel only) */
+    int32_t reserved;
+    int64_t last_tiled_circuits;   /* ... and the circuits they held */
 } gst_stats;
 
 GST_API int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *opt, gst_plan **out);
@@ -171,6 +174,14 @@ GST_API int gst_plan_create_from_table(const gst_table_desc *desc, const gst_opt
  *       difference them.  Finite-difference fills never use it. */
 #define GST_OPT_FAST_CHAINS 2
 #define GST_OPT_FAST_PROBS 3
+/*   GST_OPT_ANALYTIC_TILES (value 0 / 1; default 0; set before the plan's first exact fill): the D = 16 exact contraction
+ *       over TILES of the design's product structure -- circuits prep_i . W . meas_m read the same forward states whatever m and
+ *       the same backward states whatever i; a workgroup stages them once in LDS for 8 x 4 circuits (gst_kernels_tiles.hip,
+ *       gst_get_tile_stats) -- instead of one or two circuits per wavefront.  Same values to re-association (1e-12).  OFF by
+ *       default: measured on the 2Q L <= 1024 design it removes the L1 miss stalls of the item kernel (its block stream runs at
+ *       0.77 of the fp64 matrix pipes) but serialises what the item kernel's twelve wavefronts per CU overlap -- 2.08 + 0.70 ms
+ *       (tiles + the circuits no tile holds) against 2.47 ms. */
+#define GST_OPT_ANALYTIC_TILES 4
 GST_API int gst_set_option(gst_plan *plan, int32_t option, int64_t value);
 GST_API int gst_plan_create_from_circuits(const gst_circuits_desc *desc, const gst_options *opt, gst_plan **out);
 GST_API int gst_plan_destroy(gst_plan *plan);
@@ -639,6 +650,13 @@ GST_API int gst_get_fd_queues(gst_plan *plan, const int64_t *param_idx, int64_t 
  * Executed flops of the fill = 2 D^2 * 64 * out[0] + 2 D * 64 * out[2] (every lane of a wavefront issues); the reference
  * schedule's flops = n_param * (2 D^2 A + 2 D nE). */
 GST_API int gst_get_fd_work(gst_plan *plan, const int64_t *param_idx, int64_t n_param, int64_t *out);
+/* Host-only (no device needed): the TILES the D = 16 exact contraction forms for this plan (gst_kernels_tiles.hip: circuits
+ * prep_i . W . meas_m that share their forward states row-wise and their backward states column-wise over W, 8 x 4 per
+ * workgroup), checked against the per-circuit application tables the item kernel reads.  out[8] =
+ *   [0] tiles   [1] circuits in tiles   [2] segment slots (x rows x columns = applications served from LDS)
+ *   [3] remnant applications (gathered per circuit)   [4] INCONSISTENCIES found by the check (0)   [5] longest segment
+ *   [6] circuits of the plan   [7] circuits that appear in exactly one tile (= [1]) */
+GST_API int gst_get_tile_stats(gst_plan *plan, int64_t *out);
 
 /* The state-id graph behind the NODE markers: parent state id (-1 for a state preparation) and gate / rho index of
  * every state, and the id of each expanded circuit's final state (what the analytic mode walks backwards). */

@@ -19,6 +19,7 @@ DERIV_FD, DERIV_ANALYTIC = 0, 1
 OPT_ANALYTIC_KEEP_ZEROS = 1
 OPT_FAST_CHAINS = 2       # 0 never / 1 where it pays (default) / 2 always: log-depth level pass for the modes without an ordering contract
 OPT_FAST_PROBS = 3        # fill_probs through the level pass (<= 1e-10, not bit-identical)
+OPT_ANALYTIC_TILES = 4    # the D = 16 exact contraction over product tiles (off by default; before the first exact fill)
 OBJ_CHI2, OBJ_POISSON_DLOGL = 0, 1
 TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1
 COMM_ID_BYTES = 128
@@ -87,13 +88,14 @@ class Stats(C.Structure):
                 ("trie_nodes", C.c_int64), ("applies_per_pass", C.c_int64), ("n_tasks", C.c_int64),
                 ("prog_words", C.c_int64), ("max_slots", C.c_int32), ("max_depth", C.c_int32),
                 ("last_kernel_ms", C.c_double), ("last_total_ms", C.c_double), ("last_launches", C.c_int64),
-                ("last_fd_form", C.c_int32), ("last_fd_aborted", C.c_int32), ("last_levels", C.c_int32), ("last_zeros_resident", C.c_int32)]
+                ("last_fd_form", C.c_int32), ("last_fd_aborted", C.c_int32), ("last_levels", C.c_int32), ("last_zeros_resident", C.c_int32),
+                ("last_tiles", C.c_int32), ("reserved", C.c_int32), ("last_tiled_circuits", C.c_int64)]
 
 
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_fill_normal_eqs_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_get_fd_work", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_fill_normal_eqs_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_get_fd_work", "gst_get_tile_stats", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_set_composite", "gst_set_composite_values", "gst_set_composite_general", "gst_get_model", "gst_get_lindblad_model_sets",
@@ -150,6 +152,7 @@ def lib():
         L.gst_get_dirty_programs.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i32)]
         L.gst_get_fd_queues.argtypes = [vp, vp, i64, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
         L.gst_get_fd_work.argtypes = [vp, vp, i64, vp]
+        L.gst_get_tile_stats.argtypes = [vp, vp]
         L.gst_sort_circuits.argtypes = [i64, vp, vp, vp, vp, vp]
         L.gst_circuit_first_use.argtypes = [i64, vp, vp, i32, vp]
         L.gst_get_state_graph.argtypes = [vp, vp, vp, i64, vp, i64, C.POINTER(i64)]
@@ -689,6 +692,13 @@ class Plan:
         keys = ("wave_applies_executed", "col_applies_executed", "wave_dots_executed", "col_dots_executed",
                 "wave_applies_schedule", "col_applies_schedule", "n_waves", "n_tasks")
         return {k: int(v) for k, v in zip(keys, out)}
+
+    def tile_stats(self):
+        """gst_get_tile_stats (host only): the tiles of the D = 16 exact contraction, checked against the application tables."""
+        out = (C.c_int64 * 8)()
+        check(lib().gst_get_tile_stats(self._h, out))
+        keys = ("n_tiles", "tiled_circuits", "segment_slots", "remnant_applications", "inconsistencies", "longest_segment", "n_circuits", "circuits_in_one_tile")
+        return dict(zip(keys, [int(v) for v in out]))
 
     def state_graph(self):
         n = C.c_int64(0)

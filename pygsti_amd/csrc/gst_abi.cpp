@@ -249,6 +249,8 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
             else if (key == "hess_composed") p->hess_composed = iv != 0;
             else if (key == "cache_limit") p->test_cache_limit = val;
             else if (key == "poison") g_poison_fill = iv ? 0xFF : 0;
+            else if (key == "tiles") p->ana_tiles = iv != 0;
+            else if (key == "tile_dbg") p->tile_dbg = iv;
             else if (key == "comm_self") {}          // (read by gst_comm_create: gst_comm.cpp)
             else { delete p; return fail(GST_EINVAL, "GST_TEST_FORCE: unknown key '" + key + "'"); }
         }
@@ -910,6 +912,7 @@ int gst_get_stats(const gst_plan* p, gst_stats* s)
     s->last_kernel_ms = p->last_kernel_ms; s->last_total_ms = p->last_total_ms; s->last_launches = p->last_launches;
     s->last_fd_form = p->last_fd_form; s->last_fd_aborted = 0;
     s->last_levels = p->last_levels ? 1 : 0; s->last_zeros_resident = p->last_zeros_resident ? 1 : 0;
+    s->last_tiles = p->last_tiles ? p->n_tiles : 0; s->reserved = 0; s->last_tiled_circuits = p->last_tiles ? p->tile_stats[0] : 0;
     if (p->last_fd_form >= 1 && p->d_bin_head.p && p->n_bins > 0 && p->dev_ready) {
         uint32_t flag = 0;                  // the abort flag sits behind the queue heads
         HIP_TRY(hipSetDevice(p->device));
@@ -1016,6 +1019,10 @@ int gst_set_option(gst_plan* p, int32_t option, int64_t value)
         return GST_OK;
     case GST_OPT_FAST_PROBS:
         p->fast_probs = value != 0;
+        return GST_OK;
+    case GST_OPT_ANALYTIC_TILES:
+        if (p->rev_ready && (value != 0) != p->ana_tiles) return fail(GST_ESTATE, "GST_OPT_ANALYTIC_TILES must be set before the plan's first exact fill");
+        p->ana_tiles = value != 0;
         return GST_OK;
     default:
         return fail(GST_EINVAL, "unknown option " + std::to_string(option));

@@ -3,9 +3,238 @@
 // (gst_set_derivs / gst_set_second_derivs).
 #include "gst_state.hpp"
 
+#include <map>
+
 using namespace gst_impl;
 
 namespace gst_impl {
+
+// ---- tiles of the D = 16 contraction (gst_kernels_tiles.hip) ----------------------------------------------------------------
+// Circuits whose strings are P_i . W . Q_m for rows i and columns m: over the middle segment W the forward states depend on
+// the row only and the backward states on the column only.  Found from the two tries alone:
+//   * in suffix order (circuits sorted by their state in the reversed plan) neighbours that share most of their suffix form
+//     a RUN (one Q_m behind all the P_i); T = the suffix length common to the whole run; a member's segment starts at
+//     s = n - T and its row key is the forward state it is in there;
+//   * runs with the same set of row keys are the columns of one product; rows x columns are cut into tiles of 8 x 4;
+//   * the segment length K of a tile is verified, not assumed: the longest stretch from s on which every row's forward ids
+//     agree across the tile's columns (inside the common suffix the backward ids agree across rows by construction).
+// Everything a circuit has outside [s, s + K) goes to its remnant lists.  Tiles with K < 16 or fewer than 2 rows / 2 columns
+// are not formed; their circuits stay with the item kernel.
+// (measured with 4: 98.6 % of the 2Q design's circuits tiled, and slower -- a tile's fixed costs, ~45 us of dependent loads,
+//  barriers and stores per tile, are not worth it for middles of a few gates: 2.89 + 0.11 ms against 2.08 + 0.70 ms)
+constexpr int TILE_MIN_SEGMENT = 16;
+struct TileSet {
+    std::vector<int32_t> order, cid, blk, tsf, tsr, rem_ptr, rem_f, rem_r;
+    std::vector<uint8_t> tiled;
+    int32_t n_tiles = 0;
+    int64_t n_tiled = 0, seg_slots = 0, rem_slots = 0;
+};
+
+static void build_tiles(const gst::HostPlan& h, const gst::HostPlan& R, const std::vector<int32_t>& suffix_order, TileSet& T)
+{
+    constexpr int TRW = gst::TILE_ROWS, TCL = gst::TILE_COLS, TRC = TRW * TCL;
+    const int nG = h.n_gates;
+    const int64_t nC = h.n_circuits;
+    T.tiled.assign((size_t)nC, 0);
+    auto len = [&](int32_t c) { return (int32_t)(h.circ_ptr[c + 1] - h.circ_ptr[c]); };
+    auto gates = [&](int32_t c) { return h.circ_gates.data() + h.circ_ptr[c]; };
+    auto plain4 = [&](int32_t c) {
+        if (h.eff_ptr[c + 1] - h.eff_ptr[c] != 4) return false;
+        for (int x = 0; x < 4; x++) if (h.eff_label[(size_t)h.eff_ptr[c] + x] != x) return false;
+        return true;
+    };
+    auto fpath = [&](int32_t c, std::vector<int32_t>& f) {      // f[k] = forward state after k gates
+        const int32_t n = len(c);
+        f.resize((size_t)n + 1);
+        int32_t id = h.circ_leaf[c];
+        for (int32_t k = n; k >= 0; k--) { f[(size_t)k] = id; if (k > 0) id = h.node_parent[id]; }
+    };
+    auto rpath = [&](int32_t c, std::vector<int32_t>& r) {      // r[d] = reversed-plan state after the last d gates
+        const int32_t n = len(c);
+        r.resize((size_t)n + 1);
+        int32_t id = R.circ_leaf[c];
+        for (int32_t d = n; d >= 0; d--) { r[(size_t)d] = id; if (d > 0) id = R.node_parent[id]; }
+    };
+    auto mix = [](uint64_t x, uint64_t v) { x ^= v + 0x9E3779B97F4A7C15ull + (x << 6) + (x >> 2); x *= 0xff51afd7ed558ccdull; return x ^ (x >> 33); };
+    auto prefix_hash = [&](int32_t c, int32_t n_gates_in) {      // (preparation, first n gates): names a forward state whatever task holds it
+        uint64_t x = mix(0x1234567ull, (uint64_t)h.circ_rho[(size_t)c]);
+        const int32_t* g = gates(c);
+        for (int32_t k = 0; k < n_gates_in; k++) x = mix(x, (uint64_t)g[k] + 1);
+        return x;
+    };
+    // ---- runs of the suffix order: one ending (and middle) behind different SHORT beginnings ---------------------------------
+    // (strings are compared, not state ids: both plans are cut into tasks, and a state shared across a cut has two ids -- with
+    //  equal values; the tile then reads row 0's backward states for the column and column 0's forward states for the row)
+    struct Run { std::vector<int32_t> members; int32_t T = 0x7fffffff; std::vector<uint64_t> keys; };
+    std::vector<Run> runs;
+    {
+        int32_t prev = -1;
+        for (int64_t k = 0; k < (int64_t)suffix_order.size(); k++) {
+            const int32_t c = suffix_order[(size_t)k];
+            if (!plain4(c)) { prev = -1; continue; }
+            bool joined = false;
+            if (prev >= 0) {
+                const int32_t n1 = len(prev), n2 = len(c), lim = std::min(n1, n2);
+                const int32_t *g1 = gates(prev) + n1, *g2 = gates(c) + n2;
+                int32_t lcs = 0;
+                while (lcs < lim && g1[-1 - lcs] == g2[-1 - lcs]) lcs++;
+                if (lcs >= TILE_MIN_SEGMENT && std::max(n1, n2) - lcs <= 12) {
+                    runs.back().members.push_back(c);
+                    runs.back().T = std::min(runs.back().T, lcs);
+                    joined = true;
+                }
+            }
+            if (!joined) { runs.emplace_back(); runs.back().members.push_back(c); }
+            prev = c;
+        }
+    }
+    // ---- row keys (the beginning each member has in front of the common suffix); runs with the same rows AND the same
+    //      middle string are the columns of one product -------------------------------------------------------------------------
+    std::map<std::vector<uint64_t>, std::vector<int32_t>> groups;
+    for (size_t q = 0; q < runs.size(); q++) {
+        Run& r = runs[q];
+        if (r.members.size() < 2) continue;
+        std::vector<std::pair<uint64_t, int32_t>> km;
+        for (int32_t c : r.members) km.emplace_back(prefix_hash(c, len(c) - r.T), c);
+        std::sort(km.begin(), km.end());
+        bool dup = false;
+        for (size_t k = 1; k < km.size(); k++) dup = dup || km[k].first == km[k - 1].first;
+        if (dup) continue;
+        r.keys.clear(); r.members.clear();
+        for (auto& x : km) { r.keys.push_back(x.first); r.members.push_back(x.second); }
+        const std::vector<uint64_t>& key = r.keys;
+        groups[key].push_back((int32_t)q);
+    }
+    // ---- tiles ---------------------------------------------------------------------------------------------------------------
+    std::vector<int64_t> tile_work;
+    std::vector<std::vector<int32_t>> fp((size_t)TRC), rcol((size_t)TCL);
+    std::vector<std::vector<int32_t>> g_slots((size_t)nG);
+    for (auto& kv : groups) {
+        // the columns of one product: runs whose common suffixes agree but for their last few gates.  Sorted by suffix string,
+        // such runs are neighbours; a chunk of up to TILE_COLS of them is extended while the next one shares all but <= 8
+        // gates of the LONGER suffix with the chunk's first
+        std::vector<int32_t> sorted_runs = kv.second;
+        auto suffix = [&](int32_t q, const int32_t*& g, int32_t& n) { const Run& r = runs[(size_t)q]; const int32_t c = r.members[0]; n = r.T; g = gates(c) + (len(c) - r.T); };
+        std::sort(sorted_runs.begin(), sorted_runs.end(), [&](int32_t x, int32_t y) {
+            const int32_t *gx, *gy; int32_t nx, ny;
+            suffix(x, gx, nx); suffix(y, gy, ny);
+            return std::lexicographical_compare(gx, gx + nx, gy, gy + ny);
+        });
+        const int n_rows_all = (int)kv.first.size();
+        std::vector<std::vector<int32_t>> chunks;
+        for (size_t k = 0; k < sorted_runs.size();) {
+            std::vector<int32_t> ch{sorted_runs[k]};
+            const int32_t *g0; int32_t n0;
+            suffix(sorted_runs[k], g0, n0);
+            size_t k2 = k + 1;
+            while (k2 < sorted_runs.size() && (int)ch.size() < TCL) {
+                const int32_t *g1; int32_t n1;
+                suffix(sorted_runs[k2], g1, n1);
+                int32_t l = 0;
+                while (l < n0 && l < n1 && g0[l] == g1[l]) l++;
+                if (l < TILE_MIN_SEGMENT || l < std::max(n0, n1) - 8) break;
+                ch.push_back(sorted_runs[k2]); k2++;
+            }
+            chunks.push_back(ch);
+            k = k2;
+        }
+        for (const std::vector<int32_t>& cols : chunks) {
+            const size_t c0 = 0;
+            const int ncol = (int)cols.size();
+            if (ncol < 2 && n_rows_all < 4) continue;          // (a single column is still worth a tile when it has rows to share it)
+            for (int r0 = 0; r0 < n_rows_all; r0 += TRW) {
+                const int nrow = std::min(TRW, n_rows_all - r0);
+                if (nrow < 2) continue;
+                auto circ = [&](int i, int m) { return runs[(size_t)cols[c0 + (size_t)m]].members[(size_t)(r0 + i)]; };
+                auto seg0 = [&](int i, int m) { return len(circ(i, m)) - runs[(size_t)cols[c0 + (size_t)m]].T; };
+                int32_t K = 0x7fffffff;
+                for (int m = 0; m < ncol; m++) K = std::min(K, runs[(size_t)cols[c0 + (size_t)m]].T);
+                // every row: the same beginning in every column (exactly, not by hash), then the same gates from s on
+                bool ok = true;
+                for (int i = 0; i < nrow && ok && K >= TILE_MIN_SEGMENT; i++)
+                    for (int m = 1; m < ncol && ok; m++) {
+                        const int32_t ca = circ(i, 0), cb = circ(i, m), s0 = seg0(i, 0), sm = seg0(i, m);
+                        ok = s0 == sm && h.circ_rho[(size_t)ca] == h.circ_rho[(size_t)cb] && std::equal(gates(ca), gates(ca) + s0, gates(cb));
+                        if (!ok) break;
+                        const int32_t *ga = gates(ca) + s0, *gb = gates(cb) + sm;
+                        int32_t u = 0;
+                        while (u < K && ga[u] == gb[u]) u++;
+                        K = std::min(K, u);
+                    }
+                if (!ok || K < TILE_MIN_SEGMENT) continue;
+                const int32_t tile = T.n_tiles++;
+                T.cid.resize((size_t)T.n_tiles * TRC, -1);
+                for (int i = 0; i < nrow; i++)
+                    for (int m = 0; m < ncol; m++) { T.cid[(size_t)tile * TRC + (size_t)i * TCL + m] = circ(i, m); T.tiled[(size_t)circ(i, m)] = 1; T.n_tiled++; }
+                for (int i = 0; i < nrow; i++) fpath(circ(i, 0), fp[(size_t)i * TCL]);      // the row's forward states: column 0's circuit
+                for (int m = 0; m < ncol; m++) rpath(circ(0, m), rcol[(size_t)m]);          // the column's backward states: row 0's circuit
+                for (auto& v : g_slots) v.clear();
+                {
+                    const int32_t cc = circ(0, 0), s = seg0(0, 0);
+                    for (int32_t u = 0; u < K; u++) g_slots[(size_t)gates(cc)[s + u]].push_back(u);
+                }
+                T.blk.resize((size_t)T.n_tiles * (nG + 1));
+                for (int g = 0; g < nG; g++) {
+                    T.blk[(size_t)tile * (nG + 1) + g] = (int32_t)(T.tsf.size() / (4 * TRW));
+                    const auto& us = g_slots[(size_t)g];
+                    for (size_t q = 0; q < us.size(); q += 4) {
+                        const size_t fb = T.tsf.size(), rb = T.tsr.size();
+                        T.tsf.resize(fb + 4 * TRW, -1); T.tsr.resize(rb + 4 * TCL, -1);
+                        for (size_t sl = 0; sl < 4 && q + sl < us.size(); sl++) {
+                            const int32_t u = us[q + sl];
+                            for (int i = 0; i < nrow; i++) T.tsf[fb + sl * TRW + (size_t)i] = fp[(size_t)i * TCL][(size_t)(seg0(i, 0) + u)];
+                            for (int m = 0; m < ncol; m++) {
+                                const int32_t n = len(circ(0, m)), s = seg0(0, m);
+                                T.tsr[rb + sl * TCL + (size_t)m] = rcol[(size_t)m][(size_t)(n - (s + u + 1))];
+                            }
+                        }
+                    }
+                    T.seg_slots += (int64_t)us.size();
+                }
+                T.blk[(size_t)tile * (nG + 1) + nG] = (int32_t)(T.tsf.size() / (4 * TRW));
+                // remnants: per gate, per circuit slot, the applications outside [s, s + K) -- the circuit's OWN state ids
+                T.rem_ptr.resize((size_t)T.n_tiles * nG * (TRC + 1));
+                std::vector<std::vector<std::pair<int32_t, int32_t>>> per_gate((size_t)nG * TRC);
+                std::vector<int32_t> ff, rr;
+                for (int i = 0; i < nrow; i++)
+                    for (int m = 0; m < ncol; m++) {
+                        const int32_t cc = circ(i, m), n = len(cc), s = seg0(i, m);
+                        fpath(cc, ff); rpath(cc, rr);
+                        for (int32_t k = 1; k <= n; k++) {
+                            if (k > s && k <= s + K) continue;
+                            const int g = gates(cc)[k - 1];
+                            per_gate[(size_t)g * TRC + (size_t)i * TCL + m].emplace_back(ff[(size_t)(k - 1)], rr[(size_t)(n - k)]);
+                        }
+                    }
+                for (int g = 0; g < nG; g++) {
+                    int32_t* rp = &T.rem_ptr[((size_t)tile * nG + g) * (TRC + 1)];
+                    for (int sl = 0; sl < TRC; sl++) {
+                        rp[sl] = (int32_t)(T.rem_f.size() / 4);
+                        const auto& v = per_gate[(size_t)g * TRC + sl];
+                        for (size_t q = 0; q < v.size(); q++) { T.rem_f.push_back(v[q].first); T.rem_r.push_back(v[q].second); }
+                        while (T.rem_f.size() % 4) { T.rem_f.push_back(-1); T.rem_r.push_back(v.back().second); }
+                        T.rem_slots += (int64_t)v.size();
+                    }
+                    rp[TRC] = (int32_t)(T.rem_f.size() / 4);
+                }
+                tile_work.push_back((int64_t)K * nrow * ncol);
+            }
+        }
+    }
+    if (std::getenv("GST_TILE_DEBUG")) {
+        size_t big = 0, g2 = 0;
+        for (auto& r : runs) big += r.members.size() >= 2;
+        for (auto& kv : groups) g2 += kv.second.size() >= 2;
+        std::fprintf(stderr, "[tiles] %zu runs (%zu with >= 2 members), %zu groups (%zu with >= 2 columns), %d tiles, %lld circuits\n",
+                     runs.size(), big, groups.size(), g2, T.n_tiles, (long long)T.n_tiled);
+    }
+    T.order.resize((size_t)T.n_tiles);
+    for (int32_t k = 0; k < T.n_tiles; k++) T.order[(size_t)k] = k;
+    std::stable_sort(T.order.begin(), T.order.end(), [&](int32_t x, int32_t y) { return tile_work[(size_t)x] > tile_work[(size_t)y]; });
+    if (T.tsf.empty()) { T.tsf.assign(4 * TRW, -1); T.tsr.assign(4 * TCL, -1); }
+    if (T.rem_f.empty()) { T.rem_f.assign(4, -1); T.rem_r.assign(4, 0); }
+}
+
 
 // Analytic mode, D = 16: reversed plan + pair tables, built and uploaded once per plan.
 int ensure_reverse(gst_plan* p)
@@ -54,135 +283,173 @@ int ensure_reverse(gst_plan* p)
         const int64_t longer = std::max(h.circ_ptr[c + 1] - h.circ_ptr[c], h.circ_ptr[c2 + 1] - h.circ_ptr[c2]);
         return common >= 8 && 2 * common >= longer;
     };
-    if (h.D == 16 && p->ana_germ_order && h.n_circuits > 1) {
-        // Locality of the FORWARD states.  Pure suffix order keeps the backward chains of neighbours together but walks
-        // through every prefix family (preparation fiducial x germ) for each measurement fiducial and germ power, so the
-        // forward chains -- 128 bytes per application of every item -- never stay in an XCD's 4 MB L2.  Runs of
-        // neighbours that end alike (one germ power and measurement fiducial behind all the preparation fiducials)
-        // are kept whole, and the runs are ordered by the forward-trie family their first member belongs to (the root
-        // of its state's parent chain = the task of the forward plan): all the runs of one germ become consecutive, their
-        // 16 forward chains (2 MB) stay in L2 while the germ's backward chains stream through once.
-        std::vector<int32_t> root((size_t)h.n_state_ids, -2);
-        auto root_of = [&](int32_t id) {
-            int32_t r = id;
-            while (root[(size_t)r] == -2 && h.node_parent[(size_t)r] >= 0) r = h.node_parent[(size_t)r];
-            const int32_t top = root[(size_t)r] == -2 ? r : root[(size_t)r];
-            for (int32_t q = id; q != r; q = h.node_parent[(size_t)q]) root[(size_t)q] = top;
-            root[(size_t)r] = top;
-            return top;
-        };
-        std::vector<int32_t> run_of((size_t)h.n_circuits, 0), run_key;
-        int32_t run = 0;
-        run_key.push_back(root_of(h.circ_leaf[(size_t)order[0]]));
-        for (int64_t k = 1; k < h.n_circuits; k++) {
-            const int32_t c = order[(size_t)k - 1], c2 = order[(size_t)k];
-            if (!similar(c, c2, common_tail(c, c2, nullptr))) { run++; run_key.push_back(0x7fffffff); }
-            run_of[(size_t)k] = run;
-            run_key[(size_t)run] = std::min(run_key[(size_t)run], root_of(h.circ_leaf[(size_t)c2]));
+    // The work items of the item kernel over a set of circuits (suffix order in, locality order / pairing / ranges / block
+    // stream out): once for ALL circuits (what every mode of the contraction can run on), and -- when tiles were formed --
+    // once more for the circuits no tile holds.
+    struct ItemBufs { DevBuf<int32_t>*order, *partner, *common, *bf1, *bf2, *br, *bptr; DevBuf<uint32_t>*range, *counter; };
+    auto build_items = [&](std::vector<int32_t> order, const ItemBufs& B, int64_t* n_items_out) -> int {
+        const int64_t nC = (int64_t)order.size();
+        int rc = GST_OK;
+        if (h.D == 16 && p->ana_germ_order && nC > 1) {
+            // Locality of the FORWARD states.  Pure suffix order keeps the backward chains of neighbours together but walks
+            // through every prefix family (preparation fiducial x germ) for each measurement fiducial and germ power, so the
+            // forward chains -- 128 bytes per application of every item -- never stay in an XCD's 4 MB L2.  Runs of
+            // neighbours that end alike (one germ power and measurement fiducial behind all the preparation fiducials)
+            // are kept whole, and the runs are ordered by the forward-trie family their first member belongs to (the root
+            // of its state's parent chain = the task of the forward plan): all the runs of one germ become consecutive, their
+            // 16 forward chains (2 MB) stay in L2 while the germ's backward chains stream through once.
+            std::vector<int32_t> root((size_t)h.n_state_ids, -2);
+            auto root_of = [&](int32_t id) {
+                int32_t r = id;
+                while (root[(size_t)r] == -2 && h.node_parent[(size_t)r] >= 0) r = h.node_parent[(size_t)r];
+                const int32_t top = root[(size_t)r] == -2 ? r : root[(size_t)r];
+                for (int32_t q = id; q != r; q = h.node_parent[(size_t)q]) root[(size_t)q] = top;
+                root[(size_t)r] = top;
+                return top;
+            };
+            std::vector<int32_t> run_of((size_t)nC, 0), run_key;
+            int32_t run = 0;
+            run_key.push_back(root_of(h.circ_leaf[(size_t)order[0]]));
+            for (int64_t k = 1; k < nC; k++) {
+                const int32_t c = order[(size_t)k - 1], c2 = order[(size_t)k];
+                if (!similar(c, c2, common_tail(c, c2, nullptr))) { run++; run_key.push_back(0x7fffffff); }
+                run_of[(size_t)k] = run;
+                run_key[(size_t)run] = std::min(run_key[(size_t)run], root_of(h.circ_leaf[(size_t)c2]));
+            }
+            std::vector<int32_t> posn((size_t)nC);
+            for (int64_t k = 0; k < nC; k++) posn[(size_t)k] = (int32_t)k;
+            std::stable_sort(posn.begin(), posn.end(), [&](int32_t x, int32_t y) { return run_key[(size_t)run_of[(size_t)x]] < run_key[(size_t)run_of[(size_t)y]]; });
+            std::vector<int32_t> reordered((size_t)nC);
+            for (int64_t k = 0; k < nC; k++) reordered[(size_t)k] = order[(size_t)posn[(size_t)k]];
+            order.swap(reordered);
         }
-        std::vector<int32_t> posn((size_t)h.n_circuits);
-        for (int64_t k = 0; k < h.n_circuits; k++) posn[(size_t)k] = (int32_t)k;
-        std::stable_sort(posn.begin(), posn.end(), [&](int32_t x, int32_t y) { return run_key[(size_t)run_of[(size_t)x]] < run_key[(size_t)run_of[(size_t)y]]; });
-        std::vector<int32_t> reordered((size_t)h.n_circuits);
-        for (int64_t k = 0; k < h.n_circuits; k++) reordered[(size_t)k] = order[(size_t)posn[(size_t)k]];
-        order.swap(reordered);
-    }
-    // Work items of the D = 16 contraction: a circuit, or TWO neighbours of the suffix order whose last applications
-    // coincide (same germ power and measurement fiducial behind different preparation fiducials): over the common
-    // tail their backward states are the same vectors and the kernel gathers them once for both.
-    std::vector<int32_t> item_first, item_partner, item_common;
-    const bool pairing = h.D == 16 && h.n_effects == 4 && p->ana_pairs;
-    auto plain4 = [&](int32_t c) {
-        if (h.eff_ptr[c + 1] - h.eff_ptr[c] != 4) return false;
-        for (int x = 0; x < 4; x++) if (h.eff_label[(size_t)h.eff_ptr[c] + x] != x) return false;
-        return true;
-    };
-    for (int64_t k = 0; k < h.n_circuits; k++) {
-        const int32_t c = order[(size_t)k];
-        bool paired = false;
-        if (pairing && k + 1 < h.n_circuits) {
-            const int32_t c2 = order[(size_t)k + 1];
-            if (plain4(c) && plain4(c2)) {
-                std::vector<int32_t> cg((size_t)nG, 0);
-                const int64_t common = common_tail(c, c2, cg.data());
-                if (similar(c, c2, common)) {
-                    item_first.push_back(c); item_partner.push_back(c2);
-                    item_common.insert(item_common.end(), cg.begin(), cg.end());
-                    paired = true;
-                    k++;
+        // Work items of the D = 16 contraction: a circuit, or TWO neighbours of the suffix order whose last applications
+        // coincide (same germ power and measurement fiducial behind different preparation fiducials): over the common
+        // tail their backward states are the same vectors and the kernel gathers them once for both.
+        std::vector<int32_t> item_first, item_partner, item_common;
+        const bool pairing = h.D == 16 && h.n_effects == 4 && p->ana_pairs;
+        auto plain4 = [&](int32_t c) {
+            if (h.eff_ptr[c + 1] - h.eff_ptr[c] != 4) return false;
+            for (int x = 0; x < 4; x++) if (h.eff_label[(size_t)h.eff_ptr[c] + x] != x) return false;
+            return true;
+        };
+        for (int64_t k = 0; k < nC; k++) {
+            const int32_t c = order[(size_t)k];
+            bool paired = false;
+            if (pairing && k + 1 < nC) {
+                const int32_t c2 = order[(size_t)k + 1];
+                if (plain4(c) && plain4(c2)) {
+                    std::vector<int32_t> cg((size_t)nG, 0);
+                    const int64_t common = common_tail(c, c2, cg.data());
+                    if (similar(c, c2, common)) {
+                        item_first.push_back(c); item_partner.push_back(c2);
+                        item_common.insert(item_common.end(), cg.begin(), cg.end());
+                        paired = true;
+                        k++;
+                    }
                 }
             }
-        }
-        if (!paired) {
-            item_first.push_back(c); item_partner.push_back(-1);
-            item_common.insert(item_common.end(), (size_t)nG, 0);
-        }
-    }
-    const int64_t n_items = (int64_t)item_first.size();
-    if (h.D == 16) {
-        if ((rc = upload_i32(p, p->d_circ_order, item_first))) return rc;
-        if ((rc = upload_i32(p, p->d_circ_partner, item_partner))) return rc;
-        if ((rc = upload_i32(p, p->d_pair_common, item_common))) return rc;
-    } else {
-        if ((rc = upload_i32(p, p->d_circ_order, order))) return rc;
-    }
-    // 8 contiguous ranges of the item list with equal numbers of gate applications (+ a constant per circuit)
-    std::vector<uint32_t> range_begin(9, 0);
-    {
-        auto work = [&](int64_t k) {
-            double w = (double)(h.circ_ptr[item_first[(size_t)k] + 1] - h.circ_ptr[item_first[(size_t)k]]) + 24.0;
-            if (item_partner[(size_t)k] >= 0) w += (double)(h.circ_ptr[item_partner[(size_t)k] + 1] - h.circ_ptr[item_partner[(size_t)k]]) + 24.0;
-            return w;
-        };
-        double total = 0;
-        for (int64_t k = 0; k < n_items; k++) total += work(k);
-        double acc = 0;
-        int r = 1;
-        for (int64_t k = 0; k < n_items && r < 8; k++) {
-            acc += work(k);
-            while (r < 8 && acc >= total * r / 8.0) range_begin[r++] = (uint32_t)(k + 1);
-        }
-        for (; r < 8; r++) range_begin[r] = (uint32_t)n_items;
-        range_begin[8] = (uint32_t)n_items;
-    }
-    if (h.D != 16) {            // (the other contraction kernels index the plain permutation; their ranges are unused)
-        for (int r = 0; r <= 8; r++) range_begin[r] = (uint32_t)(h.n_circuits * r / 8);
-    }
-    HIP_TRY(p->d_range_begin.ensure(9));
-    H2D_TRY(p, p->d_range_begin.p, range_begin.data(), 9 * 4);
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(p->d_work_counter.ensure(8));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    if (h.D == 16 && pairing && p->ana_stream && nG <= 63) {
-        // Two-circuit items as ONE stream of blocks of 4 "slots": per gate the common tail (slot = one application of
-        // both circuits: their two forward ids and the shared backward id), then what each circuit has before the tail
-        // (the other circuit's forward id = -1: its operand is zeroed), padded to a multiple of 4 with dead slots.  The
-        // contraction's gather pipeline then runs through a whole item without draining at every gate and segment.
-        const size_t blk_slots = 4 * (size_t)gst::analytic_stream_chunks();
-        std::vector<int32_t> bf1, bf2, br, bptr((size_t)n_items * (size_t)nG + 1, 0);
-        bf1.reserve(pf.size()); bf2.reserve(pf.size()); br.reserve(pf.size());
-        for (int64_t k = 0; k < n_items; k++) {
-            const int32_t c = item_first[(size_t)k], c2 = item_partner[(size_t)k];
-            for (int g = 0; g < nG; g++) {
-                bptr[(size_t)k * nG + g] = (int32_t)(bf1.size() / blk_slots);
-                if (c2 < 0) continue;
-                const int64_t p0 = pos_ptr[(size_t)c * nG + g], p1 = pos_ptr[(size_t)c * nG + g + 1];
-                const int64_t q0 = pos_ptr[(size_t)c2 * nG + g], q1 = pos_ptr[(size_t)c2 * nG + g + 1];
-                const int64_t cg = item_common[(size_t)k * nG + g];
-                for (int64_t t = 0; t < cg; t++) { bf1.push_back(pf[(size_t)(p1 - cg + t)]); bf2.push_back(pf[(size_t)(q1 - cg + t)]); br.push_back(pr[(size_t)(p1 - cg + t)]); }
-                for (int64_t j = p0; j < p1 - cg; j++) { bf1.push_back(pf[(size_t)j]); bf2.push_back(-1); br.push_back(pr[(size_t)j]); }
-                for (int64_t j = q0; j < q1 - cg; j++) { bf1.push_back(-1); bf2.push_back(pf[(size_t)j]); br.push_back(pr[(size_t)j]); }
-                while (bf1.size() % blk_slots) { bf1.push_back(-1); bf2.push_back(-1); br.push_back(br.empty() ? 0 : br.back()); }
+            if (!paired) {
+                item_first.push_back(c); item_partner.push_back(-1);
+                item_common.insert(item_common.end(), (size_t)nG, 0);
             }
-            if (bf1.size() / 4 > 0x1ffffff0u) return fail(GST_EUNSUPPORTED, "analytic block stream too long");
         }
-        bptr[(size_t)n_items * nG] = (int32_t)(bf1.size() / blk_slots);
-        if (bf1.empty()) { bf1.assign(blk_slots, -1); bf2.assign(blk_slots, -1); br.assign(blk_slots, 0); }
-        if ((rc = upload_i32(p, p->d_blk_f1, bf1))) return rc;
-        if ((rc = upload_i32(p, p->d_blk_f2, bf2))) return rc;
-        if ((rc = upload_i32(p, p->d_blk_r, br))) return rc;
-        if ((rc = upload_i32(p, p->d_blk_ptr, bptr))) return rc;
+        const int64_t n_items = (int64_t)item_first.size();
+        if (h.D == 16) {
+            if ((rc = upload_i32(p, (*B.order), item_first))) return rc;
+            if ((rc = upload_i32(p, (*B.partner), item_partner))) return rc;
+            if ((rc = upload_i32(p, (*B.common), item_common))) return rc;
+        } else {
+            if ((rc = upload_i32(p, (*B.order), order))) return rc;
+        }
+        // 8 contiguous ranges of the item list with equal numbers of gate applications (+ a constant per circuit)
+        std::vector<uint32_t> range_begin(9, 0);
+        {
+            auto work = [&](int64_t k) {
+                double w = (double)(h.circ_ptr[item_first[(size_t)k] + 1] - h.circ_ptr[item_first[(size_t)k]]) + 24.0;
+                if (item_partner[(size_t)k] >= 0) w += (double)(h.circ_ptr[item_partner[(size_t)k] + 1] - h.circ_ptr[item_partner[(size_t)k]]) + 24.0;
+                return w;
+            };
+            double total = 0;
+            for (int64_t k = 0; k < n_items; k++) total += work(k);
+            double acc = 0;
+            int r = 1;
+            for (int64_t k = 0; k < n_items && r < 8; k++) {
+                acc += work(k);
+                while (r < 8 && acc >= total * r / 8.0) range_begin[r++] = (uint32_t)(k + 1);
+            }
+            for (; r < 8; r++) range_begin[r] = (uint32_t)n_items;
+            range_begin[8] = (uint32_t)n_items;
+        }
+        if (h.D != 16) {            // (the other contraction kernels index the plain permutation; their ranges are unused)
+            for (int r = 0; r <= 8; r++) range_begin[r] = (uint32_t)(nC * r / 8);
+        }
+        HIP_TRY((*B.range).ensure(9));
+        H2D_TRY(p, (*B.range).p, range_begin.data(), 9 * 4);
         HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY((*B.counter).ensure(8));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (h.D == 16 && pairing && p->ana_stream && nG <= 63) {
+            // Two-circuit items as ONE stream of blocks of 4 "slots": per gate the common tail (slot = one application of
+            // both circuits: their two forward ids and the shared backward id), then what each circuit has before the tail
+            // (the other circuit's forward id = -1: its operand is zeroed), padded to a multiple of 4 with dead slots.  The
+            // contraction's gather pipeline then runs through a whole item without draining at every gate and segment.
+            const size_t blk_slots = 4 * (size_t)gst::analytic_stream_chunks();
+            std::vector<int32_t> bf1, bf2, br, bptr((size_t)n_items * (size_t)nG + 1, 0);
+            bf1.reserve(pf.size()); bf2.reserve(pf.size()); br.reserve(pf.size());
+            for (int64_t k = 0; k < n_items; k++) {
+                const int32_t c = item_first[(size_t)k], c2 = item_partner[(size_t)k];
+                for (int g = 0; g < nG; g++) {
+                    bptr[(size_t)k * nG + g] = (int32_t)(bf1.size() / blk_slots);
+                    if (c2 < 0) continue;
+                    const int64_t p0 = pos_ptr[(size_t)c * nG + g], p1 = pos_ptr[(size_t)c * nG + g + 1];
+                    const int64_t q0 = pos_ptr[(size_t)c2 * nG + g], q1 = pos_ptr[(size_t)c2 * nG + g + 1];
+                    const int64_t cg = item_common[(size_t)k * nG + g];
+                    for (int64_t t = 0; t < cg; t++) { bf1.push_back(pf[(size_t)(p1 - cg + t)]); bf2.push_back(pf[(size_t)(q1 - cg + t)]); br.push_back(pr[(size_t)(p1 - cg + t)]); }
+                    for (int64_t j = p0; j < p1 - cg; j++) { bf1.push_back(pf[(size_t)j]); bf2.push_back(-1); br.push_back(pr[(size_t)j]); }
+                    for (int64_t j = q0; j < q1 - cg; j++) { bf1.push_back(-1); bf2.push_back(pf[(size_t)j]); br.push_back(pr[(size_t)j]); }
+                    while (bf1.size() % blk_slots) { bf1.push_back(-1); bf2.push_back(-1); br.push_back(br.empty() ? 0 : br.back()); }
+                }
+                if (bf1.size() / 4 > 0x1ffffff0u) return fail(GST_EUNSUPPORTED, "analytic block stream too long");
+            }
+            bptr[(size_t)n_items * nG] = (int32_t)(bf1.size() / blk_slots);
+            if (bf1.empty()) { bf1.assign(blk_slots, -1); bf2.assign(blk_slots, -1); br.assign(blk_slots, 0); }
+            if ((rc = upload_i32(p, (*B.bf1), bf1))) return rc;
+            if ((rc = upload_i32(p, (*B.bf2), bf2))) return rc;
+            if ((rc = upload_i32(p, (*B.br), br))) return rc;
+            if ((rc = upload_i32(p, (*B.bptr), bptr))) return rc;
+            HIP_TRY(hipStreamSynchronize(p->stream));
+        }
+        *n_items_out = n_items;
+        return GST_OK;
+    };
+    // tiles first (they need the reversed plan's state graph, like the level programs below)
+    std::vector<int32_t> leftover;
+    p->n_tiles = 0; p->n_lo_circuits = 0;
+    if (h.D == 16 && h.n_effects == 4 && p->ana_pairs && p->ana_stream && p->ana_tiles && nG <= 63 && h.n_circuits >= 64) {
+        TileSet T;
+        build_tiles(h, p->rev, order, T);
+        if (T.n_tiles > 0) {
+            if ((rc = upload_i32(p, p->d_tile_order, T.order)) || (rc = upload_i32(p, p->d_tile_cid, T.cid)) || (rc = upload_i32(p, p->d_tile_blk, T.blk)) ||
+                (rc = upload_i32(p, p->d_tsf, T.tsf)) || (rc = upload_i32(p, p->d_tsr, T.tsr)) || (rc = upload_i32(p, p->d_rem_ptr, T.rem_ptr)) ||
+                (rc = upload_i32(p, p->d_rem_f, T.rem_f)) || (rc = upload_i32(p, p->d_rem_r, T.rem_r))) return rc;
+            HIP_TRY(p->d_tile_counter.ensure(1));
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            p->n_tiles = T.n_tiles;
+            p->tile_stats[0] = T.n_tiled; p->tile_stats[1] = T.seg_slots; p->tile_stats[2] = T.rem_slots;
+            for (int32_t c : order) if (!T.tiled[(size_t)c]) leftover.push_back(c);
+            p->n_lo_circuits = (int64_t)leftover.size();
+        }
+    }
+    int64_t n_items = 0;
+    {
+        ItemBufs B{&p->d_circ_order, &p->d_circ_partner, &p->d_pair_common, &p->d_blk_f1, &p->d_blk_f2, &p->d_blk_r, &p->d_blk_ptr, &p->d_range_begin, &p->d_work_counter};
+        if ((rc = build_items(order, B, &n_items))) return rc;
+    }
+    if (p->n_tiles > 0 && !leftover.empty()) {
+        ItemBufs B{&p->d_lo_order, &p->d_lo_partner, &p->d_lo_common, &p->d_lo_blk_f1, &p->d_lo_blk_f2, &p->d_lo_blk_r, &p->d_lo_blk_ptr, &p->d_lo_range_begin, &p->d_lo_counter};
+        int64_t n_lo_items = 0;
+        if ((rc = build_items(leftover, B, &n_lo_items))) return rc;
     }
     if (h.D == 16) build_levels_host(p, true);      // (needs the reversed plan's state graph, dropped below; whatever GST_OPT_FAST_CHAINS says NOW)
     // (the host copies of the reversed programs are not needed any more)
@@ -370,12 +637,37 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
         if (!claim) gst::track_touch(d_out, extent);
         p->last_zeros_resident = a.zeros_resident != 0;
         p->ana_zero_out = d_out; p->ana_zero_ld = ld; p->ana_zero_valid = (D == 16);
+        // D = 16, a plain Jacobian fill: the circuits of the tiles on the tile kernel, the rest on the item kernel (disjoint rows)
+        const bool use_tiles = D == 16 && p->n_tiles > 0 && !a.wide && !p->want_cache_path && a.blk_ptr != nullptr;
+        p->last_tiles = use_tiles;
+        if (use_tiles) {
+            gst::TileArgs t;
+            std::memset(&t, 0, sizeof(t));
+            t.a = a;
+            t.n_tiles = p->n_tiles; t.debug = p->tile_dbg;
+            t.tile_order = p->d_tile_order.p; t.tile_cid = p->d_tile_cid.p; t.tile_blk = p->d_tile_blk.p; t.tsf = p->d_tsf.p; t.tsr = p->d_tsr.p;
+            t.rem_ptr = p->d_rem_ptr.p; t.rem_f = p->d_rem_f.p; t.rem_r = p->d_rem_r.p; t.counter = p->d_tile_counter.p;
+            HIP_TRY(hipMemsetAsync(p->d_tile_counter.p, 0, sizeof(uint32_t), p->stream));
+            HIP_TRY(gst::launch_analytic_tiles(t, p->n_cus, p->stream));
+            p->last_launches++;
+            if (p->n_lo_circuits > 0) {
+                gst::AnaArgs lo = a;
+                lo.n_circuits = p->n_lo_circuits;
+                lo.circ_order = p->d_lo_order.p; lo.circ_partner = p->d_lo_partner.p; lo.pair_common = p->d_lo_common.p;
+                lo.blk_f1 = p->d_lo_blk_f1.p; lo.blk_f2 = p->d_lo_blk_f2.p; lo.blk_r = p->d_lo_blk_r.p; lo.blk_ptr = p->d_lo_blk_ptr.p;
+                lo.range_begin = p->d_lo_range_begin.p; lo.work_counter = p->d_lo_counter.p;
+                HIP_TRY(hipMemsetAsync(p->d_lo_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
+                HIP_TRY(gst::launch_analytic_mfma(lo, p->stream));
+                p->last_launches++;
+            }
+        } else {
         HIP_TRY(hipMemsetAsync(p->d_work_counter.p, 0, 8 * sizeof(uint32_t), p->stream));
         if (D == 64) HIP_TRY(gst::launch_analytic_mfma64(a, p->stream));
         else if (D == 16) HIP_TRY(gst::launch_analytic_mfma(a, p->stream));
         else HIP_TRY(gst::launch_analytic_small(a, p->stream));
-        TIME_REC(p, evk1);
         p->last_launches++;
+        }
+        TIME_REC(p, evk1);
         if (claim) {         // what this fill leaves behind; the word reads 1 again whatever a row scaling did to it before
             if (uint32_t* w = gst::track_claim_set(d_out, extent, sig, p->device, p->uid)) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)w, 1, 1, p->stream));
         }
@@ -612,6 +904,95 @@ int gst_set_second_derivs(gst_plan* p, int32_t n_objs, const int32_t* nonzero, c
     }
     p->dv2_off = off;
     p->dv2_set = total > 0;
+    return GST_OK;
+    });
+}
+
+
+// Host-only: form the tiles of the D = 16 exact contraction for this plan and CHECK them against the pair tables the item
+// kernel reads -- for every tiled circuit and every gate, the (forward id, backward id) pairs of its segment slots and of its
+// remnant lists together must be exactly the circuit's applications of that gate (build_pair_tables), as a multiset.
+int gst_get_tile_stats(gst_plan* p, int64_t* out)
+{
+    return guarded([&]() -> int {
+    if (!p || !out) return fail(GST_EINVAL, "NULL argument");
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    const gst::HostPlan& h = p->hp;
+    if (h.D != 16 || h.n_effects != 4 || h.n_gates > 63) return GST_OK;          // (no tiles for such plans)
+    gst::HostPlan R;
+    std::string err = gst::build_reverse_plan(h, R, 0, 1);
+    if (!err.empty()) return fail(GST_EINVAL, "reversed plan: " + err);
+    std::vector<int32_t> pf, pr;
+    std::vector<int64_t> pos_ptr;
+    gst::build_pair_tables(h, R, pf, pr, pos_ptr);
+    std::vector<int32_t> order((size_t)h.n_circuits);
+    for (int64_t c = 0; c < h.n_circuits; c++) order[(size_t)c] = (int32_t)c;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return R.circ_leaf[x] < R.circ_leaf[y]; });
+    TileSet T;
+    build_tiles(h, R, order, T);
+    constexpr int TRW = gst::TILE_ROWS, TCL = gst::TILE_COLS, TRC = TRW * TCL;
+    const int nG = h.n_gates;
+    int64_t bad = 0, max_K = 0;
+    // A state is named by its string, not by its id: both plans are cut into tasks, and a tile reads a row's forward states /
+    // a column's backward states through ONE member's ids (equal strings, equal values).  Path hashes of both state graphs:
+    auto path_hashes = [](const gst::HostPlan& P, std::vector<uint64_t>& out) {
+        auto mix = [](uint64_t x, uint64_t v) { x ^= v + 0x9E3779B97F4A7C15ull + (x << 6) + (x >> 2); x *= 0xff51afd7ed558ccdull; return x ^ (x >> 33); };
+        out.assign((size_t)P.n_state_ids, 0);
+        std::vector<uint8_t> done((size_t)P.n_state_ids, 0);
+        std::vector<int32_t> stack;
+        for (int64_t id0 = 0; id0 < P.n_state_ids; id0++) {
+            int32_t id = (int32_t)id0;
+            while (!done[(size_t)id]) {
+                const int32_t par = P.node_parent[(size_t)id];
+                if (par >= 0 && !done[(size_t)par]) { stack.push_back(id); id = par; continue; }
+                out[(size_t)id] = par < 0 ? mix(0xABCDEFull, (uint64_t)P.node_sym[(size_t)id]) : mix(out[(size_t)par], (uint64_t)P.node_sym[(size_t)id] + 1);
+                done[(size_t)id] = 1;
+                if (stack.empty()) break;
+                id = stack.back(); stack.pop_back();
+            }
+        }
+    };
+    std::vector<uint64_t> hF, hR;
+    path_hashes(h, hF); path_hashes(R, hR);
+    std::vector<std::pair<uint64_t, uint64_t>> got, want;
+    for (int32_t t = 0; t < T.n_tiles; t++) {
+        int64_t K = 0;
+        for (int g = 0; g < nG; g++) {
+            const int32_t b0 = T.blk[(size_t)t * (nG + 1) + g], b1 = T.blk[(size_t)t * (nG + 1) + g + 1];
+            for (int sl = 0; sl < TRC; sl++) {
+                const int32_t c = T.cid[(size_t)t * TRC + sl];
+                const int i = sl / TCL, m = sl % TCL;
+                const int32_t r0 = T.rem_ptr[((size_t)t * nG + g) * (TRC + 1) + sl], r1 = T.rem_ptr[((size_t)t * nG + g) * (TRC + 1) + sl + 1];
+                if (c < 0) { if (r1 != r0) bad++; continue; }
+                got.clear(); want.clear();
+                for (int32_t b = b0; b < b1; b++)
+                    for (int q = 0; q < 4; q++) {
+                        const int32_t f = T.tsf[((size_t)b * 4 + q) * TRW + i], r = T.tsr[((size_t)b * 4 + q) * TCL + m];
+                        if ((f < 0) != (r < 0)) { bad++; continue; }
+                        if (f >= 0) got.emplace_back(hF[(size_t)f], hR[(size_t)r]);
+                    }
+                if (sl == 0) K += (int64_t)got.size();
+                for (int32_t b = r0; b < r1; b++)
+                    for (int q = 0; q < 4; q++) {
+                        const int32_t f = T.rem_f[(size_t)b * 4 + q], r = T.rem_r[(size_t)b * 4 + q];
+                        if (r < 0) bad++;
+                        if (f >= 0) got.emplace_back(hF[(size_t)f], hR[(size_t)r]);
+                    }
+                for (int64_t a = pos_ptr[(size_t)c * nG + g]; a < pos_ptr[(size_t)c * nG + g + 1]; a++) want.emplace_back(hF[(size_t)pf[(size_t)a]], hR[(size_t)pr[(size_t)a]]);
+                std::sort(got.begin(), got.end()); std::sort(want.begin(), want.end());
+                if (got != want) bad++;
+            }
+        }
+        max_K = std::max(max_K, K);
+    }
+    int64_t n_once = 0;
+    {
+        std::vector<int32_t> seen((size_t)h.n_circuits, 0);
+        for (int32_t c : T.cid) if (c >= 0) seen[(size_t)c]++;
+        for (int64_t c = 0; c < h.n_circuits; c++) { if (seen[(size_t)c] > 1 || (seen[(size_t)c] == 1) != (T.tiled[(size_t)c] != 0)) bad++; n_once += seen[(size_t)c] == 1; }
+    }
+    out[0] = T.n_tiles; out[1] = T.n_tiled; out[2] = T.seg_slots; out[3] = T.rem_slots; out[4] = bad; out[5] = max_K;
+    out[6] = h.n_circuits; out[7] = n_once;
     return GST_OK;
     });
 }

@@ -191,6 +191,7 @@ struct TileArgs {
     const int32_t* rem_f;         // [n_rem_blocks][4]: forward id (-1: dead slot)
     const int32_t* rem_r;         // [n_rem_blocks][4]: backward id (always valid)
     uint32_t* counter;            // one word, zeroed before the launch
+    int32_t debug;                // development: 1 = no stores, 2 = no remnants, 4 = no segment stream (GST_TEST_FORCE tile_dbg=)
 };
 hipError_t launch_analytic_tiles(const TileArgs& t, int n_cus, hipStream_t stream);
 hipError_t launch_analytic(int D, const AnaArgs& a, hipStream_t stream);

@@ -26,7 +26,6 @@ typedef double t_d4 __attribute__((ext_vector_type(4)));
 typedef double t_d2 __attribute__((ext_vector_type(2)));
 constexpr int TD = 16, TNX = 4;
 constexpr int TR = TILE_ROWS, TC = TILE_COLS;          // 8 x 4
-constexpr int T_REM_INFLIGHT = 2;                      // remnant blocks per circuit gathered ahead of a gate's segment stream
 
 __device__ __forceinline__ void lds_barrier()
 {
@@ -108,37 +107,17 @@ __global__ __launch_bounds__(512) void analytic_tile_kernel(const TileArgs t)
                 r1[li] = c[li] >= 0 ? __builtin_amdgcn_readfirstlane(rp[slot + 1]) : r0[li];
                 any_rem = any_rem || r1[li] > r0[li];
             }
-            // ---- remnants, first blocks: ids, then the gathers -- in flight while the segment stream runs --------------------
-            double RF[4][T_REM_INFLIGHT], RB[4][T_REM_INFLIGHT][NX];
-            bool rok[4][T_REM_INFLIGHT];
-            {
-                int32_t rf[4][T_REM_INFLIGHT], rr[4][T_REM_INFLIGHT];
-#pragma unroll
-                for (int li = 0; li < 4; li++)
-#pragma unroll
-                    for (int q = 0; q < T_REM_INFLIGHT; q++) {
-                        const bool on = r0[li] + q < r1[li];
-                        const int64_t o = (int64_t)(on ? r0[li] + q : 0) * 4 + lk;
-                        rf[li][q] = on ? t.rem_f[o] : -1; rr[li][q] = on ? t.rem_r[o] : 0;
-                    }
-#pragma unroll
-                for (int li = 0; li < 4; li++)
-#pragma unroll
-                    for (int q = 0; q < T_REM_INFLIGHT; q++) {
-                        rok[li][q] = rf[li][q] >= 0;
-                        RF[li][q] = *(const double*)(fb + (uint64_t)(uint32_t)(rf[li][q] < 0 ? 0 : rf[li][q]) * fstride + lr * 8);
-                        const t_d2* q2 = (const t_d2*)__builtin_assume_aligned(rb + (uint64_t)(uint32_t)rr[li][q] * rstride + lr * 32, 16);
-                        const t_d2 u0 = q2[0], u1 = q2[1];
-                        RB[li][q][0] = u0.x; RB[li][q][1] = u0.y; RB[li][q][2] = u1.x; RB[li][q][3] = u1.y;
-                    }
-            }
             t_d4 acc[4][NX];
 #pragma unroll
             for (int li = 0; li < 4; li++)
 #pragma unroll
                 for (int x = 0; x < NX; x++) acc[li][x] = (t_d4){0.0, 0.0, 0.0, 0.0};
             // ---- the tile's segment of gate g: blocks b0 .. b1 - 1 through LDS ------------------------------------------------
-            if (b1 > b0) {          // (workgroup-uniform)
+            if (b1 > b0 && !(t.debug & 4)) {          // (workgroup-uniform)
+                // (no load sits under a branch -- the compiler counts the loads in flight exactly only on straight-line code, and
+                //  otherwise waits for ALL of them before every use: blocks past the end re-read the last one and come out dead)
+                // (and nothing is DONE with a loaded index before its ring slot comes round: a select right behind the load would
+                //  make every iteration wait for the load it has just issued -- dead blocks are zeroed when they are staged)
                 auto ids = [&](int32_t b, int32_t& fi, int32_t& ri) {
                     const int32_t bc = b < b1 ? b : b1 - 1;
                     fi = t.tsf[(int64_t)bc * (4 * TR) + sF_v];
@@ -148,43 +127,53 @@ __global__ __launch_bounds__(512) void analytic_tile_kernel(const TileArgs t)
                     fv = *(const double*)(fb + (uint64_t)(uint32_t)(fi < 0 ? 0 : fi) * fstride + sF_c * 8);
                     bv = *(const t_d2*)__builtin_assume_aligned(rb + (uint64_t)(uint32_t)(ri < 0 ? 0 : ri) * rstride + sB_q * 16, 16);
                 };
-                auto stage = [&](int buf, int32_t fi, int32_t ri, double fv, t_d2 bv) {
-                    (&Fs[buf][0][0][0])[sF_v * D + sF_c] = fi < 0 ? 0.0 : fv;
+                auto stage = [&](int buf, bool live, int32_t fi, int32_t ri, double fv, t_d2 bv) {
+                    (&Fs[buf][0][0][0])[sF_v * D + sF_c] = (!live || fi < 0) ? 0.0 : fv;
                     double* bd = &Bs[buf][0][0][0][0] + sB_v * (NX * D);
-                    bd[sB_x * D + sB_a] = ri < 0 ? 0.0 : bv.x;
-                    bd[(sB_x + 1) * D + sB_a] = ri < 0 ? 0.0 : bv.y;
+                    bd[sB_x * D + sB_a] = (!live || ri < 0) ? 0.0 : bv.x;
+                    bd[(sB_x + 1) * D + sB_a] = (!live || ri < 0) ? 0.0 : bv.y;
                 };
-                int32_t fiA, riA, fiB, riB;
-                double fv; t_d2 bv;
-                ids(b0, fiA, riA);
-                ids(b0 + 1, fiB, riB);
-                fetch(fiA, riA, fv, bv);
+                // Register ring: the vectors of block b + PF and the indices of block b + 2 PF are requested while block b is
+                // multiplied -- with two wavefronts per SIMD nothing else hides the L2 / HBM latency of the gathers.
+                constexpr int PF = 4;
+                int32_t fi[PF], ri[PF], fin[PF], rin[PF];
+                double fvq[PF]; t_d2 bvq[PF];
+#pragma unroll
+                for (int j = 0; j < PF; j++) ids(b0 + j, fi[j], ri[j]);
+#pragma unroll
+                for (int j = 0; j < PF; j++) ids(b0 + PF + j, fin[j], rin[j]);
+#pragma unroll
+                for (int j = 0; j < PF; j++) fetch(fi[j], ri[j], fvq[j], bvq[j]);
                 __syncthreads();                                           // (nobody still reads either buffer)
-                stage(0, fiA, riA, fv, bv);
-                fetch(fiB, riB, fv, bv);                                   // block b0 + 1 in flight
-                fiA = fiB; riA = riB;                                      // (what `fv / bv` belong to)
-                ids(b0 + 2, fiB, riB);
+                stage(0, true, fi[0], ri[0], fvq[0], bvq[0]);
+                fi[0] = fin[0]; ri[0] = rin[0];
+                fetch(fi[0], ri[0], fvq[0], bvq[0]);                       // block b0 + PF into the freed ring slot
+                ids(b0 + 2 * PF, fin[0], rin[0]);
                 lds_barrier();
                 int buf = 0;
-                for (int32_t b = b0; b < b1; b++) {
-                    // operands of block b from LDS buffer `buf`
-                    double Fo[4], Ao[NX];
+                for (int32_t bg = b0; bg < b1; bg += PF) {
 #pragma unroll
-                    for (int li = 0; li < 4; li++) Fo[li] = Fs[buf][lk][4 * ig + li][lr];
+                    for (int j = 0; j < PF; j++) {
+                        const int32_t b = bg + j;                          // (b >= b1 in the last group: a dead block, all zeros)
+                        double Fo[4], Ao[NX];
 #pragma unroll
-                    for (int x = 0; x < NX; x++) Ao[x] = Bs[buf][lk][mc][x][lr];
+                        for (int li = 0; li < 4; li++) Fo[li] = Fs[buf][lk][4 * ig + li][lr];
 #pragma unroll
-                    for (int li = 0; li < 4; li++)
+                        for (int x = 0; x < NX; x++) Ao[x] = Bs[buf][lk][mc][x][lr];
 #pragma unroll
-                        for (int x = 0; x < NX; x++) acc[li][x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ao[x], Fo[li], acc[li][x], 0, 0, 0);
-                    if (b + 1 < b1) {                                      // (uniform) block b + 1: registers -> the other buffer
-                        stage(buf ^ 1, fiA, riA, fv, bv);
-                        fetch(fiB, riB, fv, bv);                           // block b + 2
-                        fiA = fiB; riA = riB;
-                        ids(b + 3, fiB, riB);
+                        for (int li = 0; li < 4; li++)
+#pragma unroll
+                            for (int x = 0; x < NX; x++) acc[li][x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ao[x], Fo[li], acc[li][x], 0, 0, 0);
+                        {                                                  // block b + 1: ring slot -> the other buffer
+                            const int q = (j + 1) % PF;                    // ring slot of block b + 1 (a constant once unrolled)
+                            stage(buf ^ 1, b + 1 < b1, fi[q], ri[q], fvq[q], bvq[q]);
+                            fi[q] = fin[q]; ri[q] = rin[q];
+                            fetch(fi[q], ri[q], fvq[q], bvq[q]);           // block b + 1 + PF
+                            ids(b + 1 + 2 * PF, fin[q], rin[q]);
+                        }
+                        lds_barrier();
+                        buf ^= 1;
                     }
-                    lds_barrier();
-                    buf ^= 1;
                 }
             } else if (!any_rem) {
                 // nobody in this wavefront applies g here: exact zeros (which a tracked destination already holds)
@@ -208,33 +197,43 @@ __global__ __launch_bounds__(512) void analytic_tile_kernel(const TileArgs t)
                 }
                 continue;
             }
-            // ---- remnants: the blocks gathered above, then whatever a circuit has beyond them ------------------------------------
+            // ---- remnants: what each of this wavefront's circuits applies of g outside the tile's segment -- its own state ids,
+            //      gathered straight from the caches: all four circuits' blocks of one round are in flight together ------------------
+            {
+                int32_t nrb = 0;
 #pragma unroll
-            for (int li = 0; li < 4; li++)
+                for (int li = 0; li < 4; li++) nrb = (r1[li] - r0[li]) > nrb ? (r1[li] - r0[li]) : nrb;
+                if (t.debug & 2) nrb = 0;
+                for (int32_t q = 0; q < nrb; q++) {
+                    int32_t rf[4], rr[4];
 #pragma unroll
-                for (int q = 0; q < T_REM_INFLIGHT; q++) {
-                    if (r0[li] + q >= r1[li]) continue;                    // (uniform)
-                    const double Fz = rok[li][q] ? RF[li][q] : 0.0;
+                    for (int li = 0; li < 4; li++) {
+                        const bool on = r0[li] + q < r1[li];
+                        const int64_t o = (int64_t)(on ? r0[li] + q : 0) * 4 + lk;
+                        rf[li] = on ? t.rem_f[o] : -1; rr[li] = on ? t.rem_r[o] : 0;
+                    }
+                    double RF[4]; t_d2 RB0[4], RB1[4];
 #pragma unroll
-                    for (int x = 0; x < NX; x++) acc[li][x] = __builtin_amdgcn_mfma_f64_16x16x4f64(RB[li][q][x], Fz, acc[li][x], 0, 0, 0);
+                    for (int li = 0; li < 4; li++) {
+                        RF[li] = *(const double*)(fb + (uint64_t)(uint32_t)(rf[li] < 0 ? 0 : rf[li]) * fstride + lr * 8);
+                        const t_d2* q2 = (const t_d2*)__builtin_assume_aligned(rb + (uint64_t)(uint32_t)rr[li] * rstride + lr * 32, 16);
+                        RB0[li] = q2[0]; RB1[li] = q2[1];
+                    }
+#pragma unroll
+                    for (int li = 0; li < 4; li++) {
+                        if (r0[li] + q >= r1[li]) continue;                    // (uniform)
+                        const double Fz = rf[li] >= 0 ? RF[li] : 0.0;
+                        acc[li][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(RB0[li].x, Fz, acc[li][0], 0, 0, 0);
+                        acc[li][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(RB0[li].y, Fz, acc[li][1], 0, 0, 0);
+                        acc[li][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(RB1[li].x, Fz, acc[li][2], 0, 0, 0);
+                        acc[li][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(RB1[li].y, Fz, acc[li][3], 0, 0, 0);
+                    }
                 }
-#pragma unroll
-            for (int li = 0; li < 4; li++)
-                for (int32_t rbk = r0[li] + T_REM_INFLIGHT; rbk < r1[li]; rbk++) {
-                    const int32_t f = t.rem_f[(int64_t)rbk * 4 + lk], r = t.rem_r[(int64_t)rbk * 4 + lk];
-                    const double Fv = *(const double*)(fb + (uint64_t)(uint32_t)(f < 0 ? 0 : f) * fstride + lr * 8);
-                    const t_d2* q2 = (const t_d2*)__builtin_assume_aligned(rb + (uint64_t)(uint32_t)r * rstride + lr * 32, 16);
-                    const t_d2 u0 = q2[0], u1 = q2[1];
-                    const double Fz = f >= 0 ? Fv : 0.0;
-                    acc[li][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u0.x, Fz, acc[li][0], 0, 0, 0);
-                    acc[li][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u0.y, Fz, acc[li][1], 0, 0, 0);
-                    acc[li][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1.x, Fz, acc[li][2], 0, 0, 0);
-                    acc[li][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1.y, Fz, acc[li][3], 0, 0, 0);
-                }
+            }
             // ---- the 16 x 16 blocks of gate g: rows (circuit, outcome), D-matrix layout of the MFMA ---------------------------------
 #pragma unroll
             for (int li = 0; li < 4; li++) {
-                if (c[li] < 0) continue;
+                if (c[li] < 0 || (t.debug & 1)) continue;
                 if (zeros_resident && b1 == b0 && r1[li] == r0[li]) continue;     // this circuit never applies g: zeros already there
 #pragma unroll
                 for (int x = 0; x < NX; x++) {

@@ -167,6 +167,18 @@ struct gst_plan {
     const void* ana_zero_out = nullptr; // destination of the last stream-form analytic Jacobian, its leading dimension
     int64_t ana_zero_ld = 0;
     bool ana_zero_valid = false;
+    // tiles of the D = 16 contraction (gst_kernels_tiles.hip; build_tiles in gst_fill_analytic.cpp) and the item tables of the
+    // circuits no tile holds
+    bool ana_tiles = false;             // GST_OPT_ANALYTIC_TILES (GST_TEST_FORCE tiles=1): the product tiles of the design on the tile kernel
+    int32_t n_tiles = 0;
+    int32_t tile_dbg = 0;               // GST_TEST_FORCE tile_dbg= (development: see TileArgs::debug)
+    int64_t n_lo_circuits = 0;
+    int64_t tile_stats[3] = {0, 0, 0};  // tiled circuits, segment slots, remnant slots
+    DevBuf<int32_t> d_tile_order, d_tile_cid, d_tile_blk, d_tsf, d_tsr, d_rem_ptr, d_rem_f, d_rem_r;
+    DevBuf<uint32_t> d_tile_counter;
+    DevBuf<int32_t> d_lo_order, d_lo_partner, d_lo_common, d_lo_blk_f1, d_lo_blk_f2, d_lo_blk_r, d_lo_blk_ptr;
+    DevBuf<uint32_t> d_lo_range_begin, d_lo_counter;
+    bool last_tiles = false;            // the last exact fill ran the tile kernel
     static constexpr bool ana_group_fetch = true;  // the four wavefronts of a workgroup take four consecutive items together
     DevBuf<double> d_rev_cache;
     DevBuf<uint32_t> d_work_counter, d_range_begin;
@@ -340,6 +352,8 @@ struct gst_plan {
         d_pair_r.release(); d_circ_rho.release(); d_circ_order.release(); d_circ_partner.release();
         d_pair_common.release(); d_rev_cache.release(); d_work_counter.release(); d_range_begin.release();
         d_blk_f1.release(); d_blk_f2.release(); d_blk_r.release(); d_blk_ptr.release();
+        d_tile_order.release(); d_tile_cid.release(); d_tile_blk.release(); d_tsf.release(); d_tsr.release(); d_rem_ptr.release(); d_rem_f.release(); d_rem_r.release(); d_tile_counter.release();
+        d_lo_order.release(); d_lo_partner.release(); d_lo_common.release(); d_lo_blk_f1.release(); d_lo_blk_f2.release(); d_lo_blk_r.release(); d_lo_blk_ptr.release(); d_lo_range_begin.release(); d_lo_counter.release();
         d_dv_deriv.release(); d_dv2.release(); d_helem.release(); d_hw.release(); d_hcsc.release();
         d_rowmask.release(); d_jelem.release(); d_dv_colmap.release(); d_hscratch.release(); d_dF.release(); d_dB.release();
         d_theta.release(); d_obj_dt.release(); d_obj_ht.release(); d_obj_pc.release(); d_obj_tmp.release();
