@@ -523,7 +523,7 @@ def main():
         FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md).  None when no profile matches."""
         if world != 1 or lay_world != 1 or args.design != "full" or args.max_len != 1024:
             return None
-        for name in ("r05_hbm_counters.json", "r04_hbm_counters.json", "r03_hbm_counters.json", "r02_hbm_counters.json", "r01_hbm_counters.json"):
+        for name in ("r06_hbm_counters.json", "r05_hbm_counters.json", "r04_hbm_counters.json", "r03_hbm_counters.json", "r02_hbm_counters.json", "r01_hbm_counters.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     prof = json.load(f)[args.deriv]
@@ -539,7 +539,7 @@ def main():
         (profiles/r*_bench_pmc_sq_current.json), with its file name -- the cross-check of `executed`."""
         if world != 1 or lay_world != 1 or args.design != "full" or args.max_len != 1024:
             return None
-        for name in ("r05_bench_pmc_sq_current.json", "r04_bench_pmc_sq_current.json"):
+        for name in ("r06_bench_pmc_sq_current.json", "r05_bench_pmc_sq_current.json", "r04_bench_pmc_sq_current.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     prof = json.load(f)[args.deriv]

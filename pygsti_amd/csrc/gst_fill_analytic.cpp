@@ -355,6 +355,26 @@ int ensure_reverse(gst_plan* p)
             }
         }
         const int64_t n_items = (int64_t)item_first.size();
+        if (h.D == 16 && p->ana_lpt && n_items > 1) {
+            // Longest first: an item of depth 1,030 occupies its wavefront for a quarter of the whole launch, and the launch
+            // ends with whichever long item was started last.  Items are bucketed by the power of two of their work and the
+            // buckets dispatched in descending order; inside a bucket the locality order above (germ-major runs) is kept.
+            std::vector<int32_t> bucket((size_t)n_items), perm((size_t)n_items);
+            for (int64_t k = 0; k < n_items; k++) {
+                int64_t w = h.circ_ptr[item_first[(size_t)k] + 1] - h.circ_ptr[item_first[(size_t)k]];
+                if (item_partner[(size_t)k] >= 0) w += h.circ_ptr[item_partner[(size_t)k] + 1] - h.circ_ptr[item_partner[(size_t)k]];
+                int b = 0;
+                while ((w >> b) > 1) b++;
+                bucket[(size_t)k] = b; perm[(size_t)k] = (int32_t)k;
+            }
+            std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return bucket[(size_t)x] > bucket[(size_t)y]; });
+            std::vector<int32_t> f2((size_t)n_items), p2((size_t)n_items), c2(item_common.size());
+            for (int64_t k = 0; k < n_items; k++) {
+                f2[(size_t)k] = item_first[(size_t)perm[(size_t)k]]; p2[(size_t)k] = item_partner[(size_t)perm[(size_t)k]];
+                std::copy(item_common.begin() + (size_t)perm[(size_t)k] * nG, item_common.begin() + ((size_t)perm[(size_t)k] + 1) * nG, c2.begin() + (size_t)k * nG);
+            }
+            item_first.swap(f2); item_partner.swap(p2); item_common.swap(c2);
+        }
         if (h.D == 16) {
             if ((rc = upload_i32(p, (*B.order), item_first))) return rc;
             if ((rc = upload_i32(p, (*B.partner), item_partner))) return rc;

@@ -171,6 +171,7 @@ struct gst_plan {
     // circuits no tile holds
     bool ana_tiles = false;             // GST_OPT_ANALYTIC_TILES (GST_TEST_FORCE tiles=1): the product tiles of the design on the tile kernel
     int32_t n_tiles = 0;
+    bool ana_lpt = true;                // items dispatched longest power-of-two bucket first (GST_TEST_FORCE lpt=0: locality order only)
     int32_t tile_dbg = 0;               // GST_TEST_FORCE tile_dbg= (development: see TileArgs::debug)
     int64_t n_lo_circuits = 0;
     int64_t tile_stats[3] = {0, 0, 0};  // tiled circuits, segment slots, remnant slots
