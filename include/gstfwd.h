@@ -132,8 +132,8 @@ typedef struct {
                                   GST_OPT_FAST_PROBS), 0: from the sequential walk */
     int32_t last_zeros_resident;   /* 1: the last exact Jacobian fill did not re-store the destination's structural zeros */
     int32_t last_tiles;            /* tiles the last exact Jacobian fill contracted on the tile kernel (0: item kernel only) */
-    int32_t reserved;
-    int64_t last_tiled_circuits;   /* ... and the circuits they held */
+    int32_t lm_graph_replays;      /* gst_lm_step_dev: iterations served by replaying the captured HIP graph so far (-1: a capture was refused) */
+    int64_t last_tiled_circuits;   /* tiles: the circuits they held */
 } gst_stats;
 
 GST_API int gst_plan_create_from_table(const gst_table_desc *desc, const gst_options *opt, gst_plan **out);
@@ -468,6 +468,21 @@ typedef struct gst_objective_desc {
 GST_API int gst_objective_rows_dev(gst_plan *plan, const gst_objective_desc *desc, double *d_probs, const double *d_counts,
                            const double *d_totals, int64_t n, double *d_lsvec, double *d_rowscale, double *d_terms,
                            double *sum_terms);
+
+/* One Levenberg-Marquardt evaluation in one BLOCKING call (round 6): the model of the last gst_set_model is uploaded, then
+ *   gst_fill_dprobs_dev(all n_params parameters, GST_DERIV_FD, eps) -> d_J [nE][ld], d_probs
+ *   gst_objective_rows_dev                                          -> d_lsvec, d_rowscale, *sum_terms
+ *   gst_fill_normal_eqs_dev                                         -> d_jtj [n_params][n_params], d_jtf [n_params]
+ * run back to back -- the same kernels, the same bits.  For LAUNCH-BOUND plans (at most 65,536 states: the 1Q designs of
+ * BASELINE configs[1], where such an iteration is seven kernel launches, two memsets and two copies around microseconds of
+ * work) the sequence is captured into a HIP graph at the second call with the same arguments and replayed afterwards: one
+ * graph launch per iteration.  The graph reads the model from a page-locked buffer of the library's that every call
+ * overwrites; another request, other pointers or another parameter map drop it; a capture the runtime refuses is not
+ * retried.  Element-mapped models (gst_set_param_map, full TP without a complement effect) only.  Replaces, per iteration,
+ * simplerlm.py:663-678 + objectivefns.py:4573-4665 + distlayout.py:1220-1359 on device data. */
+GST_API int gst_lm_step_dev(gst_plan *plan, const gst_objective_desc *desc, int64_t n_params, double eps, const double *d_counts,
+                    const double *d_totals, double *d_J, int64_t ld, double *d_probs, double *d_lsvec, double *d_rowscale,
+                    double *d_jtj, double *d_jtf, double *sum_terms);
 
 /* One (n1 x n2) block of the objective's Hessian without moving the hprobs block off the device: what
  * TimeIndependentMDCObjectiveFunction._construct_hessian does per rectangle (objectivefns.py:1640-1690) with

@@ -89,13 +89,13 @@ class Stats(C.Structure):
                 ("prog_words", C.c_int64), ("max_slots", C.c_int32), ("max_depth", C.c_int32),
                 ("last_kernel_ms", C.c_double), ("last_total_ms", C.c_double), ("last_launches", C.c_int64),
                 ("last_fd_form", C.c_int32), ("last_fd_aborted", C.c_int32), ("last_levels", C.c_int32), ("last_zeros_resident", C.c_int32),
-                ("last_tiles", C.c_int32), ("reserved", C.c_int32), ("last_tiled_circuits", C.c_int64)]
+                ("last_tiles", C.c_int32), ("lm_graph_replays", C.c_int32), ("last_tiled_circuits", C.c_int64)]
 
 
 # every symbol include/gstfwd.h declares (tests check the library exports all of them)
 EXPORTS = ["gst_plan_create_from_table", "gst_plan_create_from_circuits", "gst_plan_destroy", "gst_set_model",
            "gst_set_param_map", "gst_set_complement_effect", "gst_set_derivs", "gst_set_second_derivs", "gst_fill_probs", "gst_fill_dprobs", "gst_fill_hprobs", "gst_fill_hprobs_analytic", "gst_fill_probs_dev",
-           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_fill_normal_eqs_dev", "gst_objective_rows_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_get_fd_work", "gst_get_tile_stats", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
+           "gst_fill_dprobs_dev", "gst_fill_jtj_dev", "gst_fill_jtf_dev", "gst_fill_normal_eqs_dev", "gst_objective_rows_dev", "gst_lm_step_dev", "gst_objective_hessian_block", "gst_memcpy_h2d", "gst_copy_block_dev", "gst_sync", "gst_device_malloc", "gst_device_malloc_tracked", "gst_device_free", "gst_device_touch", "gst_memcpy_d2h", "gst_memcpy_d2h_async", "gst_get_stats", "gst_get_program", "gst_get_level_program", "gst_get_dirty_programs", "gst_get_state_graph", "gst_get_fd_queues", "gst_get_fd_work", "gst_get_tile_stats", "gst_sort_circuits", "gst_circuit_first_use", "gst_device_count",
            "gst_last_error", "gst_version", "gst_host_register", "gst_host_unregister",
            "gst_fill_dprobs_models", "gst_fill_dprobs_models_dev",
            "gst_set_option", "gst_set_lindblad", "gst_set_lindblad_params", "gst_set_composite", "gst_set_composite_values", "gst_set_composite_general", "gst_get_model", "gst_get_lindblad_model_sets",
@@ -153,6 +153,7 @@ def lib():
         L.gst_get_fd_queues.argtypes = [vp, vp, i64, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
         L.gst_get_fd_work.argtypes = [vp, vp, i64, vp]
         L.gst_get_tile_stats.argtypes = [vp, vp]
+        L.gst_lm_step_dev.argtypes = [vp, vp, i64, C.c_double, vp, vp, vp, i64, vp, vp, vp, vp, vp, C.POINTER(C.c_double)]
         L.gst_sort_circuits.argtypes = [i64, vp, vp, vp, vp, vp]
         L.gst_circuit_first_use.argtypes = [i64, vp, vp, i32, vp]
         L.gst_get_state_graph.argtypes = [vp, vp, vp, i64, vp, i64, C.POINTER(i64)]
@@ -621,6 +622,20 @@ class Plan:
         if probs_out is not None:
             self.memcpy_d2h(probs_out, d_pr)
         return total, jtj, jtf
+
+    def lm_step_dev(self, n_params, d_counts, d_totals, d_J, ld, d_probs, d_lsvec, d_rowscale, d_jtj, d_jtf, objective="logl",
+                    eps=1e-7, min_prob_clip=1e-4, radius=1e-4, prob_clip_interval=None):
+        """gst_lm_step_dev: model upload -> FD Jacobian -> objective rows -> J_s^T J_s, J_s^T lsvec in one blocking call on device
+        buffers the caller keeps (replayed as ONE HIP graph launch on launch-bound plans from the third call on).  Returns
+        sum(terms)."""
+        k = {"chi2": OBJ_CHI2, "logl": OBJ_POISSON_DLOGL}[objective] if isinstance(objective, str) else int(objective)
+        lo, hi = (0.0, 0.0) if prob_clip_interval is None else (float(prob_clip_interval[0]), float(prob_clip_interval[1]))
+        d = ObjectiveDesc(k, 0, float(min_prob_clip), float(radius), lo, hi)
+        vp = lambda x: C.c_void_p(int(x))
+        tot = C.c_double(0.0)
+        check(lib().gst_lm_step_dev(self._h, C.byref(d), int(n_params), float(eps), vp(d_counts), vp(d_totals), vp(d_J), int(ld), vp(d_probs),
+                                    vp(d_lsvec), vp(d_rowscale), vp(d_jtj), vp(d_jtf), C.byref(tot)))
+        return tot.value
 
     def objective_hessian_block(self, kind, d_counts, d_totals, idx1, idx2, eps=1e-5, min_prob_clip=1e-4, radius=1e-4,
                                 prob_clip_interval=None, mode=DERIV_FD):

@@ -252,6 +252,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
             else if (key == "tiles") p->ana_tiles = iv != 0;
             else if (key == "tile_dbg") p->tile_dbg = iv;
             else if (key == "lpt") p->ana_lpt = iv != 0;
+            else if (key == "lm_graph") p->lm_graph_enabled = iv != 0;
             else if (key == "comm_self") {}          // (read by gst_comm_create: gst_comm.cpp)
             else { delete p; return fail(GST_EINVAL, "GST_TEST_FORCE: unknown key '" + key + "'"); }
         }
@@ -913,7 +914,7 @@ int gst_get_stats(const gst_plan* p, gst_stats* s)
     s->last_kernel_ms = p->last_kernel_ms; s->last_total_ms = p->last_total_ms; s->last_launches = p->last_launches;
     s->last_fd_form = p->last_fd_form; s->last_fd_aborted = 0;
     s->last_levels = p->last_levels ? 1 : 0; s->last_zeros_resident = p->last_zeros_resident ? 1 : 0;
-    s->last_tiles = p->last_tiles ? p->n_tiles : 0; s->reserved = 0; s->last_tiled_circuits = p->last_tiles ? p->tile_stats[0] : 0;
+    s->last_tiles = p->last_tiles ? p->n_tiles : 0; s->lm_graph_replays = p->lm_graph.failed ? -1 : (int32_t)std::min<int64_t>(p->lm_graph.replays, 0x7fffffff); s->last_tiled_circuits = p->last_tiles ? p->tile_stats[0] : 0;
     if (p->last_fd_form >= 1 && p->d_bin_head.p && p->n_bins > 0 && p->dev_ready) {
         uint32_t flag = 0;                  // the abort flag sits behind the queue heads
         HIP_TRY(hipSetDevice(p->device));

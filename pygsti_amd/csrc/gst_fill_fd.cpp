@@ -338,6 +338,7 @@ int run_dprobs_fd(gst_plan* p, double* d_out, int64_t ld, const int64_t* param_i
         HIP_TRY(hipStreamSynchronize(p->stream));       // the host vectors go out of scope
         p->remember_request(1, param_idx, dest_idx, n_param);
         p->cached_n_waves = L.n_waves;
+        p->fd_request_serial++;
     }
     // ---- the base pass ----------------------------------------------------------------------------------------------
     // Persistent launches (small atoms, D = 16) walk the base chains INSIDE the FD kernel: ~0.45 ms of pure latency that

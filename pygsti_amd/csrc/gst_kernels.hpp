@@ -204,6 +204,7 @@ hipError_t launch_scale_rows(double* J, int64_t n_rows, int64_t n_cols, int64_t 
 hipError_t launch_symmetrize(double* C, int64_t n, hipStream_t s);
 // Normal equations (gst_kernels_normal.hip): split-K MFMA fp64 J^T J and streaming J^T f
 int jtj_num_slabs(int64_t n_rows, int n_cols, int n_cus = 256);
+int jtf_num_slabs(int64_t n_rows);
 // pmask (may be NULL): per 16-row panel, bit t = the panel holds a non-zero in the 128 columns of tile t
 // (launch_jtj_panel_masks; n_cols <= 32 * 128); panels whose two tiles are not both marked are skipped
 // w (may be NULL): row weights applied while a panel is staged -- (diag(w) J)^T (diag(w) J) with J left untouched

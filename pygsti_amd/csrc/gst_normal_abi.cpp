@@ -57,7 +57,7 @@ int gst_fill_jtf_dev(gst_plan* p, const double* d_J, int64_t n_rows, int64_t n_c
     int rc = ensure_device(p);
     if (rc) return rc;
     if (n_cols == 0) return GST_OK;
-    const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(256, (n_rows + 255) / 256));
+    const int n_slabs = gst::jtf_num_slabs(n_rows);
     gst::track_touch(d_jtf, (size_t)n_cols * 8);
     HIP_TRY(p->d_jtf_part.ensure((size_t)n_slabs * n_cols));
     HIP_TRY(gst::launch_jtf(d_J, d_f, n_rows, (int)n_cols, ld, p->d_jtf_part.p, n_slabs, d_jtf, p->stream));
@@ -105,7 +105,7 @@ int gst_fill_normal_eqs_dev(gst_plan* p, const double* d_J, int64_t n_rows, int6
         TIME_REC(p, evk1);
     }
     if (d_jtf && !jtf_done) {
-        const int n_slabs = (int)std::max<int64_t>(1, std::min<int64_t>(256, (n_rows + 255) / 256));
+        const int n_slabs = gst::jtf_num_slabs(n_rows);
         gst::track_touch(d_jtf, (size_t)n_cols * 8);
         HIP_TRY(p->d_jtf_part.ensure((size_t)n_slabs * n_cols));
         HIP_TRY(gst::launch_jtf(d_J, d_f, n_rows, (int)n_cols, ld, p->d_jtf_part.p, n_slabs, d_jtf, p->stream, d_row_scale));
@@ -139,6 +139,120 @@ int gst_objective_rows_dev(gst_plan* p, const gst_objective_desc* d, double* d_p
         double s = 0.0;
         for (double x : part) s += x;
         *sum_terms = s;
+    }
+    return GST_OK;
+    });
+}
+
+
+// One Levenberg-Marquardt evaluation in ONE call: model upload -> finite-difference Jacobian of all parameters -> objective rows
+// -> J_s^T J_s and J_s^T lsvec, blocking, with sum(terms) returned -- what `Plan.lsq_step` composes from four calls.  For
+// LAUNCH-BOUND plans (<= 65,536 states: the 1Q designs, where a fill is microseconds of work behind as many microseconds of
+// launches) the whole sequence is captured into a HIP graph at the second call with the same arguments and replayed from then
+// on: one graph launch per LM iteration instead of seven kernel launches, two memsets and two copies.  The graph reads the model
+// from a page-locked buffer of its own that every call overwrites first; its kernels are the ordinary ones (bit-identical
+// results).  Anything that changes what the sequence looks like -- another request, other pointers, a new parameter map --
+// drops the graph; a capture the runtime refuses is not retried (the ordinary path serves the plan).
+int gst_lm_step_dev(gst_plan* p, const gst_objective_desc* d, int64_t n_params, double eps, const double* d_counts,
+                    const double* d_totals, double* d_J, int64_t ld, double* d_probs, double* d_lsvec, double* d_rowscale,
+                    double* d_jtj, double* d_jtf, double* sum_terms)
+{
+    return guarded([&]() -> int {
+    if (!p || !d || !d_counts || !d_totals || !d_J || !d_probs || !d_lsvec || !d_rowscale || !d_jtj || !d_jtf || n_params <= 0 || ld < n_params)
+        return fail(GST_EINVAL, "bad argument");
+    if (d->kind != GST_OBJ_CHI2 && d->kind != GST_OBJ_POISSON_DLOGL) return fail(GST_EINVAL, "unknown objective kind");
+    if (!(d->min_prob_clip > 0.0) || (d->kind == GST_OBJ_POISSON_DLOGL && !(d->radius > 0.0)))
+        return fail(GST_EINVAL, "min_prob_clip and radius must be positive");
+    int rc = ensure_device(p);
+    if (rc) return rc;
+    if (!p->have_model) return fail(GST_ESTATE, "gst_set_model has not been called");
+    if (!p->have_pmap || p->lb.set || p->cmp.set || p->derivs_set) return fail(GST_EUNSUPPORTED, "gst_lm_step_dev serves element-mapped (`full`, full TP) models");
+    if (n_params != (int64_t)p->pkind.size()) return fail(GST_EINVAL, "n_params is not the parameter map's size");
+    const int64_t nE = p->hp.n_elements;
+    if (nE == 0) { if (sum_terms) *sum_terms = 0.0; return GST_OK; }
+    std::vector<int64_t> pidx((size_t)n_params);
+    for (int64_t q = 0; q < n_params; q++) pidx[(size_t)q] = q;
+    const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (nE + 255) / 256));
+    HIP_TRY(p->d_obj_part.ensure((size_t)n_blocks));
+    gst_plan::LmGraph& G = p->lm_graph;
+    if (!G.h_part) HIP_TRY(hipHostMalloc((void**)&G.h_part, 1024 * sizeof(double), hipHostMallocDefault));
+    const size_t ng = p->h_gates.size(), nr = p->h_rhos.size(), ne = p->h_effects.size(), n_model = 2 * ng + nr + ne;
+    // the sequence on p->stream; `from_graph_buffer`: the model comes from G.h_model (captured) instead of upload_model's pair
+    auto sequence = [&](bool from_graph_buffer) -> int {
+        int rcs;
+        if (from_graph_buffer) {
+            HIP_TRY(hipMemcpyAsync(p->d_model.p, G.h_model, n_model * 8, hipMemcpyHostToDevice, p->stream));
+        } else if ((rcs = upload_model(p))) return rcs;
+        if ((rcs = run_dprobs_fd(p, d_J, ld, pidx.data(), nullptr, n_params, eps, d_probs, nullptr, 0))) return rcs;
+        HIP_TRY(gst::launch_objective_rows(d->kind, d_probs, d_counts, d_totals, nE, d->min_prob_clip, d->radius, d->prob_clip_lo,
+                                           d->prob_clip_hi, d_lsvec, d_rowscale, nullptr, p->d_obj_part.p, n_blocks, p->stream));
+        HIP_TRY(hipMemcpyAsync(G.h_part, p->d_obj_part.p, (size_t)n_blocks * 8, hipMemcpyDeviceToHost, p->stream));
+        return gst_fill_normal_eqs_dev(p, d_J, nE, n_params, ld, d_rowscale, d_lsvec, d_jtj, d_jtf);
+    };
+    auto fill_graph_model = [&]() {
+        if (ng) { std::memcpy(G.h_model, p->h_gates.data(), ng * 8); std::memcpy(G.h_model + ng, p->h_gates_t.data(), ng * 8); }
+        std::memcpy(G.h_model + 2 * ng, p->h_rhos.data(), nr * 8);
+        std::memcpy(G.h_model + 2 * ng + nr, p->h_effects.data(), ne * 8);
+    };
+    for (double* w : {d_J, d_probs, d_lsvec, d_rowscale, d_jtj, d_jtf}) gst::track_touch(w, 8);      // (claims on these destinations end: FD results)
+    const uint64_t sig = (uint64_t)(uintptr_t)d_J ^ ((uint64_t)(uintptr_t)d_probs << 1) ^ ((uint64_t)(uintptr_t)d_lsvec << 2) ^ ((uint64_t)(uintptr_t)d_rowscale << 3) ^
+                         ((uint64_t)(uintptr_t)d_jtj << 4) ^ ((uint64_t)(uintptr_t)d_jtf << 5) ^ ((uint64_t)(uintptr_t)d_counts << 6) ^ ((uint64_t)(uintptr_t)d_totals << 7) ^
+                         ((uint64_t)ld * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)d->kind << 60) ^ (uint64_t)n_model;
+    const bool small = p->lm_graph_enabled && p->hp.n_state_ids <= 65536 && p->hp.D <= 16 && p->comp_index < 0;
+    const bool same = G.exec && G.sig == sig && G.eps == eps && std::memcmp(&G.desc, d, sizeof(*d)) == 0 && G.request_serial == p->fd_request_serial &&
+                      p->request_cached(1, pidx.data(), nullptr, n_params);
+    p->last_launches = 0;
+    if (small && same) {
+        fill_graph_model();
+        p->model_dirty = true;                        // (the ordinary upload pair no longer mirrors the device)
+        HIP_TRY(hipGraphLaunch(G.exec, p->stream));
+        G.replays++;
+    } else {
+        if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+        const bool saved_timing = p->timing;
+        bool captured = false;
+        // capture at the second call with these arguments (the first one allocates, packs and uploads the request's tables)
+        if (small && !G.failed && G.warm_sig == sig && p->request_cached(1, pidx.data(), nullptr, n_params) && p->d_model.p) {
+            if (!G.h_model || G.h_model_n < n_model) {
+                if (G.h_model) (void)hipHostFree(G.h_model);
+                G.h_model = nullptr;
+                HIP_TRY(hipHostMalloc((void**)&G.h_model, std::max<size_t>(n_model, 1) * 8, hipHostMallocDefault));
+                G.h_model_n = n_model;
+            }
+            fill_graph_model();
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            p->timing = false;                        // (no event records inside the graph)
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal);
+            int rcs = GST_OK;
+            if (e == hipSuccess) {
+                rcs = sequence(true);
+                e = hipStreamEndCapture(p->stream, &graph);
+            }
+            p->timing = saved_timing;
+            if (e == hipSuccess && rcs == GST_OK && graph) {
+                e = hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (e == hipSuccess) {
+                    G.sig = sig; G.eps = eps; G.desc = *d; G.request_serial = p->fd_request_serial; G.n_blocks = n_blocks;
+                    p->model_dirty = true;
+                    HIP_TRY(hipGraphLaunch(G.exec, p->stream));
+                    G.replays = 1;
+                    captured = true;
+                } else G.exec = nullptr;
+            } else if (graph) (void)hipGraphDestroy(graph);
+            if (!captured) { (void)hipGetLastError(); G.failed = true; p->model_dirty = true; }
+        }
+        if (!captured) {
+            G.warm_sig = sig;
+            if ((rc = sequence(false))) return rc;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (sum_terms) {
+        double sacc = 0.0;
+        for (int k = 0; k < n_blocks; k++) sacc += G.h_part[k];
+        *sum_terms = sacc;
     }
     return GST_OK;
     });

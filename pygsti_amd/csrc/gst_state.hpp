@@ -333,6 +333,22 @@ struct gst_plan {
         if (didx) cached_didx.assign(didx, didx + n); else cached_didx.clear();
     }
 
+    // gst_lm_step_dev: the captured LM-iteration sequence of a launch-bound plan (gst_normal_abi.cpp)
+    struct LmGraph {
+        hipGraphExec_t exec = nullptr;
+        uint64_t sig = 0, warm_sig = 0, request_serial = 0;
+        double eps = 0;
+        gst_objective_desc desc{};
+        double* h_model = nullptr;      // page-locked: the graph's model source
+        size_t h_model_n = 0;
+        double* h_part = nullptr;       // page-locked: the objective's partial sums
+        int n_blocks = 0;
+        bool failed = false;
+        int64_t replays = 0;
+    } lm_graph;
+    bool lm_graph_enabled = true;       // GST_TEST_FORCE lm_graph=0
+    uint64_t fd_request_serial = 0;     // bumped whenever the FD request tables are rebuilt
+
     double last_kernel_ms = 0, last_total_ms = 0;
     int64_t last_launches = 0;
     bool timing = true;         // gst_options.timing: record the HIP events behind gst_stats.last_*_ms
@@ -363,6 +379,9 @@ struct gst_plan {
         d_model.release();
         if (h_stage) (void)hipHostFree(h_stage);
         h_stage = nullptr; h_stage_bytes = 0;
+        if (lm_graph.exec) (void)hipGraphExecDestroy(lm_graph.exec);
+        if (lm_graph.h_model) (void)hipHostFree(lm_graph.h_model);
+        if (lm_graph.h_part) (void)hipHostFree(lm_graph.h_part);
         if (h_up) (void)hipHostFree(h_up);
         h_up = nullptr; h_up_bytes = 0;
         for (int i = 0; i < 2; i++) {

@@ -56,7 +56,8 @@ def test_every_host_copy_goes_through_the_staging_helpers():
             if "hipMemcpyDeviceToDevice" in line or "Symbol(" in line:     # (symbol copies: the phase timers of the development builds)
                 continue
             assert f == "gst_abi.cpp" and re.search(r"h_stage|h_up|h_model_pinned|\bh, total|mapped|\(dst, d_src|\(d_dst, src|hipMemcpy2DAsync\(dst", line) or \
-                (f == "gst_comm.cpp" and ("peer" in line or "h_desc" in line)), "%s:%d: %s" % (f, i, line.strip())      # (h_desc: page-locked, 80 bytes)
+                (f == "gst_comm.cpp" and ("peer" in line or "h_desc" in line)) or \
+                (f == "gst_normal_abi.cpp" and ("G.h_model" in line or "G.h_part" in line)), "%s:%d: %s" % (f, i, line.strip())      # (h_desc: page-locked, 80 bytes)
 
 
 def _no_gpu():

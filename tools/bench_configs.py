@@ -87,6 +87,25 @@ def one_q():
     l_fd = lat(lambda: plan.fill_dprobs(J, pidx, None, 1e-7, pr, _lib.DERIV_FD))
     l_an = lat(lambda: plan.fill_dprobs(J, pidx, None, 1e-7, pr, _lib.DERIV_ANALYTIC))
     layout.free_local_array(J); layout.free_local_array(pr)
+    # one Levenberg-Marquardt evaluation, blocking: the four-call composition against gst_lm_step_dev (one call; a HIP graph from the
+    # third call on: a 1Q iteration is seven launches around microseconds of work)
+    bufs = [plan.device_malloc(n * 8) for n in (nE, nE, nE, nE, nP * nP, nP)]
+    d_c, d_N, d_ls, d_w, d_jtj, d_jtf = bufs
+    cnt = np.random.default_rng(3).binomial(1000, np.clip(plan.fill_probs(), 0, 1)).astype(np.float64)
+    plan.memcpy_h2d(d_c, cnt); plan.memcpy_h2d(d_N, np.full(nE, 1000.0))
+    G_, R_, E_ = layout.model_arrays(model)
+    def four_calls():
+        plan.set_model(G_, R_, E_)
+        plan.fill_dprobs_dev(d_J, nP, pidx, None, 1e-7, d_p, _lib.DERIV_FD)
+        plan.objective_rows_dev("logl", d_p, d_c, d_N, nE, d_ls, d_w)
+        plan.fill_normal_eqs_dev(d_J, nE, nP, nP, d_w, d_ls, d_jtj, d_jtf)
+        plan.sync()
+    def one_call():
+        plan.set_model(G_, R_, E_)
+        plan.lm_step_dev(nP, d_c, d_N, d_J, nP, d_p, d_ls, d_w, d_jtj, d_jtf, "logl")
+    l_lm4 = lat(four_calls)
+    one_call(); one_call()
+    l_lm1 = lat(one_call)
     D = 4
     fl_pass = 2.0 * D * D * st["applies_per_pass"] + 2.0 * D * nE           # flops of one probability pass
     roof = {"probs": _roof_compute(fl_pass, t_p), "dprobs_fd": _roof_compute(nP * fl_pass, t_fd),
@@ -95,6 +114,8 @@ def one_q():
     return {"config": "smq1Q_XYI L<=128 (BASELINE configs[1]): %d circuits, nE=%d, nP=%d, D=4" % (len(circuits), nE, nP),
             "roofline": roof,
             "blocking_host_fill_us": {"probs": 1e6 * l_p, "dprobs_fd": 1e6 * l_fd, "dprobs_analytic": 1e6 * l_an},
+            "lm_step_blocking_us": {"four_calls": 1e6 * l_lm4, "gst_lm_step_dev_hip_graph": 1e6 * l_lm1,
+                                    "note": "model upload + FD Jacobian + objective rows + JtJ + Jtf + sum(terms), results on the device"},
             "probs_us": 1e6 * t_p, "probs_per_s": nE / t_p,
             "dprobs_fd_us": 1e6 * t_fd, "dprobs_fd_el_per_s": nE * nP / t_fd,
             "dprobs_analytic_us": 1e6 * t_an, "dprobs_analytic_el_per_s": nE * nP / t_an,
