@@ -522,3 +522,30 @@ def test_mpi_control_plane_speaks_mpi4py():
     mine = lay.atoms[0].element_slice
     assert np.array_equal(out[mine], loc[mine])
     part = np.ones(5); gdist.allreduce_sum_host(part, expect_size=3, control=ctl2); assert np.array_equal(part, np.full(5, 3.0))
+
+
+@pytest.mark.parametrize("n_atoms,size", [(5, 2), (7, 3), (8, 8), (9, 4)])
+def test_atoms_are_dealt_in_sequential_blocks(n_atoms, size):
+    """distlayout.py:327-329 (`distribute_indices_base` + `_assert_sequential`, mpitools.py:191-215): atom-processor r owns a
+    sequential block of atoms -- the first `natoms mod size` processors one atom more -- so its rows are ONE contiguous range of
+    the global element dimension; together the ranges tile it."""
+    from pygsti_amd import modelpacks as MP
+    from pygsti_amd.layout import HipCOPALayout
+    pack = MP.smq1Q_XYI
+    model = pack.target_model()
+    circuits = pack.create_gst_circuits(4)
+    base, extra = divmod(n_atoms, size)
+    start, seen = 0, []
+    for r in range(size):
+        lay = HipCOPALayout(circuits, model, num_atoms=n_atoms, rank=r, size=size)
+        assert len(lay.all_atoms) == n_atoms
+        want = list(range(start, start + base + (1 if r < extra else 0)))            # the reference's loc_indices
+        got = [k for k, at in enumerate(lay.all_atoms) if any(at is mine for mine in lay.atoms)]
+        assert got == want, (r, got, want)
+        sl = lay.local_element_slice
+        assert sl.start == lay.atoms[0].element_slice.start and sl.stop == lay.atoms[-1].element_slice.stop
+        assert sum(a.num_elements for a in lay.atoms) == sl.stop - sl.start
+        seen.append((sl.start, sl.stop))
+        assert [lay.atom_owner_rank(a) for a in want] == [r] * len(want)
+        start += len(want)
+    assert seen[0][0] == 0 and seen[-1][1] == lay.global_num_elements and all(seen[k][1] == seen[k + 1][0] for k in range(size - 1))
