@@ -649,6 +649,10 @@ def main():
             rf["analytic_traffic"] = tr
             rf["analytic_traffic_frac_of_peak"] = (tr / (ana_info["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr and ana_info["kernel_ms"] else None
             rf["analytic_zeros_resident"] = ana_info["structural_zeros"].startswith("resident")
+            # the practical roof of a store stream on this part, measured here (hipMemsetAsync over 4 GiB), next to the 8 TB/s read peak
+            ceil = legs.store_only_ceiling(device) if world == 1 else None
+            rf["store_only_ceiling_GBps"] = ceil
+            rf["analytic_frac_of_store_ceiling"] = (ar["achieved"] / ceil) if (ceil and ar.get("achieved")) else None
         if host_fill:
             out["config"]["host_fill_elements_per_s"] = host_fill.get("elements_per_s")
             out["config"]["host_fill_ms"] = host_fill.get("ms")

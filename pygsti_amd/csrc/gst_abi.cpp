@@ -252,6 +252,7 @@ int finish_create(gst_plan* p, const gst_options* opt, gst_plan** out)
             else if (key == "tiles") p->ana_tiles = iv != 0;
             else if (key == "tile_dbg") p->tile_dbg = iv;
             else if (key == "lpt") p->ana_lpt = iv != 0;
+            else if (key == "chain_resident") p->chain_resident = iv != 0;
             else if (key == "lm_graph") p->lm_graph_enabled = iv != 0;
             else if (key == "comm_self") {}          // (read by gst_comm_create: gst_comm.cpp)
             else { delete p; return fail(GST_EINVAL, "GST_TEST_FORCE: unknown key '" + key + "'"); }

@@ -582,6 +582,18 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
     if (will_fork && chain_ok) {
         if ((rc = ensure_reverse(p))) return rc;
         rev_small = (double)p->rev.n_state_ids * h.n_effects * D * 8 < cache_limit;
+        if (h.D == 64 && will_fork && p->chain_resident && p->fast_chains && !p->d_c64_order.p &&
+            gst::chain64_resident_fits(std::min(16, h.n_effects), p->rev.max_slots, h.n_gates)) {
+            // backward walk with resident gates (chain64_resident_kernel): its tasks longest first, the pop counter
+            const int64_t nT = p->rev.n_tasks();
+            std::vector<uint32_t> order((size_t)nT);
+            for (int64_t t = 0; t < nT; t++) order[(size_t)t] = (uint32_t)t;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return p->rev.task_applies[x] > p->rev.task_applies[y]; });
+            HIP_TRY(p->d_c64_order.ensure((size_t)nT));
+            HIP_TRY(p->d_c64_counter.ensure(1));
+            H2D_TRY(p, p->d_c64_order.p, order.data(), (size_t)nT * sizeof(uint32_t));
+            HIP_TRY(hipStreamSynchronize(p->stream));          // once per plan: the second stream's fork event is already recorded
+        }
     }
     if (will_fork && chain_ok) {
         a.wide = (caches_small && rev_small) ? 0 : 1;
@@ -615,9 +627,20 @@ int run_dprobs_analytic(gst_plan* p, double* d_out, int64_t ld, const int64_t* p
             HIP_TRY(gst::launch_level_pass(ra, p->rev.n_tasks(), p->stream2));
             p->last_launches++;
         } else if (D == 64 && p->fast_chains && gst::chain64_fits(std::min(16, h.n_effects), p->rev.max_slots)) {      // all effects of a task as one row block on the matrix cores
+            // opt-in (GST_TEST_FORCE chain_resident=1): <= 10 gates resident in registers, one persistent workgroup per CU
+            const bool resident = p->chain_resident && p->d_c64_order.p != nullptr;          // (task order uploaded above)
             for (int e0 = 0; e0 < h.n_effects; e0 += 16) {
                 w.start0 = e0;
-                HIP_TRY(gst::launch_chain64(w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));
+                if (resident && std::min(16, h.n_effects - e0) > 1) {
+                    w.block_order = p->d_c64_order.p; w.bin_head = p->d_c64_counter.p;
+                    // after the forward pass, not beside it: a 452-register wavefront shares its SIMD with nothing
+                    hipStream_t sb = p->stream;
+                    HIP_TRY(hipMemsetAsync(p->d_c64_counter.p, 0, sizeof(uint32_t), sb));
+                    HIP_TRY(gst::launch_chain64_resident(w, p->rev.n_tasks(), p->rev.max_slots, p->n_cus, sb));
+                    w.block_order = nullptr; w.bin_head = nullptr;
+                } else {
+                    HIP_TRY(gst::launch_chain64(w, p->rev.n_tasks(), p->rev.max_slots, p->stream2));
+                }
                 p->last_launches++;
             }
         } else if (D == 64) {                                  // one wavefront per (task, effect), a single launch

@@ -411,6 +411,10 @@ hipError_t launch_walk_rows(int D, const WalkArgs& a, int64_t n_tasks, int n_slo
 // the S = 0 walk of a D = 64 plan on the matrix cores (gst_kernels_chain64.hip): modes without an ordering contract only
 hipError_t launch_chain64(const WalkArgs& a, int64_t n_tasks, int n_slots, hipStream_t stream);
 bool chain64_fits(int nv, int n_slots);
+// the multi-start walk with every gate resident in registers (<= 10 gates), two tasks interleaved per workgroup: persistent, a.bin_head = zeroed counter,
+// a.block_order = task order (longest first) or NULL
+bool chain64_resident_fits(int nv, int n_slots, int n_gates);
+hipError_t launch_chain64_resident(const WalkArgs& a, int64_t n_tasks, int n_slots, int n_cus, hipStream_t stream);
 // out[e * ld + dest[m]] = (raw[m * raw_stride + e] - pbase[e]) / eps for m < n_models (dest == NULL: column m0 + m):
 // the finite-difference quotient of gst_fill_dprobs_models, transposed through LDS tiles (correctly rounded division)
 hipError_t launch_fd_from_models(const double* raw, int64_t raw_stride, const double* pbase, int64_t nE, int32_t n_models,

@@ -177,6 +177,8 @@ struct gst_plan {
     int64_t tile_stats[3] = {0, 0, 0};  // tiled circuits, segment slots, remnant slots
     DevBuf<int32_t> d_tile_order, d_tile_cid, d_tile_blk, d_tsf, d_tsr, d_rem_ptr, d_rem_f, d_rem_r;
     DevBuf<uint32_t> d_tile_counter;
+    DevBuf<uint32_t> d_c64_order, d_c64_counter;   // resident-gate backward walk (D = 64): tasks longest first, pop counter
+    bool chain_resident = false;        // GST_TEST_FORCE chain_resident=1: backward walk with register-resident gates (measured slower overall: DESIGN 4.5)
     DevBuf<int32_t> d_lo_order, d_lo_partner, d_lo_common, d_lo_blk_f1, d_lo_blk_f2, d_lo_blk_r, d_lo_blk_ptr;
     DevBuf<uint32_t> d_lo_range_begin, d_lo_counter;
     bool last_tiles = false;            // the last exact fill ran the tile kernel

@@ -46,6 +46,35 @@ def fast_probs(B):
     return fast_info
 
 
+
+def store_only_ceiling(device, nbytes=4 << 30, reps=10):
+    """What a store-only kernel reaches on this part: hipMemsetAsync (the runtime's fill kernel) over a scratch buffer far
+    larger than L2 + the 256 MB memory-side cache.  The exact Jacobian is a store stream (8 nE nP bytes written once, reads
+    a few per cent of that), so THIS is its practical roof; the 8 TB/s figure is the read peak.  Returns GB/s or None."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+        hip.hipFree.argtypes = [ctypes.c_void_p]
+        if hip.hipSetDevice(int(device)) != 0:
+            return None
+        p = ctypes.c_void_p()
+        if hip.hipMalloc(ctypes.byref(p), nbytes) != 0:
+            return None
+        for _ in range(3):
+            hip.hipMemsetAsync(p, 0, nbytes, None)
+        hip.hipDeviceSynchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hip.hipMemsetAsync(p, 0, nbytes, None)
+        hip.hipDeviceSynchronize()
+        dt = (time.perf_counter() - t0) / reps
+        hip.hipFree(p)
+        return nbytes / dt / 1e9
+    except Exception:
+        return None
+
 def analytic(B):
     (args, plan, ctx, comm, world, rank, lay_world, layout, model, pack, gates, rhos, effects, d_out, d_probs, d_pfull, pidx, nP, nP_local, nE_local, nE_total, mode, blocks, row0, exchange, grid, col_split, barrier_sync, exchange_probs, log, n_pr, HBM_PEAK_GBS) = _unpack(B)
     # secondary: the same Jacobian by analytic derivatives (MatrixForwardSimulator semantics, <= 1e-8 vs that simulator)
