@@ -653,6 +653,7 @@ def main():
             ceil = legs.store_only_ceiling(device) if world == 1 else None
             rf["store_only_ceiling_GBps"] = ceil
             rf["analytic_frac_of_store_ceiling"] = (ar["achieved"] / ceil) if (ceil and ar.get("achieved")) else None
+            rf["analytic_traffic_frac_of_store_ceiling"] = (tr / (ana_info["kernel_ms"] * 1e-3) / 1e9 / ceil) if (ceil and tr and ana_info["kernel_ms"]) else None
         if host_fill:
             out["config"]["host_fill_elements_per_s"] = host_fill.get("elements_per_s")
             out["config"]["host_fill_ms"] = host_fill.get("ms")
