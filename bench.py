@@ -517,7 +517,7 @@ def main():
         except Exception as e:                       # a secondary leg must not take the headline down with it
             fit_info = {"error": "%s: %s" % (type(e).__name__, e)}
         log("fit replay leg done")
-    def measured_traffic(kernel_prefix):
+    def measured_traffic(kernel_prefix, section=None):
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
         (profiles/r0x_hbm_counters.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; KB -> bytes, and
         FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md).  None when no profile matches."""
@@ -526,7 +526,7 @@ def main():
         for name in ("r06_hbm_counters.json", "r05_hbm_counters.json", "r04_hbm_counters.json", "r03_hbm_counters.json", "r02_hbm_counters.json", "r01_hbm_counters.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
-                    prof = json.load(f)[args.deriv]
+                    prof = json.load(f)[section or args.deriv]
                 for k, v in prof.items():
                     if kernel_prefix in k:
                         return (2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0
@@ -640,7 +640,7 @@ def main():
         rf = out["roofline"]
         if ana_info and ana_info.get("roofline"):
             ar = ana_info["roofline"]
-            tr = measured_traffic("analytic_mfma_kernel")
+            tr = measured_traffic("analytic_mfma_kernel", "analytic")
             rf["analytic_kernel"] = "analytic_mfma_kernel"
             rf["analytic_kernel_ms"] = ana_info["kernel_ms"]
             rf["analytic_frac_hbm"] = ar["frac"]

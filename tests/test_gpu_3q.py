@@ -105,3 +105,27 @@ def test_3q_analytic_hprobs_vs_numpy_oracle(oracle_built):
     scale = max(1.0, np.abs(Ho).max())
     assert np.abs(H - Ho).max() < 1e-8 * scale
     assert np.abs(Ho).max() > 1e-3
+
+
+def test_3q_analytic_dprobs_with_register_resident_backward_walk(oracle_built, monkeypatch):
+    """The opt-in backward walk of the exact Jacobian (chain64_resident_kernel: every gate's MFMA operands resident in
+    registers, two tasks interleaved per workgroup; off by default because it is slower overall) gives the
+    same Jacobian: against the numpy oracle (1e-8) and against the default walk (re-association only)."""
+    pl0, tbl, mdl, nP = _make(n_circ=60, max_len=128, seed=13)
+    fx = dict(tbl); fx.update(mdl)
+    rng = np.random.default_rng(17)
+    cols = np.sort(np.concatenate([np.arange(0, 64), np.arange(64, 64 + 512), 576 + 4096 * 2 + rng.choice(4096, 500, replace=False),
+                                   576 + 4096 * 9 + rng.choice(4096, 300, replace=False), [nP - 1]]))
+    J0 = pl0.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)
+    pl0.close()
+    monkeypatch.setenv("GST_TEST_FORCE", "chain_resident=1")
+    pl1, _, _, _ = _make(n_circ=60, max_len=128, seed=13)
+    pr = np.empty(tbl["nE"])
+    J1 = pl1.fill_dprobs(param_idx=cols, probs_out=pr, mode=_lib.DERIV_ANALYTIC)
+    J1b = pl1.fill_dprobs(param_idx=cols, mode=_lib.DERIV_ANALYTIC)          # (the pop counter is reset per launch)
+    Jo, po = oracle_built.analytic_dprobs(fx, cols)
+    scale = max(1.0, np.abs(Jo).max())
+    assert np.abs(J1 - Jo).max() < 1e-8 * scale
+    assert np.abs(J1 - J0).max() < 1e-11 * scale
+    assert np.array_equal(J1, J1b)
+    assert np.abs(pr - po).max() < 1e-10 * max(1.0, np.abs(po).max())       # (seeded random gates: |p| grows with depth)
