@@ -35,8 +35,11 @@ for k in range(n_cases):
         if D > 16:
             n_circ = int(rng.choice([10, 40, 120])); nG = int(rng.integers(1, 5)); max_len = int(rng.choice([4, 20, 60])); max_slots = int(rng.choice([0, 1, 2, 3]))
     persist = str(rng.choice(["0", "2"]))
+    extra = os.environ.get("GST_FUZZ_FORCE", "")          # further test-hook keys for every case, e.g. chain_resident=1
     if persist:
-        os.environ["GST_TEST_FORCE"] = "persist=%s" % persist
+        os.environ["GST_TEST_FORCE"] = "persist=%s" % persist + ("," + extra if extra else "")
+    elif extra:
+        os.environ["GST_TEST_FORCE"] = extra
     else:
         os.environ.pop("GST_TEST_FORCE", None)
     a, tbl, mdl, nP = _random_case(D, seed0 + k, n_circ=n_circ, nG=nG, nR=nR, nEl=nEl, max_len=max_len)
