@@ -875,17 +875,74 @@ __global__ __launch_bounds__(256, 2) void analytic_mfma64_kernel(const AnaArgs a
         const char* const fb = (const char*)a.base_cache;
         const char* const rb = (const char*)a.rev_cache + (uint32_t)e * (D * 8);
         const uint32_t lane_b = (uint32_t)i * 8u;
-        for (int g = 0; g < nG; g++) {
+        // The gates of the item one after the other.  A gate's block is 32 KB of output behind a few MFMA rounds: left to
+        // themselves, "gather - MFMA - store" run one after the other in a wavefront, and the gathers of every wavefront
+        // of the CU queue behind the stores of the others in the CU's one memory pipeline (measured on 4,000 circuits:
+        // 3.09 ms, against 1.84 ms for the stores alone and 1.48 ms without them).  So the operands of the NEXT gate's
+        // first PF rounds are requested before the current block is stored -- their state ids a block earlier still --
+        // and arrive while the wavefront's own 64 stores are being accepted.
+        constexpr int PF = 4;
+        double pF[PF][4], pB[PF][4];
+        int32_t idF[PF], idR[PF];
+        int64_t np0 = 0, np1 = 0;                       // the positions of the gate the prefetch registers belong to
+        int gn = 0;
+        while (gn < nG && as_const(a.gate_col0)[gn] == -2) gn++;
+        auto fetch_ids = [&](int g) {                   // (per lane: the position q + kk of round `it`, clamped to the gate's last)
+            np0 = as_const(a.pos_ptr)[c * nG + g]; np1 = as_const(a.pos_ptr)[c * nG + g + 1];
+#pragma unroll
+            for (int it = 0; it < PF; it++) {
+                const int64_t pi = np0 + 4 * it + kk;
+                const int64_t pc = pi < np1 ? pi : (np1 > np0 ? np1 - 1 : np0);
+                const bool any = np0 + 4 * it < np1;
+                idF[it] = any ? a.pair_f[pc] : 0;
+                idR[it] = any ? a.pair_r[pc] : 0;
+            }
+        };
+        auto fetch_vectors = [&]() {
+#pragma unroll
+            for (int it = 0; it < PF; it++) {
+                if (np0 + 4 * it < np1) {
+                    const off_t fo = (off_t)(uint32_t)idF[it] * fstride + lane_b;
+                    const off_t ro = (off_t)(uint32_t)idR[it] * rstride + lane_b;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        pF[it][t] = *(const double*)(fb + fo + t * 128);
+                        pB[it][t] = *(const double*)(rb + ro + t * 128);
+                    }
+                }
+            }
+        };
+        if (gn < nG) { fetch_ids(gn); fetch_vectors(); }
+        while (gn < nG) {
+            const int g = gn;
             const int32_t c0 = as_const(a.gate_col0)[g];
-            if (c0 == -2) continue;
-            const int64_t p0 = as_const(a.pos_ptr)[c * nG + g], p1 = as_const(a.pos_ptr)[c * nG + g + 1];
+            const int64_t p0 = np0, p1 = np1;
+            gn = g + 1;
+            while (gn < nG && as_const(a.gate_col0)[gn] == -2) gn++;
             d4_t acc[4][4];
 #pragma unroll
             for (int tr = 0; tr < 4; tr++)
 #pragma unroll
                 for (int tc = 0; tc < 4; tc++) acc[tr][tc] = (d4_t){0.0, 0.0, 0.0, 0.0};
             const int64_t last = p1 - 1;
-            for (int64_t q = p0; q < p1; q += 4) {
+            // rounds 0 .. PF-1 from the prefetched registers
+#pragma unroll
+            for (int it = 0; it < PF; it++) {
+                if (p0 + 4 * it < p1) {
+                    const bool ok = p0 + 4 * it + kk <= last;
+                    double Fv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) Fv[t] = ok ? pF[it][t] : 0.0;
+#pragma unroll
+                    for (int tr = 0; tr < 4; tr++)
+#pragma unroll
+                        for (int tc = 0; tc < 4; tc++)
+                            acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(pB[it][tr], Fv[tc], acc[tr][tc], 0, 0, 0);
+                }
+            }
+            // the next gate's state ids: on their way during the remaining rounds
+            if (gn < nG) fetch_ids(gn);
+            for (int64_t q = p0 + 4 * PF; q < p1; q += 4) {
                 const int64_t pi = q + kk;
                 const bool ok = pi <= last;
                 const int64_t pc = ok ? pi : last;
@@ -905,6 +962,8 @@ __global__ __launch_bounds__(256, 2) void analytic_mfma64_kernel(const AnaArgs a
                     for (int tc = 0; tc < 4; tc++)
                         acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bv[tr], Fv[tc], acc[tr][tc], 0, 0, 0);
             }
+            // the next gate's operands go out BEFORE this block's stores
+            if (gn < nG) fetch_vectors();
             // tile (tr, tc), lane l, register r -> block entry (16 tr + (l>>4) + 4r, 16 tc + (l&15))
             if (c0 >= 0) {
 #pragma unroll
