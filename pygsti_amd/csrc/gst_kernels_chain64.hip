@@ -25,6 +25,7 @@ namespace gst {
 namespace {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) uint32_t* c64_prog_t;     // (walk programs are read through the scalar cache)
 constexpr int C64_D = 64;
 // Row stride of X in LDS (doubles), per kernel: what matters is how the sixteen A-operand reads X[lr][4 s + lk] of a lane
 // (dword address 2 (XS lr + 4 s + lk)) fall on the banks, and the LDS serves each read instruction in its own lane groups
@@ -76,22 +77,17 @@ __global__ __launch_bounds__(256) void chain64_mfma_kernel(const WalkArgs a, con
     for (int k = tid; k < 2 * 16 * XS; k += 256) lds[k] = 0.0;          // rows >= nv stay zero for the whole walk
     __syncthreads();
 
-    const int64_t pc0 = a.task_off[task];
-    const int32_t n_words = (int32_t)(a.task_off[task + 1] - pc0);
-    const uint32_t* gprog = a.prog + pc0;
-    int32_t wbase = 0, pc = 0;
-    uint32_t win_cur = (lane < n_words) ? gprog[lane] : 0u;
-    uint32_t win_nxt = (64 + lane < n_words) ? gprog[64 + lane] : 0u;
+    // The walk program through the SCALAR cache (constant address space: s_load_dword).  A 64-word window in vector
+    // registers read with v_readlane, refilled by a load under a rare branch, made the compiler put `s_waitcnt vmcnt(0)` in
+    // front of every v_readlane -- i.e. every step waited for the state-cache stores of the step before and for the next
+    // gate's operands it had just requested (round 6; the prefetch then only covered the step's own MFMAs).
+    const c64_prog_t gprog = (c64_prog_t)(a.prog + a.task_off[task]);
+    int32_t pc = 0;
     uint32_t op, arg;
 #define C64_FETCH()                                                                                   \
     do {                                                                                              \
-        if (pc - wbase == 64) {                                                                       \
-            wbase += 64;                                                                              \
-            win_cur = win_nxt;                                                                        \
-            win_nxt = (wbase + 64 + lane < n_words) ? gprog[wbase + 64 + lane] : 0u;                  \
-        }                                                                                             \
-        const uint32_t w_ = (uint32_t)__builtin_amdgcn_readlane((int)win_cur, (int)(pc - wbase));     \
-        op = GST_OP(w_); arg = GST_ARG(w_); pc++;                                                     \
+        const uint32_t w_ = gprog[pc++];                                                              \
+        op = GST_OP(w_); arg = GST_ARG(w_);                                                           \
     } while (0)
     // B operand of gate g for this wavefront's 16 columns: b[s] = M[4 s + lk][16 w + lr]
     // (VEC: b[s] = M[16 lk + s][16 w + lr])
@@ -212,8 +208,6 @@ __global__ __launch_bounds__(256) void chain64_mfma_kernel(const WalkArgs a, con
 //    sixteen MFMAs themselves (measured: 0.87 us per step against 0.48 us of MFMAs).  The second task's MFMAs run there:
 //    both tasks' A operands are read behind ONE barrier, task 1's reads issue between task 0's MFMAs, task 0's result is
 //    written while task 1's MFMAs are in the pipe.
-typedef const __attribute__((address_space(4))) uint32_t* c64_prog_t;
-
 // The asm statements of a step.  The B operands stay where they were loaded -- architectural registers for the first
 // C64_VGPR_GATES gates ("v"), accumulation registers for the rest ("a").  Left to the register allocator, the 320 operand
 // registers are spilled to the accumulation file and every MFMA gets a two-instruction reload into ONE temporary pair in
