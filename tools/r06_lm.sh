@@ -36,7 +36,7 @@ def lat(fn, reps=300):
     return 1e6 * (time.perf_counter() - t0) / reps
 print(json.dumps({"one_call_us": lat(one), "replays": plan.stats()["lm_graph_replays"], "four_calls_us": lat(four), "fd_only_blocking_us": lat(fd_only)}))
 PY
-timeout 600 python -X faulthandler -m pytest tests/test_gpu_lm_graph.py -m gpu -q -x --timeout 300 -p no:cacheprovider 2>&1 | tail -3
+timeout 600 python -X faulthandler -m pytest tests/test_gpu_lm_graph.py tests/test_gpu_jtj.py tests/test_fit_replay2q.py tests/test_fit_replay.py -m gpu -q -x --timeout 300 -p no:cacheprovider 2>&1 | tail -3
 timeout 120 python /tmp/lm1q.py 2>&1 | tail -2
 GST_TEST_FORCE=lm_graph=0 timeout 120 python /tmp/lm1q.py 2>&1 | tail -2
 cd /tmp; export TMPDIR=/tmp
